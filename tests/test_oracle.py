@@ -1,0 +1,237 @@
+"""Pins the oracle (oracle/fdx_oracle.py + oracle/bcd_ref.c) to golden vectors captured from the
+reference (tests/golden/make_golden.py).  CPU only.  If these pass, the oracle is a faithful
+restatement of the reference path and the -m gpu tests may use it as the checker."""
+import hashlib
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import datagen
+import fdx_oracle as orc
+from conftest import load_golden, rel_fro
+
+
+def csr(indptr, indices, n):
+    return sparse.csr_matrix((np.ones(len(indices)), indices, indptr), shape=(n, n))
+
+
+# ------------------------------------------------------------------ hash / sign
+def test_hash_sign_bit_exact_all_cases():
+    g = load_golden("omega_tables.npz")
+    for (G, d, s) in g["cases"]:
+        tag = f"G{G}_d{d}_s{s}"
+        b, sg = orc.countsketch_draw(int(s), int(G), int(d))
+        assert np.array_equal(b, g[tag + "_bucket"]), tag
+        assert np.array_equal(sg, g[tag + "_sign"]), tag
+        _, w = orc.countsketch_omega(int(G), int(d), None, int(s))
+        np.testing.assert_allclose(w, g[tag + "_data"], rtol=1e-15, atol=0)
+
+
+def test_hash_sign_survey_sha_prefixes():
+    # SHA-256 prefixes of the int64 bucket / sign arrays measured on the reference
+    want = {(2000, 512, 0): ("05a042303654ef9b", "b1eb7de76691736b"),
+            (5000, 1024, 0): ("08f6af1fd0994aff", "8dfac271e63bac7e"),
+            (2000, 512, 123): ("fc30ace4a16cb6d8", "5198e2754ce9b59e"),
+            (100, 32, 42): ("5963eff021a79e49", "fef1d2795a659f47")}
+    for (G, d, s), (hb, hs) in want.items():
+        b, sg = orc.countsketch_draw(s, G, d)
+        assert hashlib.sha256(b.tobytes()).hexdigest().startswith(hb)
+        assert hashlib.sha256(sg.tobytes()).hexdigest().startswith(hs)
+    b, sg = orc.countsketch_draw(0, 2000, 512)
+    assert list(b[:10]) == [172, 47, 117, 192, 323, 251, 195, 359, 9, 211]
+    assert list(sg[:10]) == [1, 1, -1, -1, -1, 1, -1, -1, -1, 1]
+
+
+def test_pure_python_mt_matches_c_and_numpy():
+    for (G, d, s) in [(100, 32, 42), (64, 3, 5), (50, 500, 9)]:
+        b1, s1 = orc.countsketch_draw_py(s, G, d)
+        b2, s2 = orc.countsketch_draw(s, G, d)
+        rs = np.random.RandomState(s)
+        b3 = rs.randint(0, d, size=G)
+        s3 = rs.choice([-1, 1], size=G)
+        assert np.array_equal(b1, b2) and np.array_equal(b2, b3)
+        assert np.array_equal(s1, s2) and np.array_equal(s2, s3)
+
+
+def test_leverage_weighted_omega():
+    g = load_golden("omega_tables.npz")
+    b, w = orc.countsketch_omega(300, 64, g["lev_input"], 11)
+    assert np.array_equal(b, g["lev_bucket"])
+    np.testing.assert_allclose(w, g["lev_data"], rtol=1e-14)
+
+
+# -------------------------------------------------------------------- leverage
+def test_leverage_scores():
+    g = load_golden("leverage.npz")
+    for name in g["names"]:
+        lev = orc.leverage_scores(g[f"{name}_X"])
+        np.testing.assert_allclose(lev, g[f"{name}_lev"], rtol=1e-10, atol=1e-15, err_msg=str(name))
+
+
+# ---------------------------------------------------------------------- graphs
+def test_graphs_bruteforce_equals_reference():
+    g = load_golden("graphs.npz")
+    for name in g["names"]:
+        coords = g[f"{name}_coords"]
+        method = str(g[f"{name}_method"])
+        radius = float(g[f"{name}_radius"])
+        A = orc.coords_to_adjacency(coords, method, int(g[f"{name}_k"]), None if radius < 0 else radius)
+        A = A.tocsr()
+        A.sort_indices()
+        assert np.array_equal(A.indptr, g[f"{name}_indptr"]), name
+        assert np.array_equal(A.indices, g[f"{name}_indices"]), name
+        if method == "knn":
+            B = orc.knn_graph_kdtree(coords, int(g[f"{name}_k"])).tocsr()
+            assert np.array_equal(B.indptr, g[f"{name}_indptr"]) and np.array_equal(B.indices, g[f"{name}_indices"])
+
+
+# ---------------------------------------------------------------------- solver
+SOLVER_CASES = ["det60", "simple50", "k30", "lam0", "bigrho", "k1", "k33"]
+
+
+@pytest.mark.parametrize("name", SOLVER_CASES)
+def test_bcd_solve_c_engine(name):
+    g = load_golden("solver_small.npz")
+    Ys, Xs = g[f"{name}_Ys"], g[f"{name}_Xs"]
+    A = csr(g[f"{name}_indptr"], g[f"{name}_indices"], Ys.shape[0])
+    lam, rho, max_iter, tol, _ = g[f"{name}_params"]
+    for t in (0, 1, 2, 10):
+        b, info = orc.bcd_solve(Ys, Xs, A, lam, rho, max_iter=t, tol=1e-30)
+        np.testing.assert_allclose(b, g[f"{name}_beta_it{t}"], rtol=1e-10, atol=1e-13)
+        assert info["n_iterations"] == int(g[f"{name}_it{t}_n_iterations"])
+        np.testing.assert_allclose(info["final_objective"], float(g[f"{name}_it{t}_final_objective"]), rtol=1e-10)
+    b, info = orc.bcd_solve(Ys, Xs, A, lam, rho, max_iter=int(max_iter), tol=tol, verbose=True)
+    np.testing.assert_allclose(b, g[f"{name}_beta"], rtol=1e-9, atol=1e-12)
+    assert info["n_iterations"] == int(g[f"{name}_n_iterations"])
+    assert info["converged"] == bool(g[f"{name}_converged"])
+    np.testing.assert_allclose(info["final_change"], float(g[f"{name}_final_change"]), rtol=1e-7, atol=1e-14)
+    np.testing.assert_allclose(info["final_objective"], float(g[f"{name}_final_objective"]), rtol=1e-10)
+    np.testing.assert_allclose(info["objectives"], g[f"{name}_verbose_objectives"], rtol=1e-10)
+    np.testing.assert_allclose(orc.normalize_proportions(b), g[f"{name}_props"], rtol=1e-9, atol=1e-12)
+
+
+def test_bcd_py_engine_equals_c_engine():
+    g = load_golden("solver_small.npz")
+    for name in ("det60", "k1"):
+        Ys, Xs = g[f"{name}_Ys"], g[f"{name}_Xs"]
+        A = csr(g[f"{name}_indptr"], g[f"{name}_indices"], Ys.shape[0])
+        lam, rho, _, _, _ = g[f"{name}_params"]
+        b1, i1 = orc.bcd_solve(Ys, Xs, A, lam, rho, max_iter=3, tol=1e-30, engine="py")
+        b2, i2 = orc.bcd_solve(Ys, Xs, A, lam, rho, max_iter=3, tol=1e-30, engine="c")
+        np.testing.assert_allclose(b1, b2, rtol=1e-12, atol=1e-15)
+
+
+def test_isolated_spots_and_normalise_edges():
+    g = load_golden("solver_small.npz")
+    b, info = orc.bcd_solve(g["iso_Ys"], g["iso_Xs"], sparse.csr_matrix((30, 30)), 0.2, 0.01, max_iter=15, tol=1e-9)
+    np.testing.assert_allclose(b, g["iso_beta"], rtol=1e-10, atol=1e-13)
+    assert info["n_iterations"] == int(g["iso_n_iterations"])
+    np.testing.assert_array_equal(orc.normalize_proportions(g["norm_in"]), g["norm_out"])
+
+
+def test_objective_values():
+    g = load_golden("objective.npz")
+    Ys, Xs, beta = g["Ys"], g["Xs"], g["beta"]
+    A = csr(g["indptr"], g["indices"], Ys.shape[0])
+    XtX, H, YtY = Xs @ Xs.T, Xs @ Ys.T, float(np.sum(Ys ** 2))
+    for (lam, rho), want in zip(g["lam_rho"], g["obj"]):
+        np.testing.assert_allclose(orc.objective(beta, H, XtX, YtY, A, lam, rho), want, rtol=1e-12)
+
+
+# ------------------------------------------------------------------- full fits
+def _check_fit(gname, Y, X, coords, **kw):
+    g = load_golden(gname)
+    out = orc.fit(Y, X, coords, **kw)
+    assert np.array_equal(out["gene_idx"], g["gene_idx"])
+    np.testing.assert_allclose(out["leverage"], g["leverage"], rtol=1e-9, atol=1e-16)
+    assert np.array_equal(out["bucket"], g["omega_bucket"])
+    np.testing.assert_allclose(out["weight"], g["omega_data"], rtol=1e-9)
+    np.testing.assert_allclose(out["X_sketch"], g["X_sketch"], rtol=1e-9, atol=1e-12)
+    n_head = g["Y_sketch_head"].shape[0]
+    ys_tol = kw.pop("ys_rtol", 1e-9)
+    np.testing.assert_allclose(out["Y_sketch"][:n_head], g["Y_sketch_head"], rtol=ys_tol, atol=ys_tol)
+    np.testing.assert_allclose((out["Y_sketch"] ** 2).sum(axis=1), g["Y_sketch_rowsq"], rtol=max(ys_tol, 1e-9) * 10)
+    A = out["adjacency"].tocsr()
+    assert np.array_equal(A.indptr, g["indptr"]) and np.array_equal(A.indices, g["indices"])
+    np.testing.assert_allclose(out["lambda_used"], float(g["lambda_used"]), rtol=1e-9)
+    assert out["info"]["n_iterations"] == int(g["n_iterations"])
+    assert out["info"]["converged"] == bool(g["converged"])
+    assert rel_fro(out["beta"], g["beta"]) < 1e-8
+    assert rel_fro(out["proportions"], g["proportions"]) < 1e-8
+    np.testing.assert_allclose(out["info"]["final_objective"], float(g["final_objective"]), rtol=1e-8)
+    return g, out
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_fit_counts_small(d):
+    g = load_golden(f"fit_counts_100x500x5_d{d}.npz")
+    _check_fit(f"fit_counts_100x500x5_d{d}.npz", g["Y"].astype(np.int64), g["X"], g["coords"], sketch_dim=d)
+
+
+def test_fit_counts_small_regenerates_reference_fixture():
+    g = load_golden("fit_counts_100x500x5_d64.npz")
+    Y, X, coords, _ = datagen.count_like(100, 500, 5, 0.1, 42)
+    assert np.array_equal(Y, g["Y"]) and np.array_equal(X, g["X"]) and np.array_equal(coords, g["coords"])
+
+
+def test_fit_counts_small_csr():
+    g = load_golden("fit_counts_100x500x5_d64_csr.npz")
+    Y = sparse.csr_matrix(g["Y"].astype(np.float64))
+    _check_fit("fit_counts_100x500x5_d64_csr.npz", Y, g["X"], g["coords"], sketch_dim=64)
+
+
+def test_fit_genesel():
+    g = load_golden("fit_genesel_150x600x4.npz")
+    Y = g["Y"].astype(np.int64)
+    _check_fit("fit_genesel_150x600x4.npz", Y, g["X"], g["coords"], sketch_dim=64, n_hvg=200, n_markers_per_type=10, max_iter=30)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(orc.select_hvg(Y, 200), g["hvg_idx"])
+        assert np.array_equal(orc.select_hvg(sparse.csr_matrix(Y.astype(np.float64)), 200), g["hvg_idx_csr"])
+    assert np.array_equal(orc.select_markers(g["X"], 10), g["marker_idx"])
+
+
+@pytest.mark.parametrize("suffix", ["", "_csr"])
+def test_fit_pearson(suffix):
+    g = load_golden(f"fit_pearson_120x300x4{suffix}.npz")
+    Y = g["Y"].astype(np.int64)
+    if suffix:
+        Y = sparse.csr_matrix(Y.astype(np.float64))
+    _check_fit(f"fit_pearson_120x300x4{suffix}.npz", Y, g["X"], g["coords"], sketch_dim=48, preprocess_method="pearson", max_iter=40)
+
+
+def test_fit_gauss_1000():
+    g = load_golden("fit_gauss_1000x2000x10.npz")
+    Y, X, coords, _ = datagen.gaussian_raw(1000, 2000, 10, seed=0)
+    assert datagen.sha256_arrays(Y, X, coords) == str(g["input_sha256"])
+    _check_fit("fit_gauss_1000x2000x10.npz", Y, X, coords, sketch_dim=512, preprocess_method="raw")
+
+
+def test_fit_gauss_800_fixed_lambda():
+    g = load_golden("fit_gauss_800x2000x20.npz")
+    Y, X, coords, _ = datagen.gaussian_raw(800, 2000, 20, seed=1)
+    assert datagen.sha256_arrays(Y, X, coords) == str(g["input_sha256"])
+    _check_fit("fit_gauss_800x2000x20.npz", Y, X, coords, sketch_dim=512, preprocess_method="raw", lambda_spatial=0.5, rho_sparsity=0.02)
+
+
+def test_fit_counts_1000_hits_max_iter():
+    g = load_golden("fit_counts_1000x2000x10.npz")
+    Y, X, coords, _ = datagen.count_like(1000, 2000, 10, 0.1, 0)
+    assert datagen.sha256_arrays(Y, X, coords) == str(g["input_sha256"])
+    gg, out = _check_fit("fit_counts_1000x2000x10.npz", Y, X, coords, sketch_dim=512)
+    assert out["info"]["n_iterations"] == 100 and not out["info"]["converged"]
+
+
+def test_fit_counts_600_k30():
+    g = load_golden("fit_counts_600x1000x30.npz")
+    Y, X, coords, _ = datagen.count_like(600, 1000, 30, 0.1, 3)
+    assert datagen.sha256_arrays(Y, X, coords) == str(g["input_sha256"])
+    _check_fit("fit_counts_600x1000x30.npz", Y, X, coords, sketch_dim=256, max_iter=60)
+
+
+def test_project_loops_definition():
+    rs = np.random.RandomState(0)
+    Yt = rs.rand(7, 90)
+    b, w = orc.countsketch_omega(90, 16, None, 4)
+    Ys, _ = orc.project(Yt, rs.rand(3, 90), b, w, 16)
+    np.testing.assert_allclose(orc.project_loops(Yt, b, w, 16), Ys, rtol=1e-13)
