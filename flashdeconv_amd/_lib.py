@@ -1,0 +1,147 @@
+"""ctypes binding of libfdx.so (the C ABI declared in include/fdx.h).
+
+This module is the whole Python<->native boundary: plain pointers and sizes.  There is no CPU
+fallback: if the shared library is missing or no MI355X is visible, the calls raise.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdx.so")
+
+c_int = ctypes.c_int
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_double = ctypes.c_double
+c_void_p = ctypes.c_void_p
+c_size_t = ctypes.c_size_t
+p_double = ctypes.POINTER(ctypes.c_double)
+p_i64 = ctypes.POINTER(ctypes.c_int64)
+p_i32 = ctypes.POINTER(ctypes.c_int32)
+
+
+class FdxError(RuntimeError):
+    """A libfdx call failed (message from fdx_last_error())."""
+
+
+class SolveInfo(ctypes.Structure):
+    _fields_ = [
+        ("converged", c_i32),
+        ("n_iterations", c_i32),
+        ("final_objective", c_double),
+        ("final_change", c_double),
+        ("n_objectives", c_i32),
+        ("reserved", c_i32),
+        ("sweep_ms", c_double),
+        ("total_ms", c_double),
+    ]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/fdx.h
+SIGNATURES = {
+    "fdx_version": (c_int, []),
+    "fdx_last_error": (ctypes.c_char_p, []),
+    "fdx_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "fdx_set_device": (c_int, [c_int]),
+    "fdx_device_name": (c_int, [ctypes.c_char_p, c_int]),
+    "fdx_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size_t]),
+    "fdx_free": (c_int, [c_void_p]),
+    "fdx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fdx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fdx_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "fdx_stream_sync": (c_int, [c_void_p]),
+    "fdx_graph_from_csr": (c_int, [p_i64, p_i64, c_i64, ctypes.POINTER(c_void_p)]),
+    "fdx_graph_destroy": (c_int, [c_void_p]),
+    "fdx_graph_info": (c_int, [c_void_p, p_i64, p_i64, p_i32]),
+    "fdx_bcd_solve": (c_int, [c_void_p, p_double, p_double, c_i64, c_i32, c_i32, c_double, c_double, c_i32, c_double,
+                              c_i32, p_double, p_double, p_double, ctypes.POINTER(SolveInfo)]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Load libfdx.so once and attach the signatures.  Raises FdxError if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise FdxError(
+                    f"{LIB_PATH} not found: build it with `make -C flashdeconv_amd/csrc` "
+                    "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().fdx_last_error()
+        raise FdxError(f"libfdx error {rc}: {msg.decode() if msg else 'unknown'}")
+
+
+def require_gpu():
+    """Fail loudly when no HIP device is visible (the product path has no CPU fallback)."""
+    lib = load()
+    n = c_int(0)
+    rc = lib.fdx_device_count(ctypes.byref(n))
+    if rc != 0 or n.value <= 0:
+        raise FdxError("flashdeconv_amd needs an AMD Instinct GPU (gfx950); no HIP device is visible "
+                       "and there is no CPU fallback.")
+    return n.value
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr_f64(a):
+    return a.ctypes.data_as(p_double)
+
+
+def ptr_i64(a):
+    return a.ctypes.data_as(p_i64)
+
+
+class Graph:
+    """Owns an fdx_graph handle (device-resident sliced-ELL graph)."""
+
+    def __init__(self, handle):
+        self._h = c_void_p(handle)
+
+    @classmethod
+    def from_csr(cls, indptr, indices, n):
+        lib = load()
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int64)
+        h = c_void_p()
+        check(lib.fdx_graph_from_csr(ptr_i64(indptr), ptr_i64(indices), int(n), ctypes.byref(h)))
+        return cls(h.value)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        n, nnz, md = c_i64(0), c_i64(0), c_i32(0)
+        check(load().fdx_graph_info(self._h, ctypes.byref(n), ctypes.byref(nnz), ctypes.byref(md)))
+        return n.value, nnz.value, md.value
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            load().fdx_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

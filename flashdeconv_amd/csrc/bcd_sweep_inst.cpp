@@ -1,0 +1,148 @@
+// Block-coordinate-descent sweep for the graph-regularised NNLS (the hot loop).
+//
+// Replaces the reference's numba kernels
+//   flashdeconv/core/solver.py:104-184  _bcd_iteration_fused  (Jacobi over spots, prange)
+//   flashdeconv/core/solver.py:29-101   update_spot_with_Xty  (Gauss-Seidel over cell types)
+//   flashdeconv/core/solver.py:18-26    soft_threshold
+// and the host-side convergence reduction of core/solver.py:395-397.
+//
+// Mapping (gfx950, wave64): ONE LANE = ONE SPOT, one wavefront = one 64-spot slice of the sliced-ELL
+// graph.  The K abundances of the spot live in VGPRs for the whole sweep (the coordinate steps are
+// sequential in k, so a lane-per-type mapping would leave 63/64 of the VALU idle - see DESIGN.md).
+// beta and H are stored type-major ("SoA", (K, ld)) so that every own-row access of a wave is one
+// fully coalesced 512-byte transaction; neighbour rows are gathered from the same planes and are
+// served by L2 because the spots are in Morton order.  XtX (K x K) is wave-uniform and is read
+// through the scalar cache (s_load) straight into the SGPR operand of v_fma_f64.
+//
+// Arithmetic per spot (float64, IEEE division, no fast-math):
+//   nbr_k  = sum_{j in N(i)} beta_in[j,k]                      (CSR order, padded with exact +0.0)
+//   r_k    = sum_j XtX[k,j] * b_j       with b_j already updated for j < k   (maintained residual of
+//            solver.py:72,96-99 evaluated on demand: same value, K^2 instead of 1.5 K^2 FMAs, no r[] array)
+//   res    = H[k,i] - r_k + XtX[k,k]*b_k (+ lambda*nbr_k if deg>0)          (solver.py:79-83)
+//   b_k    = den > 1e-10 ? max(0, soft(res, rho)/den) : 0 ,  den = XtX[k,k] + lambda*deg  (solver.py:86-93)
+// Convergence statistics max_i max_k|b_new-b_old| and max_i max_k|b_old| (solver.py:173-184) are reduced
+// with wave shuffles and one integer atomicMax per wave into 64 slots (order-free, hence deterministic).
+// The NEXT sweep (or the finishing kernel) folds the 64 slots and evaluates
+//   rel_change = max_diff / (max_abs_old + 1e-10) < tol                       (solver.py:395-397,409)
+// on the device, so a converged solve turns the already-queued sweeps into no-ops without a host round trip.
+#include "bcd_device.h"
+
+// This translation unit is compiled several times (csrc/Makefile) with -DFDX_PART=p -DFDX_K_LO=a -DFDX_K_HI=b so the
+// 64 register-resident instantiations build in parallel; each build exports bcd_sweep_dispatch_part<p>().
+#ifndef FDX_PART
+#error "compile with -DFDX_PART=<n> -DFDX_K_LO=<lo> -DFDX_K_HI=<hi>"
+#endif
+
+namespace fdx {
+
+constexpr int sweep_chunk(int K) { return K < 8 ? K : 8; }
+
+template <int K, int KC>
+__global__ __launch_bounds__(256) void bcd_sweep_kernel(
+    const double* __restrict__ H, const double* __restrict__ XtX, const double* __restrict__ beta_in,
+    double* __restrict__ beta_out, const int* __restrict__ ell_base, const int* __restrict__ slice_off,
+    const int* __restrict__ deg, unsigned long long* __restrict__ stats, double* __restrict__ rel_change,
+    const double lambda, const double rho, const double tol, const int ldh, const int ld_, const int n,
+    const int n_slices, const int it) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, provably so
+
+    if (it > 0) {  // device-side stopping rule on the previous sweep's statistics
+        const double rc = fold_rel_change(stats + (size_t)(it - 1) * 128, lane);
+        if (blockIdx.x == 0 && threadIdx.x == 0) rel_change[it - 1] = rc;
+        if (rc < tol) return;
+    }
+
+    const int slice = xcd_remap(blockIdx.x, gridDim.x) * 4 + wib;
+    if (slice >= n_slices) return;
+    // Lanes past the last spot mirror spot n-1 (same loads, same value stored to the same address), so the
+    // whole wave stays convergent and no lane needs predication.
+    const int i = min(slice * 64 + lane, n - 1);
+    const size_t ld = (size_t)ld_;
+
+    const int w0 = slice_off[slice];
+    const int w = slice_off[slice + 1] - w0;  // wave-uniform ELL width of this slice
+
+    double b[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) b[k] = beta_in[k * ld + i];
+    const int* ell = ell_base + (size_t)w0 * 64 + (i & 63);  // mirrored lanes read the mirrored spot's row
+    const int dg = deg[i];
+    const double lam_deg = lambda * (double)dg;
+    const double lam_eff = (dg > 0) ? lambda : 0.0;  // spatial term only when the spot has neighbours
+
+    double dmax = 0.0, amax = 0.0;
+    // Cell types are processed in chunks of KC: gather the chunk's neighbour sums (KC independent
+    // loads in flight per neighbour), then run the chunk's sequential coordinate steps.
+#pragma unroll
+    for (int kc = 0; kc < K; kc += KC) {
+        double c[KC];
+#pragma unroll
+        for (int q = 0; q < KC; ++q) c[q] = 0.0;
+#pragma unroll 2
+        for (int m = 0; m < w; ++m) {
+            const int j = ell[(size_t)m * 64];
+#pragma unroll
+            for (int q = 0; q < KC; ++q)
+                if (kc + q < K) c[q] += beta_in[(kc + q) * ld + j];
+        }
+#pragma unroll
+        for (int q = 0; q < KC; ++q) {
+            const int k = kc + q;
+            if (k < K) {
+                const double h = H[k * (size_t)ldh + i];
+                const double* g = XtX + k * K;
+                double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+                for (int j = 0; j + 1 < K; j += 2) {
+                    r0 = fma(g[j], b[j], r0);
+                    r1 = fma(g[j + 1], b[j + 1], r1);
+                }
+                if (K & 1) r0 = fma(g[K - 1], b[K - 1], r0);
+                const double gkk = g[k];
+                const double old = b[k];
+                const double res = (h - (r0 + r1) + gkk * old) + lam_eff * c[q];
+                const double den = gkk + lam_deg;
+                const double st = res > rho ? res - rho : (res < -rho ? res + rho : 0.0);
+                const double qv = fmax(0.0, st / den);
+                const double nw = (den > 1e-10) ? qv : 0.0;
+                dmax = fmax(dmax, fabs(nw - old));
+                amax = fmax(amax, fabs(old));
+                b[k] = nw;
+                beta_out[k * ld + i] = nw;
+            }
+        }
+    }
+    dmax = wave_max(dmax);
+    amax = wave_max(amax);
+    if (lane == 0) {
+        unsigned long long* s = stats + (size_t)it * 128;
+        const int slot = slice & 63;
+        atomicMax(s + slot, (unsigned long long)__double_as_longlong(dmax));
+        atomicMax(s + 64 + slot, (unsigned long long)__double_as_longlong(amax));
+    }
+}
+
+template <int K>
+static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
+    const int nblk = ceil_div(a.n_slices, 4);
+    hipLaunchKernelGGL((bcd_sweep_kernel<K, sweep_chunk(K)>), dim3(nblk), dim3(256), 0, st, a.H, a.XtX, a.beta_in,
+                       a.beta_out, a.ell, a.slice_off, a.deg, a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh,
+                       a.ld, a.n, a.n_slices, a.it);
+}
+
+template <int... Is>
+static bool dispatch_range(const BcdSweepArgs& a, hipStream_t st, std::integer_sequence<int, Is...>) {
+    bool hit = false;
+    (void)std::initializer_list<int>{((a.K == FDX_K_LO + Is) ? (launch_k<FDX_K_LO + Is>(a, st), hit = true, 0) : 0)...};
+    return hit;
+}
+
+#define FDX_CAT2(a, b) a##b
+#define FDX_CAT(a, b) FDX_CAT2(a, b)
+bool FDX_CAT(bcd_sweep_dispatch_part, FDX_PART)(const BcdSweepArgs& a, hipStream_t st) {
+    if (a.K < FDX_K_LO || a.K > FDX_K_HI) return false;
+    return dispatch_range(a, st, std::make_integer_sequence<int, FDX_K_HI - FDX_K_LO + 1>{});
+}
+
+}  // namespace fdx

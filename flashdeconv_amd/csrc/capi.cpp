@@ -1,0 +1,246 @@
+// C-ABI layer of libfdx.so (see include/fdx.h for the contract and the reference lines each entry replaces).
+#include "../../include/fdx.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "fdx_graph.h"
+#include "fdx_internal.h"
+#include "fdx_kernels.h"
+#include "solver.h"
+
+namespace fdx {
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+}  // namespace fdx
+
+using namespace fdx;
+
+extern "C" {
+
+int fdx_version(void) { return 100; }  // 0.1.0
+
+const char* fdx_last_error(void) { return g_last_error.c_str(); }
+
+int fdx_device_count(int* count) {
+    FDX_REQUIRE(count != nullptr, "fdx_device_count: null output");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(FDX_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = c;
+    return 0;
+}
+
+int fdx_set_device(int device) {
+    FDX_HIP(hipSetDevice(device));
+    return 0;
+}
+
+int fdx_device_name(char* buf, int buflen) {
+    FDX_REQUIRE(buf != nullptr && buflen > 0, "fdx_device_name: bad buffer");
+    int dev = 0;
+    FDX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FDX_HIP(hipGetDeviceProperties(&prop, dev));
+    std::snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int fdx_malloc(void** dev_ptr, size_t bytes) {
+    FDX_REQUIRE(dev_ptr != nullptr, "fdx_malloc: null output");
+    FDX_HIP(hipMalloc(dev_ptr, bytes ? bytes : 8));
+    return 0;
+}
+
+int fdx_free(void* dev_ptr) {
+    if (dev_ptr) FDX_HIP(hipFree(dev_ptr));
+    return 0;
+}
+
+int fdx_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    FDX_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    FDX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int fdx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    FDX_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    FDX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int fdx_memset(void* dev_dst, int value, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    FDX_HIP(hipMemsetAsync(dev_dst, value, bytes, (hipStream_t)stream));
+    return 0;
+}
+
+int fdx_stream_sync(void* stream) {
+    FDX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ graph
+// Host CSR -> device sliced ELL.  The conversion runs on the host because its input is a host matrix handed
+// over by the caller (the `A` of bcd_solve); graphs built from coordinates are produced on the device
+// (graph_kernels.cpp) and never pass through here.
+int fdx_graph_from_csr(const int64_t* indptr, const int64_t* indices, int64_t n, fdx_graph** out) {
+    FDX_REQUIRE(out != nullptr, "fdx_graph_from_csr: null output");
+    *out = nullptr;
+    FDX_REQUIRE(n >= 0 && n < 0x7fffff00LL, "fdx_graph_from_csr: n out of range");
+    FDX_REQUIRE(n == 0 || indptr != nullptr, "fdx_graph_from_csr: null indptr");
+    const int64_t nnz = n ? indptr[n] : 0;
+    FDX_REQUIRE(nnz >= 0 && nnz < 0x7fffff00LL, "fdx_graph_from_csr: nnz out of range");
+    FDX_REQUIRE(nnz == 0 || indices != nullptr, "fdx_graph_from_csr: null indices");
+    for (int64_t i = 0; i < n; ++i)
+        FDX_REQUIRE(indptr[i + 1] >= indptr[i], "fdx_graph_from_csr: indptr must be non-decreasing");
+    for (int64_t p = 0; p < nnz; ++p)
+        FDX_REQUIRE(indices[p] >= 0 && indices[p] < n, "fdx_graph_from_csr: neighbour index out of range");
+
+    fdx_graph* g = new fdx_graph();
+    g->n = n;
+    g->n_total = n;
+    g->nnz = nnz;
+    g->n_slices = (int)((n + 63) / 64);
+    std::vector<int> slice_off((size_t)g->n_slices + 1, 0), deg((size_t)n, 0);
+    int max_deg = 0;
+    for (int s = 0; s < g->n_slices; ++s) {
+        int w = 0;
+        for (int64_t i = (int64_t)s * 64; i < std::min<int64_t>(n, (int64_t)s * 64 + 64); ++i) {
+            const int dgi = (int)(indptr[i + 1] - indptr[i]);
+            deg[(size_t)i] = dgi;
+            w = std::max(w, dgi);
+        }
+        max_deg = std::max(max_deg, w);
+        slice_off[(size_t)s + 1] = slice_off[(size_t)s] + w;
+    }
+    g->max_deg = max_deg;
+    g->ell_rows = g->n_slices ? slice_off[(size_t)g->n_slices] : 0;
+    std::vector<int> ell((size_t)g->ell_rows * 64, (int)n);  // pad = index of the all-zero row
+    for (int64_t i = 0; i < n; ++i) {
+        const int s = (int)(i >> 6), lane = (int)(i & 63);
+        const int64_t b = indptr[i];
+        for (int m = 0; m < deg[(size_t)i]; ++m)
+            ell[((size_t)slice_off[(size_t)s] + m) * 64 + lane] = (int)indices[b + m];
+    }
+    int rc = 0;
+    if ((rc = g->ell.alloc(ell.size() * sizeof(int))) || (rc = g->slice_off.alloc(slice_off.size() * sizeof(int))) ||
+        (rc = g->deg.alloc(deg.size() * sizeof(int)))) {
+        delete g;
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    if (!ell.empty()) e = hipMemcpy(g->ell.p, ell.data(), ell.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->slice_off.p, slice_off.data(), slice_off.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !deg.empty()) e = hipMemcpy(g->deg.p, deg.data(), deg.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        delete g;
+        return fail(FDX_ERR_HIP, std::string("fdx_graph_from_csr upload: ") + hipGetErrorString(e));
+    }
+    *out = g;
+    return 0;
+}
+
+int fdx_graph_destroy(fdx_graph* g) {
+    delete g;
+    return 0;
+}
+
+int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_deg) {
+    FDX_REQUIRE(g != nullptr, "fdx_graph_info: null graph");
+    if (n) *n = g->n;
+    if (nnz) *nnz = g->nnz;
+    if (max_deg) *max_deg = g->max_deg;
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------- solver
+int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sketch, int64_t n, int32_t d, int32_t K,
+                  double lambda, double rho, int32_t max_iter, double tol, int32_t verbose, double* beta_out,
+                  double* objectives_out, double* rel_changes_out, fdx_solve_info* info) {
+    FDX_REQUIRE(info != nullptr, "fdx_bcd_solve: null info");
+    std::memset(info, 0, sizeof(*info));
+    FDX_REQUIRE(n >= 0 && K >= 0 && d >= 0, "fdx_bcd_solve: negative size");
+    FDX_REQUIRE(max_iter >= 0, "fdx_bcd_solve: max_iter must be non-negative");
+    if (n == 0 || K == 0) {  // core/solver.py:334-343
+        info->converged = 1;
+        return 0;
+    }
+    FDX_REQUIRE(g != nullptr, "fdx_bcd_solve: null graph");
+    FDX_REQUIRE(g->n == n, "fdx_bcd_solve: graph size does not match n");
+    FDX_REQUIRE(d > 0, "fdx_bcd_solve: sketch_dim must be positive");
+    FDX_REQUIRE(Y_sketch && X_sketch && beta_out, "fdx_bcd_solve: null array");
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    FDX_HIP(hipEventCreate(&e0));
+    FDX_HIP(hipEventCreate(&e1));
+    FDX_HIP(hipEventRecord(e0, st));
+
+    const long long ld = round_up(n + 1, 64);
+    DevBuf dY, dX, dH, dG, dB0, dB1, dPart, dSum, dOut;
+    FDX_TRY(dY.alloc((size_t)n * d * sizeof(double)));
+    FDX_TRY(dX.alloc((size_t)K * d * sizeof(double)));
+    FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
+    FDX_TRY(dB0.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dPart.alloc((size_t)xyt_partials_count(n) * sizeof(double)));
+    FDX_TRY(dSum.alloc(sizeof(double)));
+    FDX_TRY(dOut.alloc((size_t)n * K * sizeof(double)));
+    FDX_HIP(hipMemcpyAsync(dY.p, Y_sketch, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_HIP(hipMemcpyAsync(dX.p, X_sketch, (size_t)K * d * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_HIP(hipMemsetAsync(dH.p, 0, dH.bytes, st));
+    // XtX = Xs Xs^T (solver.py:346), H = Xs Ys^T (:347), YtY = ||Ys||^2 (:348)
+    FDX_TRY(launch_xyt(dX.as<double>(), dX.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, st));
+    FDX_TRY(launch_xyt(dX.as<double>(), dY.as<double>(), d, n, d, K, dH.as<double>(), ld, dPart.as<double>(), st));
+    FDX_TRY(launch_sum_partials(dPart.as<double>(), xyt_partials_count(n), dSum.as<double>(), 1, 1, st));
+    std::vector<double> G((size_t)K * K);
+    double YtY = 0.0;
+    FDX_HIP(hipMemcpyAsync(G.data(), dG.p, G.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipMemcpyAsync(&YtY, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    double diag_mean = 0.0;  // rho <- rho * mean(diag XtX)   (solver.py:359-360)
+    for (int k = 0; k < K; ++k) diag_mean += G[(size_t)k * K + k];
+    diag_mean /= (double)K;
+
+    SolveProblem p;
+    p.graph = g; p.H = dH.as<double>(); p.ldh = ld; p.XtX = dG.as<double>();
+    p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = K; p.YtY = YtY;
+    p.lambda = lambda; p.rho_eff = rho * diag_mean; p.max_iter = max_iter; p.tol = tol; p.verbose = verbose;
+    SolveResult r;
+    FDX_TRY(solver_run(p, &r, st));
+    FDX_TRY(launch_normalize_export(p.beta[r.result_buffer], ld, g->identity_order ? nullptr : g->perm.as<int>(), (int)n,
+                                    g->n_slices, K, dOut.as<double>(), nullptr, st));
+    FDX_HIP(hipMemcpyAsync(beta_out, dOut.p, (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipEventRecord(e1, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    FDX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    info->converged = r.converged;
+    info->n_iterations = r.n_iterations;
+    info->final_objective = r.final_objective;
+    info->final_change = r.final_change;
+    info->n_objectives = (int32_t)r.objectives.size();
+    info->sweep_ms = r.sweep_ms;
+    info->total_ms = ms;
+    if (objectives_out)
+        for (size_t t = 0; t < r.objectives.size(); ++t) objectives_out[t] = r.objectives[t];
+    if (rel_changes_out)
+        for (size_t t = 0; t < r.rel_changes.size(); ++t) rel_changes_out[t] = r.rel_changes[t];
+    return 0;
+}
+
+}  // extern "C"

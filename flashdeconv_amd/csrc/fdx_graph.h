@@ -1,0 +1,22 @@
+// Device-resident spatial graph in the layout the BCD sweep consumes (internal).
+#pragma once
+#include "fdx_internal.h"
+
+struct fdx_graph {
+    long long n = 0;         // spots owned (updated) by this graph
+    long long n_total = 0;   // owned + halo spots addressable by neighbour indices; the all-zero pad row is n_total
+    long long nnz = 0;       // structural non-zeros of the owned rows
+    int n_slices = 0;        // ceil(n / 64)
+    long long ell_rows = 0;  // sum of per-slice widths
+    int max_deg = 0;
+    // Sliced ELL (slice = 64 consecutive spots = one wavefront): entry m of spot i in slice s lives at
+    // ell[(slice_off[s] + m) * 64 + (i & 63)]; rows shorter than the slice width are padded with n_total,
+    // the index of a spot whose abundances are identically zero.  Row entries keep CSR (ascending original
+    // index) order so neighbour sums add in the reference's order.
+    fdx::DevBuf ell, slice_off, deg;
+    // Spot order used by the solver: position p holds original spot perm[p]; rank[perm[p]] = p.  Null = identity.
+    fdx::DevBuf perm, rank;
+    bool identity_order = true;
+    // CSR in the caller's labels (device), kept for export; built lazily by the coordinate builders.
+    fdx::DevBuf csr_indptr, csr_indices;
+};

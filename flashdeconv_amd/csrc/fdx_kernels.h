@@ -1,0 +1,54 @@
+// Internal launch interfaces between the kernel translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <utility>
+#include <initializer_list>
+
+namespace fdx {
+
+constexpr int FDX_MAX_K_FAST = 64;  // register-resident sweep kernels are instantiated for K = 1..64
+
+// One BCD sweep over `n` spots (lane = spot, wave = 64-spot slice).
+struct BcdSweepArgs {
+    const double* H;         // (K, ldh) type-major: H[k*ldh + i] = <X_sketch[k], Y_sketch[i]>
+    const double* XtX;       // (K, K) row-major Gram matrix
+    const double* beta_in;   // (K, ld) type-major, read only (Jacobi)
+    double* beta_out;        // (K, ld) type-major
+    const int* ell;          // sliced-ELL neighbour indices: ell[(slice_off[s] + m)*64 + lane]
+    const int* slice_off;    // (n_slices+1) prefix sum of per-slice widths
+    const int* deg;          // (n) structural neighbour count per spot
+    unsigned long long* stats;  // (max_iter, 2, 64) per-iteration max slots (bit patterns of doubles >= 0)
+    double* rel_change;      // (max_iter) rel_change per iteration, written by the following kernel
+    double lambda;
+    double rho;              // already scaled by mean(diag XtX)   (solver.py:359-360)
+    double tol;
+    int ldh;
+    int ld;
+    int n;                   // spots updated by this sweep (own spots; halo rows are read only)
+    int n_slices;
+    int K;
+    int it;                  // iteration index (selects the statistics slot, enables the early-exit test)
+};
+
+// ---- gram_kernels.cpp
+int launch_xyt(const double* Xs, const double* Ys, long long ldy, long long n, int d, int K, double* Hout,
+               long long ldh, double* sumsq_partials, hipStream_t st);
+long long xyt_partials_count(long long n);
+int launch_sum_partials(const double* in, long long count, double* out, int n_out, long long stride, hipStream_t st);
+
+// ---- finish_kernels.cpp
+int objective_partials_count(int n_slices);
+int launch_objective_partials(const double* beta, long long ld, const double* H, long long ldh, const double* XtX,
+                              const int* ell, const int* slice_off, const int* deg, int n, int n_slices, int K,
+                              double* partials, hipStream_t st);
+int launch_normalize_export(const double* beta, long long ld, const int* perm, int n, int n_slices, int K,
+                            double* beta_out, double* prop_out, hipStream_t st);
+
+// ---- bcd_kernels.cpp
+int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scratch_ld, hipStream_t st);
+int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, int it, hipStream_t st);
+
+}  // namespace fdx

@@ -1,0 +1,143 @@
+// Host-side driver of the BCD solve (replaces the Python loop of flashdeconv/core/solver.py:287-428).
+//
+// All iteration state stays in HBM.  Sweeps are queued back to back in growing chunks; the stopping rule is
+// evaluated on the device by the next sweep's prologue (bcd_kernels.cpp), so the host only reads back the
+// rel_change trace once per chunk and sweeps queued past convergence retire as no-ops.
+#include "solver.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace fdx {
+
+__global__ void fill_beta_kernel(double* b, long long ld, long long n_fill, int K, double value) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= ld) return;
+    const double v = (i < n_fill) ? value : 0.0;  // pad rows (incl. the all-zero neighbour row) stay exactly 0
+    for (int k = 0; k < K; ++k) b[(size_t)k * ld + i] = v;
+}
+
+int solver_init_beta(double* beta, long long ld, long long n_fill, int K, hipStream_t st) {
+    if (ld <= 0 || K <= 0) return 0;
+    hipLaunchKernelGGL(fill_beta_kernel, dim3(ceil_div(ld, 256)), dim3(256), 0, st, beta, ld, n_fill, K, 1.0 / (double)K);
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+int solver_objective(const fdx_graph& g, const double* beta, long long ld, const double* H, long long ldh,
+                     const double* XtX, int K, double YtY, double lambda, double rho_eff, double* scratch_partials,
+                     double* scratch_out4, double* obj_host, hipStream_t st) {
+    // compute_objective (core/solver.py:269-284)
+    const int nblk = objective_partials_count(g.n_slices);
+    FDX_TRY(launch_objective_partials(beta, ld, H, ldh, XtX, g.ell.as<int>(), g.slice_off.as<int>(), g.deg.as<int>(),
+                                      (int)g.n, g.n_slices, K, scratch_partials, st));
+    FDX_TRY(launch_sum_partials(scratch_partials, nblk, scratch_out4, 4, 4, st));
+    double r[4];
+    FDX_HIP(hipMemcpyAsync(r, scratch_out4, sizeof(r), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    *obj_host = 0.5 * (YtY - 2.0 * r[0] + r[1]) + 0.5 * lambda * r[2] + rho_eff * r[3];
+    return 0;
+}
+
+int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
+    const fdx_graph& g = *p.graph;
+    const int K = p.K;
+    res->result_buffer = 0;
+    res->n_iterations = 0;
+    res->converged = 0;
+    res->final_change = 0.0;
+    res->final_objective = 0.0;
+    res->objective_iters.clear();
+    res->objectives.clear();
+    res->rel_changes.clear();
+    res->sweep_ms = 0.0;
+    if (g.n == 0 || K == 0) {  // core/solver.py:334-343
+        res->converged = 1;
+        return 0;
+    }
+    FDX_REQUIRE(p.ld >= g.n_total + 1, "solver: ld must cover owned + halo spots + the zero pad row");
+    FDX_REQUIRE(p.max_iter >= 0, "solver: max_iter must be >= 0");
+
+    const int max_iter = p.max_iter;
+    DevBuf stats, relchg, obj_partials, obj_out, generic_scratch, obj_trace;
+    FDX_TRY(stats.alloc((size_t)std::max(max_iter, 1) * 128 * sizeof(unsigned long long)));
+    FDX_TRY(relchg.alloc((size_t)std::max(max_iter, 1) * sizeof(double)));
+    FDX_TRY(obj_partials.alloc((size_t)objective_partials_count(g.n_slices) * 4 * sizeof(double)));
+    FDX_TRY(obj_out.alloc(4 * sizeof(double)));
+    FDX_HIP(hipMemsetAsync(stats.p, 0, stats.bytes, st));
+    FDX_HIP(hipMemsetAsync(relchg.p, 0, relchg.bytes, st));
+    size_t scratch_ld = 0;
+    if (K > FDX_MAX_K_FAST) {
+        scratch_ld = (size_t)g.n_slices * 64;
+        FDX_TRY(generic_scratch.alloc(scratch_ld * 2 * K * sizeof(double)));
+    }
+    if (p.init_beta) FDX_TRY(solver_init_beta(p.beta[0], p.ld, g.n_total, K, st));   // beta0 = 1/K (solver.py:372)
+    // the second buffer's pad rows must also read as zero
+    if (p.init_beta) FDX_HIP(hipMemsetAsync(p.beta[1], 0, (size_t)K * p.ld * sizeof(double), st));
+
+    BcdSweepArgs a{};
+    a.H = p.H; a.XtX = p.XtX; a.ell = g.ell.as<int>(); a.slice_off = g.slice_off.as<int>(); a.deg = g.deg.as<int>();
+    a.stats = stats.as<unsigned long long>(); a.rel_change = relchg.as<double>();
+    a.lambda = p.lambda; a.rho = p.rho_eff; a.tol = p.tol; a.ldh = (int)p.ldh; a.ld = (int)p.ld; a.n = (int)g.n;
+    a.n_slices = g.n_slices; a.K = K;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    FDX_HIP(hipEventCreate(&ev0));
+    FDX_HIP(hipEventCreate(&ev1));
+    FDX_HIP(hipEventRecord(ev0, st));
+
+    std::vector<double> rc_host((size_t)std::max(max_iter, 1), 0.0);
+    int done = 0;          // iterations whose rel_change is known on the host
+    int n_iter = 0;
+    bool converged = false;
+    int chunk = p.first_chunk > 0 ? p.first_chunk : 4;
+    // verbose objective trace: evaluated on the NEW buffer at it % 10 == 0 or it == max_iter-1 (solver.py:399-404)
+    std::vector<std::pair<int, double>> trace;
+    while (done < max_iter && !converged) {
+        const int end = std::min(max_iter, done + chunk);
+        for (int it = done; it < end; ++it) {
+            a.it = it;
+            a.beta_in = p.beta[it & 1];
+            a.beta_out = p.beta[(it + 1) & 1];
+            FDX_TRY(launch_bcd_sweep(a, generic_scratch.as<double>(), scratch_ld, st));
+            if (p.verbose && (it % 10 == 0 || it == max_iter - 1)) {
+                double obj = 0.0;  // synchronous; verbose mode trades speed for the trace, as the reference does
+                FDX_TRY(solver_objective(g, a.beta_out, p.ld, p.H, p.ldh, p.XtX, K, p.YtY, p.lambda, p.rho_eff,
+                                         obj_partials.as<double>(), obj_out.as<double>(), &obj, st));
+                trace.emplace_back(it, obj);
+            }
+        }
+        FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, end - 1, st));
+        FDX_HIP(hipMemcpyAsync(rc_host.data() + done, relchg.as<double>() + done, (size_t)(end - done) * sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        for (int it = done; it < end; ++it) {
+            n_iter = it + 1;
+            if (rc_host[it] < p.tol) { converged = true; break; }   // solver.py:409-413
+        }
+        done = end;
+        chunk = std::min(chunk * 2, 32);
+    }
+    FDX_HIP(hipEventRecord(ev1, st));
+    FDX_HIP(hipEventSynchronize(ev1));
+    float ms = 0.f;
+    FDX_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    res->sweep_ms = ms;
+
+    res->n_iterations = n_iter;                        // iteration + 1 (solver.py:422); 0 when max_iter == 0
+    res->converged = converged ? 1 : 0;
+    res->final_change = n_iter > 0 ? rc_host[n_iter - 1] : 0.0;
+    res->result_buffer = n_iter & 1;                   // sweep `it` writes buffer (it+1)&1
+    res->rel_changes.assign(rc_host.begin(), rc_host.begin() + n_iter);
+    for (auto& t : trace)
+        if (t.first < n_iter) { res->objective_iters.push_back(t.first); res->objectives.push_back(t.second); }
+    if (p.compute_objective)
+        FDX_TRY(solver_objective(g, p.beta[res->result_buffer], p.ld, p.H, p.ldh, p.XtX, K, p.YtY, p.lambda, p.rho_eff,
+                                 obj_partials.as<double>(), obj_out.as<double>(), &res->final_objective, st));
+    return 0;
+}
+
+}  // namespace fdx

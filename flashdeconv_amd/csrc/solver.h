@@ -1,0 +1,48 @@
+// Internal interface of the BCD solve driver (solver.cpp).
+#pragma once
+#include <vector>
+
+#include "fdx_graph.h"
+#include "fdx_internal.h"
+#include "fdx_kernels.h"
+
+namespace fdx {
+
+struct SolveProblem {
+    const fdx_graph* graph = nullptr;
+    const double* H = nullptr;     // device (K, ldh) type-major
+    long long ldh = 0;
+    const double* XtX = nullptr;   // device (K, K)
+    double* beta[2] = {nullptr, nullptr};  // device (K, ld) type-major double buffer
+    long long ld = 0;
+    int K = 0;
+    double YtY = 0.0;
+    double lambda = 0.0;
+    double rho_eff = 0.0;          // rho * mean(diag XtX)
+    int max_iter = 100;
+    double tol = 1e-4;
+    int verbose = 0;
+    int init_beta = 1;             // fill beta[0] with 1/K and clear the pad rows
+    int compute_objective = 1;
+    int first_chunk = 4;
+};
+
+struct SolveResult {
+    int result_buffer = 0;         // index into SolveProblem::beta holding the final abundances
+    int n_iterations = 0;
+    int converged = 0;
+    double final_change = 0.0;
+    double final_objective = 0.0;
+    double sweep_ms = 0.0;
+    std::vector<int> objective_iters;
+    std::vector<double> objectives;
+    std::vector<double> rel_changes;
+};
+
+int solver_init_beta(double* beta, long long ld, long long n_fill, int K, hipStream_t st);
+int solver_objective(const fdx_graph& g, const double* beta, long long ld, const double* H, long long ldh,
+                     const double* XtX, int K, double YtY, double lambda, double rho_eff, double* scratch_partials,
+                     double* scratch_out4, double* obj_host, hipStream_t st);
+int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st);
+
+}  // namespace fdx

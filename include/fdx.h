@@ -1,0 +1,96 @@
+/*
+ * fdx.h -- C ABI of libfdx.so, the MI355X (gfx950) implementation of FlashDeconv's
+ * sketched graph-regularised NNLS hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry names the
+ * reference function it replaces (paths under flashdeconv/ of cafferychen777/flashdeconv v0.1.6).
+ * The reference is pure Python (numpy/scipy/numba); a maintainer binds these with ctypes (see
+ * INTEGRATION.md), and flashdeconv_amd/_lib.py is exactly such a binding.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, <0 on failure (FDX_ERR_*); fdx_last_error() returns the
+ *     message of the last failure on the calling thread.
+ *   - "host" pointers are ordinary C-contiguous arrays owned by the caller; "dev" pointers are HIP device
+ *     pointers on the current device (e.g. torch.Tensor.data_ptr()).  The library never frees caller memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Device-pointer entry points
+ *     only enqueue work on that stream unless stated otherwise; host-pointer entry points are synchronous.
+ *   - Device layout of abundances and of H is TYPE-MAJOR: element (type k, spot i) lives at [k*ld + i].
+ *     Host-visible results (beta, proportions) are (n_spots, n_types) row-major like the reference.
+ *   - Not thread-safe per handle; distinct handles may be used from distinct threads.
+ */
+#ifndef FDX_H
+#define FDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDX_OK 0
+#define FDX_ERR_INVALID (-1)
+#define FDX_ERR_HIP (-2)
+#define FDX_ERR_UNSUPPORTED (-3)
+#define FDX_ERR_INTERNAL (-4)
+
+/* dtype codes for the spot-by-gene matrix Y */
+#define FDX_F32 0
+#define FDX_F64 1
+
+/* preprocess modes (core/deconv.py:147-235) */
+#define FDX_PRE_RAW 0
+#define FDX_PRE_LOG_CPM 1       /* dense rule: log1p(y / (rowsum + 1e-10) * 1e4)   (core/deconv.py:190-191) */
+#define FDX_PRE_LOG_CPM_SPARSE 2 /* sparse rule: rowsum 0 -> 1, log1p on stored values (core/deconv.py:183-188) */
+
+int fdx_version(void);
+const char* fdx_last_error(void);
+int fdx_device_count(int* count);
+int fdx_set_device(int device);
+int fdx_device_name(char* buf, int buflen);
+
+/* ---- plain device memory helpers (so a ctypes-only binding needs no other GPU runtime) ---------------- */
+int fdx_malloc(void** dev_ptr, size_t bytes);
+int fdx_free(void* dev_ptr);
+int fdx_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes, void* stream);
+int fdx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes, void* stream);
+int fdx_memset(void* dev_dst, int value, size_t bytes, void* stream);
+int fdx_stream_sync(void* stream);
+
+/* ---- spatial graph (replaces utils/graph.py:25-212 and the CSR handling of core/solver.py:363-365) ---- */
+typedef struct fdx_graph fdx_graph;
+
+/* From an existing adjacency structure (the `A` argument of core/solver.py:287 bcd_solve): host CSR,
+ * int64 indptr (n+1) / indices (nnz); values are ignored (structure only, core/solver.py:157-159).
+ * Spots keep their order. */
+int fdx_graph_from_csr(const int64_t* indptr, const int64_t* indices, int64_t n, fdx_graph** out);
+int fdx_graph_destroy(fdx_graph* g);
+/* n spots, structural nnz, maximum degree */
+int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_deg);
+
+/* ---- solver (replaces core/solver.py:287-428 bcd_solve and everything it calls) ---------------------- */
+typedef struct fdx_solve_info {
+    int32_t converged;        /* info['converged']        */
+    int32_t n_iterations;     /* info['n_iterations']     */
+    double final_objective;   /* info['final_objective']  */
+    double final_change;      /* info['final_change']     */
+    int32_t n_objectives;     /* len(info['objectives']) (0 unless verbose) */
+    int32_t reserved;
+    double sweep_ms;          /* GPU time of the BCD sweeps (hipEvent), additive diagnostics */
+    double total_ms;
+} fdx_solve_info;
+
+/* Host-pointer form of bcd_solve(Y_sketch, X_sketch, A, lambda_, rho, max_iter, tol, verbose):
+ *   Y_sketch (n, d) row-major f64, X_sketch (K, d) row-major f64, graph built from A.
+ *   beta_out (n, K) row-major f64.  rho is the user-facing fraction; it is scaled by mean(diag XtX)
+ *   inside, as core/solver.py:359-360 does.  objectives_out (max_iter doubles, may be NULL) receives the
+ *   verbose objective trace (core/solver.py:399-404); rel_changes_out (max_iter doubles, may be NULL)
+ *   receives rel_change of every executed iteration. */
+int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sketch, int64_t n, int32_t d,
+                  int32_t K, double lambda, double rho, int32_t max_iter, double tol, int32_t verbose,
+                  double* beta_out, double* objectives_out, double* rel_changes_out, fdx_solve_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDX_H */

@@ -1,0 +1,118 @@
+"""-m gpu parity tests of the BCD solver through the C ABI (fdx_bcd_solve) against the golden vectors
+captured from the reference and against the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import datagen
+import fdx_oracle as orc
+from conftest import load_golden, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9   # BASELINE.json asks for 1e-4 relative Frobenius; the f64 kernels are ~1e-13
+
+
+def csr(indptr, indices, n):
+    return sparse.csr_matrix((np.ones(len(indices)), indices, indptr), shape=(n, n))
+
+
+@pytest.fixture(scope="module")
+def fdx():
+    from flashdeconv_amd.core import solver
+    return solver
+
+
+CASES = ["det60", "simple50", "k30", "lam0", "bigrho", "k1", "k33"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bcd_solve_matches_reference_golden(fdx, name):
+    g = load_golden("solver_small.npz")
+    Ys, Xs = g[f"{name}_Ys"], g[f"{name}_Xs"]
+    A = csr(g[f"{name}_indptr"], g[f"{name}_indices"], Ys.shape[0])
+    lam, rho, max_iter, tol, _ = g[f"{name}_params"]
+    for t in (0, 1, 2, 10):
+        b, info = fdx.bcd_solve(Ys, Xs, A, lambda_=lam, rho=rho, max_iter=t, tol=1e-30)
+        assert info["n_iterations"] == int(g[f"{name}_it{t}_n_iterations"])
+        assert rel_fro(b, g[f"{name}_beta_it{t}"]) < TOL, (name, t)
+        np.testing.assert_allclose(info["final_objective"], float(g[f"{name}_it{t}_final_objective"]), rtol=1e-9)
+    b, info = fdx.bcd_solve(Ys, Xs, A, lambda_=lam, rho=rho, max_iter=int(max_iter), tol=tol)
+    assert info["n_iterations"] == int(g[f"{name}_n_iterations"])
+    assert info["converged"] == bool(g[f"{name}_converged"])
+    assert rel_fro(b, g[f"{name}_beta"]) < TOL
+    assert np.all(b >= 0)
+    np.testing.assert_allclose(info["final_change"], float(g[f"{name}_final_change"]), rtol=1e-6, atol=1e-13)
+    np.testing.assert_allclose(info["final_objective"], float(g[f"{name}_final_objective"]), rtol=1e-9)
+    assert info["objectives"] == []
+    np.testing.assert_allclose(fdx.normalize_proportions(b), g[f"{name}_props"], rtol=1e-7, atol=1e-10)
+
+
+def test_verbose_objective_trace(fdx, capsys):
+    g = load_golden("solver_small.npz")
+    name = "k30"
+    Ys, Xs = g[f"{name}_Ys"], g[f"{name}_Xs"]
+    A = csr(g[f"{name}_indptr"], g[f"{name}_indices"], Ys.shape[0])
+    lam, rho, max_iter, tol, _ = g[f"{name}_params"]
+    b, info = fdx.bcd_solve(Ys, Xs, A, lambda_=lam, rho=rho, max_iter=int(max_iter), tol=tol, verbose=True)
+    np.testing.assert_allclose(info["objectives"], g[f"{name}_verbose_objectives"], rtol=1e-9)
+    assert "Iteration 0: objective" in capsys.readouterr().out
+
+
+def test_isolated_spots_and_empty_inputs(fdx):
+    g = load_golden("solver_small.npz")
+    b, info = fdx.bcd_solve(g["iso_Ys"], g["iso_Xs"], sparse.csr_matrix((30, 30)), lambda_=0.2, rho=0.01, max_iter=15, tol=1e-9)
+    assert rel_fro(b, g["iso_beta"]) < TOL and info["n_iterations"] == int(g["iso_n_iterations"])
+    b, info = fdx.bcd_solve(np.zeros((0, 8)), np.zeros((3, 8)), sparse.csr_matrix((0, 0)))
+    assert b.shape == (0, 3) and info["converged"] and info["n_iterations"] == 0
+    b, info = fdx.bcd_solve(np.zeros((5, 8)), np.zeros((0, 8)), sparse.csr_matrix((5, 5)))
+    assert b.shape == (5, 0) and info["final_objective"] == 0.0
+
+
+def test_run_to_run_bit_determinism(fdx):
+    # reference tests/test_solver.py:295-321
+    Ys, Xs, coords, _ = datagen.sketched_problem(60, 7, 48, seed=42, noise=0.05)
+    A = orc.knn_graph(coords, 4)
+    h = []
+    for _ in range(3):
+        b, info = fdx.bcd_solve(Ys, Xs, A, lambda_=0.1, rho=0.01, max_iter=30, tol=1e-6)
+        h.append((hashlib.sha256(b.tobytes()).hexdigest(), info["n_iterations"], info["converged"]))
+    assert h[0] == h[1] == h[2]
+
+
+@pytest.mark.parametrize("K", [2, 8, 17, 31, 40, 50, 64, 70])
+def test_all_kernel_variants_vs_oracle(fdx, K):
+    n, d = 700, 96
+    Ys, Xs, coords, _ = datagen.sketched_problem(n, K, d, seed=K)
+    A = orc.knn_graph_kdtree(coords * 30, 6)
+    want, winfo = orc.bcd_solve(Ys, Xs, A, 0.2, 0.02, max_iter=25, tol=1e-7)
+    got, ginfo = fdx.bcd_solve(Ys, Xs, A, lambda_=0.2, rho=0.02, max_iter=25, tol=1e-7)
+    assert ginfo["n_iterations"] == winfo["n_iterations"]
+    assert rel_fro(got, want) < TOL
+    np.testing.assert_allclose(ginfo["final_objective"], winfo["final_objective"], rtol=1e-9)
+
+
+def test_irregular_graph_and_odd_sketch_dim(fdx):
+    # hub-and-spoke + ring: one row far wider than the slice average, d not a multiple of 16
+    n, K, d = 333, 9, 37
+    Ys, Xs, _, _ = datagen.sketched_problem(n, K, d, seed=5)
+    rows = [0] * (n - 1) + list(range(1, n)) + list(range(n)) + [(i + 1) % n for i in range(n)]
+    cols = list(range(1, n)) + [0] * (n - 1) + [(i + 1) % n for i in range(n)] + list(range(n))
+    A = sparse.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+    A.data[:] = 1.0
+    want, winfo = orc.bcd_solve(Ys, Xs, A, 0.05, 0.01, max_iter=20, tol=1e-8)
+    got, ginfo = fdx.bcd_solve(Ys, Xs, A, lambda_=0.05, rho=0.01, max_iter=20, tol=1e-8)
+    assert ginfo["n_iterations"] == winfo["n_iterations"] and rel_fro(got, want) < TOL
+
+
+def test_medium_size_convergence_path(fdx):
+    # 20k spots: several chunks of queued sweeps, convergence detected on the device
+    n, K, d = 20000, 20, 128
+    Ys, Xs, coords, _ = datagen.sketched_problem(n, K, d, seed=11)
+    A = orc.knn_graph_kdtree(coords * np.sqrt(n), 6)
+    want, winfo = orc.bcd_solve(Ys, Xs, A, 0.1, 0.01, max_iter=100, tol=1e-4)
+    got, ginfo = fdx.bcd_solve(Ys, Xs, A, lambda_=0.1, rho=0.01, max_iter=100, tol=1e-4)
+    assert ginfo["n_iterations"] == winfo["n_iterations"] and ginfo["converged"] == winfo["converged"]
+    assert rel_fro(got, want) < TOL
