@@ -53,6 +53,12 @@ SIGNATURES = {
     "fdx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fdx_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "fdx_stream_sync": (c_int, [c_void_p]),
+    "fdx_sketch": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_i64, p_i32, p_double, c_i32, c_i32, p_double]),
+    "fdx_column_sums": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_double]),
+    "fdx_graph_build_knn": (c_int, [p_double, c_i64, c_i32, c_i32, ctypes.POINTER(c_void_p)]),
+    "fdx_graph_build_radius": (c_int, [p_double, c_i64, c_i32, c_double, ctypes.POINTER(c_void_p)]),
+    "fdx_nearest_distance": (c_int, [p_double, c_i64, c_i32, p_double]),
+    "fdx_graph_export_csr": (c_int, [c_void_p, p_i64, p_i32]),
     "fdx_graph_from_csr": (c_int, [p_i64, p_i64, c_i64, ctypes.POINTER(c_void_p)]),
     "fdx_graph_destroy": (c_int, [c_void_p]),
     "fdx_graph_info": (c_int, [c_void_p, p_i64, p_i64, p_i32]),
@@ -111,6 +117,31 @@ def ptr_i64(a):
     return a.ctypes.data_as(p_i64)
 
 
+def ptr_i32(a):
+    return a.ctypes.data_as(p_i32)
+
+
+FDX_F32, FDX_F64 = 0, 1
+PRE_RAW, PRE_LOG_CPM, PRE_LOG_CPM_SPARSE = 0, 1, 2
+
+
+def as_device_matrix(Y):
+    """Dense spot-by-gene matrix -> (C-contiguous float32/float64 array, dtype code).
+
+    float32/float64 inputs are passed through; integer counts become float32 when every value is exactly
+    representable (< 2**24), float64 otherwise.  Arithmetic on the device is float64 either way."""
+    Y = np.asarray(Y)
+    if Y.dtype == np.float32:
+        return np.ascontiguousarray(Y), FDX_F32
+    if Y.dtype == np.float64:
+        return np.ascontiguousarray(Y), FDX_F64
+    if np.issubdtype(Y.dtype, np.integer) or Y.dtype == np.bool_:
+        if Y.size == 0 or (Y.dtype.itemsize <= 2) or (np.abs(Y).max() < (1 << 24)):
+            return np.ascontiguousarray(Y, dtype=np.float32), FDX_F32
+        return np.ascontiguousarray(Y, dtype=np.float64), FDX_F64
+    return np.ascontiguousarray(Y, dtype=np.float64), FDX_F64
+
+
 class Graph:
     """Owns an fdx_graph handle (device-resident sliced-ELL graph)."""
 
@@ -125,6 +156,28 @@ class Graph:
         h = c_void_p()
         check(lib.fdx_graph_from_csr(ptr_i64(indptr), ptr_i64(indices), int(n), ctypes.byref(h)))
         return cls(h.value)
+
+    @classmethod
+    def from_coords_knn(cls, coords, k):
+        coords = as_f64(coords)
+        h = c_void_p()
+        check(load().fdx_graph_build_knn(ptr_f64(coords), coords.shape[0], coords.shape[1], int(k), ctypes.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_coords_radius(cls, coords, radius):
+        coords = as_f64(coords)
+        h = c_void_p()
+        check(load().fdx_graph_build_radius(ptr_f64(coords), coords.shape[0], coords.shape[1], float(radius), ctypes.byref(h)))
+        return cls(h.value)
+
+    def to_csr_arrays(self):
+        """(indptr int64, indices int32) in the caller's spot order, indices ascending per row."""
+        n, nnz, _ = self.info()
+        indptr = np.zeros(n + 1, dtype=np.int64)
+        indices = np.zeros(max(nnz, 1), dtype=np.int32)
+        check(load().fdx_graph_export_csr(self._h, ptr_i64(indptr), ptr_i32(indices)))
+        return indptr, indices[:nnz]
 
     @property
     def handle(self):

@@ -7,8 +7,10 @@
 #include <vector>
 
 #include "fdx_graph.h"
+#include "graph_build.h"
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
+#include "sketch_plan.h"
 #include "solver.h"
 
 namespace fdx {
@@ -152,6 +154,62 @@ int fdx_graph_from_csr(const int64_t* indptr, const int64_t* indices, int64_t n,
     return 0;
 }
 
+static int upload_coords(const double* coords, int64_t n, int32_t dim, DevBuf* d) {
+    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
+    FDX_REQUIRE(n >= 0, "graph: negative n");
+    FDX_REQUIRE(n == 0 || coords != nullptr, "graph: null coords");
+    FDX_TRY(d->alloc((size_t)n * dim * sizeof(double)));
+    if (n) FDX_HIP(hipMemcpy(d->p, coords, (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int fdx_graph_build_knn(const double* coords, int64_t n, int32_t dim, int32_t k, fdx_graph** out) {
+    FDX_REQUIRE(out != nullptr, "fdx_graph_build_knn: null output");
+    *out = nullptr;
+    DevBuf dc;
+    FDX_TRY(upload_coords(coords, n, dim, &dc));
+    fdx_graph* g = new fdx_graph();
+    const int rc = graph_build_knn(dc.as<double>(), n, dim, k, g, nullptr);
+    if (rc) { delete g; return rc; }
+    *out = g;
+    return 0;
+}
+
+int fdx_graph_build_radius(const double* coords, int64_t n, int32_t dim, double radius, fdx_graph** out) {
+    FDX_REQUIRE(out != nullptr, "fdx_graph_build_radius: null output");
+    *out = nullptr;
+    DevBuf dc;
+    FDX_TRY(upload_coords(coords, n, dim, &dc));
+    fdx_graph* g = new fdx_graph();
+    const int rc = graph_build_radius(dc.as<double>(), n, dim, radius, g, nullptr);
+    if (rc) { delete g; return rc; }
+    *out = g;
+    return 0;
+}
+
+int fdx_nearest_distance(const double* coords, int64_t n, int32_t dim, double* dist_out) {
+    FDX_REQUIRE(dist_out != nullptr, "fdx_nearest_distance: null output");
+    DevBuf dc, dd;
+    FDX_TRY(upload_coords(coords, n, dim, &dc));
+    FDX_TRY(dd.alloc((size_t)n * sizeof(double)));
+    FDX_TRY(graph_nearest_distance(dc.as<double>(), n, dim, dd.as<double>(), nullptr));
+    FDX_HIP(hipMemcpy(dist_out, dd.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int fdx_graph_export_csr(const fdx_graph* g, int64_t* indptr, int32_t* indices) {
+    FDX_REQUIRE(g != nullptr && indptr != nullptr, "fdx_graph_export_csr: null argument");
+    FDX_REQUIRE(g->nnz == 0 || indices != nullptr, "fdx_graph_export_csr: null indices");
+    DevBuf dp, di;
+    FDX_TRY(dp.alloc((size_t)(g->n + 1) * 8));
+    FDX_TRY(di.alloc((size_t)std::max<long long>(g->nnz, 1) * 4));
+    FDX_HIP(hipMemset(dp.p, 0, dp.bytes));
+    FDX_TRY(graph_export_csr(g, dp.as<long long>(), di.as<int>(), nullptr));
+    FDX_HIP(hipMemcpy(indptr, dp.p, (size_t)(g->n + 1) * 8, hipMemcpyDeviceToHost));
+    if (g->nnz) FDX_HIP(hipMemcpy(indices, di.p, (size_t)g->nnz * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int fdx_graph_destroy(fdx_graph* g) {
     delete g;
     return 0;
@@ -162,6 +220,45 @@ int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_de
     if (n) *n = g->n;
     if (nnz) *nnz = g->nnz;
     if (max_deg) *max_deg = g->max_deg;
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------- sketch
+static size_t dtype_size(int dtype) { return dtype == FDX_F32 ? 4 : 8; }
+
+int fdx_sketch(const void* Y, int32_t dtype, int64_t n, int32_t G, const int64_t* col_ptr, const int32_t* gene_idx,
+               const double* weight, int32_t d, int32_t mode, double* Ys_out) {
+    FDX_REQUIRE(dtype == FDX_F32 || dtype == FDX_F64, "fdx_sketch: dtype must be FDX_F32 or FDX_F64");
+    FDX_REQUIRE(n >= 0 && G > 0 && d > 0, "fdx_sketch: bad shape");
+    if (n == 0) return 0;
+    FDX_REQUIRE(Y && Ys_out, "fdx_sketch: null array");
+    hipStream_t st = nullptr;
+    SketchPlan plan;
+    FDX_TRY(plan.build((const long long*)col_ptr, gene_idx, weight, G, d, st));
+    DevBuf dY, dYs;
+    const size_t ybytes = (size_t)n * G * dtype_size(dtype);
+    FDX_TRY(dY.alloc(ybytes));
+    FDX_TRY(dYs.alloc((size_t)n * d * sizeof(double)));
+    FDX_HIP(hipMemcpyAsync(dY.p, Y, ybytes, hipMemcpyHostToDevice, st));
+    FDX_TRY(launch_sketch_rows(dY.p, dtype, G, nullptr, n, G, d, mode, plan.dev(), dYs.as<double>(), d, nullptr, st));
+    FDX_HIP(hipMemcpyAsync(Ys_out, dYs.p, (size_t)n * d * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int fdx_column_sums(const void* Y, int32_t dtype, int64_t n, int32_t G, double* sums_out) {
+    FDX_REQUIRE(dtype == FDX_F32 || dtype == FDX_F64, "fdx_column_sums: dtype must be FDX_F32 or FDX_F64");
+    FDX_REQUIRE(n >= 0 && G > 0 && sums_out, "fdx_column_sums: bad arguments");
+    hipStream_t st = nullptr;
+    DevBuf dY, dPart, dOut;
+    const size_t ybytes = (size_t)n * G * dtype_size(dtype);
+    FDX_TRY(dY.alloc(ybytes));
+    FDX_TRY(dPart.alloc((size_t)column_sums_parts(n) * G * sizeof(double)));
+    FDX_TRY(dOut.alloc((size_t)G * sizeof(double)));
+    if (n) FDX_HIP(hipMemcpyAsync(dY.p, Y, ybytes, hipMemcpyHostToDevice, st));
+    FDX_TRY(launch_column_sums(dY.p, dtype, G, n, G, dPart.as<double>(), dOut.as<double>(), st));
+    FDX_HIP(hipMemcpyAsync(sums_out, dOut.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
     return 0;
 }
 

@@ -17,6 +17,8 @@ struct fdx_graph {
     // Spot order used by the solver: position p holds original spot perm[p]; rank[perm[p]] = p.  Null = identity.
     fdx::DevBuf perm, rank;
     bool identity_order = true;
-    // CSR in the caller's labels (device), kept for export; built lazily by the coordinate builders.
-    fdx::DevBuf csr_indptr, csr_indices;
+    // Row segments in solver space (neighbour positions ordered by ORIGINAL index), kept by the coordinate
+    // builders for export / sharding: row p is rows[p*row_stride + row_extra[p] .. + deg[p]).
+    fdx::DevBuf rows, row_extra;
+    int row_stride = 0;
 };

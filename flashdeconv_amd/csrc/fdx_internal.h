@@ -67,6 +67,13 @@ struct DevBuf {
         bytes = 0;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    void take(DevBuf& o) {   // move ownership
+        release();
+        p = o.p;
+        bytes = o.bytes;
+        o.p = nullptr;
+        o.bytes = 0;
+    }
 };
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

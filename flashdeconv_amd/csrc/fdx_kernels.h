@@ -33,6 +33,21 @@ struct BcdSweepArgs {
     int it;                  // iteration index (selects the statistics slot, enables the early-exit test)
 };
 
+// ---- sketch_kernels.cpp / sketch_plan.cpp
+// Static gather schedule of a CountSketch (device pointers; owned by SketchPlan).
+struct SketchPlanDev {
+    const int* sched_gene = nullptr;    // (total_len, 64): gene index read by lane l at schedule row e
+    const double* sched_w = nullptr;    // (total_len, 64): Omega weight of that gene (0 for padding entries)
+    const int* group_off = nullptr;     // (n_groups+1): schedule rows of group j are [group_off[j], group_off[j+1])
+    const int* slot_bucket = nullptr;   // (n_groups*64): output bucket of slot j*64+l, -1 for unused slots
+    int n_groups = 0;
+};
+int launch_sketch_rows(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
+                       const SketchPlanDev& plan, double* Ys, long long ldys, double* row_sumsq, hipStream_t st);
+int column_sums_parts(long long n);
+int launch_column_sums(const void* Y, int dtype, long long ldy, long long n, int G, double* partials, double* out,
+                       hipStream_t st);
+
 // ---- gram_kernels.cpp
 int launch_xyt(const double* Xs, const double* Ys, long long ldy, long long n, int d, int K, double* Hout,
                long long ldh, double* sumsq_partials, hipStream_t st);

@@ -1,0 +1,15 @@
+// Device graph builders (graph_kernels.cpp); internal.
+#pragma once
+#include "fdx_graph.h"
+
+namespace fdx {
+
+// coords: device (n, dim) row-major float64, dim in {1,2,3}
+int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_graph* g, hipStream_t st);
+int graph_build_radius(const double* d_coords, long long n, int dim, double radius, fdx_graph* g, hipStream_t st);
+// distance of every point to its nearest other point (caller's order); used by the "grid" method (graph.py:163-167)
+int graph_nearest_distance(const double* d_coords, long long n, int dim, double* d_out, hipStream_t st);
+// CSR in the caller's labels; device outputs indptr (n+1) int64, indices (nnz) int32 ascending per row
+int graph_export_csr(const fdx_graph* g, long long* d_indptr, int* d_indices, hipStream_t st);
+
+}  // namespace fdx

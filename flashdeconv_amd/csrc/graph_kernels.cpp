@@ -1,0 +1,633 @@
+// Spatial graph construction on the device.
+//
+// Replaces flashdeconv/utils/graph.py:
+//   build_knn_graph    :25-83   (cKDTree build + query k+1 incl. self, drop self, A + A^T, binary)
+//   build_radius_graph :86-133  (cKDTree.query_pairs(r), symmetric)
+// and hands the result to the solver in the sliced-ELL layout of fdx_graph.h.
+//
+// Pipeline (all on the stream, one small D2H for the bounding box):
+//   1. bounding box -> uniform grid with ~2 points per cell; cell id with the LONGEST axis slowest, so that contiguous
+//      ranges of the sorted order are slabs across the short side (2 halo peers per GPU when sharded).
+//   2. stable radix sort of (cell id, original index) (rocPRIM)  -> perm / rank; points inside a cell keep caller order.
+//   3. exact k-NN: one lane per point scans the cells of growing Chebyshev shells until the k+1-th best squared distance
+//      is provably inside the scanned block.  Squared distances are evaluated in float64 WITHOUT fma contraction
+//      ((dx*dx + dy*dy) + dz*dz, each rounded) and ties are broken by the lower original index.
+//   4. union symmetrisation: in-degree count, reverse lists, per-row sort by original index + unique.
+//   5. sliced ELL (slice = 64 consecutive sorted points = one wavefront of the BCD sweep).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "fdx_graph.h"
+#include "fdx_internal.h"
+#include "fdx_kernels.h"
+#include "graph_build.h"
+
+namespace fdx {
+
+struct GridParams {
+    double mn[3];
+    double inv_h[3];
+    double h[3];
+    int nc[3];       // cells per axis (1 for unused / zero-extent axes)
+    int stride[3];   // cell id = sum_a c_a * stride[a]
+    int dim;
+};
+
+// ------------------------------------------------------------------------------------------------ bbox
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const double* __restrict__ coords, long long n, int dim,
+                                                           double* __restrict__ part /* (nblk, 6) */) {
+    __shared__ double smn[3][256], smx[3][256];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        for (int a = 0; a < dim; ++a) {
+            const double v = coords[(size_t)i * dim + a];
+            mn[a] = fmin(mn[a], v);
+            mx[a] = fmax(mx[a], v);
+        }
+    for (int a = 0; a < 3; ++a) { smn[a][threadIdx.x] = mn[a]; smx[a][threadIdx.x] = mx[a]; }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int a = 0; a < 3; ++a) {
+                smn[a][threadIdx.x] = fmin(smn[a][threadIdx.x], smn[a][threadIdx.x + s]);
+                smx[a][threadIdx.x] = fmax(smx[a][threadIdx.x], smx[a][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) {
+        part[(size_t)blockIdx.x * 6 + threadIdx.x] = smn[threadIdx.x][0];
+        part[(size_t)blockIdx.x * 6 + 3 + threadIdx.x] = smx[threadIdx.x][0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ binning
+__device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int nc) {
+    int c = (int)floor((x - mn) * inv_h);
+    return max(0, min(nc - 1, c));
+}
+
+__global__ __launch_bounds__(256) void cell_key_kernel(const double* __restrict__ coords, long long n, GridParams gp,
+                                                       unsigned int* __restrict__ keys, int* __restrict__ vals) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    int id = 0;
+    for (int a = 0; a < gp.dim; ++a)
+        id += cell_coord(coords[(size_t)i * gp.dim + a], gp.mn[a], gp.inv_h[a], gp.nc[a]) * gp.stride[a];
+    keys[i] = (unsigned int)id;
+    vals[i] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void cell_range_kernel(const unsigned int* __restrict__ skeys, long long n,
+                                                         int* __restrict__ cstart, int* __restrict__ cend) {
+    const long long p = blockIdx.x * 256LL + threadIdx.x;
+    if (p >= n) return;
+    const unsigned int k = skeys[p];
+    if (p == 0 || skeys[p - 1] != k) cstart[k] = (int)p;
+    if (p == n - 1 || skeys[p + 1] != k) cend[k] = (int)p + 1;
+}
+
+// sorted coordinate planes sc[a*n + p] and rank[perm[p]] = p
+__global__ __launch_bounds__(256) void gather_sorted_kernel(const double* __restrict__ coords, const int* __restrict__ perm,
+                                                            long long n, int dim, double* __restrict__ sc,
+                                                            int* __restrict__ rank) {
+    const long long p = blockIdx.x * 256LL + threadIdx.x;
+    if (p >= n) return;
+    const int o = perm[p];
+    for (int a = 0; a < 3; ++a) sc[(size_t)a * n + p] = (a < dim) ? coords[(size_t)o * dim + a] : 0.0;
+    rank[o] = (int)p;
+}
+
+// ------------------------------------------------------------------------------------------------ k-NN
+__device__ __forceinline__ double dist2_exact(double dx, double dy, double dz) {
+    // sum of squares with every product and sum rounded (no fma contraction), as a host float64 loop computes it
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+__device__ __forceinline__ bool lex_less(double d1, int i1, double d2, int i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
+
+// kk = k+1 nearest INCLUDING self (cKDTree.query(coords, k+1), graph.py:63); nbr_out has stride kk, -1 padded.
+template <int KMAX>
+__global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc, const int* __restrict__ perm,
+                                                  const int* __restrict__ cstart, const int* __restrict__ cend,
+                                                  long long n, GridParams gp, int kk, int* __restrict__ nbr_out,
+                                                  int* __restrict__ nbr_cnt, double* __restrict__ nn_dist) {
+    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
+    const double pc[3] = {px, py, pz};
+    int c[3];
+    for (int a = 0; a < 3; ++a) c[a] = (a < gp.dim) ? cell_coord(pc[a], gp.mn[a], gp.inv_h[a], gp.nc[a]) : 0;
+    double bd[KMAX];
+    int bi[KMAX], bq[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; bq[s] = -1; }
+
+    const int maxR = max(gp.nc[0], max(gp.nc[1], gp.nc[2]));
+    for (int R = 0; R <= maxR; ++R) {
+        // visit the shell max_a |dc_a| == R of the cell block around c
+        const int lo0 = max(0, c[0] - R), hi0 = min(gp.nc[0] - 1, c[0] + R);
+        const int lo1 = max(0, c[1] - R), hi1 = min(gp.nc[1] - 1, c[1] + R);
+        const int lo2 = max(0, c[2] - R), hi2 = min(gp.nc[2] - 1, c[2] + R);
+        for (int z = lo2; z <= hi2; ++z)
+            for (int y = lo1; y <= hi1; ++y) {
+                const bool edge_zy = (abs(z - c[2]) == R) || (abs(y - c[1]) == R);
+                for (int x = lo0; x <= hi0; ++x) {
+                    if (!edge_zy && abs(x - c[0]) != R) {      // interior of the shell: jump to the far face
+                        if (x < c[0] + R) { x = c[0] + R - 1; }
+                        continue;
+                    }
+                    const int cell = x * gp.stride[0] + y * gp.stride[1] + z * gp.stride[2];
+                    const int s0 = cstart[cell], s1 = cend[cell];
+                    for (int q = s0; q < s1; ++q) {
+                        const double d2 = dist2_exact(sc[q] - px, sc[(size_t)n + q] - py, sc[2 * (size_t)n + q] - pz);
+                        const int oi = perm[q];
+                        if (lex_less(d2, oi, bd[KMAX - 1], bi[KMAX - 1])) {
+                            bd[KMAX - 1] = d2; bi[KMAX - 1] = oi; bq[KMAX - 1] = q;
+#pragma unroll
+                            for (int s = KMAX - 1; s > 0; --s) {
+                                if (lex_less(bd[s], bi[s], bd[s - 1], bi[s - 1])) {
+                                    const double td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
+                                    const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
+                                    const int tq = bq[s]; bq[s] = bq[s - 1]; bq[s - 1] = tq;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        // done when the kk-th best is provably inside the scanned block
+        bool covers_all = true;
+        double safe = INFINITY;
+        for (int a = 0; a < gp.dim; ++a) {
+            const double slack = 1e-12 * (fabs(pc[a]) + gp.h[a] * (double)gp.nc[a]);
+            if (c[a] - R > 0) {
+                covers_all = false;
+                safe = fmin(safe, pc[a] - (gp.mn[a] + (double)(c[a] - R) * gp.h[a]) - slack);
+            }
+            if (c[a] + R < gp.nc[a] - 1) {
+                covers_all = false;
+                safe = fmin(safe, (gp.mn[a] + (double)(c[a] + R + 1) * gp.h[a]) - pc[a] - slack);
+            }
+        }
+        if (covers_all) break;
+        // bd[] holds the KMAX best; the kk-th best is bd[kk-1] (selected without dynamic register indexing)
+        double kth = INFINITY;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) if (s == kk - 1) kth = bd[s];
+        if (safe > 0.0 && kth < safe * safe) break;
+    }
+    if (nn_dist) {   // distance to the nearest OTHER point (entry 0 is self unless points coincide)
+        double d1 = INFINITY;
+#pragma unroll
+        for (int s = KMAX - 1; s >= 0; --s) if (s < kk && bq[s] >= 0 && bq[s] != (int)p) d1 = bd[s];
+        nn_dist[perm[p]] = sqrt(d1);
+        return;
+    }
+    // drop self (graph.py:70-74); if self is not among the kk nearest (coincident points) keep all kk, as the reference does
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+        if (s < kk && bq[s] >= 0 && bq[s] != (int)p) nbr_out[(size_t)p * kk + cnt++] = bq[s];
+    for (int s = cnt; s < kk; ++s) nbr_out[(size_t)p * kk + s] = -1;
+    nbr_cnt[p] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------ radius graph
+// PASS 0 counts, PASS 1 fills nbr[off[p] + m] (sorted-space indices, unsorted order)
+template <int PASS>
+__global__ __launch_bounds__(128) void radius_kernel(const double* __restrict__ sc, const int* __restrict__ cstart,
+                                                     const int* __restrict__ cend, long long n, GridParams gp,
+                                                     double radius, int R, int* __restrict__ cnt,
+                                                     const int* __restrict__ off, int* __restrict__ nbr) {
+    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
+    const double pc[3] = {px, py, pz};
+    int c[3];
+    for (int a = 0; a < 3; ++a) c[a] = (a < gp.dim) ? cell_coord(pc[a], gp.mn[a], gp.inv_h[a], gp.nc[a]) : 0;
+    int m = 0;
+    const int base = PASS ? off[p] : 0;
+    for (int z = max(0, c[2] - R); z <= min(gp.nc[2] - 1, c[2] + R); ++z)
+        for (int y = max(0, c[1] - R); y <= min(gp.nc[1] - 1, c[1] + R); ++y)
+            for (int x = max(0, c[0] - R); x <= min(gp.nc[0] - 1, c[0] + R); ++x) {
+                const int cell = x * gp.stride[0] + y * gp.stride[1] + z * gp.stride[2];
+                for (int q = cstart[cell]; q < cend[cell]; ++q) {
+                    if (q == (int)p) continue;
+                    const double d2 = dist2_exact(sc[q] - px, sc[(size_t)n + q] - py, sc[2 * (size_t)n + q] - pz);
+                    if (sqrt(d2) <= radius) {   // query_pairs(r): distance <= r   (graph.py:115)
+                        if (PASS) nbr[base + m] = q;
+                        ++m;
+                    }
+                }
+            }
+    if (!PASS) cnt[p] = m;
+}
+
+// ------------------------------------------------------------------------------------------------ symmetrise
+__global__ __launch_bounds__(256) void indegree_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
+                                                       long long n, int kk, int* __restrict__ indeg) {
+    const long long p = blockIdx.x * 256LL + threadIdx.x;
+    if (p >= n) return;
+    for (int m = 0; m < nbr_cnt[p]; ++m) atomicAdd(&indeg[nbr[(size_t)p * kk + m]], 1);
+}
+
+__global__ __launch_bounds__(256) void fill_reverse_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
+                                                           long long n, int kk, const int* __restrict__ rev_off,
+                                                           int* __restrict__ cursor, int* __restrict__ rev) {
+    const long long p = blockIdx.x * 256LL + threadIdx.x;
+    if (p >= n) return;
+    for (int m = 0; m < nbr_cnt[p]; ++m) {
+        const int q = nbr[(size_t)p * kk + m];
+        rev[rev_off[q] + atomicAdd(&cursor[q], 1)] = (int)p;
+    }
+}
+
+// Row p: candidates = out(p) U in(p) -> sorted by ORIGINAL index, duplicates removed, stored at ws[seg_off(p) ...].
+// seg_off(p) = p*kk + rev_off[p] (capacity kk + indeg[p]).  The arrival order of the reverse list is arbitrary (atomics);
+// sorting makes the result deterministic.
+__global__ __launch_bounds__(128) void merge_rows_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
+                                                         const int* __restrict__ rev, const int* __restrict__ rev_off,
+                                                         const int* __restrict__ perm, long long n, int kk,
+                                                         int* __restrict__ ws, int* __restrict__ deg) {
+    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int* seg = ws + (size_t)p * kk + rev_off[p];
+    int m = 0;
+    for (int t = 0; t < nbr_cnt[p]; ++t) seg[m++] = nbr[(size_t)p * kk + t];
+    for (int t = rev_off[p]; t < rev_off[p + 1]; ++t) seg[m++] = rev[t];
+    for (int a = 1; a < m; ++a) {   // insertion sort by original index
+        const int v = seg[a];
+        const int kv = perm[v];
+        int b = a - 1;
+        while (b >= 0 && perm[seg[b]] > kv) { seg[b + 1] = seg[b]; --b; }
+        seg[b + 1] = v;
+    }
+    int u = 0;
+    for (int a = 0; a < m; ++a)
+        if (a == 0 || seg[a] != seg[a - 1]) seg[u++] = seg[a];
+    deg[p] = u;
+}
+
+// Variant for already-symmetric neighbour lists with explicit offsets (radius graph): sort only.
+__global__ __launch_bounds__(128) void sort_rows_kernel(int* __restrict__ nbr, const int* __restrict__ off,
+                                                        const int* __restrict__ perm, long long n) {
+    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int* seg = nbr + off[p];
+    const int m = off[p + 1] - off[p];
+    for (int a = 1; a < m; ++a) {
+        const int v = seg[a];
+        const int kv = perm[v];
+        int b = a - 1;
+        while (b >= 0 && perm[seg[b]] > kv) { seg[b + 1] = seg[b]; --b; }
+        seg[b + 1] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ELL
+__global__ __launch_bounds__(256) void slice_width_kernel(const int* __restrict__ deg, long long n, int n_slices,
+                                                          int* __restrict__ width) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const long long i = (long long)s * 64 + lane;
+    int w = (i < n) ? deg[i] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w = max(w, __shfl_xor(w, off, 64));
+    if (lane == 0) width[s] = w;
+}
+
+// seg_off(p) = p*seg_stride + seg_extra[p]   (k-NN: seg_stride = kk, seg_extra = rev_off; radius: stride 0, extra = off)
+__global__ __launch_bounds__(256) void fill_ell_kernel(const int* __restrict__ ws, int seg_stride,
+                                                       const int* __restrict__ seg_extra, const int* __restrict__ deg,
+                                                       const int* __restrict__ slice_off, long long n, int n_slices,
+                                                       int pad, int* __restrict__ ell) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const long long i = (long long)s * 64 + lane;
+    const int w0 = slice_off[s], w = slice_off[s + 1] - w0;
+    const int dg = (i < n) ? deg[i] : 0;
+    const int* seg = (i < n) ? ws + (size_t)i * seg_stride + seg_extra[i] : ws;
+    for (int m = 0; m < w; ++m) ell[((size_t)w0 + m) * 64 + lane] = (m < dg) ? seg[m] : pad;
+}
+
+// export: CSR in the caller's labels.  deg_orig[perm[p]] = deg[p]; then indices[indptr[o] + m] = perm[seg_p[m]].
+__global__ __launch_bounds__(256) void deg_to_orig_kernel(const int* __restrict__ deg, const int* __restrict__ perm,
+                                                          long long n, int* __restrict__ deg_orig) {
+    const long long p = blockIdx.x * 256LL + threadIdx.x;
+    if (p < n) deg_orig[perm[p]] = deg[p];
+}
+
+__global__ __launch_bounds__(256) void export_rows_kernel(const int* __restrict__ ws, int seg_stride,
+                                                          const int* __restrict__ seg_extra, const int* __restrict__ deg,
+                                                          const int* __restrict__ perm, const long long* __restrict__ indptr,
+                                                          long long n, int* __restrict__ indices) {
+    const long long p = blockIdx.x * 256LL + threadIdx.x;
+    if (p >= n) return;
+    const int* seg = ws + (size_t)p * seg_stride + seg_extra[p];
+    const long long base = indptr[perm[p]];
+    for (int m = 0; m < deg[p]; ++m) indices[base + m] = perm[seg[m]];
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long long n) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i < n) v[i] = (int)i;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int exclusive_scan_int(const int* in, int* out, long long count, hipStream_t st, DevBuf& tmp) {
+    size_t bytes = 0;
+    FDX_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)count, rocprim::plus<int>(), st));
+    if (tmp.bytes < bytes) FDX_TRY(tmp.alloc(bytes));
+    FDX_HIP(rocprim::exclusive_scan(tmp.p, bytes, in, out, 0, (size_t)count, rocprim::plus<int>(), st));
+    return 0;
+}
+
+static int exclusive_scan_i64(const int* in, long long* out, long long count, hipStream_t st, DevBuf& tmp) {
+    size_t bytes = 0;
+    auto in64 = rocprim::make_transform_iterator(in, [] __device__(int v) { return (long long)v; });
+    FDX_HIP(rocprim::exclusive_scan(nullptr, bytes, in64, out, 0LL, (size_t)count, rocprim::plus<long long>(), st));
+    if (tmp.bytes < bytes) FDX_TRY(tmp.alloc(bytes));
+    FDX_HIP(rocprim::exclusive_scan(tmp.p, bytes, in64, out, 0LL, (size_t)count, rocprim::plus<long long>(), st));
+    return 0;
+}
+
+static int make_grid(const double* d_coords, long long n, int dim, double target_per_cell, double min_h,
+                     GridParams* gp, hipStream_t st) {
+    const int nblk = (int)std::min<long long>(1024, (n + 255) / 256);
+    DevBuf part;
+    FDX_TRY(part.alloc((size_t)nblk * 6 * sizeof(double)));
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblk), dim3(256), 0, st, d_coords, n, dim, part.as<double>());
+    FDX_CHECK_LAUNCH();
+    std::vector<double> h_part((size_t)nblk * 6);
+    FDX_HIP(hipMemcpyAsync(h_part.data(), part.p, h_part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (int a = 0; a < dim; ++a) {
+        mn[a] = INFINITY; mx[a] = -INFINITY;
+        for (int b = 0; b < nblk; ++b) {
+            mn[a] = std::min(mn[a], h_part[(size_t)b * 6 + a]);
+            mx[a] = std::max(mx[a], h_part[(size_t)b * 6 + 3 + a]);
+        }
+        if (!(std::isfinite(mn[a]) && std::isfinite(mx[a])))
+            return fail(FDX_ERR_INVALID, "graph: coordinates contain NaN or infinity");
+    }
+    // cell edge from the occupied volume: ~target_per_cell points per cell over the axes with non-zero extent
+    double vol = 1.0;
+    int eff = 0;
+    for (int a = 0; a < dim; ++a)
+        if (mx[a] > mn[a]) { vol *= (mx[a] - mn[a]); ++eff; }
+    double h = 1.0;
+    if (eff > 0) h = std::pow(vol * target_per_cell / (double)std::max<long long>(n, 1), 1.0 / eff);
+    if (min_h > 0.0) h = std::max(h, min_h);
+    if (!(h > 0.0) || !std::isfinite(h)) h = 1.0;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        double cells = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            gp->mn[a] = (a < dim) ? mn[a] : 0.0;
+            gp->h[a] = h;
+            gp->inv_h[a] = 1.0 / h;
+            double nca = (a < dim && mx[a] > mn[a]) ? std::floor((mx[a] - mn[a]) / h) + 1.0 : 1.0;
+            cells *= nca;
+            gp->nc[a] = (int)std::min(nca, 2.0e9);
+        }
+        if (cells <= std::max(4.0 * (double)n, 4096.0) && cells < 2.0e9) break;
+        h *= 1.5;   // very elongated / clustered inputs: coarsen until the table is O(N)
+    }
+    gp->dim = dim;
+    // slowest-varying axis = most cells
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int a, int b) { return gp->nc[a] < gp->nc[b]; });
+    int stride = 1;
+    for (int t = 0; t < 3; ++t) { gp->stride[order[t]] = stride; stride *= gp->nc[order[t]]; }
+    return 0;
+}
+
+struct BinnedPoints {
+    GridParams gp;
+    DevBuf perm, rank, sc, cstart, cend;
+    long long n = 0;
+    int n_cells = 0;
+};
+
+static int bin_points(const double* d_coords, long long n, int dim, double target_per_cell, double min_h,
+                      BinnedPoints* b, hipStream_t st) {
+    b->n = n;
+    FDX_TRY(make_grid(d_coords, n, dim, target_per_cell, min_h, &b->gp, st));
+    b->n_cells = b->gp.nc[0] * b->gp.nc[1] * b->gp.nc[2];
+    DevBuf keys, vals, skeys, tmp;
+    FDX_TRY(keys.alloc((size_t)n * 4));
+    FDX_TRY(vals.alloc((size_t)n * 4));
+    FDX_TRY(skeys.alloc((size_t)n * 4));
+    FDX_TRY(b->perm.alloc((size_t)n * 4));
+    FDX_TRY(b->rank.alloc((size_t)n * 4));
+    FDX_TRY(b->sc.alloc((size_t)n * 3 * sizeof(double)));
+    FDX_TRY(b->cstart.alloc((size_t)b->n_cells * 4));
+    FDX_TRY(b->cend.alloc((size_t)b->n_cells * 4));
+    const int nb = ceil_div(n, 256);
+    hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, st, d_coords, n, b->gp, keys.as<unsigned int>(), vals.as<int>());
+    FDX_CHECK_LAUNCH();
+    int bits = 1;
+    while ((1LL << bits) < (long long)b->n_cells && bits < 32) ++bits;
+    size_t bytes = 0;
+    FDX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.as<unsigned int>(), skeys.as<unsigned int>(), vals.as<int>(),
+                                      b->perm.as<int>(), (size_t)n, 0, (unsigned)bits, st));
+    FDX_TRY(tmp.alloc(bytes));
+    FDX_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.as<unsigned int>(), skeys.as<unsigned int>(), vals.as<int>(),
+                                      b->perm.as<int>(), (size_t)n, 0, (unsigned)bits, st));
+    FDX_HIP(hipMemsetAsync(b->cstart.p, 0, b->cstart.bytes, st));
+    FDX_HIP(hipMemsetAsync(b->cend.p, 0, b->cend.bytes, st));
+    hipLaunchKernelGGL(cell_range_kernel, dim3(nb), dim3(256), 0, st, skeys.as<unsigned int>(), n, b->cstart.as<int>(), b->cend.as<int>());
+    FDX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nb), dim3(256), 0, st, d_coords, b->perm.as<int>(), n, dim, b->sc.as<double>(), b->rank.as<int>());
+    FDX_CHECK_LAUNCH();
+    FDX_HIP(hipStreamSynchronize(st));   // temporaries are released at scope exit
+    return 0;
+}
+
+// deg + row segments -> sliced ELL inside g (pad index = n_total)
+static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* seg_extra, hipStream_t st) {
+    const long long n = g->n;
+    g->n_slices = (int)((n + 63) / 64);
+    DevBuf width, tmp;
+    FDX_TRY(width.alloc((size_t)(g->n_slices + 1) * 4));
+    FDX_TRY(g->slice_off.alloc((size_t)(g->n_slices + 1) * 4));
+    FDX_HIP(hipMemsetAsync(width.p, 0, width.bytes, st));
+    hipLaunchKernelGGL(slice_width_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, g->deg.as<int>(), n, g->n_slices, width.as<int>());
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(exclusive_scan_int(width.as<int>(), g->slice_off.as<int>(), g->n_slices + 1, st, tmp));
+    int total = 0;
+    FDX_HIP(hipMemcpyAsync(&total, g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
+    // nnz and max degree
+    size_t rb = 0;
+    DevBuf red, rtmp;
+    FDX_TRY(red.alloc(16));
+    auto deg64 = rocprim::make_transform_iterator(g->deg.as<int>(), [] __device__(int v) { return (long long)v; });
+    FDX_HIP(rocprim::reduce(nullptr, rb, deg64, red.as<long long>(), 0LL, (size_t)n, rocprim::plus<long long>(), st));
+    FDX_TRY(rtmp.alloc(rb));
+    FDX_HIP(rocprim::reduce(rtmp.p, rb, deg64, red.as<long long>(), 0LL, (size_t)n, rocprim::plus<long long>(), st));
+    size_t rb2 = 0;
+    FDX_HIP(rocprim::reduce(nullptr, rb2, width.as<int>(), red.as<int>() + 2, 0, (size_t)g->n_slices, rocprim::maximum<int>(), st));
+    if (rb2 > rtmp.bytes) FDX_TRY(rtmp.alloc(rb2));
+    FDX_HIP(rocprim::reduce(rtmp.p, rb2, width.as<int>(), red.as<int>() + 2, 0, (size_t)g->n_slices, rocprim::maximum<int>(), st));
+    long long h_red[2] = {0, 0};
+    FDX_HIP(hipMemcpyAsync(h_red, red.p, 16, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    g->ell_rows = total;
+    g->nnz = h_red[0];
+    g->max_deg = (int)(h_red[1] & 0xffffffffLL);
+    FDX_TRY(g->ell.alloc((size_t)std::max<long long>(g->ell_rows, 1) * 64 * 4));
+    hipLaunchKernelGGL(fill_ell_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, ws, seg_stride, seg_extra,
+                       g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>());
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+static int empty_graph(long long n, fdx_graph* g, hipStream_t st) {
+    g->n = n; g->n_total = n; g->nnz = 0; g->max_deg = 0; g->ell_rows = 0;
+    g->n_slices = (int)((n + 63) / 64);
+    g->identity_order = true;
+    FDX_TRY(g->deg.alloc((size_t)std::max<long long>(n, 1) * 4));
+    FDX_TRY(g->slice_off.alloc((size_t)(g->n_slices + 1) * 4));
+    FDX_TRY(g->ell.alloc(256));
+    FDX_HIP(hipMemsetAsync(g->deg.p, 0, g->deg.bytes, st));
+    FDX_HIP(hipMemsetAsync(g->slice_off.p, 0, g->slice_off.bytes, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <int KMAX>
+static void launch_knn(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, hipStream_t st) {
+    hipLaunchKernelGGL(knn_kernel<KMAX>, dim3(ceil_div(b.n, 128)), dim3(128), 0, st, b.sc.as<double>(), perm,
+                       b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist);
+}
+
+int graph_nearest_distance(const double* d_coords, long long n, int dim, double* d_out, hipStream_t st) {
+    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
+    FDX_REQUIRE(n >= 2 && n < 0x7fffff00LL, "graph: nearest distance needs at least two points");
+    BinnedPoints b;
+    FDX_TRY(bin_points(d_coords, n, dim, 2.0, 0.0, &b, st));
+    launch_knn<8>(b, b.perm.as<int>(), 2, nullptr, nullptr, d_out, st);
+    FDX_CHECK_LAUNCH();
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_graph* g, hipStream_t st) {
+    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
+    FDX_REQUIRE(n >= 0 && n < 0x7fffff00LL, "graph: n out of range");
+    FDX_REQUIRE(k >= 0, "graph: k must be non-negative");
+    const int k_act = (int)std::min<long long>(k, n - 1);           // graph.py:51
+    if (k_act <= 0) return empty_graph(n, g, st);                   // graph.py:53-57
+    const int kk = k_act + 1;
+    FDX_REQUIRE(kk <= 64, "graph: k_neighbors above 63 is not supported");
+    FDX_REQUIRE((long long)n * kk < 0x7fffff00LL, "graph: n*k too large");
+    BinnedPoints b;
+    FDX_TRY(bin_points(d_coords, n, dim, 2.0, 0.0, &b, st));
+    g->n = n; g->n_total = n; g->identity_order = false;
+    g->perm.take(b.perm);
+    g->rank.take(b.rank);
+    const int* perm = g->perm.as<int>();
+    DevBuf nbr, cnt, indeg, rev_off, cursor, rev, tmp;
+    FDX_TRY(nbr.alloc((size_t)n * kk * 4));
+    FDX_TRY(cnt.alloc((size_t)n * 4));
+    if (kk <= 8) launch_knn<8>(b, perm, kk, nbr.as<int>(), cnt.as<int>(), nullptr, st);
+    else if (kk <= 16) launch_knn<16>(b, perm, kk, nbr.as<int>(), cnt.as<int>(), nullptr, st);
+    else if (kk <= 32) launch_knn<32>(b, perm, kk, nbr.as<int>(), cnt.as<int>(), nullptr, st);
+    else launch_knn<64>(b, perm, kk, nbr.as<int>(), cnt.as<int>(), nullptr, st);
+    FDX_CHECK_LAUNCH();
+    // symmetrise: A + A^T, binary   (graph.py:80-81)
+    FDX_TRY(indeg.alloc((size_t)(n + 1) * 4));
+    FDX_TRY(rev_off.alloc((size_t)(n + 1) * 4));
+    FDX_TRY(cursor.alloc((size_t)n * 4));
+    FDX_HIP(hipMemsetAsync(indeg.p, 0, indeg.bytes, st));
+    FDX_HIP(hipMemsetAsync(cursor.p, 0, cursor.bytes, st));
+    const int nb = ceil_div(n, 256);
+    hipLaunchKernelGGL(indegree_kernel, dim3(nb), dim3(256), 0, st, nbr.as<int>(), cnt.as<int>(), n, kk, indeg.as<int>());
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(exclusive_scan_int(indeg.as<int>(), rev_off.as<int>(), n + 1, st, tmp));
+    FDX_TRY(rev.alloc((size_t)n * kk * 4));
+    hipLaunchKernelGGL(fill_reverse_kernel, dim3(nb), dim3(256), 0, st, nbr.as<int>(), cnt.as<int>(), n, kk, rev_off.as<int>(), cursor.as<int>(), rev.as<int>());
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(g->rows.alloc((size_t)n * kk * 2 * 4));     // capacity sum_p (kk + indeg[p]) <= 2*n*kk
+    FDX_TRY(g->deg.alloc((size_t)n * 4));
+    hipLaunchKernelGGL(merge_rows_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, st, nbr.as<int>(), cnt.as<int>(), rev.as<int>(),
+                       rev_off.as<int>(), g->perm.as<int>(), n, kk, g->rows.as<int>(), g->deg.as<int>());
+    FDX_CHECK_LAUNCH();
+    g->row_stride = kk;
+    g->row_extra.take(rev_off);   // keep: segment offsets
+    FDX_TRY(finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int graph_build_radius(const double* d_coords, long long n, int dim, double radius, fdx_graph* g, hipStream_t st) {
+    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
+    FDX_REQUIRE(n >= 0 && n < 0x7fffff00LL, "graph: n out of range");
+    FDX_REQUIRE(radius > 0.0 && std::isfinite(radius), "graph: radius must be positive");
+    if (n <= 1) return empty_graph(n, g, st);
+    BinnedPoints b;
+    FDX_TRY(bin_points(d_coords, n, dim, 1.0, radius, &b, st));   // cell edge >= radius: one shell suffices
+    const int R = (int)std::ceil(radius / b.gp.h[0] * (1.0 + 1e-12));
+    g->n = n; g->n_total = n; g->identity_order = false;
+    g->perm.take(b.perm);
+    g->rank.take(b.rank);
+    DevBuf cnt, tmp;
+    FDX_TRY(cnt.alloc((size_t)(n + 1) * 4));
+    FDX_TRY(g->row_extra.alloc((size_t)(n + 1) * 4));
+    FDX_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes, st));
+    const int nb = ceil_div(n, 128);
+    hipLaunchKernelGGL(radius_kernel<0>, dim3(nb), dim3(128), 0, st, b.sc.as<double>(), b.cstart.as<int>(), b.cend.as<int>(), n,
+                       b.gp, radius, R, cnt.as<int>(), (const int*)nullptr, (int*)nullptr);
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(exclusive_scan_int(cnt.as<int>(), g->row_extra.as<int>(), n + 1, st, tmp));
+    int total = 0;
+    FDX_HIP(hipMemcpyAsync(&total, g->row_extra.as<int>() + n, 4, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    FDX_REQUIRE(total >= 0, "graph: radius graph has too many edges");
+    FDX_TRY(g->rows.alloc((size_t)std::max(total, 1) * 4));
+    hipLaunchKernelGGL(radius_kernel<1>, dim3(nb), dim3(128), 0, st, b.sc.as<double>(), b.cstart.as<int>(), b.cend.as<int>(), n,
+                       b.gp, radius, R, (int*)nullptr, g->row_extra.as<int>(), g->rows.as<int>());
+    FDX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(nb), dim3(128), 0, st, g->rows.as<int>(), g->row_extra.as<int>(), g->perm.as<int>(), n);
+    FDX_CHECK_LAUNCH();
+    g->deg.take(cnt);
+    g->row_stride = 0;
+    FDX_TRY(finish_ell(g, g->rows.as<int>(), 0, g->row_extra.as<int>(), st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// CSR in the caller's labels: indptr (n+1) int64, indices (nnz) int32 ascending per row.  Device outputs.
+int graph_export_csr(const fdx_graph* g, long long* d_indptr, int* d_indices, hipStream_t st) {
+    const long long n = g->n;
+    if (n == 0) return 0;
+    if (g->nnz == 0) {
+        FDX_HIP(hipMemsetAsync(d_indptr, 0, (size_t)(n + 1) * 8, st));
+        return 0;
+    }
+    FDX_REQUIRE(!g->identity_order && g->rows.p, "graph export: graph was not built from coordinates");
+    DevBuf deg_o, tmp;
+    FDX_TRY(deg_o.alloc((size_t)(n + 1) * 4));
+    FDX_HIP(hipMemsetAsync(deg_o.p, 0, deg_o.bytes, st));
+    const int nb = ceil_div(n, 256);
+    hipLaunchKernelGGL(deg_to_orig_kernel, dim3(nb), dim3(256), 0, st, g->deg.as<int>(), g->perm.as<int>(), n, deg_o.as<int>());
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(exclusive_scan_i64(deg_o.as<int>(), d_indptr, n + 1, st, tmp));
+    hipLaunchKernelGGL(export_rows_kernel, dim3(nb), dim3(256), 0, st, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(),
+                       g->deg.as<int>(), g->perm.as<int>(), d_indptr, n, d_indices);
+    FDX_CHECK_LAUNCH();
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace fdx

@@ -1,0 +1,27 @@
+// Host-built static schedule for the CountSketch gather (internal).
+#pragma once
+#include "fdx_internal.h"
+#include "fdx_kernels.h"
+
+namespace fdx {
+
+struct SketchPlan {
+    int G = 0, d = 0;
+    int n_groups = 0;
+    long long total_len = 0;
+    DevBuf sched_gene, sched_w, group_off, slot_bucket;
+    SketchPlanDev dev() const {
+        SketchPlanDev p;
+        p.sched_gene = sched_gene.as<int>();
+        p.sched_w = sched_w.as<double>();
+        p.group_off = group_off.as<int>();
+        p.slot_bucket = slot_bucket.as<int>();
+        p.n_groups = n_groups;
+        return p;
+    }
+    // Omega (G x d) in CSC form on the host: col_ptr (d+1), gene_idx / weight (nnz), genes ascending per column.
+    // A CountSketch has exactly one entry per gene; any sparse Omega works (project_to_sketch accepts one).
+    int build(const long long* col_ptr, const int* gene_idx, const double* weight, int G_, int d_, hipStream_t st);
+};
+
+}  // namespace fdx

@@ -1,0 +1,130 @@
+"""Spatial neighbour graphs from spot coordinates: same functions as the reference's
+``flashdeconv/utils/graph.py``, built on the GPU (csrc/graph_kernels.cpp) and returned as the same
+``scipy.sparse.csr_matrix`` of ones (float64, int32 indices, sorted).
+
+    build_knn_graph      <- utils/graph.py:25-83
+    build_radius_graph   <- utils/graph.py:86-133
+    build_grid_graph     <- utils/graph.py:136-172
+    coords_to_adjacency  <- utils/graph.py:175-212
+
+Coordinates with 1, 2 or 3 columns are supported on the device.  On exactly tied distances (regular lattices) the
+k-th neighbour is chosen by the lower spot index, whereas the reference inherits cKDTree's traversal order.
+"""
+import numpy as np
+from scipy import sparse
+
+from .. import _lib
+
+
+def _validate_coords(coords):
+    if coords.ndim != 2 or coords.shape[1] == 0:                        # utils/graph.py:16-22
+        raise ValueError(f"coords must be 2D with at least 1 coordinate dimension, got shape {coords.shape}")
+    if coords.shape[1] > 3:
+        raise NotImplementedError("flashdeconv_amd builds spatial graphs for 1-, 2- or 3-dimensional coordinates")
+
+
+def _to_csr(graph, n):
+    indptr, indices = graph.to_csr_arrays()
+    data = np.ones(len(indices), dtype=np.float64)
+    return sparse.csr_matrix((data, indices, indptr.astype(np.int32) if len(indices) < 2**31 - 1 else indptr), shape=(n, n))
+
+
+def knn_graph_handle(coords, k=6):
+    """Device graph handle for the k-NN graph (used by FlashDeconv.fit to avoid a host round trip)."""
+    coords = np.asarray(coords, dtype=np.float64)
+    _validate_coords(coords)
+    _lib.require_gpu()
+    return _lib.Graph.from_coords_knn(coords, k)
+
+
+def build_knn_graph(coords, k=6, include_self=False):
+    coords = np.asarray(coords, dtype=np.float64)
+    _validate_coords(coords)
+    n = coords.shape[0]
+    if min(k, n - 1) <= 0:                                               # utils/graph.py:51-57
+        if include_self and n > 0:
+            return sparse.eye(n, dtype=np.float64, format="csr")
+        return sparse.csr_matrix((n, n), dtype=np.float64)
+    g = knn_graph_handle(coords, k)
+    try:
+        A = _to_csr(g, n)
+    finally:
+        g.close()
+    if include_self:
+        A = (A + sparse.eye(n, dtype=np.float64, format="csr")).tocsr()
+        A.data[:] = 1.0
+    return A
+
+
+def radius_graph_handle(coords, radius):
+    coords = np.asarray(coords, dtype=np.float64)
+    _validate_coords(coords)
+    _lib.require_gpu()
+    return _lib.Graph.from_coords_radius(coords, radius)
+
+
+def build_radius_graph(coords, radius, include_self=False):
+    coords = np.asarray(coords, dtype=np.float64)
+    _validate_coords(coords)
+    n = coords.shape[0]
+    g = radius_graph_handle(coords, radius)
+    try:
+        A = _to_csr(g, n)
+    finally:
+        g.close()
+    if A.nnz == 0:                                                       # utils/graph.py:117-121
+        if include_self and n > 0:
+            return sparse.eye(n, dtype=np.float64, format="csr")
+        return sparse.csr_matrix((n, n), dtype=np.float64)
+    if include_self:
+        A = (A + sparse.eye(n, dtype=np.float64)).tocsr()
+    return A
+
+
+def grid_radius(coords):
+    """1.5 x the median nearest-neighbour distance (utils/graph.py:163-170)."""
+    coords = _lib.as_f64(coords)
+    dist = np.empty(coords.shape[0], dtype=np.float64)
+    _lib.require_gpu()
+    _lib.check(_lib.load().fdx_nearest_distance(_lib.ptr_f64(coords), coords.shape[0], coords.shape[1], _lib.ptr_f64(dist)))
+    return float(np.median(dist)) * 1.5
+
+
+def build_grid_graph(coords, grid_spacing=None):
+    coords = np.asarray(coords, dtype=np.float64)
+    _validate_coords(coords)
+    n = coords.shape[0]
+    if n <= 1:                                                           # utils/graph.py:160-161
+        return sparse.csr_matrix((n, n), dtype=np.float64)
+    radius = grid_radius(coords) if grid_spacing is None else grid_spacing * 1.5
+    return build_radius_graph(coords, radius)
+
+
+def coords_to_adjacency(coords, method="knn", k=6, radius=None):
+    if method == "knn":
+        return build_knn_graph(coords, k=k)
+    if method == "radius":
+        if radius is None:
+            raise ValueError("radius must be specified for radius method")
+        return build_radius_graph(coords, radius=radius)
+    if method == "grid":
+        return build_grid_graph(coords)
+    raise ValueError(f"Unknown method: {method}")
+
+
+def coords_to_graph_handle(coords, method="knn", k=6, radius=None):
+    """Same dispatch as coords_to_adjacency but returns the device handle (no CSR materialised on the host)."""
+    coords = np.asarray(coords, dtype=np.float64)
+    _validate_coords(coords)
+    n = coords.shape[0]
+    if method == "knn":
+        return knn_graph_handle(coords, k)
+    if method == "radius":
+        if radius is None:
+            raise ValueError("radius must be specified for radius method")
+        return radius_graph_handle(coords, radius)
+    if method == "grid":
+        if n <= 1:
+            return knn_graph_handle(coords, 0)
+        return radius_graph_handle(coords, grid_radius(coords))
+    raise ValueError(f"Unknown method: {method}")

@@ -57,6 +57,16 @@ int fdx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes, void* stre
 int fdx_memset(void* dev_dst, int value, size_t bytes, void* stream);
 int fdx_stream_sync(void* stream);
 
+/* ---- preprocess + sketch (replaces core/deconv.py:147-235 and core/sketching.py:160-206) ------------- */
+/* Y_sketch = f(Y) @ Omega for host arrays.  Y is (n, G) row-major of `dtype`; Omega (G x d) is given in CSC form
+ * (col_ptr int64[d+1], gene_idx int32[nnz] ascending per column, weight f64[nnz]); `mode` is FDX_PRE_*.
+ * For "pearson" pass FDX_PRE_RAW with the weights already divided by sigma_g (core/deconv.py:199-225).
+ * Ys_out is (n, d) f64.  This is project_to_sketch(Y_tilde, ., Omega) when mode = FDX_PRE_RAW. */
+int fdx_sketch(const void* Y, int32_t dtype, int64_t n, int32_t G, const int64_t* col_ptr, const int32_t* gene_idx,
+               const double* weight, int32_t d, int32_t mode, double* Ys_out);
+/* Per-gene column sums of a host (n, G) matrix (pearson's mean: core/deconv.py:207-214). */
+int fdx_column_sums(const void* Y, int32_t dtype, int64_t n, int32_t G, double* sums_out);
+
 /* ---- spatial graph (replaces utils/graph.py:25-212 and the CSR handling of core/solver.py:363-365) ---- */
 typedef struct fdx_graph fdx_graph;
 
@@ -64,6 +74,18 @@ typedef struct fdx_graph fdx_graph;
  * int64 indptr (n+1) / indices (nnz); values are ignored (structure only, core/solver.py:157-159).
  * Spots keep their order. */
 int fdx_graph_from_csr(const int64_t* indptr, const int64_t* indices, int64_t n, fdx_graph** out);
+/* From coordinates, entirely on the device: coords is a HOST (n, dim) row-major f64 array, dim in {1,2,3}.
+ *   fdx_graph_build_knn    <- utils/graph.py:25-83  build_knn_graph(coords, k)   (k clamped to n-1, union symmetrised)
+ *   fdx_graph_build_radius <- utils/graph.py:86-133 build_radius_graph(coords, radius)
+ * Spots are reordered internally (grid-cell order) for locality; every host-visible result uses the caller's order. */
+int fdx_graph_build_knn(const double* coords, int64_t n, int32_t dim, int32_t k, fdx_graph** out);
+int fdx_graph_build_radius(const double* coords, int64_t n, int32_t dim, double radius, fdx_graph** out);
+/* Distance from every spot to its nearest other spot (host in/out, n >= 2): the quantity whose median sets the
+ * radius of build_grid_graph (utils/graph.py:163-170). */
+int fdx_nearest_distance(const double* coords, int64_t n, int32_t dim, double* dist_out);
+/* Adjacency as CSR in the caller's labels: indptr int64[n+1], indices int32[nnz] ascending per row (host outputs;
+ * all values of the reference's matrix are 1.0).  Call fdx_graph_info first to size `indices`. */
+int fdx_graph_export_csr(const fdx_graph* g, int64_t* indptr, int32_t* indices);
 int fdx_graph_destroy(fdx_graph* g);
 /* n spots, structural nnz, maximum degree */
 int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_deg);

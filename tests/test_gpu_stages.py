@@ -1,0 +1,110 @@
+"""-m gpu parity tests of the sketch and graph stages through the C ABI."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import datagen
+import fdx_oracle as orc
+from conftest import load_golden, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------- graphs
+def test_graphs_match_reference_golden():
+    from flashdeconv_amd.utils import graph as G
+    g = load_golden("graphs.npz")
+    for name in g["names"]:
+        coords = g[f"{name}_coords"]
+        method = str(g[f"{name}_method"])
+        radius = float(g[f"{name}_radius"])
+        A = G.coords_to_adjacency(coords, method=method, k=int(g[f"{name}_k"]), radius=None if radius < 0 else radius)
+        assert A.shape == (coords.shape[0],) * 2
+        assert np.array_equal(A.indptr, g[f"{name}_indptr"]), name
+        assert np.array_equal(A.indices, g[f"{name}_indices"]), name
+        assert A.dtype == np.float64 and (A.nnz == 0 or np.all(A.data == 1.0))
+
+
+@pytest.mark.parametrize("n,dim,k", [(5000, 2, 6), (3000, 3, 8), (4000, 2, 15), (2500, 1, 3), (777, 2, 40)])
+def test_knn_vs_oracle_kdtree(n, dim, k):
+    from flashdeconv_amd.utils import graph as G
+    rs = np.random.RandomState(n + k)
+    coords = rs.rand(n, dim) * (n ** (1.0 / dim))
+    A = G.build_knn_graph(coords, k=k)
+    B = orc.knn_graph_kdtree(coords, k)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    assert (A != A.T).nnz == 0 and A.diagonal().sum() == 0
+
+
+def test_knn_clustered_and_elongated():
+    from flashdeconv_amd.utils import graph as G
+    rs = np.random.RandomState(3)
+    coords = np.concatenate([rs.randn(3000, 2) * 0.01, rs.rand(3000, 2) * np.array([5000.0, 2.0])])
+    A = G.build_knn_graph(coords, k=6)
+    B = orc.knn_graph_kdtree(coords, 6)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+
+
+def test_radius_and_grid_vs_oracle():
+    from flashdeconv_amd.utils import graph as G
+    rs = np.random.RandomState(8)
+    coords = rs.rand(1500, 2) * 30
+    A = G.build_radius_graph(coords, 1.7)
+    B = orc.radius_graph(coords, 1.7)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    jc = datagen.count_like(900, 30, 2, seed=4)[2]
+    A = G.build_grid_graph(jc)
+    B = orc.grid_graph(jc)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+
+
+def test_graph_errors():
+    from flashdeconv_amd.utils import graph as G
+    with pytest.raises(ValueError, match="coords must be 2D"):
+        G.build_knn_graph(np.zeros(5))
+    with pytest.raises(ValueError, match="radius must be specified"):
+        G.coords_to_adjacency(np.zeros((4, 2)), method="radius")
+    with pytest.raises(ValueError, match="Unknown method"):
+        G.coords_to_adjacency(np.zeros((4, 2)), method="nope")
+
+
+# ------------------------------------------------------------------------------------------- sketch
+def test_countsketch_tables_bit_exact():
+    from flashdeconv_amd.core import sketching as S
+    g = load_golden("omega_tables.npz")
+    for (Gn, d, s) in g["cases"]:
+        tag = f"G{Gn}_d{d}_s{s}"
+        Om = S.build_countsketch_matrix(int(Gn), int(d), None, int(s)).tocsr()
+        assert np.array_equal(Om.indices, g[tag + "_bucket"])
+        assert np.array_equal(np.sign(Om.data).astype(np.int64), g[tag + "_sign"])
+        np.testing.assert_allclose(Om.data, g[tag + "_data"], rtol=1e-15)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,G,d", [(37, 90, 16), (300, 2000, 512), (65, 1001, 500), (10, 64, 1), (129, 5003, 1024)])
+def test_project_to_sketch_vs_oracle(n, G, d, dtype):
+    from flashdeconv_amd.core import sketching as S
+    rs = np.random.RandomState(n)
+    Yt = rs.randn(n, G).astype(dtype)
+    Xt = rs.rand(7, G)
+    lev = rs.rand(G)
+    Ys, Xs, Om = S.sketch_data(Yt, Xt, sketch_dim=d, leverage_scores=lev, random_state=5)
+    b, w = orc.countsketch_omega(G, d, lev, 5)
+    assert np.array_equal(Om.tocsr().indices, b)
+    want_Y, want_X = orc.project(Yt.astype(np.float64), Xt, b, w, d)
+    assert rel_fro(Ys, want_Y) < 1e-13 and rel_fro(Xs, want_X) < 1e-13
+    assert Ys.shape == (n, d) and Xs.shape == (7, d)
+
+
+def test_project_linearity_and_general_omega():
+    # reference tests/test_sketching.py:95-110 (linearity) + an Omega with several entries per gene
+    from flashdeconv_amd.core import sketching as S
+    rs = np.random.RandomState(0)
+    Y1, Y2, X = rs.rand(40, 120), rs.rand(40, 120), rs.rand(3, 120)
+    Om = sparse.random(120, 24, density=0.2, random_state=1, format="csr")
+    a, _ = S.project_to_sketch(Y1, X, Om)
+    b, _ = S.project_to_sketch(Y2, X, Om)
+    c, xs = S.project_to_sketch(Y1 + Y2, X, Om)
+    np.testing.assert_allclose(a + b, c, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(c, (Y1 + Y2) @ Om.toarray(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(xs, X @ Om.toarray(), rtol=1e-12, atol=1e-12)
