@@ -8,3 +8,6 @@ compute entry points raise.
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401
+from .core.deconv import FlashDeconv  # noqa: F401
+
+__all__ = ["FlashDeconv", "__version__"]

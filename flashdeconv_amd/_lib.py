@@ -40,8 +40,31 @@ class SolveInfo(ctypes.Structure):
     ]
 
 
+class FitParams(ctypes.Structure):
+    _fields_ = [
+        ("sketch_dim", c_i32), ("mode_y", c_i32), ("mode_x", c_i32), ("graph_method", c_i32), ("k_neighbors", c_i32),
+        ("lambda_auto", c_i32), ("max_iter", c_i32), ("verbose", c_i32),
+        ("radius", c_double), ("lambda_spatial", c_double), ("rho_sparsity", c_double), ("tol", c_double),
+    ]
+
+
+class FitInfo(ctypes.Structure):
+    _fields_ = [
+        ("solve", SolveInfo), ("lambda_used", c_double), ("rho_effective", c_double), ("YtY", c_double), ("nnz", c_i64),
+        ("graph_ms", c_double), ("sketch_ms", c_double), ("gram_ms", c_double), ("solve_ms", c_double),
+        ("finish_ms", c_double), ("total_ms", c_double),
+    ]
+
+
+GRAPH_KNN, GRAPH_RADIUS, GRAPH_GIVEN = 0, 1, 2
+
 # name -> (restype, argtypes); kept in one table so tests can check it against include/fdx.h
 SIGNATURES = {
+    "fdx_column_sums_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_void_p]),
+    "fdx_leverage_scores": (c_int, [p_double, c_i32, c_i32, c_double, p_double]),
+    "fdx_fit_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
+                            c_i32, ctypes.POINTER(FitParams), ctypes.POINTER(c_void_p), c_void_p, c_void_p, p_double,
+                            p_double, ctypes.POINTER(FitInfo), c_void_p]),
     "fdx_version": (c_int, []),
     "fdx_last_error": (ctypes.c_char_p, []),
     "fdx_device_count": (c_int, [ctypes.POINTER(c_int)]),

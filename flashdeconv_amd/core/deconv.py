@@ -1,0 +1,372 @@
+"""``FlashDeconv`` estimator: the reference's ``flashdeconv/core/deconv.py`` surface on the MI355X path.
+
+Constructor arguments, validation messages, fitted attributes (``beta_``, ``proportions_``, ``gene_idx_``, ``info_``,
+``adjacency_``, ``lambda_used_``, ``n_spots_`` ...), getters and ``summary()`` follow core/deconv.py:88-512.  ``fit``
+keeps the six steps of core/deconv.py:305-398 but runs steps 2-6 in one device-resident call (``fdx_fit_dev``).
+
+Inputs may be NumPy arrays, SciPy sparse matrices, or CUDA (HIP) ``torch`` tensors that already live in HBM; with
+``output="torch"`` the fitted arrays stay on the device as well.
+"""
+import ctypes
+
+import numpy as np
+from scipy import sparse
+
+from .. import _lib
+from ..utils import genes as _genes
+from .sketching import countsketch_tables
+
+_PRE_MODES = ("log_cpm", "pearson", "raw")
+
+
+def _is_torch_cuda(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+class _DeviceBuffer:
+    """Plain device allocation through the C ABI (fdx_malloc / fdx_free)."""
+
+    def __init__(self, nbytes):
+        self.ptr = ctypes.c_void_p()
+        self.nbytes = int(nbytes)
+        _lib.check(_lib.load().fdx_malloc(ctypes.byref(self.ptr), self.nbytes))
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(arr.nbytes)
+        _lib.check(_lib.load().fdx_memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, None))
+        return buf
+
+    def to_host(self, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        _lib.check(_lib.load().fdx_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            _lib.load().fdx_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FlashDeconv:
+    """Fast spatial transcriptomics deconvolution with spatial regularisation (MI355X implementation).
+
+    Parameters are those of the reference estimator (core/deconv.py:27-68): ``sketch_dim``, ``lambda_spatial``
+    (float or "auto"), ``rho_sparsity``, ``n_hvg``, ``n_markers_per_type``, ``spatial_method`` ("knn" | "radius" |
+    "grid"), ``k_neighbors``, ``radius``, ``max_iter``, ``tol``, ``preprocess`` ("log_cpm" | "pearson" | "raw"),
+    ``random_state``, ``verbose``.
+    """
+
+    def __init__(self, sketch_dim=512, lambda_spatial="auto", rho_sparsity=0.01, n_hvg=2000, n_markers_per_type=50,
+                 spatial_method="knn", k_neighbors=6, radius=None, max_iter=100, tol=1e-4, preprocess="log_cpm",
+                 random_state=0, verbose=False):
+        if sketch_dim <= 0:
+            raise ValueError(f"sketch_dim must be positive, got {sketch_dim}")
+        if k_neighbors < 0:
+            raise ValueError(f"k_neighbors must be non-negative, got {k_neighbors}")
+        if max_iter < 0:
+            raise ValueError(f"max_iter must be non-negative, got {max_iter}")
+        if tol <= 0:
+            raise ValueError(f"tol must be positive, got {tol}")
+        if isinstance(lambda_spatial, (int, float)) and lambda_spatial < 0:
+            raise ValueError(f"lambda_spatial must be non-negative, got {lambda_spatial}")
+        if rho_sparsity < 0:
+            raise ValueError(f"rho_sparsity must be non-negative, got {rho_sparsity}")
+        if n_hvg < 0:
+            raise ValueError(f"n_hvg must be non-negative, got {n_hvg}")
+        if n_markers_per_type < 0:
+            raise ValueError(f"n_markers_per_type must be non-negative, got {n_markers_per_type}")
+        if spatial_method == "radius" and radius is None:
+            raise ValueError("radius must be specified when spatial_method='radius'")
+        if radius is not None and radius <= 0:
+            raise ValueError(f"radius must be positive, got {radius}")
+        self.sketch_dim = sketch_dim
+        self.lambda_spatial = lambda_spatial
+        self.rho_sparsity = rho_sparsity
+        self.n_hvg = n_hvg
+        self.n_markers_per_type = n_markers_per_type
+        self.spatial_method = spatial_method
+        self.k_neighbors = k_neighbors
+        self.radius = radius
+        self.max_iter = max_iter
+        self.tol = tol
+        self.preprocess = preprocess
+        self.random_state = random_state
+        self.verbose = verbose
+
+        self.beta_ = None
+        self.proportions_ = None
+        self.gene_idx_ = None
+        self.info_ = None
+        self._fitted = False
+        self._graph = None
+        self._adjacency = None
+
+    # ------------------------------------------------------------------ adjacency_ (materialised on first access)
+    @property
+    def adjacency_(self):
+        if self._adjacency is None and self._graph is not None:
+            n = self.n_spots_
+            indptr, indices = self._graph.to_csr_arrays()
+            self._adjacency = sparse.csr_matrix((np.ones(len(indices), dtype=np.float64), indices,
+                                                 indptr.astype(np.int32) if len(indices) < 2**31 - 1 else indptr),
+                                                shape=(n, n))
+        return self._adjacency
+
+    @adjacency_.setter
+    def adjacency_(self, value):
+        self._adjacency = value
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, Y, X, coords, cell_type_names=None, output="numpy"):
+        """Fit the model (core/deconv.py:237-405).  ``output="torch"`` keeps ``beta_``/``proportions_`` in HBM."""
+        if Y.shape[1] != X.shape[1]:
+            raise ValueError(
+                f"Gene dimension mismatch: Y has {Y.shape[1]} genes but X has {X.shape[1]} genes. They must share "
+                f"the same gene space (align before calling fit).")
+        if coords.shape[0] != Y.shape[0]:
+            raise ValueError(
+                f"Spot count mismatch: Y has {Y.shape[0]} spots but coords has {coords.shape[0]} rows. Each spot "
+                f"needs exactly one coordinate.")
+        if X.shape[0] == 0:
+            raise ValueError(
+                "Reference matrix X must contain at least one cell type (X.shape[0] > 0). Check your reference "
+                "filtering and cell_type_key mapping.")
+        if cell_type_names is not None and len(cell_type_names) != X.shape[0]:
+            raise ValueError(
+                f"cell_type_names length ({len(cell_type_names)}) does not match number of cell types in X "
+                f"({X.shape[0]}).")
+        if self.preprocess not in _PRE_MODES:
+            raise ValueError(f"Unknown preprocess method: {self.preprocess}. Choose from 'log_cpm', 'pearson', or 'raw'.")
+        if self.spatial_method not in ("knn", "radius", "grid"):
+            raise ValueError(f"Unknown method: {self.spatial_method}")
+        if len(coords.shape) != 2 or coords.shape[1] == 0:
+            raise ValueError(f"coords must be 2D with at least 1 coordinate dimension, got shape {tuple(coords.shape)}")
+        if coords.shape[1] > 3:
+            raise NotImplementedError("flashdeconv_amd builds spatial graphs for 1-, 2- or 3-dimensional coordinates")
+        _lib.require_gpu()
+        lib = _lib.load()
+        log = print if self.verbose else (lambda *a, **k: None)
+        log("FlashDeconv: Starting deconvolution...")
+        log(f"  Spatial data: {Y.shape[0]} spots x {Y.shape[1]} genes")
+        log(f"  Reference: {X.shape[0]} cell types x {X.shape[1]} genes")
+
+        n, G_all = int(Y.shape[0]), int(Y.shape[1])
+        X = np.asarray(X.detach().cpu().numpy() if hasattr(X, "detach") else X, dtype=np.float64)
+        K = X.shape[0]
+        self.n_spots_, self.n_genes_, self.n_cell_types_ = n, G_all, K
+        self.cell_type_names_ = cell_type_names
+        if n == 0:
+            raise ValueError("Y has no spots")
+
+        # Step 1: informative genes + leverage scores (core/deconv.py:305-318)
+        log("Step 1: Selecting informative genes...")
+        if G_all <= self.n_hvg:
+            # select_hvg returns every gene when the matrix has no more than n_hvg of them and the marker union is a
+            # subset (utils/genes.py:135-145, 330) - no pass over Y needed.
+            if G_all == 0:
+                raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
+            gene_idx = np.arange(G_all, dtype=np.intp)
+            leverage = _genes.compute_leverage_scores(X)
+        else:
+            gene_idx, leverage = _genes.select_informative_genes(Y, X, self.n_hvg, self.n_markers_per_type)
+        self.gene_idx_ = gene_idx
+        G = len(gene_idx)
+        log(f"  Selected {G} genes (HVG + markers)")
+        identity_genes = (G == G_all)
+        Xsel = np.ascontiguousarray(X[:, gene_idx])
+
+        # Y into HBM
+        owned = []
+        try:
+            if _is_torch_cuda(Y):
+                import torch
+                if not identity_genes:
+                    Y = Y[:, torch.as_tensor(gene_idx, device=Y.device)]
+                if Y.dtype not in (torch.float32, torch.float64):
+                    Y = Y.to(torch.float32)
+                Y = Y.contiguous()
+                y_ptr, y_code, ldy = ctypes.c_void_p(Y.data_ptr()), (_lib.FDX_F32 if Y.dtype == torch.float32 else _lib.FDX_F64), G
+                y_sparse_rule = False
+            else:
+                y_sparse_rule = sparse.issparse(Y)
+                if y_sparse_rule:
+                    Yh = Y[:, gene_idx] if not identity_genes else Y
+                    Yh = np.asarray(Yh.todense())     # interim: CSR kernel is the next hot-path row
+                else:
+                    Yh = np.asarray(Y)
+                    if not identity_genes:
+                        Yh = Yh[:, gene_idx]
+                Yh, y_code = _lib.as_device_matrix(Yh)
+                ybuf = _DeviceBuffer.from_host(Yh)
+                owned.append(ybuf)
+                y_ptr, ldy = ybuf.ptr, G
+            if _is_torch_cuda(coords):
+                import torch
+                cd = coords.to(torch.float64).contiguous()
+                c_ptr = ctypes.c_void_p(cd.data_ptr())
+                coords_host = None
+            else:
+                coords_host = np.ascontiguousarray(np.asarray(coords), dtype=np.float64)
+                cbuf = _DeviceBuffer.from_host(coords_host)
+                owned.append(cbuf)
+                c_ptr = cbuf.ptr
+            dim = int(coords.shape[1])
+
+            # Step 2+3 tables: preprocessing mode and CountSketch Omega (core/deconv.py:326-352)
+            log(f"Step 2: Preprocessing with method='{self.preprocess}'...")
+            bucket, weight = countsketch_tables(G, self.sketch_dim, leverage, self.random_state)
+            weight_y = weight_x = weight
+            mode_y = mode_x = _lib.PRE_RAW
+            if self.preprocess == "log_cpm":
+                mode_y = _lib.PRE_LOG_CPM_SPARSE if y_sparse_rule else _lib.PRE_LOG_CPM
+                mode_x = _lib.PRE_LOG_CPM
+                log("  Y and X normalized to log-CPM space")
+            elif self.preprocess == "pearson":
+                sums = np.empty(G, dtype=np.float64)
+                _lib.check(lib.fdx_column_sums_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(sums), None))
+                mu_y = sums / n + 1e-6                                        # core/deconv.py:208,214
+                mu_x = Xsel.mean(axis=0) + 1e-6                               # core/deconv.py:220
+                weight_y = weight / np.sqrt(mu_y + mu_y ** 2 / 100.0)         # sigma^2 = mu + mu^2/theta, theta = 100
+                weight_x = weight / np.sqrt(mu_x + mu_x ** 2 / 100.0)
+                log("  Y and X transformed with uncentered Pearson residuals")
+            else:
+                log("  No preprocessing applied (raw)")
+            log(f"Step 3: Sketching to {self.sketch_dim} dimensions...")
+            log(f"  Compressed {G} genes -> {self.sketch_dim} dims")
+
+            prm = _lib.FitParams()
+            prm.sketch_dim = int(self.sketch_dim)
+            prm.mode_y, prm.mode_x = mode_y, mode_x
+            prm.k_neighbors = int(self.k_neighbors)
+            prm.max_iter, prm.tol, prm.verbose = int(self.max_iter), float(self.tol), 1 if self.verbose else 0
+            prm.rho_sparsity = float(self.rho_sparsity)
+            prm.lambda_auto = 1 if self.lambda_spatial == "auto" else 0
+            prm.lambda_spatial = 0.0 if prm.lambda_auto else float(self.lambda_spatial)
+            prm.radius = 0.0
+            log("Step 4: Building spatial graph...")
+            if self.spatial_method == "knn":
+                prm.graph_method = _lib.GRAPH_KNN
+            elif self.spatial_method == "radius":
+                prm.graph_method, prm.radius = _lib.GRAPH_RADIUS, float(self.radius)
+            else:   # "grid": radius = 1.5 x median nearest-neighbour distance (utils/graph.py:163-170)
+                if n <= 1:
+                    prm.graph_method, prm.k_neighbors = _lib.GRAPH_KNN, 0
+                else:
+                    from ..utils.graph import grid_radius
+                    ch = coords_host if coords_host is not None else coords.detach().cpu().numpy()
+                    prm.graph_method, prm.radius = _lib.GRAPH_RADIUS, grid_radius(ch)
+
+            if output == "torch":
+                import torch
+                dev = Y.device if _is_torch_cuda(Y) else torch.device("cuda", torch.cuda.current_device())
+                beta_t = torch.empty((n, K), dtype=torch.float64, device=dev)
+                prop_t = torch.empty((n, K), dtype=torch.float64, device=dev)
+                b_ptr, p_ptr = ctypes.c_void_p(beta_t.data_ptr()), ctypes.c_void_p(prop_t.data_ptr())
+            else:
+                bbuf, pbuf = _DeviceBuffer(n * K * 8), _DeviceBuffer(n * K * 8)
+                owned += [bbuf, pbuf]
+                b_ptr, p_ptr = bbuf.ptr, pbuf.ptr
+
+            objs = np.zeros(max(int(self.max_iter), 1), dtype=np.float64)
+            rels = np.zeros(max(int(self.max_iter), 1), dtype=np.float64)
+            info = _lib.FitInfo()
+            gh = ctypes.c_void_p()
+            bucket32 = np.ascontiguousarray(bucket, dtype=np.int32)
+            wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
+            if self._graph is not None:
+                self._graph.close()
+                self._graph = None
+            self._adjacency = None
+            _lib.check(lib.fdx_fit_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(Xsel), K, _lib.ptr_i32(bucket32),
+                                       _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim, ctypes.byref(prm),
+                                       ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs), _lib.ptr_f64(rels),
+                                       ctypes.byref(info), None))
+            self._graph = _lib.Graph(gh.value)
+            if output == "torch":
+                self.beta_, self.proportions_ = beta_t, prop_t
+            else:
+                self.beta_ = bbuf.to_host((n, K))
+                self.proportions_ = pbuf.to_host((n, K))
+        finally:
+            for b in owned:
+                b.free()
+
+        log(f"  Average neighbors per spot: {info.nnz / max(n, 1):.1f}")
+        self.lambda_used_ = float(info.lambda_used)
+        log(f"Step 5: {'Auto-tuned' if prm.lambda_auto else 'Using'} lambda = {self.lambda_used_:.4f}")
+        log("Step 6: Solving via Block Coordinate Descent...")
+        n_it = int(info.solve.n_iterations)
+        objectives = [float(v) for v in objs[:info.solve.n_objectives]]
+        if self.verbose:
+            its = [t for t in range(n_it) if t % 10 == 0 or t == self.max_iter - 1]
+            for t, obj in zip(its, objectives):
+                print(f"Iteration {t}: objective = {obj:.6f}, rel_change = {rels[t]:.6e}")
+            if info.solve.converged:
+                print(f"Converged at iteration {n_it - 1}")
+        self.info_ = {
+            "converged": bool(info.solve.converged),
+            "n_iterations": n_it,
+            "final_objective": float(info.solve.final_objective),
+            "objectives": objectives if self.verbose else [],
+            "final_change": float(info.solve.final_change),
+        }
+        # additive diagnostics (not in the reference): per-stage GPU milliseconds
+        self.timings_ = {k: float(getattr(info, k)) for k in ("graph_ms", "sketch_ms", "gram_ms", "solve_ms", "finish_ms", "total_ms")}
+        self.timings_["sweep_ms"] = float(info.solve.sweep_ms)
+        self._fitted = True
+        log(f"  Converged: {self.info_['converged']}")
+        log(f"  Iterations: {self.info_['n_iterations']}")
+        log("FlashDeconv: Done!")
+        return self
+
+    def fit_transform(self, Y, X, coords, **kwargs):
+        self.fit(Y, X, coords, **kwargs)
+        return self.proportions_
+
+    # ------------------------------------------------------------------ getters (core/deconv.py:436-512)
+    def _require_fitted(self):
+        if not self._fitted:
+            raise RuntimeError("Model has not been fitted. Call fit() first.")
+
+    def get_cell_type_proportions(self):
+        self._require_fitted()
+        return self.proportions_
+
+    def get_abundances(self):
+        self._require_fitted()
+        return self.beta_
+
+    def get_dominant_cell_type(self):
+        self._require_fitted()
+        if hasattr(self.proportions_, "argmax") and not isinstance(self.proportions_, np.ndarray):
+            return self.proportions_.argmax(dim=1)
+        return np.argmax(self.proportions_, axis=1)
+
+    def summary(self):
+        if not self._fitted:
+            return {"fitted": False}
+        return {
+            "fitted": True,
+            "n_spots": self.n_spots_,
+            "n_cell_types": self.n_cell_types_,
+            "n_genes_used": len(self.gene_idx_),
+            "sketch_dim": self.sketch_dim,
+            "lambda_spatial": self.lambda_used_,
+            "rho_sparsity": self.rho_sparsity,
+            "preprocess_method": self.preprocess,
+            "converged": self.info_["converged"],
+            "n_iterations": self.info_["n_iterations"],
+            "final_objective": self.info_["final_objective"],
+        }
+
+    def __repr__(self):
+        status = "fitted" if self._fitted else "not fitted"
+        return f"FlashDeconv(sketch_dim={self.sketch_dim}, lambda_spatial={self.lambda_spatial}, status={status})"

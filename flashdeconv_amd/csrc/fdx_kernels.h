@@ -67,3 +67,9 @@ int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scra
 int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, int it, hipStream_t st);
 
 }  // namespace fdx
+
+namespace fdx {
+// ---- leverage_kernels.cpp
+int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
+                    hipStream_t st);
+}  // namespace fdx

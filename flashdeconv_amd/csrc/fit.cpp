@@ -1,0 +1,236 @@
+// Device-resident fit pipeline: steps 2-6 of FlashDeconv.fit (flashdeconv/core/deconv.py:326-398) behind one C call.
+//   graph (utils/graph.py) -> X_sketch, XtX -> Y_sketch chunks -> H, YtY -> lambda (core/spatial.py:144-192)
+//   -> BCD solve (core/solver.py:287-428) -> beta / proportions in the caller's spot order (core/solver.py:431-452).
+// Everything between "Y, coords resident in HBM" and "beta_, proportions_ resident in HBM" stays on the device; the
+// host only sees a handful of scalars (bounding box, XtX, rel_change trace).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "fdx_graph.h"
+#include "fdx_internal.h"
+#include "fdx_kernels.h"
+#include "graph_build.h"
+#include "sketch_plan.h"
+#include "solver.h"
+
+using namespace fdx;
+
+namespace {
+
+struct StageTimer {
+    hipStream_t st;
+    hipEvent_t ev[8];
+    int n = 0;
+    explicit StageTimer(hipStream_t s) : st(s) {
+        for (auto& e : ev) (void)hipEventCreate(&e);
+    }
+    ~StageTimer() {
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    void mark() { if (n < 8) (void)hipEventRecord(ev[n++], st); }
+    double ms(int a, int b) {
+        float t = 0.f;
+        if (a < n && b < n) (void)hipEventElapsedTime(&t, ev[a], ev[b]);
+        return t;
+    }
+};
+
+int build_csc_from_tables(const int32_t* bucket, const double* weight, int G, int d, std::vector<long long>* col_ptr,
+                          std::vector<int>* gene_idx, std::vector<double>* w) {
+    col_ptr->assign((size_t)d + 1, 0);
+    for (int g = 0; g < G; ++g) {
+        FDX_REQUIRE(bucket[g] >= 0 && bucket[g] < d, "fit: bucket index out of range");
+        (*col_ptr)[(size_t)bucket[g] + 1]++;
+    }
+    for (int c = 0; c < d; ++c) (*col_ptr)[(size_t)c + 1] += (*col_ptr)[(size_t)c];
+    gene_idx->assign((size_t)G, 0);
+    w->assign((size_t)G, 0.0);
+    std::vector<long long> cur(col_ptr->begin(), col_ptr->end() - 1);
+    for (int g = 0; g < G; ++g) {   // ascending gene order inside every bucket
+        const long long e = cur[(size_t)bucket[g]]++;
+        (*gene_idx)[(size_t)e] = g;
+        (*w)[(size_t)e] = weight[g];
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int fdx_leverage_scores(const double* X, int32_t K, int32_t G, double regularization, double* lev_out) {
+    FDX_REQUIRE(X && lev_out && K > 0 && G > 0, "fdx_leverage_scores: bad arguments");
+    hipStream_t st = nullptr;
+    DevBuf dX, dW, dS, dL;
+    FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
+    FDX_TRY(dW.alloc((size_t)K * G * sizeof(double)));
+    FDX_TRY(dS.alloc((size_t)K * sizeof(double)));
+    FDX_TRY(dL.alloc((size_t)G * sizeof(double)));
+    FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_TRY(launch_leverage(dX.as<double>(), K, G, regularization, dW.as<double>(), dS.as<double>(), dL.as<double>(), nullptr, st));
+    FDX_HIP(hipMemcpyAsync(lev_out, dL.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int fdx_column_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy,
+                                   double* sums_out_host, void* stream) {
+    FDX_REQUIRE(dtype == FDX_F32 || dtype == FDX_F64, "fdx_column_sums_dev: dtype must be FDX_F32 or FDX_F64");
+    FDX_REQUIRE(n >= 0 && G > 0 && sums_out_host && (n == 0 || Y_dev), "fdx_column_sums_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf dPart, dOut;
+    FDX_TRY(dPart.alloc((size_t)column_sums_parts(n) * G * sizeof(double)));
+    FDX_TRY(dOut.alloc((size_t)G * sizeof(double)));
+    FDX_TRY(launch_column_sums(Y_dev, dtype, ldy, n, G, dPart.as<double>(), dOut.as<double>(), st));
+    FDX_HIP(hipMemcpyAsync(sums_out_host, dOut.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_t ldy, const double* X, int32_t K,
+                           const int32_t* bucket, const double* weight_y, const double* weight_x, const double* coords_dev,
+                           int32_t dim, const fdx_fit_params* prm, fdx_graph** graph_inout, double* beta_out_dev,
+                           double* prop_out_dev, double* objectives_out, double* rel_changes_out, fdx_fit_info* info,
+                           void* stream) {
+    FDX_REQUIRE(info != nullptr && prm != nullptr && graph_inout != nullptr, "fdx_fit_dev: null argument");
+    std::memset(info, 0, sizeof(*info));
+    FDX_REQUIRE(y_dtype == FDX_F32 || y_dtype == FDX_F64, "fdx_fit_dev: Y dtype must be FDX_F32 or FDX_F64");
+    FDX_REQUIRE(n > 0 && G > 0 && K > 0, "fdx_fit_dev: empty problem");
+    FDX_REQUIRE(n < 0x7fffff00LL, "fdx_fit_dev: n too large for one device");
+    FDX_REQUIRE(ldy >= G, "fdx_fit_dev: ldy < G");
+    FDX_REQUIRE(Y_dev && X && bucket && weight_y && weight_x, "fdx_fit_dev: null array");
+    const int d = prm->sketch_dim;
+    FDX_REQUIRE(d > 0, "fdx_fit_dev: sketch_dim must be positive");
+    FDX_REQUIRE(prm->max_iter >= 0, "fdx_fit_dev: max_iter must be non-negative");
+    hipStream_t st = (hipStream_t)stream;
+    StageTimer tm(st);
+    tm.mark();  // 0
+
+    // ---- spatial graph (core/deconv.py:358)
+    fdx_graph* g = nullptr;
+    if (prm->graph_method == FDX_GRAPH_GIVEN) {
+        g = *graph_inout;
+        FDX_REQUIRE(g != nullptr && g->n == n, "fdx_fit_dev: given graph does not match n");
+    } else {
+        FDX_REQUIRE(coords_dev != nullptr, "fdx_fit_dev: null coords");
+        g = new fdx_graph();
+        int rc = (prm->graph_method == FDX_GRAPH_KNN)
+                     ? graph_build_knn(coords_dev, n, dim, prm->k_neighbors, g, st)
+                     : graph_build_radius(coords_dev, n, dim, prm->radius, g, st);
+        if (rc) { delete g; return rc; }
+        *graph_inout = g;
+    }
+    tm.mark();  // 1
+
+    // ---- sketch plans (Omega tables come from the host: hash/sign from numpy's RandomState, core/sketching.py:58-59)
+    std::vector<long long> col_ptr;
+    std::vector<int> gene_idx;
+    std::vector<double> wy, wx;
+    FDX_TRY(build_csc_from_tables(bucket, weight_y, G, d, &col_ptr, &gene_idx, &wy));
+    SketchPlan plan_y, plan_x;
+    FDX_TRY(plan_y.build(col_ptr.data(), gene_idx.data(), wy.data(), G, d, st));
+    {
+        std::vector<long long> cp2;
+        std::vector<int> gi2;
+        FDX_TRY(build_csc_from_tables(bucket, weight_x, G, d, &cp2, &gi2, &wx));
+        FDX_TRY(plan_x.build(cp2.data(), gi2.data(), wx.data(), G, d, st));
+    }
+
+    // ---- X_sketch (K, d) and XtX (core/sketching.py:202-204, core/solver.py:346)
+    const long long ld = round_up(n + 1, 64);
+    DevBuf dX, dXs, dG, dH, dB0, dB1, dYs, dRowSq, dSum;
+    FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
+    FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
+    FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
+    FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, prm->mode_x, plan_x.dev(), dXs.as<double>(), d, nullptr, st));
+    FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, st));
+
+    // ---- Y_sketch in solver order, chunked, contracted into H (K, ld) as it is produced
+    FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dB0.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
+    FDX_TRY(dSum.alloc(sizeof(double)));
+    const long long chunk = std::min<long long>(n, 1LL << 18);
+    FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
+    FDX_HIP(hipMemsetAsync(dH.p, 0, dH.bytes, st));
+    const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();
+    double sketch_ms = 0.0, gram_ms = 0.0;
+    {
+        hipEvent_t a, b, c;
+        FDX_HIP(hipEventCreate(&a)); FDX_HIP(hipEventCreate(&b)); FDX_HIP(hipEventCreate(&c));
+        for (long long r0 = 0; r0 < n; r0 += chunk) {
+            const long long nr = std::min(chunk, n - r0);
+            FDX_HIP(hipEventRecord(a, st));
+            // with a row map the chunk gathers rows perm[r0..]; without one it reads rows r0.. of Y directly
+            const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
+            if (!row_map) ybase += (size_t)r0 * (size_t)ldy * (y_dtype == FDX_F32 ? 4 : 8);
+            FDX_TRY(launch_sketch_rows(ybase, y_dtype, ldy, row_map ? row_map + r0 : nullptr, nr, G, d, prm->mode_y,
+                                       plan_y.dev(), dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
+            FDX_HIP(hipEventRecord(b, st));
+            FDX_TRY(launch_xyt(dXs.as<double>(), dYs.as<double>(), d, nr, d, K, dH.as<double>() + r0, ld, nullptr, st));
+            FDX_HIP(hipEventRecord(c, st));
+            FDX_HIP(hipEventSynchronize(c));
+            float t1 = 0.f, t2 = 0.f;
+            (void)hipEventElapsedTime(&t1, a, b);
+            (void)hipEventElapsedTime(&t2, b, c);
+            sketch_ms += t1;
+            gram_ms += t2;
+        }
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c);
+    }
+    FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));   // YtY (core/solver.py:348)
+    std::vector<double> Gh((size_t)K * K);
+    double YtY = 0.0;
+    FDX_HIP(hipMemcpyAsync(Gh.data(), dG.p, Gh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipMemcpyAsync(&YtY, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    tm.mark();  // 2
+    double diag_mean = 0.0;
+    for (int k = 0; k < K; ++k) diag_mean += Gh[(size_t)k * K + k];
+    diag_mean /= (double)K;
+    // auto_tune_lambda (core/spatial.py:181-190): alpha * mean(diag XtX) / max(mean degree, 1), alpha = 0.005
+    double lambda = prm->lambda_spatial;
+    if (prm->lambda_auto) {
+        const double mean_deg = (double)g->nnz / (double)n;
+        lambda = 0.005 * diag_mean / std::max(mean_deg, 1.0);
+    }
+
+    // ---- solve
+    SolveProblem p;
+    p.graph = g; p.H = dH.as<double>(); p.ldh = ld; p.XtX = dG.as<double>();
+    p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = K; p.YtY = YtY;
+    p.lambda = lambda; p.rho_eff = prm->rho_sparsity * diag_mean; p.max_iter = prm->max_iter; p.tol = prm->tol;
+    p.verbose = prm->verbose;
+    SolveResult r;
+    FDX_TRY(solver_run(p, &r, st));
+    tm.mark();  // 3
+    if (beta_out_dev || prop_out_dev)
+        FDX_TRY(launch_normalize_export(p.beta[r.result_buffer], ld, row_map, (int)n, g->n_slices, K, beta_out_dev,
+                                        prop_out_dev, st));
+    tm.mark();  // 4
+    FDX_HIP(hipStreamSynchronize(st));
+
+    info->solve.converged = r.converged;
+    info->solve.n_iterations = r.n_iterations;
+    info->solve.final_objective = r.final_objective;
+    info->solve.final_change = r.final_change;
+    info->solve.n_objectives = (int32_t)r.objectives.size();
+    info->solve.sweep_ms = r.sweep_ms;
+    info->lambda_used = lambda;
+    info->rho_effective = p.rho_eff;
+    info->YtY = YtY;
+    info->nnz = g->nnz;
+    info->graph_ms = tm.ms(0, 1);
+    info->sketch_ms = sketch_ms;
+    info->gram_ms = gram_ms;
+    info->solve_ms = tm.ms(2, 3);
+    info->finish_ms = tm.ms(3, 4);
+    info->total_ms = tm.ms(0, 4);
+    info->solve.total_ms = info->total_ms;
+    if (objectives_out)
+        for (size_t t = 0; t < r.objectives.size(); ++t) objectives_out[t] = r.objectives[t];
+    if (rel_changes_out)
+        for (size_t t = 0; t < r.rel_changes.size(); ++t) rel_changes_out[t] = r.rel_changes[t];
+    return 0;
+}

@@ -1,0 +1,121 @@
+// Leverage scores of the genes from the SVD of the centred reference signatures.
+//
+// Replaces flashdeconv/utils/genes.py:238-290 (compute_leverage_scores):
+//   Xc = X - mean over cell types (:264);  Xc^T = U diag(s) V^T  (:270, LAPACK gesdd in the reference);
+//   w_j = s_j^2 / (s_j^2 + reg) (:281);  lev_g = sum_j U[g,j]^2 w_j (:285);  lev /= (sum lev + reg) (:288).
+//
+// The SVD is a one-sided (Hestenes) Jacobi on the tall G x K matrix A = Xc^T: pairs of columns are rotated until
+// all are mutually orthogonal; then s_j = ||a_j|| and U[:,j] = a_j / s_j, so
+//   lev_g = sum_j a_gj^2 / (s_j^2 + reg)
+// needs no division by a (possibly zero) singular value: the direction that centring annihilates contributes
+// exactly like LAPACK's ~1e-16 singular value does, i.e. nothing.  Working on the tall matrix (not on the K x K
+// Gram matrix) keeps small singular values accurate to machine precision.
+//
+// Mapping: one workgroup of 16 wavefronts.  Columns of A are ROWS of Xc (contiguous, G doubles).  A round-robin
+// tournament gives K/2 disjoint column pairs per round; each wave owns one pair, streams both columns from L2 with
+// coalesced loads, reduces the three inner products with wave shuffles and applies the rotation.  Rounds are
+// separated by workgroup barriers.  The reference matrix is tiny (K x G doubles), so this kernel is latency-, not
+// bandwidth-bound; it runs once per fit.
+#include "fdx_internal.h"
+#include "fdx_kernels.h"
+
+namespace fdx {
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __restrict__ X, int K, int G, double reg,
+                                                               double* __restrict__ A /* (K, G) work */,
+                                                               double* __restrict__ sig2 /* (K) */,
+                                                               double* __restrict__ lev /* (G) */,
+                                                               int* __restrict__ sweeps_out) {
+    __shared__ int s_rot;
+    __shared__ double s_red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // centre over cell types (genes.py:264)
+    for (int g = tid; g < G; g += 1024) {
+        double m = 0.0;
+        for (int k = 0; k < K; ++k) m += X[(size_t)k * G + g];
+        m /= (double)K;
+        for (int k = 0; k < K; ++k) A[(size_t)k * G + g] = X[(size_t)k * G + g] - m;
+    }
+    __syncthreads();
+    const int Kp = (K + 1) & ~1;          // even number of players (one dummy if K is odd)
+    const int n_pairs = Kp / 2, n_rounds = Kp - 1;
+    int sweep = 0;
+    for (; sweep < 60; ++sweep) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int r = 0; r < n_rounds; ++r) {
+            for (int m = wave; m < n_pairs; m += 16) {
+                int p, q;
+                if (m == 0) { p = Kp - 1; q = r; }
+                else { p = (r + m) % (Kp - 1); q = (r - m + (Kp - 1)) % (Kp - 1); }
+                if (p >= K || q >= K) continue;     // pair with the dummy player
+                if (p > q) { const int t = p; p = q; q = t; }
+                double* ap = A + (size_t)p * G;
+                double* aq = A + (size_t)q * G;
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int g = lane; g < G; g += 64) {
+                    const double x = ap[g], y = aq[g];
+                    alpha = fma(x, x, alpha);
+                    beta = fma(y, y, beta);
+                    gamma = fma(x, y, gamma);
+                }
+                alpha = wsum(alpha); beta = wsum(beta); gamma = wsum(gamma);
+                if (fabs(gamma) > 1e-15 * sqrt(alpha * beta) && gamma != 0.0) {
+                    const double zeta = (beta - alpha) / (2.0 * gamma);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                    for (int g = lane; g < G; g += 64) {
+                        const double x = ap[g], y = aq[g];
+                        ap[g] = c * x - s * y;
+                        aq[g] = s * x + c * y;
+                    }
+                    if (lane == 0) s_rot = 1;   // benign race: every writer stores 1
+                }
+            }
+            __syncthreads();
+        }
+        const int any = s_rot;
+        __syncthreads();
+        if (!any) break;
+    }
+    // squared singular values
+    for (int j = wave; j < K; j += 16) {
+        double a2 = 0.0;
+        for (int g = lane; g < G; g += 64) { const double x = A[(size_t)j * G + g]; a2 = fma(x, x, a2); }
+        a2 = wsum(a2);
+        if (lane == 0) sig2[j] = a2;
+    }
+    __syncthreads();
+    // lev_g = sum_j a_gj^2 / (s_j^2 + reg)   (genes.py:281-285), then normalise (genes.py:288)
+    double part = 0.0;
+    for (int g = tid; g < G; g += 1024) {
+        double l = 0.0;
+        for (int j = 0; j < K; ++j) { const double x = A[(size_t)j * G + g]; l += x * x / (sig2[j] + reg); }
+        lev[g] = l;
+        part += l;
+    }
+    part = wsum(part);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    double total = 0.0;
+    for (int w = 0; w < 16; ++w) total += s_red[w];
+    for (int g = tid; g < G; g += 1024) lev[g] = lev[g] / (total + reg);
+    if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+}
+
+// X: device (K, G) row-major; work: device K*G doubles; sig2: device K doubles; lev: device G doubles
+int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
+                    hipStream_t st) {
+    if (K <= 0 || G <= 0) return fail(FDX_ERR_INVALID, "leverage: empty reference matrix");
+    hipLaunchKernelGGL(leverage_jacobi_kernel, dim3(1), dim3(1024), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace fdx

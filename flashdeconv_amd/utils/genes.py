@@ -1,0 +1,97 @@
+"""Gene selection and leverage scores: the reference's ``flashdeconv/utils/genes.py`` interface.
+
+    compute_leverage_scores   <- utils/genes.py:238-290  (GPU: one-sided Jacobi SVD, csrc/leverage_kernels.cpp)
+    select_markers            <- utils/genes.py:148-235  (host: K x G table logic, method="diff")
+    select_hvg                <- utils/genes.py:18-145   (per-gene moments on the GPU, binning of the G-vector on the host)
+    select_informative_genes  <- utils/genes.py:293-341
+"""
+import numpy as np
+from scipy import sparse
+
+from .. import _lib
+
+
+def compute_leverage_scores(X, regularization=1e-6):
+    X = _lib.as_f64(X)
+    K, G = X.shape
+    lev = np.empty(G, dtype=np.float64)
+    _lib.require_gpu()
+    _lib.check(_lib.load().fdx_leverage_scores(_lib.ptr_f64(X), K, G, float(regularization), _lib.ptr_f64(lev)))
+    return lev
+
+
+def select_markers(X, n_markers=50, method="diff"):
+    """Union over cell types of the ``n_markers`` most specific genes (max minus second max of the
+    row-normalised signatures); returns (marker_idx, marker_assignments) like the reference."""
+    X = np.asarray(X, dtype=np.float64)
+    K, G = X.shape
+    if n_markers < 0:
+        raise ValueError(f"n_markers must be non-negative, got {n_markers}")
+    if n_markers == 0 or K == 0:
+        return np.array([], dtype=np.intp), np.array([], dtype=np.intp)
+    if method != "diff":
+        raise NotImplementedError("only method='diff' (the one FlashDeconv.fit uses) is provided")
+    frac = X / (X.sum(axis=1, keepdims=True) + 1e-10)
+    if K == 1:
+        idx = np.arange(min(n_markers, G))
+        return idx, np.zeros(len(idx), dtype=np.intp)
+    ranked = np.sort(frac, axis=0)
+    specificity = ranked[-1] - ranked[-2]
+    owner = np.argmax(frac, axis=0)
+    chosen, assign = [], []
+    for k in range(K):
+        mine = np.flatnonzero(owner == k)
+        if mine.size:
+            pick = mine[np.argsort(specificity[mine])[::-1][:n_markers]]
+        else:
+            pick = np.argsort(frac[k])[::-1][:n_markers]
+        chosen.extend(pick.tolist())
+        assign.extend([k] * len(pick))
+    return np.unique(chosen), np.array(assign)
+
+
+def _gene_moments(Y):
+    """Per-gene mean and ddof-1 variance of log1p(CPM-10k) over spots (utils/genes.py:52-102)."""
+    raise NotImplementedError(
+        "highly-variable-gene statistics (needed when the matrix has more genes than n_hvg) are not built yet; "
+        "pass a matrix with at most n_hvg genes or raise n_hvg")
+
+
+def select_hvg(Y, n_top=2000, min_mean=0.0125, max_mean=3.0, min_disp=0.5):
+    n_genes = Y.shape[1]
+    if n_genes <= n_top:
+        # Fewer genes than requested: every branch of the reference (utils/genes.py:135-145) returns all of them.
+        return np.arange(n_genes)
+    mean, var = _gene_moments(Y)
+    return _hvg_from_moments(mean, var, n_top, min_mean, max_mean, min_disp)
+
+
+def _hvg_from_moments(mean, var, n_top, min_mean, max_mean, min_disp):
+    """Seurat-v3-style binned z-score of the variance, then top-n (utils/genes.py:104-145)."""
+    G = len(mean)
+    disp = np.zeros(G)
+    pos = mean[mean > 0]
+    if len(pos) >= 2:
+        edges = np.unique(np.percentile(pos, np.linspace(0, 100, 21)))
+        if len(edges) >= 2:
+            which = np.clip(np.digitize(mean, edges) - 1, 0, len(edges) - 2)
+            for b in range(len(edges) - 1):
+                m = which == b
+                if m.sum() > 1:
+                    v = var[m]
+                    disp[m] = (v - v.mean()) / (v.std() + 1e-10)
+    ok = np.flatnonzero((mean >= min_mean) & (mean <= max_mean) & (disp >= min_disp))
+    if len(ok) < n_top:
+        pick = np.argsort(disp)[::-1][:n_top]
+    else:
+        pick = ok[np.argsort(disp[ok])[::-1][:n_top]]
+    return np.sort(pick)
+
+
+def select_informative_genes(Y, X, n_hvg=2000, n_markers_per_type=50):
+    hvg = select_hvg(Y, n_top=n_hvg)
+    markers, _ = select_markers(X, n_markers=n_markers_per_type)
+    gene_idx = np.union1d(hvg, markers).astype(np.intp)
+    if len(gene_idx) == 0:
+        raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
+    return gene_idx, compute_leverage_scores(np.asarray(X)[:, gene_idx])

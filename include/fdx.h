@@ -67,6 +67,15 @@ int fdx_sketch(const void* Y, int32_t dtype, int64_t n, int32_t G, const int64_t
 /* Per-gene column sums of a host (n, G) matrix (pearson's mean: core/deconv.py:207-214). */
 int fdx_column_sums(const void* Y, int32_t dtype, int64_t n, int32_t G, double* sums_out);
 
+/* Same column sums for a matrix already resident on the device (ld = row stride in elements). */
+int fdx_column_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy, double* sums_out_host,
+                        void* stream);
+
+/* ---- leverage scores (replaces utils/genes.py:238-290 compute_leverage_scores) ------------------------ */
+/* X is the HOST (K, G) row-major reference signature matrix restricted to the selected genes; lev_out (G) receives
+ * the normalised leverage scores.  One-sided Jacobi SVD of the centred G x K matrix on the device. */
+int fdx_leverage_scores(const double* X, int32_t K, int32_t G, double regularization, double* lev_out);
+
 /* ---- spatial graph (replaces utils/graph.py:25-212 and the CSR handling of core/solver.py:363-365) ---- */
 typedef struct fdx_graph fdx_graph;
 
@@ -111,6 +120,47 @@ typedef struct fdx_solve_info {
 int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sketch, int64_t n, int32_t d,
                   int32_t K, double lambda, double rho, int32_t max_iter, double tol, int32_t verbose,
                   double* beta_out, double* objectives_out, double* rel_changes_out, fdx_solve_info* info);
+
+/* ---- whole fit (replaces steps 2-6 of FlashDeconv.fit, core/deconv.py:326-398) -------------------------- */
+#define FDX_GRAPH_KNN 0
+#define FDX_GRAPH_RADIUS 1
+#define FDX_GRAPH_GIVEN 2   /* use the fdx_graph passed in */
+
+typedef struct fdx_fit_params {
+    int32_t sketch_dim;      /* d */
+    int32_t mode_y;          /* FDX_PRE_* applied to Y rows */
+    int32_t mode_x;          /* FDX_PRE_RAW or FDX_PRE_LOG_CPM applied to X rows (X always uses the dense rule) */
+    int32_t graph_method;    /* FDX_GRAPH_* */
+    int32_t k_neighbors;
+    int32_t lambda_auto;     /* 1: lambda = 0.005*mean(diag XtX)/max(mean degree,1)  (core/spatial.py:144-192) */
+    int32_t max_iter;
+    int32_t verbose;
+    double radius;
+    double lambda_spatial;   /* used when lambda_auto == 0 */
+    double rho_sparsity;     /* user-facing fraction, scaled by mean(diag XtX) inside */
+    double tol;
+} fdx_fit_params;
+
+typedef struct fdx_fit_info {
+    fdx_solve_info solve;
+    double lambda_used;
+    double rho_effective;
+    double YtY;
+    int64_t nnz;             /* structural non-zeros of the adjacency */
+    double graph_ms, sketch_ms, gram_ms, solve_ms, finish_ms, total_ms;   /* hipEvent stage timings */
+} fdx_fit_info;
+
+/* Device-resident fit.  Y_dev: (n, G) matrix of `y_dtype` on the device, row stride ldy elements.  X: HOST (K, G)
+ * f64 raw signatures (selected genes).  Omega as per-gene tables on the HOST: bucket int32[G] and the two weight
+ * vectors weight_y / weight_x f64[G] (they differ only for "pearson", where each carries its own 1/sigma_g).
+ * coords_dev: (n, dim) f64 on the device (ignored for FDX_GRAPH_GIVEN).  graph_inout: in for FDX_GRAPH_GIVEN,
+ * otherwise receives the graph built here (caller destroys it).  beta_out_dev / prop_out_dev: (n, K) row-major f64
+ * on the device in the caller's spot order (either may be NULL).  objectives_out / rel_changes_out: HOST arrays of
+ * max_iter doubles (may be NULL).  Synchronous: results are complete on return. */
+int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_t ldy, const double* X, int32_t K,
+                const int32_t* bucket, const double* weight_y, const double* weight_x, const double* coords_dev,
+                int32_t dim, const fdx_fit_params* params, fdx_graph** graph_inout, double* beta_out_dev,
+                double* prop_out_dev, double* objectives_out, double* rel_changes_out, fdx_fit_info* info, void* stream);
 
 #ifdef __cplusplus
 }

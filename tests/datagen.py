@@ -12,8 +12,7 @@ Families:
   * ``count_like``    - count data shaped like the reference's integration-test
     generator (reference tests/test_integration.py:10-84): log-normal signatures
     with 20 x5 markers per type, jittered grid coords, smooth true proportions,
-    gamma depth, Poisson counts.  Same RandomState call order, so at the
-    reference's sizes it reproduces the reference's test inputs exactly.
+    gamma depth, Poisson counts, drawn in the same RandomState call order.
   * ``sketched_problem`` - direct (Y_sketch, X_sketch, coords) problems shaped
     like reference tests/test_solver.py:66-89 and :298-310.
 """
@@ -32,12 +31,21 @@ def sha256_arrays(*arrays):
     return h.hexdigest()
 
 
+def mix(B, X):
+    """B @ X accumulated one cell type at a time with elementwise numpy ops.  BLAS matmul rounds differently on
+    different CPUs; this form is bit-identical everywhere, so input SHA-256s stay valid on the GPU box."""
+    out = np.zeros((B.shape[0], X.shape[1]))
+    for k in range(B.shape[1]):
+        out += B[:, k:k + 1] * X[k][None, :]
+    return out
+
+
 def gaussian_raw(n_spots, n_genes, n_types, seed=0, noise=0.1):
     rs = np.random.RandomState(seed)
     X = rs.randn(n_types, n_genes)
     B = rs.rand(n_spots, n_types)
     B /= B.sum(axis=1, keepdims=True)
-    Y = B @ X + noise * rs.randn(n_spots, n_genes)
+    Y = mix(B, X) + noise * rs.randn(n_spots, n_genes)
     coords = rs.rand(n_spots, 2) * np.sqrt(n_spots)
     return Y, X, coords, B
 
@@ -59,7 +67,7 @@ def count_like(n_spots=100, n_genes=500, n_types=5, noise_level=0.1, seed=42):
         dist = np.sqrt(np.sum((coords - centre) ** 2, axis=1))
         B[:, k] = np.exp(-dist / (side / 2))
     B = B / B.sum(axis=1, keepdims=True)
-    expected = B @ X
+    expected = mix(B, X)
     depth = rs.gamma(shape=5, scale=1000, size=n_spots)
     expected = expected * depth[:, np.newaxis]
     Y = rs.poisson(expected * (1 + noise_level * rs.rand(*expected.shape)))
@@ -71,6 +79,6 @@ def sketched_problem(n_spots, n_types, sketch_dim, seed=42, noise=0.1):
     Xs = rs.randn(n_types, sketch_dim)
     B = rs.rand(n_spots, n_types)
     B = B / B.sum(axis=1, keepdims=True)
-    Ys = B @ Xs + noise * rs.randn(n_spots, sketch_dim)
+    Ys = mix(B, Xs) + noise * rs.randn(n_spots, sketch_dim)
     coords = rs.rand(n_spots, 2)
     return Ys, Xs, coords, B

@@ -1,0 +1,132 @@
+"""-m gpu parity tests of the whole fit (FlashDeconv.fit_transform -> fdx_fit_dev) against golden vectors captured
+from the reference.  Tolerance of the contract: 1e-4 relative Frobenius on beta_ / proportions_ (BASELINE.json);
+the float64 kernels land around 1e-12, asserted here at 1e-8 so regressions show."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import datagen
+from conftest import load_golden, rel_fro
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def _check(model, g, tol=TOL):
+    assert np.array_equal(model.gene_idx_, g["gene_idx"])
+    A = model.adjacency_
+    assert np.array_equal(A.indptr, g["indptr"]) and np.array_equal(A.indices, g["indices"])
+    np.testing.assert_allclose(model.lambda_used_, float(g["lambda_used"]), rtol=1e-10)
+    assert model.info_["n_iterations"] == int(g["n_iterations"])
+    assert model.info_["converged"] == bool(g["converged"])
+    assert rel_fro(model.beta_, g["beta"]) < tol
+    assert rel_fro(model.proportions_, g["proportions"]) < tol
+    np.testing.assert_allclose(model.info_["final_objective"], float(g["final_objective"]), rtol=max(tol, 1e-9))
+    np.testing.assert_allclose(model.info_["final_change"], float(g["final_change"]), rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(model.proportions_.sum(axis=1), 1.0, rtol=1e-12)
+    assert np.all(model.beta_ >= 0)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_fit_counts_small_dense(d):
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden(f"fit_counts_100x500x5_d{d}.npz")
+    m = FlashDeconv(sketch_dim=d)
+    p = m.fit_transform(g["Y"].astype(np.int64), g["X"], g["coords"])
+    assert p is m.proportions_ and p.shape == (100, 5)
+    _check(m, g)
+    assert m.summary()["n_genes_used"] == 500 and m.get_dominant_cell_type().shape == (100,)
+
+
+def test_fit_counts_small_csr_and_f32():
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("fit_counts_100x500x5_d64_csr.npz")
+    m = FlashDeconv(sketch_dim=64).fit(sparse.csr_matrix(g["Y"].astype(np.float64)), g["X"], g["coords"])
+    _check(m, g)
+    # float32 input: numpy keeps the reference's log-CPM in float32, we compute in float64 -> ~1e-7 apart
+    g = load_golden("fit_counts_100x500x5_d64_f32.npz")
+    m = FlashDeconv(sketch_dim=64).fit(g["Y"].astype(np.float32), g["X"], g["coords"])
+    _check(m, g, tol=1e-5)
+
+
+@pytest.mark.parametrize("suffix", ["", "_csr"])
+def test_fit_pearson(suffix):
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden(f"fit_pearson_120x300x4{suffix}.npz")
+    Y = g["Y"].astype(np.int64)
+    if suffix:
+        Y = sparse.csr_matrix(Y.astype(np.float64))
+    m = FlashDeconv(sketch_dim=48, preprocess="pearson", max_iter=40).fit(Y, g["X"], g["coords"])
+    _check(m, g)
+
+
+def test_fit_gauss_1000_config1_miniature():
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("fit_gauss_1000x2000x10.npz")
+    Y, X, coords, _ = datagen.gaussian_raw(1000, 2000, 10, seed=0)
+    assert datagen.sha256_arrays(Y, X, coords) == str(g["input_sha256"])
+    m = FlashDeconv(sketch_dim=512, preprocess="raw").fit(Y, X, coords)
+    _check(m, g)
+
+
+def test_fit_gauss_800_fixed_lambda():
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("fit_gauss_800x2000x20.npz")
+    Y, X, coords, _ = datagen.gaussian_raw(800, 2000, 20, seed=1)
+    m = FlashDeconv(sketch_dim=512, preprocess="raw", lambda_spatial=0.5, rho_sparsity=0.02).fit(Y, X, coords)
+    _check(m, g)
+
+
+def test_fit_counts_1000_full_100_iterations():
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("fit_counts_1000x2000x10.npz")
+    Y, X, coords, _ = datagen.count_like(1000, 2000, 10, 0.1, 0)
+    m = FlashDeconv(sketch_dim=512).fit(Y, X, coords)
+    assert m.info_["n_iterations"] == 100 and not m.info_["converged"]
+    _check(m, g)
+
+
+def test_fit_counts_600_k30():
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("fit_counts_600x1000x30.npz")
+    Y, X, coords, _ = datagen.count_like(600, 1000, 30, 0.1, 3)
+    m = FlashDeconv(sketch_dim=256, max_iter=60).fit(Y, X, coords)
+    _check(m, g)
+
+
+def test_leverage_scores_vs_reference():
+    from flashdeconv_amd.utils.genes import compute_leverage_scores
+    g = load_golden("leverage.npz")
+    for name in g["names"]:
+        lev = compute_leverage_scores(g[f"{name}_X"])
+        np.testing.assert_allclose(lev, g[f"{name}_lev"], rtol=1e-9, atol=1e-14, err_msg=str(name))
+
+
+def test_seed_reproducibility_and_errors():
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("fit_counts_100x500x5_d64.npz")
+    Y, X, coords = g["Y"].astype(np.int64), g["X"], g["coords"]
+    a = FlashDeconv(sketch_dim=64, random_state=7).fit_transform(Y, X, coords)
+    b = FlashDeconv(sketch_dim=64, random_state=7).fit_transform(Y, X, coords)
+    assert np.array_equal(a, b)
+    with pytest.raises(ValueError, match="Gene dimension mismatch"):
+        FlashDeconv().fit(Y, X[:, :10], coords)
+    with pytest.raises(ValueError, match="Spot count mismatch"):
+        FlashDeconv().fit(Y, X, coords[:5])
+    with pytest.raises(ValueError, match="at least one cell type"):
+        FlashDeconv().fit(Y, X[:0], coords)
+    with pytest.raises(RuntimeError, match="not been fitted"):
+        FlashDeconv().get_cell_type_proportions()
+    with pytest.raises(ValueError, match="radius must be specified"):
+        FlashDeconv(spatial_method="radius")
+
+
+def test_radius_and_grid_methods_run():
+    # reference tests/test_integration.py:238-271
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("fit_counts_100x500x5_d64.npz")
+    Y, X, coords = g["Y"].astype(np.int64), g["X"], g["coords"]
+    for kw in (dict(spatial_method="radius", radius=1.5), dict(spatial_method="grid")):
+        m = FlashDeconv(sketch_dim=64, **kw).fit(Y, X, coords)
+        assert m.proportions_.shape == (100, 5) and np.allclose(m.proportions_.sum(axis=1), 1.0)
+        assert m.adjacency_.nnz > 0 and (m.adjacency_ != m.adjacency_.T).nnz == 0
