@@ -72,6 +72,7 @@ SIGNATURES = {
     "fdx_device_name": (c_int, [ctypes.c_char_p, c_int]),
     "fdx_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size_t]),
     "fdx_free": (c_int, [c_void_p]),
+    "fdx_trim": (c_int, []),
     "fdx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fdx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fdx_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),

@@ -26,6 +26,7 @@
 //   rel_change = max_diff / (max_abs_old + 1e-10) < tol                       (solver.py:395-397,409)
 // on the device, so a converged solve turns the already-queued sweeps into no-ops without a host round trip.
 #include "bcd_device.h"
+#include "fdx_graph.h"
 
 // This translation unit is compiled several times (csrc/Makefile) with -DFDX_PART=p -DFDX_K_LO=a -DFDX_K_HI=b so the
 // 64 register-resident instantiations build in parallel; each build exports bcd_sweep_dispatch_part<p>().
@@ -123,8 +124,125 @@ __global__ __launch_bounds__(256) void bcd_sweep_kernel(
     }
 }
 
+// LDS-tiled variant (graphs built from coordinates): a workgroup owns a TILE of 256 consecutive Morton-ordered spots.
+// Per chunk of KC cell types the tile's own old abundances (from registers) and its halo (the neighbour positions outside
+// the tile, one coalesced-ish global gather per halo spot and type) are staged in LDS, and all neighbour sums are then
+// served by ds_read_b64 from tile-local slots - ~0.5 global gathers per spot and type instead of ~11.  Arithmetic and
+// summation order are identical to bcd_sweep_kernel, so both variants produce the same bits.
+template <int K, int KC>
+__global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
+    const double* __restrict__ H, const double* __restrict__ XtX, const double* __restrict__ beta_in,
+    double* __restrict__ beta_out, const unsigned short* __restrict__ ell_local, const int* __restrict__ slice_off,
+    const int* __restrict__ deg, const int* __restrict__ tile_halo, const int* __restrict__ tile_hcnt,
+    unsigned long long* __restrict__ stats, double* __restrict__ rel_change, const double lambda, const double rho,
+    const double tol, const int ldh, const int ld_, const int n, const int S, const int it) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [KC][S]: 256 own | halo | zero slot
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    if (it > 0) {
+        const double rc = fold_rel_change(stats + (size_t)(it - 1) * 128, lane);
+        if (blockIdx.x == 0 && tid == 0) rel_change[it - 1] = rc;
+        if (rc < tol) return;          // uniform over the whole grid
+    }
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int i = min(tile * 256 + tid, n - 1);   // lanes past the last spot mirror spot n-1
+    const size_t ld = (size_t)ld_;
+    const int slice = __builtin_amdgcn_readfirstlane(i >> 6);
+    const int w0 = slice_off[slice];
+    const int w = slice_off[slice + 1] - w0;
+    const int Ht = tile_hcnt[tile];
+    const int* halo = tile_halo + (size_t)tile * FDX_TILE_HALO_CAP;
+
+    double b[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) b[k] = beta_in[k * ld + i];
+    const unsigned short* ell = ell_local + (size_t)w0 * 64 + (i & 63);
+    const int dg = deg[i];
+    const double lam_deg = lambda * (double)dg;
+    const double lam_eff = (dg > 0) ? lambda : 0.0;
+    const int hidx0 = (tid < Ht) ? halo[tid] : 0;
+
+    double dmax = 0.0, amax = 0.0;
+#pragma unroll
+    for (int kc = 0; kc < K; kc += KC) {
+        // ---- stage old values of this chunk: own from registers, halo from global
+#pragma unroll
+        for (int q = 0; q < KC; ++q)
+            if (kc + q < K) lds[q * S + tid] = b[kc + q];
+        if (tid < Ht) {
+#pragma unroll
+            for (int q = 0; q < KC; ++q)
+                if (kc + q < K) lds[q * S + 256 + tid] = beta_in[(kc + q) * ld + hidx0];
+        }
+        for (int h = tid + 256; h < Ht; h += 256) {
+            const int j = halo[h];
+#pragma unroll
+            for (int q = 0; q < KC; ++q)
+                if (kc + q < K) lds[q * S + 256 + h] = beta_in[(kc + q) * ld + j];
+        }
+        if (tid < KC) lds[tid * S + 256 + Ht] = 0.0;
+        __syncthreads();
+        double c[KC];
+#pragma unroll
+        for (int q = 0; q < KC; ++q) c[q] = 0.0;
+#pragma unroll 2
+        for (int m = 0; m < w; ++m) {
+            const int slot = ell[(size_t)m * 64];
+#pragma unroll
+            for (int q = 0; q < KC; ++q)
+                if (kc + q < K) c[q] += lds[q * S + slot];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KC; ++q) {
+            const int k = kc + q;
+            if (k < K) {
+                const double h = H[k * (size_t)ldh + i];
+                const double* g = XtX + k * K;
+                double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+                for (int j = 0; j + 1 < K; j += 2) {
+                    r0 = fma(g[j], b[j], r0);
+                    r1 = fma(g[j + 1], b[j + 1], r1);
+                }
+                if (K & 1) r0 = fma(g[K - 1], b[K - 1], r0);
+                const double gkk = g[k];
+                const double old = b[k];
+                const double res = (h - (r0 + r1) + gkk * old) + lam_eff * c[q];
+                const double den = gkk + lam_deg;
+                const double st = res > rho ? res - rho : (res < -rho ? res + rho : 0.0);
+                const double qv = fmax(0.0, st / den);
+                const double nw = (den > 1e-10) ? qv : 0.0;
+                dmax = fmax(dmax, fabs(nw - old));
+                amax = fmax(amax, fabs(old));
+                b[k] = nw;
+                beta_out[k * ld + i] = nw;
+            }
+        }
+    }
+    dmax = wave_max(dmax);
+    amax = wave_max(amax);
+    if (lane == 0) {
+        unsigned long long* s = stats + (size_t)it * 128;
+        const int slot = slice & 63;
+        atomicMax(s + slot, (unsigned long long)__double_as_longlong(dmax));
+        atomicMax(s + 64 + slot, (unsigned long long)__double_as_longlong(amax));
+    }
+}
+
 template <int K>
 static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
+    if (a.tiled) {
+        constexpr int KC = sweep_chunk(K);
+        const int S = 256 + a.halo_max + 1;
+        const size_t lds = (size_t)KC * S * sizeof(double);
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX, a.beta_in,
+                               a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt, a.stats,
+                               a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it);
+            return;
+        }
+    }
     const int nblk = ceil_div(a.n_slices, 4);
     hipLaunchKernelGGL((bcd_sweep_kernel<K, sweep_chunk(K)>), dim3(nblk), dim3(256), 0, st, a.H, a.XtX, a.beta_in,
                        a.beta_out, a.ell, a.slice_off, a.deg, a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh,

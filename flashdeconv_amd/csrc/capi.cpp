@@ -59,12 +59,18 @@ int fdx_device_name(char* buf, int buflen) {
 
 int fdx_malloc(void** dev_ptr, size_t bytes) {
     FDX_REQUIRE(dev_ptr != nullptr, "fdx_malloc: null output");
-    FDX_HIP(hipMalloc(dev_ptr, bytes ? bytes : 8));
+    size_t cap = 0;
+    FDX_TRY(pool_alloc(bytes ? bytes : 8, dev_ptr, &cap));   // served from the caching pool (pool.cpp)
     return 0;
 }
 
 int fdx_free(void* dev_ptr) {
-    if (dev_ptr) FDX_HIP(hipFree(dev_ptr));
+    if (dev_ptr) pool_free(dev_ptr, 0);
+    return 0;
+}
+
+int fdx_trim(void) {
+    pool_trim();
     return 0;
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include "fdx_internal.h"
 
+#define FDX_TILE_HALO_CAP 1024
+
 struct fdx_graph {
     long long n = 0;         // spots owned (updated) by this graph
     long long n_total = 0;   // owned + halo spots addressable by neighbour indices; the all-zero pad row is n_total
@@ -21,4 +23,12 @@ struct fdx_graph {
     // builders for export / sharding: row p is rows[p*row_stride + row_extra[p] .. + deg[p]).
     fdx::DevBuf rows, row_extra;
     int row_stride = 0;
+    // Workgroup tiles of the LDS-tiled BCD sweep (tile = 256 consecutive spots): tile_halo[t*FDX_TILE_HALO_CAP + h] is
+    // the h-th neighbour position outside tile t (ascending, tile_hcnt[t] entries); ell_local mirrors `ell` with
+    // tile-local slots (0..255 own, 256+h halo, 256+hcnt = all-zero pad).  `tiled` is false when some tile's halo does
+    // not fit (graphs without spatial locality); the sweep then gathers from global memory.
+    fdx::DevBuf tile_halo, tile_hcnt, ell_local;
+    int n_tiles = 0;
+    int halo_max = 0;
+    bool tiled = false;
 };

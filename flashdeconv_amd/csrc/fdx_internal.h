@@ -43,9 +43,17 @@ inline hipError_t last_launch_error() { return hipGetLastError(); }
 #define FDX_CHECK_LAUNCH() FDX_HIP(::fdx::last_launch_error())
 
 // ---- device scratch buffer (RAII) ---------------------------------------------------------------
+// Caching device allocator (pool.cpp): hipMalloc/hipFree cost 0.1-several ms and hipFree synchronises the device, so
+// scratch blocks are recycled through per-device free lists keyed by a rounded capacity.  A recycled block is only
+// ever handed to work queued later on the caller's stream, which orders it after the block's previous users.
+int pool_alloc(size_t bytes, void** p, size_t* cap);
+void pool_free(void* p, size_t cap);
+void pool_trim();   // return every cached block to the driver
+
 struct DevBuf {
     void* p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;   // requested size
+    size_t cap = 0;     // capacity class of the pooled block
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -53,26 +61,25 @@ struct DevBuf {
     int alloc(size_t n) {
         release();
         if (n == 0) n = 8;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) {
-            p = nullptr;
-            return fail(FDX_ERR_HIP, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
-        }
+        FDX_TRY(pool_alloc(n, &p, &cap));
         bytes = n;
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p, cap);
         p = nullptr;
         bytes = 0;
+        cap = 0;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
     void take(DevBuf& o) {   // move ownership
         release();
         p = o.p;
         bytes = o.bytes;
+        cap = o.cap;
         o.p = nullptr;
         o.bytes = 0;
+        o.cap = 0;
     }
 };
 

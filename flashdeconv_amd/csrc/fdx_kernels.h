@@ -20,6 +20,13 @@ struct BcdSweepArgs {
     const int* ell;          // sliced-ELL neighbour indices: ell[(slice_off[s] + m)*64 + lane]
     const int* slice_off;    // (n_slices+1) prefix sum of per-slice widths
     const int* deg;          // (n) structural neighbour count per spot
+    // LDS-tiled variant (see fdx_graph.h): used when `tiled` is set
+    const unsigned short* ell_local = nullptr;
+    const int* tile_halo = nullptr;
+    const int* tile_hcnt = nullptr;
+    int n_tiles = 0;
+    int halo_max = 0;
+    int tiled = 0;
     unsigned long long* stats;  // (max_iter, 2, 64) per-iteration max slots (bit patterns of doubles >= 0)
     double* rel_change;      // (max_iter) rel_change per iteration, written by the following kernel
     double lambda;

@@ -6,9 +6,9 @@
 // and hands the result to the solver in the sliced-ELL layout of fdx_graph.h.
 //
 // Pipeline (all on the stream, one small D2H for the bounding box):
-//   1. bounding box -> uniform grid with ~2 points per cell; cell id with the LONGEST axis slowest, so that contiguous
-//      ranges of the sorted order are slabs across the short side (2 halo peers per GPU when sharded).
-//   2. stable radix sort of (cell id, original index) (rocPRIM)  -> perm / rank; points inside a cell keep caller order.
+//   1. bounding box -> uniform grid with ~2 points per cell.
+//   2. stable radix sort of (Morton code of the cell, original index) (rocPRIM) -> perm / rank; points inside a cell
+//      keep caller order, and any 256 consecutive sorted points form a compact patch (small tile halo in the BCD sweep).
 //   3. exact k-NN: one lane per point scans the cells of growing Chebyshev shells until the k+1-th best squared distance
 //      is provably inside the scanned block.  Squared distances are evaluated in float64 WITHOUT fma contraction
 //      ((dx*dx + dy*dy) + dz*dz, each rounded) and ties are broken by the lower original index.
@@ -74,24 +74,55 @@ __device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int
     return max(0, min(nc - 1, c));
 }
 
+// Morton (Z-order) code of a cell: 256 consecutive points of the sorted order form a compact 2-D/3-D patch, which keeps
+// the halo of a 256-spot workgroup tile of the BCD sweep small (perimeter instead of two full grid rows).
+__host__ __device__ __forceinline__ unsigned long long spread_bits_2(unsigned long long v) {   // abcd -> 0a0b0c0d
+    v &= 0xffffffffULL;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffULL;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffULL;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | (v << 2)) & 0x3333333333333333ULL;
+    v = (v | (v << 1)) & 0x5555555555555555ULL;
+    return v;
+}
+__host__ __device__ __forceinline__ unsigned long long spread_bits_3(unsigned long long v) {   // 21 bits -> every third bit
+    v &= 0x1fffffULL;
+    v = (v | (v << 32)) & 0x1f00000000ffffULL;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffULL;
+    v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
+    v = (v | (v << 2)) & 0x1249249249249249ULL;
+    return v;
+}
+__device__ __forceinline__ unsigned long long morton_key(const int c[3], int dim) {
+    if (dim == 1) return (unsigned long long)c[0];
+    if (dim == 2) return spread_bits_2((unsigned)c[0]) | (spread_bits_2((unsigned)c[1]) << 1);
+    return spread_bits_3((unsigned)c[0]) | (spread_bits_3((unsigned)c[1]) << 1) | (spread_bits_3((unsigned)c[2]) << 2);
+}
+
 __global__ __launch_bounds__(256) void cell_key_kernel(const double* __restrict__ coords, long long n, GridParams gp,
-                                                       unsigned int* __restrict__ keys, int* __restrict__ vals) {
+                                                       unsigned long long* __restrict__ keys, int* __restrict__ vals) {
     const long long i = blockIdx.x * 256LL + threadIdx.x;
     if (i >= n) return;
-    int id = 0;
-    for (int a = 0; a < gp.dim; ++a)
-        id += cell_coord(coords[(size_t)i * gp.dim + a], gp.mn[a], gp.inv_h[a], gp.nc[a]) * gp.stride[a];
-    keys[i] = (unsigned int)id;
+    int c[3] = {0, 0, 0};
+    for (int a = 0; a < gp.dim; ++a) c[a] = cell_coord(coords[(size_t)i * gp.dim + a], gp.mn[a], gp.inv_h[a], gp.nc[a]);
+    keys[i] = morton_key(c, gp.dim);
     vals[i] = (int)i;
 }
 
-__global__ __launch_bounds__(256) void cell_range_kernel(const unsigned int* __restrict__ skeys, long long n,
+// cell table (row-major cell id -> [start, end) in the sorted order); equal Morton key <=> same cell
+__global__ __launch_bounds__(256) void cell_range_kernel(const unsigned long long* __restrict__ skeys,
+                                                         const double* __restrict__ sc, long long n, GridParams gp,
                                                          int* __restrict__ cstart, int* __restrict__ cend) {
     const long long p = blockIdx.x * 256LL + threadIdx.x;
     if (p >= n) return;
-    const unsigned int k = skeys[p];
-    if (p == 0 || skeys[p - 1] != k) cstart[k] = (int)p;
-    if (p == n - 1 || skeys[p + 1] != k) cend[k] = (int)p + 1;
+    const unsigned long long k = skeys[p];
+    const bool first = (p == 0 || skeys[p - 1] != k), last = (p == n - 1 || skeys[p + 1] != k);
+    if (!first && !last) return;
+    int id = 0;
+    for (int a = 0; a < gp.dim; ++a) id += cell_coord(sc[(size_t)a * n + p], gp.mn[a], gp.inv_h[a], gp.nc[a]) * gp.stride[a];
+    if (first) cstart[id] = (int)p;
+    if (last) cend[id] = (int)p + 1;
 }
 
 // sorted coordinate planes sc[a*n + p] and rank[perm[p]] = p
@@ -343,6 +374,87 @@ __global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long lon
     if (i < n) v[i] = (int)i;
 }
 
+// ------------------------------------------------------------------------------------------------ sweep tiles
+// A tile = 256 consecutive sorted spots = one workgroup of the tiled BCD sweep.  For every tile: the sorted, duplicate-
+// free list of neighbour positions OUTSIDE the tile (its halo), and every ELL entry of its rows translated to a
+// tile-local slot: 0..255 own spot, 256+h the h-th halo entry, 256+H the all-zero pad slot.
+constexpr int TILE_HASH = 2048;
+__global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ ws, int seg_stride,
+                                                        const int* __restrict__ seg_extra, const int* __restrict__ deg,
+                                                        const int* __restrict__ slice_off, long long n,
+                                                        int* __restrict__ tile_halo, int* __restrict__ tile_hcnt,
+                                                        unsigned short* __restrict__ ell_local) {
+    __shared__ int tab[TILE_HASH];
+    __shared__ int list[FDX_TILE_HALO_CAP];
+    __shared__ int s_cnt, s_over;
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    for (int s = tid; s < TILE_HASH; s += 256) tab[s] = -1;
+    if (tid == 0) { s_cnt = 0; s_over = 0; }
+    __syncthreads();
+    const long long p = (long long)tile * 256 + tid;
+    const int dg = (p < n) ? deg[p] : 0;
+    const int* seg = (p < n) ? ws + (size_t)p * seg_stride + seg_extra[p] : ws;
+    for (int m = 0; m < dg; ++m) {
+        const int q = seg[m];
+        if ((q >> 8) == tile) continue;
+        unsigned h = ((unsigned)q * 2654435761u) >> 21;   // 11 bits
+        int probes = 0;
+        while (true) {
+            const int old = atomicCAS(&tab[h], -1, q);
+            if (old == -1 || old == q) break;
+            h = (h + 1) & (TILE_HASH - 1);
+            if (++probes > TILE_HASH) { s_over = 1; break; }
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < TILE_HASH; s += 256)
+        if (tab[s] != -1) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < FDX_TILE_HALO_CAP) list[pos] = tab[s];
+        }
+    __syncthreads();
+    const int H = s_cnt;
+    if (H > FDX_TILE_HALO_CAP || s_over) {      // irregular graph: this tile cannot use the LDS path
+        if (tid == 0) tile_hcnt[tile] = -1;
+        return;
+    }
+    int P = 1;
+    while (P < H) P <<= 1;
+    for (int s = H + tid; s < P; s += 256) list[s] = 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = tid; idx < P; idx += 256) {
+                const int ixj = idx ^ j;
+                if (ixj > idx) {
+                    const int a = list[idx], b = list[ixj];
+                    const bool up = ((idx & k) == 0);
+                    if ((a > b) == up) { list[idx] = b; list[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int h = tid; h < H; h += 256) tile_halo[(size_t)tile * FDX_TILE_HALO_CAP + h] = list[h];
+    if (tid == 0) tile_hcnt[tile] = H;
+    if (p < n) {
+        const int s = (int)(p >> 6), lane = (int)(p & 63);
+        const int w0 = slice_off[s], w = slice_off[s + 1] - w0;
+        for (int m = 0; m < w; ++m) {
+            int slot = 256 + H;   // pad -> zero slot
+            if (m < dg) {
+                const int q = seg[m];
+                if ((q >> 8) == tile) slot = q & 255;
+                else {
+                    int lo = 0, hi = H;   // lower_bound in the sorted halo list
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (list[mid] < q) lo = mid + 1; else hi = mid; }
+                    slot = 256 + lo;
+                }
+            }
+            ell_local[((size_t)w0 + m) * 64 + lane] = (unsigned short)slot;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int exclusive_scan_int(const int* in, int* out, long long count, hipStream_t st, DevBuf& tmp) {
     size_t bytes = 0;
@@ -400,7 +512,9 @@ static int make_grid(const double* d_coords, long long n, int dim, double target
             cells *= nca;
             gp->nc[a] = (int)std::min(nca, 2.0e9);
         }
-        if (cells <= std::max(4.0 * (double)n, 4096.0) && cells < 2.0e9) break;
+        const int max_axis = std::max(gp->nc[0], std::max(gp->nc[1], gp->nc[2]));
+        const bool morton_ok = (dim < 3) || max_axis < (1 << 21);   // 21 bits per axis in the 3-D Morton key
+        if (cells <= std::max(4.0 * (double)n, 4096.0) && cells < 2.0e9 && morton_ok) break;
         h *= 1.5;   // very elongated / clustered inputs: coarsen until the table is O(N)
     }
     gp->dim = dim;
@@ -425,30 +539,34 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     FDX_TRY(make_grid(d_coords, n, dim, target_per_cell, min_h, &b->gp, st));
     b->n_cells = b->gp.nc[0] * b->gp.nc[1] * b->gp.nc[2];
     DevBuf keys, vals, skeys, tmp;
-    FDX_TRY(keys.alloc((size_t)n * 4));
+    FDX_TRY(keys.alloc((size_t)n * 8));
     FDX_TRY(vals.alloc((size_t)n * 4));
-    FDX_TRY(skeys.alloc((size_t)n * 4));
+    FDX_TRY(skeys.alloc((size_t)n * 8));
     FDX_TRY(b->perm.alloc((size_t)n * 4));
     FDX_TRY(b->rank.alloc((size_t)n * 4));
     FDX_TRY(b->sc.alloc((size_t)n * 3 * sizeof(double)));
     FDX_TRY(b->cstart.alloc((size_t)b->n_cells * 4));
     FDX_TRY(b->cend.alloc((size_t)b->n_cells * 4));
     const int nb = ceil_div(n, 256);
-    hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, st, d_coords, n, b->gp, keys.as<unsigned int>(), vals.as<int>());
+    typedef unsigned long long u64;
+    hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, st, d_coords, n, b->gp, keys.as<u64>(), vals.as<int>());
     FDX_CHECK_LAUNCH();
-    int bits = 1;
-    while ((1LL << bits) < (long long)b->n_cells && bits < 32) ++bits;
+    const int max_axis = std::max(b->gp.nc[0], std::max(b->gp.nc[1], b->gp.nc[2]));
+    int axis_bits = 1;
+    while ((1LL << axis_bits) < (long long)max_axis) ++axis_bits;
+    const int bits = std::min(64, axis_bits * dim);      // significant bits of the Morton key
     size_t bytes = 0;
-    FDX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.as<unsigned int>(), skeys.as<unsigned int>(), vals.as<int>(),
-                                      b->perm.as<int>(), (size_t)n, 0, (unsigned)bits, st));
+    FDX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.as<u64>(), skeys.as<u64>(), vals.as<int>(), b->perm.as<int>(),
+                                      (size_t)n, 0, (unsigned)bits, st));
     FDX_TRY(tmp.alloc(bytes));
-    FDX_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.as<unsigned int>(), skeys.as<unsigned int>(), vals.as<int>(),
-                                      b->perm.as<int>(), (size_t)n, 0, (unsigned)bits, st));
+    FDX_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.as<u64>(), skeys.as<u64>(), vals.as<int>(), b->perm.as<int>(),
+                                      (size_t)n, 0, (unsigned)bits, st));
     FDX_HIP(hipMemsetAsync(b->cstart.p, 0, b->cstart.bytes, st));
     FDX_HIP(hipMemsetAsync(b->cend.p, 0, b->cend.bytes, st));
-    hipLaunchKernelGGL(cell_range_kernel, dim3(nb), dim3(256), 0, st, skeys.as<unsigned int>(), n, b->cstart.as<int>(), b->cend.as<int>());
-    FDX_CHECK_LAUNCH();
     hipLaunchKernelGGL(gather_sorted_kernel, dim3(nb), dim3(256), 0, st, d_coords, b->perm.as<int>(), n, dim, b->sc.as<double>(), b->rank.as<int>());
+    FDX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cell_range_kernel, dim3(nb), dim3(256), 0, st, skeys.as<u64>(), b->sc.as<double>(), n, b->gp,
+                       b->cstart.as<int>(), b->cend.as<int>());
     FDX_CHECK_LAUNCH();
     FDX_HIP(hipStreamSynchronize(st));   // temporaries are released at scope exit
     return 0;
@@ -489,6 +607,27 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     hipLaunchKernelGGL(fill_ell_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, ws, seg_stride, seg_extra,
                        g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>());
     FDX_CHECK_LAUNCH();
+    // workgroup tiles of the LDS-tiled sweep
+    g->n_tiles = (int)((n + 255) / 256);
+    g->tiled = false;
+    g->halo_max = 0;
+    if (g->n_tiles > 0 && g->ell_rows > 0) {
+        FDX_TRY(g->tile_halo.alloc((size_t)g->n_tiles * FDX_TILE_HALO_CAP * 4));
+        FDX_TRY(g->tile_hcnt.alloc((size_t)g->n_tiles * 4));
+        FDX_TRY(g->ell_local.alloc((size_t)g->ell_rows * 64 * 2));
+        hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, ws, seg_stride, seg_extra, g->deg.as<int>(),
+                           g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
+                           g->ell_local.as<unsigned short>());
+        FDX_CHECK_LAUNCH();
+        std::vector<int> hc((size_t)g->n_tiles);
+        FDX_HIP(hipMemcpyAsync(hc.data(), g->tile_hcnt.p, hc.size() * 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        bool ok = true;
+        int mx = 0;
+        for (int v : hc) { if (v < 0) ok = false; mx = std::max(mx, v); }
+        g->tiled = ok;
+        g->halo_max = mx;
+    }
     return 0;
 }
 

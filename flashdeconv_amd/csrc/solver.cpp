@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace fdx {
@@ -81,6 +82,10 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
     a.stats = stats.as<unsigned long long>(); a.rel_change = relchg.as<double>();
     a.lambda = p.lambda; a.rho = p.rho_eff; a.tol = p.tol; a.ldh = (int)p.ldh; a.ld = (int)p.ld; a.n = (int)g.n;
     a.n_slices = g.n_slices; a.K = K;
+    if (g.tiled && !getenv("FDX_NO_TILED")) {
+        a.tiled = 1; a.ell_local = g.ell_local.as<unsigned short>(); a.tile_halo = g.tile_halo.as<int>();
+        a.tile_hcnt = g.tile_hcnt.as<int>(); a.n_tiles = g.n_tiles; a.halo_max = g.halo_max;
+    }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     FDX_HIP(hipEventCreate(&ev0));

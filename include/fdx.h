@@ -52,6 +52,8 @@ int fdx_device_name(char* buf, int buflen);
 /* ---- plain device memory helpers (so a ctypes-only binding needs no other GPU runtime) ---------------- */
 int fdx_malloc(void** dev_ptr, size_t bytes);
 int fdx_free(void* dev_ptr);
+/* Device scratch is recycled through a caching pool; fdx_trim() returns every cached block to the driver. */
+int fdx_trim(void);
 int fdx_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes, void* stream);
 int fdx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes, void* stream);
 int fdx_memset(void* dev_dst, int value, size_t bytes, void* stream);
