@@ -48,6 +48,12 @@ struct SketchPlanDev {
     const int* group_off = nullptr;     // (n_groups+1): schedule rows of group j are [group_off[j], group_off[j+1])
     const int* slot_bucket = nullptr;   // (n_groups*64): output bucket of slot j*64+l, -1 for unused slots
     int n_groups = 0;
+    int total_len = 0;                  // schedule rows in total (= group_off[n_groups])
+    // packed schedule for the register-resident kernel (valid when pack_ok): gene | bucket_code << 20 per entry,
+    // bit e of end_mask set when a group ends after round e
+    const unsigned int* sched_pack = nullptr;
+    unsigned long long end_mask = 0ULL;
+    int pack_ok = 0;
 };
 int launch_sketch_rows(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, double* Ys, long long ldys, double* row_sumsq, hipStream_t st);

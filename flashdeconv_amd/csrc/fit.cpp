@@ -5,6 +5,7 @@
 // host only sees a handful of scalars (bounding box, XtX, rel_change trace).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "fdx_graph.h"
@@ -151,33 +152,45 @@ extern "C" int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_
     FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
     FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
     FDX_TRY(dSum.alloc(sizeof(double)));
-    const long long chunk = std::min<long long>(n, 1LL << 18);
+    // Y_sketch is produced and consumed in chunks of 256k rows (1 GB at d = 512): measured on MI355X, smaller chunks
+    // (down to Infinity-Cache size) under-fill the chip and are slower, larger ones gain nothing.
+    long long chunk_rows = 1LL << 18;
+    if (const char* e = getenv("FDX_FIT_CHUNK")) chunk_rows = std::max<long long>(64, atoll(e));
+    const long long chunk = std::min<long long>(n, chunk_rows);
     FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
     FDX_HIP(hipMemsetAsync(dH.p, 0, dH.bytes, st));
     const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();
     double sketch_ms = 0.0, gram_ms = 0.0;
     {
-        hipEvent_t a, b, c;
-        FDX_HIP(hipEventCreate(&a)); FDX_HIP(hipEventCreate(&b)); FDX_HIP(hipEventCreate(&c));
-        for (long long r0 = 0; r0 < n; r0 += chunk) {
+        const int n_chunks = (int)((n + chunk - 1) / chunk);
+        const int n_timed = std::min(n_chunks, 64);             // stage timing from up to 64 chunks, scaled
+        std::vector<hipEvent_t> ev((size_t)n_timed * 3);
+        for (auto& e : ev) FDX_HIP(hipEventCreate(&e));
+        int ci = 0;
+        for (long long r0 = 0; r0 < n; r0 += chunk, ++ci) {
             const long long nr = std::min(chunk, n - r0);
-            FDX_HIP(hipEventRecord(a, st));
+            if (ci < n_timed) FDX_HIP(hipEventRecord(ev[(size_t)ci * 3], st));
             // with a row map the chunk gathers rows perm[r0..]; without one it reads rows r0.. of Y directly
             const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
             if (!row_map) ybase += (size_t)r0 * (size_t)ldy * (y_dtype == FDX_F32 ? 4 : 8);
             FDX_TRY(launch_sketch_rows(ybase, y_dtype, ldy, row_map ? row_map + r0 : nullptr, nr, G, d, prm->mode_y,
                                        plan_y.dev(), dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
-            FDX_HIP(hipEventRecord(b, st));
+            if (ci < n_timed) FDX_HIP(hipEventRecord(ev[(size_t)ci * 3 + 1], st));
             FDX_TRY(launch_xyt(dXs.as<double>(), dYs.as<double>(), d, nr, d, K, dH.as<double>() + r0, ld, nullptr, st));
-            FDX_HIP(hipEventRecord(c, st));
-            FDX_HIP(hipEventSynchronize(c));
+            if (ci < n_timed) FDX_HIP(hipEventRecord(ev[(size_t)ci * 3 + 2], st));
+        }
+        FDX_HIP(hipStreamSynchronize(st));
+        for (int c = 0; c < n_timed; ++c) {
             float t1 = 0.f, t2 = 0.f;
-            (void)hipEventElapsedTime(&t1, a, b);
-            (void)hipEventElapsedTime(&t2, b, c);
+            (void)hipEventElapsedTime(&t1, ev[(size_t)c * 3], ev[(size_t)c * 3 + 1]);
+            (void)hipEventElapsedTime(&t2, ev[(size_t)c * 3 + 1], ev[(size_t)c * 3 + 2]);
             sketch_ms += t1;
             gram_ms += t2;
         }
-        (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c);
+        const double scale = (double)n_chunks / (double)n_timed;
+        sketch_ms *= scale;
+        gram_ms *= scale;
+        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));   // YtY (core/solver.py:348)
     std::vector<double> Gh((size_t)K * K);

@@ -59,21 +59,43 @@ __global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __r
                 double* ap = A + (size_t)p * G;
                 double* aq = A + (size_t)q * G;
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int g = lane; g < G; g += 64) {
-                    const double x = ap[g], y = aq[g];
-                    alpha = fma(x, x, alpha);
-                    beta = fma(y, y, beta);
-                    gamma = fma(x, y, gamma);
+                // 8 independent element pairs per lane per step keep 16 loads in flight (the matrix lives in L2)
+                for (int g0 = 0; g0 < G; g0 += 512) {
+                    double x[8], y[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int g = g0 + u * 64 + lane;
+                        x[u] = (g < G) ? ap[g] : 0.0;
+                        y[u] = (g < G) ? aq[g] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        alpha = fma(x[u], x[u], alpha);
+                        beta = fma(y[u], y[u], beta);
+                        gamma = fma(x[u], y[u], gamma);
+                    }
                 }
                 alpha = wsum(alpha); beta = wsum(beta); gamma = wsum(gamma);
                 if (fabs(gamma) > 1e-15 * sqrt(alpha * beta) && gamma != 0.0) {
                     const double zeta = (beta - alpha) / (2.0 * gamma);
                     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                     const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                    for (int g = lane; g < G; g += 64) {
-                        const double x = ap[g], y = aq[g];
-                        ap[g] = c * x - s * y;
-                        aq[g] = s * x + c * y;
+                    for (int g0 = 0; g0 < G; g0 += 512) {
+                        double x[8], y[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int g = g0 + u * 64 + lane;
+                            x[u] = (g < G) ? ap[g] : 0.0;
+                            y[u] = (g < G) ? aq[g] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int g = g0 + u * 64 + lane;
+                            if (g < G) {
+                                ap[g] = c * x[u] - s * y[u];
+                                aq[g] = s * x[u] + c * y[u];
+                            }
+                        }
                     }
                     if (lane == 0) s_rot = 1;   // benign race: every writer stores 1
                 }

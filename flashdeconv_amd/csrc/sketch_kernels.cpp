@@ -17,6 +17,8 @@
 // the wave's private LDS slice (the only HBM traffic: G*sizeof(T) per spot), the library size for log-CPM is reduced
 // on the way in, then lanes gather their genes from LDS.  No workgroup barrier is needed: a wave only reads LDS it
 // wrote itself.  Results are un-permuted through LDS and written as one coalesced d*8-byte row.
+#include <cstdlib>
+
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
 
@@ -30,6 +32,40 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// log1p for the log-CPM transform.  The library log1p costs ~200 issue slots per element, which makes the log-CPM
+// sketch VALU-bound; this is the classic fdlibm decomposition specialised to x >= 0 (counts):
+//   u = 1 + x = 2^k * m,  m in [sqrt(1/2), sqrt(2));   log1p(x) = k*ln2 + log(m) + c/u,   c = x - (u - 1) (rounding of 1+x)
+//   log(m): f = m - 1, s = f/(2+f), log(m) = f - (f^2/2 - s*(f^2/2 + R(s^2))),  R = degree-7 minimax (fdlibm Lg1..Lg7)
+// Error < 1 ulp (checked against numpy.log1p in tests/test_gpu_stages.py).  Negative / non-finite inputs take the
+// library path (the reference yields NaN for x < -1 as well).
+__device__ __forceinline__ double fast_log1p(double x) {
+    if (!(x >= 0.0) || x > 1e300) return log1p(x);
+    const double u = 1.0 + x;
+    const double c = (x >= 1.0) ? 1.0 - (u - x) : x - (u - 1.0);
+    const double c_over_u = c * (double)__frcp_rn((float)u);          // |c| <= ulp(u)/2: 24-bit reciprocal is plenty
+    long long bits = __double_as_longlong(u);
+    int k = (int)((bits >> 52) & 0x7ff) - 1023;
+    long long mant = bits & 0x000fffffffffffffLL;
+    // m in [sqrt(1/2), sqrt(2)): mantissas above sqrt(2) move down one binade
+    const int up = (mant >= 0x0006a09e667f3bcdLL) ? 1 : 0;
+    k += up;
+    const double m = __longlong_as_double(mant | ((long long)(1023 - up) << 52));
+    const double f = m - 1.0;
+    const double den = 2.0 + f;
+    double r = __drcp_rn(den);                                          // den in [1.70, 2.42]
+    double s = f * r;
+    s = fma(r, fma(-s, den, f), s);                                     // one correction step: s = f/den to ~0.5 ulp
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + (dk * ln2_lo + c_over_u))) - f);
 }
 
 // MODE: FDX_PRE_RAW (0), FDX_PRE_LOG_CPM (1, dense rule), FDX_PRE_LOG_CPM_SPARSE (2, zero library size -> 1)
@@ -64,12 +100,25 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const T* __restrict__ 
             const int nvec = G / PER;
             const V* src = reinterpret_cast<const V*>(yrow);
             V* dst = reinterpret_cast<V*>(rowbuf);
-            for (int v = lane; v < nvec; v += 64) {
-                const V x = src[v];
-                dst[v] = x;
-                if (MODE != FDX_PRE_RAW) {
+            // batches of 8 independent 16-byte loads per lane (8 KB per wave in flight) before the LDS writes: the row
+            // comes straight from HBM, so a load-wait-store loop would pay the full memory latency once per 1 KB
+            for (int v0 = 0; v0 < nvec; v0 += 512) {
+                V x[8];
 #pragma unroll
-                    for (int e = 0; e < PER; ++e) part += (double)x[e];
+                for (int u = 0; u < 8; ++u) {
+                    const int v = v0 + u * 64 + lane;
+                    if (v < nvec) x[u] = src[v];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int v = v0 + u * 64 + lane;
+                    if (v < nvec) {
+                        dst[v] = x[u];
+                        if (MODE != FDX_PRE_RAW) {
+#pragma unroll
+                            for (int e = 0; e < PER; ++e) part += (double)x[u][e];
+                        }
+                    }
                 }
             }
             for (int g = nvec * PER + lane; g < G; g += 64) {
@@ -103,7 +152,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const T* __restrict__ 
                 const int g = sched_gene[(size_t)e * 64 + lane];
                 const double w = sched_w[(size_t)e * 64 + lane];
                 double y = (double)rowbuf[g];
-                if (MODE != FDX_PRE_RAW) y = log1p(y * scale);
+                if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
                 acc = fma(w, y, acc);
             }
             const int slot = j * 64 + lane;
@@ -147,11 +196,150 @@ __global__ __launch_bounds__(256) void fold_column_partials_kernel(const double*
     out[g] = acc;
 }
 
+// Register-resident schedule variant: when the whole schedule is at most NR rounds long (G/d up to ~7 genes per
+// bucket) every lane keeps its NR (gene index, weight) pairs in VGPRs for the life of the wave, so a row costs one
+// LDS gather + convert + fma per round and NO schedule traffic (the generic kernel above re-reads 12 bytes of
+// schedule per round per lane from L2, ~3x the bytes of the row itself).  Same arithmetic, same summation order.
+template <typename T, int MODE, bool VEC, int NR>
+__global__ __launch_bounds__(256, 2) void sketch_rows_reg_kernel(const T* __restrict__ Y, long long ldy,
+                                                              const int* __restrict__ row_map, long long n, int G, int d,
+                                                              const unsigned int* __restrict__ sched_pack,
+                                                              const double* __restrict__ sched_w, int total_len,
+                                                              unsigned long long end_mask,
+                                                              double* __restrict__ Ys, long long ldys,
+                                                              double* __restrict__ row_sumsq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_blk = blockDim.x >> 6;
+    const size_t row_bytes = ((size_t)G * sizeof(T) + 15) & ~(size_t)15;
+    const size_t per_wave = row_bytes + (size_t)d * sizeof(double);
+    T* rowbuf = reinterpret_cast<T*>(smem + (size_t)wib * per_wave);
+    double* outbuf = reinterpret_cast<double*>(smem + (size_t)wib * per_wave + row_bytes);
+
+    // schedule -> registers (entry = gene | bucket_code << 20; see sketch_plan.cpp)
+    unsigned int gi[NR];
+    double wt[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        gi[e] = (e < total_len) ? sched_pack[(size_t)e * 64 + lane] : 0xFFF00000u;
+        wt[e] = (e < total_len) ? sched_w[(size_t)e * 64 + lane] : 0.0;
+    }
+    for (int c = lane; c < d; c += 64) outbuf[c] = 0.0;   // buckets no gene hashes to stay exactly 0
+
+    const long long wave0 = (long long)blockIdx.x * waves_per_blk + wib;
+    const long long wave_stride = (long long)gridDim.x * waves_per_blk;
+    for (long long p = wave0; p < n; p += wave_stride) {
+        const long long src_row = row_map ? (long long)row_map[p] : p;
+        const T* yrow = Y + (size_t)src_row * ldy;
+        double part = 0.0;
+        if (VEC) {
+            typedef typename Vec4<T>::type V;
+            constexpr int PER = 16 / sizeof(T);
+            const int nvec = G / PER;
+            const V* src = reinterpret_cast<const V*>(yrow);
+            V* dst = reinterpret_cast<V*>(rowbuf);
+            // batches of 8 independent 16-byte loads per lane (8 KB per wave in flight) before the LDS writes: the row
+            // comes straight from HBM, so a load-wait-store loop would pay the full memory latency once per 1 KB
+            for (int v0 = 0; v0 < nvec; v0 += 512) {
+                V x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int v = v0 + u * 64 + lane;
+                    if (v < nvec) x[u] = src[v];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int v = v0 + u * 64 + lane;
+                    if (v < nvec) {
+                        dst[v] = x[u];
+                        if (MODE != FDX_PRE_RAW) {
+#pragma unroll
+                            for (int e = 0; e < PER; ++e) part += (double)x[u][e];
+                        }
+                    }
+                }
+            }
+            for (int g = nvec * PER + lane; g < G; g += 64) {
+                const T x = yrow[g];
+                rowbuf[g] = x;
+                if (MODE != FDX_PRE_RAW) part += (double)x;
+            }
+        } else {
+            for (int g = lane; g < G; g += 64) {
+                const T x = yrow[g];
+                rowbuf[g] = x;
+                if (MODE != FDX_PRE_RAW) part += (double)x;
+            }
+        }
+        double scale = 1.0;
+        if (MODE == FDX_PRE_LOG_CPM) {
+            const double s = wave_sum(part);
+            scale = (1.0 / (s + 1e-10)) * 1e4;
+        } else if (MODE == FDX_PRE_LOG_CPM_SPARSE) {
+            double s = wave_sum(part);
+            if (s == 0.0) s = 1.0;
+            scale = 1e4 / s;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        double sq = 0.0, acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            if (e < total_len) {                       // wave-uniform
+                double y = (double)rowbuf[gi[e] & 0xFFFFFu];
+                if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
+                acc = fma(wt[e], y, acc);
+                if ((end_mask >> e) & 1ULL) {          // a group ends here (wave-uniform, scalar test)
+                    const unsigned code = gi[e] >> 20;
+                    if (code != 0xFFFu) {
+                        outbuf[code] = acc;
+                        sq = fma(acc, acc, sq);
+                    }
+                    acc = 0.0;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        double* dst = Ys + (size_t)p * ldys;
+        for (int c = lane; c < d; c += 64) dst[c] = outbuf[c];
+        if (row_sumsq) {
+            sq = wave_sum(sq);
+            if (lane == 0) row_sumsq[p] = sq;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
+template <typename T, int MODE, bool VEC>
+static const void* pick_reg_kernel(int total_len) {
+    if (total_len <= 16) return (const void*)sketch_rows_reg_kernel<T, MODE, VEC, 16>;
+    if (total_len <= 24) return (const void*)sketch_rows_reg_kernel<T, MODE, VEC, 24>;
+    if (total_len <= 32) return (const void*)sketch_rows_reg_kernel<T, MODE, VEC, 32>;
+    if (total_len <= 40) return (const void*)sketch_rows_reg_kernel<T, MODE, VEC, 40>;
+    if (total_len <= 48) return (const void*)sketch_rows_reg_kernel<T, MODE, VEC, 48>;
+    return nullptr;
+}
+
 template <typename T, int MODE>
 static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, long long n, int G, int d,
                               const SketchPlanDev& plan, double* Ys, long long ldys, double* row_sumsq, hipStream_t st) {
     const size_t row_bytes = ((size_t)G * sizeof(T) + 15) & ~(size_t)15;
     const size_t per_wave = row_bytes + (size_t)d * sizeof(double);
+    {   // register-resident schedule when it is short enough and at least one gene is hashed to the first group
+        const bool vec0 = (ldy % (16 / (long long)sizeof(T)) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+        const void* rk = (plan.pack_ok && !getenv("FDX_SKETCH_NO_REG"))
+                             ? (vec0 ? pick_reg_kernel<T, MODE, true>(plan.total_len) : pick_reg_kernel<T, MODE, false>(plan.total_len))
+                             : nullptr;
+        if (rk && per_wave * 4 <= 64 * 1024) {
+            const size_t lds_r = per_wave * 4;
+            const int blocks_r = (int)std::min<long long>((n + 3) / 4, 256LL * 8);
+            void* args[] = {(void*)&Y, (void*)&ldy, (void*)&row_map, (void*)&n, (void*)&G, (void*)&d,
+                            (void*)&plan.sched_pack, (void*)&plan.sched_w, (void*)&plan.total_len, (void*)&plan.end_mask,
+                            (void*)&Ys, (void*)&ldys, (void*)&row_sumsq};
+            FDX_HIP(hipLaunchKernel(rk, dim3(blocks_r), dim3(256), args, lds_r, st));
+            return 0;
+        }
+    }
     int waves = 4;
     while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;   // keep >= 2 blocks per CU where possible
     const size_t lds = per_wave * waves;

@@ -54,6 +54,25 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
                 sw[e] = weight[L[t]];
             }
         }
+    // Packed form for the register-resident kernel: entry = gene | bucket_code << 20, where bucket_code is the output
+    // bucket of the lane's slot in the group the round belongs to (0xFFF = unused slot); end_mask bit e is set when a
+    // group ends after round e.  Usable when G < 2^20, d < 4095 and the schedule has at most 64 rounds.
+    pack_ok = (G < (1 << 20)) && (d < 4095) && (total_len >= 1) && (total_len <= 64);
+    end_mask = 0ULL;
+    std::vector<unsigned int> sp((size_t)std::max<long long>(total_len, 1) * 64, 0xFFF00000u);
+    if (pack_ok) {
+        for (int j = 0; j < n_groups; ++j) {
+            if (goff[(size_t)j + 1] > goff[(size_t)j]) end_mask |= 1ULL << (goff[(size_t)j + 1] - 1);
+            for (int l = 0; l < 64; ++l) {
+                const int b = slot_b[(size_t)j * 64 + l];
+                const unsigned code = (b < 0) ? 0xFFFu : (unsigned)b;
+                for (int e = goff[(size_t)j]; e < goff[(size_t)j + 1]; ++e)
+                    sp[(size_t)e * 64 + (size_t)l] = (unsigned)sg[(size_t)e * 64 + (size_t)l] | (code << 20);
+            }
+        }
+    }
+    FDX_TRY(sched_pack.alloc(sp.size() * sizeof(unsigned int)));
+    FDX_HIP(hipMemcpyAsync(sched_pack.p, sp.data(), sp.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     FDX_TRY(sched_gene.alloc(sg.size() * sizeof(int)));
     FDX_TRY(sched_w.alloc(sw.size() * sizeof(double)));
     FDX_TRY(group_off.alloc(goff.size() * sizeof(int)));

@@ -9,14 +9,20 @@ struct SketchPlan {
     int G = 0, d = 0;
     int n_groups = 0;
     long long total_len = 0;
-    DevBuf sched_gene, sched_w, group_off, slot_bucket;
+    bool pack_ok = false;
+    unsigned long long end_mask = 0ULL;
+    DevBuf sched_gene, sched_w, group_off, slot_bucket, sched_pack;
     SketchPlanDev dev() const {
         SketchPlanDev p;
         p.sched_gene = sched_gene.as<int>();
         p.sched_w = sched_w.as<double>();
         p.group_off = group_off.as<int>();
         p.slot_bucket = slot_bucket.as<int>();
+        p.sched_pack = sched_pack.as<unsigned int>();
         p.n_groups = n_groups;
+        p.total_len = (int)total_len;
+        p.pack_ok = pack_ok ? 1 : 0;
+        p.end_mask = end_mask;
         return p;
     }
     // Omega (G x d) in CSC form on the host: col_ptr (d+1), gene_idx / weight (nnz), genes ascending per column.

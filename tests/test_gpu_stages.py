@@ -108,3 +108,31 @@ def test_project_linearity_and_general_omega():
     np.testing.assert_allclose(a + b, c, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(c, (Y1 + Y2) @ Om.toarray(), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(xs, X @ Om.toarray(), rtol=1e-12, atol=1e-12)
+
+
+def test_log_cpm_transform_accuracy():
+    """The device log1p (fdlibm decomposition in sketch_kernels.cpp) against numpy.log1p, through fdx_sketch with an
+    identity-like Omega (one gene per bucket, weight 1) so that Y_sketch IS the transformed matrix."""
+    from flashdeconv_amd import _lib
+    rs = np.random.RandomState(0)
+    G = 700
+    Y = np.zeros((64, G))
+    Y[:32] = 10.0 ** rs.uniform(-12, 6, size=(32, G))          # 18 decades
+    Y[32:48] = rs.poisson(3.0, size=(16, G))                   # counts incl. zeros
+    Y[48:] = rs.rand(16, G) * 1e-3
+    Y[5, :] = 0.0                                               # all-zero row
+    col_ptr = np.arange(G + 1, dtype=np.int64)
+    gene_idx = np.arange(G, dtype=np.int32)
+    weight = np.ones(G)
+    out = np.empty((64, G))
+    _lib.require_gpu()
+    for dtype, code in ((np.float64, _lib.FDX_F64), (np.float32, _lib.FDX_F32)):
+        Yd = np.ascontiguousarray(Y.astype(dtype))
+        _lib.check(_lib.load().fdx_sketch(Yd.ctypes.data, code, 64, G, _lib.ptr_i64(col_ptr), _lib.ptr_i32(gene_idx),
+                                          _lib.ptr_f64(weight), G, _lib.PRE_LOG_CPM, _lib.ptr_f64(out)))
+        Y64 = Yd.astype(np.float64)
+        scale = (1.0 / (Y64.sum(axis=1, keepdims=True) + 1e-10)) * 1e4
+        want = np.log1p(Y64 * scale)
+        # the row sum is reduced in a different order on the device (~1e-16 relative on the scale)
+        np.testing.assert_allclose(out, want, rtol=2e-14, atol=0)
+        assert np.all(out[5] == 0.0)
