@@ -144,16 +144,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = bool(os.environ.get("FDX_BENCH_FORCE_DIST"))       # exercise the sharded driver with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         barrier = dist.barrier
     else:
         barrier = lambda: None
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    if world > 1:
+    if world > 1 or force_dist:
         from flashdeconv_amd import distributed as fdist   # sharded driver
         return fdist.bench_main(a, rank, world, local_rank)
 

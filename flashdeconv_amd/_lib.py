@@ -65,6 +65,19 @@ SIGNATURES = {
     "fdx_fit_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
                             c_i32, ctypes.POINTER(FitParams), ctypes.POINTER(c_void_p), c_void_p, c_void_p, p_double,
                             p_double, ctypes.POINTER(FitInfo), c_void_p]),
+    "fdx_graph_build_dev": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i32, c_double, c_void_p, ctypes.POINTER(c_void_p)]),
+    "fdx_graph_perm_dev": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fdx_graph_localize": (c_int, [c_void_p, c_i32, p_i64, c_i32, c_void_p, ctypes.POINTER(c_void_p)]),
+    "fdx_graph_halo_info": (c_int, [c_void_p, p_i64, p_i32, p_i32]),
+    "fdx_graph_send_indices_dev": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fdx_prepare_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, c_void_p, p_double, c_i32, p_i32, p_double, p_double,
+                                c_i32, c_i32, c_i32, c_void_p, c_i64, c_void_p, p_double, p_double, c_void_p]),
+    "fdx_init_beta_dev": (c_int, [c_void_p, c_i64, c_i64, c_i32, c_void_p]),
+    "fdx_bcd_sweep_dev": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_double, c_double,
+                                  c_double, c_i32, c_void_p, c_void_p, c_void_p]),
+    "fdx_bcd_fold_dev": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
+    "fdx_objective_partials_dev": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i32, p_double, c_void_p]),
+    "fdx_normalize_dev": (c_int, [c_void_p, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
     "fdx_version": (c_int, []),
     "fdx_last_error": (ctypes.c_char_p, []),
     "fdx_device_count": (c_int, [ctypes.POINTER(c_int)]),

@@ -1,0 +1,201 @@
+// Device-pointer C-ABI building blocks used by the spot-sharded multi-GPU driver (see include/fdx.h).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "fdx_graph.h"
+#include "fdx_internal.h"
+#include "fdx_kernels.h"
+#include "graph_build.h"
+#include "sketch_plan.h"
+#include "solver.h"
+
+using namespace fdx;
+
+namespace {
+int csc_from_tables(const int32_t* bucket, const double* weight, int G, int d, std::vector<long long>* col_ptr,
+                    std::vector<int>* gene_idx, std::vector<double>* w) {
+    col_ptr->assign((size_t)d + 1, 0);
+    for (int g = 0; g < G; ++g) {
+        FDX_REQUIRE(bucket[g] >= 0 && bucket[g] < d, "bucket index out of range");
+        (*col_ptr)[(size_t)bucket[g] + 1]++;
+    }
+    for (int c = 0; c < d; ++c) (*col_ptr)[(size_t)c + 1] += (*col_ptr)[(size_t)c];
+    gene_idx->assign((size_t)G, 0);
+    w->assign((size_t)G, 0.0);
+    std::vector<long long> cur(col_ptr->begin(), col_ptr->end() - 1);
+    for (int g = 0; g < G; ++g) {
+        const long long e = cur[(size_t)bucket[g]]++;
+        (*gene_idx)[(size_t)e] = g;
+        (*w)[(size_t)e] = weight[g];
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t method, int32_t k, double radius,
+                        void* stream, fdx_graph** out) {
+    FDX_REQUIRE(out != nullptr, "fdx_graph_build_dev: null output");
+    *out = nullptr;
+    FDX_REQUIRE(n == 0 || coords_dev != nullptr, "fdx_graph_build_dev: null coords");
+    fdx_graph* g = new fdx_graph();
+    int rc;
+    if (method == FDX_GRAPH_KNN) rc = graph_build_knn(coords_dev, n, dim, k, g, (hipStream_t)stream);
+    else if (method == FDX_GRAPH_RADIUS) rc = graph_build_radius(coords_dev, n, dim, radius, g, (hipStream_t)stream);
+    else rc = fail(FDX_ERR_INVALID, "fdx_graph_build_dev: unknown method");
+    if (rc) { delete g; return rc; }
+    *out = g;
+    return 0;
+}
+
+int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream) {
+    FDX_REQUIRE(g && (g->n == 0 || perm_out_dev), "fdx_graph_perm_dev: null argument");
+    return graph_copy_perm(g, perm_out_dev, (hipStream_t)stream);
+}
+
+int fdx_graph_localize(const fdx_graph* full, int32_t n_ranks, const int64_t* bounds, int32_t my_rank, void* stream,
+                       fdx_graph** local) {
+    FDX_REQUIRE(full && bounds && local, "fdx_graph_localize: null argument");
+    FDX_REQUIRE(n_ranks >= 1 && my_rank >= 0 && my_rank < n_ranks, "fdx_graph_localize: bad rank");
+    FDX_REQUIRE(bounds[0] == 0 && bounds[n_ranks] == full->n, "fdx_graph_localize: bounds must cover [0, n]");
+    for (int r = 0; r < n_ranks; ++r) {
+        FDX_REQUIRE(bounds[r + 1] >= bounds[r], "fdx_graph_localize: bounds must be non-decreasing");
+        FDX_REQUIRE(bounds[r] % 256 == 0, "fdx_graph_localize: range starts must be multiples of 256");
+    }
+    *local = nullptr;
+    fdx_graph* g = new fdx_graph();
+    std::vector<long long> b(bounds, bounds + n_ranks + 1);
+    const int rc = graph_localize(full, b[(size_t)my_rank], b[(size_t)my_rank + 1], n_ranks, b.data(), my_rank, g,
+                                  (hipStream_t)stream);
+    if (rc) { delete g; return rc; }
+    *local = g;
+    return 0;
+}
+
+int fdx_graph_halo_info(const fdx_graph* local, int64_t* n_halo, int32_t* send_counts, int32_t* recv_counts) {
+    FDX_REQUIRE(local != nullptr, "fdx_graph_halo_info: null graph");
+    if (n_halo) *n_halo = local->n_total - local->n;
+    const size_t R = local->send_off.empty() ? 0 : local->send_off.size() - 1;
+    for (size_t r = 0; r < R; ++r) {
+        if (send_counts) send_counts[r] = local->send_off[r + 1] - local->send_off[r];
+        if (recv_counts) recv_counts[r] = local->recv_off[r + 1] - local->recv_off[r];
+    }
+    return 0;
+}
+
+int fdx_graph_send_indices_dev(const fdx_graph* local, int32_t* idx_out_dev, void* stream) {
+    FDX_REQUIRE(local != nullptr, "fdx_graph_send_indices_dev: null graph");
+    const int total = local->send_off.empty() ? 0 : local->send_off.back();
+    if (total == 0) return 0;
+    FDX_REQUIRE(idx_out_dev != nullptr, "fdx_graph_send_indices_dev: null output");
+    FDX_HIP(hipMemcpyAsync(idx_out_dev, local->send_idx.p, (size_t)total * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_t ldy, const int32_t* row_map_dev,
+                    const double* X, int32_t K, const int32_t* bucket, const double* weight_y, const double* weight_x,
+                    int32_t d, int32_t mode_y, int32_t mode_x, double* H_out_dev, int64_t ldh, double* XtX_out_dev,
+                    double* XtX_out_host, double* YtY_partial_out, void* stream) {
+    FDX_REQUIRE(y_dtype == FDX_F32 || y_dtype == FDX_F64, "fdx_prepare_dev: Y dtype must be FDX_F32 or FDX_F64");
+    FDX_REQUIRE(n >= 0 && G > 0 && K > 0 && d > 0, "fdx_prepare_dev: bad shape");
+    FDX_REQUIRE(X && bucket && weight_y && weight_x && H_out_dev && XtX_out_dev, "fdx_prepare_dev: null array");
+    FDX_REQUIRE(ldh >= n && ldy >= G, "fdx_prepare_dev: leading dimension too small");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<long long> cp;
+    std::vector<int> gi;
+    std::vector<double> w;
+    SketchPlan plan_y, plan_x;
+    FDX_TRY(csc_from_tables(bucket, weight_y, G, d, &cp, &gi, &w));
+    FDX_TRY(plan_y.build(cp.data(), gi.data(), w.data(), G, d, st));
+    FDX_TRY(csc_from_tables(bucket, weight_x, G, d, &cp, &gi, &w));
+    FDX_TRY(plan_x.build(cp.data(), gi.data(), w.data(), G, d, st));
+    DevBuf dX, dXs, dYs, dRowSq, dSum;
+    FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
+    FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
+    FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, plan_x.dev(), dXs.as<double>(), d, nullptr, st));
+    FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, XtX_out_dev, K, nullptr, st));
+    double yty = 0.0;
+    if (n > 0) {
+        FDX_REQUIRE(Y_dev != nullptr, "fdx_prepare_dev: null Y");
+        const long long chunk = std::min<long long>(n, 1LL << 18);
+        FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
+        FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
+        FDX_TRY(dSum.alloc(sizeof(double)));
+        for (long long r0 = 0; r0 < n; r0 += chunk) {
+            const long long nr = std::min(chunk, n - r0);
+            const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
+            if (!row_map_dev) ybase += (size_t)r0 * (size_t)ldy * (y_dtype == FDX_F32 ? 4 : 8);
+            FDX_TRY(launch_sketch_rows(ybase, y_dtype, ldy, row_map_dev ? row_map_dev + r0 : nullptr, nr, G, d, mode_y,
+                                       plan_y.dev(), dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
+            FDX_TRY(launch_xyt(dXs.as<double>(), dYs.as<double>(), d, nr, d, K, H_out_dev + r0, ldh, nullptr, st));
+        }
+        FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));
+        FDX_HIP(hipMemcpyAsync(&yty, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (XtX_out_host)
+        FDX_HIP(hipMemcpyAsync(XtX_out_host, XtX_out_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    if (YtY_partial_out) *YtY_partial_out = yty;
+    return 0;
+}
+
+int fdx_init_beta_dev(double* beta_dev, int64_t ld, int64_t n_fill, int32_t K, void* stream) {
+    FDX_REQUIRE(beta_dev && ld > 0 && K > 0 && n_fill <= ld, "fdx_init_beta_dev: bad arguments");
+    return solver_init_beta(beta_dev, ld, n_fill, K, (hipStream_t)stream);
+}
+
+int fdx_bcd_sweep_dev(const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, const double* beta_in,
+                      double* beta_out, int64_t ld, int32_t K, double lambda, double rho_eff, double tol, int32_t it,
+                      void* stats_dev, double* rel_change_dev, void* stream) {
+    FDX_REQUIRE(g && H_dev && XtX_dev && beta_in && beta_out && stats_dev && rel_change_dev, "fdx_bcd_sweep_dev: null argument");
+    FDX_REQUIRE(ld >= g->n_total + 1, "fdx_bcd_sweep_dev: ld must cover own + halo + zero row");
+    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_FAST, "fdx_bcd_sweep_dev: K must be in 1..64 on the sharded path");
+    if (g->n == 0) return 0;
+    BcdSweepArgs a{};
+    a.H = H_dev; a.XtX = XtX_dev; a.beta_in = beta_in; a.beta_out = beta_out;
+    a.ell = g->ell.as<int>(); a.slice_off = g->slice_off.as<int>(); a.deg = g->deg.as<int>();
+    a.stats = (unsigned long long*)stats_dev; a.rel_change = rel_change_dev;
+    a.lambda = lambda; a.rho = rho_eff; a.tol = tol; a.ldh = (int)ldh; a.ld = (int)ld; a.n = (int)g->n;
+    a.n_slices = g->n_slices; a.K = K; a.it = it;
+    if (g->tiled) {
+        a.tiled = 1; a.ell_local = g->ell_local.as<unsigned short>(); a.tile_halo = g->tile_halo.as<int>();
+        a.tile_hcnt = g->tile_hcnt.as<int>(); a.n_tiles = g->n_tiles; a.halo_max = g->halo_max;
+    }
+    return launch_bcd_sweep(a, nullptr, 0, (hipStream_t)stream);
+}
+
+int fdx_bcd_fold_dev(void* stats_dev, double* rel_change_dev, int32_t it, void* stream) {
+    FDX_REQUIRE(stats_dev && rel_change_dev && it >= 0, "fdx_bcd_fold_dev: bad arguments");
+    return launch_bcd_fold_last((const unsigned long long*)stats_dev, rel_change_dev, it, (hipStream_t)stream);
+}
+
+int fdx_objective_partials_dev(const fdx_graph* g, const double* beta_dev, int64_t ld, const double* H_dev, int64_t ldh,
+                               const double* XtX_dev, int32_t K, double* out4_host, void* stream) {
+    FDX_REQUIRE(g && beta_dev && H_dev && XtX_dev && out4_host, "fdx_objective_partials_dev: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    out4_host[0] = out4_host[1] = out4_host[2] = out4_host[3] = 0.0;
+    if (g->n == 0) return 0;
+    DevBuf part, out;
+    const int nblk = objective_partials_count(g->n_slices);
+    FDX_TRY(part.alloc((size_t)nblk * 4 * sizeof(double)));
+    FDX_TRY(out.alloc(4 * sizeof(double)));
+    FDX_TRY(launch_objective_partials(beta_dev, ld, H_dev, ldh, XtX_dev, g->ell.as<int>(), g->slice_off.as<int>(),
+                                      g->deg.as<int>(), (int)g->n, g->n_slices, K, part.as<double>(), st));
+    FDX_TRY(launch_sum_partials(part.as<double>(), nblk, out.as<double>(), 4, 4, st));
+    FDX_HIP(hipMemcpyAsync(out4_host, out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int fdx_normalize_dev(const double* beta_dev, int64_t ld, int64_t n, int32_t K, double* beta_out_dev, double* prop_out_dev,
+                      void* stream) {
+    FDX_REQUIRE(beta_dev && n >= 0 && K > 0, "fdx_normalize_dev: bad arguments");
+    if (n == 0) return 0;
+    return launch_normalize_export(beta_dev, ld, nullptr, (int)n, (int)((n + 63) / 64), K, beta_out_dev, prop_out_dev,
+                                   (hipStream_t)stream);
+}
+
+}  // extern "C"

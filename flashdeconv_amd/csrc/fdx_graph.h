@@ -1,5 +1,7 @@
 // Device-resident spatial graph in the layout the BCD sweep consumes (internal).
 #pragma once
+#include <vector>
+
 #include "fdx_internal.h"
 
 #define FDX_TILE_HALO_CAP 1024
@@ -31,4 +33,11 @@ struct fdx_graph {
     int n_tiles = 0;
     int halo_max = 0;
     bool tiled = false;
+    // Sharded (local) graphs only: own spots are global sorted positions [global_lo, global_lo + n); local indices
+    // n .. n_total-1 are the halo, halo_global[h] their global positions (ascending, hence grouped by owner rank:
+    // rows recv_off[r] .. recv_off[r+1] come from rank r).  send_idx[send_off[r] .. send_off[r+1]) are the own local
+    // indices rank r needs from this rank, in the order rank r stores them.
+    long long global_lo = 0;
+    fdx::DevBuf halo_global, send_idx;
+    std::vector<int> send_off, recv_off;
 };

@@ -12,4 +12,10 @@ int graph_nearest_distance(const double* d_coords, long long n, int dim, double*
 // CSR in the caller's labels; device outputs indptr (n+1) int64, indices (nnz) int32 ascending per row
 int graph_export_csr(const fdx_graph* g, long long* d_indptr, int* d_indices, hipStream_t st);
 
+// Shard [lo, hi) of a full coordinate-built graph for rank `my_rank` of `n_ranks` (bounds: n_ranks+1 range starts).
+int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_ranks, const long long* bounds, int my_rank,
+                   fdx_graph* loc, hipStream_t st);
+// solver position -> caller's spot id, device int32 (n)
+int graph_copy_perm(const fdx_graph* g, int* d_out, hipStream_t st);
+
 }  // namespace fdx

@@ -379,8 +379,7 @@ __global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long lon
 // free list of neighbour positions OUTSIDE the tile (its halo), and every ELL entry of its rows translated to a
 // tile-local slot: 0..255 own spot, 256+h the h-th halo entry, 256+H the all-zero pad slot.
 constexpr int TILE_HASH = 2048;
-__global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ ws, int seg_stride,
-                                                        const int* __restrict__ seg_extra, const int* __restrict__ deg,
+__global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ ell, const int* __restrict__ deg,
                                                         const int* __restrict__ slice_off, long long n,
                                                         int* __restrict__ tile_halo, int* __restrict__ tile_hcnt,
                                                         unsigned short* __restrict__ ell_local) {
@@ -393,9 +392,10 @@ __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ 
     __syncthreads();
     const long long p = (long long)tile * 256 + tid;
     const int dg = (p < n) ? deg[p] : 0;
-    const int* seg = (p < n) ? ws + (size_t)p * seg_stride + seg_extra[p] : ws;
+    // row p of the sliced ELL: entry m at ell[(slice_off[p/64] + m)*64 + p%64]
+    const int* seg = (p < n) ? ell + (size_t)slice_off[p >> 6] * 64 + (p & 63) : ell;
     for (int m = 0; m < dg; ++m) {
-        const int q = seg[m];
+        const int q = seg[(size_t)m * 64];
         if ((q >> 8) == tile) continue;
         unsigned h = ((unsigned)q * 2654435761u) >> 21;   // 11 bits
         int probes = 0;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ 
         for (int m = 0; m < w; ++m) {
             int slot = 256 + H;   // pad -> zero slot
             if (m < dg) {
-                const int q = seg[m];
+                const int q = seg[(size_t)m * 64];
                 if ((q >> 8) == tile) slot = q & 255;
                 else {
                     int lo = 0, hi = H;   // lower_bound in the sorted halo list
@@ -572,6 +572,32 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     return 0;
 }
 
+// workgroup tiles of the LDS-tiled sweep (needs g->ell / deg / slice_off / ell_rows / n)
+static int build_tiles(fdx_graph* g, hipStream_t st) {
+    const long long n = g->n;
+    g->n_tiles = (int)((n + 255) / 256);
+    g->tiled = false;
+    g->halo_max = 0;
+    if (g->n_tiles > 0 && g->ell_rows > 0) {
+        FDX_TRY(g->tile_halo.alloc((size_t)g->n_tiles * FDX_TILE_HALO_CAP * 4));
+        FDX_TRY(g->tile_hcnt.alloc((size_t)g->n_tiles * 4));
+        FDX_TRY(g->ell_local.alloc((size_t)g->ell_rows * 64 * 2));
+        hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, g->ell.as<int>(), g->deg.as<int>(),
+                           g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
+                           g->ell_local.as<unsigned short>());
+        FDX_CHECK_LAUNCH();
+        std::vector<int> hc((size_t)g->n_tiles);
+        FDX_HIP(hipMemcpyAsync(hc.data(), g->tile_hcnt.p, hc.size() * 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        bool ok = true;
+        int mx = 0;
+        for (int v : hc) { if (v < 0) ok = false; mx = std::max(mx, v); }
+        g->tiled = ok;
+        g->halo_max = mx;
+    }
+    return 0;
+}
+
 // deg + row segments -> sliced ELL inside g (pad index = n_total)
 static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* seg_extra, hipStream_t st) {
     const long long n = g->n;
@@ -607,27 +633,7 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     hipLaunchKernelGGL(fill_ell_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, ws, seg_stride, seg_extra,
                        g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>());
     FDX_CHECK_LAUNCH();
-    // workgroup tiles of the LDS-tiled sweep
-    g->n_tiles = (int)((n + 255) / 256);
-    g->tiled = false;
-    g->halo_max = 0;
-    if (g->n_tiles > 0 && g->ell_rows > 0) {
-        FDX_TRY(g->tile_halo.alloc((size_t)g->n_tiles * FDX_TILE_HALO_CAP * 4));
-        FDX_TRY(g->tile_hcnt.alloc((size_t)g->n_tiles * 4));
-        FDX_TRY(g->ell_local.alloc((size_t)g->ell_rows * 64 * 2));
-        hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, ws, seg_stride, seg_extra, g->deg.as<int>(),
-                           g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
-                           g->ell_local.as<unsigned short>());
-        FDX_CHECK_LAUNCH();
-        std::vector<int> hc((size_t)g->n_tiles);
-        FDX_HIP(hipMemcpyAsync(hc.data(), g->tile_hcnt.p, hc.size() * 4, hipMemcpyDeviceToHost, st));
-        FDX_HIP(hipStreamSynchronize(st));
-        bool ok = true;
-        int mx = 0;
-        for (int v : hc) { if (v < 0) ok = false; mx = std::max(mx, v); }
-        g->tiled = ok;
-        g->halo_max = mx;
-    }
+    FDX_TRY(build_tiles(g, st));
     return 0;
 }
 
@@ -766,6 +772,190 @@ int graph_export_csr(const fdx_graph* g, long long* d_indptr, int* d_indices, hi
                        g->deg.as<int>(), g->perm.as<int>(), d_indptr, n, d_indices);
     FDX_CHECK_LAUNCH();
     FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ sharding
+// A rank owns the contiguous range [lo, hi) of the sorted order (lo a multiple of 256).  Its local graph indexes own
+// spots 0..n_own-1, then the halo (neighbour positions outside the range, ascending global position), then the zero row.
+__global__ __launch_bounds__(256) void mark_halo_kernel(const int* __restrict__ ell, const int* __restrict__ slice_off,
+                                                        const int* __restrict__ deg, long long lo, long long hi,
+                                                        int* __restrict__ flags) {
+    const long long p = lo + blockIdx.x * 256LL + threadIdx.x;
+    if (p >= hi) return;
+    const int* seg = ell + (size_t)slice_off[p >> 6] * 64 + (p & 63);
+    for (int m = 0; m < deg[p]; ++m) {
+        const int q = seg[(size_t)m * 64];
+        if (q < lo || q >= hi) flags[q] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_flags_kernel(const int* __restrict__ flags, const int* __restrict__ pos,
+                                                            long long n, int* __restrict__ out) {
+    const long long q = blockIdx.x * 256LL + threadIdx.x;
+    if (q < n && flags[q]) out[pos[q]] = (int)q;
+}
+
+__global__ __launch_bounds__(256) void localize_ell_kernel(const int* __restrict__ ell_g, const int* __restrict__ slice_off_g,
+                                                           const int* __restrict__ deg_g, const int* __restrict__ perm_g,
+                                                           const int* __restrict__ pos, long long lo, long long hi,
+                                                           int n_total_g, int* __restrict__ ell_l,
+                                                           int* __restrict__ slice_off_l, int* __restrict__ deg_l,
+                                                           int* __restrict__ perm_l) {
+    const long long n_own = hi - lo;
+    const int n_slices_l = (int)((n_own + 63) / 64);
+    const int s0 = (int)(lo >> 6);
+    const int base_rows = slice_off_g[s0];
+    const long long t = blockIdx.x * 256LL + threadIdx.x;
+    if (t <= n_slices_l) slice_off_l[t] = slice_off_g[s0 + t] - base_rows;
+    if (t < n_own) {
+        deg_l[t] = deg_g[lo + t];
+        perm_l[t] = perm_g ? perm_g[lo + t] : (int)(lo + t);
+    }
+    const int s = (int)(t >> 6), lane = (int)(t & 63);
+    if (s < n_slices_l) {
+        const int w0 = slice_off_g[s0 + s], w = slice_off_g[s0 + s + 1] - w0;
+        const int n_total_l = (int)n_own + pos[n_total_g];   // pos has n_total_g + 1 entries: the last is the halo count
+        for (int m = 0; m < w; ++m) {
+            const int q = ell_g[((size_t)w0 + m) * 64 + lane];
+            int v;
+            if (q == n_total_g) v = n_total_l;                 // pad -> local zero row
+            else if (q >= lo && q < hi) v = (int)(q - lo);
+            else v = (int)n_own + pos[q];
+            ell_l[((size_t)(w0 - base_rows) + m) * 64 + lane] = v;
+        }
+    }
+}
+
+// own spots with at least one neighbour in [plo, phi): the rows a peer needs from this rank (graph is symmetric)
+__global__ __launch_bounds__(256) void mark_send_kernel(const int* __restrict__ ell, const int* __restrict__ slice_off,
+                                                        const int* __restrict__ deg, long long lo, long long hi,
+                                                        long long plo, long long phi, int* __restrict__ flags) {
+    const long long p = lo + blockIdx.x * 256LL + threadIdx.x;
+    if (p >= hi) return;
+    const int* seg = ell + (size_t)slice_off[p >> 6] * 64 + (p & 63);
+    int f = 0;
+    for (int m = 0; m < deg[p]; ++m) {
+        const int q = seg[(size_t)m * 64];
+        if (q >= plo && q < phi) f = 1;
+    }
+    flags[p - lo] = f;
+}
+
+int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_ranks, const long long* bounds, int my_rank,
+                   fdx_graph* loc, hipStream_t st) {
+    FDX_REQUIRE(full && loc && bounds, "graph_localize: null argument");
+    FDX_REQUIRE(lo >= 0 && hi >= lo && hi <= full->n, "graph_localize: bad range");
+    FDX_REQUIRE(lo % 256 == 0, "graph_localize: range start must be a multiple of 256");
+    FDX_REQUIRE(full->n_total == full->n, "graph_localize: input must be a full (unsharded) graph");
+    const long long ng = full->n, n_own = hi - lo;
+    loc->n = n_own;
+    loc->identity_order = false;
+    loc->global_lo = lo;
+    loc->n_slices = (int)((n_own + 63) / 64);
+    DevBuf flags, pos, tmp;
+    FDX_TRY(flags.alloc((size_t)(ng + 2) * 4));
+    FDX_TRY(pos.alloc((size_t)(ng + 2) * 4));
+    FDX_HIP(hipMemsetAsync(flags.p, 0, flags.bytes, st));
+    if (n_own > 0 && full->ell_rows > 0) {
+        hipLaunchKernelGGL(mark_halo_kernel, dim3(ceil_div(n_own, 256)), dim3(256), 0, st, full->ell.as<int>(),
+                           full->slice_off.as<int>(), full->deg.as<int>(), lo, hi, flags.as<int>());
+        FDX_CHECK_LAUNCH();
+    }
+    FDX_TRY(exclusive_scan_int(flags.as<int>(), pos.as<int>(), ng + 1, st, tmp));
+    int n_halo = 0;
+    FDX_HIP(hipMemcpyAsync(&n_halo, pos.as<int>() + ng, 4, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    loc->n_total = n_own + n_halo;
+    FDX_TRY(loc->halo_global.alloc((size_t)std::max(n_halo, 1) * 4));
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(ceil_div(ng, 256)), dim3(256), 0, st, flags.as<int>(), pos.as<int>(), ng,
+                       loc->halo_global.as<int>());
+    FDX_CHECK_LAUNCH();
+    // local ELL / deg / perm
+    const int s0 = (int)(lo >> 6);
+    std::vector<int> so((size_t)full->n_slices + 1);
+    FDX_HIP(hipMemcpyAsync(so.data(), full->slice_off.p, so.size() * 4, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    loc->ell_rows = (loc->n_slices > 0) ? so[(size_t)s0 + loc->n_slices] - so[(size_t)s0] : 0;
+    FDX_TRY(loc->ell.alloc((size_t)std::max<long long>(loc->ell_rows, 1) * 64 * 4));
+    FDX_TRY(loc->slice_off.alloc((size_t)(loc->n_slices + 1) * 4));
+    FDX_TRY(loc->deg.alloc((size_t)std::max<long long>(n_own, 1) * 4));
+    FDX_TRY(loc->perm.alloc((size_t)std::max<long long>(n_own, 1) * 4));
+    if (n_own > 0) {
+        hipLaunchKernelGGL(localize_ell_kernel, dim3(ceil_div(loc->n_slices * 64LL + 1, 256)), dim3(256), 0, st,
+                           full->ell.as<int>(), full->slice_off.as<int>(), full->deg.as<int>(),
+                           full->identity_order ? (const int*)nullptr : full->perm.as<int>(), pos.as<int>(), lo, hi, (int)ng,
+                           loc->ell.as<int>(), loc->slice_off.as<int>(), loc->deg.as<int>(), loc->perm.as<int>());
+        FDX_CHECK_LAUNCH();
+    } else {
+        FDX_HIP(hipMemsetAsync(loc->slice_off.p, 0, loc->slice_off.bytes, st));
+    }
+    // nnz / max degree of the own rows
+    {
+        std::vector<int> dg((size_t)std::max<long long>(n_own, 1), 0);
+        if (n_own) FDX_HIP(hipMemcpyAsync(dg.data(), loc->deg.p, (size_t)n_own * 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        long long nnz = 0;
+        int md = 0;
+        for (long long i = 0; i < n_own; ++i) { nnz += dg[(size_t)i]; md = std::max(md, dg[(size_t)i]); }
+        loc->nnz = nnz;
+        loc->max_deg = md;
+    }
+    FDX_TRY(build_tiles(loc, st));
+    // halo ownership (recv) and send lists per peer
+    loc->recv_off.assign((size_t)n_ranks + 1, 0);
+    loc->send_off.assign((size_t)n_ranks + 1, 0);
+    std::vector<int> hg((size_t)std::max(n_halo, 1));
+    if (n_halo) FDX_HIP(hipMemcpyAsync(hg.data(), loc->halo_global.p, (size_t)n_halo * 4, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    for (int r = 0; r < n_ranks; ++r) {
+        const long long e = bounds[r + 1];
+        loc->recv_off[(size_t)r + 1] = (int)(std::lower_bound(hg.begin(), hg.begin() + n_halo, (int)std::min<long long>(e, 0x7fffffff)) - hg.begin());
+    }
+    DevBuf sflag, spos, slist;
+    FDX_TRY(sflag.alloc((size_t)(n_own + 2) * 4));
+    FDX_TRY(spos.alloc((size_t)(n_own + 2) * 4));
+    std::vector<std::vector<int>> lists((size_t)n_ranks);
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == my_rank || n_own == 0 || full->ell_rows == 0 || bounds[r + 1] <= bounds[r]) continue;
+        FDX_HIP(hipMemsetAsync(sflag.p, 0, sflag.bytes, st));
+        hipLaunchKernelGGL(mark_send_kernel, dim3(ceil_div(n_own, 256)), dim3(256), 0, st, full->ell.as<int>(),
+                           full->slice_off.as<int>(), full->deg.as<int>(), lo, hi, bounds[r], bounds[r + 1], sflag.as<int>());
+        FDX_CHECK_LAUNCH();
+        FDX_TRY(exclusive_scan_int(sflag.as<int>(), spos.as<int>(), n_own + 1, st, tmp));
+        int cnt = 0;
+        FDX_HIP(hipMemcpyAsync(&cnt, spos.as<int>() + n_own, 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        lists[(size_t)r].resize((size_t)cnt);
+        if (cnt) {
+            FDX_TRY(slist.alloc((size_t)cnt * 4));
+            hipLaunchKernelGGL(compact_flags_kernel, dim3(ceil_div(n_own, 256)), dim3(256), 0, st, sflag.as<int>(),
+                               spos.as<int>(), n_own, slist.as<int>());
+            FDX_CHECK_LAUNCH();
+            FDX_HIP(hipMemcpyAsync(lists[(size_t)r].data(), slist.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
+            FDX_HIP(hipStreamSynchronize(st));
+        }
+    }
+    std::vector<int> all_send;
+    for (int r = 0; r < n_ranks; ++r) {
+        all_send.insert(all_send.end(), lists[(size_t)r].begin(), lists[(size_t)r].end());
+        loc->send_off[(size_t)r + 1] = (int)all_send.size();
+    }
+    FDX_TRY(loc->send_idx.alloc(std::max<size_t>(all_send.size(), 1) * 4));
+    if (!all_send.empty())
+        FDX_HIP(hipMemcpyAsync(loc->send_idx.p, all_send.data(), all_send.size() * 4, hipMemcpyHostToDevice, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int graph_copy_perm(const fdx_graph* g, int* d_out, hipStream_t st) {
+    if (g->n == 0) return 0;
+    if (g->identity_order || !g->perm.p) {
+        hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(g->n, 256)), dim3(256), 0, st, d_out, g->n);
+        FDX_CHECK_LAUNCH();
+    } else {
+        FDX_HIP(hipMemcpyAsync(d_out, g->perm.p, (size_t)g->n * 4, hipMemcpyDeviceToDevice, st));
+    }
     return 0;
 }
 

@@ -164,6 +164,46 @@ int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_
                 int32_t dim, const fdx_fit_params* params, fdx_graph** graph_inout, double* beta_out_dev,
                 double* prop_out_dev, double* objectives_out, double* rel_changes_out, fdx_fit_info* info, void* stream);
 
+/* ---- device-pointer building blocks (spot-sharded multi-GPU driver, flashdeconv_amd/distributed.py) ------- *
+ * One process per GPU; the host side (torch.distributed over RCCL) owns the buffers and the halo exchange, these
+ * entry points only enqueue kernels on `stream`.  Same reference lines as the single-GPU entries above.           */
+
+/* Graph from coordinates already on the device (method FDX_GRAPH_KNN / FDX_GRAPH_RADIUS). */
+int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t method, int32_t k, double radius,
+                        void* stream, fdx_graph** out);
+/* perm_out_dev[p] = caller's spot id at solver position p (int32, n entries, device). */
+int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
+/* Shard of a full graph for rank `my_rank`: own spots are solver positions [bounds[my_rank], bounds[my_rank+1])
+ * (range starts must be multiples of 256).  The local graph indexes own spots first, then the halo. */
+int fdx_graph_localize(const fdx_graph* full, int32_t n_ranks, const int64_t* bounds, int32_t my_rank, void* stream,
+                       fdx_graph** local);
+/* Halo bookkeeping of a local graph: n_halo; send_counts[r] own rows rank r needs; recv_counts[r] halo rows owned by r. */
+int fdx_graph_halo_info(const fdx_graph* local, int64_t* n_halo, int32_t* send_counts, int32_t* recv_counts);
+/* Own local indices to send, grouped by destination rank ascending (sum(send_counts) int32 entries, device). */
+int fdx_graph_send_indices_dev(const fdx_graph* local, int32_t* idx_out_dev, void* stream);
+
+/* X_sketch, XtX (device K*K and host copy), H (K, ldh) for `n` rows of Y (row_map_dev: int32 row ids or NULL),
+ * and this shard's part of YtY.  core/sketching.py:160-206, core/solver.py:187-223,348. */
+int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_t ldy, const int32_t* row_map_dev,
+                    const double* X, int32_t K, const int32_t* bucket, const double* weight_y, const double* weight_x,
+                    int32_t d, int32_t mode_y, int32_t mode_x, double* H_out_dev, int64_t ldh, double* XtX_out_dev,
+                    double* XtX_out_host, double* YtY_partial_out, void* stream);
+/* beta[k*ld + i] = 1/K for i < n_fill, 0 beyond (core/solver.py:372 plus the zero pad row). */
+int fdx_init_beta_dev(double* beta_dev, int64_t ld, int64_t n_fill, int32_t K, void* stream);
+/* One BCD sweep of the own spots of `g` (core/solver.py:104-184).  stats_dev: (max_iter, 128) uint64 slots zeroed by
+ * the caller; rel_change_dev: (max_iter) doubles.  Sweep `it` tests sweep it-1's statistics on the device and
+ * becomes a no-op once they are below tol, so the caller all-reduces (MAX) slot row it-1 across ranks first. */
+int fdx_bcd_sweep_dev(const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, const double* beta_in,
+                      double* beta_out, int64_t ld, int32_t K, double lambda, double rho_eff, double tol, int32_t it,
+                      void* stats_dev, double* rel_change_dev, void* stream);
+int fdx_bcd_fold_dev(void* stats_dev, double* rel_change_dev, int32_t it, void* stream);
+/* (cross, quad, spatial, l1) partial sums of the objective over the own spots (core/solver.py:269-284), to host. */
+int fdx_objective_partials_dev(const fdx_graph* g, const double* beta_dev, int64_t ld, const double* H_dev, int64_t ldh,
+                               const double* XtX_dev, int32_t K, double* out4_host, void* stream);
+/* beta (K, ld) type-major -> beta_out / prop_out (n, K) row-major in solver order of the own spots. */
+int fdx_normalize_dev(const double* beta_dev, int64_t ld, int64_t n, int32_t K, double* beta_out_dev, double* prop_out_dev,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -407,8 +407,11 @@ def bcd_iteration_py(H, XtX, b_in, b_out, indices, indptr, lam, rho_eff):
     return diffs, absm
 
 
-def bcd_iteration_c(H, XtX, b_in, b_out, indices, indptr, lam, rho_eff):
-    N, K = b_in.shape
+def bcd_iteration_c(H, XtX, b_in, b_out, indices, indptr, lam, rho_eff, n_rows=None):
+    """One sweep over the first `n_rows` spots (default: all); neighbour indices may point at any row of b_in
+    (rows >= n_rows are a read-only halo in the sharded tests).  H is (K, n_rows)."""
+    K = b_in.shape[1]
+    N = b_in.shape[0] if n_rows is None else int(n_rows)
     diffs = np.empty(N)
     absm = np.empty(N)
     _lib().oracle_bcd_iteration(_dptr(H), _dptr(XtX), _dptr(b_in), _dptr(b_out), _iptr(indices), _iptr(indptr),

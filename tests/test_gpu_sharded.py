@@ -1,0 +1,145 @@
+"""-m gpu tests of the device side of the spot-sharded path on ONE GPU.
+
+(1) `ShardedFlashDeconv` with a 1-rank nccl group must reproduce `FlashDeconv` bit for bit.
+(2) "Virtual ranks": the full graph is cut into W shards with fdx_graph_localize; each shard gets its own buffers and
+    runs fdx_bcd_sweep_dev on its local graph; halos are moved with the send / recv lists the C ABI reports (in-process
+    copies standing in for RCCL).  The assembled result must equal the single-GPU solve bit for bit, for the same
+    number of iterations.  Together with tests/test_distributed_cpu.py (the real exchange loop over gloo) this covers
+    every piece of the N > 1 path without needing N GPUs."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+
+def _st(torch):
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("W", [2, 3, 5])
+def test_virtual_ranks_equal_single_gpu(W):
+    import torch
+    from flashdeconv_amd import FlashDeconv, _lib
+    from flashdeconv_amd.core.sketching import countsketch_tables
+    from flashdeconv_amd.distributed import HipBackend, diag_mean, shard_bounds
+    from flashdeconv_amd.utils.genes import compute_leverage_scores
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n, G, K, d = 6000, 300, 12, 64
+    Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 11)
+    coords = coords + np.random.RandomState(0).rand(n, 2) * 1e-3
+    ref = FlashDeconv(sketch_dim=d, max_iter=60, tol=1e-5).fit(Y, X, coords)
+    T = ref.info_["n_iterations"]
+
+    cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
+    h = ctypes.c_void_p()
+    _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, _lib.GRAPH_KNN, 6, 0.0, _st(torch), ctypes.byref(h)))
+    full = _lib.Graph(h.value)
+    bounds = shard_bounds(n, W)
+    lev = compute_leverage_scores(X)
+    bucket, weight = countsketch_tables(G, d, lev, 0)
+    b32 = np.ascontiguousarray(bucket, dtype=np.int32)
+    Yt = torch.from_numpy(Y.astype(np.float32)).to(dev)
+    ranks = []
+    yty = 0.0
+    for r in range(W):
+        hl = ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_localize(full.handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
+        g = _lib.Graph(hl.value)
+        n_own = int(bounds[r + 1] - bounds[r])
+        perm = torch.empty(max(n_own, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.fdx_graph_perm_dev(g.handle, ctypes.c_void_p(perm.data_ptr()), _st(torch)))
+        own = perm[:n_own].long()
+        nh = ctypes.c_int64(0)
+        sc, rc = np.zeros(W, dtype=np.int32), np.zeros(W, dtype=np.int32)
+        _lib.check(lib.fdx_graph_halo_info(g.handle, ctypes.byref(nh), _lib.ptr_i32(sc), _lib.ptr_i32(rc)))
+        sidx = torch.empty(max(int(sc.sum()), 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.fdx_graph_send_indices_dev(g.handle, ctypes.c_void_p(sidx.data_ptr()), _st(torch)))
+        n_total = n_own + int(nh.value)
+        ld = ((n_total + 1 + 63) // 64) * 64
+        Hm = torch.zeros((K, ld), dtype=torch.float64, device=dev)
+        XtX = torch.empty((K, K), dtype=torch.float64, device=dev)
+        XtX_h = np.empty((K, K))
+        part = ctypes.c_double(0.0)
+        Yown = Yt[own].contiguous()
+        _lib.check(lib.fdx_prepare_dev(ctypes.c_void_p(Yown.data_ptr()), _lib.FDX_F32, n_own, G, G, None, _lib.ptr_f64(np.ascontiguousarray(X)), K,
+                                       _lib.ptr_i32(b32), _lib.ptr_f64(weight), _lib.ptr_f64(weight), d, _lib.PRE_LOG_CPM,
+                                       _lib.PRE_LOG_CPM, ctypes.c_void_p(Hm.data_ptr()), ld, ctypes.c_void_p(XtX.data_ptr()),
+                                       _lib.ptr_f64(XtX_h), ctypes.byref(part), _st(torch)))
+        yty += part.value
+        be = HipBackend(g, Hm, ld, XtX, K)
+        beta = [torch.zeros((K, ld), dtype=torch.float64, device=dev) for _ in range(2)]
+        be.init_beta(beta[0], n_total)
+        ranks.append(dict(g=g, own=own, n_own=n_own, n_total=n_total, ld=ld, be=be, beta=beta, sc=sc, rc=rc,
+                          sidx=sidx[:int(sc.sum())].long(), XtX_h=XtX_h,
+                          stats=torch.zeros((60, 128), dtype=torch.float64, device=dev),
+                          rel=torch.zeros(60, dtype=torch.float64, device=dev)))
+        assert sum(rc) == nh.value
+    # symmetric bookkeeping: what r sends to q is what q expects from r
+    for r in range(W):
+        for q in range(W):
+            assert ranks[r]["sc"][q] == ranks[q]["rc"][r]
+    lam, rho_eff = ref.lambda_used_, 0.01 * diag_mean(ranks[0]["XtX_h"])
+    n_iter, conv = 0, False
+    for it in range(60):
+        for R in ranks:
+            R["be"].sweep(it, R["beta"][it & 1], R["beta"][(it + 1) & 1], lam, rho_eff, 1e-5, R["stats"], R["rel"])
+        for r, R in enumerate(ranks):                      # halo exchange (in-process stand-in for RCCL send/recv)
+            soff = np.concatenate([[0], np.cumsum(R["sc"])])
+            for q, Q in enumerate(ranks):
+                if q == r or R["sc"][q] == 0:
+                    continue
+                rows = R["beta"][(it + 1) & 1].index_select(1, R["sidx"][soff[q]:soff[q + 1]])
+                roff = np.concatenate([[0], np.cumsum(Q["rc"])])
+                lo = Q["n_own"] + roff[r]
+                Q["beta"][(it + 1) & 1][:, lo:lo + R["sc"][q]] = rows
+        mx = torch.stack([R["stats"][it] for R in ranks]).max(dim=0).values      # all-reduce(MAX)
+        for R in ranks:
+            R["stats"][it] = mx
+        ranks[0]["be"].fold(ranks[0]["stats"], ranks[0]["rel"], it)
+        rc_it = float(ranks[0]["rel"][it].item())
+        n_iter = it + 1
+        if rc_it < 1e-5:
+            conv = True
+            break
+    assert n_iter == T and conv == ref.info_["converged"]
+    beta = torch.zeros((n, K), dtype=torch.float64, device=dev)
+    for R in ranks:
+        out = torch.empty((R["n_own"], K), dtype=torch.float64, device=dev)
+        _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(R["beta"][n_iter & 1].data_ptr()), R["ld"], R["n_own"], K,
+                                         ctypes.c_void_p(out.data_ptr()), None, _st(torch)))
+        beta[R["own"]] = out
+    torch.cuda.synchronize()
+    assert np.array_equal(beta.cpu().numpy(), ref.beta_)
+
+
+def test_sharded_class_world1_equals_flashdeconv():
+    import torch
+    import torch.distributed as dist
+    from flashdeconv_amd import FlashDeconv
+    from flashdeconv_amd.distributed import ShardedFlashDeconv
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n, G, K = 5000, 400, 9
+        Y, X, coords, _ = datagen.gaussian_raw(n, G, K, seed=2)
+        ref = FlashDeconv(sketch_dim=128, preprocess="raw", n_hvg=G).fit(Y, X, coords)
+        m = ShardedFlashDeconv(sketch_dim=128, preprocess="raw", n_hvg=G)
+        own = m.plan(torch.from_numpy(coords).to(dev))
+        P = m.fit_transform(torch.from_numpy(Y).to(dev)[own], X)
+        got = np.zeros((n, K))
+        got[own.cpu().numpy()] = P.cpu().numpy()
+        assert m.info_["n_iterations"] == ref.info_["n_iterations"] and m.info_["converged"] == ref.info_["converged"]
+        assert np.array_equal(got, ref.proportions_)
+        np.testing.assert_allclose(m.info_["final_objective"], ref.info_["final_objective"], rtol=1e-12)
+        np.testing.assert_allclose(m.lambda_used_, ref.lambda_used_, rtol=1e-14)
+    finally:
+        dist.destroy_process_group()
