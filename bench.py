@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--sketch-dim", type=int, default=512)
     ap.add_argument("--family", choices=["gaussian", "counts", "both"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=50_000)
+    ap.add_argument("--cpu-sample", type=int, default=200_000)
     return ap.parse_args()
 
 
