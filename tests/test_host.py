@@ -1,0 +1,151 @@
+"""CPU-only tests of the host side: the C ABI library loads and exports every symbol include/fdx.h declares, the Python
+mirror of the reference interface validates like the reference, the hash/sign tables are bit-exact, and the product never
+touches the oracle or a CPU fallback.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from conftest import ROOT, load_golden
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "fdx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fdx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    names = _declared_functions()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/fdx.h but not exported by libfdx.so"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in flashdeconv_amd/_lib.py"
+    for name in _lib.SIGNATURES:
+        assert name in names, f"{name} bound in _lib.py but not declared in include/fdx.h"
+    assert lib.fdx_version() >= 100
+    assert isinstance(lib.fdx_last_error(), bytes)
+
+
+def test_no_gpu_fails_loudly_and_no_fallback():
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    n = ctypes.c_int(-1)
+    rc = lib.fdx_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.FdxError, match="no CPU fallback"):
+        _lib.require_gpu()
+    from flashdeconv_amd import FlashDeconv
+    from flashdeconv_amd.core.solver import bcd_solve
+    with pytest.raises(_lib.FdxError):
+        bcd_solve(np.zeros((4, 3)), np.ones((2, 3)), sparse.identity(4, format="csr"))
+    with pytest.raises(_lib.FdxError):
+        FlashDeconv().fit(np.ones((5, 7)), np.ones((2, 7)), np.random.rand(5, 2))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "flashdeconv_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "fdx_oracle" not in src and "liboracle" not in src and "oracle/" not in src, f
+
+
+def test_constructor_and_fit_validation_messages():
+    # reference core/deconv.py:105-124, 270-292 and tests/test_integration.py:384-422
+    from flashdeconv_amd import FlashDeconv
+    for kw, msg in [(dict(sketch_dim=0), "sketch_dim must be positive"), (dict(k_neighbors=-1), "k_neighbors must be non-negative"),
+                    (dict(max_iter=-1), "max_iter must be non-negative"), (dict(tol=0), "tol must be positive"),
+                    (dict(lambda_spatial=-1.0), "lambda_spatial must be non-negative"), (dict(rho_sparsity=-0.1), "rho_sparsity"),
+                    (dict(n_hvg=-1), "n_hvg"), (dict(n_markers_per_type=-2), "n_markers_per_type"),
+                    (dict(spatial_method="radius"), "radius must be specified"), (dict(radius=-1.0), "radius must be positive")]:
+        with pytest.raises(ValueError, match=msg):
+            FlashDeconv(**kw)
+    m = FlashDeconv()
+    assert repr(m) == "FlashDeconv(sketch_dim=512, lambda_spatial=auto, status=not fitted)"
+    assert m.summary() == {"fitted": False}
+    for getter in (m.get_cell_type_proportions, m.get_abundances, m.get_dominant_cell_type):
+        with pytest.raises(RuntimeError, match="Model has not been fitted"):
+            getter()
+    Y, X, c = np.ones((6, 9)), np.ones((3, 9)), np.random.rand(6, 2)
+    with pytest.raises(ValueError, match="Gene dimension mismatch"):
+        m.fit(Y, X[:, :4], c)
+    with pytest.raises(ValueError, match="Spot count mismatch"):
+        m.fit(Y, X, c[:3])
+    with pytest.raises(ValueError, match="at least one cell type"):
+        m.fit(Y, X[:0], c)
+    with pytest.raises(ValueError, match="cell_type_names length"):
+        m.fit(Y, X, c, cell_type_names=np.array(["a"]))
+    with pytest.raises(ValueError, match="Unknown preprocess method"):
+        FlashDeconv(preprocess="zscore").fit(Y, X, c)
+
+
+def test_countsketch_tables_bit_exact_on_host():
+    from flashdeconv_amd.core.sketching import build_countsketch_matrix, countsketch_tables
+    g = load_golden("omega_tables.npz")
+    for (G, d, s) in g["cases"]:
+        tag = f"G{G}_d{d}_s{s}"
+        bucket, weight = countsketch_tables(int(G), int(d), None, int(s))
+        assert np.array_equal(bucket, g[tag + "_bucket"])
+        assert np.array_equal(np.sign(weight).astype(np.int64), g[tag + "_sign"])
+        np.testing.assert_allclose(weight, g[tag + "_data"], rtol=1e-15)
+    Om = build_countsketch_matrix(300, 64, g["lev_input"], 11).tocsr()
+    assert np.array_equal(Om.indices, g["lev_bucket"]) and np.all(np.diff(Om.indptr) == 1)
+    np.testing.assert_allclose(Om.data, g["lev_data"], rtol=1e-14)
+    # seed reproducibility / RandomState instance / None (reference tests/test_sketching.py:36-41)
+    a = countsketch_tables(50, 8, None, 3)
+    b = countsketch_tables(50, 8, None, np.random.RandomState(3))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    np.random.seed(3)
+    c = countsketch_tables(50, 8, None, None)
+    assert np.array_equal(a[0], c[0])
+
+
+def test_check_random_state_semantics():
+    from flashdeconv_amd.utils.random import check_random_state
+    assert check_random_state(None) is np.random.mtrand._rand
+    rs = np.random.RandomState(1)
+    assert check_random_state(rs) is rs
+    assert check_random_state(5).randint(0, 100) == np.random.RandomState(5).randint(0, 100)
+    with pytest.raises(ValueError, match="cannot be used to seed"):
+        check_random_state("x")
+
+
+def test_markers_and_hvg_binning_vs_reference_golden():
+    from flashdeconv_amd.utils import genes
+    g = load_golden("fit_genesel_150x600x4.npz")
+    idx, assign = genes.select_markers(g["X"], n_markers=10)
+    assert np.array_equal(idx, g["marker_idx"]) and np.array_equal(assign, g["marker_assign"])
+    Y = g["Y"].astype(np.float64)
+    Z = np.log1p(Y / np.maximum(Y.sum(axis=1, keepdims=True), 1) * 10000)
+    hv = genes._hvg_from_moments(Z.mean(axis=0), Z.var(axis=0, ddof=1), 200, 0.0125, 3.0, 0.5)
+    assert np.array_equal(hv, g["hvg_idx"])
+    assert np.array_equal(genes.select_hvg(Y[:, :150], n_top=200), np.arange(150))        # identity short-circuit
+    assert genes.select_markers(g["X"], 0)[0].size == 0
+    with pytest.raises(ValueError, match="non-negative"):
+        genes.select_markers(g["X"], -1)
+
+
+def test_spatial_helpers():
+    from flashdeconv_amd.core.spatial import auto_tune_lambda, compute_laplacian, compute_laplacian_quadratic, get_neighbor_indices
+    A = sparse.csr_matrix(np.array([[0, 1, 1, 0], [1, 0, 0, 0], [1, 0, 0, 1], [0, 0, 1, 0]], dtype=float))
+    L = compute_laplacian(A)
+    assert np.allclose(np.asarray(L.sum(axis=1)).ravel(), 0)                               # reference tests/test_spatial.py:122-139
+    assert np.all(compute_laplacian(A, normalized=True).diagonal() <= 1 + 1e-12)
+    assert compute_laplacian_quadratic(np.ones((4, 3)), L) == pytest.approx(0.0)
+    assert [list(v) for v in get_neighbor_indices(A)] == [[1, 2], [0], [0, 3], [2]]
+    Xs = np.arange(12.0).reshape(3, 4)
+    assert auto_tune_lambda(None, Xs, A) == pytest.approx(0.005 * np.mean(np.diag(Xs @ Xs.T)) / 1.5)
+
+
+def test_normalize_proportions_exact():
+    from flashdeconv_amd.core.solver import normalize_proportions
+    g = load_golden("solver_small.npz")
+    np.testing.assert_array_equal(normalize_proportions(g["norm_in"]), g["norm_out"])
