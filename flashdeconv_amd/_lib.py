@@ -78,6 +78,8 @@ SIGNATURES = {
     "fdx_bcd_fold_dev": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "fdx_objective_partials_dev": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i32, p_double, c_void_p]),
     "fdx_normalize_dev": (c_int, [c_void_p, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
+    "fdx_gene_moments_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, p_double, c_void_p]),
+    "fdx_gather_columns_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_i32, c_i32, c_void_p, c_void_p]),
     "fdx_version": (c_int, []),
     "fdx_last_error": (ctypes.c_char_p, []),
     "fdx_device_count": (c_int, [ctypes.POINTER(c_int)]),

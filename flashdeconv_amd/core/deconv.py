@@ -166,48 +166,54 @@ class FlashDeconv:
         if n == 0:
             raise ValueError("Y has no spots")
 
-        # Step 1: informative genes + leverage scores (core/deconv.py:305-318)
-        log("Step 1: Selecting informative genes...")
-        if G_all <= self.n_hvg:
-            # select_hvg returns every gene when the matrix has no more than n_hvg of them and the marker union is a
-            # subset (utils/genes.py:135-145, 330) - no pass over Y needed.
-            if G_all == 0:
-                raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
-            gene_idx = np.arange(G_all, dtype=np.intp)
-            leverage = _genes.compute_leverage_scores(X)
-        else:
-            gene_idx, leverage = _genes.select_informative_genes(Y, X, self.n_hvg, self.n_markers_per_type)
-        self.gene_idx_ = gene_idx
-        G = len(gene_idx)
-        log(f"  Selected {G} genes (HVG + markers)")
-        identity_genes = (G == G_all)
-        Xsel = np.ascontiguousarray(X[:, gene_idx])
-
-        # Y into HBM
+        # Y into HBM (full gene set), then Step 1: informative genes + leverage scores (core/deconv.py:305-318)
         owned = []
         try:
+            if G_all == 0:
+                raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
             if _is_torch_cuda(Y):
                 import torch
-                if not identity_genes:
-                    Y = Y[:, torch.as_tensor(gene_idx, device=Y.device)]
                 if Y.dtype not in (torch.float32, torch.float64):
                     Y = Y.to(torch.float32)
                 Y = Y.contiguous()
-                y_ptr, y_code, ldy = ctypes.c_void_p(Y.data_ptr()), (_lib.FDX_F32 if Y.dtype == torch.float32 else _lib.FDX_F64), G
+                y_ptr, y_code = ctypes.c_void_p(Y.data_ptr()), (_lib.FDX_F32 if Y.dtype == torch.float32 else _lib.FDX_F64)
                 y_sparse_rule = False
             else:
                 y_sparse_rule = sparse.issparse(Y)
                 if y_sparse_rule:
-                    Yh = Y[:, gene_idx] if not identity_genes else Y
-                    Yh = np.asarray(Yh.todense())     # interim: CSR kernel is the next hot-path row
+                    if Y.shape[0] * Y.shape[1] > (1 << 33):
+                        raise NotImplementedError("sparse input this large needs the CSR kernels (next hot-path row)")
+                    Yh = np.asarray(Y.todense())      # interim: CSR kernel is the next hot-path row
                 else:
                     Yh = np.asarray(Y)
-                    if not identity_genes:
-                        Yh = Yh[:, gene_idx]
                 Yh, y_code = _lib.as_device_matrix(Yh)
                 ybuf = _DeviceBuffer.from_host(Yh)
                 owned.append(ybuf)
-                y_ptr, ldy = ybuf.ptr, G
+                y_ptr = ybuf.ptr
+            log("Step 1: Selecting informative genes...")
+            if G_all <= self.n_hvg:
+                # select_hvg returns every gene when the matrix has no more than n_hvg of them and the marker union is a
+                # subset (utils/genes.py:135-145, 330) - no pass over Y needed.
+                gene_idx = np.arange(G_all, dtype=np.intp)
+            else:
+                mean, var = _genes.gene_moments_device(y_ptr, y_code, n, G_all, G_all)
+                hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
+                markers, _ = _genes.select_markers(X, n_markers=self.n_markers_per_type)
+                gene_idx = np.union1d(hvg, markers).astype(np.intp)                  # utils/genes.py:330
+                if len(gene_idx) == 0:
+                    raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
+            self.gene_idx_ = gene_idx
+            G = len(gene_idx)
+            log(f"  Selected {G} genes (HVG + markers)")
+            Xsel = np.ascontiguousarray(X[:, gene_idx])
+            leverage = _genes.compute_leverage_scores(Xsel)
+            if G != G_all:                          # Y[:, gene_idx] (core/deconv.py:321) as a compact device matrix
+                sub = _DeviceBuffer(n * G * (4 if y_code == _lib.FDX_F32 else 8))
+                owned.append(sub)
+                gi32 = np.ascontiguousarray(gene_idx, dtype=np.int32)
+                _lib.check(lib.fdx_gather_columns_dev(y_ptr, y_code, n, G_all, G_all, _lib.ptr_i32(gi32), G, sub.ptr, None))
+                y_ptr = sub.ptr
+            ldy = G
             if _is_torch_cuda(coords):
                 import torch
                 cd = coords.to(torch.float64).contiguous()

@@ -199,3 +199,32 @@ int fdx_normalize_dev(const double* beta_dev, int64_t ld, int64_t n, int32_t K, 
 }
 
 }  // extern "C"
+
+extern "C" int fdx_gene_moments_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy, double* mean_out_host,
+                                    double* var_out_host, void* stream) {
+    FDX_REQUIRE(Y_dev && mean_out_host && var_out_host && n > 0 && G > 0, "fdx_gene_moments_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf scale, part, mean, var;
+    FDX_TRY(scale.alloc((size_t)n * 8));
+    FDX_TRY(part.alloc((size_t)column_sums_parts(n) * 2 * G * 8));
+    FDX_TRY(mean.alloc((size_t)G * 8));
+    FDX_TRY(var.alloc((size_t)G * 8));
+    FDX_TRY(launch_gene_moments(Y_dev, dtype, ldy, n, G, scale.as<double>(), part.as<double>(), mean.as<double>(), var.as<double>(), st));
+    FDX_HIP(hipMemcpyAsync(mean_out_host, mean.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipMemcpyAsync(var_out_host, var.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int fdx_gather_columns_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy, const int32_t* idx_host,
+                                      int32_t G_sel, void* out_dev, void* stream) {
+    FDX_REQUIRE(n >= 0 && G > 0 && G_sel > 0 && idx_host && (n == 0 || (Y_dev && out_dev)), "fdx_gather_columns_dev: bad arguments");
+    for (int j = 0; j < G_sel; ++j) FDX_REQUIRE(idx_host[j] >= 0 && idx_host[j] < G, "fdx_gather_columns_dev: column index out of range");
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf di;
+    FDX_TRY(di.alloc((size_t)G_sel * 4));
+    FDX_HIP(hipMemcpyAsync(di.p, idx_host, (size_t)G_sel * 4, hipMemcpyHostToDevice, st));
+    FDX_TRY(launch_gather_columns(Y_dev, dtype, ldy, n, G, di.as<int>(), G_sel, out_dev, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}

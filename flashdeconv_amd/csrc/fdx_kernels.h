@@ -86,3 +86,11 @@ namespace fdx {
 int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
                     hipStream_t st);
 }  // namespace fdx
+
+namespace fdx {
+// ---- gene statistics / column gather (sketch_kernels.cpp)
+int launch_gene_moments(const void* Y, int dtype, long long ldy, long long n, int G, double* scale, double* partials,
+                        double* mean, double* var, hipStream_t st);
+int launch_gather_columns(const void* Y, int dtype, long long ldy, long long n, int G, const int* idx, int Gs, void* out,
+                          hipStream_t st);
+}  // namespace fdx

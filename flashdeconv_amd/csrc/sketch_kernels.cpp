@@ -396,3 +396,129 @@ int launch_column_sums(const void* Y, int dtype, long long ldy, long long n, int
 }
 
 }  // namespace fdx
+
+// ------------------------------------------------------------------------------------------------ gene statistics
+// Highly-variable-gene moments (flashdeconv/utils/genes.py:85-102 dense, :52-83 sparse; same arithmetic):
+//   z = log1p(y / max(rowsum, 1) * 1e4);  per gene  mean = sum z / N,  var = (sum z^2 - (sum z)^2 / N) / (N - 1).
+// Two passes over Y: row scales (one wave per row), then per-gene sums of z and z^2 (lane = gene, coalesced; a block sums
+// a contiguous stripe of rows, stripes are folded in order -> deterministic).
+namespace fdx {
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_scale_kernel(const T* __restrict__ Y, long long ldy, long long n, int G,
+                                                        double* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    if (row >= n) return;
+    const T* y = Y + (size_t)row * ldy;
+    double s = 0.0;
+    for (int g0 = 0; g0 < G; g0 += 512) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int g = g0 + u * 64 + lane; x[u] = (g < G) ? (double)y[g] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u];
+    }
+    s = wave_sum(s);
+    if (lane == 0) scale[row] = 10000.0 / fmax(s, 1.0);          // genes.py:90-92 / :57-59
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gene_moment_partials_kernel(const T* __restrict__ Y, long long ldy, long long n, int G,
+                                                                   int rows_per_block, const double* __restrict__ scale,
+                                                                   double* __restrict__ part /* (parts, 2, G) */) {
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(n, r0 + rows_per_block);
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (long long r = r0; r < r1; ++r) {
+        const double z = fast_log1p((double)Y[(size_t)r * ldy + g] * scale[r]);
+        s1 += z;
+        s2 = fma(z, z, s2);
+    }
+    part[((size_t)blockIdx.y * 2 + 0) * G + g] = s1;
+    part[((size_t)blockIdx.y * 2 + 1) * G + g] = s2;
+}
+
+__global__ __launch_bounds__(256) void fold_moments_kernel(const double* __restrict__ part, int n_parts, int G, long long n,
+                                                           double* __restrict__ mean, double* __restrict__ var) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < n_parts; ++b) { s1 += part[((size_t)b * 2) * G + g]; s2 += part[((size_t)b * 2 + 1) * G + g]; }
+    const double m = s1 / (double)n;
+    mean[g] = m;
+    var[g] = (n >= 2) ? fmax(((s2 / (double)n) - m * m) * ((double)n / (double)(n - 1)), 0.0) : 0.0;   // genes.py:74-83
+}
+
+// out[r, j] = Y[r, idx[j]]  (core/deconv.py:321 Y[:, gene_idx]); one wave per row, row staged through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void gather_columns_kernel(const T* __restrict__ Y, long long ldy, long long n, int G,
+                                                             const int* __restrict__ idx, int Gs, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    T* rowbuf = reinterpret_cast<T*>(smem) + (size_t)wib * G;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + wib;
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long r = wave0; r < n; r += stride) {
+        const T* y = Y + (size_t)r * ldy;
+        for (int g0 = 0; g0 < G; g0 += 512) {
+            T x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int g = g0 + u * 64 + lane; if (g < G) x[u] = y[g]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int g = g0 + u * 64 + lane; if (g < G) rowbuf[g] = x[u]; }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int j = lane; j < Gs; j += 64) out[(size_t)r * Gs + j] = rowbuf[idx[j]];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
+int launch_gene_moments(const void* Y, int dtype, long long ldy, long long n, int G, double* scale, double* partials,
+                        double* mean, double* var, hipStream_t st) {
+    if (G <= 0 || n <= 0) return fail(FDX_ERR_INVALID, "gene moments: empty matrix");
+    const int parts = column_sums_parts(n);
+    const int rows_per_block = (int)((n + parts - 1) / parts);
+    const int rb = (int)((n * 64 + 255) / 256);
+    dim3 grid(ceil_div(G, 256), parts);
+    if (dtype == FDX_F32) {
+        hipLaunchKernelGGL(row_scale_kernel<float>, dim3(rb), dim3(256), 0, st, (const float*)Y, ldy, n, G, scale);
+        hipLaunchKernelGGL(gene_moment_partials_kernel<float>, grid, dim3(256), 0, st, (const float*)Y, ldy, n, G, rows_per_block, scale, partials);
+    } else if (dtype == FDX_F64) {
+        hipLaunchKernelGGL(row_scale_kernel<double>, dim3(rb), dim3(256), 0, st, (const double*)Y, ldy, n, G, scale);
+        hipLaunchKernelGGL(gene_moment_partials_kernel<double>, grid, dim3(256), 0, st, (const double*)Y, ldy, n, G, rows_per_block, scale, partials);
+    } else {
+        return fail(FDX_ERR_INVALID, "gene moments: dtype must be FDX_F32 or FDX_F64");
+    }
+    FDX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_moments_kernel, dim3(ceil_div(G, 256)), dim3(256), 0, st, partials, parts, G, n, mean, var);
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_gather_columns(const void* Y, int dtype, long long ldy, long long n, int G, const int* idx, int Gs, void* out,
+                          hipStream_t st) {
+    if (n <= 0 || Gs <= 0) return 0;
+    const size_t esz = dtype == FDX_F32 ? 4 : 8;
+    int waves = 4;
+    while (waves > 1 && (size_t)G * esz * waves > 64 * 1024) waves >>= 1;
+    const size_t lds = (size_t)G * esz * waves;
+    if (lds > 160 * 1024) return fail(FDX_ERR_UNSUPPORTED, "gather columns: one gene row does not fit in LDS");
+    const int blocks = (int)std::min<long long>((n + waves - 1) / waves, 256LL * 8);
+    if (dtype == FDX_F32) {
+        if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute((const void*)gather_columns_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gather_columns_kernel<float>, dim3(blocks), dim3(waves * 64), lds, st, (const float*)Y, ldy, n, G, idx, Gs, (float*)out);
+    } else if (dtype == FDX_F64) {
+        if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute((const void*)gather_columns_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gather_columns_kernel<double>, dim3(blocks), dim3(waves * 64), lds, st, (const double*)Y, ldy, n, G, idx, Gs, (double*)out);
+    } else {
+        return fail(FDX_ERR_INVALID, "gather columns: dtype must be FDX_F32 or FDX_F64");
+    }
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace fdx

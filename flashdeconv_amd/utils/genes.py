@@ -50,11 +50,30 @@ def select_markers(X, n_markers=50, method="diff"):
     return np.unique(chosen), np.array(assign)
 
 
+def gene_moments_device(y_ptr, y_code, n, G, ldy):
+    """Per-gene mean / ddof-1 variance of log1p(CPM-10k) for a matrix already in HBM (utils/genes.py:52-102)."""
+    mean = np.empty(G, dtype=np.float64)
+    var = np.empty(G, dtype=np.float64)
+    _lib.check(_lib.load().fdx_gene_moments_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(mean), _lib.ptr_f64(var), None))
+    return mean, var
+
+
 def _gene_moments(Y):
-    """Per-gene mean and ddof-1 variance of log1p(CPM-10k) over spots (utils/genes.py:52-102)."""
-    raise NotImplementedError(
-        "highly-variable-gene statistics (needed when the matrix has more genes than n_hvg) are not built yet; "
-        "pass a matrix with at most n_hvg genes or raise n_hvg")
+    import ctypes
+    if sparse.issparse(Y):
+        if Y.shape[0] * Y.shape[1] > (1 << 32):
+            raise NotImplementedError("sparse matrices this large need the CSR kernels (next hot-path row); densify a subset")
+        Y = np.asarray(Y.todense())
+    Yh, code = _lib.as_device_matrix(Y)
+    _lib.require_gpu()
+    lib = _lib.load()
+    ptr = ctypes.c_void_p()
+    _lib.check(lib.fdx_malloc(ctypes.byref(ptr), Yh.nbytes))
+    try:
+        _lib.check(lib.fdx_memcpy_h2d(ptr, Yh.ctypes.data, Yh.nbytes, None))
+        return gene_moments_device(ptr, code, Yh.shape[0], Yh.shape[1], Yh.shape[1])
+    finally:
+        lib.fdx_free(ptr)
 
 
 def select_hvg(Y, n_top=2000, min_mean=0.0125, max_mean=3.0, min_disp=0.5):

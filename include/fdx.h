@@ -73,6 +73,16 @@ int fdx_column_sums(const void* Y, int32_t dtype, int64_t n, int32_t G, double* 
 int fdx_column_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy, double* sums_out_host,
                         void* stream);
 
+/* ---- gene selection support (utils/genes.py:18-145 select_hvg, core/deconv.py:321 gene subset) --------------- */
+/* Per-gene mean and ddof-1 variance of log1p(y / max(rowsum,1) * 1e4) over the n spots of a device matrix (the
+ * statistics select_hvg ranks genes by; utils/genes.py:85-102 and :52-83).  Host outputs of G doubles each. */
+int fdx_gene_moments_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy, double* mean_out_host,
+                         double* var_out_host, void* stream);
+/* out[r, j] = Y[r, idx[j]]: the gene subset Y[:, gene_idx] (core/deconv.py:321) as a dense (n, G_sel) device matrix of
+ * the same dtype.  idx_host: G_sel int32 column indices. */
+int fdx_gather_columns_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy, const int32_t* idx_host,
+                           int32_t G_sel, void* out_dev, void* stream);
+
 /* ---- leverage scores (replaces utils/genes.py:238-290 compute_leverage_scores) ------------------------ */
 /* X is the HOST (K, G) row-major reference signature matrix restricted to the selected genes; lev_out (G) receives
  * the normalised leverage scores.  One-sided Jacobi SVD of the centred G x K matrix on the device. */

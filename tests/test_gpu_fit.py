@@ -130,3 +130,19 @@ def test_radius_and_grid_methods_run():
         m = FlashDeconv(sketch_dim=64, **kw).fit(Y, X, coords)
         assert m.proportions_.shape == (100, 5) and np.allclose(m.proportions_.sum(axis=1), 1.0)
         assert m.adjacency_.nnz > 0 and (m.adjacency_ != m.adjacency_.T).nnz == 0
+
+
+def test_fit_with_gene_selection_active():
+    """G > n_hvg: HVG moments on the GPU + markers + gene subset (reference utils/genes.py:18-145, 293-341)."""
+    from flashdeconv_amd import FlashDeconv
+    from flashdeconv_amd.utils import genes
+    g = load_golden("fit_genesel_150x600x4.npz")
+    Y = g["Y"].astype(np.int64)
+    assert np.array_equal(genes.select_hvg(Y, 200), g["hvg_idx"])
+    assert np.array_equal(genes.select_hvg(sparse.csr_matrix(Y.astype(np.float64)), 200), g["hvg_idx_csr"])
+    gi, lev = genes.select_informative_genes(Y, g["X"], 200, 10)
+    assert np.array_equal(gi, g["gene_idx"])
+    np.testing.assert_allclose(lev, g["leverage"], rtol=1e-9, atol=1e-15)
+    m = FlashDeconv(sketch_dim=64, n_hvg=200, n_markers_per_type=10, max_iter=30).fit(Y, g["X"], g["coords"])
+    _check(m, g)
+    assert m.summary()["n_genes_used"] == len(g["gene_idx"]) < 600
