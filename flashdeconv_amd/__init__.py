@@ -9,5 +9,6 @@ __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401
 from .core.deconv import FlashDeconv  # noqa: F401
+from . import tl  # noqa: F401
 
-__all__ = ["FlashDeconv", "__version__"]
+__all__ = ["FlashDeconv", "tl", "__version__"]

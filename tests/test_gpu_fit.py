@@ -146,3 +146,45 @@ def test_fit_with_gene_selection_active():
     m = FlashDeconv(sketch_dim=64, n_hvg=200, n_markers_per_type=10, max_iter=30).fit(Y, g["X"], g["coords"])
     _check(m, g)
     assert m.summary()["n_genes_used"] == len(g["gene_idx"]) < 600
+
+
+class _FakeAnnData:
+    """Duck-typed AnnData: exactly the attributes io/loader.py and tl/_deconvolve.py touch."""
+
+    def __init__(self, X, var_names, obs_names, obs=None, obsm=None, layers=None):
+        import pandas as pd
+        self.X, self.var_names, self.obs_names = X, np.array(var_names), np.array(obs_names)
+        self.obs = pd.DataFrame(obs or {}, index=self.obs_names)
+        self.obsm, self.layers, self.uns = dict(obsm or {}), dict(layers or {}), {}
+        self.n_obs = X.shape[0]
+
+    def copy(self):
+        c = _FakeAnnData(self.X.copy(), self.var_names, self.obs_names, obsm=dict(self.obsm), layers=dict(self.layers))
+        c.obs = self.obs.copy()
+        return c
+
+
+def test_tl_deconvolve_anndata_surface():
+    # reference tests/test_integration.py:274-344: obsm / obs / uns layout and kwargs forwarding
+    import flashdeconv_amd as fd
+    g = load_golden("fit_counts_100x500x5_d64.npz")
+    Y, X, coords = g["Y"].astype(np.float64), g["X"], g["coords"]
+    rs = np.random.RandomState(0)
+    genes = np.array([f"g{i}" for i in range(500)])
+    labels = np.repeat([f"type{k}" for k in range(5)], 8)
+    cells = np.vstack([rs.poisson(X[k] * 3.0, size=(8, 500)) for k in range(5)]).astype(np.float64)
+    ref = _FakeAnnData(cells, genes[::-1], [f"c{i}" for i in range(40)], obs={"celltype": labels})
+    ref.X = cells[:, ::-1]
+    st = _FakeAnnData(Y, genes, [f"s{i}" for i in range(100)], obsm={"spatial": coords})
+    out = fd.tl.deconvolve(st, ref, cell_type_key="celltype", sketch_dim=64, k_neighbors=4, copy=True)
+    assert "flashdeconv" not in st.obsm and out is not st
+    P = out.obsm["flashdeconv"]
+    assert list(P.columns) == [f"type{k}" for k in range(5)] and list(P.index) == list(st.obs_names)
+    np.testing.assert_allclose(P.values.sum(axis=1), 1.0, rtol=1e-12)
+    assert str(out.obs["flashdeconv_dominant"].dtype) == "category"
+    prm = out.uns["flashdeconv_params"]
+    assert len(prm) == 15 and prm["k_neighbors"] == 4 and prm["n_genes_used"] == 500 and prm["n_cell_types"] == 5
+    assert fd.tl.deconvolve(st, ref, cell_type_key="celltype", sketch_dim=64, key_added="fdx") is None
+    assert "fdx" in st.obsm and "fdx_dominant" in st.obs and "fdx_params" in st.uns
+    with pytest.raises(ValueError, match="not found in adata_ref.obs"):
+        fd.tl.deconvolve(st, ref, cell_type_key="nope")
