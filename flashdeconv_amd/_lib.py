@@ -109,6 +109,27 @@ _lock = threading.Lock()
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as the system one).  Two HIP runtimes in one
+    process do not coexist (the second one sees no GPUs), so when torch is installed its copy is loaded first and
+    libfdx.so binds to it; whichever of torch / libfdx is imported first, there is exactly one runtime."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load():
     """Load libfdx.so once and attach the signatures.  Raises FdxError if it has not been built."""
     global _lib
@@ -118,6 +139,7 @@ def load():
                 raise FdxError(
                     f"{LIB_PATH} not found: build it with `make -C flashdeconv_amd/csrc` "
                     "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+            _preload_shared_hip_runtime()
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

@@ -124,6 +124,21 @@ int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scra
     return 0;
 }
 
+int launch_bcd_objective_tiled(const BcdSweepArgs& a0, double* partials, hipStream_t st) {
+    if (!a0.tiled || a0.K < 1 || a0.K > FDX_MAX_K_FAST) return 1;
+    const int KC = a0.K < 8 ? a0.K : 8;
+    if ((size_t)KC * (256 + a0.halo_max + 1) * sizeof(double) > 64 * 1024) return 1;
+    BcdSweepArgs a = a0;
+    a.objective = 1;
+    a.rel_change = partials;
+    a.it = 0;
+    const bool hit = bcd_sweep_dispatch_part0(a, st) || bcd_sweep_dispatch_part1(a, st) || bcd_sweep_dispatch_part2(a, st) ||
+                     bcd_sweep_dispatch_part3(a, st) || bcd_sweep_dispatch_part4(a, st) || bcd_sweep_dispatch_part5(a, st);
+    if (!hit) return 1;
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, int it, hipStream_t st) {
     hipLaunchKernelGGL(bcd_fold_last_kernel, dim3(1), dim3(64), 0, st, stats, rel_change, it);
     FDX_CHECK_LAUNCH();

@@ -129,22 +129,25 @@ __global__ __launch_bounds__(256) void bcd_sweep_kernel(
 // the tile, one coalesced-ish global gather per halo spot and type) are staged in LDS, and all neighbour sums are then
 // served by ds_read_b64 from tile-local slots - ~0.5 global gathers per spot and type instead of ~11.  Arithmetic and
 // summation order are identical to bcd_sweep_kernel, so both variants produce the same bits.
-template <int K, int KC>
+template <int K, int KC, bool OBJ>
 __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
     const double* __restrict__ H, const double* __restrict__ XtX, const double* __restrict__ beta_in,
     double* __restrict__ beta_out, const unsigned short* __restrict__ ell_local, const int* __restrict__ slice_off,
     const int* __restrict__ deg, const int* __restrict__ tile_halo, const int* __restrict__ tile_hcnt,
     unsigned long long* __restrict__ stats, double* __restrict__ rel_change, const double lambda, const double rho,
     const double tol, const int ldh, const int ld_, const int n, const int S, const int it) {
+    // OBJ = true turns the same traversal into the objective evaluation (core/solver.py:269-284): no update, no store;
+    // `rel_change` then receives the per-block partial sums (cross, quad, spatial, l1) at [4*block + o].
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [KC][S]: 256 own | halo | zero slot
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    if (it > 0) {
+    if (!OBJ && it > 0) {
         const double rc = fold_rel_change(stats + (size_t)(it - 1) * 128, lane);
         if (blockIdx.x == 0 && tid == 0) rel_change[it - 1] = rc;
         if (rc < tol) return;          // uniform over the whole grid
     }
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const bool real = (tile * 256 + tid) < n;
     const int i = min(tile * 256 + tid, n - 1);   // lanes past the last spot mirror spot n-1
     const size_t ld = (size_t)ld_;
     const int slice = __builtin_amdgcn_readfirstlane(i >> 6);
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
     const int hidx0 = (tid < Ht) ? halo[tid] : 0;
 
     double dmax = 0.0, amax = 0.0;
+    double o_cross = 0.0, o_quad = 0.0, o_spat = 0.0, o_l1 = 0.0;
 #pragma unroll
     for (int kc = 0; kc < K; kc += KC) {
         // ---- stage old values of this chunk: own from registers, halo from global
@@ -208,6 +212,13 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
                 if (K & 1) r0 = fma(g[K - 1], b[K - 1], r0);
                 const double gkk = g[k];
                 const double old = b[k];
+                if (OBJ) {
+                    o_cross = fma(old, h, o_cross);
+                    o_quad = fma(old, r0 + r1, o_quad);
+                    o_spat = fma(old, (double)dg * old - c[q], o_spat);
+                    o_l1 += fabs(old);
+                    continue;
+                }
                 const double res = (h - (r0 + r1) + gkk * old) + lam_eff * c[q];
                 const double den = gkk + lam_deg;
                 const double st = res > rho ? res - rho : (res < -rho ? res + rho : 0.0);
@@ -219,6 +230,21 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
                 beta_out[k * ld + i] = nw;
             }
         }
+    }
+    if (OBJ) {
+        if (!real) { o_cross = o_quad = o_spat = o_l1 = 0.0; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            o_cross += __shfl_xor(o_cross, off, 64);
+            o_quad += __shfl_xor(o_quad, off, 64);
+            o_spat += __shfl_xor(o_spat, off, 64);
+            o_l1 += __shfl_xor(o_l1, off, 64);
+        }
+        __syncthreads();                    // lds is free again after the last chunk
+        if (lane == 0) { lds[(tid >> 6) * 4 + 0] = o_cross; lds[(tid >> 6) * 4 + 1] = o_quad; lds[(tid >> 6) * 4 + 2] = o_spat; lds[(tid >> 6) * 4 + 3] = o_l1; }
+        __syncthreads();
+        if (tid < 4) rel_change[(size_t)tile * 4 + tid] = ((lds[tid] + lds[4 + tid]) + lds[8 + tid]) + lds[12 + tid];
+        return;
     }
     dmax = wave_max(dmax);
     amax = wave_max(amax);
@@ -237,9 +263,14 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
         const int S = 256 + a.halo_max + 1;
         const size_t lds = (size_t)KC * S * sizeof(double);
         if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX, a.beta_in,
-                               a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt, a.stats,
-                               a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it);
+            if (a.objective)
+                hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
+                                   a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
+                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it);
+            else
+                hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
+                                   a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
+                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it);
             return;
         }
     }

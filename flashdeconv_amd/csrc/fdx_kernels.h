@@ -27,6 +27,7 @@ struct BcdSweepArgs {
     int n_tiles = 0;
     int halo_max = 0;
     int tiled = 0;
+    int objective = 0;       // tiled kernel only: evaluate the objective partial sums instead of sweeping (see bcd_sweep_inst.cpp)
     unsigned long long* stats;  // (max_iter, 2, 64) per-iteration max slots (bit patterns of doubles >= 0)
     double* rel_change;      // (max_iter) rel_change per iteration, written by the following kernel
     double lambda;
@@ -77,6 +78,8 @@ int launch_normalize_export(const double* beta, long long ld, const int* perm, i
 
 // ---- bcd_kernels.cpp
 int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scratch_ld, hipStream_t st);
+// objective through the tiled traversal; returns 1 if not applicable (caller falls back to the generic kernel)
+int launch_bcd_objective_tiled(const BcdSweepArgs& a, double* partials /* (n_tiles, 4) */, hipStream_t st);
 int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, int it, hipStream_t st);
 
 }  // namespace fdx

@@ -109,7 +109,37 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const double* __rest
     }
 }
 
+// Stage 1 of the two-level sum for long inputs: block b reduces a contiguous range to mid[b*n_out + o].
+__global__ __launch_bounds__(256) void sum_ranges_kernel(const double* __restrict__ in, long long count, int n_out,
+                                                         long long stride, long long per_block, double* __restrict__ mid) {
+    __shared__ double sh[256];
+    const long long i0 = (long long)blockIdx.x * per_block, i1 = min(count, i0 + per_block);
+    for (int o = 0; o < n_out; ++o) {
+        double acc = 0.0;
+        for (long long i = i0 + threadIdx.x; i < i1; i += 256) acc += in[i * stride + o];
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) mid[(size_t)blockIdx.x * n_out + o] = sh[0];
+        __syncthreads();
+    }
+}
+
 int launch_sum_partials(const double* in, long long count, double* out, int n_out, long long stride, hipStream_t st) {
+    if (count > 65536) {   // two fixed-shape levels: deterministic, and the long level uses the whole chip
+        static thread_local DevBuf mid;
+        const int nb = 512;
+        const long long per_block = (count + nb - 1) / nb;
+        if (mid.bytes < (size_t)nb * n_out * sizeof(double)) FDX_TRY(mid.alloc((size_t)nb * n_out * sizeof(double)));
+        hipLaunchKernelGGL(sum_ranges_kernel, dim3(nb), dim3(256), 0, st, in, count, n_out, stride, per_block, mid.as<double>());
+        FDX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, mid.as<double>(), (long long)nb, out, n_out, (long long)n_out);
+        FDX_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, in, count, out, n_out, stride);
     FDX_CHECK_LAUNCH();
     return 0;

@@ -11,7 +11,7 @@
 // exactly like LAPACK's ~1e-16 singular value does, i.e. nothing.  Working on the tall matrix (not on the K x K
 // Gram matrix) keeps small singular values accurate to machine precision.
 //
-// Mapping: one workgroup of 16 wavefronts.  Columns of A are ROWS of Xc (contiguous, G doubles).  A round-robin
+// Mapping: one workgroup of 8 wavefronts (2 per SIMD, so a wave can hold both of its columns in 256 VGPRs).  Columns of A are ROWS of Xc (contiguous, G doubles).  A round-robin
 // tournament gives K/2 disjoint column pairs per round; each wave owns one pair, streams both columns from L2 with
 // coalesced loads, reduces the three inner products with wave shuffles and applies the rotation.  Rounds are
 // separated by workgroup barriers.  The reference matrix is tiny (K x G doubles), so this kernel is latency-, not
@@ -27,7 +27,8 @@ __device__ __forceinline__ double wsum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __restrict__ X, int K, int G, double reg,
+template <int NCH>
+__global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __restrict__ X, int K, int G, double reg,
                                                                double* __restrict__ A /* (K, G) work */,
                                                                double* __restrict__ sig2 /* (K) */,
                                                                double* __restrict__ lev /* (G) */,
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __r
     __shared__ double s_red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // centre over cell types (genes.py:264)
-    for (int g = tid; g < G; g += 1024) {
+    for (int g = tid; g < G; g += 512) {
         double m = 0.0;
         for (int k = 0; k < K; ++k) m += X[(size_t)k * G + g];
         m /= (double)K;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __r
         if (tid == 0) s_rot = 0;
         __syncthreads();
         for (int r = 0; r < n_rounds; ++r) {
-            for (int m = wave; m < n_pairs; m += 16) {
+            for (int m = wave; m < n_pairs; m += 8) {
                 int p, q;
                 if (m == 0) { p = Kp - 1; q = r; }
                 else { p = (r + m) % (Kp - 1); q = (r - m + (Kp - 1)) % (Kp - 1); }
@@ -59,7 +60,41 @@ __global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __r
                 double* ap = A + (size_t)p * G;
                 double* aq = A + (size_t)q * G;
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                // 8 independent element pairs per lane per step keep 16 loads in flight (the matrix lives in L2)
+                if (NCH > 0) {
+                    // register-resident round (G <= NCH*512): both columns are loaded ONCE (all loads in flight together, the
+                    // matrix lives in L2), reduced, rotated in registers and stored - one L2 round trip per round
+                    constexpr int NE = NCH > 0 ? NCH * 8 : 1;
+                    double x[NE], y[NE];
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) {
+                        const int g = u * 64 + lane;
+                        x[u] = (g < G) ? ap[g] : 0.0;
+                        y[u] = (g < G) ? aq[g] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) {
+                        alpha = fma(x[u], x[u], alpha);
+                        beta = fma(y[u], y[u], beta);
+                        gamma = fma(x[u], y[u], gamma);
+                    }
+                    alpha = wsum(alpha); beta = wsum(beta); gamma = wsum(gamma);
+                    if (fabs(gamma) > 1e-15 * sqrt(alpha * beta) && gamma != 0.0) {
+                        const double zeta = (beta - alpha) / (2.0 * gamma);
+                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) {
+                            const int g = u * 64 + lane;
+                            if (g < G) {
+                                ap[g] = c * x[u] - s * y[u];
+                                aq[g] = s * x[u] + c * y[u];
+                            }
+                        }
+                        if (lane == 0) s_rot = 1;
+                    }
+                    continue;
+                }
+                // streaming round (any G): 8 independent element pairs per lane per step keep 16 loads in flight
                 for (int g0 = 0; g0 < G; g0 += 512) {
                     double x[8], y[8];
 #pragma unroll
@@ -107,7 +142,7 @@ __global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __r
         if (!any) break;
     }
     // squared singular values
-    for (int j = wave; j < K; j += 16) {
+    for (int j = wave; j < K; j += 8) {
         double a2 = 0.0;
         for (int g = lane; g < G; g += 64) { const double x = A[(size_t)j * G + g]; a2 = fma(x, x, a2); }
         a2 = wsum(a2);
@@ -116,7 +151,7 @@ __global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __r
     __syncthreads();
     // lev_g = sum_j a_gj^2 / (s_j^2 + reg)   (genes.py:281-285), then normalise (genes.py:288)
     double part = 0.0;
-    for (int g = tid; g < G; g += 1024) {
+    for (int g = tid; g < G; g += 512) {
         double l = 0.0;
         for (int j = 0; j < K; ++j) { const double x = A[(size_t)j * G + g]; l += x * x / (sig2[j] + reg); }
         lev[g] = l;
@@ -126,8 +161,8 @@ __global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __r
     if (lane == 0) s_red[wave] = part;
     __syncthreads();
     double total = 0.0;
-    for (int w = 0; w < 16; ++w) total += s_red[w];
-    for (int g = tid; g < G; g += 1024) lev[g] = lev[g] / (total + reg);
+    for (int w = 0; w < 8; ++w) total += s_red[w];
+    for (int g = tid; g < G; g += 512) lev[g] = lev[g] / (total + reg);
     if (tid == 0 && sweeps_out) *sweeps_out = sweep;
 }
 
@@ -135,7 +170,11 @@ __global__ __launch_bounds__(1024) void leverage_jacobi_kernel(const double* __r
 int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
                     hipStream_t st) {
     if (K <= 0 || G <= 0) return fail(FDX_ERR_INVALID, "leverage: empty reference matrix");
-    hipLaunchKernelGGL(leverage_jacobi_kernel, dim3(1), dim3(1024), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
+    const int nch = (G + 511) / 512;
+    if (nch == 1) hipLaunchKernelGGL(leverage_jacobi_kernel<1>, dim3(1), dim3(512), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
+    else if (nch == 2) hipLaunchKernelGGL(leverage_jacobi_kernel<2>, dim3(1), dim3(512), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
+    else if (nch <= 4) hipLaunchKernelGGL(leverage_jacobi_kernel<4>, dim3(1), dim3(512), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
+    else hipLaunchKernelGGL(leverage_jacobi_kernel<0>, dim3(1), dim3(512), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
     FDX_CHECK_LAUNCH();
     return 0;
 }
