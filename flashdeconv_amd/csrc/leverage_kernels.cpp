@@ -33,6 +33,7 @@ __global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __re
                                                                double* __restrict__ sig2 /* (K) */,
                                                                double* __restrict__ lev /* (G) */,
                                                                int* __restrict__ sweeps_out) {
+    extern __shared__ __attribute__((aligned(16))) double s_gram[];   // 2 x 64 x 65 doubles (Gram matrix, rotations)
     __shared__ int s_rot;
     __shared__ double s_red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,6 +45,76 @@ __global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __re
         for (int k = 0; k < K; ++k) A[(size_t)k * G + g] = X[(size_t)k * G + g] - m;
     }
     __syncthreads();
+    // ---- preconditioning (K <= 64): rotate the columns by the eigenvectors of the K x K Gram matrix, A <- A V.
+    // V is a product of plane rotations (orthogonal to machine precision), so A V has exactly A's singular values and
+    // left vectors, but nearly orthogonal columns: the one-sided sweeps below then converge in 2-3 instead of ~13.
+    // The Gram matrix only steers; every inner product that decides the result is recomputed from the columns.
+    if (K <= 64 && K >= 2) {
+        double (*C)[65] = reinterpret_cast<double (*)[65]>(s_gram);
+        double (*V)[65] = reinterpret_cast<double (*)[65]>(s_gram + 64 * 65);
+        for (int p = wave; p < K; p += 8)                 // C = A A^T (upper triangle by row owner, mirrored)
+            for (int q = p; q < K; ++q) {
+                double acc = 0.0;
+                for (int g0 = 0; g0 < G; g0 += 512) {     // 16 independent loads in flight per step
+                    double x[8], y[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int g = g0 + u * 64 + lane;
+                        x[u] = (g < G) ? A[(size_t)p * G + g] : 0.0;
+                        y[u] = (g < G) ? A[(size_t)q * G + g] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = fma(x[u], y[u], acc);
+                }
+                acc = wsum(acc);
+                if (lane == 0) { C[p][q] = acc; C[q][p] = acc; }
+            }
+        for (int e = tid; e < K * K; e += 512) V[e / K][e % K] = (e / K == e % K) ? 1.0 : 0.0;
+        __syncthreads();
+        if (wave == 0) {                                  // cyclic two-sided Jacobi on C, lanes over the vector index
+            for (int sw = 0; sw < 5; ++sw) {             // a few sweeps suffice: the one-sided sweeps below finish the job
+                double off = 0.0, dia = 0.0;
+                for (int p = 0; p < K - 1; ++p)
+                    for (int q = p + 1; q < K; ++q) {
+                        const double cpq = C[p][q], cpp = C[p][p], cqq = C[q][q];
+                        off = fmax(off, fabs(cpq));
+                        dia = fmax(dia, fmax(fabs(cpp), fabs(cqq)));
+                        if (fabs(cpq) <= 1e-17 * sqrt(fabs(cpp * cqq)) || cpq == 0.0) continue;
+                        const double theta = (cqq - cpp) / (2.0 * cpq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                        // rows/cols p,q of C and columns p,q of V; lane k owns index k
+                        for (int k = lane; k < K; k += 64) {
+                            const double ckp = C[k][p], ckq = C[k][q];
+                            C[k][p] = c * ckp - s * ckq;
+                            C[k][q] = s * ckp + c * ckq;
+                            const double vkp = V[k][p], vkq = V[k][q];
+                            V[k][p] = c * vkp - s * vkq;
+                            V[k][q] = s * vkp + c * vkq;
+                        }
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        for (int k = lane; k < K; k += 64) {
+                            const double cpk = C[p][k], cqk = C[q][k];
+                            C[p][k] = c * cpk - s * cqk;
+                            C[q][k] = s * cpk + c * cqk;
+                        }
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                    }
+                if (off <= 1e-14 * dia) break;
+            }
+        }
+        __syncthreads();
+        for (int g = tid; g < G; g += 512) {              // A[:, g] <- V^T A[:, g]   (column j of A V = sum_i V[i][j] a_i)
+            double av[64];
+            for (int i = 0; i < K; ++i) av[i] = A[(size_t)i * G + g];
+            for (int j = 0; j < K; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < K; ++i) acc = fma(V[i][j], av[i], acc);
+                A[(size_t)j * G + g] = acc;
+            }
+        }
+        __syncthreads();
+    }
     const int Kp = (K + 1) & ~1;          // even number of players (one dummy if K is odd)
     const int n_pairs = Kp / 2, n_rounds = Kp - 1;
     int sweep = 0;
@@ -170,11 +241,16 @@ __global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __re
 int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
                     hipStream_t st) {
     if (K <= 0 || G <= 0) return fail(FDX_ERR_INVALID, "leverage: empty reference matrix");
+    constexpr size_t kLevLds = 2 * 64 * 65 * sizeof(double);
+    FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));
+    FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));
+    FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));
+    FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));
     const int nch = (G + 511) / 512;
-    if (nch == 1) hipLaunchKernelGGL(leverage_jacobi_kernel<1>, dim3(1), dim3(512), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
-    else if (nch == 2) hipLaunchKernelGGL(leverage_jacobi_kernel<2>, dim3(1), dim3(512), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
-    else if (nch <= 4) hipLaunchKernelGGL(leverage_jacobi_kernel<4>, dim3(1), dim3(512), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
-    else hipLaunchKernelGGL(leverage_jacobi_kernel<0>, dim3(1), dim3(512), 0, st, X, K, G, reg, work, sig2, lev, sweeps);
+    if (nch == 1) hipLaunchKernelGGL(leverage_jacobi_kernel<1>, dim3(1), dim3(512), kLevLds, st, X, K, G, reg, work, sig2, lev, sweeps);
+    else if (nch == 2) hipLaunchKernelGGL(leverage_jacobi_kernel<2>, dim3(1), dim3(512), kLevLds, st, X, K, G, reg, work, sig2, lev, sweeps);
+    else if (nch <= 4) hipLaunchKernelGGL(leverage_jacobi_kernel<4>, dim3(1), dim3(512), kLevLds, st, X, K, G, reg, work, sig2, lev, sweeps);
+    else hipLaunchKernelGGL(leverage_jacobi_kernel<0>, dim3(1), dim3(512), kLevLds, st, X, K, G, reg, work, sig2, lev, sweeps);
     FDX_CHECK_LAUNCH();
     return 0;
 }
