@@ -67,9 +67,16 @@ extern "C" int fdx_leverage_scores(const double* X, int32_t K, int32_t G, double
     FDX_TRY(dS.alloc((size_t)K * sizeof(double)));
     FDX_TRY(dL.alloc((size_t)G * sizeof(double)));
     FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_TRY(launch_leverage(dX.as<double>(), K, G, regularization, dW.as<double>(), dS.as<double>(), dL.as<double>(), nullptr, st));
+    DevBuf dDbg;
+    FDX_TRY(dDbg.alloc(8 * sizeof(int)));
+    FDX_TRY(launch_leverage(dX.as<double>(), K, G, regularization, dW.as<double>(), dS.as<double>(), dL.as<double>(), dDbg.as<int>(), st));
     FDX_HIP(hipMemcpyAsync(lev_out, dL.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
+    int dbg[8] = {0};
+    FDX_HIP(hipMemcpyAsync(dbg, dDbg.p, sizeof(dbg), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
+    if (getenv("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
+        std::fprintf(stderr, "[fdx] leverage: K=%d G=%d sweeps=%d  us: gram=%d eigen=%d apply=%d polish=%d end=%d\n", K, G, dbg[0],
+                     dbg[1] / 100, (dbg[2] - dbg[1]) / 100, (dbg[3] - dbg[2]) / 100, (dbg[4] - dbg[3]) / 100, (dbg[5] - dbg[4]) / 100);
     return 0;
 }
 

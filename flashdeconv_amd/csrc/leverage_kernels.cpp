@@ -44,6 +44,7 @@ __global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __re
         m /= (double)K;
         for (int k = 0; k < K; ++k) A[(size_t)k * G + g] = X[(size_t)k * G + g] - m;
     }
+    long long t_dbg0 = wall_clock64();
     __syncthreads();
     // ---- preconditioning (K <= 64): rotate the columns by the eigenvectors of the K x K Gram matrix, A <- A V.
     // V is a product of plane rotations (orthogonal to machine precision), so A V has exactly A's singular values and
@@ -71,50 +72,85 @@ __global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __re
             }
         for (int e = tid; e < K * K; e += 512) V[e / K][e % K] = (e / K == e % K) ? 1.0 : 0.0;
         __syncthreads();
-        if (wave == 0) {                                  // cyclic two-sided Jacobi on C, lanes over the vector index
-            for (int sw = 0; sw < 5; ++sw) {             // a few sweeps suffice: the one-sided sweeps below finish the job
-                double off = 0.0, dia = 0.0;
-                for (int p = 0; p < K - 1; ++p)
-                    for (int q = p + 1; q < K; ++q) {
-                        const double cpq = C[p][q], cpp = C[p][p], cqq = C[q][q];
-                        off = fmax(off, fabs(cpq));
-                        dia = fmax(dia, fmax(fabs(cpp), fabs(cqq)));
-                        if (fabs(cpq) <= 1e-17 * sqrt(fabs(cpp * cqq)) || cpq == 0.0) continue;
-                        const double theta = (cqq - cpp) / (2.0 * cpq);
-                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
-                        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                        // rows/cols p,q of C and columns p,q of V; lane k owns index k
-                        for (int k = lane; k < K; k += 64) {
-                            const double ckp = C[k][p], ckq = C[k][q];
-                            C[k][p] = c * ckp - s * ckq;
-                            C[k][q] = s * ckp + c * ckq;
-                            const double vkp = V[k][p], vkq = V[k][q];
-                            V[k][p] = c * vkp - s * vkq;
-                            V[k][q] = s * vkp + c * vkq;
+        if (tid == 0 && sweeps_out) sweeps_out[1] = (int)(wall_clock64() - t_dbg0);
+        // parallel-order two-sided Jacobi on C: the K/2 disjoint pairs of a round-robin round are rotated together
+        // (rotation parameters -> column update of C and V -> row update of C, workgroup barriers in between)
+        {
+            double* cs = s_gram + 2 * 64 * 65;            // (c, s) per pair of the current round
+            const int Kq = (K + 1) & ~1, npair = Kq / 2;
+            for (int sw = 0; sw < 12; ++sw) {
+                if (tid == 0) s_rot = 0;
+                __syncthreads();
+                for (int r = 0; r < Kq - 1; ++r) {
+                    if (tid < npair) {
+                        int p, q;
+                        if (tid == 0) { p = Kq - 1; q = r; } else { p = (r + tid) % (Kq - 1); q = (r - tid + (Kq - 1)) % (Kq - 1); }
+                        if (p > q) { const int t = p; p = q; q = t; }
+                        double c = 1.0, sn = 0.0;
+                        if (q < K) {
+                            const double cpq = C[p][q], cpp = C[p][p], cqq = C[q][q];
+                            if (fabs(cpq) > 1e-15 * sqrt(fabs(cpp * cqq)) && cpq != 0.0) {
+                                const double theta = (cqq - cpp) / (2.0 * cpq);
+                                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
+                                c = 1.0 / sqrt(1.0 + t * t);
+                                sn = c * t;
+                                s_rot = 1;
+                            }
                         }
-                        __builtin_amdgcn_s_waitcnt(0xc07f);
-                        for (int k = lane; k < K; k += 64) {
-                            const double cpk = C[p][k], cqk = C[q][k];
-                            C[p][k] = c * cpk - s * cqk;
-                            C[q][k] = s * cpk + c * cqk;
-                        }
-                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        cs[2 * tid] = c; cs[2 * tid + 1] = sn;
                     }
-                if (off <= 1e-14 * dia) break;
+                    __syncthreads();
+                    for (int e = tid; e < npair * K; e += 512) {          // columns p,q of C and V
+                        const int m = e / K, k = e - m * K;
+                        int p, q;
+                        if (m == 0) { p = Kq - 1; q = r; } else { p = (r + m) % (Kq - 1); q = (r - m + (Kq - 1)) % (Kq - 1); }
+                        if (p > q) { const int t = p; p = q; q = t; }
+                        if (q >= K) continue;
+                        const double c = cs[2 * m], sn = cs[2 * m + 1];
+                        const double ckp = C[k][p], ckq = C[k][q];
+                        C[k][p] = c * ckp - sn * ckq;
+                        C[k][q] = sn * ckp + c * ckq;
+                        const double vkp = V[k][p], vkq = V[k][q];
+                        V[k][p] = c * vkp - sn * vkq;
+                        V[k][q] = sn * vkp + c * vkq;
+                    }
+                    __syncthreads();
+                    for (int e = tid; e < npair * K; e += 512) {          // rows p,q of C
+                        const int m = e / K, k = e - m * K;
+                        int p, q;
+                        if (m == 0) { p = Kq - 1; q = r; } else { p = (r + m) % (Kq - 1); q = (r - m + (Kq - 1)) % (Kq - 1); }
+                        if (p > q) { const int t = p; p = q; q = t; }
+                        if (q >= K) continue;
+                        const double c = cs[2 * m], sn = cs[2 * m + 1];
+                        const double cpk = C[p][k], cqk = C[q][k];
+                        C[p][k] = c * cpk - sn * cqk;
+                        C[q][k] = sn * cpk + c * cqk;
+                    }
+                    __syncthreads();
+                }
+                const int any = s_rot;
+                __syncthreads();
+                if (!any) break;
             }
         }
-        __syncthreads();
-        for (int g = tid; g < G; g += 512) {              // A[:, g] <- V^T A[:, g]   (column j of A V = sum_i V[i][j] a_i)
+        if (tid == 0 && sweeps_out) sweeps_out[2] = (int)(wall_clock64() - t_dbg0);
+        // A[:, g] <- V^T A[:, g]: lane = gene, the gene's K values in registers, V broadcast from LDS
+        for (int g0 = wave * 64; g0 < G; g0 += 512) {
+            const int g = g0 + lane;
             double av[64];
-            for (int i = 0; i < K; ++i) av[i] = A[(size_t)i * G + g];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) av[i] = (i < K && g < G) ? A[(size_t)i * G + g] : 0.0;
             for (int j = 0; j < K; ++j) {
                 double acc = 0.0;
-                for (int i = 0; i < K; ++i) acc = fma(V[i][j], av[i], acc);
-                A[(size_t)j * G + g] = acc;
+#pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    if (i < K) acc = fma(V[i][j], av[i], acc);
+                if (g < G) A[(size_t)j * G + g] = acc;
             }
         }
         __syncthreads();
     }
+    if (tid == 0 && sweeps_out) sweeps_out[3] = (int)(wall_clock64() - t_dbg0);
     const int Kp = (K + 1) & ~1;          // even number of players (one dummy if K is odd)
     const int n_pairs = Kp / 2, n_rounds = Kp - 1;
     int sweep = 0;
@@ -212,6 +248,7 @@ __global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __re
         __syncthreads();
         if (!any) break;
     }
+    if (tid == 0 && sweeps_out) sweeps_out[4] = (int)(wall_clock64() - t_dbg0);
     // squared singular values
     for (int j = wave; j < K; j += 8) {
         double a2 = 0.0;
@@ -234,14 +271,14 @@ __global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __re
     double total = 0.0;
     for (int w = 0; w < 8; ++w) total += s_red[w];
     for (int g = tid; g < G; g += 512) lev[g] = lev[g] / (total + reg);
-    if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+    if (tid == 0 && sweeps_out) { *sweeps_out = sweep; sweeps_out[5] = (int)(wall_clock64() - t_dbg0); }
 }
 
 // X: device (K, G) row-major; work: device K*G doubles; sig2: device K doubles; lev: device G doubles
 int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
                     hipStream_t st) {
     if (K <= 0 || G <= 0) return fail(FDX_ERR_INVALID, "leverage: empty reference matrix");
-    constexpr size_t kLevLds = 2 * 64 * 65 * sizeof(double);
+    constexpr size_t kLevLds = (2 * 64 * 65 + 64) * sizeof(double);   // Gram matrix, rotations, per-round (c, s) pairs
     FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));
     FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));
     FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));
