@@ -97,6 +97,19 @@ def alg_bytes(n, G, K, s_y, nnz, n_slices_width_rows, T):
     return sketch, sweep
 
 
+def pmc_traffic(kernel, shape):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE of this same command, gfx950 correction applied); None for other workloads."""
+    if shape != (1_000_000, 2000, 30, 512):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return int(k["hbm_bytes_corrected"]) if k else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
     from flashdeconv_amd import FlashDeconv
     model = FlashDeconv(**model_kw)
@@ -179,14 +192,20 @@ def main():
         sweep_ms = stage["sweep_ms"] / max(T, 1)
         sk_ms = stage["sketch_ms"]
         dom = "bcd_sweep" if stage["sweep_ms"] >= sk_ms else "sketch_rows"
-        ach = (sw_bytes / (sweep_ms * 1e-3) if dom == "bcd_sweep" else sk_bytes / (sk_ms * 1e-3)) / 1e9
+        n_chunks = -(-n // (1 << 18))                 # the sketch kernel is launched once per 262144-row chunk (fit.cpp)
+        if dom == "bcd_sweep":
+            bytes_launch, ms_launch = sw_bytes, sweep_ms
+            kname = "fdx::bcd_sweep_tiled_kernel<%d, 8, false>" % K
+        else:
+            bytes_launch, ms_launch = sk_bytes / n_chunks, sk_ms / n_chunks
+            kname = "fdx::sketch_rows_reg_kernel<float, %d, true, 40>" % (0 if fam == "gaussian" else 1)
+        ach = bytes_launch / (ms_launch * 1e-3) / 1e9
         results[fam] = {
             "value": n * steps / dt, "ms_per_step": dt / steps * 1e3, "n_iterations": T, "converged": model.info_["converged"],
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                         "alg_bytes_per_launch": sw_bytes if dom == "bcd_sweep" else sk_bytes,
-                         "ms_per_launch": round(sweep_ms if dom == "bcd_sweep" else sk_ms, 4)},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, (n, G, K, d)),
+                         "alg_bytes_per_launch": int(bytes_launch), "ms_per_launch": round(ms_launch, 4)},
             "steps": steps,
         }
         del Y, coords, model
