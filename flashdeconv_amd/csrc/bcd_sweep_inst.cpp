@@ -36,6 +36,7 @@
 
 namespace fdx {
 
+// cell types per chunk (8: measured best at K=30 on MI355X; 10 costs a wave of occupancy)
 constexpr int sweep_chunk(int K) { return K < 8 ? K : 8; }
 
 template <int K, int KC>
@@ -164,6 +165,15 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
     const double lam_deg = lambda * (double)dg;
     const double lam_eff = (dg > 0) ? lambda : 0.0;
     const int hidx0 = (tid < Ht) ? halo[tid] : 0;
+    // tile-local neighbour slots of this spot: the first 16 live in registers for all chunks (two 16-bit slots per VGPR),
+    // wider slices (rare) read the rest from memory
+    unsigned slots[8];
+#pragma unroll
+    for (int m2 = 0; m2 < 8; ++m2) {
+        const unsigned lo = (2 * m2 < w) ? (unsigned)ell[(size_t)(2 * m2) * 64] : 0u;
+        const unsigned hi = (2 * m2 + 1 < w) ? (unsigned)ell[(size_t)(2 * m2 + 1) * 64] : 0u;
+        slots[m2] = lo | (hi << 16);
+    }
 
     double dmax = 0.0, amax = 0.0;
     double o_cross = 0.0, o_quad = 0.0, o_spat = 0.0, o_l1 = 0.0;
@@ -189,8 +199,16 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
         double c[KC];
 #pragma unroll
         for (int q = 0; q < KC; ++q) c[q] = 0.0;
-#pragma unroll 2
-        for (int m = 0; m < w; ++m) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < w) {                                   // wave-uniform
+                const int slot = (int)((slots[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+#pragma unroll
+                for (int q = 0; q < KC; ++q)
+                    if (kc + q < K) c[q] += lds[q * S + slot];
+            }
+        }
+        for (int m = 16; m < w; ++m) {
             const int slot = ell[(size_t)m * 64];
 #pragma unroll
             for (int q = 0; q < KC; ++q)
