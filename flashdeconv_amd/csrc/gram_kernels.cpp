@@ -11,6 +11,9 @@
 // plane (128-byte segments of the type-major H).  Within a 16-wide block of the contraction index, lane (r, q=l>>4)
 // loads the 4 CONSECUTIVE doubles 4q..4q+3 of row r (full 128-byte lines per row per wave) and MFMA step s
 // contracts {s, 4+s, 8+s, 12+s} - any order works as long as A and B agree.
+#include <algorithm>
+#include <cstdlib>
+
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
 
@@ -91,6 +94,75 @@ __global__ __launch_bounds__(256) void xyt_kernel(const double* __restrict__ Xs,
     }
 }
 
+// Split-d variant for the large contraction H = X_s Y_s^T (n >> K): a workgroup of 8 waves walks 16-spot tiles; wave v
+// owns the slice [v*16*NB, (v+1)*16*NB) of the contraction index and keeps ITS slice of X_sketch (the MFMA A operands of
+// all T type tiles) in registers for the whole kernel, so X_sketch is read once per workgroup instead of once per tile
+// (the plain kernel above re-reads it from L2 for every 16 spots: 2x the Y_sketch bytes).  Per tile each wave streams its
+// 16 x 16*NB block of Y_sketch (full 128-byte lines), issues NB*T*4 MFMAs, and the 8 partial accumulators are summed in
+// a fixed order through LDS (deterministic).  Requires d % 16 == 0, d <= 128*NB, K <= 16*T, 32-byte aligned rows.
+template <int NB, int T>
+__global__ __launch_bounds__(512) void xyt_split_kernel(const double* __restrict__ Xs, const double* __restrict__ Ys,
+                                                        long long ldy, int n, int d, int K, double* __restrict__ Hout,
+                                                        long long ldh) {
+    __shared__ double red[2][8][T * 4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    double a[NB][T][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int c0 = (wave * NB + b) * 16 + 4 * q;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int type = t * 16 + r;
+            const bool ok = type < K && c0 < d;
+            const double4_t v = ok ? *reinterpret_cast<const double4_t*>(Xs + (size_t)type * d + c0) : double4_t{0.0, 0.0, 0.0, 0.0};
+            a[b][t][0] = v.x; a[b][t][1] = v.y; a[b][t][2] = v.z; a[b][t][3] = v.w;
+        }
+    }
+    const int n_tiles = (n + 15) / 16;
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        const int s0 = tile * 16;
+        const int spot = s0 + r;
+        const bool spot_ok = spot < n;
+        const double* yrow = Ys + (size_t)(spot_ok ? spot : (n - 1)) * ldy;
+        double4_t acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+        double4_t bv[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c0 = (wave * NB + b) * 16 + 4 * q;
+            bv[b] = (c0 < d) ? *reinterpret_cast<const double4_t*>(yrow + c0) : double4_t{0.0, 0.0, 0.0, 0.0};
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double x[4] = {bv[b].x, bv[b].y, bv[b].z, bv[b].w};
+            if (!spot_ok) { x[0] = x[1] = x[2] = x[3] = 0.0; }
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b][t][s], x[s], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[buf][wave][(t * 4 + rr) * 64 + lane] = acc[t][rr];
+        __syncthreads();
+        for (int o = tid; o < T * 4 * 64; o += 512) {
+            double sum = 0.0;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) sum += red[buf][v][o];
+            const int l = o & 63, tr = o >> 6;
+            const int type = (tr >> 2) * 16 + (l >> 4) + 4 * (tr & 3);
+            const int sp = s0 + (l & 15);
+            if (type < K && sp < n) Hout[(size_t)type * ldh + sp] = sum;
+        }
+        // the other buffer is used by the next tile; a tile's buffer is reused two tiles later, after another barrier
+    }
+}
+
 // Deterministic sum of `count` doubles by one workgroup: fixed strided partial sums, fixed tree.
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const double* __restrict__ in, long long count,
                                                             double* __restrict__ out, int n_out, long long stride) {
@@ -153,6 +225,24 @@ int launch_xyt(const double* Xs, const double* Ys, long long ldy, long long n, i
     if (n > 0x7fffff00LL) return fail(FDX_ERR_UNSUPPORTED, "launch_xyt: n too large");
     const long long waves = (n + 15) / 16;
     const int blocks = (int)((waves + 3) / 4);
+    {   // large-n fast path: X_sketch register-resident, contraction split over 8 waves
+        const bool ok = !sumsq_partials && (d % 16 == 0) && d <= 1024 && K <= 32 && (ldy % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(Xs) & 31) == 0) && ((reinterpret_cast<uintptr_t>(Ys) & 31) == 0) &&
+                        !getenv("FDX_XYT_PLAIN");
+        if (ok) {
+            const int nb = (d + 127) / 128;             // 16-wide blocks per wave
+            const int T = (K + 15) / 16;
+            const int grid = (int)std::min<long long>(waves, 256LL * 2);
+#define FDX_XYT_SPLIT(NB_, T_) hipLaunchKernelGGL((xyt_split_kernel<NB_, T_>), dim3(grid), dim3(512), 0, st, Xs, Ys, ldy, (int)n, d, K, Hout, ldh)
+            if (nb <= 1) { if (T == 1) FDX_XYT_SPLIT(1, 1); else FDX_XYT_SPLIT(1, 2); }
+            else if (nb <= 2) { if (T == 1) FDX_XYT_SPLIT(2, 1); else FDX_XYT_SPLIT(2, 2); }
+            else if (nb <= 4) { if (T == 1) FDX_XYT_SPLIT(4, 1); else FDX_XYT_SPLIT(4, 2); }
+            else { if (T == 1) FDX_XYT_SPLIT(8, 1); else FDX_XYT_SPLIT(8, 2); }
+#undef FDX_XYT_SPLIT
+            FDX_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const bool aligned = (d % 16 == 0) && (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(Xs) & 31) == 0) &&
                          ((reinterpret_cast<uintptr_t>(Ys) & 31) == 0);
     if (aligned)
