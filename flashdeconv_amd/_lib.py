@@ -62,6 +62,8 @@ GRAPH_KNN, GRAPH_RADIUS, GRAPH_GIVEN = 0, 1, 2
 SIGNATURES = {
     "fdx_column_sums_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_void_p]),
     "fdx_leverage_scores": (c_int, [p_double, c_i32, c_i32, c_double, p_double]),
+    "fdx_leverage_begin": (c_int, [p_double, c_i32, c_i32, c_double, ctypes.POINTER(c_void_p)]),
+    "fdx_leverage_end": (c_int, [c_void_p, p_double]),
     "fdx_fit_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
                             c_i32, ctypes.POINTER(FitParams), ctypes.POINTER(c_void_p), c_void_p, c_void_p, p_double,
                             p_double, ctypes.POINTER(FitInfo), c_void_p]),

@@ -8,6 +8,7 @@ Inputs may be NumPy arrays, SciPy sparse matrices, or CUDA (HIP) ``torch`` tenso
 ``output="torch"`` the fitted arrays stay on the device as well.
 """
 import ctypes
+import time
 
 import numpy as np
 from scipy import sparse
@@ -206,7 +207,7 @@ class FlashDeconv:
             G = len(gene_idx)
             log(f"  Selected {G} genes (HVG + markers)")
             Xsel = np.ascontiguousarray(X[:, gene_idx])
-            leverage = _genes.compute_leverage_scores(Xsel)
+            lev_job = _genes.LeverageJob(Xsel)     # side stream; collected after the graph build below
             if G != G_all:                          # Y[:, gene_idx] (core/deconv.py:321) as a compact device matrix
                 sub = _DeviceBuffer(n * G * (4 if y_code == _lib.FDX_F32 else 8))
                 owned.append(sub)
@@ -225,6 +226,20 @@ class FlashDeconv:
                 owned.append(cbuf)
                 c_ptr = cbuf.ptr
             dim = int(coords.shape[1])
+
+            # Step 4 runs here, under the leverage SVD (no data dependence between core/deconv.py:318 and :358)
+            t_graph = time.perf_counter()
+            g_method, g_k, g_radius = self._graph_request(coords, coords_host)
+            if self._graph is not None:
+                self._graph.close()
+                self._graph = None
+            self._adjacency = None
+            gh = ctypes.c_void_p()
+            _lib.check(lib.fdx_graph_build_dev(c_ptr, n, dim, g_method, g_k, g_radius, None, ctypes.byref(gh)))
+            self._graph = _lib.Graph(gh.value)
+            t_lev = time.perf_counter()
+            leverage = lev_job.result()
+            t_done = time.perf_counter()
 
             # Step 2+3 tables: preprocessing mode and CountSketch Omega (core/deconv.py:326-352)
             log(f"Step 2: Preprocessing with method='{self.preprocess}'...")
@@ -257,18 +272,8 @@ class FlashDeconv:
             prm.lambda_auto = 1 if self.lambda_spatial == "auto" else 0
             prm.lambda_spatial = 0.0 if prm.lambda_auto else float(self.lambda_spatial)
             prm.radius = 0.0
+            prm.graph_method = _lib.GRAPH_GIVEN
             log("Step 4: Building spatial graph...")
-            if self.spatial_method == "knn":
-                prm.graph_method = _lib.GRAPH_KNN
-            elif self.spatial_method == "radius":
-                prm.graph_method, prm.radius = _lib.GRAPH_RADIUS, float(self.radius)
-            else:   # "grid": radius = 1.5 x median nearest-neighbour distance (utils/graph.py:163-170)
-                if n <= 1:
-                    prm.graph_method, prm.k_neighbors = _lib.GRAPH_KNN, 0
-                else:
-                    from ..utils.graph import grid_radius
-                    ch = coords_host if coords_host is not None else coords.detach().cpu().numpy()
-                    prm.graph_method, prm.radius = _lib.GRAPH_RADIUS, grid_radius(ch)
 
             if output == "torch":
                 import torch
@@ -284,18 +289,13 @@ class FlashDeconv:
             objs = np.zeros(max(int(self.max_iter), 1), dtype=np.float64)
             rels = np.zeros(max(int(self.max_iter), 1), dtype=np.float64)
             info = _lib.FitInfo()
-            gh = ctypes.c_void_p()
+            gh = ctypes.c_void_p(self._graph.handle.value)
             bucket32 = np.ascontiguousarray(bucket, dtype=np.int32)
             wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
-            if self._graph is not None:
-                self._graph.close()
-                self._graph = None
-            self._adjacency = None
             _lib.check(lib.fdx_fit_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(Xsel), K, _lib.ptr_i32(bucket32),
                                        _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim, ctypes.byref(prm),
                                        ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs), _lib.ptr_f64(rels),
                                        ctypes.byref(info), None))
-            self._graph = _lib.Graph(gh.value)
             if output == "torch":
                 self.beta_, self.proportions_ = beta_t, prop_t
             else:
@@ -327,11 +327,30 @@ class FlashDeconv:
         # additive diagnostics (not in the reference): per-stage GPU milliseconds
         self.timings_ = {k: float(getattr(info, k)) for k in ("graph_ms", "sketch_ms", "gram_ms", "solve_ms", "finish_ms", "total_ms")}
         self.timings_["sweep_ms"] = float(info.solve.sweep_ms)
+        # host wall of the graph build call, and of the wait for the leverage SVD that ran beside it
+        self.timings_["graph_ms"] = (t_lev - t_graph) * 1e3
+        self.timings_["leverage_wait_ms"] = (t_done - t_lev) * 1e3
         self._fitted = True
         log(f"  Converged: {self.info_['converged']}")
         log(f"  Iterations: {self.info_['n_iterations']}")
         log("FlashDeconv: Done!")
         return self
+
+    def _graph_request(self, coords, coords_host):
+        """(method, k, radius) of the graph build for this model's spatial_method (utils/graph.py:175-212)."""
+        if self.spatial_method == "knn":
+            return _lib.GRAPH_KNN, int(self.k_neighbors), 0.0
+        if self.spatial_method == "radius":
+            if self.radius is None:
+                raise ValueError("radius must be specified for radius method")
+            return _lib.GRAPH_RADIUS, 0, float(self.radius)
+        if self.spatial_method == "grid":  # radius = 1.5 x median nearest-neighbour distance (utils/graph.py:163-170)
+            if coords.shape[0] < 2:
+                return _lib.GRAPH_KNN, 0, 0.0
+            from ..utils.graph import grid_radius
+            ch = coords_host if coords_host is not None else coords.detach().cpu().numpy()
+            return _lib.GRAPH_RADIUS, 0, grid_radius(ch)
+        raise ValueError(f"Unknown method: {self.spatial_method}. Choose from 'knn', 'radius', 'grid'.")
 
     def fit_transform(self, Y, X, coords, **kwargs):
         self.fit(Y, X, coords, **kwargs)

@@ -58,26 +58,90 @@ int build_csc_from_tables(const int32_t* bucket, const double* weight, int G, in
 
 }  // namespace
 
+// The Jacobi SVD runs in ONE workgroup, so it occupies one CU for ~1.6 ms while the other 255 idle.  begin/end let the
+// caller put the spatial-graph build (many short, latency-bound kernels on the caller's stream) under it: the job runs
+// on a library-owned non-blocking side stream.
+struct fdx_leverage_job {
+    DevBuf dX, dW, dS, dL, dDbg;
+    std::vector<double> hX;   // the caller may drop X once begin returns
+    int K = 0, G = 0;
+    hipStream_t st = nullptr;
+};
+
+namespace {
+hipStream_t leverage_side_stream() {
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!streams[dev]) {
+        // A priority of its own keeps the side stream off the hardware queue the caller's streams share (HIP multiplexes
+        // same-priority streams over a few queues; with RCCL's streams around, aliasing with the caller's stream
+        // serialised the SVD with the graph build).
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, hi) != hipSuccess &&
+            hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess)
+            streams[dev] = nullptr;
+    }
+    return streams[dev];
+}
+}  // namespace
+
+extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double regularization, fdx_leverage_job** out) {
+    FDX_REQUIRE(X && out && K > 0 && G > 0, "fdx_leverage_begin: bad arguments");
+    *out = nullptr;
+    auto* job = new fdx_leverage_job();
+    job->K = K;
+    job->G = G;
+    job->st = leverage_side_stream();
+    auto run = [&]() -> int {
+        FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
+        FDX_TRY(job->dW.alloc((size_t)K * G * sizeof(double)));
+        FDX_TRY(job->dS.alloc((size_t)K * sizeof(double)));
+        FDX_TRY(job->dL.alloc((size_t)G * sizeof(double)));
+        FDX_TRY(job->dDbg.alloc(8 * sizeof(int)));
+        job->hX.assign(X, X + (size_t)K * G);
+        FDX_HIP(hipMemcpyAsync(job->dX.p, job->hX.data(), (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, job->st));
+        FDX_TRY(launch_leverage(job->dX.as<double>(), K, G, regularization, job->dW.as<double>(), job->dS.as<double>(),
+                                job->dL.as<double>(), job->dDbg.as<int>(), job->st));
+        return 0;
+    };
+    const int rc = run();
+    if (rc) {
+        (void)hipStreamSynchronize(job->st);
+        delete job;
+        return rc;
+    }
+    *out = job;
+    return 0;
+}
+
+extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) {
+    FDX_REQUIRE(job != nullptr, "fdx_leverage_end: null job");
+    int rc = 0;
+    int dbg[8] = {0};
+    auto run = [&]() -> int {
+        FDX_REQUIRE(lev_out != nullptr, "fdx_leverage_end: null output");
+        FDX_HIP(hipMemcpyAsync(lev_out, job->dL.p, (size_t)job->G * sizeof(double), hipMemcpyDeviceToHost, job->st));
+        FDX_HIP(hipMemcpyAsync(dbg, job->dDbg.p, sizeof(dbg), hipMemcpyDeviceToHost, job->st));
+        return 0;
+    };
+    rc = run();
+    const hipError_t e = hipStreamSynchronize(job->st);   // always drain before the buffers go back to the pool
+    if (!rc && e != hipSuccess) rc = fail(FDX_ERR_HIP, hipGetErrorString(e));
+    if (!rc && getenv("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
+        std::fprintf(stderr, "[fdx] leverage: K=%d G=%d sweeps=%d  us: gram=%d eigen=%d apply=%d polish=%d end=%d\n", job->K, job->G,
+                     dbg[0], dbg[1] / 100, (dbg[2] - dbg[1]) / 100, (dbg[3] - dbg[2]) / 100, (dbg[4] - dbg[3]) / 100,
+                     (dbg[5] - dbg[4]) / 100);
+    delete job;
+    return rc;
+}
+
 extern "C" int fdx_leverage_scores(const double* X, int32_t K, int32_t G, double regularization, double* lev_out) {
     FDX_REQUIRE(X && lev_out && K > 0 && G > 0, "fdx_leverage_scores: bad arguments");
-    hipStream_t st = nullptr;
-    DevBuf dX, dW, dS, dL;
-    FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
-    FDX_TRY(dW.alloc((size_t)K * G * sizeof(double)));
-    FDX_TRY(dS.alloc((size_t)K * sizeof(double)));
-    FDX_TRY(dL.alloc((size_t)G * sizeof(double)));
-    FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
-    DevBuf dDbg;
-    FDX_TRY(dDbg.alloc(8 * sizeof(int)));
-    FDX_TRY(launch_leverage(dX.as<double>(), K, G, regularization, dW.as<double>(), dS.as<double>(), dL.as<double>(), dDbg.as<int>(), st));
-    FDX_HIP(hipMemcpyAsync(lev_out, dL.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
-    int dbg[8] = {0};
-    FDX_HIP(hipMemcpyAsync(dbg, dDbg.p, sizeof(dbg), hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
-    if (getenv("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
-        std::fprintf(stderr, "[fdx] leverage: K=%d G=%d sweeps=%d  us: gram=%d eigen=%d apply=%d polish=%d end=%d\n", K, G, dbg[0],
-                     dbg[1] / 100, (dbg[2] - dbg[1]) / 100, (dbg[3] - dbg[2]) / 100, (dbg[4] - dbg[3]) / 100, (dbg[5] - dbg[4]) / 100);
-    return 0;
+    fdx_leverage_job* job = nullptr;
+    FDX_TRY(fdx_leverage_begin(X, K, G, regularization, &job));
+    return fdx_leverage_end(job, lev_out);
 }
 
 extern "C" int fdx_column_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy,

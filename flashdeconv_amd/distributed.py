@@ -16,6 +16,8 @@ One-off all-reduces (SUM): YtY and the four objective partials.  Everything else
 the same loop runs on GPUs (HipBackend + torch.distributed/nccl) and in the CPU tests (oracle sweep + gloo).
 """
 import ctypes
+import os
+import time
 
 import numpy as np
 
@@ -192,11 +194,31 @@ class ShardedFlashDeconv:
         self.max_iter, self.tol, self.preprocess, self.random_state = max_iter, tol, preprocess, random_state
         self.comm = TorchComm(group)
         self._full = self._local = None
+        self.timings_ = {}
+        self._profile = bool(os.environ.get("FDX_DIST_TIMING"))
 
-    def plan(self, coords):
-        """Build the (replicated) spatial graph, cut it into shards, return the caller's ids of this rank's spots."""
+    def _tick(self, name, t0):
+        """Stage timing for tools/dist_probe.py (FDX_DIST_TIMING=1: synchronises, so only for diagnosis)."""
+        if not self._profile:
+            return t0
         import torch
+        torch.cuda.current_stream().synchronize()      # this stream only: the leverage side stream keeps running
+        t1 = time.perf_counter()
+        self.timings_[name] = self.timings_.get(name, 0.0) + (t1 - t0) * 1e3
+        return t1
+
+    def plan(self, coords, X=None):
+        """Build the (replicated) spatial graph, cut it into shards, return the caller's ids of this rank's spots.
+        With the signatures X given, their leverage SVD (one workgroup, side stream) runs under the graph build and
+        the next fit_transform(Y_own, X) collects it."""
+        import torch
+        from .utils.genes import LeverageJob
         lib = _lib.load()
+        self._lev_job = None
+        if X is not None:
+            Xj = np.ascontiguousarray(X, dtype=np.float64)
+            if Xj.shape[1] <= self.n_hvg:
+                self._lev_job = (Xj, LeverageJob(Xj))
         assert coords.is_cuda and coords.dtype == torch.float64
         coords = coords.contiguous()
         n, dim = coords.shape
@@ -204,11 +226,13 @@ class ShardedFlashDeconv:
         for g in (self._local, self._full):
             if g is not None:
                 g.close()
+        t0 = time.perf_counter()
         h = ctypes.c_void_p()
         method = _lib.GRAPH_KNN if self.spatial_method == "knn" else _lib.GRAPH_RADIUS
         _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, method, int(self.k_neighbors),
                                            float(self.radius or 0.0), st, ctypes.byref(h)))
         self._full = _lib.Graph(h.value)
+        t0 = self._tick("plan_build", t0)
         self.n_total_spots = n
         self.nnz_total = self._full.info()[1]
         self.bounds = shard_bounds(n, self.comm.world)
@@ -216,6 +240,7 @@ class ShardedFlashDeconv:
         _lib.check(lib.fdx_graph_localize(self._full.handle, self.comm.world, _lib.ptr_i64(self.bounds), self.comm.rank, st,
                                           ctypes.byref(hl)))
         self._local = _lib.Graph(hl.value)
+        t0 = self._tick("plan_localize", t0)
         self.n_own = int(self.bounds[self.comm.rank + 1] - self.bounds[self.comm.rank])
         perm = torch.empty(max(self.n_own, 1), dtype=torch.int32, device=coords.device)
         _lib.check(lib.fdx_graph_perm_dev(self._local.handle, ctypes.c_void_p(perm.data_ptr()), st))
@@ -228,6 +253,7 @@ class ShardedFlashDeconv:
         sidx = torch.empty(max(int(sc.sum()), 1), dtype=torch.int32, device=coords.device)
         _lib.check(lib.fdx_graph_send_indices_dev(self._local.handle, ctypes.c_void_p(sidx.data_ptr()), st))
         self._halo = HaloExchange(self.comm, self.n_own, sidx[:int(sc.sum())].long(), sc, rc)
+        self._tick("plan_lists", t0)
         return self.own_ids
 
     def fit_transform(self, Y_own, X):
@@ -245,7 +271,13 @@ class ShardedFlashDeconv:
             Y_own = Y_own.to(torch.float32)
         Y_own = Y_own.contiguous()
         assert Y_own.shape == (self.n_own, G)
-        lev = compute_leverage_scores(X)
+        t0 = time.perf_counter()
+        job, self._lev_job = getattr(self, "_lev_job", None), None
+        if job is not None and job[0].shape == X.shape and np.array_equal(job[0], X):
+            lev = job[1].result()
+        else:
+            lev = compute_leverage_scores(X)
+        t0 = self._tick("leverage", t0)
         bucket, weight = countsketch_tables(G, self.sketch_dim, lev, self.random_state)
         weight_y = weight_x = weight
         mode_y = mode_x = _lib.PRE_RAW
@@ -264,6 +296,7 @@ class ShardedFlashDeconv:
             weight_x = weight / np.sqrt(mu_x + mu_x ** 2 / 100.0)
         elif self.preprocess != "raw":
             raise ValueError(f"Unknown preprocess method: {self.preprocess}. Choose from 'log_cpm', 'pearson', or 'raw'.")
+        t0 = self._tick("tables", t0)
         n_own, n_total = self.n_own, self.n_own + self.n_halo
         ld = ((n_total + 1 + 63) // 64) * 64
         H = torch.zeros((K, ld), dtype=torch.float64, device=dev)
@@ -276,6 +309,7 @@ class ShardedFlashDeconv:
                                        n_own, G, G, None, _lib.ptr_f64(X), K, _lib.ptr_i32(b32), _lib.ptr_f64(wy), _lib.ptr_f64(wx),
                                        int(self.sketch_dim), mode_y, mode_x, ctypes.c_void_p(H.data_ptr()), ld,
                                        ctypes.c_void_p(XtX.data_ptr()), _lib.ptr_f64(XtX_h), ctypes.byref(yty), st))
+        t0 = self._tick("prepare", t0)
         t = torch.tensor([yty.value], dtype=torch.float64, device=dev)
         self.comm.all_reduce_sum(t)
         YtY = float(t.item())
@@ -285,9 +319,11 @@ class ShardedFlashDeconv:
         else:
             lam = float(self.lambda_spatial)
         rho_eff = float(self.rho_sparsity) * dmean                            # core/solver.py:359-360
+        t0 = self._tick("scalars", t0)
         backend = HipBackend(self._local, H, ld, XtX, K)
         solver = ShardedSolver(backend, self.comm, self._halo, K, ld, n_own, n_total, self.max_iter, self.tol)
         beta, info = solver.run(lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev), lam, rho_eff)
+        t0 = self._tick("solve", t0)
         part = torch.from_numpy(backend.objective_partials(beta)).to(dev)
         self.comm.all_reduce_sum(part)
         c = part.cpu().numpy()
@@ -298,6 +334,7 @@ class ShardedFlashDeconv:
         _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(beta.data_ptr()), ld, n_own, K, ctypes.c_void_p(self.beta_.data_ptr()),
                                          ctypes.c_void_p(self.proportions_.data_ptr()), st))
         torch.cuda.current_stream().synchronize()
+        self._tick("finish", t0)
         self.lambda_used_, self.info_ = lam, info
         return self.proportions_
 
@@ -328,7 +365,7 @@ def bench_main(a, rank, world, local_rank):
     Xh = X.cpu().numpy()
 
     def step():
-        model.plan(coords)
+        model.plan(coords, Xh)
         model.fit_transform(Y, Xh)
 
     for _ in range(a.warmup):

@@ -5,6 +5,8 @@
     select_hvg                <- utils/genes.py:18-145   (per-gene moments on the GPU, binning of the G-vector on the host)
     select_informative_genes  <- utils/genes.py:293-341
 """
+import ctypes
+
 import numpy as np
 from scipy import sparse
 
@@ -18,6 +20,34 @@ def compute_leverage_scores(X, regularization=1e-6):
     _lib.require_gpu()
     _lib.check(_lib.load().fdx_leverage_scores(_lib.ptr_f64(X), K, G, float(regularization), _lib.ptr_f64(lev)))
     return lev
+
+
+class LeverageJob:
+    """compute_leverage_scores split in two: the constructor enqueues the single-workgroup SVD on a side stream,
+    ``result()`` waits for it.  FlashDeconv.fit builds the spatial graph in between."""
+
+    def __init__(self, X, regularization=1e-6):
+        X = _lib.as_f64(X)
+        self.G = X.shape[1]
+        _lib.require_gpu()
+        self._job = ctypes.c_void_p()
+        _lib.check(_lib.load().fdx_leverage_begin(_lib.ptr_f64(X), X.shape[0], X.shape[1], float(regularization),
+                                                  ctypes.byref(self._job)))
+
+    def result(self):
+        if self._job is None:
+            raise RuntimeError("leverage job already collected")
+        lev = np.empty(self.G, dtype=np.float64)
+        job, self._job = self._job, None
+        _lib.check(_lib.load().fdx_leverage_end(job, _lib.ptr_f64(lev)))
+        return lev
+
+    def __del__(self):
+        if getattr(self, "_job", None) is not None:
+            try:
+                self.result()
+            except Exception:
+                pass
 
 
 def select_markers(X, n_markers=50, method="diff"):

@@ -87,6 +87,13 @@ int fdx_gather_columns_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t 
 /* X is the HOST (K, G) row-major reference signature matrix restricted to the selected genes; lev_out (G) receives
  * the normalised leverage scores.  One-sided Jacobi SVD of the centred G x K matrix on the device. */
 int fdx_leverage_scores(const double* X, int32_t K, int32_t G, double regularization, double* lev_out);
+/* Split form: begin enqueues the job on a library-owned side stream and returns; end waits, copies the scores to
+ * lev_out and frees the job.  The kernel is a single workgroup, so a caller can build the spatial graph on its own
+ * stream between the two calls (core/deconv.py:305-318 and :358 have no data dependence).  X may be released after
+ * begin returns. */
+typedef struct fdx_leverage_job fdx_leverage_job;
+int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double regularization, fdx_leverage_job** job);
+int fdx_leverage_end(fdx_leverage_job* job, double* lev_out);
 
 /* ---- spatial graph (replaces utils/graph.py:25-212 and the CSR handling of core/solver.py:363-365) ---- */
 typedef struct fdx_graph fdx_graph;
