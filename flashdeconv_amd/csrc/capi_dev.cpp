@@ -182,9 +182,7 @@ int fdx_objective_partials_dev(const fdx_graph* g, const double* beta_dev, int64
     const int nblk = objective_partials_count(g->n_slices);
     FDX_TRY(part.alloc((size_t)nblk * 4 * sizeof(double)));
     FDX_TRY(out.alloc(4 * sizeof(double)));
-    FDX_TRY(launch_objective_partials(beta_dev, ld, H_dev, ldh, XtX_dev, g->ell.as<int>(), g->slice_off.as<int>(),
-                                      g->deg.as<int>(), (int)g->n, g->n_slices, K, part.as<double>(), st));
-    FDX_TRY(launch_sum_partials(part.as<double>(), nblk, out.as<double>(), 4, 4, st));
+    FDX_TRY(solver_objective_partials(*g, beta_dev, ld, H_dev, ldh, XtX_dev, K, part.as<double>(), out.as<double>(), st));
     FDX_HIP(hipMemcpyAsync(out4_host, out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
     return 0;

@@ -26,17 +26,16 @@ int solver_init_beta(double* beta, long long ld, long long n_fill, int K, hipStr
     return 0;
 }
 
-int solver_objective(const fdx_graph& g, const double* beta, long long ld, const double* H, long long ldh,
-                     const double* XtX, int K, double YtY, double lambda, double rho_eff, double* scratch_partials,
-                     double* scratch_out4, double* obj_host, hipStream_t st) {
-    // compute_objective (core/solver.py:269-284)
+int solver_objective_partials(const fdx_graph& g, const double* beta, long long ld, const double* H, long long ldh,
+                              const double* XtX, int K, double* scratch_partials, double* out4_dev, hipStream_t st) {
+    // the four sums of compute_objective (core/solver.py:269-284): <H,beta>, beta' XtX beta, smoothness, |beta|_1
     int nblk = objective_partials_count(g.n_slices);
     int rc_t = 1;
     if (g.tiled && !getenv("FDX_NO_TILED")) {          // same LDS-tiled traversal as the sweep (n_tiles <= nblk partial rows)
         BcdSweepArgs a{};
         a.H = H; a.XtX = XtX; a.beta_in = beta; a.beta_out = nullptr; a.ell = g.ell.as<int>();
         a.slice_off = g.slice_off.as<int>(); a.deg = g.deg.as<int>(); a.stats = nullptr; a.rel_change = nullptr;
-        a.lambda = lambda; a.rho = rho_eff; a.tol = 0.0; a.ldh = (int)ldh; a.ld = (int)ld; a.n = (int)g.n;
+        a.lambda = 0.0; a.rho = 0.0; a.tol = 0.0; a.ldh = (int)ldh; a.ld = (int)ld; a.n = (int)g.n;
         a.n_slices = g.n_slices; a.K = K; a.tiled = 1; a.ell_local = g.ell_local.as<unsigned short>();
         a.tile_halo = g.tile_halo.as<int>(); a.tile_hcnt = g.tile_hcnt.as<int>(); a.n_tiles = g.n_tiles; a.halo_max = g.halo_max;
         rc_t = launch_bcd_objective_tiled(a, scratch_partials, st);
@@ -46,7 +45,13 @@ int solver_objective(const fdx_graph& g, const double* beta, long long ld, const
     if (rc_t != 0)
         FDX_TRY(launch_objective_partials(beta, ld, H, ldh, XtX, g.ell.as<int>(), g.slice_off.as<int>(), g.deg.as<int>(),
                                           (int)g.n, g.n_slices, K, scratch_partials, st));
-    FDX_TRY(launch_sum_partials(scratch_partials, nblk, scratch_out4, 4, 4, st));
+    return launch_sum_partials(scratch_partials, nblk, out4_dev, 4, 4, st);
+}
+
+int solver_objective(const fdx_graph& g, const double* beta, long long ld, const double* H, long long ldh,
+                     const double* XtX, int K, double YtY, double lambda, double rho_eff, double* scratch_partials,
+                     double* scratch_out4, double* obj_host, hipStream_t st) {
+    FDX_TRY(solver_objective_partials(g, beta, ld, H, ldh, XtX, K, scratch_partials, scratch_out4, st));
     double r[4];
     FDX_HIP(hipMemcpyAsync(r, scratch_out4, sizeof(r), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
