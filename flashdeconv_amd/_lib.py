@@ -48,6 +48,12 @@ class FitParams(ctypes.Structure):
     ]
 
 
+class CsrView(ctypes.Structure):
+    """fdx_csr_view: device pointers of a CSR matrix (include/fdx.h)."""
+    _fields_ = [("indptr", c_void_p), ("indices", c_void_p), ("data", c_void_p), ("dtype", c_i32), ("n", c_i64),
+                ("nnz", c_i64), ("G", c_i32)]
+
+
 class FitInfo(ctypes.Structure):
     _fields_ = [
         ("solve", SolveInfo), ("lambda_used", c_double), ("rho_effective", c_double), ("YtY", c_double), ("nnz", c_i64),
@@ -62,6 +68,11 @@ GRAPH_KNN, GRAPH_RADIUS, GRAPH_GIVEN = 0, 1, 2
 SIGNATURES = {
     "fdx_column_sums_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_void_p]),
     "fdx_leverage_scores": (c_int, [p_double, c_i32, c_i32, c_double, p_double]),
+    "fdx_csr_check_dev": (c_int, [ctypes.POINTER(CsrView), c_void_p]),
+    "fdx_csr_gene_moments_dev": (c_int, [ctypes.POINTER(CsrView), p_double, p_double, p_double, c_void_p]),
+    "fdx_fit_csr_dev": (c_int, [ctypes.POINTER(CsrView), p_i32, c_i32, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
+                                c_i32, ctypes.POINTER(FitParams), ctypes.POINTER(c_void_p), c_void_p, c_void_p, p_double,
+                                p_double, ctypes.POINTER(FitInfo), c_void_p]),
     "fdx_leverage_begin": (c_int, [p_double, c_i32, c_i32, c_double, ctypes.POINTER(c_void_p)]),
     "fdx_leverage_end": (c_int, [c_void_p, p_double]),
     "fdx_fit_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
@@ -261,3 +272,102 @@ class Graph:
             self.close()
         except Exception:
             pass
+
+
+class CsrOnDevice:
+    """A CSR spot matrix resident in HBM (int64 indptr, int32 column indices, f32/f64 values) and its fdx_csr_view.
+
+    Built from a scipy.sparse matrix (uploaded: bytes proportional to the stored entries) or from a CUDA
+    ``torch.sparse_csr`` tensor (zero-copy when its index dtypes already match).  Structure is validated on the device
+    once (fdx_csr_check_dev) so that no kernel ever indexes with an out-of-range column."""
+
+    def __init__(self):
+        self._owned, self._keep = [], []
+        self.view = CsrView()
+
+    @staticmethod
+    def _value_dtype(data):
+        if data.dtype == np.float32:
+            return np.float32
+        if data.dtype == np.float64:
+            return np.float64
+        if data.dtype.kind in "iub" and (data.size == 0 or float(np.abs(data).max()) < 2.0 ** 24):
+            return np.float32                       # counts: exact in float32
+        return np.float64
+
+    @classmethod
+    def from_scipy(cls, Y):
+        lib = load()
+        if Y.format != "csr":
+            Y = Y.tocsr()
+        n, G = Y.shape
+        if G >= 2 ** 31:
+            raise ValueError("CSR matrix has too many columns")
+        indptr = np.ascontiguousarray(Y.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(Y.indices, dtype=np.int32)
+        data = np.ascontiguousarray(Y.data, dtype=cls._value_dtype(Y.data))
+        self = cls()
+        ptrs = []
+        for arr in (indptr, indices, data):
+            p = c_void_p()
+            check(lib.fdx_malloc(ctypes.byref(p), max(arr.nbytes, 8)))
+            self._owned.append(p)
+            if arr.nbytes:
+                check(lib.fdx_memcpy_h2d(p, arr.ctypes.data, arr.nbytes, None))
+            ptrs.append(p)
+        self._fill(ptrs[0].value, ptrs[1].value, ptrs[2].value, FDX_F32 if data.dtype == np.float32 else FDX_F64, n,
+                   int(indptr[-1]) if len(indptr) else 0, G)
+        return self
+
+    @classmethod
+    def from_torch(cls, Y):
+        import torch
+        n, G = Y.shape
+        crow = Y.crow_indices().to(torch.int64).contiguous()
+        col = Y.col_indices().to(torch.int32).contiguous()
+        val = Y.values()
+        if val.dtype not in (torch.float32, torch.float64):
+            val = val.to(torch.float32)
+        val = val.contiguous()
+        self = cls()
+        self._keep = [crow, col, val]
+        self._fill(crow.data_ptr(), col.data_ptr(), val.data_ptr(), FDX_F32 if val.dtype == torch.float32 else FDX_F64,
+                   n, int(val.numel()), G)
+        return self
+
+    def _fill(self, indptr, indices, data, dtype, n, nnz, G):
+        v = self.view
+        v.indptr, v.indices, v.data, v.dtype, v.n, v.nnz, v.G = indptr, indices, data, dtype, int(n), int(nnz), int(G)
+        try:
+            check(load().fdx_csr_check_dev(ctypes.byref(v), None))
+        except Exception:
+            self.free()
+            raise
+
+    def gene_moments(self):
+        """(mean, var, colsum) per column: utils/genes.py:52-83 and the raw column sums."""
+        G = self.view.G
+        mean, var, colsum = np.empty(G), np.empty(G), np.empty(G)
+        check(load().fdx_csr_gene_moments_dev(ctypes.byref(self.view), ptr_f64(mean), ptr_f64(var), ptr_f64(colsum), None))
+        return mean, var, colsum
+
+    def free(self):
+        lib = load()
+        for p in self._owned:
+            if p is not None and p.value:
+                lib.fdx_free(p)
+        self._owned, self._keep = [], []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def is_torch_sparse_csr(x):
+    try:
+        import torch
+    except Exception:
+        return False
+    return isinstance(x, torch.Tensor) and x.layout == torch.sparse_csr and x.is_cuda

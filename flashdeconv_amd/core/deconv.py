@@ -172,7 +172,13 @@ class FlashDeconv:
         try:
             if G_all == 0:
                 raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
-            if _is_torch_cuda(Y):
+            csr = None
+            if sparse.issparse(Y) or _lib.is_torch_sparse_csr(Y):
+                # sparse stays sparse in HBM: gene statistics, log-CPM and the sketch read the stored entries only
+                csr = _lib.CsrOnDevice.from_scipy(Y) if sparse.issparse(Y) else _lib.CsrOnDevice.from_torch(Y)
+                owned.append(csr)
+                y_ptr, y_code, y_sparse_rule = None, csr.view.dtype, True
+            elif _is_torch_cuda(Y):
                 import torch
                 if Y.dtype not in (torch.float32, torch.float64):
                     Y = Y.to(torch.float32)
@@ -180,24 +186,22 @@ class FlashDeconv:
                 y_ptr, y_code = ctypes.c_void_p(Y.data_ptr()), (_lib.FDX_F32 if Y.dtype == torch.float32 else _lib.FDX_F64)
                 y_sparse_rule = False
             else:
-                y_sparse_rule = sparse.issparse(Y)
-                if y_sparse_rule:
-                    if Y.shape[0] * Y.shape[1] > (1 << 33):
-                        raise NotImplementedError("sparse input this large needs the CSR kernels (next hot-path row)")
-                    Yh = np.asarray(Y.todense())      # interim: CSR kernel is the next hot-path row
-                else:
-                    Yh = np.asarray(Y)
-                Yh, y_code = _lib.as_device_matrix(Yh)
+                y_sparse_rule = False
+                Yh, y_code = _lib.as_device_matrix(np.asarray(Y))
                 ybuf = _DeviceBuffer.from_host(Yh)
                 owned.append(ybuf)
                 y_ptr = ybuf.ptr
+            csr_colsum = None
             log("Step 1: Selecting informative genes...")
             if G_all <= self.n_hvg:
                 # select_hvg returns every gene when the matrix has no more than n_hvg of them and the marker union is a
                 # subset (utils/genes.py:135-145, 330) - no pass over Y needed.
                 gene_idx = np.arange(G_all, dtype=np.intp)
             else:
-                mean, var = _genes.gene_moments_device(y_ptr, y_code, n, G_all, G_all)
+                if csr is not None:
+                    mean, var, csr_colsum = csr.gene_moments()
+                else:
+                    mean, var = _genes.gene_moments_device(y_ptr, y_code, n, G_all, G_all)
                 hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
                 markers, _ = _genes.select_markers(X, n_markers=self.n_markers_per_type)
                 gene_idx = np.union1d(hvg, markers).astype(np.intp)                  # utils/genes.py:330
@@ -208,7 +212,7 @@ class FlashDeconv:
             log(f"  Selected {G} genes (HVG + markers)")
             Xsel = np.ascontiguousarray(X[:, gene_idx])
             lev_job = _genes.LeverageJob(Xsel)     # side stream; collected after the graph build below
-            if G != G_all:                          # Y[:, gene_idx] (core/deconv.py:321) as a compact device matrix
+            if G != G_all and csr is None:          # Y[:, gene_idx] (core/deconv.py:321) as a compact device matrix
                 sub = _DeviceBuffer(n * G * (4 if y_code == _lib.FDX_F32 else 8))
                 owned.append(sub)
                 gi32 = np.ascontiguousarray(gene_idx, dtype=np.int32)
@@ -251,8 +255,13 @@ class FlashDeconv:
                 mode_x = _lib.PRE_LOG_CPM
                 log("  Y and X normalized to log-CPM space")
             elif self.preprocess == "pearson":
-                sums = np.empty(G, dtype=np.float64)
-                _lib.check(lib.fdx_column_sums_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(sums), None))
+                if csr is not None:
+                    if csr_colsum is None:
+                        _, _, csr_colsum = csr.gene_moments()
+                    sums = csr_colsum[gene_idx]
+                else:
+                    sums = np.empty(G, dtype=np.float64)
+                    _lib.check(lib.fdx_column_sums_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(sums), None))
                 mu_y = sums / n + 1e-6                                        # core/deconv.py:208,214
                 mu_x = Xsel.mean(axis=0) + 1e-6                               # core/deconv.py:220
                 weight_y = weight / np.sqrt(mu_y + mu_y ** 2 / 100.0)         # sigma^2 = mu + mu^2/theta, theta = 100
@@ -292,10 +301,17 @@ class FlashDeconv:
             gh = ctypes.c_void_p(self._graph.handle.value)
             bucket32 = np.ascontiguousarray(bucket, dtype=np.int32)
             wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
-            _lib.check(lib.fdx_fit_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(Xsel), K, _lib.ptr_i32(bucket32),
-                                       _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim, ctypes.byref(prm),
-                                       ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs), _lib.ptr_f64(rels),
-                                       ctypes.byref(info), None))
+            if csr is not None:
+                gi32 = np.ascontiguousarray(gene_idx, dtype=np.int32)
+                _lib.check(lib.fdx_fit_csr_dev(ctypes.byref(csr.view), _lib.ptr_i32(gi32), G, _lib.ptr_f64(Xsel), K,
+                                               _lib.ptr_i32(bucket32), _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim,
+                                               ctypes.byref(prm), ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs),
+                                               _lib.ptr_f64(rels), ctypes.byref(info), None))
+            else:
+                _lib.check(lib.fdx_fit_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(Xsel), K, _lib.ptr_i32(bucket32),
+                                           _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim, ctypes.byref(prm),
+                                           ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs), _lib.ptr_f64(rels),
+                                           ctypes.byref(info), None))
             if output == "torch":
                 self.beta_, self.proportions_ = beta_t, prop_t
             else:

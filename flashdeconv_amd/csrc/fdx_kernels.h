@@ -91,6 +91,18 @@ int launch_leverage(const double* X, int K, int G, double reg, double* work, dou
 }  // namespace fdx
 
 namespace fdx {
+// ---- CSR spot matrix (csr_kernels.cpp)
+int launch_sketch_csr(const long long* indptr, const int* indices, const void* data, int dtype, const int* row_map,
+                      long long row0, long long n, int d, int mode, const void* table, double* Ys, long long ldys,
+                      double* row_sumsq, hipStream_t st);
+size_t csr_gene_slot_bytes();
+int csr_moment_copies();
+int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, int G,
+                       double* sums, double* mean, double* var, double* colsum, hipStream_t st);
+int launch_csr_check(const long long* indptr, const int* indices, long long n, long long nnz, int G, int* flag, hipStream_t st);
+}  // namespace fdx
+
+namespace fdx {
 // ---- gene statistics / column gather (sketch_kernels.cpp)
 int launch_gene_moments(const void* Y, int dtype, long long ldy, long long n, int G, double* scale, double* partials,
                         double* mean, double* var, hipStream_t st);

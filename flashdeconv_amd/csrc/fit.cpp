@@ -158,18 +158,38 @@ extern "C" int fdx_column_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, 
     return 0;
 }
 
-extern "C" int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_t ldy, const double* X, int32_t K,
-                           const int32_t* bucket, const double* weight_y, const double* weight_x, const double* coords_dev,
-                           int32_t dim, const fdx_fit_params* prm, fdx_graph** graph_inout, double* beta_out_dev,
-                           double* prop_out_dev, double* objectives_out, double* rel_changes_out, fdx_fit_info* info,
-                           void* stream) {
+namespace {
+
+// Where the spot rows come from: a dense (n, G) device matrix, or a CSR matrix over G_all columns of which gene_idx
+// (host, G entries; NULL = all columns in order) are the selected genes.
+struct YSource {
+    const void* dense = nullptr;
+    int32_t dtype = FDX_F32;
+    int64_t ldy = 0;
+    const fdx_csr_view* csr = nullptr;
+    const int32_t* gene_idx = nullptr;
+};
+
+struct GeneSlotHost {   // layout of csr_kernels.cpp's GeneSlot
+    double w;
+    int bucket;
+    int pad;
+};
+
+int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t K, const int32_t* bucket,
+             const double* weight_y, const double* weight_x, const double* coords_dev, int32_t dim,
+             const fdx_fit_params* prm, fdx_graph** graph_inout, double* beta_out_dev, double* prop_out_dev,
+             double* objectives_out, double* rel_changes_out, fdx_fit_info* info, void* stream) {
     FDX_REQUIRE(info != nullptr && prm != nullptr && graph_inout != nullptr, "fdx_fit_dev: null argument");
     std::memset(info, 0, sizeof(*info));
+    const void* Y_dev = ysrc.dense;
+    const int32_t y_dtype = ysrc.csr ? ysrc.csr->dtype : ysrc.dtype;
+    const int64_t ldy = ysrc.ldy;
     FDX_REQUIRE(y_dtype == FDX_F32 || y_dtype == FDX_F64, "fdx_fit_dev: Y dtype must be FDX_F32 or FDX_F64");
     FDX_REQUIRE(n > 0 && G > 0 && K > 0, "fdx_fit_dev: empty problem");
     FDX_REQUIRE(n < 0x7fffff00LL, "fdx_fit_dev: n too large for one device");
-    FDX_REQUIRE(ldy >= G, "fdx_fit_dev: ldy < G");
-    FDX_REQUIRE(Y_dev && X && bucket && weight_y && weight_x, "fdx_fit_dev: null array");
+    FDX_REQUIRE(ysrc.csr || ldy >= G, "fdx_fit_dev: ldy < G");
+    FDX_REQUIRE((Y_dev || ysrc.csr) && X && bucket && weight_y && weight_x, "fdx_fit_dev: null array");
     const int d = prm->sketch_dim;
     FDX_REQUIRE(d > 0, "fdx_fit_dev: sketch_dim must be positive");
     FDX_REQUIRE(prm->max_iter >= 0, "fdx_fit_dev: max_iter must be non-negative");
@@ -199,7 +219,23 @@ extern "C" int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_
     std::vector<double> wy, wx;
     FDX_TRY(build_csc_from_tables(bucket, weight_y, G, d, &col_ptr, &gene_idx, &wy));
     SketchPlan plan_y, plan_x;
-    FDX_TRY(plan_y.build(col_ptr.data(), gene_idx.data(), wy.data(), G, d, st));
+    DevBuf dSlots;               // CSR source: per-column {weight, bucket} table over all G_all columns
+    if (ysrc.csr) {
+        const int G_all = ysrc.csr->G;
+        FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(GeneSlotHost), "fit: gene slot layout mismatch");
+        std::vector<GeneSlotHost> slots((size_t)G_all, GeneSlotHost{0.0, -1, 0});
+        for (int j = 0; j < G; ++j) {
+            const int c = ysrc.gene_idx ? ysrc.gene_idx[j] : j;
+            FDX_REQUIRE(c >= 0 && c < G_all, "fdx_fit_csr_dev: gene index out of range");
+            FDX_REQUIRE(slots[(size_t)c].bucket < 0, "fdx_fit_csr_dev: duplicate gene index");
+            slots[(size_t)c] = GeneSlotHost{weight_y[j], bucket[j], 0};
+        }
+        FDX_TRY(dSlots.alloc(slots.size() * sizeof(GeneSlotHost)));
+        FDX_HIP(hipMemcpyAsync(dSlots.p, slots.data(), slots.size() * sizeof(GeneSlotHost), hipMemcpyHostToDevice, st));
+        FDX_HIP(hipStreamSynchronize(st));   // `slots` is a stack-scoped host buffer
+    } else {
+        FDX_TRY(plan_y.build(col_ptr.data(), gene_idx.data(), wy.data(), G, d, st));
+    }
     {
         std::vector<long long> cp2;
         std::vector<int> gi2;
@@ -242,10 +278,16 @@ extern "C" int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_
             const long long nr = std::min(chunk, n - r0);
             if (ci < n_timed) FDX_HIP(hipEventRecord(ev[(size_t)ci * 3], st));
             // with a row map the chunk gathers rows perm[r0..]; without one it reads rows r0.. of Y directly
-            const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
-            if (!row_map) ybase += (size_t)r0 * (size_t)ldy * (y_dtype == FDX_F32 ? 4 : 8);
-            FDX_TRY(launch_sketch_rows(ybase, y_dtype, ldy, row_map ? row_map + r0 : nullptr, nr, G, d, prm->mode_y,
-                                       plan_y.dev(), dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
+            if (ysrc.csr) {
+                FDX_TRY(launch_sketch_csr((const long long*)ysrc.csr->indptr, ysrc.csr->indices, ysrc.csr->data, y_dtype,
+                                          row_map ? row_map + r0 : nullptr, r0, nr, d, prm->mode_y, dSlots.p,
+                                          dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
+            } else {
+                const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
+                if (!row_map) ybase += (size_t)r0 * (size_t)ldy * (y_dtype == FDX_F32 ? 4 : 8);
+                FDX_TRY(launch_sketch_rows(ybase, y_dtype, ldy, row_map ? row_map + r0 : nullptr, nr, G, d, prm->mode_y,
+                                           plan_y.dev(), dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
+            }
             if (ci < n_timed) FDX_HIP(hipEventRecord(ev[(size_t)ci * 3 + 1], st));
             FDX_TRY(launch_xyt(dXs.as<double>(), dYs.as<double>(), d, nr, d, K, dH.as<double>() + r0, ld, nullptr, st));
             if (ci < n_timed) FDX_HIP(hipEventRecord(ev[(size_t)ci * 3 + 2], st));
@@ -317,4 +359,77 @@ extern "C" int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_
     if (rel_changes_out)
         for (size_t t = 0; t < r.rel_changes.size(); ++t) rel_changes_out[t] = r.rel_changes[t];
     return 0;
+}
+
+}  // namespace
+
+extern "C" int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_t ldy, const double* X, int32_t K,
+                           const int32_t* bucket, const double* weight_y, const double* weight_x, const double* coords_dev,
+                           int32_t dim, const fdx_fit_params* prm, fdx_graph** graph_inout, double* beta_out_dev,
+                           double* prop_out_dev, double* objectives_out, double* rel_changes_out, fdx_fit_info* info,
+                           void* stream) {
+    FDX_REQUIRE(Y_dev != nullptr, "fdx_fit_dev: null array");
+    YSource ys;
+    ys.dense = Y_dev;
+    ys.dtype = y_dtype;
+    ys.ldy = ldy;
+    return fit_impl(ys, n, G, X, K, bucket, weight_y, weight_x, coords_dev, dim, prm, graph_inout, beta_out_dev, prop_out_dev,
+                    objectives_out, rel_changes_out, info, stream);
+}
+
+static int csr_view_ok(const fdx_csr_view* Y, const char* who) {
+    FDX_REQUIRE(Y != nullptr, std::string(who) + ": null matrix");
+    FDX_REQUIRE(Y->n >= 0 && Y->nnz >= 0 && Y->G > 0, std::string(who) + ": bad CSR shape");
+    FDX_REQUIRE(Y->indptr != nullptr && (Y->nnz == 0 || (Y->indices && Y->data)), std::string(who) + ": null CSR array");
+    FDX_REQUIRE(Y->dtype == FDX_F32 || Y->dtype == FDX_F64, std::string(who) + ": dtype must be FDX_F32 or FDX_F64");
+    return 0;
+}
+
+extern "C" int fdx_csr_check_dev(const fdx_csr_view* Y, void* stream) {
+    FDX_TRY(csr_view_ok(Y, "fdx_csr_check_dev"));
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf flag;
+    FDX_TRY(flag.alloc(sizeof(int)));
+    FDX_TRY(launch_csr_check((const long long*)Y->indptr, Y->indices, Y->n, Y->nnz, Y->G, flag.as<int>(), st));
+    int bad = 0;
+    FDX_HIP(hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    FDX_REQUIRE(bad == 0, "CSR matrix is malformed (indptr not monotone from 0 to nnz, or a column index outside [0, G))");
+    return 0;
+}
+
+extern "C" int fdx_csr_gene_moments_dev(const fdx_csr_view* Y, double* mean_out_host, double* var_out_host,
+                                        double* colsum_out_host, void* stream) {
+    FDX_TRY(csr_view_ok(Y, "fdx_csr_gene_moments_dev"));
+    FDX_REQUIRE(Y->n > 0, "fdx_csr_gene_moments_dev: empty matrix");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t G = (size_t)Y->G;
+    DevBuf sums, out;
+    FDX_TRY(sums.alloc((size_t)csr_moment_copies() * 3 * G * sizeof(double)));
+    FDX_TRY(out.alloc(3 * G * sizeof(double)));
+    double* o = out.as<double>();
+    FDX_TRY(launch_csr_moments((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, Y->n, Y->G, sums.as<double>(), o,
+                               o + G, o + 2 * G, st));
+    if (mean_out_host) FDX_HIP(hipMemcpyAsync(mean_out_host, o, G * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (var_out_host) FDX_HIP(hipMemcpyAsync(var_out_host, o + G, G * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (colsum_out_host) FDX_HIP(hipMemcpyAsync(colsum_out_host, o + 2 * G, G * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int fdx_fit_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t G, const double* X, int32_t K,
+                               const int32_t* bucket, const double* weight_y, const double* weight_x,
+                               const double* coords_dev, int32_t dim, const fdx_fit_params* prm, fdx_graph** graph_inout,
+                               double* beta_out_dev, double* prop_out_dev, double* objectives_out, double* rel_changes_out,
+                               fdx_fit_info* info, void* stream) {
+    FDX_TRY(csr_view_ok(Y, "fdx_fit_csr_dev"));
+    FDX_REQUIRE(gene_idx != nullptr || G == Y->G, "fdx_fit_csr_dev: gene_idx may be NULL only when G equals the matrix width");
+    FDX_REQUIRE(prm != nullptr, "fdx_fit_csr_dev: null argument");
+    FDX_REQUIRE(prm->mode_y == FDX_PRE_RAW || prm->mode_y == FDX_PRE_LOG_CPM_SPARSE,
+                "fdx_fit_csr_dev: mode_y must be FDX_PRE_RAW or FDX_PRE_LOG_CPM_SPARSE");
+    YSource ys;
+    ys.csr = Y;
+    ys.gene_idx = gene_idx;
+    return fit_impl(ys, Y->n, G, X, K, bucket, weight_y, weight_x, coords_dev, dim, prm, graph_inout, beta_out_dev,
+                    prop_out_dev, objectives_out, rel_changes_out, info, stream);
 }

@@ -89,11 +89,14 @@ def gene_moments_device(y_ptr, y_code, n, G, ldy):
 
 
 def _gene_moments(Y):
-    import ctypes
-    if sparse.issparse(Y):
-        if Y.shape[0] * Y.shape[1] > (1 << 32):
-            raise NotImplementedError("sparse matrices this large need the CSR kernels (next hot-path row); densify a subset")
-        Y = np.asarray(Y.todense())
+    if sparse.issparse(Y) or _lib.is_torch_sparse_csr(Y):      # sparse branch (utils/genes.py:52-83) on the CSR arrays
+        _lib.require_gpu()
+        csr = _lib.CsrOnDevice.from_scipy(Y) if sparse.issparse(Y) else _lib.CsrOnDevice.from_torch(Y)
+        try:
+            mean, var, _ = csr.gene_moments()
+        finally:
+            csr.free()
+        return mean, var
     Yh, code = _lib.as_device_matrix(Y)
     _lib.require_gpu()
     lib = _lib.load()

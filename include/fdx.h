@@ -181,6 +181,36 @@ int fdx_fit_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_
                 int32_t dim, const fdx_fit_params* params, fdx_graph** graph_inout, double* beta_out_dev,
                 double* prop_out_dev, double* objectives_out, double* rel_changes_out, fdx_fit_info* info, void* stream);
 
+/* ---- CSR (sparse) spot matrix on the device --------------------------------------------------------------- *
+ * The reference accepts scipy.sparse Y and keeps it sparse through gene statistics, log-CPM and the sketch product
+ * (utils/genes.py:52-83, core/deconv.py:181-188, core/sketching.py:194-199).  A view holds DEVICE pointers of a
+ * canonical CSR matrix with G columns: indptr int64[n+1], indices int32[nnz], data dtype[nnz].                    */
+typedef struct fdx_csr_view {
+    const int64_t* indptr;
+    const int32_t* indices;
+    const void* data;
+    int32_t dtype;           /* FDX_F32 or FDX_F64 */
+    int64_t n;
+    int64_t nnz;
+    int32_t G;
+} fdx_csr_view;
+
+/* Structure check (monotone indptr from 0 to nnz, columns inside [0, G)); call once after an upload, before any
+ * kernel indexes with the arrays.  FDX_ERR_INVALID with a message on violation. */
+int fdx_csr_check_dev(const fdx_csr_view* Y, void* stream);
+/* select_hvg statistics of the sparse branch (utils/genes.py:52-83): z = log1p(y * 1e4 / max(rowsum, 1)) on the stored
+ * entries, mean_g = sum z / n, var_g = n/(n-1) * (sum z^2 / n - mean_g^2) clipped at 0; colsum_g = sum y (the "pearson"
+ * means of core/deconv.py:207-212 are colsum / n).  HOST outputs of G doubles each; any may be NULL. */
+int fdx_csr_gene_moments_dev(const fdx_csr_view* Y, double* mean_out_host, double* var_out_host, double* colsum_out_host,
+                             void* stream);
+/* fdx_fit_dev for a CSR matrix.  gene_idx: HOST int32[G] selected columns of Y (Y[:, gene_idx], core/deconv.py:321;
+ * NULL = all G == Y->G columns); X, bucket, weight_y, weight_x are indexed by position in gene_idx as in fdx_fit_dev.
+ * params->mode_y must be FDX_PRE_RAW or FDX_PRE_LOG_CPM_SPARSE (library size over the selected genes, 0 -> 1). */
+int fdx_fit_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t G, const double* X, int32_t K,
+                    const int32_t* bucket, const double* weight_y, const double* weight_x, const double* coords_dev,
+                    int32_t dim, const fdx_fit_params* params, fdx_graph** graph_inout, double* beta_out_dev,
+                    double* prop_out_dev, double* objectives_out, double* rel_changes_out, fdx_fit_info* info, void* stream);
+
 /* ---- device-pointer building blocks (spot-sharded multi-GPU driver, flashdeconv_amd/distributed.py) ------- *
  * One process per GPU; the host side (torch.distributed over RCCL) owns the buffers and the halo exchange, these
  * entry points only enqueue kernels on `stream`.  Same reference lines as the single-GPU entries above.           */

@@ -342,6 +342,21 @@ def golden_fits():
     save("fit_gauss_800x2000x20.npz", **o)
 
 
+def golden_fits_sparse():
+    """CSR input with gene selection active: the sparse branches of select_hvg (utils/genes.py:52-83), of log-CPM
+    (core/deconv.py:181-188) and of project_to_sketch (core/sketching.py:194-199) in one fit.  ~94 % zeros."""
+    print("sparse: count-like 300x900x5 CSR, n_hvg=250, n_markers=10, log_cpm and pearson")
+    Y, X, coords, B = datagen.count_like(300, 900, 5, 0.1, 9)
+    rs = np.random.RandomState(9)
+    Y = (Y * (rs.rand(*Y.shape) < 0.08)).astype(np.int32)          # thin the counts to a realistically sparse matrix
+    Y[7] = 0                                                        # an empty spot: library size 0 -> 1
+    Ys = sparse.csr_matrix(Y.astype(np.float64))
+    for pre in ("log_cpm", "pearson", "raw"):
+        o = run_fit_stages(Ys, X, coords, sketch_dim=64, preprocess=pre, n_hvg=250, n_markers=10, max_iter=30)
+        o.update(Y=Y, X=X, coords=coords)
+        save(f"fit_sparse_{pre}_300x900x5.npz", **o)
+
+
 def golden_objective():
     print("objective identity cases")
     out = {}
@@ -364,7 +379,8 @@ def golden_objective():
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(omega=golden_omega, leverage=golden_leverage, graphs=golden_graphs, solver=golden_solver,
-                objective=golden_objective, fits=golden_fits)
+                objective=golden_objective, fits=golden_fits,
+                fits_sparse=golden_fits_sparse)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -60,6 +60,50 @@ def test_fit_pearson(suffix):
     _check(m, g)
 
 
+@pytest.mark.parametrize("pre", ["log_cpm", "pearson", "raw"])
+@pytest.mark.parametrize("kind", ["scipy_f64", "scipy_i32", "csc", "torch_csr"])
+def test_fit_sparse_input_stays_sparse(pre, kind):
+    """CSR spot matrix, gene selection active, an empty spot: the device CSR kernels (csr_kernels.cpp) against the
+    reference's sparse branches (utils/genes.py:52-83, core/deconv.py:181-188, core/sketching.py:194-199)."""
+    import torch
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden(f"fit_sparse_{pre}_300x900x5.npz")
+    Yd = g["Y"]
+    if kind == "scipy_f64":
+        Y = sparse.csr_matrix(Yd.astype(np.float64))
+    elif kind == "scipy_i32":
+        Y = sparse.csr_matrix(Yd.astype(np.int32))
+    elif kind == "csc":
+        Y = sparse.csc_matrix(Yd.astype(np.float32))
+    else:
+        Y = torch.from_numpy(Yd.astype(np.float32)).cuda().to_sparse_csr()
+    m = FlashDeconv(sketch_dim=64, preprocess=pre, n_hvg=250, n_markers_per_type=10, max_iter=30).fit(Y, g["X"], g["coords"])
+    _check(m, g)
+
+
+def test_csr_gene_moments_and_validation():
+    from flashdeconv_amd import _lib
+    from flashdeconv_amd.utils import genes
+    rs = np.random.RandomState(3)
+    Yd = (rs.poisson(0.3, size=(500, 700)) * (rs.rand(500, 700) < 0.3)).astype(np.float64)
+    Yd[11] = 0
+    Y = sparse.csr_matrix(Yd)
+    csr = _lib.CsrOnDevice.from_scipy(Y)
+    mean, var, colsum = csr.gene_moments()
+    csr.free()
+    lib_size = np.maximum(Yd.sum(axis=1, keepdims=True), 1.0)
+    Z = np.log1p(Yd / lib_size * 1e4)
+    np.testing.assert_allclose(mean, Z.mean(axis=0), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(var, Z.var(axis=0, ddof=1), rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(colsum, Yd.sum(axis=0), rtol=1e-13)
+    assert np.array_equal(genes.select_hvg(Y, 100), genes.select_hvg(Yd, 100))
+    bad = sparse.csr_matrix(Yd)
+    bad.indices = bad.indices.copy()
+    bad.indices[5] = 700                                    # column out of range: rejected before any kernel uses it
+    with pytest.raises(_lib.FdxError, match="malformed"):
+        _lib.CsrOnDevice.from_scipy(bad)
+
+
 def test_fit_gauss_1000_config1_miniature():
     from flashdeconv_amd import FlashDeconv
     g = load_golden("fit_gauss_1000x2000x10.npz")

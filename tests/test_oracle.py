@@ -200,6 +200,16 @@ def test_fit_pearson(suffix):
     _check_fit(f"fit_pearson_120x300x4{suffix}.npz", Y, g["X"], g["coords"], sketch_dim=48, preprocess_method="pearson", max_iter=40)
 
 
+@pytest.mark.parametrize("pre", ["log_cpm", "pearson", "raw"])
+def test_fit_sparse_with_gene_selection(pre):
+    """CSR input, G > n_hvg: sparse branches of select_hvg, log-CPM (empty spot: library size 0 -> 1) and the sketch."""
+    name = f"fit_sparse_{pre}_300x900x5.npz"
+    g = load_golden(name)
+    Y = sparse.csr_matrix(g["Y"].astype(np.float64))
+    assert Y.nnz < 0.1 * Y.shape[0] * Y.shape[1] and Y[7].nnz == 0
+    _check_fit(name, Y, g["X"], g["coords"], sketch_dim=64, preprocess_method=pre, n_hvg=250, n_markers_per_type=10, max_iter=30)
+
+
 def test_fit_gauss_1000():
     g = load_golden("fit_gauss_1000x2000x10.npz")
     Y, X, coords, _ = datagen.gaussian_raw(1000, 2000, 10, seed=0)
