@@ -344,11 +344,13 @@ class CsrOnDevice:
             self.free()
             raise
 
-    def gene_moments(self):
-        """(mean, var, colsum) per column: utils/genes.py:52-83 and the raw column sums."""
+    def gene_moments(self, want_colsum=False):
+        """(mean, var, colsum) per column: utils/genes.py:52-83; colsum (raw column sums, for "pearson") on request."""
         G = self.view.G
-        mean, var, colsum = np.empty(G), np.empty(G), np.empty(G)
-        check(load().fdx_csr_gene_moments_dev(ctypes.byref(self.view), ptr_f64(mean), ptr_f64(var), ptr_f64(colsum), None))
+        mean, var = np.empty(G), np.empty(G)
+        colsum = np.empty(G) if want_colsum else None
+        check(load().fdx_csr_gene_moments_dev(ctypes.byref(self.view), ptr_f64(mean), ptr_f64(var),
+                                              ptr_f64(colsum) if want_colsum else None, None))
         return mean, var, colsum
 
     def free(self):

@@ -199,7 +199,7 @@ class FlashDeconv:
                 gene_idx = np.arange(G_all, dtype=np.intp)
             else:
                 if csr is not None:
-                    mean, var, csr_colsum = csr.gene_moments()
+                    mean, var, csr_colsum = csr.gene_moments(want_colsum=self.preprocess == "pearson")
                 else:
                     mean, var = _genes.gene_moments_device(y_ptr, y_code, n, G_all, G_all)
                 hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
@@ -257,7 +257,7 @@ class FlashDeconv:
             elif self.preprocess == "pearson":
                 if csr is not None:
                     if csr_colsum is None:
-                        _, _, csr_colsum = csr.gene_moments()
+                        _, _, csr_colsum = csr.gene_moments(want_colsum=True)
                     sums = csr_colsum[gene_idx]
                 else:
                     sums = np.empty(G, dtype=np.float64)

@@ -35,39 +35,98 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 }
 
 // MODE: FDX_PRE_RAW or FDX_PRE_LOG_CPM_SPARSE (the sparse rule is the only log-CPM rule for CSR input)
+//
+// A row is a chain of dependent hops (indptr -> indices -> table -> LDS), so the loop is software-pipelined: entries are
+// taken 4 x 64 at a time, and the loads of the NEXT group (and the extents of the NEXT row) are issued after the table
+// gathers of the current one - vector memory returns in order, so that placement lets the wave wait for its gathers
+// while the next group's loads stay in flight.
+template <typename T>
+struct CsrGroup {
+    int c[4];
+    T y[4];
+};
+
+template <typename T>
+__device__ __forceinline__ void csr_load_group(CsrGroup<T>& g, const int* __restrict__ indices, const T* __restrict__ data,
+                                               long long q0, long long end, int lane) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long q = q0 + u * 64 + lane;
+        const bool ok = q < end;
+        g.c[u] = ok ? indices[q] : -1;
+        g.y[u] = ok ? data[q] : (T)0;
+    }
+}
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void sketch_csr_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
                                                          const T* __restrict__ data, const int* __restrict__ row_map,
                                                          long long row0, long long n, int d,
-                                                         const GeneSlot* __restrict__ table, double* __restrict__ Ys,
-                                                         long long ldys, double* __restrict__ row_sumsq) {
+                                                         const GeneSlot* __restrict__ table,
+                                                         const unsigned* __restrict__ sel_bits, int sel_words,
+                                                         double* __restrict__ Ys, long long ldys,
+                                                         double* __restrict__ row_sumsq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_blk = blockDim.x >> 6;
     double* acc = reinterpret_cast<double*>(smem) + (size_t)wib * d;
+    // "is this column selected?" as a bitmap in LDS (G_all / 8 bytes): typically one stored entry in six belongs to a
+    // selected gene, and only those go on to the 16-byte table gather - a gather per stored entry made the kernel
+    // L2-request-bound (1.4e9 scattered 16-byte reads at 1M spots x 1438 entries).
+    unsigned* bits = reinterpret_cast<unsigned*>(smem + (size_t)waves_per_blk * d * sizeof(double));
+    for (int j = threadIdx.x; j < sel_words; j += blockDim.x) bits[j] = sel_bits[j];
+    __syncthreads();
     const long long wave0 = (long long)blockIdx.x * waves_per_blk + wib;
     const long long stride = (long long)gridDim.x * waves_per_blk;
+    long long beg = 0, end = 0;
+    if (wave0 < n) {
+        const long long row = row_map ? (long long)row_map[wave0] : row0 + wave0;
+        beg = indptr[row];
+        end = indptr[row + 1];
+    }
     for (long long p = wave0; p < n; p += stride) {
-        const long long row = row_map ? (long long)row_map[p] : row0 + p;
-        const long long beg = indptr[row], end = indptr[row + 1];
+        long long nbeg = 0, nend = 0;                                  // extents of this wave's next row, fetched early
+        if (p + stride < n) {
+            const long long nrow = row_map ? (long long)row_map[p + stride] : row0 + p + stride;
+            nbeg = indptr[nrow];
+            nend = indptr[nrow + 1];
+        }
         for (int c = lane; c < d; c += 64) acc[c] = 0.0;
         double scale = 1.0;
+        CsrGroup<T> cur, nxt;
         if (MODE != FDX_PRE_RAW) {      // library size over the SELECTED genes (the subset is taken first, deconv.py:321)
             double s = 0.0;
-            for (long long q = beg + lane; q < end; q += 64)
-                if (table[indices[q]].bucket >= 0) s += (double)data[q];
+            csr_load_group(cur, indices, data, beg, end, lane);
+            for (long long q0 = beg; q0 < end; q0 += 256) {
+                csr_load_group(nxt, indices, data, q0 + 256, end, lane);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u)) s += (double)cur.y[u];
+                cur = nxt;
+            }
             s = wave_sum(s);
             scale = 10000.0 / (s == 0.0 ? 1.0 : s);                    // deconv.py:183-185
         }
+        csr_load_group(cur, indices, data, beg, end, lane);
         __builtin_amdgcn_s_waitcnt(0xc07f);                            // zeroing done before the adds
-        for (long long q = beg + lane; q < end; q += 64) {
-            const GeneSlot e = table[indices[q]];
-            if (e.bucket >= 0) {
-                double y = (double)data[q];
-                if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
-                lds_add(acc + e.bucket, e.w * y);
+        for (long long q0 = beg; q0 < end; q0 += 256) {
+            GeneSlot e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                e[u].bucket = -1;
+                if (cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u)) e[u] = table[cur.c[u]];
             }
+            csr_load_group(nxt, indices, data, q0 + 256, end, lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e[u].bucket >= 0) {
+                    double v = (double)cur.y[u];
+                    if (MODE != FDX_PRE_RAW) v = fast_log1p(v * scale);
+                    lds_add(acc + e[u].bucket, e[u].w * v);
+                }
+            }
+            cur = nxt;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         double* dst = Ys + (size_t)p * ldys;
@@ -82,23 +141,25 @@ __global__ __launch_bounds__(256) void sketch_csr_kernel(const long long* __rest
             if (lane == 0) row_sumsq[p] = sq;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                            // reads of acc done before the next row zeroes it
+        beg = nbeg;
+        end = nend;
     }
 }
 
 template <typename T>
 static int launch_sketch_csr_t(const long long* indptr, const int* indices, const T* data, const int* row_map, long long row0,
-                               long long n, int d, int mode, const void* table, double* Ys, long long ldys,
-                               double* row_sumsq, hipStream_t st) {
+                               long long n, int d, int mode, const void* table, const unsigned* sel_bits, int sel_words,
+                               double* Ys, long long ldys, double* row_sumsq, hipStream_t st) {
     int waves = 4;
     while (waves > 1 && (size_t)d * 8 * waves > 64 * 1024) waves >>= 1;
-    const size_t lds = (size_t)d * 8 * waves;
-    if (lds > 160 * 1024) return fail(FDX_ERR_UNSUPPORTED, "sketch (CSR): sketch_dim does not fit in LDS");
+    const size_t lds = (size_t)d * 8 * waves + (size_t)sel_words * 4;
+    if (lds > 160 * 1024) return fail(FDX_ERR_UNSUPPORTED, "sketch (CSR): sketch_dim and the gene bitmap do not fit in LDS");
     const int blocks = (int)std::min<long long>((n + waves - 1) / waves, 256LL * 16);
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             FDX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, indptr, indices, data, row_map, row0, n, d,
-                           (const GeneSlot*)table, Ys, ldys, row_sumsq);
+                           (const GeneSlot*)table, sel_bits, sel_words, Ys, ldys, row_sumsq);
         FDX_CHECK_LAUNCH();
         return 0;
     };
@@ -108,86 +169,140 @@ static int launch_sketch_csr_t(const long long* indptr, const int* indices, cons
 }
 
 int launch_sketch_csr(const long long* indptr, const int* indices, const void* data, int dtype, const int* row_map,
-                      long long row0, long long n, int d, int mode, const void* table, double* Ys, long long ldys,
-                      double* row_sumsq, hipStream_t st) {
+                      long long row0, long long n, int d, int mode, const void* table, const unsigned* sel_bits,
+                      int sel_words, double* Ys, long long ldys, double* row_sumsq, hipStream_t st) {
     if (n <= 0 || d <= 0) return 0;
     if (dtype == FDX_F32)
-        return launch_sketch_csr_t<float>(indptr, indices, (const float*)data, row_map, row0, n, d, mode, table, Ys, ldys, row_sumsq, st);
+        return launch_sketch_csr_t<float>(indptr, indices, (const float*)data, row_map, row0, n, d, mode, table, sel_bits,
+                                          sel_words, Ys, ldys, row_sumsq, st);
     if (dtype == FDX_F64)
-        return launch_sketch_csr_t<double>(indptr, indices, (const double*)data, row_map, row0, n, d, mode, table, Ys, ldys, row_sumsq, st);
+        return launch_sketch_csr_t<double>(indptr, indices, (const double*)data, row_map, row0, n, d, mode, table, sel_bits,
+                                           sel_words, Ys, ldys, row_sumsq, st);
     return fail(FDX_ERR_INVALID, "sketch (CSR): dtype must be FDX_F32 or FDX_F64");
 }
 
 size_t csr_gene_slot_bytes() { return sizeof(GeneSlot); }
 
 // ------------------------------------------------------------------------------------------------ gene statistics
-// One wave per row: library size over all genes, then z = log1p(y * 1e4 / max(lib, 1)) for every stored entry and three
-// per-gene sums (z, z^2, y) with f64 atomics.  The sums live in `copies` replicas (block b adds into replica b % copies)
-// so the genes almost every spot expresses do not serialise the L2 atomic units on one address; the replicas are folded
-// in index order.  (Zeros contribute nothing to any of the three sums: genes.py:52-54.)
+// z = log1p(y * 1e4 / max(lib, 1)) for every stored entry, then per gene sum z, sum z^2 (and sum y for "pearson").
+// Per-gene sums over a row-major sparse matrix are a scatter; global f64 atomics on ~30k addresses run at ~30 G adds/s
+// on MI355X (measured: 143 ms for 1.4e9 entries), so the scatter goes to LDS instead: a block owns a TILE of genes
+// (all of its sums fit in 64 KB of LDS) and a stripe of rows, scans the stripe's column indices and adds the entries
+// that fall in its tile with ds_add_f64.  Entries of one row have distinct columns, so the 64 lanes of an add never
+// collide.  Every tile re-reads the stripe's indices (G/TILE passes over 4 bytes per entry) - that is the price, and
+// it is ~10x cheaper than the global atomics.  Stripe partials are folded in stripe order.
+// (Zeros contribute nothing to any of the sums: genes.py:52-54.)
 template <typename T>
-__global__ __launch_bounds__(256) void csr_moments_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
-                                                          const T* __restrict__ data, long long n, int G, int copies,
-                                                          double* __restrict__ sums /* (copies, 3, G) */) {
+__global__ __launch_bounds__(256) void csr_row_scale_kernel(const long long* __restrict__ indptr, const T* __restrict__ data,
+                                                            long long n, double* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n) return;
+    const long long beg = indptr[row], end = indptr[row + 1];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    long long q = beg + lane;
+    for (; q + 192 < end; q += 256) {
+        const double a = (double)data[q], b = (double)data[q + 64], c = (double)data[q + 128], e = (double)data[q + 192];
+        s0 += a; s1 += b; s2 += c; s3 += e;
+    }
+    for (; q < end; q += 64) s0 += (double)data[q];
+    const double s = wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) scale[row] = 10000.0 / fmax(s, 1.0);                 // genes.py:57-59
+}
+
+template <typename T, int NS>
+__global__ __launch_bounds__(1024) void csr_moments_tiled_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+                                                                const T* __restrict__ data, const double* __restrict__ scale,
+                                                                long long n, int G, int tile, int rows_per_stripe,
+                                                                double* __restrict__ part /* (stripes, NS, G) */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* acc = reinterpret_cast<double*>(smem);                       // [NS][tile]
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int waves_per_blk = blockDim.x >> 6;
-    double* mine = sums + (size_t)(blockIdx.x % copies) * 3 * G;
-    const long long wave0 = (long long)blockIdx.x * waves_per_blk + wib;
-    const long long stride = (long long)gridDim.x * waves_per_blk;
-    for (long long row = wave0; row < n; row += stride) {
+    const int t0 = blockIdx.y * tile;
+    const int tw = min(tile, G - t0);
+    for (int j = threadIdx.x; j < NS * tile; j += 1024) acc[j] = 0.0;
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.x * rows_per_stripe;
+    const long long r1 = min(n, r0 + rows_per_stripe);
+    for (long long row = r0 + wib; row < r1; row += 16) {     // 16 waves share the tile: 2 blocks = 32 waves per CU
         const long long beg = indptr[row], end = indptr[row + 1];
-        double s = 0.0;
-        for (long long q = beg + lane; q < end; q += 64) s += (double)data[q];
-        s = wave_sum(s);
-        const double scale = 10000.0 / fmax(s, 1.0);                   // genes.py:57-59
-        for (long long q = beg + lane; q < end; q += 64) {
-            const int g = indices[q];
-            const double y = (double)data[q];
-            const double z = fast_log1p(y * scale);
-            atomicAdd(mine + g, z);
-            atomicAdd(mine + (size_t)G + g, z * z);
-            atomicAdd(mine + 2 * (size_t)G + g, y);
+        const double sc = scale[row];
+        for (long long q0 = beg; q0 < end; q0 += 256) {
+            int c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long q = q0 + u * 64 + lane;
+                c[u] = (q < end) ? indices[q] - t0 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c[u] >= 0 && c[u] < tw) {
+                    const double y = (double)data[q0 + u * 64 + lane];
+                    const double z = fast_log1p(y * sc);
+                    lds_add(acc + c[u], z);
+                    lds_add(acc + tile + c[u], z * z);
+                    if (NS == 3) lds_add(acc + 2 * tile + c[u], y);
+                }
+            }
         }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < NS * tile; j += 1024) {
+        const int s = j / tile, g = j - s * tile;
+        if (g < tw) part[((size_t)blockIdx.x * NS + s) * G + t0 + g] = acc[j];
     }
 }
 
-__global__ __launch_bounds__(256) void csr_fold_moments_kernel(const double* __restrict__ sums, int copies, int G, long long n,
+template <int NS>
+__global__ __launch_bounds__(256) void csr_fold_moments_kernel(const double* __restrict__ part, int stripes, int G, long long n,
                                                                double* __restrict__ mean, double* __restrict__ var,
                                                                double* __restrict__ colsum) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= G) return;
     double s1 = 0.0, s2 = 0.0, s0 = 0.0;
-    for (int c = 0; c < copies; ++c) {
-        const double* p = sums + (size_t)c * 3 * G;
+    for (int b = 0; b < stripes; ++b) {
+        const double* p = part + (size_t)b * NS * G;
         s1 += p[g];
         s2 += p[(size_t)G + g];
-        s0 += p[2 * (size_t)G + g];
+        if (NS == 3) s0 += p[2 * (size_t)G + g];
     }
     const double m = s1 / (double)n;
     mean[g] = m;
     var[g] = (n >= 2) ? fmax(((s2 / (double)n) - m * m) * ((double)n / (double)(n - 1)), 0.0) : 0.0;   // genes.py:74-83
-    colsum[g] = s0;
+    if (NS == 3) colsum[g] = s0;
 }
 
-int csr_moment_copies() { return 32; }
+int csr_moment_stripes(long long n) { return (int)std::min<long long>(512, std::max<long long>(1, (n + 255) / 256)); }
 
-int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, int G,
-                       double* sums, double* mean, double* var, double* colsum, hipStream_t st) {
-    if (G <= 0 || n <= 0) return fail(FDX_ERR_INVALID, "gene moments (CSR): empty matrix");
-    const int copies = csr_moment_copies();
-    FDX_HIP(hipMemsetAsync(sums, 0, (size_t)copies * 3 * G * sizeof(double), st));
-    const int blocks = (int)std::min<long long>((n + 3) / 4, 256LL * 8);
-    if (dtype == FDX_F32)
-        hipLaunchKernelGGL(csr_moments_kernel<float>, dim3(blocks), dim3(256), 0, st, indptr, indices, (const float*)data, n, G, copies, sums);
-    else if (dtype == FDX_F64)
-        hipLaunchKernelGGL(csr_moments_kernel<double>, dim3(blocks), dim3(256), 0, st, indptr, indices, (const double*)data, n, G, copies, sums);
-    else
-        return fail(FDX_ERR_INVALID, "gene moments (CSR): dtype must be FDX_F32 or FDX_F64");
+template <typename T, int NS>
+static int launch_csr_moments_t(const long long* indptr, const int* indices, const T* data, long long n, int G, double* scale,
+                                double* part, double* mean, double* var, double* colsum, hipStream_t st) {
+    const int tile = std::min(G, (int)(64 * 1024 / (NS * sizeof(double))));
+    const int tiles = ceil_div(G, tile);
+    const int stripes = csr_moment_stripes(n);
+    const int rows_per_stripe = (int)((n + stripes - 1) / stripes);
+    hipLaunchKernelGGL(csr_row_scale_kernel<T>, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, indptr, data, n, scale);
     FDX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(csr_fold_moments_kernel, dim3(ceil_div(G, 256)), dim3(256), 0, st, sums, copies, G, n, mean, var, colsum);
+    hipLaunchKernelGGL((csr_moments_tiled_kernel<T, NS>), dim3(stripes, tiles), dim3(1024), (size_t)NS * tile * sizeof(double), st,
+                       indptr, indices, data, scale, n, G, tile, rows_per_stripe, part);
+    FDX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(csr_fold_moments_kernel<NS>, dim3(ceil_div(G, 256)), dim3(256), 0, st, part, stripes, G, n, mean, var, colsum);
     FDX_CHECK_LAUNCH();
     return 0;
+}
+
+// scale: n doubles; part: csr_moment_stripes(n) * (colsum ? 3 : 2) * G doubles; colsum may be NULL
+int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, int G,
+                       double* scale, double* part, double* mean, double* var, double* colsum, hipStream_t st) {
+    if (G <= 0 || n <= 0) return fail(FDX_ERR_INVALID, "gene moments (CSR): empty matrix");
+    if (dtype == FDX_F32)
+        return colsum ? launch_csr_moments_t<float, 3>(indptr, indices, (const float*)data, n, G, scale, part, mean, var, colsum, st)
+                      : launch_csr_moments_t<float, 2>(indptr, indices, (const float*)data, n, G, scale, part, mean, var, colsum, st);
+    if (dtype == FDX_F64)
+        return colsum ? launch_csr_moments_t<double, 3>(indptr, indices, (const double*)data, n, G, scale, part, mean, var, colsum, st)
+                      : launch_csr_moments_t<double, 2>(indptr, indices, (const double*)data, n, G, scale, part, mean, var, colsum, st);
+    return fail(FDX_ERR_INVALID, "gene moments (CSR): dtype must be FDX_F32 or FDX_F64");
 }
 
 // Structure check of an uploaded CSR matrix before any kernel indexes with it (an out-of-range column would fault the

@@ -93,12 +93,12 @@ int launch_leverage(const double* X, int K, int G, double reg, double* work, dou
 namespace fdx {
 // ---- CSR spot matrix (csr_kernels.cpp)
 int launch_sketch_csr(const long long* indptr, const int* indices, const void* data, int dtype, const int* row_map,
-                      long long row0, long long n, int d, int mode, const void* table, double* Ys, long long ldys,
-                      double* row_sumsq, hipStream_t st);
+                      long long row0, long long n, int d, int mode, const void* table, const unsigned* sel_bits,
+                      int sel_words, double* Ys, long long ldys, double* row_sumsq, hipStream_t st);
 size_t csr_gene_slot_bytes();
-int csr_moment_copies();
+int csr_moment_stripes(long long n);
 int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, int G,
-                       double* sums, double* mean, double* var, double* colsum, hipStream_t st);
+                       double* scale, double* part, double* mean, double* var, double* colsum, hipStream_t st);
 int launch_csr_check(const long long* indptr, const int* indices, long long n, long long nnz, int G, int* flag, hipStream_t st);
 }  // namespace fdx
 

@@ -219,7 +219,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     std::vector<double> wy, wx;
     FDX_TRY(build_csc_from_tables(bucket, weight_y, G, d, &col_ptr, &gene_idx, &wy));
     SketchPlan plan_y, plan_x;
-    DevBuf dSlots;               // CSR source: per-column {weight, bucket} table over all G_all columns
+    DevBuf dSlots, dBits;        // CSR source: per-column {weight, bucket} table over all G_all columns + "selected" bitmap
+    int sel_words = 0;
     if (ysrc.csr) {
         const int G_all = ysrc.csr->G;
         FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(GeneSlotHost), "fit: gene slot layout mismatch");
@@ -230,8 +231,14 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
             FDX_REQUIRE(slots[(size_t)c].bucket < 0, "fdx_fit_csr_dev: duplicate gene index");
             slots[(size_t)c] = GeneSlotHost{weight_y[j], bucket[j], 0};
         }
+        sel_words = (G_all + 31) / 32;
+        std::vector<unsigned> bits((size_t)sel_words, 0u);
+        for (int c = 0; c < G_all; ++c)
+            if (slots[(size_t)c].bucket >= 0) bits[(size_t)c >> 5] |= 1u << (c & 31);
         FDX_TRY(dSlots.alloc(slots.size() * sizeof(GeneSlotHost)));
+        FDX_TRY(dBits.alloc(bits.size() * sizeof(unsigned)));
         FDX_HIP(hipMemcpyAsync(dSlots.p, slots.data(), slots.size() * sizeof(GeneSlotHost), hipMemcpyHostToDevice, st));
+        FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
         FDX_HIP(hipStreamSynchronize(st));   // `slots` is a stack-scoped host buffer
     } else {
         FDX_TRY(plan_y.build(col_ptr.data(), gene_idx.data(), wy.data(), G, d, st));
@@ -281,7 +288,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
             if (ysrc.csr) {
                 FDX_TRY(launch_sketch_csr((const long long*)ysrc.csr->indptr, ysrc.csr->indices, ysrc.csr->data, y_dtype,
                                           row_map ? row_map + r0 : nullptr, r0, nr, d, prm->mode_y, dSlots.p,
-                                          dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
+                                          dBits.as<unsigned>(), sel_words, dYs.as<double>(), d,
+                                          dRowSq.as<double>() + r0, st));
             } else {
                 const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
                 if (!row_map) ybase += (size_t)r0 * (size_t)ldy * (y_dtype == FDX_F32 ? 4 : 8);
@@ -404,12 +412,14 @@ extern "C" int fdx_csr_gene_moments_dev(const fdx_csr_view* Y, double* mean_out_
     FDX_REQUIRE(Y->n > 0, "fdx_csr_gene_moments_dev: empty matrix");
     hipStream_t st = (hipStream_t)stream;
     const size_t G = (size_t)Y->G;
-    DevBuf sums, out;
-    FDX_TRY(sums.alloc((size_t)csr_moment_copies() * 3 * G * sizeof(double)));
+    DevBuf scale, part, out;
+    const int ns = colsum_out_host ? 3 : 2;
+    FDX_TRY(scale.alloc((size_t)Y->n * sizeof(double)));
+    FDX_TRY(part.alloc((size_t)csr_moment_stripes(Y->n) * ns * G * sizeof(double)));
     FDX_TRY(out.alloc(3 * G * sizeof(double)));
     double* o = out.as<double>();
-    FDX_TRY(launch_csr_moments((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, Y->n, Y->G, sums.as<double>(), o,
-                               o + G, o + 2 * G, st));
+    FDX_TRY(launch_csr_moments((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, Y->n, Y->G, scale.as<double>(),
+                               part.as<double>(), o, o + G, colsum_out_host ? o + 2 * G : nullptr, st));
     if (mean_out_host) FDX_HIP(hipMemcpyAsync(mean_out_host, o, G * sizeof(double), hipMemcpyDeviceToHost, st));
     if (var_out_host) FDX_HIP(hipMemcpyAsync(var_out_host, o + G, G * sizeof(double), hipMemcpyDeviceToHost, st));
     if (colsum_out_host) FDX_HIP(hipMemcpyAsync(colsum_out_host, o + 2 * G, G * sizeof(double), hipMemcpyDeviceToHost, st));

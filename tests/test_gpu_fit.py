@@ -89,7 +89,9 @@ def test_csr_gene_moments_and_validation():
     Yd[11] = 0
     Y = sparse.csr_matrix(Yd)
     csr = _lib.CsrOnDevice.from_scipy(Y)
-    mean, var, colsum = csr.gene_moments()
+    mean, var, colsum = csr.gene_moments(want_colsum=True)
+    mean2, var2, none = csr.gene_moments()
+    assert none is None and np.allclose(mean2, mean, rtol=1e-14) and np.allclose(var2, var, rtol=1e-12)
     csr.free()
     lib_size = np.maximum(Yd.sum(axis=1, keepdims=True), 1.0)
     Z = np.log1p(Yd / lib_size * 1e4)
