@@ -193,6 +193,7 @@ class FlashDeconv:
                 y_ptr = ybuf.ptr
             csr_colsum = None
             log("Step 1: Selecting informative genes...")
+            t_sel = time.perf_counter()
             if G_all <= self.n_hvg:
                 # select_hvg returns every gene when the matrix has no more than n_hvg of them and the marker union is a
                 # subset (utils/genes.py:135-145, 330) - no pass over Y needed.
@@ -208,6 +209,7 @@ class FlashDeconv:
                 if len(gene_idx) == 0:
                     raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
             self.gene_idx_ = gene_idx
+            t_sel = time.perf_counter() - t_sel
             G = len(gene_idx)
             log(f"  Selected {G} genes (HVG + markers)")
             Xsel = np.ascontiguousarray(X[:, gene_idx])
@@ -345,6 +347,7 @@ class FlashDeconv:
         self.timings_["sweep_ms"] = float(info.solve.sweep_ms)
         # host wall of the graph build call, and of the wait for the leverage SVD that ran beside it
         self.timings_["graph_ms"] = (t_lev - t_graph) * 1e3
+        self.timings_["select_ms"] = t_sel * 1e3      # gene statistics on the device + HVG/marker ranking on the host
         self.timings_["leverage_wait_ms"] = (t_done - t_lev) * 1e3
         self._fitted = True
         log(f"  Converged: {self.info_['converged']}")
