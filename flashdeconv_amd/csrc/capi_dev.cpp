@@ -50,6 +50,32 @@ int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_
     return 0;
 }
 
+int fdx_graph_knn_lists_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t k, int64_t lo, int64_t hi,
+                            int32_t* nbr_dev, int32_t* cnt_dev, void* stream, fdx_graph_plan** plan) {
+    FDX_REQUIRE(plan != nullptr, "fdx_graph_knn_lists_dev: null output");
+    *plan = nullptr;
+    FDX_REQUIRE(coords_dev && nbr_dev && cnt_dev, "fdx_graph_knn_lists_dev: null argument");
+    return graph_knn_lists(coords_dev, n, dim, k, lo, hi, nbr_dev, cnt_dev, plan, (hipStream_t)stream);
+}
+
+int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, const int32_t* cnt_dev, int64_t lo, int64_t hi,
+                                 void* stream, fdx_graph** out) {
+    FDX_REQUIRE(plan != nullptr, "fdx_graph_from_knn_lists_dev: null plan");
+    int rc = 0;
+    fdx_graph* g = nullptr;
+    if (!out || !nbr_dev || !cnt_dev) {
+        rc = fail(FDX_ERR_INVALID, "fdx_graph_from_knn_lists_dev: null argument");
+    } else {
+        *out = nullptr;
+        g = new fdx_graph();
+        rc = graph_from_knn_lists(plan, nbr_dev, cnt_dev, lo, hi, g, (hipStream_t)stream);
+    }
+    graph_plan_destroy(plan);                      // consumed either way
+    if (rc) { delete g; return rc; }
+    *out = g;
+    return 0;
+}
+
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream) {
     FDX_REQUIRE(g && (g->n == 0 || perm_out_dev), "fdx_graph_perm_dev: null argument");
     return graph_copy_perm(g, perm_out_dev, (hipStream_t)stream);

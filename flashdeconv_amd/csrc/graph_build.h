@@ -2,10 +2,19 @@
 #pragma once
 #include "fdx_graph.h"
 
+struct fdx_graph_plan;   // binned points of a two-phase k-NN build (graph_kernels.cpp)
+
 namespace fdx {
 
 // coords: device (n, dim) row-major float64, dim in {1,2,3}
 int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_graph* g, hipStream_t st);
+// two-phase k-NN build for spot shards (see graph_kernels.cpp): lists of rows [lo, hi) -> caller all-gathers -> own rows
+int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long long lo, long long hi, int* nbr, int* cnt,
+                    fdx_graph_plan** out, hipStream_t st);
+int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, long long lo, long long hi, fdx_graph* g,
+                         hipStream_t st);
+void graph_plan_destroy(fdx_graph_plan* plan);
+int graph_plan_kk(const fdx_graph_plan* plan);
 int graph_build_radius(const double* d_coords, long long n, int dim, double radius, fdx_graph* g, hipStream_t st);
 // distance of every point to its nearest other point (caller's order); used by the "grid" method (graph.py:163-167)
 int graph_nearest_distance(const double* d_coords, long long n, int dim, double* d_out, hipStream_t st);

@@ -149,9 +149,10 @@ template <int KMAX>
 __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc, const int* __restrict__ perm,
                                                   const int* __restrict__ cstart, const int* __restrict__ cend,
                                                   long long n, GridParams gp, int kk, int* __restrict__ nbr_out,
-                                                  int* __restrict__ nbr_cnt, double* __restrict__ nn_dist) {
-    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (p >= n) return;
+                                                  int* __restrict__ nbr_cnt, double* __restrict__ nn_dist,
+                                                  long long lo, long long hi) {
+    const long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;      // rows [lo, hi) of the sorted order
+    if (p >= hi) return;
     const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
     const double pc[3] = {px, py, pz};
     int c[3];
@@ -264,20 +265,23 @@ __global__ __launch_bounds__(128) void radius_kernel(const double* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------ symmetrise
 __global__ __launch_bounds__(256) void indegree_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
-                                                       long long n, int kk, int* __restrict__ indeg) {
+                                                       long long n, int kk, int* __restrict__ indeg, int lo, int hi) {
     const long long p = blockIdx.x * 256LL + threadIdx.x;
     if (p >= n) return;
-    for (int m = 0; m < nbr_cnt[p]; ++m) atomicAdd(&indeg[nbr[(size_t)p * kk + m]], 1);
+    for (int m = 0; m < nbr_cnt[p]; ++m) {           // only edges INTO rows [lo, hi) (a shard builds its own rows)
+        const int q = nbr[(size_t)p * kk + m];
+        if (q >= lo && q < hi) atomicAdd(&indeg[q], 1);
+    }
 }
 
 __global__ __launch_bounds__(256) void fill_reverse_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
                                                            long long n, int kk, const int* __restrict__ rev_off,
-                                                           int* __restrict__ cursor, int* __restrict__ rev) {
+                                                           int* __restrict__ cursor, int* __restrict__ rev, int lo, int hi) {
     const long long p = blockIdx.x * 256LL + threadIdx.x;
     if (p >= n) return;
     for (int m = 0; m < nbr_cnt[p]; ++m) {
         const int q = nbr[(size_t)p * kk + m];
-        rev[rev_off[q] + atomicAdd(&cursor[q], 1)] = (int)p;
+        if (q >= lo && q < hi) rev[rev_off[q] + atomicAdd(&cursor[q], 1)] = (int)p;
     }
 }
 
@@ -286,10 +290,10 @@ __global__ __launch_bounds__(256) void fill_reverse_kernel(const int* __restrict
 // sorting makes the result deterministic.
 __global__ __launch_bounds__(128) void merge_rows_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
                                                          const int* __restrict__ rev, const int* __restrict__ rev_off,
-                                                         const int* __restrict__ perm, long long n, int kk,
+                                                         const int* __restrict__ perm, long long lo, long long hi, int kk,
                                                          int* __restrict__ ws, int* __restrict__ deg) {
-    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (p >= n) return;
+    const long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (p >= hi) return;
     int* seg = ws + (size_t)p * kk + rev_off[p];
     const int n_out = nbr_cnt[p], n_in = rev_off[p + 1] - rev_off[p];
     const int m = n_out + n_in;
@@ -678,9 +682,16 @@ static int empty_graph(long long n, fdx_graph* g, hipStream_t st) {
 }
 
 template <int KMAX>
+static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, long long lo,
+                             long long hi, hipStream_t st) {
+    if (hi <= lo) return;
+    hipLaunchKernelGGL(knn_kernel<KMAX>, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), perm,
+                       b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi);
+}
+
+template <int KMAX>
 static void launch_knn(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, hipStream_t st) {
-    hipLaunchKernelGGL(knn_kernel<KMAX>, dim3(ceil_div(b.n, 128)), dim3(128), 0, st, b.sc.as<double>(), perm,
-                       b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist);
+    launch_knn_range<KMAX>(b, perm, kk, nbr, cnt, nn_dist, 0, b.n, st);
 }
 
 int graph_nearest_distance(const double* d_coords, long long n, int dim, double* d_out, hipStream_t st) {
@@ -694,6 +705,93 @@ int graph_nearest_distance(const double* d_coords, long long n, int dim, double*
     return 0;
 }
 
+// ---- k-NN graph in two phases, so that a spot shard can build only its own rows ------------------------------------
+// Phase 1 (knn_lists): bin ALL points (replicated; the Morton order defines the solver positions on every rank) and find
+// the k nearest neighbours of the rows [lo, hi) only.  Phase 2 (from_knn_lists): row p of the symmetrised graph is
+// out(p) U in(p); in(p) needs the lists of every row that points at p, so between the phases the ranks all-gather
+// their list rows (the one exchange step of the build).  Phase 2 then touches own rows only: rows outside [lo, hi) keep
+// degree 0 (their slices have width 0), which is all graph_localize reads of a full graph anyway (symmetry).
+// Single GPU: [lo, hi) = [0, n), no exchange - the same code.
+}  // namespace fdx
+struct fdx_graph_plan {
+    fdx::BinnedPoints b;
+    long long n = 0;
+    int kk = 0;
+};
+namespace fdx {
+
+int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long long lo, long long hi, int* nbr, int* cnt,
+                    fdx_graph_plan** out, hipStream_t st) {
+    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
+    FDX_REQUIRE(n >= 2 && n < 0x7fffff00LL, "graph: n out of range");
+    FDX_REQUIRE(k >= 1, "graph: k must be positive");
+    FDX_REQUIRE(0 <= lo && lo <= hi && hi <= n, "graph: bad row range");
+    const int k_act = (int)std::min<long long>(k, n - 1);           // graph.py:51
+    const int kk = k_act + 1;
+    FDX_REQUIRE(kk <= 64, "graph: k_neighbors above 63 is not supported");
+    FDX_REQUIRE((long long)n * kk < 0x7fffff00LL, "graph: n*k too large");
+    auto* plan = new fdx_graph_plan();
+    plan->n = n;
+    plan->kk = kk;
+    int rc = bin_points(d_coords, n, dim, 2.0, 0.0, &plan->b, st);
+    if (rc) { delete plan; return rc; }
+    const BinnedPoints& b = plan->b;
+    const int* perm = b.perm.as<int>();
+    if (kk <= 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st);
+    else if (kk <= 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st);
+    else if (kk <= 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st);
+    else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st);
+    if (hipGetLastError() != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: k-NN kernel launch failed"); }
+    *out = plan;
+    return 0;
+}
+
+void graph_plan_destroy(fdx_graph_plan* plan) { delete plan; }
+int graph_plan_kk(const fdx_graph_plan* plan) { return plan->kk; }
+
+int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, long long lo, long long hi, fdx_graph* g,
+                         hipStream_t st) {
+    const long long n = plan->n;
+    const int kk = plan->kk;
+    FDX_REQUIRE(0 <= lo && lo <= hi && hi <= n, "graph: bad row range");
+    FDX_REQUIRE(lo % 64 == 0, "graph: a shard must start on a 64-row slice boundary");
+    g->n = n; g->n_total = n; g->identity_order = false;
+    g->perm.take(plan->b.perm);
+    g->rank.take(plan->b.rank);
+    DevBuf indeg, rev_off, cursor, rev, tmp;
+    // symmetrise: A + A^T, binary   (graph.py:80-81)
+    FDX_TRY(indeg.alloc((size_t)(n + 1) * 4));
+    FDX_TRY(rev_off.alloc((size_t)(n + 1) * 4));
+    FDX_TRY(cursor.alloc((size_t)n * 4));
+    FDX_HIP(hipMemsetAsync(indeg.p, 0, indeg.bytes, st));
+    FDX_HIP(hipMemsetAsync(cursor.p, 0, cursor.bytes, st));
+    const int nb = ceil_div(n, 256);
+    hipLaunchKernelGGL(indegree_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, indeg.as<int>(), (int)lo, (int)hi);
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(exclusive_scan_int(indeg.as<int>(), rev_off.as<int>(), n + 1, st, tmp));
+    int total_in = 0;                                    // edges into [lo, hi): known only now
+    FDX_HIP(hipMemcpyAsync(&total_in, rev_off.as<int>() + n, 4, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    FDX_REQUIRE(total_in >= 0 && (long long)total_in <= n * (long long)kk, "graph: reverse edge count out of range");
+    FDX_TRY(rev.alloc((size_t)std::max(total_in, 1) * 4));
+    hipLaunchKernelGGL(fill_reverse_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, rev_off.as<int>(), cursor.as<int>(),
+                       rev.as<int>(), (int)lo, (int)hi);
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(g->rows.alloc((size_t)n * kk * 2 * 4));     // capacity sum_p (kk + indeg[p]) <= 2*n*kk
+    FDX_TRY(g->deg.alloc((size_t)n * 4));
+    if (lo > 0 || hi < n) FDX_HIP(hipMemsetAsync(g->deg.p, 0, g->deg.bytes, st));
+    if (hi > lo) {
+        hipLaunchKernelGGL(merge_rows_kernel, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, nbr, cnt, rev.as<int>(),
+                           rev_off.as<int>(), g->perm.as<int>(), lo, hi, kk, g->rows.as<int>(), g->deg.as<int>());
+        FDX_CHECK_LAUNCH();
+    }
+    g->row_stride = kk;
+    g->row_extra.take(rev_off);   // keep: segment offsets
+    FDX_TRY(finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_graph* g, hipStream_t st) {
     FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
     FDX_REQUIRE(n >= 0 && n < 0x7fffff00LL, "graph: n out of range");
@@ -703,43 +801,14 @@ int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_gra
     const int kk = k_act + 1;
     FDX_REQUIRE(kk <= 64, "graph: k_neighbors above 63 is not supported");
     FDX_REQUIRE((long long)n * kk < 0x7fffff00LL, "graph: n*k too large");
-    BinnedPoints b;
-    FDX_TRY(bin_points(d_coords, n, dim, 2.0, 0.0, &b, st));
-    g->n = n; g->n_total = n; g->identity_order = false;
-    g->perm.take(b.perm);
-    g->rank.take(b.rank);
-    const int* perm = g->perm.as<int>();
-    DevBuf nbr, cnt, indeg, rev_off, cursor, rev, tmp;
+    DevBuf nbr, cnt;
     FDX_TRY(nbr.alloc((size_t)n * kk * 4));
     FDX_TRY(cnt.alloc((size_t)n * 4));
-    if (kk <= 8) launch_knn<8>(b, perm, kk, nbr.as<int>(), cnt.as<int>(), nullptr, st);
-    else if (kk <= 16) launch_knn<16>(b, perm, kk, nbr.as<int>(), cnt.as<int>(), nullptr, st);
-    else if (kk <= 32) launch_knn<32>(b, perm, kk, nbr.as<int>(), cnt.as<int>(), nullptr, st);
-    else launch_knn<64>(b, perm, kk, nbr.as<int>(), cnt.as<int>(), nullptr, st);
-    FDX_CHECK_LAUNCH();
-    // symmetrise: A + A^T, binary   (graph.py:80-81)
-    FDX_TRY(indeg.alloc((size_t)(n + 1) * 4));
-    FDX_TRY(rev_off.alloc((size_t)(n + 1) * 4));
-    FDX_TRY(cursor.alloc((size_t)n * 4));
-    FDX_HIP(hipMemsetAsync(indeg.p, 0, indeg.bytes, st));
-    FDX_HIP(hipMemsetAsync(cursor.p, 0, cursor.bytes, st));
-    const int nb = ceil_div(n, 256);
-    hipLaunchKernelGGL(indegree_kernel, dim3(nb), dim3(256), 0, st, nbr.as<int>(), cnt.as<int>(), n, kk, indeg.as<int>());
-    FDX_CHECK_LAUNCH();
-    FDX_TRY(exclusive_scan_int(indeg.as<int>(), rev_off.as<int>(), n + 1, st, tmp));
-    FDX_TRY(rev.alloc((size_t)n * kk * 4));
-    hipLaunchKernelGGL(fill_reverse_kernel, dim3(nb), dim3(256), 0, st, nbr.as<int>(), cnt.as<int>(), n, kk, rev_off.as<int>(), cursor.as<int>(), rev.as<int>());
-    FDX_CHECK_LAUNCH();
-    FDX_TRY(g->rows.alloc((size_t)n * kk * 2 * 4));     // capacity sum_p (kk + indeg[p]) <= 2*n*kk
-    FDX_TRY(g->deg.alloc((size_t)n * 4));
-    hipLaunchKernelGGL(merge_rows_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, st, nbr.as<int>(), cnt.as<int>(), rev.as<int>(),
-                       rev_off.as<int>(), g->perm.as<int>(), n, kk, g->rows.as<int>(), g->deg.as<int>());
-    FDX_CHECK_LAUNCH();
-    g->row_stride = kk;
-    g->row_extra.take(rev_off);   // keep: segment offsets
-    FDX_TRY(finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), st));
-    FDX_HIP(hipStreamSynchronize(st));
-    return 0;
+    fdx_graph_plan* plan = nullptr;
+    FDX_TRY(graph_knn_lists(d_coords, n, dim, k, 0, n, nbr.as<int>(), cnt.as<int>(), &plan, st));
+    const int rc = graph_from_knn_lists(plan, nbr.as<int>(), cnt.as<int>(), 0, n, g, st);
+    delete plan;
+    return rc;
 }
 
 int graph_build_radius(const double* d_coords, long long n, int dim, double radius, fdx_graph* g, hipStream_t st) {

@@ -57,6 +57,32 @@ class TorchComm:
     def all_reduce_sum(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def all_gather_rows(self, nbr, cnt, bounds):
+        """Every rank has written rows [bounds[rank], bounds[rank+1]) of nbr (n, kk) / cnt (n); fill in the rows of the
+        other ranks.  One all-gather of equal, padded segments (the shards differ by at most 256 rows)."""
+        import torch
+        W, r = self.world, self.rank
+        if W == 1:
+            return
+        kk = nbr.shape[1]
+        seg = int(max(int(bounds[i + 1] - bounds[i]) for i in range(W)))
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        send = torch.zeros((seg, kk + 1), dtype=nbr.dtype, device=nbr.device)
+        send[:hi - lo, :kk] = nbr[lo:hi]
+        send[:hi - lo, kk] = cnt[lo:hi]
+        out = torch.empty((W * seg, kk + 1), dtype=nbr.dtype, device=nbr.device)
+        try:
+            self.dist.all_gather_into_tensor(out, send, group=self.group)
+        except (RuntimeError, NotImplementedError):                      # backend without the fused form
+            parts = [out[q * seg:(q + 1) * seg] for q in range(W)]
+            self.dist.all_gather(parts, send, group=self.group)
+        for q in range(W):
+            if q == r:
+                continue
+            a, b = int(bounds[q]), int(bounds[q + 1])
+            nbr[a:b] = out[q * seg:q * seg + (b - a), :kk]
+            cnt[a:b] = out[q * seg:q * seg + (b - a), kk]
+
     def exchange(self, send_bufs, recv_bufs):
         """send_bufs / recv_bufs: {peer: contiguous tensor}.  Grouped point-to-point."""
         ops = []
@@ -228,14 +254,40 @@ class ShardedFlashDeconv:
                 g.close()
         t0 = time.perf_counter()
         h = ctypes.c_void_p()
-        method = _lib.GRAPH_KNN if self.spatial_method == "knn" else _lib.GRAPH_RADIUS
-        _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, method, int(self.k_neighbors),
-                                           float(self.radius or 0.0), st, ctypes.byref(h)))
-        self._full = _lib.Graph(h.value)
+        self.bounds = shard_bounds(n, self.comm.world)
+        k = int(self.k_neighbors)
+        if self.spatial_method == "knn" and self.comm.world > 1 and n >= 2 and k >= 1:
+            # sharded build: own k-NN lists -> all-gather of the list rows -> own rows of the symmetrised graph
+            lo, hi = int(self.bounds[self.comm.rank]), int(self.bounds[self.comm.rank + 1])
+            kk = min(k, n - 1) + 1
+            nbr = torch.empty((n, kk), dtype=torch.int32, device=coords.device)
+            cnt = torch.empty((n,), dtype=torch.int32, device=coords.device)
+            plan = ctypes.c_void_p()
+            _lib.check(lib.fdx_graph_knn_lists_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, lo, hi,
+                                                   ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), st,
+                                                   ctypes.byref(plan)))
+            t0 = self._tick("plan_knn", t0)
+            try:
+                self.comm.all_gather_rows(nbr, cnt, self.bounds)
+            except Exception:
+                nbr[:lo], nbr[hi:], cnt[:lo], cnt[hi:] = -1, -1, 0, 0      # never hand unwritten rows to the kernels
+                raise
+            finally:
+                t0 = self._tick("plan_gather", t0)
+                _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()),
+                                                            ctypes.c_void_p(cnt.data_ptr()), lo, hi, st, ctypes.byref(h)))
+            self._full = _lib.Graph(h.value)
+            own_nnz = torch.tensor([float(self._full.info()[1])], dtype=torch.float64, device=coords.device)
+            self.comm.all_reduce_sum(own_nnz)                               # nnz of the whole graph (auto lambda)
+            self.nnz_total = int(round(float(own_nnz.item())))
+        else:
+            method = _lib.GRAPH_KNN if self.spatial_method == "knn" else _lib.GRAPH_RADIUS
+            _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, method, k,
+                                               float(self.radius or 0.0), st, ctypes.byref(h)))
+            self._full = _lib.Graph(h.value)
+            self.nnz_total = self._full.info()[1]
         t0 = self._tick("plan_build", t0)
         self.n_total_spots = n
-        self.nnz_total = self._full.info()[1]
-        self.bounds = shard_bounds(n, self.comm.world)
         hl = ctypes.c_void_p()
         _lib.check(lib.fdx_graph_localize(self._full.handle, self.comm.world, _lib.ptr_i64(self.bounds), self.comm.rank, st,
                                           ctypes.byref(hl)))

@@ -218,6 +218,20 @@ int fdx_fit_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t G, c
 /* Graph from coordinates already on the device (method FDX_GRAPH_KNN / FDX_GRAPH_RADIUS). */
 int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t method, int32_t k, double radius,
                         void* stream, fdx_graph** out);
+/* The same k-NN graph in two phases, so that a spot shard builds only its own rows (utils/graph.py:25-83):
+ *   1. knn_lists: every rank bins ALL coordinates (replicated; the Morton order fixes the solver positions) and finds
+ *      the k nearest neighbours of solver positions [lo, hi) only.  Rows [lo, hi) of nbr_dev (n x kk int32 solver
+ *      positions, -1 padded, kk = min(k, n-1) + 1) and of cnt_dev (n int32) are written; needs n >= 2, k >= 1.
+ *   2. the caller all-gathers the rows of the other ranks into the same two arrays (RCCL) - the symmetrisation
+ *      A + A^T (graph.py:80-81) needs the lists of every spot that points at an own spot;
+ *   3. from_knn_lists: symmetrise, sort and lay out rows [lo, hi) (lo a multiple of 64); rows outside keep degree 0.
+ *      The result is a full-size graph that fdx_graph_localize can cut for this rank.  The plan is consumed.
+ * With [lo, hi) = [0, n) and no exchange this is fdx_graph_build_dev(FDX_GRAPH_KNN). */
+typedef struct fdx_graph_plan fdx_graph_plan;
+int fdx_graph_knn_lists_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t k, int64_t lo, int64_t hi,
+                            int32_t* nbr_dev, int32_t* cnt_dev, void* stream, fdx_graph_plan** plan);
+int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, const int32_t* cnt_dev, int64_t lo, int64_t hi,
+                                 void* stream, fdx_graph** out);
 /* perm_out_dev[p] = caller's spot id at solver position p (int32, n entries, device). */
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
 /* Shard of a full graph for rank `my_rank`: own spots are solver positions [bounds[my_rank], bounds[my_rank+1])

@@ -21,8 +21,9 @@ def _st(torch):
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+@pytest.mark.parametrize("build", ["replicated", "sharded"])
 @pytest.mark.parametrize("W", [2, 3, 5])
-def test_virtual_ranks_equal_single_gpu(W):
+def test_virtual_ranks_equal_single_gpu(W, build):
     import torch
     from flashdeconv_amd import FlashDeconv, _lib
     from flashdeconv_amd.core.sketching import countsketch_tables
@@ -37,10 +38,40 @@ def test_virtual_ranks_equal_single_gpu(W):
     T = ref.info_["n_iterations"]
 
     cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
-    h = ctypes.c_void_p()
-    _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, _lib.GRAPH_KNN, 6, 0.0, _st(torch), ctypes.byref(h)))
-    full = _lib.Graph(h.value)
     bounds = shard_bounds(n, W)
+    if build == "replicated":
+        h = ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, _lib.GRAPH_KNN, 6, 0.0, _st(torch), ctypes.byref(h)))
+        fulls = [_lib.Graph(h.value)] * W
+    else:
+        # sharded build: every rank finds the k-NN lists of its own rows, the rows are all-gathered (here: copied between
+        # the virtual ranks' buffers), every rank symmetrises its own rows only
+        kk = 7
+        nbrs = [torch.full((n, kk), -7, dtype=torch.int32, device=dev) for _ in range(W)]
+        cnts = [torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(W)]
+        plans = []
+        for r in range(W):
+            pl = ctypes.c_void_p()
+            _lib.check(lib.fdx_graph_knn_lists_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, 6, int(bounds[r]), int(bounds[r + 1]),
+                                                   ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()),
+                                                   _st(torch), ctypes.byref(pl)))
+            plans.append(pl)
+        for r in range(W):
+            for q in range(W):
+                if q != r:
+                    a, b = int(bounds[q]), int(bounds[q + 1])
+                    nbrs[r][a:b] = nbrs[q][a:b]
+                    cnts[r][a:b] = cnts[q][a:b]
+        fulls, nnz_sum = [], 0
+        for r in range(W):
+            assert int(cnts[r].min()) >= 0 and int(nbrs[r].min()) >= -1
+            h = ctypes.c_void_p()
+            _lib.check(lib.fdx_graph_from_knn_lists_dev(plans[r], ctypes.c_void_p(nbrs[r].data_ptr()),
+                                                        ctypes.c_void_p(cnts[r].data_ptr()), int(bounds[r]), int(bounds[r + 1]),
+                                                        _st(torch), ctypes.byref(h)))
+            fulls.append(_lib.Graph(h.value))
+            nnz_sum += fulls[-1].info()[1]
+        assert nnz_sum == ref.adjacency_.nnz
     lev = compute_leverage_scores(X)
     bucket, weight = countsketch_tables(G, d, lev, 0)
     b32 = np.ascontiguousarray(bucket, dtype=np.int32)
@@ -49,7 +80,7 @@ def test_virtual_ranks_equal_single_gpu(W):
     yty = 0.0
     for r in range(W):
         hl = ctypes.c_void_p()
-        _lib.check(lib.fdx_graph_localize(full.handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
+        _lib.check(lib.fdx_graph_localize(fulls[r].handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
         g = _lib.Graph(hl.value)
         n_own = int(bounds[r + 1] - bounds[r])
         perm = torch.empty(max(n_own, 1), dtype=torch.int32, device=dev)

@@ -10,6 +10,9 @@ class FakeComm:
     def __init__(self, rank, world): self.rank, self.world = rank, world
     def all_reduce_max(self, t): pass
     def all_reduce_sum(self, t): pass
+    def all_gather_rows(self, nbr, cnt, bounds):          # other ranks' rows: empty lists (valid input, fewer edges)
+        lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        nbr[:lo] = -1; nbr[hi:] = -1; cnt[:lo] = 0; cnt[hi:] = 0
     def exchange(self, send, recv):
         for t in recv.values(): t.zero_()
 
