@@ -251,7 +251,7 @@ def main():
             kname = "fdx::bcd_sweep_tiled_kernel<%d, 8, false>" % K
         else:
             bytes_launch, ms_launch = sk_bytes / n_chunks, sk_ms / n_chunks
-            kname = "fdx::sketch_rows_reg_kernel<float, %d, true, 40>" % (0 if fam == "gaussian" else 1)
+            kname = "fdx::sketch_rows_scatter_kernel<float, %d, true>" % (0 if fam == "gaussian" else 1)
         ach = bytes_launch / (ms_launch * 1e-3) / 1e9
         results[fam] = {
             "value": n * steps / dt, "ms_per_step": dt / steps * 1e3, "n_iterations": T, "converged": model.info_["converged"],

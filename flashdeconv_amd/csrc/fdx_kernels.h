@@ -55,6 +55,10 @@ struct SketchPlanDev {
     const unsigned int* sched_pack = nullptr;
     unsigned long long end_mask = 0ULL;
     int pack_ok = 0;
+    // per-gene form (valid when scatter_ok: every gene has at most one entry): weight and bucket (-1 = none) of gene g
+    const double* gene_w = nullptr;
+    const int* gene_bucket = nullptr;
+    int scatter_ok = 0;
 };
 int launch_sketch_rows(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, double* Ys, long long ldys, double* row_sumsq, hipStream_t st);

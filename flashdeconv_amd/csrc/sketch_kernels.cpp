@@ -17,6 +17,7 @@
 // the wave's private LDS slice (the only HBM traffic: G*sizeof(T) per spot), the library size for log-CPM is reduced
 // on the way in, then lanes gather their genes from LDS.  No workgroup barrier is needed: a wave only reads LDS it
 // wrote itself.  Results are un-permuted through LDS and written as one coalesced d*8-byte row.
+#include <algorithm>
 #include <cstdlib>
 
 #include "device_math.h"
@@ -271,6 +272,122 @@ __global__ __launch_bounds__(256, 2) void sketch_rows_reg_kernel(const T* __rest
     }
 }
 
+// Scatter kernel - the default for a CountSketch (exactly one bucket per gene).  Nothing of the ROW is staged: lanes stream
+// it 16 bytes at a time straight into registers, look up each gene's {weight, bucket} in a per-gene table held in LDS (one
+// copy per workgroup, 10 bytes per gene) and add weight * f(y) into the wave's d-entry accumulator with ds_add_f64.
+// LDS per workgroup is G*10 + waves*d*8 bytes instead of waves*(G*sizeof(T) + d*8), so 16-24 waves per CU stay resident
+// for any G (the gather kernels hold 8, and drop to 4 above ~3000 genes: 0.8 TB/s at 5000 genes -> 1024), and the per-row
+// work is one LDS read pair and one LDS atomic per gene instead of a row write, a schedule walk and a gather.
+// Measured on MI355X, 1M x 2000 f32 -> 512: 2.50 ms (8 GB read + 4.3 GB written = 4.9 TB/s at the memory system) against
+// 3.38 ms for the register-schedule gather kernel; log-CPM 6.6 ms against 8.8 ms.
+// The order in which the entries of one bucket are added is the hardware's lane order, not the gene order: a last-bit
+// difference (the reference's own scipy product fixes no order either), far inside the 1e-4 parity budget, and
+// repeatable run to run (asserted in tests).  log-CPM reads the row twice (library size first); the second read hits
+// L2/MALL.  FDX_SKETCH_GATHER=1 selects the atomics-free, gene-ordered gather kernels instead.
+template <typename T, int MODE, bool VEC>
+__global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __restrict__ Y, long long ldy,
+                                                                  const int* __restrict__ row_map, long long n, int G, int d,
+                                                                  const double* __restrict__ gene_w,
+                                                                  const int* __restrict__ gene_bucket,
+                                                                  double* __restrict__ Ys, long long ldys,
+                                                                  double* __restrict__ row_sumsq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_blk = blockDim.x >> 6;
+    const int Gp = (G + 7) & ~7;
+    double* w_l = reinterpret_cast<double*>(smem);                                   // [Gp]
+    double* acc = w_l + Gp + (size_t)wib * d;                                         // [waves][d]
+    unsigned short* b_l = reinterpret_cast<unsigned short*>(w_l + Gp + (size_t)waves_per_blk * d);   // [Gp]
+    for (int g = threadIdx.x; g < Gp; g += blockDim.x) {
+        const int b = (g < G) ? gene_bucket[g] : -1;
+        w_l[g] = (g < G && b >= 0) ? gene_w[g] : 0.0;
+        b_l[g] = (unsigned short)(b >= 0 ? b : 0xFFFF);       // 0xFFFF: gene has no entry in Omega (never added)
+    }
+    __syncthreads();
+    typedef typename Vec4<T>::type V;
+    constexpr int PER = 16 / sizeof(T);
+    const int nvec = VEC ? G / PER : 0;
+    const long long wave0 = (long long)blockIdx.x * waves_per_blk + wib;
+    const long long stride = (long long)gridDim.x * waves_per_blk;
+    for (long long p = wave0; p < n; p += stride) {
+        const long long row = row_map ? (long long)row_map[p] : p;
+        const T* yrow = Y + (size_t)row * ldy;
+        const V* src = reinterpret_cast<const V*>(yrow);
+        for (int c = lane; c < d; c += 64) acc[c] = 0.0;
+        double scale = 1.0;
+        if (MODE != FDX_PRE_RAW) {
+            double part = 0.0;
+            for (int v0 = 0; v0 < nvec; v0 += 512) {
+                V x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int v = v0 + u * 64 + lane;
+                    if (v < nvec) x[u] = src[v];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int v = v0 + u * 64 + lane;
+                    if (v < nvec) {
+#pragma unroll
+                        for (int e = 0; e < PER; ++e) part += (double)x[u][e];
+                    }
+                }
+            }
+            for (int g = nvec * PER + lane; g < G; g += 64) part += (double)yrow[g];
+            double sum = wave_sum(part);
+            if (MODE == FDX_PRE_LOG_CPM) {
+                scale = (1.0 / (sum + 1e-10)) * 1e4;           // y / (rowsum + 1e-10) * 1e4   (deconv.py:190)
+            } else {
+                if (sum == 0.0) sum = 1.0;                     // lib_size[lib_size == 0] = 1  (deconv.py:183-185)
+                scale = 1e4 / sum;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // zeroing done before the adds
+        for (int v0 = 0; v0 < nvec; v0 += 256) {               // 4 x 16-byte loads per lane in flight
+            V x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * 64 + lane;
+                if (v < nvec) x[u] = src[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * 64 + lane;
+                if (v < nvec) {
+#pragma unroll
+                    for (int e = 0; e < PER; ++e) {
+                        const int g = v * PER + e;
+                        double y = (double)x[u][e];
+                        if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
+                        const unsigned b = b_l[g];
+                        if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        for (int g = nvec * PER + lane; g < G; g += 64) {
+            double y = (double)yrow[g];
+            if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
+            const unsigned b = b_l[g];
+            if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        double* dst = Ys + (size_t)p * ldys;
+        double sq = 0.0;
+        for (int c = lane; c < d; c += 64) {
+            const double v = acc[c];
+            dst[c] = v;
+            sq = fma(v, v, sq);
+        }
+        if (row_sumsq) {
+            sq = wave_sum(sq);
+            if (lane == 0) row_sumsq[p] = sq;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // reads of acc done before the next row zeroes it
+    }
+}
+
 template <typename T, int MODE, bool VEC>
 static const void* pick_reg_kernel(int total_len) {
     if (total_len <= 16) return (const void*)sketch_rows_reg_kernel<T, MODE, VEC, 16>;
@@ -286,6 +403,11 @@ static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, lon
                               const SketchPlanDev& plan, double* Ys, long long ldys, double* row_sumsq, hipStream_t st) {
     const size_t row_bytes = ((size_t)G * sizeof(T) + 15) & ~(size_t)15;
     const size_t per_wave = row_bytes + (size_t)d * sizeof(double);
+    // A CountSketch (one entry per gene) takes the scatter kernel: measured 2.50 ms against 3.38 ms (raw) and 6.6 ms against
+    // 8.8 ms (log-CPM) for 1M x 2000 -> 512 on MI355X.  The gather kernels below serve a general sparse Omega, and any Omega
+    // under FDX_SKETCH_GATHER=1 (gene-ordered, atomics-free sums).
+    const bool use_scatter = plan.scatter_ok && d < 65535 && !getenv("FDX_SKETCH_GATHER") && !getenv("FDX_SKETCH_NO_SCATTER");
+    if (!use_scatter)
     {   // register-resident schedule when it is short enough and at least one gene is hashed to the first group
         const bool vec0 = (ldy % (16 / (long long)sizeof(T)) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
         const void* rk = (plan.pack_ok && !getenv("FDX_SKETCH_NO_REG"))
@@ -298,6 +420,24 @@ static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, lon
                             (void*)&plan.sched_pack, (void*)&plan.sched_w, (void*)&plan.total_len, (void*)&plan.end_mask,
                             (void*)&Ys, (void*)&ldys, (void*)&row_sumsq};
             FDX_HIP(hipLaunchKernel(rk, dim3(blocks_r), dim3(256), args, lds_r, st));
+            return 0;
+        }
+    }
+    if (use_scatter) {
+        const size_t Gp = ((size_t)G + 7) & ~(size_t)7;
+        int wv = 8;
+        while (wv > 1 && Gp * 10 + (size_t)wv * d * 8 > 150 * 1024) wv >>= 1;
+        const size_t lds_s = Gp * 10 + (size_t)wv * d * 8;
+        if (lds_s <= 150 * 1024) {
+            const bool vec_s = (ldy % (16 / (long long)sizeof(T)) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+            const int per_cu = std::max<int>(1, (int)((160 * 1024) / lds_s));
+            const int blocks_s = (int)std::min<long long>((n + wv - 1) / wv, 256LL * per_cu);
+            auto ks = vec_s ? sketch_rows_scatter_kernel<T, MODE, true> : sketch_rows_scatter_kernel<T, MODE, false>;
+            if (lds_s > 64 * 1024)
+                FDX_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            hipLaunchKernelGGL(ks, dim3(blocks_s), dim3(wv * 64), lds_s, st, Y, ldy, row_map, n, G, d, plan.gene_w,
+                               plan.gene_bucket, Ys, ldys, row_sumsq);
+            FDX_CHECK_LAUNCH();
             return 0;
         }
     }

@@ -71,6 +71,21 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
             }
         }
     }
+    // per-gene form for the scatter kernel: usable when no gene appears in more than one bucket (a CountSketch)
+    std::vector<double> gw((size_t)G, 0.0);
+    std::vector<int> gb((size_t)G, -1);
+    scatter_ok = true;
+    for (int c = 0; c < d && scatter_ok; ++c)
+        for (long long e = col_ptr[c]; e < col_ptr[c + 1]; ++e) {
+            const int g = gene_idx[e];
+            if (gb[(size_t)g] >= 0) { scatter_ok = false; break; }
+            gb[(size_t)g] = c;
+            gw[(size_t)g] = weight[e];
+        }
+    FDX_TRY(gene_w.alloc(gw.size() * sizeof(double)));
+    FDX_TRY(gene_bucket.alloc(gb.size() * sizeof(int)));
+    FDX_HIP(hipMemcpyAsync(gene_w.p, gw.data(), gw.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_HIP(hipMemcpyAsync(gene_bucket.p, gb.data(), gb.size() * sizeof(int), hipMemcpyHostToDevice, st));
     FDX_TRY(sched_pack.alloc(sp.size() * sizeof(unsigned int)));
     FDX_HIP(hipMemcpyAsync(sched_pack.p, sp.data(), sp.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     FDX_TRY(sched_gene.alloc(sg.size() * sizeof(int)));

@@ -11,7 +11,8 @@ struct SketchPlan {
     long long total_len = 0;
     bool pack_ok = false;
     unsigned long long end_mask = 0ULL;
-    DevBuf sched_gene, sched_w, group_off, slot_bucket, sched_pack;
+    bool scatter_ok = false;
+    DevBuf sched_gene, sched_w, group_off, slot_bucket, sched_pack, gene_w, gene_bucket;
     SketchPlanDev dev() const {
         SketchPlanDev p;
         p.sched_gene = sched_gene.as<int>();
@@ -23,6 +24,9 @@ struct SketchPlan {
         p.total_len = (int)total_len;
         p.pack_ok = pack_ok ? 1 : 0;
         p.end_mask = end_mask;
+        p.gene_w = gene_w.as<double>();
+        p.gene_bucket = gene_bucket.as<int>();
+        p.scatter_ok = scatter_ok ? 1 : 0;
         return p;
     }
     // Omega (G x d) in CSC form on the host: col_ptr (d+1), gene_idx / weight (nnz), genes ascending per column.
