@@ -271,11 +271,26 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     long long chunk_rows = 1LL << 18;
     if (const char* e = getenv("FDX_FIT_CHUNK")) chunk_rows = std::max<long long>(64, atoll(e));
     const long long chunk = std::min<long long>(n, chunk_rows);
-    FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
+    const bool fused = !ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, plan_y.dev());
+    if (!fused) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
     FDX_HIP(hipMemsetAsync(dH.p, 0, dH.bytes, st));
     const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();
     double sketch_ms = 0.0, gram_ms = 0.0;
-    {
+    if (fused) {   // one kernel, no Y_sketch: rows -> LDS accumulators -> MFMA contraction -> H  (fused_kernels.cpp)
+        hipEvent_t e0, e1;
+        FDX_HIP(hipEventCreate(&e0));
+        FDX_HIP(hipEventCreate(&e1));
+        FDX_HIP(hipEventRecord(e0, st));
+        FDX_TRY(launch_sketch_contract(Y_dev, y_dtype, ldy, row_map, n, G, d, prm->mode_y, plan_y.dev(), dXs.as<double>(), K,
+                                       dH.as<double>(), ld, dRowSq.as<double>(), st));
+        FDX_HIP(hipEventRecord(e1, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        sketch_ms = t;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    } else {
         const int n_chunks = (int)((n + chunk - 1) / chunk);
         const int n_timed = std::min(n_chunks, 64);             // stage timing from up to 64 chunks, scaled
         std::vector<hipEvent_t> ev((size_t)n_timed * 3);
