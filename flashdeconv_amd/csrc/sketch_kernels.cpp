@@ -406,7 +406,8 @@ static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, lon
     // A CountSketch (one entry per gene) takes the scatter kernel: measured 2.50 ms against 3.38 ms (raw) and 6.6 ms against
     // 8.8 ms (log-CPM) for 1M x 2000 -> 512 on MI355X.  The gather kernels below serve a general sparse Omega, and any Omega
     // under FDX_SKETCH_GATHER=1 (gene-ordered, atomics-free sums).
-    const bool use_scatter = plan.scatter_ok && d < 65535 && !getenv("FDX_SKETCH_GATHER") && !getenv("FDX_SKETCH_NO_SCATTER");
+    const bool use_scatter = plan.scatter_ok && sketch_scatter_fits(G, d) && !getenv("FDX_SKETCH_GATHER") &&
+                             !getenv("FDX_SKETCH_NO_SCATTER");
     if (!use_scatter)
     {   // register-resident schedule when it is short enough and at least one gene is hashed to the first group
         const bool vec0 = (ldy % (16 / (long long)sizeof(T)) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);

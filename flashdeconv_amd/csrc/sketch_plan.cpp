@@ -5,6 +5,7 @@
 #include "sketch_plan.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -16,6 +17,35 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
     FDX_REQUIRE(col_ptr && (col_ptr[d_] == 0 || (gene_idx && weight)), "sketch plan: null table");
     G = G_;
     d = d_;
+    for (int c = 0; c < d; ++c) {
+        FDX_REQUIRE(col_ptr[c + 1] >= col_ptr[c], "sketch plan: col_ptr must be non-decreasing");
+        for (long long e = col_ptr[c]; e < col_ptr[c + 1]; ++e)
+            FDX_REQUIRE(gene_idx[e] >= 0 && gene_idx[e] < G, "sketch plan: gene index out of range");
+    }
+    // per-gene form for the scatter kernel: usable when no gene appears in more than one bucket (a CountSketch)
+    std::vector<double> gw((size_t)G, 0.0);
+    std::vector<int> gb((size_t)G, -1);
+    scatter_ok = true;
+    for (int c = 0; c < d && scatter_ok; ++c)
+        for (long long e = col_ptr[c]; e < col_ptr[c + 1]; ++e) {
+            const int g = gene_idx[e];
+            if (gb[(size_t)g] >= 0) { scatter_ok = false; break; }
+            gb[(size_t)g] = c;
+            gw[(size_t)g] = weight[e];
+        }
+    FDX_TRY(gene_w.alloc(gw.size() * sizeof(double)));
+    FDX_TRY(gene_bucket.alloc(gb.size() * sizeof(int)));
+    FDX_HIP(hipMemcpyAsync(gene_w.p, gw.data(), gw.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_HIP(hipMemcpyAsync(gene_bucket.p, gb.data(), gb.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    if (scatter_ok && sketch_scatter_fits(G, d) && !getenv("FDX_SKETCH_GATHER") && !getenv("FDX_SKETCH_NO_SCATTER")) {
+        // the scatter kernel will serve this plan: the gather schedule below is never read
+        n_groups = 0;
+        total_len = 0;
+        pack_ok = false;
+        end_mask = 0ULL;
+        FDX_HIP(hipStreamSynchronize(st));   // the host vectors die at scope exit
+        return 0;
+    }
     // Omega in CSC form: column (bucket) c holds genes gene_idx[col_ptr[c] .. col_ptr[c+1]) in ascending order.
     std::vector<std::vector<int>> lists((size_t)d);      // entry positions, so a gene may sit in several buckets
     for (int c = 0; c < d; ++c) {
@@ -71,21 +101,6 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
             }
         }
     }
-    // per-gene form for the scatter kernel: usable when no gene appears in more than one bucket (a CountSketch)
-    std::vector<double> gw((size_t)G, 0.0);
-    std::vector<int> gb((size_t)G, -1);
-    scatter_ok = true;
-    for (int c = 0; c < d && scatter_ok; ++c)
-        for (long long e = col_ptr[c]; e < col_ptr[c + 1]; ++e) {
-            const int g = gene_idx[e];
-            if (gb[(size_t)g] >= 0) { scatter_ok = false; break; }
-            gb[(size_t)g] = c;
-            gw[(size_t)g] = weight[e];
-        }
-    FDX_TRY(gene_w.alloc(gw.size() * sizeof(double)));
-    FDX_TRY(gene_bucket.alloc(gb.size() * sizeof(int)));
-    FDX_HIP(hipMemcpyAsync(gene_w.p, gw.data(), gw.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(gene_bucket.p, gb.data(), gb.size() * sizeof(int), hipMemcpyHostToDevice, st));
     FDX_TRY(sched_pack.alloc(sp.size() * sizeof(unsigned int)));
     FDX_HIP(hipMemcpyAsync(sched_pack.p, sp.data(), sp.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     FDX_TRY(sched_gene.alloc(sg.size() * sizeof(int)));
