@@ -99,8 +99,9 @@ int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, in
 
 namespace fdx {
 // ---- leverage_kernels.cpp
+size_t leverage_scratch_doubles(int K, int G);
 int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
-                    hipStream_t st);
+                    double* scratch, hipStream_t st);
 }  // namespace fdx
 
 namespace fdx {

@@ -62,7 +62,7 @@ int build_csc_from_tables(const int32_t* bucket, const double* weight, int G, in
 // caller put the spatial-graph build (many short, latency-bound kernels on the caller's stream) under it: the job runs
 // on a library-owned non-blocking side stream.
 struct fdx_leverage_job {
-    DevBuf dX, dW, dS, dL, dDbg;
+    DevBuf dX, dW, dS, dL, dDbg, dScratch;
     std::vector<double> hX;   // the caller may drop X once begin returns
     int K = 0, G = 0;
     hipStream_t st = nullptr;
@@ -102,8 +102,9 @@ extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double 
         FDX_TRY(job->dDbg.alloc(8 * sizeof(int)));
         job->hX.assign(X, X + (size_t)K * G);
         FDX_HIP(hipMemcpyAsync(job->dX.p, job->hX.data(), (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, job->st));
+        FDX_TRY(job->dScratch.alloc(leverage_scratch_doubles(K, G) * sizeof(double)));
         FDX_TRY(launch_leverage(job->dX.as<double>(), K, G, regularization, job->dW.as<double>(), job->dS.as<double>(),
-                                job->dL.as<double>(), job->dDbg.as<int>(), job->st));
+                                job->dL.as<double>(), job->dDbg.as<int>(), job->dScratch.as<double>(), job->st));
         return 0;
     };
     const int rc = run();
@@ -130,9 +131,7 @@ extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) {
     const hipError_t e = hipStreamSynchronize(job->st);   // always drain before the buffers go back to the pool
     if (!rc && e != hipSuccess) rc = fail(FDX_ERR_HIP, hipGetErrorString(e));
     if (!rc && getenv("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
-        std::fprintf(stderr, "[fdx] leverage: K=%d G=%d sweeps=%d  us: gram=%d eigen=%d apply=%d polish=%d end=%d\n", job->K, job->G,
-                     dbg[0], dbg[1] / 100, (dbg[2] - dbg[1]) / 100, (dbg[3] - dbg[2]) / 100, (dbg[4] - dbg[3]) / 100,
-                     (dbg[5] - dbg[4]) / 100);
+        std::fprintf(stderr, "[fdx] leverage: K=%d G=%d passes/sweeps=%d converged=%d\n", job->K, job->G, dbg[0], dbg[6]);
     delete job;
     return rc;
 }

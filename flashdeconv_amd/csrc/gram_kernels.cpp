@@ -104,7 +104,9 @@ template <int NB, int T>
 __global__ __launch_bounds__(512) void xyt_split_kernel(const double* __restrict__ Xs, const double* __restrict__ Ys,
                                                         long long ldy, int n, int d, int K, double* __restrict__ Hout,
                                                         long long ldh) {
-    __shared__ double red[2][8][T * 4 * 64];
+    // T <= 2: two reduction buffers, one barrier per tile; T = 3, 4: one 64 KB buffer, a second barrier per tile
+    constexpr int NBUF = (T <= 2) ? 2 : 1;
+    __shared__ double red[NBUF][8][T * 4 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(512) void xyt_split_kernel(const double* __restrict
     }
     const int n_tiles = (n + 15) / 16;
     int buf = 0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf = (NBUF == 2) ? (buf ^ 1) : 0) {
         const int s0 = tile * 16;
         const int spot = s0 + r;
         const bool spot_ok = spot < n;
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(512) void xyt_split_kernel(const double* __restrict
             const int sp = s0 + (l & 15);
             if (type < K && sp < n) Hout[(size_t)type * ldh + sp] = sum;
         }
-        // the other buffer is used by the next tile; a tile's buffer is reused two tiles later, after another barrier
+        // NBUF = 2: the other buffer is used by the next tile; a tile's buffer is reused two tiles later, after another barrier
+        if (NBUF == 1) __syncthreads();
     }
 }
 
@@ -226,18 +229,30 @@ int launch_xyt(const double* Xs, const double* Ys, long long ldy, long long n, i
     const long long waves = (n + 15) / 16;
     const int blocks = (int)((waves + 3) / 4);
     {   // large-n fast path: X_sketch register-resident, contraction split over 8 waves
-        const bool ok = !sumsq_partials && (d % 16 == 0) && d <= 1024 && K <= 32 && (ldy % 4 == 0) &&
+        const bool ok = !sumsq_partials && (d % 16 == 0) && d <= 1024 && K <= 64 && (ldy % 4 == 0) &&
                         ((reinterpret_cast<uintptr_t>(Xs) & 31) == 0) && ((reinterpret_cast<uintptr_t>(Ys) & 31) == 0) &&
                         !getenv("FDX_XYT_PLAIN");
         if (ok) {
             const int nb = (d + 127) / 128;             // 16-wide blocks per wave
             const int T = (K + 15) / 16;
             const int grid = (int)std::min<long long>(waves, 256LL * 2);
-#define FDX_XYT_SPLIT(NB_, T_) hipLaunchKernelGGL((xyt_split_kernel<NB_, T_>), dim3(grid), dim3(512), 0, st, Xs, Ys, ldy, (int)n, d, K, Hout, ldh)
-            if (nb <= 1) { if (T == 1) FDX_XYT_SPLIT(1, 1); else FDX_XYT_SPLIT(1, 2); }
-            else if (nb <= 2) { if (T == 1) FDX_XYT_SPLIT(2, 1); else FDX_XYT_SPLIT(2, 2); }
-            else if (nb <= 4) { if (T == 1) FDX_XYT_SPLIT(4, 1); else FDX_XYT_SPLIT(4, 2); }
-            else { if (T == 1) FDX_XYT_SPLIT(8, 1); else FDX_XYT_SPLIT(8, 2); }
+#define FDX_XYT_SPLIT(NB_, T_, XS_, H_, K_) hipLaunchKernelGGL((xyt_split_kernel<NB_, T_>), dim3(grid), dim3(512), 0, st, XS_, Ys, ldy, (int)n, d, K_, H_, ldh)
+            if (T <= 2) {
+                if (nb <= 1) { if (T == 1) FDX_XYT_SPLIT(1, 1, Xs, Hout, K); else FDX_XYT_SPLIT(1, 2, Xs, Hout, K); }
+                else if (nb <= 2) { if (T == 1) FDX_XYT_SPLIT(2, 1, Xs, Hout, K); else FDX_XYT_SPLIT(2, 2, Xs, Hout, K); }
+                else if (nb <= 4) { if (T == 1) FDX_XYT_SPLIT(4, 1, Xs, Hout, K); else FDX_XYT_SPLIT(4, 2, Xs, Hout, K); }
+                else { if (T == 1) FDX_XYT_SPLIT(8, 1, Xs, Hout, K); else FDX_XYT_SPLIT(8, 2, Xs, Hout, K); }
+            } else if (nb <= 4) {                       // 33..64 types, d <= 512: four type tiles in one pass
+                if (nb <= 1) FDX_XYT_SPLIT(1, 4, Xs, Hout, K);
+                else if (nb <= 2) FDX_XYT_SPLIT(2, 4, Xs, Hout, K);
+                else FDX_XYT_SPLIT(4, 4, Xs, Hout, K);
+            } else {                                    // 33..64 types, d > 512: A operands of four tiles do not fit in
+                const int K2 = K - 32;                  // registers - two passes over Y_sketch, 32 types each
+                FDX_XYT_SPLIT(8, 2, Xs, Hout, 32);
+                FDX_CHECK_LAUNCH();
+                if (K2 <= 16) FDX_XYT_SPLIT(8, 1, Xs + (size_t)32 * d, Hout + (size_t)32 * ldh, K2);
+                else FDX_XYT_SPLIT(8, 2, Xs + (size_t)32 * d, Hout + (size_t)32 * ldh, K2);
+            }
 #undef FDX_XYT_SPLIT
             FDX_CHECK_LAUNCH();
             return 0;

@@ -16,6 +16,8 @@
 // coalesced loads, reduces the three inner products with wave shuffles and applies the rotation.  Rounds are
 // separated by workgroup barriers.  The reference matrix is tiny (K x G doubles), so this kernel is latency-, not
 // bandwidth-bound; it runs once per fit.
+#include <cstdlib>
+
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
 
@@ -274,10 +276,239 @@ __global__ __launch_bounds__(512) void leverage_jacobi_kernel(const double* __re
     if (tid == 0 && sweeps_out) { *sweeps_out = sweep; sweeps_out[5] = (int)(wall_clock64() - t_dbg0); }
 }
 
-// X: device (K, G) row-major; work: device K*G doubles; sig2: device K doubles; lev: device G doubles
+// ================================================================================================================
+// Multi-CU path (K <= 64): the same orthogonalisation as a short sequence of streaming kernels.
+//
+// One-sided Jacobi keeps the whole G x K matrix inside one workgroup: 1.6 ms at 30 x 2000, 9 ms at 50 x 5000, on one of
+// 256 CUs.  Here the tall matrix is only ever touched by grid-wide streaming kernels, and the workgroup-sized part is the
+// K x K problem:
+//   pass:  C = A A^T            (lev_gram_kernel: every block reduces a stripe of genes, partials summed in block order)
+//          C = V L V^T          (lev_eigen_kernel: one workgroup, parallel-order two-sided Jacobi in LDS; sets `done`
+//                                and sig2 = diag(C) when no off-diagonal entry is above the rotation threshold)
+//          A <- V^T A           (lev_rotate_kernel: lane = gene, V broadcast from LDS)
+// V is a product of plane rotations, so every pass preserves A's singular values and left vectors to machine precision
+// and only improves the orthogonality of its columns: after pass 1 they are orthogonal to ~eps*cond^2, after pass 2 to
+// ~eps (the Gram matrix of nearly orthogonal columns is nearly diagonal, where Jacobi is accurate in the RELATIVE sense),
+// pass 3 finds nothing to rotate and records sig2_j = ||a_j||^2 from the columns themselves.  Passes after `done` return
+// at once, so the sequence is launched unconditionally (no host round trip).  Finally
+//   lev_g = sum_j a_gj^2 / (sig2_j + reg)   (genes.py:281-285),   lev /= (sum lev + reg)   (genes.py:288).
+constexpr int LEV_STRIPE = 64;     // genes per block of the Gram kernel (64 x 65 doubles of LDS)
+constexpr int LEV_PASSES = 4;
+
+__global__ __launch_bounds__(256) void lev_centre_kernel(const double* __restrict__ X, int K, int G, double* __restrict__ A) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    double m = 0.0;
+    for (int k = 0; k < K; ++k) m += X[(size_t)k * G + g];
+    m /= (double)K;                                                       // genes.py:264
+    for (int k = 0; k < K; ++k) A[(size_t)k * G + g] = X[(size_t)k * G + g] - m;
+}
+
+// part[b][p][q] = sum over the block's genes of A[p][g] A[q][g]
+__global__ __launch_bounds__(256) void lev_gram_kernel(const double* __restrict__ A, int K, int G,
+                                                       double* __restrict__ part, const int* __restrict__ done) {
+    if (*done) return;
+    __shared__ double tile[64][LEV_STRIPE + 1];
+    const int g0 = blockIdx.x * LEV_STRIPE;
+    for (int e = threadIdx.x; e < K * LEV_STRIPE; e += 256) {
+        const int k = e / LEV_STRIPE, j = e - k * LEV_STRIPE;
+        tile[k][j] = (g0 + j < G) ? A[(size_t)k * G + g0 + j] : 0.0;
+    }
+    __syncthreads();
+    double* out = part + (size_t)blockIdx.x * K * K;
+    for (int e = threadIdx.x; e < K * K; e += 256) {
+        const int p = e / K, q = e - p * K;
+        if (q < p) continue;                                              // upper triangle, mirrored
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < LEV_STRIPE; j += 2) {
+            a0 = fma(tile[p][j], tile[q][j], a0);
+            a1 = fma(tile[p][j + 1], tile[q][j + 1], a1);
+        }
+        const double v = a0 + a1;
+        out[p * K + q] = v;
+        out[q * K + p] = v;
+    }
+}
+
+// C = sum_b part[b] (block order); two-sided Jacobi; V -> global.  `done` and sig2 when C is already diagonal.
+__global__ __launch_bounds__(512) void lev_eigen_kernel(const double* __restrict__ part, int n_blocks, int K,
+                                                        double* __restrict__ Vout, double* __restrict__ sig2,
+                                                        int* __restrict__ done, int* __restrict__ passes) {
+    if (*done) return;
+    extern __shared__ __attribute__((aligned(16))) double s_gram[];
+    __shared__ int s_rot, s_first;
+    double (*C)[65] = reinterpret_cast<double (*)[65]>(s_gram);
+    double (*V)[65] = reinterpret_cast<double (*)[65]>(s_gram + 64 * 65);
+    double* cs = s_gram + 2 * 64 * 65;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < K * K; e += 512) {
+        double acc = 0.0;
+        for (int b = 0; b < n_blocks; ++b) acc += part[(size_t)b * K * K + e];
+        C[e / K][e % K] = acc;
+        V[e / K][e % K] = (e / K == e % K) ? 1.0 : 0.0;
+    }
+    if (tid == 0) s_first = 0;
+    __syncthreads();
+    if (tid < K) cs[128 + tid] = C[tid][tid];                             // ||a_j||^2 of the incoming columns
+    const int Kq = (K + 1) & ~1, npair = Kq / 2;
+    for (int sw = 0; sw < 12; ++sw) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int r = 0; r < Kq - 1; ++r) {
+            if (tid < npair) {
+                int p, q;
+                if (tid == 0) { p = Kq - 1; q = r; } else { p = (r + tid) % (Kq - 1); q = (r - tid + (Kq - 1)) % (Kq - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, sn = 0.0;
+                if (q < K) {
+                    const double cpq = C[p][q], cpp = C[p][p], cqq = C[q][q];
+                    if (fabs(cpq) > 1e-14 * sqrt(fabs(cpp * cqq)) && cpq != 0.0) {
+                        const double theta = (cqq - cpp) / (2.0 * cpq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        sn = c * t;
+                        s_rot = 1;
+                        s_first = 1;
+                    }
+                }
+                cs[2 * tid] = c; cs[2 * tid + 1] = sn;
+            }
+            __syncthreads();
+            for (int e = tid; e < npair * K; e += 512) {                  // columns p,q of C and V
+                const int m = e / K, k = e - m * K;
+                int p, q;
+                if (m == 0) { p = Kq - 1; q = r; } else { p = (r + m) % (Kq - 1); q = (r - m + (Kq - 1)) % (Kq - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                if (q >= K) continue;
+                const double c = cs[2 * m], sn = cs[2 * m + 1];
+                const double ckp = C[k][p], ckq = C[k][q];
+                C[k][p] = c * ckp - sn * ckq;
+                C[k][q] = sn * ckp + c * ckq;
+                const double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = c * vkp - sn * vkq;
+                V[k][q] = sn * vkp + c * vkq;
+            }
+            __syncthreads();
+            for (int e = tid; e < npair * K; e += 512) {                  // rows p,q of C
+                const int m = e / K, k = e - m * K;
+                int p, q;
+                if (m == 0) { p = Kq - 1; q = r; } else { p = (r + m) % (Kq - 1); q = (r - m + (Kq - 1)) % (Kq - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                if (q >= K) continue;
+                const double c = cs[2 * m], sn = cs[2 * m + 1];
+                const double cpk = C[p][k], cqk = C[q][k];
+                C[p][k] = c * cpk - sn * cqk;
+                C[q][k] = sn * cpk + c * cqk;
+            }
+            __syncthreads();
+        }
+        const int any = s_rot;
+        __syncthreads();
+        if (!any) break;
+    }
+    if (!s_first) {                      // nothing to rotate: the columns are orthogonal, their norms are the answer
+        if (tid < K) sig2[tid] = cs[128 + tid];
+        if (tid == 0) *done = 1;
+    } else {
+        for (int e = tid; e < K * K; e += 512) Vout[e] = V[e / K][e % K];
+        if (tid == 0) *passes += 1;
+    }
+}
+
+// A[:, g] <- V^T A[:, g]
+__global__ __launch_bounds__(256) void lev_rotate_kernel(double* __restrict__ A, int K, int G, const double* __restrict__ Vin,
+                                                         const int* __restrict__ done) {
+    if (*done) return;
+    __shared__ double V[64][65];
+    for (int e = threadIdx.x; e < K * K; e += 256) V[e / K][e % K] = Vin[e];
+    __syncthreads();
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    double av[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) av[i] = (i < K && g < G) ? A[(size_t)i * G + g] : 0.0;
+    for (int j = 0; j < K; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            if (i < K) acc = fma(V[i][j], av[i], acc);
+        if (g < G) A[(size_t)j * G + g] = acc;
+    }
+}
+
+// not converged within LEV_PASSES (never seen): take the column norms of the last pass's Gram diagonal anyway
+__global__ __launch_bounds__(64) void lev_diag_kernel(const double* __restrict__ part, int n_blocks, int K,
+                                                      double* __restrict__ sig2, const int* __restrict__ done) {
+    if (*done) return;
+    const int j = threadIdx.x;
+    if (j >= K) return;
+    double acc = 0.0;
+    for (int b = 0; b < n_blocks; ++b) acc += part[(size_t)b * K * K + j * K + j];
+    sig2[j] = acc;
+}
+
+__global__ __launch_bounds__(256) void lev_scores_kernel(const double* __restrict__ A, int K, int G, const double* __restrict__ sig2,
+                                                         double reg, double* __restrict__ lev, double* __restrict__ bsum) {
+    __shared__ double sh[256];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    double l = 0.0;
+    if (g < G) {
+        for (int j = 0; j < K; ++j) { const double x = A[(size_t)j * G + g]; l += x * x / (sig2[j] + reg); }
+        lev[g] = l;
+    }
+    sh[threadIdx.x] = l;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void lev_normalise_kernel(double* __restrict__ lev, int G, const double* __restrict__ bsum,
+                                                            int n_blocks, double reg) {
+    double total = 0.0;
+    for (int b = 0; b < n_blocks; ++b) total += bsum[b];                  // same order in every block
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < G) lev[g] = lev[g] / (total + reg);
+}
+
+size_t leverage_scratch_doubles(int K, int G) {
+    const size_t nb = (size_t)(G + LEV_STRIPE - 1) / LEV_STRIPE;
+    return nb * K * K + (size_t)K * K + (size_t)(G + 255) / 256 + 16;
+}
+
+static int launch_leverage_multi(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev,
+                                 int* sweeps, double* scratch, hipStream_t st) {
+    const int nb = (G + LEV_STRIPE - 1) / LEV_STRIPE, gb = (G + 255) / 256;
+    double* part = scratch;
+    double* V = part + (size_t)nb * K * K;
+    double* bsum = V + (size_t)K * K;
+    int* done = sweeps + 6;                                               // sweeps: 8 ints, [0] = passes, [6] = done flag
+    FDX_HIP(hipMemsetAsync(sweeps, 0, 8 * sizeof(int), st));
+    constexpr size_t kLds = (2 * 64 * 65 + 64 + 128 + 64) * sizeof(double);
+    FDX_HIP(hipFuncSetAttribute((const void*)lev_eigen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+    hipLaunchKernelGGL(lev_centre_kernel, dim3(gb), dim3(256), 0, st, X, K, G, work);
+    for (int pass = 0; pass < LEV_PASSES; ++pass) {
+        hipLaunchKernelGGL(lev_gram_kernel, dim3(nb), dim3(256), 0, st, work, K, G, part, done);
+        hipLaunchKernelGGL(lev_eigen_kernel, dim3(1), dim3(512), kLds, st, part, nb, K, V, sig2, done, sweeps);
+        hipLaunchKernelGGL(lev_rotate_kernel, dim3(gb), dim3(256), 0, st, work, K, G, V, done);
+    }
+    hipLaunchKernelGGL(lev_gram_kernel, dim3(nb), dim3(256), 0, st, work, K, G, part, done);
+    hipLaunchKernelGGL(lev_diag_kernel, dim3(1), dim3(64), 0, st, part, nb, K, sig2, done);
+    hipLaunchKernelGGL(lev_scores_kernel, dim3(gb), dim3(256), 0, st, work, K, G, sig2, reg, lev, bsum);
+    hipLaunchKernelGGL(lev_normalise_kernel, dim3(gb), dim3(256), 0, st, lev, G, bsum, gb, reg);
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+// X: device (K, G) row-major; work: device K*G doubles; sig2: device K doubles; lev: device G doubles; sweeps: 8 ints;
+// scratch: leverage_scratch_doubles(K, G) doubles
 int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
-                    hipStream_t st) {
+                    double* scratch, hipStream_t st) {
     if (K <= 0 || G <= 0) return fail(FDX_ERR_INVALID, "leverage: empty reference matrix");
+    if (K <= 64 && K >= 2 && scratch && !getenv("FDX_LEV_ONE_WG"))
+        return launch_leverage_multi(X, K, G, reg, work, sig2, lev, sweeps, scratch, st);
     constexpr size_t kLevLds = (2 * 64 * 65 + 64) * sizeof(double);   // Gram matrix, rotations, per-round (c, s) pairs
     FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));
     FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));

@@ -6,6 +6,7 @@ import pytest
 from scipy import sparse
 
 import datagen
+import fdx_oracle as orc
 from conftest import load_golden, rel_fro
 
 pytestmark = pytest.mark.gpu
@@ -163,6 +164,25 @@ def test_leverage_scores_vs_reference():
     for name in g["names"]:
         lev = compute_leverage_scores(g[f"{name}_X"])
         np.testing.assert_allclose(lev, g[f"{name}_lev"], rtol=1e-9, atol=1e-14, err_msg=str(name))
+
+
+@pytest.mark.parametrize("K,G,cond", [(30, 2000, 1e2), (50, 5000, 1e5), (64, 3000, 1e6), (7, 90, 1e3), (2, 50, 1.0), (33, 1000, 1e4)])
+def test_leverage_multi_cu_path_vs_lapack_and_one_workgroup(K, G, cond, monkeypatch):
+    """The streaming Gram/eigen/rotate passes against LAPACK (the reference's gesdd route, via the oracle) and against
+    the one-workgroup one-sided Jacobi kernel, on signature matrices with a prescribed condition number."""
+    from flashdeconv_amd.utils.genes import compute_leverage_scores
+    rs = np.random.RandomState(K + G)
+    U, _ = np.linalg.qr(rs.randn(G, K))
+    Vt, _ = np.linalg.qr(rs.randn(K, K))
+    s = np.geomspace(1.0, 1.0 / cond, K) * 50.0
+    X = (U * s) @ Vt + rs.rand(G, 1) * 3.0          # (G, K) with a per-gene offset that centring removes
+    X = np.ascontiguousarray(X.T)
+    want = orc.leverage_scores(X)
+    got = compute_leverage_scores(X)
+    np.testing.assert_allclose(got, want, rtol=2e-8 * max(1.0, cond / 1e4), atol=1e-15)
+    monkeypatch.setenv("FDX_LEV_ONE_WG", "1")
+    one = compute_leverage_scores(X)
+    np.testing.assert_allclose(got, one, rtol=2e-8 * max(1.0, cond / 1e4), atol=1e-15)
 
 
 def test_seed_reproducibility_and_errors():

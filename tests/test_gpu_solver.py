@@ -94,6 +94,20 @@ def test_all_kernel_variants_vs_oracle(fdx, K):
     np.testing.assert_allclose(ginfo["final_objective"], winfo["final_objective"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("K,d", [(40, 512), (64, 512), (50, 1024), (33, 640), (48, 256), (30, 1024)])
+def test_wide_contractions_vs_oracle(fdx, K, d):
+    """H = X_sketch Y_sketch^T for 33..64 cell types (four type tiles in one pass up to d = 512, two passes of 32 types
+    above) and for d = 1024, through the whole solve."""
+    n = 333
+    Ys, Xs, coords, _ = datagen.sketched_problem(n, K, d, seed=K + d)
+    A = orc.knn_graph_kdtree(coords * 30, 6)
+    want, winfo = orc.bcd_solve(Ys, Xs, A, 0.2, 0.02, max_iter=12, tol=1e-9)
+    got, ginfo = fdx.bcd_solve(Ys, Xs, A, lambda_=0.2, rho=0.02, max_iter=12, tol=1e-9)
+    assert ginfo["n_iterations"] == winfo["n_iterations"]
+    assert rel_fro(got, want) < TOL
+    np.testing.assert_allclose(ginfo["final_objective"], winfo["final_objective"], rtol=1e-9)
+
+
 def test_irregular_graph_and_odd_sketch_dim(fdx):
     # hub-and-spoke + ring: one row far wider than the slice average, d not a multiple of 16
     n, K, d = 333, 9, 37
