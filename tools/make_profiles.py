@@ -13,7 +13,7 @@ def one(pattern):
     f = glob.glob(os.path.join(src, pattern), recursive=True)
     if not f:
         raise SystemExit(f"missing {pattern} under {src}")
-    return f[0]
+    return max(f, key=os.path.getmtime)          # gpurun merges into gpurun_out/: older runs' files may still be there
 
 
 # ---- kernel stats
