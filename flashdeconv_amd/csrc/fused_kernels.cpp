@@ -220,10 +220,11 @@ size_t fused_lds_bytes(int G, int d, int K) {
 
 bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, const SketchPlanDev& plan) {
     // Opt-in (FDX_FUSED=1).  Measured on MI355X at 1M x 2000 -> 512, K = 30: 3.7-3.8 ms against 2.56 + 0.95 ms for the two
-    // kernels it replaces, with or without the software pipeline: at one LDS atomic and two LDS reads per gene the scatter
-    // phase is bound by the CU's LDS pipe (~1500 cycles per spot), not by HBM, and with one 8-wave workgroup per CU the
-    // barriers and the MFMA phase are exposed.  Kept, with its bit-equality test, as the starting point for a
-    // register-resident gene table (one LDS operation per gene instead of three).
+    // kernels it replaces, with or without the software pipeline.  The LDS footprint (table 20 KB + 16 accumulator rows
+    // 68 KB + reduction 32 KB) allows one 8-wave workgroup per CU; a wave needs ~6.5 us per row (32 dependent
+    // table-read -> atomic steps per lane, zeroing, norm) and two waves per SIMD cannot hide that.  A register-resident
+    // gene table was tried on the scatter kernel and is no faster, so the LDS reads are not the bound.  Kept, with its
+    // bit-equality test, as the starting point for a variant that holds >= 16 waves per CU.
     if (!getenv("FDX_FUSED") || getenv("FDX_NO_FUSED")) return false;
     if (!plan.scatter_ok || d % 16 != 0 || d > 512 || K > 32 || K <= 0 || G <= 0) return false;
     if (dtype != FDX_F32 && dtype != FDX_F64) return false;
