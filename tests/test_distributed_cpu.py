@@ -113,6 +113,19 @@ def _worker(rank, world, port, q):
             solver = ShardedSolver(be, comm, halo_x, K, ld, n_own, n_total, max_iter=max_iter, tol=tol)
             beta, info = solver.run(lambda shape, dt: torch.zeros(shape, dtype=dt), 0.1, rho_eff)
             out[case] = (order[lo:hi], beta[:, :n_own].numpy().T.copy(), info)
+        # the one exchange of the sharded graph build: every rank wrote its own rows of the k-NN list arrays; after
+        # all_gather_rows all ranks hold all rows (uneven, 256-aligned shards; padded equal segments on the wire)
+        n, kk = 1100, 7
+        bounds = shard_bounds(n, world)
+        full_nbr = (np.arange(n * kk, dtype=np.int32).reshape(n, kk) * 7919) % n
+        full_cnt = (np.arange(n, dtype=np.int32) % kk)
+        nbr = torch.full((n, kk), -5, dtype=torch.int32)
+        cnt = torch.full((n,), -5, dtype=torch.int32)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        nbr[lo:hi] = torch.from_numpy(full_nbr[lo:hi])
+        cnt[lo:hi] = torch.from_numpy(full_cnt[lo:hi])
+        TorchComm().all_gather_rows(nbr, cnt, bounds)
+        out["gather_ok"] = bool(np.array_equal(nbr.numpy(), full_nbr) and np.array_equal(cnt.numpy(), full_cnt))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -134,6 +147,7 @@ def test_two_gloo_ranks_reproduce_single_process_solve():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert got[0]["gather_ok"] and got[1]["gather_ok"]
     for case, (n, K, d, max_iter, tol) in {"converges": (1500, 6, 32, 100, 1e-4), "max_iter": (900, 5, 24, 7, 1e-12)}.items():
         Ys, Xs, coords, _ = datagen.sketched_problem(n, K, d, seed=3)
         A = orc.knn_graph_kdtree(coords * 40, 6)
