@@ -112,17 +112,18 @@ class HaloExchange:
     def __call__(self, beta):
         torch = self._torch
         K = beta.shape[0]
-        send, recv = {}, {}
-        for r in range(self.comm.world):
-            if r == self.comm.rank:
-                continue
-            if self.send_counts[r]:
-                idx = self.send_idx[self.send_off[r]:self.send_off[r + 1]]
-                send[r] = beta.index_select(1, idx).contiguous()
-            if self.recv_counts[r]:
-                recv[r] = torch.empty((K, self.recv_counts[r]), dtype=beta.dtype, device=beta.device)
-        self.comm.exchange(send, recv)
-        for r, t in recv.items():
+        key = (K, beta.dtype, beta.device)
+        if getattr(self, "_buf_key", None) != key:          # staging buffers are reused across iterations and fits
+            self._send = {r: torch.empty((K, c), dtype=beta.dtype, device=beta.device)
+                          for r, c in enumerate(self.send_counts) if c and r != self.comm.rank}
+            self._recv = {r: torch.empty((K, c), dtype=beta.dtype, device=beta.device)
+                          for r, c in enumerate(self.recv_counts) if c and r != self.comm.rank}
+            self._idx = {r: self.send_idx[self.send_off[r]:self.send_off[r + 1]] for r in self._send}
+            self._buf_key = key
+        for r, buf in self._send.items():
+            torch.index_select(beta, 1, self._idx[r], out=buf)
+        self.comm.exchange(self._send, self._recv)
+        for r, t in self._recv.items():
             lo = self.n_own + self.recv_off[r]
             beta[:, lo:lo + self.recv_counts[r]] = t
 

@@ -1,6 +1,13 @@
 import os
 import sys
 
+# The oracle (OpenMP C sweep, numpy/LAPACK stages) checks small problems; on a 256-core GPU host the default "one thread
+# per core" makes every tiny parallel region and LAPACK call cost milliseconds to seconds (observed: a 5-test file taking
+# 14 minutes on a busy box).  Must be set before numpy / libgomp load.
+for _var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, "8")
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 import numpy as np
 import pytest
 

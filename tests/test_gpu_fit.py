@@ -82,6 +82,31 @@ def test_fit_sparse_input_stays_sparse(pre, kind):
     _check(m, g)
 
 
+@pytest.mark.parametrize("n,G,K,d,n_hvg,pre", [(37, 90, 3, 16, 2000, "log_cpm"), (257, 700, 6, 100, 300, "log_cpm"),
+                                               (130, 64, 2, 1, 2000, "raw"), (513, 1300, 9, 192, 500, "pearson"),
+                                               (64, 40, 4, 33, 25, "log_cpm")])
+def test_sparse_fit_vs_oracle_odd_shapes(n, G, K, d, n_hvg, pre):
+    """CSR path on shapes the goldens do not cover (tiny n, sketch_dim 1 / odd, gene selection on and off): against the
+    oracle's sparse branches, plus CSR == dense input when the reference's two log-CPM rules coincide (no empty spot)."""
+    from flashdeconv_amd import FlashDeconv
+    rs = np.random.RandomState(n + G)
+    X = np.exp(rs.randn(K, G) * 0.7)
+    B = rs.dirichlet(np.ones(K), size=n)
+    Y = rs.poisson(B @ X * 3.0) * (rs.rand(n, G) < 0.35)
+    Y[:, 0] += 1                                                   # no empty spot: sparse and dense log-CPM agree
+    coords = rs.rand(n, 2) * 20
+    Ys = sparse.csr_matrix(Y.astype(np.float64))
+    kw = dict(sketch_dim=d, preprocess=pre, n_hvg=n_hvg, n_markers_per_type=5, max_iter=15, tol=1e-9)
+    m = FlashDeconv(**kw).fit(Ys, X, coords)
+    want = orc.fit(Ys, X, coords, sketch_dim=d, preprocess_method=pre, n_hvg=n_hvg, n_markers_per_type=5, max_iter=15,
+                   tol=1e-9, graph="kdtree")
+    assert np.array_equal(m.gene_idx_, want["gene_idx"])
+    assert m.info_["n_iterations"] == want["info"]["n_iterations"]
+    assert rel_fro(m.beta_, want["beta"]) < 1e-8 and rel_fro(m.proportions_, want["proportions"]) < 1e-8
+    md = FlashDeconv(**kw).fit(Y.astype(np.float64), X, coords)
+    assert np.array_equal(md.gene_idx_, m.gene_idx_) and rel_fro(md.beta_, m.beta_) < 1e-9
+
+
 def test_csr_gene_moments_and_validation():
     from flashdeconv_amd import _lib
     from flashdeconv_amd.utils import genes
