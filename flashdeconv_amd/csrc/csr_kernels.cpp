@@ -17,6 +17,7 @@
 // the 1e-4 parity budget is 12 orders of magnitude above it.  The finished row is written as one coalesced d*8-byte row
 // of Y_sketch exactly like the dense kernel, so the H contraction downstream is shared.
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_math.h"
 #include "fdx_internal.h"
@@ -65,16 +66,17 @@ __global__ __launch_bounds__(256) void sketch_csr_kernel(const long long* __rest
                                                          const GeneSlot* __restrict__ table,
                                                          const unsigned* __restrict__ sel_bits, int sel_words,
                                                          double* __restrict__ Ys, long long ldys,
-                                                         double* __restrict__ row_sumsq) {
+                                                         double* __restrict__ row_sumsq, int no_table) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_blk = blockDim.x >> 6;
-    double* acc = reinterpret_cast<double*>(smem) + (size_t)wib * d;
+    double* acc = reinterpret_cast<double*>(smem) + (size_t)wib * (d + 64);
+    double* tab = acc + d;                                             // this wave's log1p table (device_math.h)
     // "is this column selected?" as a bitmap in LDS (G_all / 8 bytes): typically one stored entry in six belongs to a
     // selected gene, and only those go on to the 16-byte table gather - a gather per stored entry made the kernel
     // L2-request-bound (1.4e9 scattered 16-byte reads at 1M spots x 1438 entries).
-    unsigned* bits = reinterpret_cast<unsigned*>(smem + (size_t)waves_per_blk * d * sizeof(double));
+    unsigned* bits = reinterpret_cast<unsigned*>(smem + (size_t)waves_per_blk * (d + 64) * sizeof(double));
     for (int j = threadIdx.x; j < sel_words; j += blockDim.x) bits[j] = sel_bits[j];
     __syncthreads();
     const long long wave0 = (long long)blockIdx.x * waves_per_blk + wib;
@@ -94,19 +96,25 @@ __global__ __launch_bounds__(256) void sketch_csr_kernel(const long long* __rest
         }
         for (int c = lane; c < d; c += 64) acc[c] = 0.0;
         double scale = 1.0;
+        bool use_tab = false;
         CsrGroup<T> cur, nxt;
         if (MODE != FDX_PRE_RAW) {      // library size over the SELECTED genes (the subset is taken first, deconv.py:321)
-            double s = 0.0;
+            double s = 0.0, mx = 0.0;
             csr_load_group(cur, indices, data, beg, end, lane);
             for (long long q0 = beg; q0 < end; q0 += 256) {
                 csr_load_group(nxt, indices, data, q0 + 256, end, lane);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u)) s += (double)cur.y[u];
+                    if (cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u)) {
+                        s += (double)cur.y[u];
+                        mx = fmax(mx, (double)cur.y[u]);
+                    }
                 cur = nxt;
             }
             s = wave_sum(s);
             scale = 10000.0 / (s == 0.0 ? 1.0 : s);                    // deconv.py:183-185
+            use_tab = !no_table && wave_max(mx) < 64.0;
+            if (use_tab) log1p_table_fill(tab, scale, lane);
         }
         csr_load_group(cur, indices, data, beg, end, lane);
         __builtin_amdgcn_s_waitcnt(0xc07f);                            // zeroing done before the adds
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void sketch_csr_kernel(const long long* __rest
             for (int u = 0; u < 4; ++u) {
                 if (e[u].bucket >= 0) {
                     double v = (double)cur.y[u];
-                    if (MODE != FDX_PRE_RAW) v = fast_log1p(v * scale);
+                    if (MODE != FDX_PRE_RAW) v = log1p_scaled(v, scale, tab, use_tab);
                     lds_add(acc + e[u].bucket, e[u].w * v);
                 }
             }
@@ -151,15 +159,15 @@ static int launch_sketch_csr_t(const long long* indptr, const int* indices, cons
                                long long n, int d, int mode, const void* table, const unsigned* sel_bits, int sel_words,
                                double* Ys, long long ldys, double* row_sumsq, hipStream_t st) {
     int waves = 4;
-    while (waves > 1 && (size_t)d * 8 * waves > 64 * 1024) waves >>= 1;
-    const size_t lds = (size_t)d * 8 * waves + (size_t)sel_words * 4;
+    while (waves > 1 && ((size_t)d + 64) * 8 * waves > 64 * 1024) waves >>= 1;
+    const size_t lds = ((size_t)d + 64) * 8 * waves + (size_t)sel_words * 4;
     if (lds > 160 * 1024) return fail(FDX_ERR_UNSUPPORTED, "sketch (CSR): sketch_dim and the gene bitmap do not fit in LDS");
     const int blocks = (int)std::min<long long>((n + waves - 1) / waves, 256LL * 16);
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             FDX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, indptr, indices, data, row_map, row0, n, d,
-                           (const GeneSlot*)table, sel_bits, sel_words, Ys, ldys, row_sumsq);
+                           (const GeneSlot*)table, sel_bits, sel_words, Ys, ldys, row_sumsq, getenv("FDX_NO_LOG_TABLE") ? 1 : 0);
         FDX_CHECK_LAUNCH();
         return 0;
     };
@@ -194,24 +202,29 @@ size_t csr_gene_slot_bytes() { return sizeof(GeneSlot); }
 // (Zeros contribute nothing to any of the sums: genes.py:52-54.)
 template <typename T>
 __global__ __launch_bounds__(256) void csr_row_scale_kernel(const long long* __restrict__ indptr, const T* __restrict__ data,
-                                                            long long n, double* __restrict__ scale) {
+                                                            long long n, double* __restrict__ scale, int no_table) {
     const int lane = threadIdx.x & 63;
     const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= n) return;
     const long long beg = indptr[row], end = indptr[row + 1];
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, mx = 0.0;
     long long q = beg + lane;
     for (; q + 192 < end; q += 256) {
         const double a = (double)data[q], b = (double)data[q + 64], c = (double)data[q + 128], e = (double)data[q + 192];
         s0 += a; s1 += b; s2 += c; s3 += e;
+        mx = fmax(fmax(mx, a), fmax(fmax(b, c), e));
     }
-    for (; q < end; q += 64) s0 += (double)data[q];
+    for (; q < end; q += 64) { s0 += (double)data[q]; mx = fmax(mx, (double)data[q]); }
     const double s = wave_sum((s0 + s1) + (s2 + s3));
-    if (lane == 0) scale[row] = 10000.0 / fmax(s, 1.0);                 // genes.py:57-59
+    mx = wave_max(mx);
+    // genes.py:57-59; the sign carries "every entry of the row is below 64" (log1p by table in the moments kernel)
+    if (lane == 0) scale[row] = ((mx < 64.0 && !no_table) ? 1.0 : -1.0) * (10000.0 / fmax(s, 1.0));
 }
 
+// 8 waves per SIMD (<= 64 VGPRs): two 16-wave workgroups per CU - at 66 VGPRs only one fits and the kernel takes 17.6 ms
+// instead of 10.7 (measured)
 template <typename T, int NS>
-__global__ __launch_bounds__(1024) void csr_moments_tiled_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+__global__ __launch_bounds__(1024, 8) void csr_moments_tiled_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
                                                                 const T* __restrict__ data, const double* __restrict__ scale,
                                                                 long long n, int G, int tile, int rows_per_stripe,
                                                                 double* __restrict__ part /* (stripes, NS, G) */) {
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(1024) void csr_moments_tiled_kernel(const long long
     double* acc = reinterpret_cast<double*>(smem);                       // [NS][tile]
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* tab = acc + (size_t)NS * tile + (size_t)wib * 64;           // per-wave log1p table (device_math.h)
     const int t0 = blockIdx.y * tile;
     const int tw = min(tile, G - t0);
     for (int j = threadIdx.x; j < NS * tile; j += 1024) acc[j] = 0.0;
@@ -227,7 +241,11 @@ __global__ __launch_bounds__(1024) void csr_moments_tiled_kernel(const long long
     const long long r1 = min(n, r0 + rows_per_stripe);
     for (long long row = r0 + wib; row < r1; row += 16) {     // 16 waves share the tile: 2 blocks = 32 waves per CU
         const long long beg = indptr[row], end = indptr[row + 1];
-        const double sc = scale[row];
+        const double sc_signed = scale[row];
+        const double sc = fabs(sc_signed);
+        const bool use_tab = sc_signed > 0.0;
+        if (use_tab) log1p_table_fill(tab, sc, lane);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         for (long long q0 = beg; q0 < end; q0 += 256) {
             int c[4];
 #pragma unroll
@@ -239,7 +257,7 @@ __global__ __launch_bounds__(1024) void csr_moments_tiled_kernel(const long long
             for (int u = 0; u < 4; ++u) {
                 if (c[u] >= 0 && c[u] < tw) {
                     const double y = (double)data[q0 + u * 64 + lane];
-                    const double z = fast_log1p(y * sc);
+                    const double z = log1p_scaled(y, sc, tab, use_tab);
                     lds_add(acc + c[u], z);
                     lds_add(acc + tile + c[u], z * z);
                     if (NS == 3) lds_add(acc + 2 * tile + c[u], y);
@@ -278,13 +296,16 @@ int csr_moment_stripes(long long n) { return (int)std::min<long long>(512, std::
 template <typename T, int NS>
 static int launch_csr_moments_t(const long long* indptr, const int* indices, const T* data, long long n, int G, double* scale,
                                 double* part, double* mean, double* var, double* colsum, hipStream_t st) {
-    const int tile = std::min(G, (int)(64 * 1024 / (NS * sizeof(double))));
+    const int tile = std::min(G, (int)(64 * 1024 / (NS * sizeof(double))));   // + 16 waves x 512 B of log1p tables
     const int tiles = ceil_div(G, tile);
     const int stripes = csr_moment_stripes(n);
     const int rows_per_stripe = (int)((n + stripes - 1) / stripes);
-    hipLaunchKernelGGL(csr_row_scale_kernel<T>, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, indptr, data, n, scale);
+    const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
+    hipLaunchKernelGGL(csr_row_scale_kernel<T>, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, indptr, data, n, scale, no_table);
     FDX_CHECK_LAUNCH();
-    hipLaunchKernelGGL((csr_moments_tiled_kernel<T, NS>), dim3(stripes, tiles), dim3(1024), (size_t)NS * tile * sizeof(double), st,
+    const size_t lds_m = (size_t)NS * tile * sizeof(double) + 16 * 64 * sizeof(double);
+    FDX_HIP(hipFuncSetAttribute((const void*)csr_moments_tiled_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    hipLaunchKernelGGL((csr_moments_tiled_kernel<T, NS>), dim3(stripes, tiles), dim3(1024), lds_m, st,
                        indptr, indices, data, scale, n, G, tile, rows_per_stripe, part);
     FDX_CHECK_LAUNCH();
     hipLaunchKernelGGL(csr_fold_moments_kernel<NS>, dim3(ceil_div(G, 256)), dim3(256), 0, st, part, stripes, G, n, mean, var, colsum);

@@ -44,4 +44,29 @@ __device__ __forceinline__ double fast_log1p(double x) {
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + (dk * ln2_lo + c_over_u))) - f);
 }
 
+// log1p(y * scale) for one row of count data.  Counts are small non-negative integers, and all entries of a row share
+// `scale`, so the wave evaluates tab[c] = fast_log1p(c * scale) for c = 0..63 once per row (one value per lane, kept in
+// LDS) and every entry that is such an integer takes a table read instead of ~45 f64 instructions; anything else - larger
+// counts, normalised or non-integer input, NaN - is computed directly.  tab[c] is the same function of the same argument,
+// so results are bit-identical with and without the table.
+__device__ __forceinline__ void log1p_table_fill(double* tab, double scale, int lane) {
+    tab[lane] = fast_log1p((double)lane * scale);
+}
+
+// use_tab is wave-uniform (row maximum below 64): rows of large counts or normalised values skip the table and its
+// per-entry test altogether.
+__device__ __forceinline__ double log1p_scaled(double y, double scale, const double* tab, bool use_tab) {
+    if (use_tab) {
+        const int c = (int)y;
+        if ((double)c == y && (unsigned)c < 64u) return tab[c];
+    }
+    return fast_log1p(y * scale);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 }  // namespace fdx

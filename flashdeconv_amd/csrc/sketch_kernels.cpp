@@ -290,15 +290,16 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
                                                                   const double* __restrict__ gene_w,
                                                                   const int* __restrict__ gene_bucket,
                                                                   double* __restrict__ Ys, long long ldys,
-                                                                  double* __restrict__ row_sumsq) {
+                                                                  double* __restrict__ row_sumsq, int no_table) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_blk = blockDim.x >> 6;
     const int Gp = (G + 7) & ~7;
     double* w_l = reinterpret_cast<double*>(smem);                                   // [Gp]
-    double* acc = w_l + Gp + (size_t)wib * d;                                         // [waves][d]
-    unsigned short* b_l = reinterpret_cast<unsigned short*>(w_l + Gp + (size_t)waves_per_blk * d);   // [Gp]
+    double* acc = w_l + Gp + (size_t)wib * (d + 64);                                  // [waves][d + 64]
+    double* tab = acc + d;                                                            // this wave's log1p table (64)
+    unsigned short* b_l = reinterpret_cast<unsigned short*>(w_l + Gp + (size_t)waves_per_blk * (d + 64));   // [Gp]
     for (int g = threadIdx.x; g < Gp; g += blockDim.x) {
         const int b = (g < G) ? gene_bucket[g] : -1;
         w_l[g] = (g < G && b >= 0) ? gene_w[g] : 0.0;
@@ -316,8 +317,10 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
         const V* src = reinterpret_cast<const V*>(yrow);
         for (int c = lane; c < d; c += 64) acc[c] = 0.0;
         double scale = 1.0;
+        bool use_tab = false;
         if (MODE != FDX_PRE_RAW) {
             double part = 0.0;
+            T mx = (T)0;                                       // row maximum in the input type (one cheap max per entry)
             for (int v0 = 0; v0 < nvec; v0 += 512) {
                 V x[8];
 #pragma unroll
@@ -330,20 +333,22 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
                     const int v = v0 + u * 64 + lane;
                     if (v < nvec) {
 #pragma unroll
-                        for (int e = 0; e < PER; ++e) part += (double)x[u][e];
+                        for (int e = 0; e < PER; ++e) { part += (double)x[u][e]; mx = x[u][e] > mx ? x[u][e] : mx; }
                     }
                 }
             }
-            for (int g = nvec * PER + lane; g < G; g += 64) part += (double)yrow[g];
+            for (int g = nvec * PER + lane; g < G; g += 64) { part += (double)yrow[g]; mx = yrow[g] > mx ? yrow[g] : mx; }
             double sum = wave_sum(part);
+            use_tab = !no_table && wave_max((double)mx) < 64.0;        // a row of small counts: log1p by table (device_math.h)
             if (MODE == FDX_PRE_LOG_CPM) {
                 scale = (1.0 / (sum + 1e-10)) * 1e4;           // y / (rowsum + 1e-10) * 1e4   (deconv.py:190)
             } else {
                 if (sum == 0.0) sum = 1.0;                     // lib_size[lib_size == 0] = 1  (deconv.py:183-185)
                 scale = 1e4 / sum;
             }
+            if (use_tab) log1p_table_fill(tab, scale, lane);
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                    // zeroing done before the adds
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // zeroing (and the table) done before the adds
         for (int v0 = 0; v0 < nvec; v0 += 256) {               // 4 x 16-byte loads per lane in flight
             V x[4];
 #pragma unroll
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
                     for (int e = 0; e < PER; ++e) {
                         const int g = v * PER + e;
                         double y = (double)x[u][e];
-                        if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
+                        if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
                         const unsigned b = b_l[g];
                         if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
         }
         for (int g = nvec * PER + lane; g < G; g += 64) {
             double y = (double)yrow[g];
-            if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
+            if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
             const unsigned b = b_l[g];
             if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -427,8 +432,8 @@ static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, lon
     if (use_scatter) {
         const size_t Gp = ((size_t)G + 7) & ~(size_t)7;
         int wv = 8;
-        while (wv > 1 && Gp * 10 + (size_t)wv * d * 8 > 150 * 1024) wv >>= 1;
-        const size_t lds_s = Gp * 10 + (size_t)wv * d * 8;
+        while (wv > 1 && Gp * 10 + (size_t)wv * (d + 64) * 8 > 150 * 1024) wv >>= 1;
+        const size_t lds_s = Gp * 10 + (size_t)wv * (d + 64) * 8;
         if (lds_s <= 150 * 1024) {
             const bool vec_s = (ldy % (16 / (long long)sizeof(T)) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
             const int per_cu = std::max<int>(1, (int)((160 * 1024) / lds_s));
@@ -436,8 +441,9 @@ static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, lon
             auto ks = vec_s ? sketch_rows_scatter_kernel<T, MODE, true> : sketch_rows_scatter_kernel<T, MODE, false>;
             if (lds_s > 64 * 1024)
                 FDX_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
             hipLaunchKernelGGL(ks, dim3(blocks_s), dim3(wv * 64), lds_s, st, Y, ldy, row_map, n, G, d, plan.gene_w,
-                               plan.gene_bucket, Ys, ldys, row_sumsq);
+                               plan.gene_bucket, Ys, ldys, row_sumsq, no_table);
             FDX_CHECK_LAUNCH();
             return 0;
         }

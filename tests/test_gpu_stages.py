@@ -154,6 +154,28 @@ def test_scatter_and_gather_sketch_kernels_agree(G, d, mode, dtype, monkeypatch)
     assert np.array_equal(run(), got)                      # run-to-run identical bits
 
 
+@pytest.mark.parametrize("kind", ["dense_f32", "dense_f64", "csr"])
+def test_log1p_count_table_is_bit_identical(kind, monkeypatch):
+    """Rows whose entries are all below 64 take log1p from a per-row table of the 64 possible values (device_math.h);
+    the table holds the same function of the same argument, so switching it off (FDX_NO_LOG_TABLE=1) must not change a
+    bit.  Mixed data: small counts, a row with a count of 70 (no table), non-integer rows (table miss per entry)."""
+    from flashdeconv_amd import FlashDeconv
+    rs = np.random.RandomState(12)
+    n, G, K = 700, 900, 5
+    Y = rs.poisson(0.8, size=(n, G)).astype(np.float64)
+    Y[5, 17] = 70.0
+    Y[9] = rs.rand(G) * 3.0
+    Y[11, ::7] += 0.5
+    X = np.exp(rs.randn(K, G) * 0.5)
+    coords = rs.rand(n, 2) * 30
+    Yin = {"dense_f32": Y.astype(np.float32), "dense_f64": Y, "csr": sparse.csr_matrix(Y)}[kind]
+    kw = dict(sketch_dim=128, preprocess="log_cpm", n_hvg=G if kind != "csr" else 400, max_iter=10)
+    a = FlashDeconv(**kw).fit(Yin, X, coords)
+    monkeypatch.setenv("FDX_NO_LOG_TABLE", "1")
+    b = FlashDeconv(**kw).fit(Yin, X, coords)
+    assert np.array_equal(a.gene_idx_, b.gene_idx_) and np.array_equal(a.beta_, b.beta_)
+
+
 def test_log_cpm_transform_accuracy():
     """The device log1p (fdlibm decomposition in sketch_kernels.cpp) against numpy.log1p, through fdx_sketch with an
     identity-like Omega (one gene per bucket, weight 1) so that Y_sketch IS the transformed matrix."""
