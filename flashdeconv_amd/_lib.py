@@ -51,7 +51,7 @@ class FitParams(ctypes.Structure):
 class CsrView(ctypes.Structure):
     """fdx_csr_view: device pointers of a CSR matrix (include/fdx.h)."""
     _fields_ = [("indptr", c_void_p), ("indices", c_void_p), ("data", c_void_p), ("dtype", c_i32), ("n", c_i64),
-                ("nnz", c_i64), ("G", c_i32)]
+                ("nnz", c_i64), ("G", c_i32), ("sorted_rows", c_i32)]
 
 
 class FitInfo(ctypes.Structure):
@@ -299,10 +299,12 @@ class CsrOnDevice:
         return np.float64
 
     @classmethod
-    def from_scipy(cls, Y):
+    def from_scipy(cls, Y, sort=True):
         lib = load()
         if Y.format != "csr":
             Y = Y.tocsr()
+        if sort and not Y.has_sorted_indices:       # canonical rows let the statistics kernel read the indices once
+            Y = Y.sorted_indices()
         n, G = Y.shape
         if G >= 2 ** 31:
             raise ValueError("CSR matrix has too many columns")
@@ -319,7 +321,7 @@ class CsrOnDevice:
                 check(lib.fdx_memcpy_h2d(p, arr.ctypes.data, arr.nbytes, None))
             ptrs.append(p)
         self._fill(ptrs[0].value, ptrs[1].value, ptrs[2].value, FDX_F32 if data.dtype == np.float32 else FDX_F64, n,
-                   int(indptr[-1]) if len(indptr) else 0, G)
+                   int(indptr[-1]) if len(indptr) else 0, G, sorted_rows=1 if Y.has_sorted_indices else 0)
         return self
 
     @classmethod
@@ -338,11 +340,18 @@ class CsrOnDevice:
                    n, int(val.numel()), G)
         return self
 
-    def _fill(self, indptr, indices, data, dtype, n, nnz, G):
+    def _fill(self, indptr, indices, data, dtype, n, nnz, G, sorted_rows=1):
         v = self.view
         v.indptr, v.indices, v.data, v.dtype, v.n, v.nnz, v.G = indptr, indices, data, dtype, int(n), int(nnz), int(G)
+        v.sorted_rows = int(sorted_rows)            # claim, verified on the device
         try:
-            check(load().fdx_csr_check_dev(ctypes.byref(v), None))
+            try:
+                check(load().fdx_csr_check_dev(ctypes.byref(v), None))
+            except FdxError as e:
+                if "sorted_rows" not in str(e):
+                    raise
+                v.sorted_rows = 0                   # e.g. a torch CSR tensor built with unsorted columns: full-scan kernels
+                check(load().fdx_csr_check_dev(ctypes.byref(v), None))
         except Exception:
             self.free()
             raise

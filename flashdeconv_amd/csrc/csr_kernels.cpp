@@ -272,6 +272,68 @@ __global__ __launch_bounds__(1024, 8) void csr_moments_tiled_kernel(const long l
     }
 }
 
+// Sorted rows (canonical CSR): the entries of a row that fall into gene tile t+1 start where those of tile t ended, so a
+// workgroup keeps its stripe of rows and walks the tiles itself, resuming every row at a saved cursor - the column
+// indices are then read once instead of once per tile (5x at 20000 genes: 29 GB -> 6 GB of the kernel's traffic).
+template <typename T, int NS>
+__global__ __launch_bounds__(1024, 8) void csr_moments_cursor_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+                                                                     const T* __restrict__ data, const double* __restrict__ scale,
+                                                                     long long n, int G, int tile, int rows_per_stripe,
+                                                                     int* __restrict__ cursor /* (n) */,
+                                                                     double* __restrict__ part /* (stripes, NS, G) */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* acc = reinterpret_cast<double*>(smem);                       // [NS][tile]
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* tab = acc + (size_t)NS * tile + (size_t)wib * 64;
+    const long long r0 = (long long)blockIdx.x * rows_per_stripe;
+    const long long r1 = min(n, r0 + rows_per_stripe);
+    for (int t0 = 0; t0 < G; t0 += tile) {
+        const int t1 = min(G, t0 + tile);
+        for (int j = threadIdx.x; j < NS * tile; j += 1024) acc[j] = 0.0;
+        __syncthreads();
+        for (long long row = r0 + wib; row < r1; row += 16) {
+            const long long beg = indptr[row], end = indptr[row + 1];
+            long long q0 = beg + (t0 == 0 ? 0 : (long long)cursor[row]);
+            const double sc_signed = scale[row];
+            const double sc = fabs(sc_signed);
+            const bool use_tab = sc_signed > 0.0;
+            if (use_tab) log1p_table_fill(tab, sc, lane);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            while (q0 < end) {                                            // wave-uniform
+                int c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long q = q0 + u * 64 + lane;
+                    c[u] = (q < end) ? indices[q] : 0x7fffffff;
+                }
+                int taken = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = c[u] < t1;                            // sorted: the taken entries are a prefix
+                    taken += __popcll(__ballot(in));
+                    if (in) {
+                        const double y = (double)data[q0 + u * 64 + lane];
+                        const double z = log1p_scaled(y, sc, tab, use_tab);
+                        lds_add(acc + (c[u] - t0), z);
+                        lds_add(acc + tile + (c[u] - t0), z * z);
+                        if (NS == 3) lds_add(acc + 2 * tile + (c[u] - t0), y);
+                    }
+                }
+                q0 += taken;
+                if (taken < 256) break;                                   // reached the next tile (or the row's end)
+            }
+            if (lane == 0) cursor[row] = (int)(q0 - beg);
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < NS * tile; j += 1024) {
+            const int s = j / tile, g = j - s * tile;
+            if (t0 + g < t1) part[((size_t)blockIdx.x * NS + s) * G + t0 + g] = acc[j];
+        }
+        __syncthreads();
+    }
+}
+
 template <int NS>
 __global__ __launch_bounds__(256) void csr_fold_moments_kernel(const double* __restrict__ part, int stripes, int G, long long n,
                                                                double* __restrict__ mean, double* __restrict__ var,
@@ -295,7 +357,7 @@ int csr_moment_stripes(long long n) { return (int)std::min<long long>(512, std::
 
 template <typename T, int NS>
 static int launch_csr_moments_t(const long long* indptr, const int* indices, const T* data, long long n, int G, double* scale,
-                                double* part, double* mean, double* var, double* colsum, hipStream_t st) {
+                                double* part, double* mean, double* var, double* colsum, int* cursor, hipStream_t st) {
     const int tile = std::min(G, (int)(64 * 1024 / (NS * sizeof(double))));   // + 16 waves x 512 B of log1p tables
     const int tiles = ceil_div(G, tile);
     const int stripes = csr_moment_stripes(n);
@@ -305,8 +367,14 @@ static int launch_csr_moments_t(const long long* indptr, const int* indices, con
     FDX_CHECK_LAUNCH();
     const size_t lds_m = (size_t)NS * tile * sizeof(double) + 16 * 64 * sizeof(double);
     FDX_HIP(hipFuncSetAttribute((const void*)csr_moments_tiled_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-    hipLaunchKernelGGL((csr_moments_tiled_kernel<T, NS>), dim3(stripes, tiles), dim3(1024), lds_m, st,
-                       indptr, indices, data, scale, n, G, tile, rows_per_stripe, part);
+    if (cursor && !getenv("FDX_CSR_NO_CURSOR")) {     // rows sorted by column: one pass over the indices
+        FDX_HIP(hipFuncSetAttribute((const void*)csr_moments_cursor_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        hipLaunchKernelGGL((csr_moments_cursor_kernel<T, NS>), dim3(stripes), dim3(1024), lds_m, st, indptr, indices, data, scale,
+                           n, G, tile, rows_per_stripe, cursor, part);
+    } else {
+        hipLaunchKernelGGL((csr_moments_tiled_kernel<T, NS>), dim3(stripes, tiles), dim3(1024), lds_m, st,
+                           indptr, indices, data, scale, n, G, tile, rows_per_stripe, part);
+    }
     FDX_CHECK_LAUNCH();
     hipLaunchKernelGGL(csr_fold_moments_kernel<NS>, dim3(ceil_div(G, 256)), dim3(256), 0, st, part, stripes, G, n, mean, var, colsum);
     FDX_CHECK_LAUNCH();
@@ -315,14 +383,14 @@ static int launch_csr_moments_t(const long long* indptr, const int* indices, con
 
 // scale: n doubles; part: csr_moment_stripes(n) * (colsum ? 3 : 2) * G doubles; colsum may be NULL
 int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, int G,
-                       double* scale, double* part, double* mean, double* var, double* colsum, hipStream_t st) {
+                       double* scale, double* part, double* mean, double* var, double* colsum, int* cursor, hipStream_t st) {
     if (G <= 0 || n <= 0) return fail(FDX_ERR_INVALID, "gene moments (CSR): empty matrix");
     if (dtype == FDX_F32)
-        return colsum ? launch_csr_moments_t<float, 3>(indptr, indices, (const float*)data, n, G, scale, part, mean, var, colsum, st)
-                      : launch_csr_moments_t<float, 2>(indptr, indices, (const float*)data, n, G, scale, part, mean, var, colsum, st);
+        return colsum ? launch_csr_moments_t<float, 3>(indptr, indices, (const float*)data, n, G, scale, part, mean, var, colsum, cursor, st)
+                      : launch_csr_moments_t<float, 2>(indptr, indices, (const float*)data, n, G, scale, part, mean, var, colsum, cursor, st);
     if (dtype == FDX_F64)
-        return colsum ? launch_csr_moments_t<double, 3>(indptr, indices, (const double*)data, n, G, scale, part, mean, var, colsum, st)
-                      : launch_csr_moments_t<double, 2>(indptr, indices, (const double*)data, n, G, scale, part, mean, var, colsum, st);
+        return colsum ? launch_csr_moments_t<double, 3>(indptr, indices, (const double*)data, n, G, scale, part, mean, var, colsum, cursor, st)
+                      : launch_csr_moments_t<double, 2>(indptr, indices, (const double*)data, n, G, scale, part, mean, var, colsum, cursor, st);
     return fail(FDX_ERR_INVALID, "gene moments (CSR): dtype must be FDX_F32 or FDX_F64");
 }
 
@@ -343,11 +411,32 @@ __global__ __launch_bounds__(256) void csr_check_kernel(const long long* __restr
     if (bad) atomicOr(flag, 1);
 }
 
-int launch_csr_check(const long long* indptr, const int* indices, long long n, long long nnz, int G, int* flag, hipStream_t st) {
+// flag bit 1: some row's column indices are not in non-decreasing order (one wave per row)
+__global__ __launch_bounds__(256) void csr_sorted_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+                                                         long long n, int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long stride = ((long long)gridDim.x * blockDim.x) >> 6;
+    int bad = 0;
+    for (long long row = wave0; row < n; row += stride) {
+        const long long beg = indptr[row], end = indptr[row + 1];
+        for (long long q = beg + lane; q + 1 < end; q += 64)
+            if (indices[q] > indices[q + 1]) bad = 1;
+    }
+    if (bad) atomicOr(flag, 2);
+}
+
+int launch_csr_check(const long long* indptr, const int* indices, long long n, long long nnz, int G, int check_sorted, int* flag,
+                     hipStream_t st) {
     FDX_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
     const int blocks = (int)std::min<long long>(std::max<long long>(1, (std::max(n, nnz) + 255) / 256), 256LL * 8);
     hipLaunchKernelGGL(csr_check_kernel, dim3(blocks), dim3(256), 0, st, indptr, indices, n, nnz, G, flag);
     FDX_CHECK_LAUNCH();
+    if (check_sorted && n > 0) {      // after the structure check in stream order: indptr is then known to be usable
+        const int sb = (int)std::min<long long>((n + 3) / 4, 256LL * 8);
+        hipLaunchKernelGGL(csr_sorted_kernel, dim3(sb), dim3(256), 0, st, indptr, indices, n, flag);
+        FDX_CHECK_LAUNCH();
+    }
     return 0;
 }
 

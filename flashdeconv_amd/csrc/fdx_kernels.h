@@ -112,8 +112,9 @@ int launch_sketch_csr(const long long* indptr, const int* indices, const void* d
 size_t csr_gene_slot_bytes();
 int csr_moment_stripes(long long n);
 int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, int G,
-                       double* scale, double* part, double* mean, double* var, double* colsum, hipStream_t st);
-int launch_csr_check(const long long* indptr, const int* indices, long long n, long long nnz, int G, int* flag, hipStream_t st);
+                       double* scale, double* part, double* mean, double* var, double* colsum, int* cursor, hipStream_t st);
+int launch_csr_check(const long long* indptr, const int* indices, long long n, long long nnz, int G, int check_sorted, int* flag,
+                     hipStream_t st);
 }  // namespace fdx
 
 namespace fdx {

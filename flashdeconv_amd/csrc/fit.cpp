@@ -412,11 +412,12 @@ extern "C" int fdx_csr_check_dev(const fdx_csr_view* Y, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     DevBuf flag;
     FDX_TRY(flag.alloc(sizeof(int)));
-    FDX_TRY(launch_csr_check((const long long*)Y->indptr, Y->indices, Y->n, Y->nnz, Y->G, flag.as<int>(), st));
+    FDX_TRY(launch_csr_check((const long long*)Y->indptr, Y->indices, Y->n, Y->nnz, Y->G, Y->sorted_rows, flag.as<int>(), st));
     int bad = 0;
     FDX_HIP(hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
-    FDX_REQUIRE(bad == 0, "CSR matrix is malformed (indptr not monotone from 0 to nnz, or a column index outside [0, G))");
+    FDX_REQUIRE((bad & 1) == 0, "CSR matrix is malformed (indptr not monotone from 0 to nnz, or a column index outside [0, G))");
+    FDX_REQUIRE((bad & 2) == 0, "CSR matrix claims sorted_rows but a row's column indices are not ascending");
     return 0;
 }
 
@@ -426,14 +427,16 @@ extern "C" int fdx_csr_gene_moments_dev(const fdx_csr_view* Y, double* mean_out_
     FDX_REQUIRE(Y->n > 0, "fdx_csr_gene_moments_dev: empty matrix");
     hipStream_t st = (hipStream_t)stream;
     const size_t G = (size_t)Y->G;
-    DevBuf scale, part, out;
+    DevBuf scale, part, out, cursor;
     const int ns = colsum_out_host ? 3 : 2;
+    if (Y->sorted_rows) FDX_TRY(cursor.alloc((size_t)Y->n * sizeof(int)));
     FDX_TRY(scale.alloc((size_t)Y->n * sizeof(double)));
     FDX_TRY(part.alloc((size_t)csr_moment_stripes(Y->n) * ns * G * sizeof(double)));
     FDX_TRY(out.alloc(3 * G * sizeof(double)));
     double* o = out.as<double>();
     FDX_TRY(launch_csr_moments((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, Y->n, Y->G, scale.as<double>(),
-                               part.as<double>(), o, o + G, colsum_out_host ? o + 2 * G : nullptr, st));
+                               part.as<double>(), o, o + G, colsum_out_host ? o + 2 * G : nullptr,
+                               Y->sorted_rows ? cursor.as<int>() : nullptr, st));
     if (mean_out_host) FDX_HIP(hipMemcpyAsync(mean_out_host, o, G * sizeof(double), hipMemcpyDeviceToHost, st));
     if (var_out_host) FDX_HIP(hipMemcpyAsync(var_out_host, o + G, G * sizeof(double), hipMemcpyDeviceToHost, st));
     if (colsum_out_host) FDX_HIP(hipMemcpyAsync(colsum_out_host, o + 2 * G, G * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -193,10 +193,12 @@ typedef struct fdx_csr_view {
     int64_t n;
     int64_t nnz;
     int32_t G;
+    int32_t sorted_rows;     /* 1: column indices ascend within every row (canonical CSR) - verified by fdx_csr_check_dev;
+                                lets the gene statistics read the indices once instead of once per gene tile */
 } fdx_csr_view;
 
-/* Structure check (monotone indptr from 0 to nnz, columns inside [0, G)); call once after an upload, before any
- * kernel indexes with the arrays.  FDX_ERR_INVALID with a message on violation. */
+/* Structure check (monotone indptr from 0 to nnz, columns inside [0, G), and the sorted_rows claim if made); call once
+ * after an upload, before any kernel indexes with the arrays.  FDX_ERR_INVALID with a message on violation. */
 int fdx_csr_check_dev(const fdx_csr_view* Y, void* stream);
 /* select_hvg statistics of the sparse branch (utils/genes.py:52-83): z = log1p(y * 1e4 / max(rowsum, 1)) on the stored
  * entries, mean_g = sum z / n, var_g = n/(n-1) * (sum z^2 / n - mean_g^2) clipped at 0; colsum_g = sum y (the "pearson"

@@ -115,6 +115,7 @@ def test_csr_gene_moments_and_validation():
     Yd[11] = 0
     Y = sparse.csr_matrix(Yd)
     csr = _lib.CsrOnDevice.from_scipy(Y)
+    assert csr.view.sorted_rows == 1                       # canonical scipy matrix: the cursor kernel is used
     mean, var, colsum = csr.gene_moments(want_colsum=True)
     mean2, var2, none = csr.gene_moments()
     assert none is None and np.allclose(mean2, mean, rtol=1e-14) and np.allclose(var2, var, rtol=1e-12)
@@ -125,6 +126,23 @@ def test_csr_gene_moments_and_validation():
     np.testing.assert_allclose(var, Z.var(axis=0, ddof=1), rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(colsum, Yd.sum(axis=0), rtol=1e-13)
     assert np.array_equal(genes.select_hvg(Y, 100), genes.select_hvg(Yd, 100))
+    # unsorted rows: same statistics through the full-scan kernel (sorted_rows = 0), and a false claim is caught
+    perm_cols = Y.copy()
+    for r in range(0, 500, 3):
+        a, b = perm_cols.indptr[r], perm_cols.indptr[r + 1]
+        perm_cols.indices[a:b] = perm_cols.indices[a:b][::-1].copy()
+        perm_cols.data[a:b] = perm_cols.data[a:b][::-1].copy()
+    perm_cols.has_sorted_indices = False
+    un = _lib.CsrOnDevice.from_scipy(perm_cols, sort=False)
+    assert un.view.sorted_rows == 0
+    m3, v3, c3 = un.gene_moments(want_colsum=True)
+    np.testing.assert_allclose(m3, mean, rtol=1e-13)
+    np.testing.assert_allclose(v3, var, rtol=1e-10, atol=1e-15)
+    np.testing.assert_allclose(c3, colsum, rtol=1e-13)
+    un.view.sorted_rows = 1
+    with pytest.raises(_lib.FdxError, match="sorted_rows"):
+        _lib.check(_lib.load().fdx_csr_check_dev(__import__("ctypes").byref(un.view), None))
+    un.free()
     bad = sparse.csr_matrix(Yd)
     bad.indices = bad.indices.copy()
     bad.indices[5] = 700                                    # column out of range: rejected before any kernel uses it
