@@ -65,8 +65,8 @@ def select_markers(X, n_markers=50, method="diff"):
     if K == 1:
         idx = np.arange(min(n_markers, G))
         return idx, np.zeros(len(idx), dtype=np.intp)
-    ranked = np.sort(frac, axis=0)
-    specificity = ranked[-1] - ranked[-2]
+    top = np.partition(frac, K - 2, axis=0)           # only the two largest fractions per gene are needed (no full sort)
+    specificity = top[K - 1] - top[K - 2]
     owner = np.argmax(frac, axis=0)
     chosen, assign = [], []
     for k in range(K):

@@ -59,3 +59,31 @@ def test_full_size_sketch_linearity_and_solver_fixed_point(big):
     b1 = FlashDeconv(**kw).fit(Y, X, coords, output="torch").beta_
     b2 = FlashDeconv(**kw).fit(Y * 2.0, X * 2.0, coords, output="torch").beta_
     assert float((b1 - b2).abs().max()) < 1e-9 * float(b1.abs().max())
+
+
+@pytest.mark.parametrize("n,K,family", [(10_000, 10, "gaussian"), (100_000, 20, "gaussian"), (30_000, 20, "counts")])
+def test_baseline_configs_at_full_size_against_the_oracle(n, K, family):
+    """BASELINE.json configs[0] (10k x 2000 x 10) and configs[1] (100k x 2000 x 20, d = 512) at their full sizes, plus a
+    count-like / log-CPM case, against the CPU oracle (the pinned restatement of the reference): same selected genes, same
+    iteration count, abundances within 1e-8 relative Frobenius (contract: 1e-4)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datagen
+    import fdx_oracle as orc
+    from conftest import rel_fro
+    from flashdeconv_amd import FlashDeconv
+    if family == "gaussian":
+        Y, X, coords, _ = datagen.gaussian_raw(n, 2000, K, seed=n % 97)
+        pre, max_iter = "raw", 100
+    else:
+        Y, X, coords, _ = datagen.count_like(n, 2000, K, 0.1, 5)
+        pre, max_iter = "log_cpm", 12
+    m = FlashDeconv(sketch_dim=512, preprocess=pre, n_hvg=2000, max_iter=max_iter).fit(Y, X, coords)
+    want = orc.fit(Y, X, coords, sketch_dim=512, preprocess_method=pre, n_hvg=2000, max_iter=max_iter, graph="kdtree")
+    assert np.array_equal(m.gene_idx_, want["gene_idx"])
+    A, B = m.adjacency_, want["adjacency"].tocsr()
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    assert m.info_["n_iterations"] == want["info"]["n_iterations"] and m.info_["converged"] == want["info"]["converged"]
+    np.testing.assert_allclose(m.lambda_used_, want["lambda_used"], rtol=1e-10)
+    assert rel_fro(m.beta_, want["beta"]) < 1e-8
+    assert rel_fro(m.proportions_, want["proportions"]) < 1e-8
