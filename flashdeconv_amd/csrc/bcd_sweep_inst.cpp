@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
     unsigned slots[8];
 #pragma unroll
     for (int m2 = 0; m2 < 8; ++m2) {
-        const unsigned lo = (2 * m2 < w) ? (unsigned)ell[(size_t)(2 * m2) * 64] : 0u;
-        const unsigned hi = (2 * m2 + 1 < w) ? (unsigned)ell[(size_t)(2 * m2 + 1) * 64] : 0u;
+        const unsigned lo = (2 * m2 < w) ? (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2) * 64]) : 0u;
+        const unsigned hi = (2 * m2 + 1 < w) ? (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2 + 1) * 64]) : 0u;
         slots[m2] = lo | (hi << 16);
     }
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
         for (int q = 0; q < KC; ++q) {
             const int k = kc + q;
             if (k < K) {
-                const double h = H[k * (size_t)ldh + i];
+                const double h = __builtin_nontemporal_load(&H[k * (size_t)ldh + i]);   // streamed once per sweep: keep L2 for beta_in (halo re-use)
                 const double* g = XtX + k * K;
                 double r0 = 0.0, r1 = 0.0;
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
                 dmax = fmax(dmax, fabs(nw - old));
                 amax = fmax(amax, fabs(old));
                 b[k] = nw;
-                beta_out[k * ld + i] = nw;
+                __builtin_nontemporal_store(nw, &beta_out[k * ld + i]);
             }
         }
     }
