@@ -54,7 +54,7 @@ __device__ __forceinline__ void csr_load_group(CsrGroup<T>& g, const int* __rest
     for (int u = 0; u < 4; ++u) {
         const long long q = q0 + u * 64 + lane;
         const bool ok = q < end;
-        g.c[u] = ok ? indices[q] : -1;
+        g.c[u] = ok ? indices[q] : -1;           // no non-temporal hint: log-CPM reads the row a second time from L2/MALL
         g.y[u] = ok ? data[q] : (T)0;
     }
 }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void sketch_csr_kernel(const long long* __rest
         double sq = 0.0;
         for (int c = lane; c < d; c += 64) {
             const double v = acc[c];
-            dst[c] = v;
+            __builtin_nontemporal_store(v, &dst[c]);
             sq = fma(v, v, sq);
         }
         if (row_sumsq) {

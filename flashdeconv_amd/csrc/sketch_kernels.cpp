@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
         double sq = 0.0;
         for (int c = lane; c < d; c += 64) {
             const double v = acc[c];
-            dst[c] = v;
+            __builtin_nontemporal_store(v, &dst[c]);           // written once, read once by the contraction: do not keep in L2
             sq = fma(v, v, sq);
         }
         if (row_sumsq) {
