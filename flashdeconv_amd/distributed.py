@@ -33,6 +33,26 @@ def diag_mean(XtX):
     return acc / XtX.shape[0]
 
 
+def combine_moment_sums(mean, var, n, device=None):
+    """(sum z, sum z^2) per gene from a shard's mean and ddof-1 variance over n spots (the statistics
+    fdx_gene_moments_dev reports: var = n/(n-1) * (sum z^2 / n - mean^2), utils/genes.py:74-83)."""
+    mean = np.asarray(mean, dtype=np.float64)
+    var = np.asarray(var, dtype=np.float64)
+    s1 = mean * n
+    s2 = (var * ((n - 1) / n) + mean * mean) * n if n >= 2 else mean * mean * n
+    if device is None:
+        return s1, s2
+    import torch
+    return torch.from_numpy(s1).to(device), torch.from_numpy(s2).to(device)
+
+
+def moments_from_sums(s1, s2, n):
+    """Global mean and ddof-1 variance from the all-reduced sums (same formula as the device fold kernel)."""
+    mean = s1 / n
+    var = np.maximum((s2 / n - mean * mean) * (n / (n - 1)), 0.0) if n >= 2 else np.zeros_like(mean)
+    return mean, var
+
+
 def shard_bounds(n, world):
     """Range starts of `world` contiguous, 256-aligned, near-equal shards of n sorted spots (tiles of the sweep are
     256 spots, so shard boundaries coincide with tile boundaries)."""
@@ -217,12 +237,13 @@ class ShardedFlashDeconv:
         props = model.fit_transform(Y_own, X)                      # rows of Y for own_ids, in that order
 
     Returns the proportions of the own spots (row i belongs to spot own_ids[i]); `beta_`, `info_`, `lambda_used_` as in
-    the reference.  Gene selection must be the identity (G <= n_hvg), as on the single-GPU path today.
+    the reference, `gene_idx_` when G > n_hvg (gene statistics are all-reduced over the shards).
     """
 
     def __init__(self, sketch_dim=512, lambda_spatial="auto", rho_sparsity=0.01, n_hvg=2000, k_neighbors=6,
                  spatial_method="knn", radius=None, max_iter=100, tol=1e-4, preprocess="log_cpm", random_state=0,
-                 group=None, comm=None):
+                 group=None, comm=None, n_markers_per_type=50):
+        self.n_markers_per_type = n_markers_per_type
         self.sketch_dim, self.lambda_spatial, self.rho_sparsity = sketch_dim, lambda_spatial, rho_sparsity
         self.n_hvg, self.k_neighbors, self.spatial_method, self.radius = n_hvg, k_neighbors, spatial_method, radius
         self.max_iter, self.tol, self.preprocess, self.random_state = max_iter, tol, preprocess, random_state
@@ -325,12 +346,35 @@ class ShardedFlashDeconv:
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         X = np.ascontiguousarray(X, dtype=np.float64)
         K, G = X.shape
-        if G > self.n_hvg:
-            raise NotImplementedError("sharded fit needs G <= n_hvg (identity gene selection)")
         if Y_own.dtype not in (torch.float32, torch.float64):
             Y_own = Y_own.to(torch.float32)
         Y_own = Y_own.contiguous()
         assert Y_own.shape == (self.n_own, G)
+        y_code = _lib.FDX_F32 if Y_own.dtype == torch.float32 else _lib.FDX_F64
+        self.gene_idx_ = np.arange(G, dtype=np.intp)
+        if G > self.n_hvg:
+            # gene selection over ALL spots (utils/genes.py:293-341): every rank reduces its own rows to per-gene sums of
+            # z = log1p(CPM-10k) and z^2 (fdx_gene_moments_dev), one all-reduce(SUM) of 2G doubles makes them global, the
+            # ranking of the G-vector and the marker table are replicated host work
+            from .utils import genes as _genes
+            sums = torch.zeros((2, G), dtype=torch.float64, device=dev)
+            if self.n_own:
+                mean_r, var_r = _genes.gene_moments_device(ctypes.c_void_p(Y_own.data_ptr()), y_code, self.n_own, G, G)
+                sums[0], sums[1] = combine_moment_sums(mean_r, var_r, self.n_own, dev)
+            self.comm.all_reduce_sum(sums)
+            mean, var = moments_from_sums(sums[0].cpu().numpy(), sums[1].cpu().numpy(), self.n_total_spots)
+            hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
+            markers, _ = _genes.select_markers(X, n_markers=self.n_markers_per_type)
+            self.gene_idx_ = np.union1d(hvg, markers).astype(np.intp)
+            if len(self.gene_idx_) == 0:
+                raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
+            gi32 = np.ascontiguousarray(self.gene_idx_, dtype=np.int32)
+            Y_sel = torch.empty((self.n_own, len(gi32)), dtype=Y_own.dtype, device=dev)
+            if self.n_own:
+                _lib.check(lib.fdx_gather_columns_dev(ctypes.c_void_p(Y_own.data_ptr()), y_code, self.n_own, G, G,
+                                                      _lib.ptr_i32(gi32), len(gi32), ctypes.c_void_p(Y_sel.data_ptr()), st))
+            Y_own, X = Y_sel, np.ascontiguousarray(X[:, self.gene_idx_])
+            G = len(gi32)
         t0 = time.perf_counter()
         job, self._lev_job = getattr(self, "_lev_job", None), None
         if job is not None and job[0].shape == X.shape and np.array_equal(job[0], X):

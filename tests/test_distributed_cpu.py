@@ -171,3 +171,24 @@ def test_shard_bounds_are_tile_aligned_and_cover():
             assert np.all(b[:-1] % 256 == 0)
             if n >= 256 * w:
                 assert np.diff(b).max() - np.diff(b).min() <= 256 + 255
+
+
+def test_shard_moment_sums_combine_to_global_statistics():
+    """Sharded gene selection: per-shard (mean, ddof-1 var) -> (sum z, sum z^2) -> all-reduce -> global (mean, var)."""
+    sys.path.insert(0, ROOT)
+    from flashdeconv_amd.distributed import combine_moment_sums, moments_from_sums
+    rs = np.random.RandomState(0)
+    Z = np.log1p(rs.poisson(1.3, size=(1000, 37)) * 2.5)
+    cuts = [0, 1, 400, 401, 1000]                     # shards of 1, 399, 1 and 599 spots
+    s1 = np.zeros(37)
+    s2 = np.zeros(37)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part = Z[a:b]
+        var = part.var(axis=0, ddof=1) if b - a >= 2 else np.zeros(37)
+        p1, p2 = combine_moment_sums(part.mean(axis=0), var, b - a)
+        s1 += p1
+        s2 += p2
+    mean, var = moments_from_sums(s1, s2, 1000)
+    np.testing.assert_allclose(mean, Z.mean(axis=0), rtol=1e-13)
+    np.testing.assert_allclose(var, Z.var(axis=0, ddof=1), rtol=1e-11)
+

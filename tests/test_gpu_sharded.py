@@ -172,5 +172,17 @@ def test_sharded_class_world1_equals_flashdeconv():
         assert np.array_equal(got, ref.proportions_)
         np.testing.assert_allclose(m.info_["final_objective"], ref.info_["final_objective"], rtol=1e-12)
         np.testing.assert_allclose(m.lambda_used_, ref.lambda_used_, rtol=1e-14)
+        # gene selection active (G > n_hvg): statistics reduced over the shards, same genes, same fit
+        Yc, Xc, cc, _ = datagen.count_like(3000, 900, 6, 0.1, 8)
+        kw = dict(sketch_dim=64, preprocess="log_cpm", n_hvg=250, n_markers_per_type=10, max_iter=20)
+        ref2 = FlashDeconv(**kw).fit(Yc, Xc, cc)
+        m2 = ShardedFlashDeconv(**kw)
+        own2 = m2.plan(torch.from_numpy(cc).to(dev))
+        P2 = m2.fit_transform(torch.from_numpy(Yc.astype(np.float32)).to(dev)[own2], Xc)
+        assert np.array_equal(m2.gene_idx_, ref2.gene_idx_) and len(m2.gene_idx_) < 900
+        got2 = np.zeros((3000, 6))
+        got2[own2.cpu().numpy()] = P2.cpu().numpy()
+        assert m2.info_["n_iterations"] == ref2.info_["n_iterations"]
+        np.testing.assert_allclose(got2, ref2.proportions_, rtol=1e-9, atol=1e-12)
     finally:
         dist.destroy_process_group()
