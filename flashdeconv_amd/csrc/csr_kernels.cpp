@@ -411,32 +411,52 @@ __global__ __launch_bounds__(256) void csr_check_kernel(const long long* __restr
     if (bad) atomicOr(flag, 1);
 }
 
-// flag bit 1: some row's column indices are not in non-decreasing order (one wave per row)
-__global__ __launch_bounds__(256) void csr_sorted_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
-                                                         long long n, int* __restrict__ flag) {
+// Row-wise variant used when the caller claims sorted rows: one wave per row checks the column range (bit 0) AND that the
+// columns do not descend (bit 1) in a single pass over the indices.  Rows are clamped to [0, nnz] so that a broken indptr
+// (reported through bit 0 by csr_indptr_kernel) cannot send the loads out of bounds.
+__global__ __launch_bounds__(256) void csr_rows_check_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+                                                             long long n, long long nnz, int G, int* __restrict__ flag) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long stride = ((long long)gridDim.x * blockDim.x) >> 6;
     int bad = 0;
     for (long long row = wave0; row < n; row += stride) {
-        const long long beg = indptr[row], end = indptr[row + 1];
-        for (long long q = beg + lane; q + 1 < end; q += 64)
-            if (indices[q] > indices[q + 1]) bad = 1;
+        const long long beg = min(max(indptr[row], 0LL), nnz), end = min(max(indptr[row + 1], 0LL), nnz);
+        for (long long q = beg + lane; q < end; q += 64) {
+            const int c = indices[q];
+            if (c < 0 || c >= G) bad |= 1;
+            if (q + 1 < end && c > indices[q + 1]) bad |= 2;
+        }
     }
-    if (bad) atomicOr(flag, 2);
+    if (bad) atomicOr(flag, bad);
+}
+
+__global__ __launch_bounds__(256) void csr_indptr_kernel(const long long* __restrict__ indptr, long long n, long long nnz,
+                                                         int* __restrict__ flag) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    int bad = 0;
+    if (t == 0 && (indptr[0] != 0 || indptr[n] != nnz)) bad = 1;
+    for (long long r = t; r < n; r += stride)
+        if (indptr[r + 1] < indptr[r]) bad = 1;
+    if (bad) atomicOr(flag, 1);
 }
 
 int launch_csr_check(const long long* indptr, const int* indices, long long n, long long nnz, int G, int check_sorted, int* flag,
                      hipStream_t st) {
     FDX_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+    if (check_sorted && n > 0) {      // one row-wise pass over the indices does range + order
+        const int ib = (int)std::min<long long>((n + 255) / 256, 256LL * 8);
+        hipLaunchKernelGGL(csr_indptr_kernel, dim3(ib), dim3(256), 0, st, indptr, n, nnz, flag);
+        FDX_CHECK_LAUNCH();
+        const int sb = (int)std::min<long long>((n + 3) / 4, 256LL * 8);
+        hipLaunchKernelGGL(csr_rows_check_kernel, dim3(sb), dim3(256), 0, st, indptr, indices, n, nnz, G, flag);
+        FDX_CHECK_LAUNCH();
+        return 0;
+    }
     const int blocks = (int)std::min<long long>(std::max<long long>(1, (std::max(n, nnz) + 255) / 256), 256LL * 8);
     hipLaunchKernelGGL(csr_check_kernel, dim3(blocks), dim3(256), 0, st, indptr, indices, n, nnz, G, flag);
     FDX_CHECK_LAUNCH();
-    if (check_sorted && n > 0) {      // after the structure check in stream order: indptr is then known to be usable
-        const int sb = (int)std::min<long long>((n + 3) / 4, 256LL * 8);
-        hipLaunchKernelGGL(csr_sorted_kernel, dim3(sb), dim3(256), 0, st, indptr, indices, n, flag);
-        FDX_CHECK_LAUNCH();
-    }
     return 0;
 }
 
