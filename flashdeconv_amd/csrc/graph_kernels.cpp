@@ -560,6 +560,7 @@ static int make_grid(const double* d_coords, long long n, int dim, double target
 struct BinnedPoints {
     GridParams gp;
     DevBuf perm, rank, sc, cstart, cend;
+    DevBuf keys, vals, skeys, sort_tmp;   // sort temporaries: kept until the struct dies so that binning needs no final sync
     long long n = 0;
     int n_cells = 0;
 };
@@ -569,7 +570,10 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     b->n = n;
     FDX_TRY(make_grid(d_coords, n, dim, target_per_cell, min_h, &b->gp, st));
     b->n_cells = b->gp.nc[0] * b->gp.nc[1] * b->gp.nc[2];
-    DevBuf keys, vals, skeys, tmp;
+    DevBuf& keys = b->keys;
+    DevBuf& vals = b->vals;
+    DevBuf& skeys = b->skeys;
+    DevBuf& tmp = b->sort_tmp;
     FDX_TRY(keys.alloc((size_t)n * 8));
     FDX_TRY(vals.alloc((size_t)n * 4));
     FDX_TRY(skeys.alloc((size_t)n * 8));
@@ -599,8 +603,7 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     hipLaunchKernelGGL(cell_range_kernel, dim3(nb), dim3(256), 0, st, skeys.as<u64>(), b->sc.as<double>(), n, b->gp,
                        b->cstart.as<int>(), b->cend.as<int>());
     FDX_CHECK_LAUNCH();
-    FDX_HIP(hipStreamSynchronize(st));   // temporaries are released at scope exit
-    return 0;
+    return 0;                            // no sync: the temporaries live in *b, whose owners synchronise before dropping it
 }
 
 // workgroup tiles of the LDS-tiled sweep (needs g->ell / deg / slice_off / ell_rows / n)
@@ -717,6 +720,8 @@ struct fdx_graph_plan {
     fdx::BinnedPoints b;
     long long n = 0;
     int kk = 0;
+    hipStream_t st = nullptr;      // stream the binning / k-NN kernels were queued on
+    ~fdx_graph_plan() { (void)hipStreamSynchronize(st); }   // nothing may still read the buffers when they go back to the pool
 };
 namespace fdx {
 
@@ -733,6 +738,7 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     auto* plan = new fdx_graph_plan();
     plan->n = n;
     plan->kk = kk;
+    plan->st = st;
     int rc = bin_points(d_coords, n, dim, 2.0, 0.0, &plan->b, st);
     if (rc) { delete plan; return rc; }
     const BinnedPoints& b = plan->b;
@@ -769,11 +775,15 @@ int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, l
     hipLaunchKernelGGL(indegree_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, indeg.as<int>(), (int)lo, (int)hi);
     FDX_CHECK_LAUNCH();
     FDX_TRY(exclusive_scan_int(indeg.as<int>(), rev_off.as<int>(), n + 1, st, tmp));
-    int total_in = 0;                                    // edges into [lo, hi): known only now
-    FDX_HIP(hipMemcpyAsync(&total_in, rev_off.as<int>() + n, 4, hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
-    FDX_REQUIRE(total_in >= 0 && (long long)total_in <= n * (long long)kk, "graph: reverse edge count out of range");
-    FDX_TRY(rev.alloc((size_t)std::max(total_in, 1) * 4));
+    if (lo == 0 && hi == n) {
+        FDX_TRY(rev.alloc((size_t)n * kk * 4));          // whole graph: every list entry is a reverse edge - no read-back
+    } else {
+        int total_in = 0;                                // edges into [lo, hi): known only now
+        FDX_HIP(hipMemcpyAsync(&total_in, rev_off.as<int>() + n, 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        FDX_REQUIRE(total_in >= 0 && (long long)total_in <= n * (long long)kk, "graph: reverse edge count out of range");
+        FDX_TRY(rev.alloc((size_t)std::max(total_in, 1) * 4));
+    }
     hipLaunchKernelGGL(fill_reverse_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, rev_off.as<int>(), cursor.as<int>(),
                        rev.as<int>(), (int)lo, (int)hi);
     FDX_CHECK_LAUNCH();
