@@ -147,10 +147,17 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
     if (n > 0) {
         FDX_REQUIRE(Y_dev != nullptr, "fdx_prepare_dev: null Y");
         const long long chunk = std::min<long long>(n, 1LL << 18);
-        FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
         FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
         FDX_TRY(dSum.alloc(sizeof(double)));
-        for (long long r0 = 0; r0 < n; r0 += chunk) {
+        // same choice as the single-GPU fit (fit.cpp): shards start on multiples of 256, so the fused kernel's groups of 16
+        // spots coincide with those of an unsharded run and H keeps the same bits
+        const bool fused = fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, mode_y, plan_y.dev());
+        if (fused)
+            FDX_TRY(launch_sketch_contract(Y_dev, y_dtype, ldy, row_map_dev, n, G, d, mode_y, plan_y.dev(), dXs.as<double>(), K,
+                                           H_out_dev, ldh, dRowSq.as<double>(), st));
+        else
+            FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
+        for (long long r0 = 0; r0 < n && !fused; r0 += chunk) {
             const long long nr = std::min(chunk, n - r0);
             const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
             if (!row_map_dev) ybase += (size_t)r0 * (size_t)ldy * (y_dtype == FDX_F32 ? 4 : 8);

@@ -67,7 +67,7 @@ inline bool sketch_scatter_fits(int G, int d) {
 int launch_sketch_rows(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, double* Ys, long long ldys, double* row_sumsq, hipStream_t st);
 // fused sketch + H contraction (fused_kernels.cpp)
-bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, const SketchPlanDev& plan);
+bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan);
 int launch_sketch_contract(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                            const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
                            hipStream_t st);

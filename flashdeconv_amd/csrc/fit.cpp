@@ -270,7 +270,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     long long chunk_rows = 1LL << 18;
     if (const char* e = getenv("FDX_FIT_CHUNK")) chunk_rows = std::max<long long>(64, atoll(e));
     const long long chunk = std::min<long long>(n, chunk_rows);
-    const bool fused = !ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, plan_y.dev());
+    const bool fused = !ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, prm->mode_y, plan_y.dev());
     if (!fused) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
     FDX_HIP(hipMemsetAsync(dH.p, 0, dH.bytes, st));
     const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();

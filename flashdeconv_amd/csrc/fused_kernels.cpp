@@ -27,32 +27,35 @@ template <typename T> struct FVec4;
 template <> struct FVec4<float> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct FVec4<double> { typedef double type __attribute__((ext_vector_type(2))); };
 
-constexpr int FUSED_ROWS = 16;   // spots per group = MFMA columns
+constexpr int FUSED_ROWS = 16;   // spots per group = MFMA columns = waves per workgroup (one row per wave)
 constexpr int FUSED_PAD = 16;    // doubles of padding per accumulator row: row stride = 128 B mod 4 KB -> conflict-free reads
 
+// NB: 16-wide blocks of the contraction index per wave (d <= 256 * NB); TT: 16-type tiles (K <= 16 * TT)
 template <typename T, int MODE, bool VEC, int NB, int TT>
-__global__ __launch_bounds__(512) void sketch_contract_kernel(const T* __restrict__ Y, long long ldy,
-                                                              const int* __restrict__ row_map, long long n, int G, int d,
-                                                              const double* __restrict__ gene_w,
-                                                              const int* __restrict__ gene_bucket,
-                                                              const double* __restrict__ Xs, int K,
-                                                              double* __restrict__ Hout, long long ldh,
-                                                              double* __restrict__ row_sumsq) {
+__global__ __launch_bounds__(1024) void sketch_contract_kernel(const T* __restrict__ Y, long long ldy,
+                                                               const int* __restrict__ row_map, long long n, int G, int d,
+                                                               const double* __restrict__ gene_w,
+                                                               const int* __restrict__ gene_bucket,
+                                                               const double* __restrict__ Xs, int K,
+                                                               double* __restrict__ Hout, long long ldh,
+                                                               double* __restrict__ row_sumsq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Gp = (G + 7) & ~7;
     const int rs = d + FUSED_PAD;                                         // accumulator row stride (doubles)
     double* w_l = reinterpret_cast<double*>(smem);                        // [Gp]
-    double* rows = w_l + Gp;                                              // [16][rs]
-    double* red = rows + FUSED_ROWS * rs;                                 // [8][TT*4*64]
-    unsigned short* b_l = reinterpret_cast<unsigned short*>(red + 8 * TT * 4 * 64);   // [Gp]
-    for (int g = tid; g < Gp; g += 512) {
+    double* rows = w_l + Gp;                                              // [16][rs]; re-used as red[16][TT*4*64]
+    const int region = max(FUSED_ROWS * rs, FUSED_ROWS * TT * 4 * 64);
+    double* tabs = rows + region;                                         // [16][64] per-wave log1p tables
+    unsigned short* b_l = reinterpret_cast<unsigned short*>(tabs + FUSED_ROWS * 64);   // [Gp]
+    double* red = rows;
+    for (int g = tid; g < Gp; g += 1024) {
         const int b = (g < G) ? gene_bucket[g] : -1;
         w_l[g] = (g < G && b >= 0) ? gene_w[g] : 0.0;
         b_l[g] = (unsigned short)(b >= 0 ? b : 0xFFFF);                   // 0xFFFF: gene has no entry in Omega
     }
-    // this wave's slice of X_sketch as MFMA A operands (xyt_split_kernel's layout)
+    // this wave's slice of X_sketch as MFMA A operands: the contraction index is split over the 16 waves
     const int r = lane & 15, q = lane >> 4;
     double a[NB][TT][4];
 #pragma unroll
@@ -70,99 +73,76 @@ __global__ __launch_bounds__(512) void sketch_contract_kernel(const T* __restric
     typedef typename FVec4<T>::type V;
     constexpr int PER = 16 / sizeof(T);
     const int nvec = VEC ? G / PER : 0;
-    const int nbat = (nvec + 511) / 512;                                  // batches of 8 x 64 sixteen-byte loads per row
+    double* acc = rows + (size_t)wave * rs;
+    double* tab = tabs + (size_t)wave * 64;
     const long long n_groups = (n + FUSED_ROWS - 1) / FUSED_ROWS;
-    // Software pipeline over this wave's rows: `cur` always holds batch 0 of the row about to be processed; the loads of
-    // the following batch - of the same row, of the wave's other row, or of its first row in the NEXT group - are
-    // issued before the current batch is consumed, so they are in flight across the barriers and the MFMA phase (8 waves
-    // per CU cannot hide HBM latency by occupancy alone: the un-pipelined version of this kernel was slower than the
-    // two kernels it replaces).
-    V cur[8], nxt[8];
-    auto row_src = [&](long long p) -> const T* {
-        const long long row = row_map ? (long long)row_map[p] : p;
-        return Y + (size_t)row * ldy;
-    };
-#define FDX_LOAD_BATCH(X_, YROW_, BI_)                                               \
-    do {                                                                             \
-        const V* src_ = reinterpret_cast<const V*>(YROW_);                           \
-        _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) {                           \
-            const int v_ = (BI_) * 512 + u_ * 64 + lane;                             \
-            if (v_ < nvec) X_[u_] = src_[v_];                                        \
-        }                                                                            \
-    } while (0)
-    {
-        const long long p0 = (long long)blockIdx.x * FUSED_ROWS + 2 * wave;
-        if (nbat > 0 && blockIdx.x < n_groups && p0 < n) FDX_LOAD_BATCH(cur, row_src(p0), 0);
-    }
     for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const long long s0 = grp * FUSED_ROWS;
-        // ---- scatter phase: two spots per wave
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            const int lr = 2 * wave + half;                               // row of the group
-            const long long p = s0 + lr;
-            double* acc = rows + (size_t)lr * rs;
-            for (int c = lane; c < d; c += 64) acc[c] = 0.0;
-            if (p >= n) continue;                                         // wave-uniform: spots past the end stay zero
-            const T* yrow = row_src(p);
-            // the row this wave streams after the current one (batch 0 is prefetched at the end of this row)
-            long long pn = half == 0 ? p + 1 : (grp + gridDim.x) * (long long)FUSED_ROWS + 2 * wave;
-            if (half == 1 && grp + gridDim.x >= n_groups) pn = n;
-            const T* ynext = (pn < n) ? row_src(pn) : yrow;
+        const long long p = s0 + wave;
+        // ---- scatter phase: one spot per wave (the arithmetic of sketch_rows_scatter_kernel)
+        for (int c = lane; c < d; c += 64) acc[c] = 0.0;
+        if (p < n) {                                                      // wave-uniform: spots past the end stay zero
+            const long long row = row_map ? (long long)row_map[p] : p;
+            const T* yrow = Y + (size_t)row * ldy;
+            const V* src = reinterpret_cast<const V*>(yrow);
             double scale = 1.0;
+            bool use_tab = false;
             if (MODE != FDX_PRE_RAW) {
                 double part = 0.0;
-                for (int bi = 0; bi < nbat; ++bi) {
-                    if (bi + 1 < nbat) FDX_LOAD_BATCH(nxt, yrow, bi + 1);
-                    else if (nbat > 1) FDX_LOAD_BATCH(nxt, yrow, 0);          // back to the start for the main pass (L2 hit)
+                T mx = (T)0;
+                for (int v0 = 0; v0 < nvec; v0 += 512) {
+                    V x[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int v = bi * 512 + u * 64 + lane;
+                        const int v = v0 + u * 64 + lane;
+                        if (v < nvec) x[u] = src[v];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int v = v0 + u * 64 + lane;
                         if (v < nvec) {
 #pragma unroll
-                            for (int e = 0; e < PER; ++e) part += (double)cur[u][e];
+                            for (int e = 0; e < PER; ++e) { part += (double)x[u][e]; mx = x[u][e] > mx ? x[u][e] : mx; }
                         }
                     }
-                    if (nbat > 1) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
-                    }
                 }
-                for (int g = nvec * PER + lane; g < G; g += 64) part += (double)yrow[g];
+                for (int g = nvec * PER + lane; g < G; g += 64) { part += (double)yrow[g]; mx = yrow[g] > mx ? yrow[g] : mx; }
                 double sum = wave_sum(part);
+                use_tab = wave_max((double)mx) < 64.0;
                 if (MODE == FDX_PRE_LOG_CPM) {
                     scale = (1.0 / (sum + 1e-10)) * 1e4;                  // y / (rowsum + 1e-10) * 1e4   (deconv.py:190)
                 } else {
                     if (sum == 0.0) sum = 1.0;                            // lib_size[lib_size == 0] = 1  (deconv.py:183-185)
                     scale = 1e4 / sum;
                 }
+                if (use_tab) log1p_table_fill(tab, scale, lane);
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                           // zeroing done before the adds
-            for (int bi = 0; bi < nbat; ++bi) {
-                if (bi + 1 < nbat) FDX_LOAD_BATCH(nxt, yrow, bi + 1);
-                else if (pn < n) FDX_LOAD_BATCH(nxt, ynext, 0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                           // zeroing (and the table) done before the adds
+            for (int v0 = 0; v0 < nvec; v0 += 256) {
+                V x[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int v = bi * 512 + u * 64 + lane;
+                for (int u = 0; u < 4; ++u) {
+                    const int v = v0 + u * 64 + lane;
+                    if (v < nvec) x[u] = src[v];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int v = v0 + u * 64 + lane;
                     if (v < nvec) {
 #pragma unroll
                         for (int e = 0; e < PER; ++e) {
                             const int g = v * PER + e;
-                            double y = (double)cur[u][e];
-                            if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
+                            double y = (double)x[u][e];
+                            if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
                             const unsigned b = b_l[g];
                             if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
-                    if (u & 1) __builtin_amdgcn_sched_barrier(0);         // keep the table reads of 32 elements from being
-                                                                          // hoisted together (420 live registers otherwise)
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
             }
             for (int g = nvec * PER + lane; g < G; g += 64) {
                 double y = (double)yrow[g];
-                if (MODE != FDX_PRE_RAW) y = fast_log1p(y * scale);
+                if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
                 const unsigned b = b_l[g];
                 if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -178,7 +158,7 @@ __global__ __launch_bounds__(512) void sketch_contract_kernel(const T* __restric
             }
         }
         __syncthreads();                                                  // the 16 x d block is complete
-        // ---- contract phase (xyt_split_kernel's MFMA sequence; B operand from LDS)
+        // ---- contract phase: B operand from LDS, this wave's slice of the contraction index
         double4_t accm[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) accm[t] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -193,39 +173,43 @@ __global__ __launch_bounds__(512) void sketch_contract_kernel(const T* __restric
 #pragma unroll
                 for (int s = 0; s < 4; ++s) accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b][t][s], x[s], accm[t], 0, 0, 0);
         }
+        __syncthreads();                                                  // every wave has read its B operands: rows -> red
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) red[(size_t)wave * (TT * 4 * 64) + (t * 4 + rr) * 64 + lane] = accm[t][rr];
         __syncthreads();
-        for (int o = tid; o < TT * 4 * 64; o += 512) {
+        for (int o = tid; o < TT * 4 * 64; o += 1024) {
             double sum = 0.0;
 #pragma unroll
-            for (int v = 0; v < 8; ++v) sum += red[(size_t)v * (TT * 4 * 64) + o];
+            for (int v = 0; v < FUSED_ROWS; ++v) sum += red[(size_t)v * (TT * 4 * 64) + o];   // wave order: deterministic
             const int l = o & 63, tr = o >> 6;
             const int type = (tr >> 2) * 16 + (l >> 4) + 4 * (tr & 3);
             const long long sp = s0 + (l & 15);
             if (type < K && sp < n) Hout[(size_t)type * ldh + sp] = sum;
         }
-        // next group: rows[] is rewritten only by waves that passed the barrier above (all MFMA reads done); red[] is
-        // rewritten after the next group's first barrier, by which time every thread has finished the sums above
+        __syncthreads();                                                  // red is rows again for the next group
     }
 }
 
 size_t fused_lds_bytes(int G, int d, int K) {
     const size_t Gp = ((size_t)G + 7) & ~(size_t)7;
-    const int TT = (K + 15) / 16;
-    return Gp * 10 + (size_t)FUSED_ROWS * (d + FUSED_PAD) * 8 + (size_t)8 * TT * 4 * 64 * 8;
+    const size_t TT = (size_t)(K + 15) / 16;
+    const size_t region = std::max((size_t)FUSED_ROWS * (d + FUSED_PAD), (size_t)FUSED_ROWS * TT * 4 * 64);   // rows / reduction
+    return Gp * 10 + region * 8 + (size_t)FUSED_ROWS * 64 * 8;
 }
 
-bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, const SketchPlanDev& plan) {
-    // Opt-in (FDX_FUSED=1).  Measured on MI355X at 1M x 2000 -> 512, K = 30: 3.7-3.8 ms against 2.56 + 0.95 ms for the two
-    // kernels it replaces, with or without the software pipeline.  The LDS footprint (table 20 KB + 16 accumulator rows
-    // 68 KB + reduction 32 KB) allows one 8-wave workgroup per CU; a wave needs ~6.5 us per row (32 dependent
-    // table-read -> atomic steps per lane, zeroing, norm) and two waves per SIMD cannot hide that.  A register-resident
-    // gene table was tried on the scatter kernel and is no faster, so the LDS reads are not the bound.  Kept, with its
-    // bit-equality test, as the starting point for a variant that holds >= 16 waves per CU.
-    if (!getenv("FDX_FUSED") || getenv("FDX_NO_FUSED")) return false;
+bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan) {
+    // History: an 8-wave version (two rows per wave, 120 KB of LDS) lost to the two-kernel path (3.8 vs 3.5 ms): all waves
+    // move through scatter / barrier / MFMA / reduce together, so HBM idled outside the scatter phase and two waves per SIMD
+    // could not hide a row's dependent LDS chain.  This version: 16 waves, one row each, reduction buffer aliased onto the
+    // accumulator rows (96 KB of LDS): 3.2 ms against 2.53 + 0.95 ms.  Prefetching the next batch / the next group's row
+    // across the barriers was tried twice and changes nothing: per group of 16 spots the CU spends ~5 us in its LDS pipe and
+    // ~7 us waiting for HBM, and with all 16 waves in the same phase the two do not overlap the way 24 independent waves of
+    // the scatter kernel do.  RAW (and pearson, which is RAW with scaled weights): default.  log-CPM: the 128-VGPR budget of 16 waves
+    // spills around fast_log1p and the fused form loses (4.75 vs 4.27 ms on counts) - two kernels unless FDX_FUSED=1.
+    if (getenv("FDX_NO_FUSED")) return false;
+    if (mode != FDX_PRE_RAW && !getenv("FDX_FUSED")) return false;
     if (!plan.scatter_ok || d % 16 != 0 || d > 512 || K > 32 || K <= 0 || G <= 0) return false;
     if (dtype != FDX_F32 && dtype != FDX_F64) return false;
     (void)ldy; (void)Y;
@@ -235,20 +219,19 @@ bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, in
 template <typename T, int MODE, bool VEC>
 static int launch_fused_nb(const T* Y, long long ldy, const int* row_map, long long n, int G, int d, const SketchPlanDev& plan,
                            const double* Xs, int K, double* H, long long ldh, double* row_sumsq, hipStream_t st) {
-    const int nb = (d + 127) / 128, TT = (K + 15) / 16;
+    const int nb = (d + 255) / 256, TT = (K + 15) / 16;         // 16 waves x NB blocks of 16 cover the contraction index
     const size_t lds = fused_lds_bytes(G, d, K);
     const long long groups = (n + FUSED_ROWS - 1) / FUSED_ROWS;
-    const int grid = (int)std::min<long long>(groups, 256);
+    const int grid = (int)std::min<long long>(groups, 256);    // one 16-wave workgroup per CU
     const void* kern = nullptr;
 #define FDX_FUSED(NB_, TT_) kern = (const void*)sketch_contract_kernel<T, MODE, VEC, NB_, TT_>
     if (nb <= 1) { if (TT == 1) FDX_FUSED(1, 1); else FDX_FUSED(1, 2); }
-    else if (nb <= 2) { if (TT == 1) FDX_FUSED(2, 1); else FDX_FUSED(2, 2); }
-    else { if (TT == 1) FDX_FUSED(4, 1); else FDX_FUSED(4, 2); }
+    else { if (TT == 1) FDX_FUSED(2, 1); else FDX_FUSED(2, 2); }
 #undef FDX_FUSED
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&Y, (void*)&ldy, (void*)&row_map, (void*)&n, (void*)&G, (void*)&d, (void*)&plan.gene_w,
                     (void*)&plan.gene_bucket, (void*)&Xs, (void*)&K, (void*)&H, (void*)&ldh, (void*)&row_sumsq};
-    FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3(512), args, lds, st));
+    FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3(1024), args, lds, st));
     return 0;
 }
 

@@ -152,19 +152,23 @@ def test_csr_gene_moments_and_validation():
 
 @pytest.mark.parametrize("pre,dtype", [("raw", np.float32), ("log_cpm", np.float32), ("log_cpm", np.float64), ("pearson", np.float32)])
 def test_fused_sketch_contraction_equals_two_kernel_path(pre, dtype, monkeypatch):
-    """sketch_contract_kernel (rows -> LDS accumulators -> MFMA -> H, no Y_sketch) must give the bits of the
-    scatter-sketch + xyt_split pair it replaces: same atomics sequence per row, same MFMA order, same reduction order."""
+    """sketch_contract_kernel (rows -> LDS accumulators -> MFMA -> H, no Y_sketch) against the scatter-sketch + xyt_split
+    pair it replaces: same per-row arithmetic, contraction index split over 16 waves instead of 8, so H agrees to
+    rounding, not to the bit."""
     from flashdeconv_amd import FlashDeconv
     n, G, K = 5003, 1200, 17                      # n not a multiple of 16: the last group is partial
     Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 4)
     Y = Y.astype(dtype)
     kw = dict(sketch_dim=256, preprocess=pre, n_hvg=G, max_iter=25)
-    monkeypatch.setenv("FDX_FUSED", "1")          # the fused kernel is opt-in (not faster than the pair yet)
+    monkeypatch.setenv("FDX_FUSED", "1")          # raw / pearson use the fused kernel by default, log-CPM on request
     a = FlashDeconv(**kw).fit(Y, X, coords)
+    a2 = FlashDeconv(**kw).fit(Y, X, coords)
     monkeypatch.delenv("FDX_FUSED")
+    monkeypatch.setenv("FDX_NO_FUSED", "1")
     b = FlashDeconv(**kw).fit(Y, X, coords)
     assert a.timings_["gram_ms"] == 0.0 and b.timings_["gram_ms"] > 0.0          # the two paths really ran
-    assert np.array_equal(a.beta_, b.beta_) and a.info_ == b.info_
+    assert np.array_equal(a.beta_, a2.beta_)                                      # deterministic
+    assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < 1e-12
 
 
 def test_fit_gauss_1000_config1_miniature():
