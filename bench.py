@@ -250,8 +250,12 @@ def main():
             bytes_launch, ms_launch = sw_bytes, sweep_ms
             kname = "fdx::bcd_sweep_tiled_kernel<%d, 8, false>" % K
         else:
-            bytes_launch, ms_launch = sk_bytes / n_chunks, sk_ms / n_chunks
-            kname = "fdx::sketch_rows_scatter_kernel<float, %d, true>" % (0 if fam == "gaussian" else 1)
+            if stage["gram_ms"] == 0.0:                # fused sketch -> H kernel: ONE launch reads all of Y, writes only H
+                bytes_launch, ms_launch = sk_bytes, sk_ms
+                kname = "fdx::sketch_contract_kernel<float, %d, true, %d, %d>" % (0 if fam == "gaussian" else 1, -(-d // 256), -(-K // 16))
+            else:
+                bytes_launch, ms_launch = sk_bytes / n_chunks, sk_ms / n_chunks
+                kname = "fdx::sketch_rows_scatter_kernel<float, %d, true>" % (0 if fam == "gaussian" else 1)
         ach = bytes_launch / (ms_launch * 1e-3) / 1e9
         results[fam] = {
             "value": n * steps / dt, "ms_per_step": dt / steps * 1e3, "n_iterations": T, "converged": model.info_["converged"],
