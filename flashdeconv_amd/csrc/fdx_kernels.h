@@ -62,7 +62,7 @@ struct SketchPlanDev {
 };
 // true when the scatter kernel's LDS footprint (per-gene table + one accumulator row) fits: the kernel then serves the plan
 inline bool sketch_scatter_fits(int G, int d) {
-    return d < 65535 && (((size_t)G + 7) & ~(size_t)7) * 10 + ((size_t)d + 64) * 8 <= 150 * 1024;
+    return d < 65535 && (((size_t)G + 256 + 7) & ~(size_t)7) * 10 + ((size_t)d + 64) * 8 <= 150 * 1024;
 }
 int launch_sketch_rows(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, double* Ys, long long ldys, double* row_sumsq, hipStream_t st);

@@ -27,12 +27,15 @@ template <typename T> struct FVec4;
 template <> struct FVec4<float> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct FVec4<double> { typedef double type __attribute__((ext_vector_type(2))); };
 
-constexpr int FUSED_ROWS = 16;   // spots per group = MFMA columns = waves per workgroup (one row per wave)
 constexpr int FUSED_PAD = 16;    // doubles of padding per accumulator row: row stride = 128 B mod 4 KB -> conflict-free reads
 
-// NB: 16-wide blocks of the contraction index per wave (d <= 256 * NB); TT: 16-type tiles (K <= 16 * TT)
-template <typename T, int MODE, bool VEC, int NB, int TT>
-__global__ __launch_bounds__(1024) void sketch_contract_kernel(const T* __restrict__ Y, long long ldy,
+// R: spots per group = waves per workgroup (one row per wave; the MFMA tile has 16 columns, columns >= R are zero);
+// NB: 16-wide blocks of the contraction index per wave (d <= 16 * R * NB); TT: 16-type tiles (K <= 16 * TT).
+// R = 16 (one 16-wave workgroup per CU, 96 KB of LDS) is the default; R = 8 (FDX_FUSED_ROWS=8: 58 KB, two workgroups per
+// CU that drift apart, half-empty MFMA tiles) measures 10 % slower - the phases were not the problem, the bank conflicts
+// of the gene-order table were (see the table layout below: 3.25 -> 2.91 ms).
+template <typename T, int MODE, bool VEC, int R, int NB, int TT>
+__global__ __launch_bounds__(R * 64, 4) void sketch_contract_kernel(const T* __restrict__ Y, long long ldy,
                                                                const int* __restrict__ row_map, long long n, int G, int d,
                                                                const double* __restrict__ gene_w,
                                                                const int* __restrict__ gene_bucket,
@@ -42,18 +45,28 @@ __global__ __launch_bounds__(1024) void sketch_contract_kernel(const T* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Gp = (G + 7) & ~7;
+    const int Gp = (G + 256 + 7) & ~7;                                    // table capacity (lane-major layout, see below)
     const int rs = d + FUSED_PAD;                                         // accumulator row stride (doubles)
     double* w_l = reinterpret_cast<double*>(smem);                        // [Gp]
     double* rows = w_l + Gp;                                              // [16][rs]; re-used as red[16][TT*4*64]
-    const int region = max(FUSED_ROWS * rs, FUSED_ROWS * TT * 4 * 64);
+    const int region = max(R * rs, R * TT * 4 * 64);
     double* tabs = rows + region;                                         // [16][64] per-wave log1p tables
-    unsigned short* b_l = reinterpret_cast<unsigned short*>(tabs + FUSED_ROWS * 64);   // [Gp]
+    unsigned short* b_l = reinterpret_cast<unsigned short*>(tabs + R * 64);   // [Gp]
     double* red = rows;
-    for (int g = tid; g < Gp; g += 1024) {
-        const int b = (g < G) ? gene_bucket[g] : -1;
-        w_l[g] = (g < G && b >= 0) ? gene_w[g] : 0.0;
-        b_l[g] = (unsigned short)(b >= 0 ? b : 0xFFFF);                   // 0xFFFF: gene has no entry in Omega
+    // The per-gene table is stored LANE-MAJOR: the entry of gene g = (v0 + u*64 + lane)*PER + e sits at
+    // ((v0/64 + u)*PER + e)*64 + lane, so the 64 lanes of a table read touch 64 consecutive entries.  In gene order a lane's
+    // PER genes are PER*8 bytes apart and a wave's ds_read_b64 hits every bank 8 times.  Genes past the last full
+    // 16-byte vector (and all genes of the scalar path) follow in gene order.
+    typedef typename FVec4<T>::type V;
+    constexpr int PER = 16 / sizeof(T);
+    const int nvec = VEC ? G / PER : 0;
+    const int tail_base = ((nvec + 63) >> 6) * 64 * PER;
+    for (int g = tid; g < G; g += R * 64) {
+        const int b = gene_bucket[g];
+        const int v = g / PER, e = g - v * PER;
+        const int idx = (g < nvec * PER) ? ((((v >> 6) * PER + e) << 6) + (v & 63)) : (tail_base + (g - nvec * PER));
+        w_l[idx] = (b >= 0) ? gene_w[g] : 0.0;
+        b_l[idx] = (unsigned short)(b >= 0 ? b : 0xFFFF);                 // 0xFFFF: gene has no entry in Omega
     }
     // this wave's slice of X_sketch as MFMA A operands: the contraction index is split over the 16 waves
     const int r = lane & 15, q = lane >> 4;
@@ -70,14 +83,11 @@ __global__ __launch_bounds__(1024) void sketch_contract_kernel(const T* __restri
         }
     }
     __syncthreads();
-    typedef typename FVec4<T>::type V;
-    constexpr int PER = 16 / sizeof(T);
-    const int nvec = VEC ? G / PER : 0;
     double* acc = rows + (size_t)wave * rs;
     double* tab = tabs + (size_t)wave * 64;
-    const long long n_groups = (n + FUSED_ROWS - 1) / FUSED_ROWS;
+    const long long n_groups = (n + R - 1) / R;
     for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const long long s0 = grp * FUSED_ROWS;
+        const long long s0 = grp * R;
         const long long p = s0 + wave;
         // ---- scatter phase: one spot per wave (the arithmetic of sketch_rows_scatter_kernel)
         for (int c = lane; c < d; c += 64) acc[c] = 0.0;
@@ -131,11 +141,11 @@ __global__ __launch_bounds__(1024) void sketch_contract_kernel(const T* __restri
                     if (v < nvec) {
 #pragma unroll
                         for (int e = 0; e < PER; ++e) {
-                            const int g = v * PER + e;
+                            const int ti = ((((v0 >> 6) + u) * PER + e) << 6) + lane;      // lane-major table index of gene v*PER+e
                             double y = (double)x[u][e];
                             if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
-                            const unsigned b = b_l[g];
-                            if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned b = b_l[ti];
+                            if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[ti] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 }
@@ -143,8 +153,9 @@ __global__ __launch_bounds__(1024) void sketch_contract_kernel(const T* __restri
             for (int g = nvec * PER + lane; g < G; g += 64) {
                 double y = (double)yrow[g];
                 if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
-                const unsigned b = b_l[g];
-                if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int ti = tail_base + (g - nvec * PER);
+                const unsigned b = b_l[ti];
+                if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[ti] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             if (row_sumsq) {
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(1024) void sketch_contract_kernel(const T* __restri
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int c0 = (wave * NB + b) * 16 + 4 * q;
-            const double4_t bv = (c0 < d) ? *reinterpret_cast<const double4_t*>(yrow_l + c0) : double4_t{0.0, 0.0, 0.0, 0.0};
+            const double4_t bv = (c0 < d && r < R) ? *reinterpret_cast<const double4_t*>(yrow_l + c0) : double4_t{0.0, 0.0, 0.0, 0.0};
             const double x[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
             for (int t = 0; t < TT; ++t)
@@ -179,24 +190,30 @@ __global__ __launch_bounds__(1024) void sketch_contract_kernel(const T* __restri
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) red[(size_t)wave * (TT * 4 * 64) + (t * 4 + rr) * 64 + lane] = accm[t][rr];
         __syncthreads();
-        for (int o = tid; o < TT * 4 * 64; o += 1024) {
+        for (int o = tid; o < TT * 4 * 64; o += R * 64) {
             double sum = 0.0;
 #pragma unroll
-            for (int v = 0; v < FUSED_ROWS; ++v) sum += red[(size_t)v * (TT * 4 * 64) + o];   // wave order: deterministic
+            for (int v = 0; v < R; ++v) sum += red[(size_t)v * (TT * 4 * 64) + o];   // wave order: deterministic
             const int l = o & 63, tr = o >> 6;
             const int type = (tr >> 2) * 16 + (l >> 4) + 4 * (tr & 3);
             const long long sp = s0 + (l & 15);
-            if (type < K && sp < n) Hout[(size_t)type * ldh + sp] = sum;
+            if (type < K && (l & 15) < R && sp < n) Hout[(size_t)type * ldh + sp] = sum;
         }
         __syncthreads();                                                  // red is rows again for the next group
     }
 }
 
+static int fused_rows() {             // spots per group (waves per workgroup): 16 unless FDX_FUSED_ROWS=8
+    const char* e = getenv("FDX_FUSED_ROWS");
+    return (e && atoi(e) == 8) ? 8 : 16;
+}
+
 size_t fused_lds_bytes(int G, int d, int K) {
-    const size_t Gp = ((size_t)G + 7) & ~(size_t)7;
+    const size_t R = (size_t)fused_rows();
+    const size_t Gp = ((size_t)G + 256 + 7) & ~(size_t)7;                   // lane-major table: up to 64 * PER slots of padding
     const size_t TT = (size_t)(K + 15) / 16;
-    const size_t region = std::max((size_t)FUSED_ROWS * (d + FUSED_PAD), (size_t)FUSED_ROWS * TT * 4 * 64);   // rows / reduction
-    return Gp * 10 + region * 8 + (size_t)FUSED_ROWS * 64 * 8;
+    const size_t region = std::max(R * (d + FUSED_PAD), R * TT * 4 * 64);   // rows / reduction
+    return Gp * 10 + region * 8 + R * 64 * 8;
 }
 
 bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan) {
@@ -219,19 +236,27 @@ bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, in
 template <typename T, int MODE, bool VEC>
 static int launch_fused_nb(const T* Y, long long ldy, const int* row_map, long long n, int G, int d, const SketchPlanDev& plan,
                            const double* Xs, int K, double* H, long long ldh, double* row_sumsq, hipStream_t st) {
-    const int nb = (d + 255) / 256, TT = (K + 15) / 16;         // 16 waves x NB blocks of 16 cover the contraction index
+    const int R = fused_rows();
+    const int nb = (d + 16 * R - 1) / (16 * R), TT = (K + 15) / 16;   // R waves x NB blocks of 16 cover the contraction index
     const size_t lds = fused_lds_bytes(G, d, K);
-    const long long groups = (n + FUSED_ROWS - 1) / FUSED_ROWS;
-    const int grid = (int)std::min<long long>(groups, 256);    // one 16-wave workgroup per CU
+    const long long groups = (n + R - 1) / R;
+    const int per_cu = std::max<int>(1, (int)((160 * 1024) / lds));
+    const int grid = (int)std::min<long long>(groups, 256LL * std::min(per_cu, R == 8 ? 2 : 1));
     const void* kern = nullptr;
-#define FDX_FUSED(NB_, TT_) kern = (const void*)sketch_contract_kernel<T, MODE, VEC, NB_, TT_>
-    if (nb <= 1) { if (TT == 1) FDX_FUSED(1, 1); else FDX_FUSED(1, 2); }
-    else { if (TT == 1) FDX_FUSED(2, 1); else FDX_FUSED(2, 2); }
+#define FDX_FUSED(R_, NB_, TT_) kern = (const void*)sketch_contract_kernel<T, MODE, VEC, R_, NB_, TT_>
+    if (R == 16) {
+        if (nb <= 1) { if (TT == 1) FDX_FUSED(16, 1, 1); else FDX_FUSED(16, 1, 2); }
+        else { if (TT == 1) FDX_FUSED(16, 2, 1); else FDX_FUSED(16, 2, 2); }
+    } else {
+        if (nb <= 1) { if (TT == 1) FDX_FUSED(8, 1, 1); else FDX_FUSED(8, 1, 2); }
+        else if (nb <= 2) { if (TT == 1) FDX_FUSED(8, 2, 1); else FDX_FUSED(8, 2, 2); }
+        else { if (TT == 1) FDX_FUSED(8, 4, 1); else FDX_FUSED(8, 4, 2); }
+    }
 #undef FDX_FUSED
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&Y, (void*)&ldy, (void*)&row_map, (void*)&n, (void*)&G, (void*)&d, (void*)&plan.gene_w,
                     (void*)&plan.gene_bucket, (void*)&Xs, (void*)&K, (void*)&H, (void*)&ldh, (void*)&row_sumsq};
-    FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3(1024), args, lds, st));
+    FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3(R * 64), args, lds, st));
     return 0;
 }
 

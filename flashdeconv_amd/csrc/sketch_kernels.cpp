@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void sketch_rows_reg_kernel(const T* __rest
 // repeatable run to run (asserted in tests).  log-CPM reads the row twice (library size first); the second read hits
 // L2/MALL.  FDX_SKETCH_GATHER=1 selects the atomics-free, gene-ordered gather kernels instead.
 template <typename T, int MODE, bool VEC>
-__global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __restrict__ Y, long long ldy,
+__global__ __launch_bounds__(512, 4) void sketch_rows_scatter_kernel(const T* __restrict__ Y, long long ldy,
                                                                   const int* __restrict__ row_map, long long n, int G, int d,
                                                                   const double* __restrict__ gene_w,
                                                                   const int* __restrict__ gene_bucket,
@@ -295,20 +295,26 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_blk = blockDim.x >> 6;
-    const int Gp = (G + 7) & ~7;
+    const int Gp = (G + 256 + 7) & ~7;                 // table capacity: lane-major layout pads up to 64 * PER slots
     double* w_l = reinterpret_cast<double*>(smem);                                   // [Gp]
     double* acc = w_l + Gp + (size_t)wib * (d + 64);                                  // [waves][d + 64]
     double* tab = acc + d;                                                            // this wave's log1p table (64)
     unsigned short* b_l = reinterpret_cast<unsigned short*>(w_l + Gp + (size_t)waves_per_blk * (d + 64));   // [Gp]
-    for (int g = threadIdx.x; g < Gp; g += blockDim.x) {
-        const int b = (g < G) ? gene_bucket[g] : -1;
-        w_l[g] = (g < G && b >= 0) ? gene_w[g] : 0.0;
-        b_l[g] = (unsigned short)(b >= 0 ? b : 0xFFFF);       // 0xFFFF: gene has no entry in Omega (never added)
-    }
-    __syncthreads();
+    // LANE-MAJOR table: the entry of gene (v0 + u*64 + lane)*PER + e sits at ((v0/64 + u)*PER + e)*64 + lane, so a wave's
+    // table read touches 64 consecutive entries (in gene order a lane's genes are PER*8 bytes apart: 8-way bank conflicts);
+    // genes past the last full 16-byte vector (all genes on the scalar path) follow in gene order.
     typedef typename Vec4<T>::type V;
     constexpr int PER = 16 / sizeof(T);
     const int nvec = VEC ? G / PER : 0;
+    const int tail_base = ((nvec + 63) >> 6) * 64 * PER;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        const int b = gene_bucket[g];
+        const int v = g / PER, e = g - v * PER;
+        const int idx = (g < nvec * PER) ? ((((v >> 6) * PER + e) << 6) + (v & 63)) : (tail_base + (g - nvec * PER));
+        w_l[idx] = (b >= 0) ? gene_w[g] : 0.0;
+        b_l[idx] = (unsigned short)(b >= 0 ? b : 0xFFFF);     // 0xFFFF: gene has no entry in Omega (never added)
+    }
+    __syncthreads();
     const long long wave0 = (long long)blockIdx.x * waves_per_blk + wib;
     const long long stride = (long long)gridDim.x * waves_per_blk;
     for (long long p = wave0; p < n; p += stride) {
@@ -362,11 +368,11 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
                 if (v < nvec) {
 #pragma unroll
                     for (int e = 0; e < PER; ++e) {
-                        const int g = v * PER + e;
+                        const int ti = ((((v0 >> 6) + u) * PER + e) << 6) + lane;   // lane-major index of gene v*PER+e
                         double y = (double)x[u][e];
                         if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
-                        const unsigned b = b_l[g];
-                        if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const unsigned b = b_l[ti];
+                        if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[ti] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
@@ -374,8 +380,9 @@ __global__ __launch_bounds__(512) void sketch_rows_scatter_kernel(const T* __res
         for (int g = nvec * PER + lane; g < G; g += 64) {
             double y = (double)yrow[g];
             if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
-            const unsigned b = b_l[g];
-            if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[g] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int ti = tail_base + (g - nvec * PER);
+            const unsigned b = b_l[ti];
+            if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[ti] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         double* dst = Ys + (size_t)p * ldys;
@@ -430,7 +437,7 @@ static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, lon
         }
     }
     if (use_scatter) {
-        const size_t Gp = ((size_t)G + 7) & ~(size_t)7;
+        const size_t Gp = ((size_t)G + 256 + 7) & ~(size_t)7;
         int wv = 8;
         while (wv > 1 && Gp * 10 + (size_t)wv * (d + 64) * 8 > 150 * 1024) wv >>= 1;
         const size_t lds_s = Gp * 10 + (size_t)wv * (d + 64) * 8;
