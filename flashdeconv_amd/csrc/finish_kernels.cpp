@@ -76,12 +76,13 @@ __global__ __launch_bounds__(256) void normalize_export_kernel(const double* __r
     const int i = slice * 64 + lane;
     const bool active = i < n;
     const int ii = active ? i : n - 1;
-    double* tile = smem + (size_t)wib * K * 64;  // [spot][k], row length K
+    const int Ks = K | 1;                        // odd row stride: the 64 lanes of a column write hit 64 different banks
+    double* tile = smem + (size_t)wib * Ks * 64; // [spot][k], row stride Ks
     double s = 0.0;
     for (int k = 0; k < K; ++k) {
         const double v = beta[(size_t)k * ld + ii];
         s += v;
-        if (use_lds) tile[lane * K + k] = v;
+        if (use_lds) tile[lane * Ks + k] = v;
     }
     // normalize_proportions: all-zero rows -> 1/K, otherwise beta / max(rowsum, 1e-10)   (solver.py:445-451)
     const double den = fmax(s, 1e-10);
@@ -104,14 +105,14 @@ __global__ __launch_bounds__(256) void normalize_export_kernel(const double* __r
         const int sp = f / K, k = f - sp * K;
         const int row = row_s[wib][sp];
         if (row < 0) continue;
-        const double v = tile[f];
+        const double v = tile[sp * Ks + k];
         const double dd = inv_s[wib][sp];
         if (beta_out) beta_out[(size_t)row * K + k] = v;
         if (prop_out) prop_out[(size_t)row * K + k] = (dd < 0.0) ? 1.0 / (double)K : v / dd;
     }
 }
 
-static inline size_t tile_lds_bytes(int K) { return (size_t)K * 256 * sizeof(double); }
+static inline size_t tile_lds_bytes(int K) { return (size_t)(K | 1) * 256 * sizeof(double); }
 static inline bool tile_fits(int K) { return tile_lds_bytes(K) <= 128 * 1024; }
 
 int objective_partials_count(int n_slices) { return ceil_div(n_slices, 4); }
