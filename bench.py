@@ -252,7 +252,7 @@ def main():
         else:
             if stage["gram_ms"] == 0.0:                # fused sketch -> H kernel: ONE launch reads all of Y, writes only H
                 bytes_launch, ms_launch = sk_bytes, sk_ms
-                kname = "fdx::sketch_contract_kernel<float, %d, true, %d, %d>" % (0 if fam == "gaussian" else 1, -(-d // 256), -(-K // 16))
+                kname = "fdx::sketch_contract_kernel<float, %d, true, 16, %d, %d>" % (0 if fam == "gaussian" else 1, -(-d // 256), -(-K // 16))
             else:
                 bytes_launch, ms_launch = sk_bytes / n_chunks, sk_ms / n_chunks
                 kname = "fdx::sketch_rows_scatter_kernel<float, %d, true>" % (0 if fam == "gaussian" else 1)
