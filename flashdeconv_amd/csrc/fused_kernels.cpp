@@ -100,15 +100,15 @@ __global__ __launch_bounds__(R * 64, 4) void sketch_contract_kernel(const T* __r
             if (MODE != FDX_PRE_RAW) {
                 double part = 0.0;
                 T mx = (T)0;
-                for (int v0 = 0; v0 < nvec; v0 += 512) {
-                    V x[8];
+                for (int v0 = 0; v0 < nvec; v0 += 256) {   // 4 loads per batch: 16 waves share 512 VGPRs per SIMD lane
+                    V x[4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 4; ++u) {
                         const int v = v0 + u * 64 + lane;
                         if (v < nvec) x[u] = src[v];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 4; ++u) {
                         const int v = v0 + u * 64 + lane;
                         if (v < nvec) {
 #pragma unroll
@@ -146,7 +146,8 @@ __global__ __launch_bounds__(R * 64, 4) void sketch_contract_kernel(const T* __r
                             if (MODE != FDX_PRE_RAW) y = log1p_scaled(y, scale, tab, use_tab);
                             const unsigned b = b_l[ti];
                             if (b != 0xFFFFu) __hip_atomic_fetch_add(acc + b, w_l[ti] * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
+                            if (MODE != FDX_PRE_RAW) __builtin_amdgcn_sched_barrier(0);   // one log1p at a time: interleaving
+                        }                                                                   // four of them spills at 128 VGPRs
                     }
                 }
             }
