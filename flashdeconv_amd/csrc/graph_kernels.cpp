@@ -19,6 +19,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
@@ -884,27 +885,41 @@ int graph_export_csr(const fdx_graph* g, long long* d_indptr, int* d_indices, hi
 // ------------------------------------------------------------------------------------------------ sharding
 // A rank owns the contiguous range [lo, hi) of the sorted order (lo a multiple of 256).  Its local graph indexes own
 // spots 0..n_own-1, then the halo (neighbour positions outside the range, ascending global position), then the zero row.
-__global__ __launch_bounds__(256) void mark_halo_kernel(const int* __restrict__ ell, const int* __restrict__ slice_off,
-                                                        const int* __restrict__ deg, long long lo, long long hi,
-                                                        int* __restrict__ flags) {
+// External neighbours of the own rows, with repetitions: PASS 0 counts them, PASS 1 appends them to `list` (order
+// irrelevant: the list is sorted and made unique afterwards).  The halo is found from what the own rows reference, so the
+// cost is proportional to the shard, not to the whole graph.
+// PASS 1 also emits, for every such reference, the key (owner rank of q) << 32 | (own row - lo): by symmetry of the graph
+// the owner of q needs this row in ITS halo, so the sorted unique keys are the send lists of all peers at once.
+template <int PASS>
+__global__ __launch_bounds__(256) void collect_halo_kernel(const int* __restrict__ ell, const int* __restrict__ slice_off,
+                                                           const int* __restrict__ deg, long long lo, long long hi,
+                                                           const long long* __restrict__ bounds, int n_ranks,
+                                                           int* __restrict__ counter, int* __restrict__ list,
+                                                           unsigned long long* __restrict__ send_keys) {
     const long long p = lo + blockIdx.x * 256LL + threadIdx.x;
     if (p >= hi) return;
     const int* seg = ell + (size_t)slice_off[p >> 6] * 64 + (p & 63);
+    int local = 0;
     for (int m = 0; m < deg[p]; ++m) {
         const int q = seg[(size_t)m * 64];
-        if (q < lo || q >= hi) flags[q] = 1;
+        if (q < lo || q >= hi) {
+            if (PASS) {
+                const int at = atomicAdd(counter, 1);
+                list[at] = q;
+                int r = 0;
+                while (r + 1 < n_ranks && (long long)q >= bounds[r + 1]) ++r;          // owner of q (a handful of ranks)
+                send_keys[at] = ((unsigned long long)r << 32) | (unsigned long long)(p - lo);
+            } else {
+                ++local;
+            }
+        }
     }
-}
-
-__global__ __launch_bounds__(256) void compact_flags_kernel(const int* __restrict__ flags, const int* __restrict__ pos,
-                                                            long long n, int* __restrict__ out) {
-    const long long q = blockIdx.x * 256LL + threadIdx.x;
-    if (q < n && flags[q]) out[pos[q]] = (int)q;
+    if (!PASS && local) atomicAdd(counter, local);
 }
 
 __global__ __launch_bounds__(256) void localize_ell_kernel(const int* __restrict__ ell_g, const int* __restrict__ slice_off_g,
                                                            const int* __restrict__ deg_g, const int* __restrict__ perm_g,
-                                                           const int* __restrict__ pos, long long lo, long long hi,
+                                                           const int* __restrict__ halo, int n_halo, long long lo, long long hi,
                                                            int n_total_g, int* __restrict__ ell_l,
                                                            int* __restrict__ slice_off_l, int* __restrict__ deg_l,
                                                            int* __restrict__ perm_l) {
@@ -921,31 +936,20 @@ __global__ __launch_bounds__(256) void localize_ell_kernel(const int* __restrict
     const int s = (int)(t >> 6), lane = (int)(t & 63);
     if (s < n_slices_l) {
         const int w0 = slice_off_g[s0 + s], w = slice_off_g[s0 + s + 1] - w0;
-        const int n_total_l = (int)n_own + pos[n_total_g];   // pos has n_total_g + 1 entries: the last is the halo count
+        const int n_total_l = (int)n_own + n_halo;
         for (int m = 0; m < w; ++m) {
             const int q = ell_g[((size_t)w0 + m) * 64 + lane];
             int v;
             if (q == n_total_g) v = n_total_l;                 // pad -> local zero row
             else if (q >= lo && q < hi) v = (int)(q - lo);
-            else v = (int)n_own + pos[q];
+            else {                                             // halo slot = rank of q in the sorted, unique halo list
+                int a = 0, b = n_halo;
+                while (a < b) { const int mid = (a + b) >> 1; if (halo[mid] < q) a = mid + 1; else b = mid; }
+                v = (int)n_own + a;
+            }
             ell_l[((size_t)(w0 - base_rows) + m) * 64 + lane] = v;
         }
     }
-}
-
-// own spots with at least one neighbour in [plo, phi): the rows a peer needs from this rank (graph is symmetric)
-__global__ __launch_bounds__(256) void mark_send_kernel(const int* __restrict__ ell, const int* __restrict__ slice_off,
-                                                        const int* __restrict__ deg, long long lo, long long hi,
-                                                        long long plo, long long phi, int* __restrict__ flags) {
-    const long long p = lo + blockIdx.x * 256LL + threadIdx.x;
-    if (p >= hi) return;
-    const int* seg = ell + (size_t)slice_off[p >> 6] * 64 + (p & 63);
-    int f = 0;
-    for (int m = 0; m < deg[p]; ++m) {
-        const int q = seg[(size_t)m * 64];
-        if (q >= plo && q < phi) f = 1;
-    }
-    flags[p - lo] = f;
 }
 
 int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_ranks, const long long* bounds, int my_rank,
@@ -959,30 +963,69 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
     loc->identity_order = false;
     loc->global_lo = lo;
     loc->n_slices = (int)((n_own + 63) / 64);
-    DevBuf flags, pos, tmp;
-    FDX_TRY(flags.alloc((size_t)(ng + 2) * 4));
-    FDX_TRY(pos.alloc((size_t)(ng + 2) * 4));
-    FDX_HIP(hipMemsetAsync(flags.p, 0, flags.bytes, st));
+    // halo = sorted unique set of the neighbour positions outside [lo, hi) that the own rows reference
+    DevBuf tmp, counter, ext, ext_sorted, n_uniq, d_bounds, skeys, skeys_sorted, skeys_uniq;
+    int n_halo = 0, n_send = 0;
+    FDX_TRY(counter.alloc(8));
+    FDX_TRY(d_bounds.alloc((size_t)(n_ranks + 1) * 8));
+    FDX_HIP(hipMemcpyAsync(d_bounds.p, bounds, (size_t)(n_ranks + 1) * 8, hipMemcpyHostToDevice, st));
     if (n_own > 0 && full->ell_rows > 0) {
-        hipLaunchKernelGGL(mark_halo_kernel, dim3(ceil_div(n_own, 256)), dim3(256), 0, st, full->ell.as<int>(),
-                           full->slice_off.as<int>(), full->deg.as<int>(), lo, hi, flags.as<int>());
+        FDX_HIP(hipMemsetAsync(counter.p, 0, 8, st));
+        hipLaunchKernelGGL(collect_halo_kernel<0>, dim3(ceil_div(n_own, 256)), dim3(256), 0, st, full->ell.as<int>(),
+                           full->slice_off.as<int>(), full->deg.as<int>(), lo, hi, d_bounds.as<long long>(), n_ranks,
+                           counter.as<int>(), (int*)nullptr, (unsigned long long*)nullptr);
         FDX_CHECK_LAUNCH();
+        int n_ext = 0;
+        FDX_HIP(hipMemcpyAsync(&n_ext, counter.p, 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        if (n_ext > 0) {
+            FDX_TRY(ext.alloc((size_t)n_ext * 4));
+            FDX_TRY(ext_sorted.alloc((size_t)n_ext * 4));
+            FDX_TRY(loc->halo_global.alloc((size_t)n_ext * 4));
+            FDX_TRY(n_uniq.alloc(8));
+            FDX_TRY(skeys.alloc((size_t)n_ext * 8));
+            FDX_TRY(skeys_sorted.alloc((size_t)n_ext * 8));
+            FDX_TRY(skeys_uniq.alloc((size_t)n_ext * 8));
+            FDX_HIP(hipMemsetAsync(counter.p, 0, 8, st));
+            hipLaunchKernelGGL(collect_halo_kernel<1>, dim3(ceil_div(n_own, 256)), dim3(256), 0, st, full->ell.as<int>(),
+                               full->slice_off.as<int>(), full->deg.as<int>(), lo, hi, d_bounds.as<long long>(), n_ranks,
+                               counter.as<int>(), ext.as<int>(), skeys.as<unsigned long long>());
+            FDX_CHECK_LAUNCH();
+            {   // send lists of all peers: sort + unique of the (peer, row) keys
+                typedef unsigned long long u64;
+                size_t b1 = 0, b2 = 0;
+                FDX_HIP(rocprim::radix_sort_keys(nullptr, b1, skeys.as<u64>(), skeys_sorted.as<u64>(), (size_t)n_ext, 0, 64, st));
+                FDX_HIP(rocprim::unique(nullptr, b2, skeys_sorted.as<u64>(), skeys_uniq.as<u64>(), n_uniq.as<int>() + 1, (size_t)n_ext,
+                                        rocprim::equal_to<u64>(), st));
+                FDX_TRY(tmp.alloc(std::max(b1, b2)));
+                FDX_HIP(rocprim::radix_sort_keys(tmp.p, b1, skeys.as<u64>(), skeys_sorted.as<u64>(), (size_t)n_ext, 0, 64, st));
+                FDX_HIP(rocprim::unique(tmp.p, b2, skeys_sorted.as<u64>(), skeys_uniq.as<u64>(), n_uniq.as<int>() + 1, (size_t)n_ext,
+                                        rocprim::equal_to<u64>(), st));
+                FDX_HIP(hipMemcpyAsync(&n_send, n_uniq.as<int>() + 1, 4, hipMemcpyDeviceToHost, st));
+            }
+            size_t sb = 0, ub = 0;
+            FDX_HIP(rocprim::radix_sort_keys(nullptr, sb, ext.as<int>(), ext_sorted.as<int>(), (size_t)n_ext, 0, 32, st));
+            FDX_HIP(rocprim::unique(nullptr, ub, ext_sorted.as<int>(), loc->halo_global.as<int>(), n_uniq.as<int>(), (size_t)n_ext,
+                                    rocprim::equal_to<int>(), st));
+            FDX_TRY(tmp.alloc(std::max(sb, ub)));
+            FDX_HIP(rocprim::radix_sort_keys(tmp.p, sb, ext.as<int>(), ext_sorted.as<int>(), (size_t)n_ext, 0, 32, st));
+            FDX_HIP(rocprim::unique(tmp.p, ub, ext_sorted.as<int>(), loc->halo_global.as<int>(), n_uniq.as<int>(), (size_t)n_ext,
+                                    rocprim::equal_to<int>(), st));
+            FDX_HIP(hipMemcpyAsync(&n_halo, n_uniq.p, 4, hipMemcpyDeviceToHost, st));
+            FDX_HIP(hipStreamSynchronize(st));
+        }
     }
-    FDX_TRY(exclusive_scan_int(flags.as<int>(), pos.as<int>(), ng + 1, st, tmp));
-    int n_halo = 0;
-    FDX_HIP(hipMemcpyAsync(&n_halo, pos.as<int>() + ng, 4, hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
+    if (!loc->halo_global.p) FDX_TRY(loc->halo_global.alloc(4));
     loc->n_total = n_own + n_halo;
-    FDX_TRY(loc->halo_global.alloc((size_t)std::max(n_halo, 1) * 4));
-    hipLaunchKernelGGL(compact_flags_kernel, dim3(ceil_div(ng, 256)), dim3(256), 0, st, flags.as<int>(), pos.as<int>(), ng,
-                       loc->halo_global.as<int>());
-    FDX_CHECK_LAUNCH();
     // local ELL / deg / perm
     const int s0 = (int)(lo >> 6);
-    std::vector<int> so((size_t)full->n_slices + 1);
-    FDX_HIP(hipMemcpyAsync(so.data(), full->slice_off.p, so.size() * 4, hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
-    loc->ell_rows = (loc->n_slices > 0) ? so[(size_t)s0 + loc->n_slices] - so[(size_t)s0] : 0;
+    int so2[2] = {0, 0};                              // the two slice offsets that bound the own rows
+    if (loc->n_slices > 0) {
+        FDX_HIP(hipMemcpyAsync(&so2[0], full->slice_off.as<int>() + s0, 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipMemcpyAsync(&so2[1], full->slice_off.as<int>() + s0 + loc->n_slices, 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+    }
+    loc->ell_rows = so2[1] - so2[0];
     FDX_TRY(loc->ell.alloc((size_t)std::max<long long>(loc->ell_rows, 1) * 64 * 4));
     FDX_TRY(loc->slice_off.alloc((size_t)(loc->n_slices + 1) * 4));
     FDX_TRY(loc->deg.alloc((size_t)std::max<long long>(n_own, 1) * 4));
@@ -990,22 +1033,31 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
     if (n_own > 0) {
         hipLaunchKernelGGL(localize_ell_kernel, dim3(ceil_div(loc->n_slices * 64LL + 1, 256)), dim3(256), 0, st,
                            full->ell.as<int>(), full->slice_off.as<int>(), full->deg.as<int>(),
-                           full->identity_order ? (const int*)nullptr : full->perm.as<int>(), pos.as<int>(), lo, hi, (int)ng,
+                           full->identity_order ? (const int*)nullptr : full->perm.as<int>(), loc->halo_global.as<int>(), n_halo,
+                           lo, hi, (int)ng,
                            loc->ell.as<int>(), loc->slice_off.as<int>(), loc->deg.as<int>(), loc->perm.as<int>());
         FDX_CHECK_LAUNCH();
     } else {
         FDX_HIP(hipMemsetAsync(loc->slice_off.p, 0, loc->slice_off.bytes, st));
     }
-    // nnz / max degree of the own rows
-    {
-        std::vector<int> dg((size_t)std::max<long long>(n_own, 1), 0);
-        if (n_own) FDX_HIP(hipMemcpyAsync(dg.data(), loc->deg.p, (size_t)n_own * 4, hipMemcpyDeviceToHost, st));
+    // nnz / max degree of the own rows (device reductions: a host loop over a 4 MB read-back was most of this function)
+    loc->nnz = 0;
+    loc->max_deg = 0;
+    if (n_own > 0) {
+        DevBuf red, rtmp;
+        FDX_TRY(red.alloc(16));
+        size_t rb = 0, rb2 = 0;
+        auto deg64 = rocprim::make_transform_iterator(loc->deg.as<int>(), [] __device__(int v) { return (long long)v; });
+        FDX_HIP(rocprim::reduce(nullptr, rb, deg64, red.as<long long>(), 0LL, (size_t)n_own, rocprim::plus<long long>(), st));
+        FDX_HIP(rocprim::reduce(nullptr, rb2, loc->deg.as<int>(), red.as<int>() + 2, 0, (size_t)n_own, rocprim::maximum<int>(), st));
+        FDX_TRY(rtmp.alloc(std::max(rb, rb2)));
+        FDX_HIP(rocprim::reduce(rtmp.p, rb, deg64, red.as<long long>(), 0LL, (size_t)n_own, rocprim::plus<long long>(), st));
+        FDX_HIP(rocprim::reduce(rtmp.p, rb2, loc->deg.as<int>(), red.as<int>() + 2, 0, (size_t)n_own, rocprim::maximum<int>(), st));
+        long long h_red[2] = {0, 0};
+        FDX_HIP(hipMemcpyAsync(h_red, red.p, 16, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipStreamSynchronize(st));
-        long long nnz = 0;
-        int md = 0;
-        for (long long i = 0; i < n_own; ++i) { nnz += dg[(size_t)i]; md = std::max(md, dg[(size_t)i]); }
-        loc->nnz = nnz;
-        loc->max_deg = md;
+        loc->nnz = h_red[0];
+        loc->max_deg = (int)(h_red[1] & 0xffffffffLL);
     }
     FDX_TRY(build_tiles(loc, st));
     // halo ownership (recv) and send lists per peer
@@ -1018,34 +1070,17 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
         const long long e = bounds[r + 1];
         loc->recv_off[(size_t)r + 1] = (int)(std::lower_bound(hg.begin(), hg.begin() + n_halo, (int)std::min<long long>(e, 0x7fffffff)) - hg.begin());
     }
-    DevBuf sflag, spos, slist;
-    FDX_TRY(sflag.alloc((size_t)(n_own + 2) * 4));
-    FDX_TRY(spos.alloc((size_t)(n_own + 2) * 4));
-    std::vector<std::vector<int>> lists((size_t)n_ranks);
-    for (int r = 0; r < n_ranks; ++r) {
-        if (r == my_rank || n_own == 0 || full->ell_rows == 0 || bounds[r + 1] <= bounds[r]) continue;
-        FDX_HIP(hipMemsetAsync(sflag.p, 0, sflag.bytes, st));
-        hipLaunchKernelGGL(mark_send_kernel, dim3(ceil_div(n_own, 256)), dim3(256), 0, st, full->ell.as<int>(),
-                           full->slice_off.as<int>(), full->deg.as<int>(), lo, hi, bounds[r], bounds[r + 1], sflag.as<int>());
-        FDX_CHECK_LAUNCH();
-        FDX_TRY(exclusive_scan_int(sflag.as<int>(), spos.as<int>(), n_own + 1, st, tmp));
-        int cnt = 0;
-        FDX_HIP(hipMemcpyAsync(&cnt, spos.as<int>() + n_own, 4, hipMemcpyDeviceToHost, st));
-        FDX_HIP(hipStreamSynchronize(st));
-        lists[(size_t)r].resize((size_t)cnt);
-        if (cnt) {
-            FDX_TRY(slist.alloc((size_t)cnt * 4));
-            hipLaunchKernelGGL(compact_flags_kernel, dim3(ceil_div(n_own, 256)), dim3(256), 0, st, sflag.as<int>(),
-                               spos.as<int>(), n_own, slist.as<int>());
-            FDX_CHECK_LAUNCH();
-            FDX_HIP(hipMemcpyAsync(lists[(size_t)r].data(), slist.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
-            FDX_HIP(hipStreamSynchronize(st));
+    // send lists: the unique (peer, row) keys are already grouped by peer and ascending in the row
+    std::vector<unsigned long long> hk((size_t)std::max(n_send, 1));
+    if (n_send) FDX_HIP(hipMemcpyAsync(hk.data(), skeys_uniq.p, (size_t)n_send * 8, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    std::vector<int> all_send((size_t)n_send);
+    {
+        int at = 0;
+        for (int r = 0; r < n_ranks; ++r) {
+            while (at < n_send && (int)(hk[(size_t)at] >> 32) == r) { all_send[(size_t)at] = (int)(hk[(size_t)at] & 0xffffffffULL); ++at; }
+            loc->send_off[(size_t)r + 1] = at;
         }
-    }
-    std::vector<int> all_send;
-    for (int r = 0; r < n_ranks; ++r) {
-        all_send.insert(all_send.end(), lists[(size_t)r].begin(), lists[(size_t)r].end());
-        loc->send_off[(size_t)r + 1] = (int)all_send.size();
     }
     FDX_TRY(loc->send_idx.alloc(std::max<size_t>(all_send.size(), 1) * 4));
     if (!all_send.empty())
