@@ -149,3 +149,17 @@ def test_normalize_proportions_exact():
     from flashdeconv_amd.core.solver import normalize_proportions
     g = load_golden("solver_small.npz")
     np.testing.assert_array_equal(normalize_proportions(g["norm_in"]), g["norm_out"])
+
+
+def test_public_header_is_plain_c99(tmp_path):
+    """include/fdx.h is the drop-in boundary: it must compile as C (no C++-isms, no torch / HIP types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "fdx.h"\nint main(void) { return fdx_version() ? 0 : 0; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
