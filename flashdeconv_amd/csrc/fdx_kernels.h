@@ -59,6 +59,7 @@ struct SketchPlanDev {
     const double* gene_w = nullptr;
     const int* gene_bucket = nullptr;
     int scatter_ok = 0;
+    const struct SketchPlan* owner = nullptr;   // host object (holds the tile kernel's schedules)
 };
 // true when the scatter kernel's LDS footprint (per-gene table + one accumulator row) fits: the kernel then serves the plan
 inline bool sketch_scatter_fits(int G, int d) {
@@ -67,7 +68,13 @@ inline bool sketch_scatter_fits(int G, int d) {
 int launch_sketch_rows(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, double* Ys, long long ldys, double* row_sumsq, hipStream_t st);
 // fused sketch + H contraction (fused_kernels.cpp)
-bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan);
+bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan,
+                              hipStream_t st = nullptr);
+// tile kernel (tile_kernels.cpp): atomic-free form of the same contraction, preferred when its schedule fits
+bool tile_sketch_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan, hipStream_t st);
+int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
+                       const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
+                       hipStream_t st);
 int launch_sketch_contract(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                            const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
                            hipStream_t st);

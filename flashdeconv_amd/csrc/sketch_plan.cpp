@@ -33,6 +33,14 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
             gb[(size_t)g] = c;
             gw[(size_t)g] = weight[e];
         }
+    if (scatter_ok) {
+        host_bucket = gb;
+        host_w = gw;
+    }
+    for (int i = 0; i < 4; ++i) {
+        tile[i].reset();
+        tile_tried[i] = false;
+    }
     FDX_TRY(gene_w.alloc(gw.size() * sizeof(double)));
     FDX_TRY(gene_bucket.alloc(gb.size() * sizeof(int)));
     FDX_HIP(hipMemcpyAsync(gene_w.p, gw.data(), gw.size() * sizeof(double), hipMemcpyHostToDevice, st));

@@ -1,9 +1,14 @@
 // Host-built static schedule for the CountSketch gather (internal).
 #pragma once
+#include <memory>
+#include <vector>
+
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
 
 namespace fdx {
+
+struct TilePlanDevice;   // tile_kernels.cpp
 
 struct SketchPlan {
     int G = 0, d = 0;
@@ -13,6 +18,12 @@ struct SketchPlan {
     unsigned long long end_mask = 0ULL;
     bool scatter_ok = false;
     DevBuf sched_gene, sched_w, group_off, slot_bucket, sched_pack, gene_w, gene_bucket;
+    // per-gene form on the host (valid when scatter_ok) and the tile kernel's schedules built from it on first use,
+    // one per (input type, raw / log) pair (tile_kernels.cpp)
+    std::vector<int> host_bucket;
+    std::vector<double> host_w;
+    mutable std::shared_ptr<TilePlanDevice> tile[4];
+    mutable bool tile_tried[4] = {false, false, false, false};
     SketchPlanDev dev() const {
         SketchPlanDev p;
         p.sched_gene = sched_gene.as<int>();
@@ -27,6 +38,7 @@ struct SketchPlan {
         p.gene_w = gene_w.as<double>();
         p.gene_bucket = gene_bucket.as<int>();
         p.scatter_ok = scatter_ok ? 1 : 0;
+        p.owner = this;
         return p;
     }
     // Omega (G x d) in CSC form on the host: col_ptr (d+1), gene_idx / weight (nnz), genes ascending per column.

@@ -66,6 +66,15 @@ int fdx_stream_sync(void* stream);
  * Ys_out is (n, d) f64.  This is project_to_sketch(Y_tilde, ., Omega) when mode = FDX_PRE_RAW. */
 int fdx_sketch(const void* Y, int32_t dtype, int64_t n, int32_t G, const int64_t* col_ptr, const int32_t* gene_idx,
                const double* weight, int32_t d, int32_t mode, double* Ys_out);
+/* Host-only inspection of the gather schedule the tile kernel (csrc/tile_kernels.cpp) runs for a CountSketch
+ * (core/sketching.py:58-74: gene g -> bucket gene_bucket[g] with weight gene_w[g]; -1 = gene not in Omega): buckets are
+ * dealt to NW waves x JW groups x 4 lane classes, genes are cut into column blocks of GB.  No device call is made, so
+ * tests can replay the schedule on the CPU.  dims_out[4] = {blocks, table entries, steps, steps of the busiest wave};
+ * the tables are returned when slot_bucket_out is non-NULL: slot_bucket (NW*JW*4), len (NW*blocks*JW),
+ * ent_base (NW*(blocks+1)), w / off (entries; cap_entries = capacity of w_out and off_out). */
+int fdx_tile_schedule(const int32_t* gene_bucket, const double* gene_w, int32_t G, int32_t d, int32_t NW, int32_t JW,
+                      int32_t GB, int32_t* dims_out, int32_t* slot_bucket_out, uint8_t* len_out, int32_t* ent_base_out,
+                      double* w_out, uint16_t* off_out, int64_t cap_entries);
 /* Per-gene column sums of a host (n, G) matrix (pearson's mean: core/deconv.py:207-214). */
 int fdx_column_sums(const void* Y, int32_t dtype, int64_t n, int32_t G, double* sums_out);
 

@@ -163,3 +163,66 @@ def test_public_header_is_plain_c99(tmp_path):
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                         "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("G,d,NW,JW,GB", [(2000, 512, 16, 8, 1024), (2000, 512, 8, 16, 768), (2000, 512, 16, 8, 2048),
+                                          (3300, 512, 16, 8, 768), (1001, 500, 16, 8, 256), (300, 64, 16, 8, 512),
+                                          (5000, 512, 8, 16, 512), (40, 7, 16, 8, 256)])
+def test_tile_schedule_replays_to_the_countsketch(G, d, NW, JW, GB):
+    """The tile kernel's static schedule (csrc/tile_plan.cpp), replayed on the host exactly as the kernel walks it,
+    must reproduce f(Y) @ Omega: every gene visited once, in its bucket, with its weight, inside its column block."""
+    import fdx_oracle as orc
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(G + d)
+    bucket, weight = orc.countsketch_omega(G, d, rs.rand(G), 3)
+    bucket = bucket.astype(np.int32)
+    if G > 50:
+        bucket[::37] = -1                                    # genes outside Omega (a CSR-style selected subset)
+    dims = np.zeros(4, dtype=np.int32)
+    _lib.check(lib.fdx_tile_schedule(_lib.ptr_i32(bucket), _lib.ptr_f64(weight), G, d, NW, JW, GB, _lib.ptr_i32(dims),
+                                     None, None, None, None, None, 0))
+    nblk, ne, steps, wave_max = (int(x) for x in dims)
+    assert nblk == -(-G // GB)
+    slot = np.zeros(NW * JW * 4, dtype=np.int32)
+    ln = np.zeros(NW * nblk * JW, dtype=np.uint8)
+    base = np.zeros(NW * (nblk + 1), dtype=np.int32)
+    w = np.zeros(ne)
+    off = np.zeros(ne, dtype=np.uint16)
+    _lib.check(lib.fdx_tile_schedule(_lib.ptr_i32(bucket), _lib.ptr_f64(weight), G, d, NW, JW, GB, _lib.ptr_i32(dims),
+                                     _lib.ptr_i32(slot), ln.ctypes.data, _lib.ptr_i32(base), _lib.ptr_f64(w), off.ctypes.data, ne))
+    slot = slot.reshape(NW, JW, 4)
+    ln = ln.reshape(NW, nblk, JW)
+    base = base.reshape(NW, nblk + 1)
+    used = slot[slot >= 0]
+    assert np.array_equal(np.sort(used), np.arange(d))       # every bucket owned by exactly one slot
+    y = rs.randn(G)
+    sk = np.zeros(d)
+    seen = np.zeros(G, dtype=int)
+    for wv in range(NW):
+        for c in range(nblk):
+            p = base[wv, c]
+            for j in range(JW):
+                for _ in range(ln[wv, c, j]):
+                    for q in range(4):
+                        e = p + q
+                        g = c * GB + int(off[e])
+                        assert g < G and g < (c + 1) * GB
+                        if w[e] != 0.0:
+                            b = slot[wv, j, q]
+                            assert b >= 0 and bucket[g] == b and w[e] == weight[g]
+                            sk[b] += w[e] * y[g]
+                            seen[g] += 1
+                    p += 4
+            assert p == base[wv, c + 1]
+        assert base[wv, nblk] + 8 <= (base[wv + 1, 0] if wv + 1 < NW else ne)   # two padding steps per wave
+    inside = bucket >= 0
+    assert np.array_equal(seen[inside & (weight != 0)], np.ones(int((inside & (weight != 0)).sum()), dtype=int))
+    assert not seen[~inside].any()
+    want = np.zeros(d)
+    np.add.at(want, bucket[inside], weight[inside] * y[inside])
+    np.testing.assert_allclose(sk, want, rtol=1e-12, atol=1e-12)
+    # lockstep padding: at most 35 % more lane-steps than genes for the shapes the fit uses (G >= 1000, up to 5 blocks)
+    if G >= 1000 and nblk <= 5:
+        assert steps * 4 <= 1.35 * inside.sum(), (steps * 4, inside.sum())
+        assert wave_max * NW <= 1.15 * steps
