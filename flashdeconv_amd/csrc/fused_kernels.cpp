@@ -219,6 +219,7 @@ size_t fused_lds_bytes(int G, int d, int K) {
 
 bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan,
                               hipStream_t st) {
+    if (getenv("FDX_NO_FUSED")) return false;
     if (tile_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st)) return true;
     // History: an 8-wave version (two rows per wave, 120 KB of LDS) lost to the two-kernel path (3.8 vs 3.5 ms): all waves
     // move through scatter / barrier / MFMA / reduce together, so HBM idled outside the scatter phase and two waves per SIMD

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <type_traits>
 
 #include "device_math.h"
 #include "fdx_internal.h"
@@ -51,23 +52,35 @@ struct TileArgs {
 };
 
 // log1p(x) for x in [0, 32000): see the header.  logt[i] = -log(c_i), c_i the reciprocal with bit pattern
-// (LOG_TAB_BASE + i) << 16.  Anything else (negative, NaN, huge) takes the library path, as the reference would.
-__device__ __forceinline__ double tile_log1p(double x, const double* logt) {
-    if (__builtin_expect(!(x >= 0.0) || !(x < 32000.0), 0)) return log1p(x);
-    const float uf = 1.0f + (float)x;
+// (LOG_TAB_BASE + i) << 16.  uf: 1 + x to float accuracy (only the 8-bit reciprocal is taken from it).
+__device__ __forceinline__ double tile_log1p_core(double x, float uf, const double* logt) {
     unsigned bits = __float_as_uint(__builtin_amdgcn_rcpf(uf));
     bits = (bits + 0x8000u) & 0xFFFF0000u;                   // reciprocal rounded to 8 significant bits
-    const float invf = __uint_as_float(bits);
-    const double inv = (double)invf;
-    const double im1 = (double)(invf - 1.0f);                // exact
-    const double r = fma(x, inv, im1);                       // (1 + x) * inv - 1 with one rounding
-    const double t = logt[(int)(bits >> 16) - LOG_TAB_BASE];
+    const double inv = (double)__uint_as_float(bits);
+    const double r = fma(x, inv, inv - 1.0);                 // (1 + x) * inv - 1 with one rounding (inv - 1 is exact)
+    const double t = *reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(logt - LOG_TAB_BASE) + ((bits >> 16) << 3));
     double p = fma(r, -1.0 / 6.0, 0.2);
     p = fma(r, p, -0.25);
     p = fma(r, p, 1.0 / 3.0);
     p = fma(r, p, -0.5);
     p = fma(r, p, 1.0);
     return fma(r, p, t);
+}
+__device__ __forceinline__ double tile_log1p_fast(double x, const double* logt) { return tile_log1p_core(x, 1.0f + (float)x, logt); }
+// the same for y * scale with y already a float: 1 + x comes from one float fma
+__device__ __forceinline__ double tile_log1p_scaled(float y, double scale, float scale_f, const double* logt) {
+    return tile_log1p_core((double)y * scale, fmaf(y, scale_f, 1.0f), logt);
+}
+__device__ __forceinline__ double tile_log1p_scaled(double y, double scale, float, const double* logt) {
+    const double x = y * scale;
+    return tile_log1p_core(x, 1.0f + (float)x, logt);
+}
+// Anything outside the fast range (negative, NaN, huge) takes the library function, as the reference would.  Kept out of
+// line: inlined into every gather loop it costs registers on the path that matters.
+__device__ __attribute__((noinline)) double tile_log1p_slow(double x) { return log1p(x); }
+__device__ __forceinline__ double tile_log1p(double x, const double* logt) {
+    if (__builtin_expect(!(x >= 0.0) || !(x < 32000.0), 0)) return tile_log1p_slow(x);
+    return tile_log1p_fast(x, logt);
 }
 
 template <typename T> struct TileVec;
@@ -80,12 +93,27 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_base) 
                                      (void __attribute__((address_space(3)))*)lds_base, 16, 0, 0);
 }
 
+// scale of one row for the log modes
+template <int MODE> __device__ __forceinline__ double tile_row_scale(double sum) {
+    if (MODE == FDX_PRE_LOG_CPM) return (1.0 / (sum + 1e-10)) * 1e4;          // y / (rowsum + 1e-10) * 1e4   (deconv.py:190)
+    if (sum == 0.0) sum = 1.0;                                               // lib_size[lib_size == 0] = 1  (deconv.py:183-185)
+    return 1e4 / sum;
+}
+
+// group lengths are stored 8 to a 64-bit word: JW rounded up
+__host__ __device__ constexpr int JW_PAD(int jw) { return (jw + 7) & ~7; }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the LDS-DMA
 // pieces of the next block, which are meant to stay in flight across the reduction at the end of a tile.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename T, int MODE, int NW, int JW, int TT>
-__global__ __launch_bounds__(NW * 64, NW / 4) void tile_sketch_kernel(
+// Waves of a workgroup: NWC consumers (they own the bucket slots: gather, MFMA, reduction) and NWL loaders (they only
+// stage: a wave that issues vector-memory instructions sits at the issue port while the memory pipeline takes a CU's
+// ~50 KB block over thousands of cycles, so staging from the consumers stalls them).  NWL = 0: the consumers stage
+// themselves - better for the log modes, where the gather is bound by the vector ALU and every wave is needed for it.
+// JW: groups per consumer wave, TT: 16-type tiles.
+template <typename T, int MODE, int NWC, int NWL, int JW, int TT>
+__global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch_kernel(
     const TileArgs a, const T* __restrict__ Yp, const int* __restrict__ row_map, const double* __restrict__ Xs,
     double* __restrict__ H, double* __restrict__ row_sumsq, const double* __restrict__ w_tab,
     const unsigned short* __restrict__ off_tab, const unsigned char* __restrict__ len_tab,
@@ -93,8 +121,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tile_sketch_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename TileVec<T>::type V;
     constexpr int PER = 16 / sizeof(T);
-    constexpr int NT = NW * 64;
-    constexpr int RPW = TILE_ROWS / NW > 0 ? TILE_ROWS / NW : 1;   // rows of the next tile a wave sums (log modes)
+    constexpr int NT = (NWC + NWL) * 64;
+    constexpr int NWS = NWL > 0 ? NWL : NWC;                                // waves that stage
+    constexpr int RPL = (TILE_ROWS + NWS - 1) / NWS;                        // rows a staging wave handles
+    constexpr int NR = NWC > 8 ? NWC / 2 : NWC;                             // partial tiles that reach the final sum
+    constexpr bool PAIR = NWC > 8;                                         // wave w + NR hands its tile to wave w first
+    static_assert(!PAIR || NWC % 2 == 0, "paired reduction needs an even number of consumer waves");
+    constexpr int TS = TT * 4 * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -102,15 +135,148 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tile_sketch_kernel(
     const int NEp = (a.NE + 7) & ~7;
     double* w_l = reinterpret_cast<double*>(smem + 2 * (size_t)stage_bytes);
     unsigned short* off_l = reinterpret_cast<unsigned short*>(w_l + NEp);
-    double* scales = reinterpret_cast<double*>(off_l + NEp);               // [2][16]
-    double* logt = scales + 2 * TILE_ROWS;                                 // [LOG_TAB_N] (log modes)
+    double* scales = reinterpret_cast<double*>(off_l + NEp);               // [2][16] scale of a row (log modes)
+    int* rowok = reinterpret_cast<int*>(scales + 2 * TILE_ROWS);           // [2][16] every log argument of the row in the fast range
+    double* logt = reinterpret_cast<double*>(rowok + 2 * TILE_ROWS);       // [LOG_TAB_N] (log modes)
     for (int i = tid; i < a.NE; i += NT) {
         w_l[i] = w_tab[i];
         off_l[i] = off_tab[i];
     }
     if (MODE != FDX_PRE_RAW)
         for (int i = tid; i < LOG_TAB_N; i += NT) logt[i] = log_tab[i];
-    // this wave's slice of X_sketch as MFMA A operands: A[m = type r][k = q] = X_sketch[type, bucket of slot (w, j, q)]
+    const long long n_tiles = (a.n + TILE_ROWS - 1) / TILE_ROWS;
+    long long tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+
+    // ---- staging (loader waves, or every wave when NWL = 0): wave lw stages rows lw, lw + NWS, ...
+    const int lw = NWL > 0 ? wave - NWC : wave;
+    auto load_rows = [&](long long t, const T* (&rp)[RPL]) {                // row addresses by scalar loads
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            const int rr = lw + NWS * k;
+            const long long sp = t * TILE_ROWS + rr;
+            rp[k] = nullptr;
+            if (rr < TILE_ROWS && t < n_tiles && sp < a.n) {
+                const long long row = row_map ? (long long)row_map[sp] : sp;
+                rp[k] = Yp + (size_t)row * (size_t)a.ldy;
+            }
+        }
+    };
+    auto issue_stage = [&](const T* const (&rp)[RPL], int c, int buf) {
+        const int gene0 = c * a.GB;
+        const int bytes = (min(a.GB, a.G - gene0)) * (int)sizeof(T);
+        unsigned char* base = smem + (size_t)buf * stage_bytes;
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            if (!rp[k]) continue;                                           // row past the end: stale LDS, never stored
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(rp[k] + gene0) + lane * 16;
+            unsigned char* dst = base + (lw + NWS * k) * a.RS;
+            for (int o = 0; o < bytes; o += 1024)
+                if (o + lane * 16 < bytes) dma16(src + o, dst + o);
+        }
+    };
+    // Row sums (log modes) in the scatter kernels' order (per-lane partials over ascending vectors, butterfly over the
+    // wave), so every sketch path sees the same bits; with them the row's extremes, which tell whether every log argument
+    // of the row lies in the fast range.  Two rows at a time: the loads of both (up to 16 KB) are in flight before the
+    // first is summed.
+    const int nvec = a.G / PER;                                             // launch requires G % PER == 0
+    constexpr bool TWO = RPL > 1;                                           // a wave with one row has no second one to overlap
+    auto scale_two = [&](const T* r0, const T* r1_, double* out_scale, int* out_ok, int i0, int i1) {
+        const T* r1 = TWO ? r1_ : nullptr;
+        const V* src0 = reinterpret_cast<const V*>(r0);
+        const V* src1 = reinterpret_cast<const V*>(r1);
+        double p0 = 0.0, p1 = 0.0;
+        T mx0 = (T)0, mx1 = (T)0, mn0 = (T)0, mn1 = (T)0;
+        for (int v0 = 0; v0 < nvec; v0 += 512) {
+            V x0[8], x1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = v0 + u * 64 + lane;
+                if (v < nvec) {
+                    if (r0) x0[u] = src0[v];
+                    if (TWO && r1) x1[u] = src1[v];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = v0 + u * 64 + lane;
+                if (v < nvec) {
+#pragma unroll
+                    for (int e = 0; e < PER; ++e) {
+                        if (r0) { p0 += (double)x0[u][e]; mx0 = x0[u][e] > mx0 ? x0[u][e] : mx0; mn0 = x0[u][e] < mn0 ? x0[u][e] : mn0; }
+                        if (TWO && r1) { p1 += (double)x1[u][e]; mx1 = x1[u][e] > mx1 ? x1[u][e] : mx1; mn1 = x1[u][e] < mn1 ? x1[u][e] : mn1; }
+                    }
+                }
+            }
+        }
+        // NaN / Inf anywhere in the row makes the sum, hence the scale, NaN or 0 * Inf below: the test fails
+        const double s0 = tile_row_scale<MODE>(wave_sum(p0));
+        const bool ok0 = wave_max((double)mx0) * s0 < 32000.0 && -wave_max(-(double)mn0) >= 0.0;
+        if (lane == 0 && r0) { out_scale[i0] = s0; out_ok[i0] = ok0 ? 1 : 0; }
+        if (TWO && r1) {
+            const double s1 = tile_row_scale<MODE>(wave_sum(p1));
+            const bool ok1 = wave_max((double)mx1) * s1 < 32000.0 && -wave_max(-(double)mn1) >= 0.0;
+            if (lane == 0) { out_scale[i1] = s1; out_ok[i1] = ok1 ? 1 : 0; }
+        }
+    };
+    // rows k = first, first + step, ... < RPL of `rp`, two at a time
+    auto scale_rows = [&](const T* const (&rp)[RPL], int first, int step, int par) {
+        for (int k = first; k < RPL; k += 2 * step) {
+            const T* r0 = nullptr;
+            const T* r1 = nullptr;
+#pragma unroll
+            for (int kk = 0; kk < RPL; ++kk) {                              // static indexing of rp[]
+                if (kk == k) r0 = rp[kk];
+                if (kk == k + step) r1 = rp[kk];
+            }
+            if (!r0 && !r1) continue;
+            scale_two(r0, r1, scales + par * TILE_ROWS, rowok + par * TILE_ROWS, lw + NWS * k, lw + NWS * (k + step));
+        }
+    };
+    const T* rowp[RPL];
+    const T* rown[RPL];
+    bool has_next = false;
+    // one block step of a staging wave: block c of the current tile has landed; stage the next block, sum a share of the
+    // next tile's rows
+    auto stage_step = [&](int c, int buf, int par) {
+        if (c + 1 < a.NBLK) issue_stage(rowp, c + 1, buf ^ 1);
+        else if (has_next) issue_stage(rown, 0, buf ^ 1);
+    };
+    auto sums_step = [&](int c, int par) {
+        if (MODE != FDX_PRE_RAW && has_next) scale_rows(rown, c, a.NBLK, par ^ 1);
+    };
+    if (NWL == 0 || wave >= NWC) {
+        load_rows(tile, rowp);
+        issue_stage(rowp, 0, 0);
+        if (MODE != FDX_PRE_RAW) scale_rows(rowp, 0, 1, 0);
+    }
+
+    if (NWL > 0 && wave >= NWC) {
+        // ================================================================================================ loader wave
+        int buf = 0, par = 0;
+        for (; tile < n_tiles; tile += gridDim.x) {
+            has_next = tile + gridDim.x < n_tiles;
+            load_rows(tile + gridDim.x, rown);
+            for (int c = 0; c < a.NBLK; ++c) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);                          // vmcnt(0): this wave's pieces of block c have landed
+                lds_barrier();                                              // everybody's have; the other buffer is free
+                stage_step(c, buf, par);
+                sums_step(c, par);
+                buf ^= 1;
+            }
+            par ^= 1;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) rowp[k] = rown[k];
+            lds_barrier();                                                  // the consumers' reduction
+            if (PAIR) lds_barrier();
+            lds_barrier();
+        }
+        return;
+    }
+
+    // ==================================================================================================== consumer wave
+    // this wave's slice of X_sketch as MFMA A operands: A[m = type r][k = q] = X_sketch[type, bucket of slot (w, j, q)];
+    // unconditional loads (index clamped, value selected) and one wait, so nothing of this is pending in the tile loop
     double av[JW][TT];
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
@@ -118,164 +284,125 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tile_sketch_kernel(
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const int type = t * 16 + r;
-            av[j][t] = (b >= 0 && type < a.K) ? Xs[(size_t)type * a.d + b] : 0.0;
+            const bool ok = b >= 0 && type < a.K;
+            const double v = Xs[(size_t)(ok ? type : 0) * a.d + (ok ? b : 0)];
+            av[j][t] = ok ? v : 0.0;
         }
     }
-    const long long n_tiles = (a.n + TILE_ROWS - 1) / TILE_ROWS;
-
-    // The wave stages (and, for the log modes, sums) the rows rr = wave + NW * k of a tile, k < RPW.  Their addresses are
-    // fetched with scalar loads one tile ahead, so no staging instruction waits for a row index.
-    auto load_rows = [&](long long tile, const T* (&rp)[RPW]) {
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            const long long sp = tile * TILE_ROWS + wave + NW * k;
-            rp[k] = nullptr;
-            if (wave + NW * k < TILE_ROWS && sp < a.n) {
-                const long long row = row_map ? (long long)row_map[sp] : sp;
-                rp[k] = Yp + (size_t)row * (size_t)a.ldy;
-            }
-        }
-    };
-    auto issue_stage = [&](const T* const (&rp)[RPW], int c, int buf) {
-        const int gene0 = c * a.GB;
-        const int bytes = (min(a.GB, a.G - gene0)) * (int)sizeof(T);
-        unsigned char* base = smem + (size_t)buf * stage_bytes;
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            if (!rp[k]) continue;                                            // row past the end: stale LDS, never stored
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(rp[k] + gene0) + lane * 16;
-            unsigned char* dst = base + (wave + NW * k) * a.RS;
-            for (int o = 0; o < bytes; o += 1024)
-                if (o + lane * 16 < bytes) dma16(src + o, dst + o);
-        }
-    };
-    // scale of one row for the log modes: sum in the scatter kernels' order (per-lane partials over ascending vectors,
-    // butterfly over the wave), so every sketch path sees the same bits
-    auto row_scale = [&](double sum) -> double {
-        if (MODE == FDX_PRE_LOG_CPM) return (1.0 / (sum + 1e-10)) * 1e4;      // y / (rowsum + 1e-10) * 1e4   (deconv.py:190)
-        if (sum == 0.0) sum = 1.0;                                           // lib_size[lib_size == 0] = 1  (deconv.py:183-185)
-        return 1e4 / sum;
-    };
-    const int nvec = a.G / PER;                                              // launch requires G % PER == 0
-    auto sum_row = [&](const T* rowp) -> double {
-        const V* src = reinterpret_cast<const V*>(rowp);
-        double part = 0.0;
-        for (int v0 = 0; v0 < nvec; v0 += 512) {
-            V x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int v = v0 + u * 64 + lane;
-                if (v < nvec) x[u] = src[v];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int v = v0 + u * 64 + lane;
-                if (v < nvec) {
-#pragma unroll
-                    for (int e = 0; e < PER; ++e) part += (double)x[u][e];
-                }
-            }
-        }
-        return wave_sum(part);
-    };
-
-    long long tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    const T* rowp[RPW];
-    const T* rown[RPW];
-    load_rows(tile, rowp);
-    issue_stage(rowp, 0, 0);
-    if (MODE != FDX_PRE_RAW) {
-#pragma unroll
-        for (int k = 0; k < RPW; ++k)
-            if (rowp[k]) {
-                const double s = row_scale(sum_row(rowp[k]));
-                if (lane == 0) scales[wave + NW * k] = s;
-            }
-    }
+    if (NWL > 0) __builtin_amdgcn_s_waitcnt(0x0f70);
     int buf = 0, par = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
-        const long long next_tile = tile + gridDim.x;
-        const bool has_next = next_tile < n_tiles;
-        load_rows(has_next ? next_tile : tile, rown);
+        if (NWL == 0) {
+            has_next = tile + gridDim.x < n_tiles;
+            load_rows(tile + gridDim.x, rown);
+        }
         double acc[JW];
 #pragma unroll
         for (int j = 0; j < JW; ++j) acc[j] = 0.0;
-        double scale = 1.0;
-        for (int c = 0; c < a.NBLK; ++c) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);                              // vmcnt(0): this wave's pieces have landed
-            __syncthreads();                                                 // everybody's have; the other buffer is free
-            if (c + 1 < a.NBLK) issue_stage(rowp, c + 1, buf ^ 1);
-            else if (has_next) issue_stage(rown, 0, buf ^ 1);
-            if (MODE != FDX_PRE_RAW && c == 0) scale = scales[par * TILE_ROWS + r];
-            // ---- gather this block's genes: software pipeline over the flat entry stream - weight and value of the
-            // current step in registers, the offset of the step after next already fetched, so a step costs one LDS
-            // round trip, not two
-            const unsigned char* rowb = smem + (size_t)buf * stage_bytes + r * a.RS;
-            int p = ent_base[wave * (a.NBLK + 1) + c] + q;
-            const unsigned long long* lens = reinterpret_cast<const unsigned long long*>(len_tab + ((size_t)wave * a.NBLK + c) * JW);
-            double wv = w_l[p];
-            T yv = *reinterpret_cast<const T*>(rowb + (size_t)off_l[p] * sizeof(T));
-            unsigned offn = off_l[p + 4];
-#pragma unroll
-            for (int j = 0; j < JW; ++j) {
-                const int len = (int)((lens[j >> 3] >> ((j & 7) * 8)) & 0xffULL);
-                for (int t = 0; t < len; ++t) {
-                    p += 4;
-                    const double wn = w_l[p];
-                    const T yn = *reinterpret_cast<const T*>(rowb + (size_t)offn * sizeof(T));
-                    offn = off_l[p + 4];
-                    double y = (double)yv;
-                    if (MODE != FDX_PRE_RAW) y = tile_log1p(y * scale, logt);
-                    acc[j] = fma(wv, y, acc[j]);
-                    wv = wn;
-                    yv = yn;
-                }
-            }
-            // ---- log modes: row sums of the next tile (this block's share of the wave's rows)
-            if (MODE != FDX_PRE_RAW && has_next) {
-#pragma unroll
-                for (int k = 0; k < RPW; ++k) {
-                    if (k % a.NBLK != c || !rown[k]) continue;
-                    const double s = row_scale(sum_row(rown[k]));
-                    if (lane == 0) scales[(par ^ 1) * TILE_ROWS + wave + NW * k] = s;
-                }
-            }
-            buf ^= 1;
-        }
-        par ^= 1;
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) rowp[k] = rown[k];
-        // ---- contraction: D[type, spot] += sum_q A[type, q] * B[q, spot]
         double4_t accm[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) accm[t] = double4_t{0.0, 0.0, 0.0, 0.0};
         double sq = 0.0;
+        double scale = 1.0;
+        float scale_f = 1.0f;
+        bool fast = true;
+        // One column block: software pipeline over the flat entry stream - weight and value of the current step in
+        // registers, the offset of the step after next already fetched, so a step costs one LDS round trip, not two.
+        // LAST: the group's sum is final when its loop ends, and its MFMAs go out at once - they run in the matrix pipe
+        // beside the gather of the following groups.  (A run-time test per group instead of the template parameter would
+        // make the accumulators merge points and serialise the MFMAs behind register copies.)  FAST: every log argument
+        // of the tile is known to be in the fast range (rowok), no per-element test.
+        auto consume = [&](int c, auto last_tag, auto fast_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const unsigned char* rowb = smem + (size_t)buf * stage_bytes + r * a.RS;
+            int p = ent_base[wave * (a.NBLK + 1) + c] + q;
+            const unsigned long long* lens = reinterpret_cast<const unsigned long long*>(len_tab + ((size_t)wave * a.NBLK + c) * JW_PAD(JW));
+            double wv = w_l[p];
+            T yv = *reinterpret_cast<const T*>(rowb + (size_t)off_l[p] * sizeof(T));
+            unsigned offn = off_l[p + 4];
+            auto f = [&](T yy) -> double {
+                if (MODE == FDX_PRE_RAW) return (double)yy;
+                if (FAST) return tile_log1p_scaled(yy, scale, scale_f, logt);
+                return tile_log1p((double)yy * scale, logt);
+            };
 #pragma unroll
-        for (int j = 0; j < JW; ++j) {
-            if (j < a.jw_used) {
+            for (int j = 0; j < JW; ++j) {
+                const int len = (int)((lens[j >> 3] >> ((j & 7) * 8)) & 0xffULL);
+                int t = 0;
+                for (; t + 2 <= len; t += 2) {                            // two steps per trip: the register sets swap roles
+                    const double wb = w_l[p + 4];
+                    const T yb = *reinterpret_cast<const T*>(rowb + (size_t)offn * sizeof(T));
+                    const unsigned offb = off_l[p + 8];
+                    acc[j] = fma(wv, f(yv), acc[j]);
+                    p += 8;
+                    wv = w_l[p];
+                    yv = *reinterpret_cast<const T*>(rowb + (size_t)offb * sizeof(T));
+                    offn = off_l[p + 4];
+                    acc[j] = fma(wb, f(yb), acc[j]);
+                }
+                if (t < len) {
+                    p += 4;
+                    const double wn = w_l[p];
+                    const T yn = *reinterpret_cast<const T*>(rowb + (size_t)offn * sizeof(T));
+                    offn = off_l[p + 4];
+                    acc[j] = fma(wv, f(yv), acc[j]);
+                    wv = wn;
+                    yv = yn;
+                }
+                if (LAST) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][t], acc[j], accm[t], 0, 0, 0);
+                    sq = fma(acc[j], acc[j], sq);
+                }
+            }
+        };
+        auto block = [&](int c, auto last_tag) {
+            if (NWL == 0) __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): this wave's pieces of block c have landed
+            lds_barrier();                                                  // everybody's have (the loaders waited for theirs)
+            if (NWL == 0) stage_step(c, buf, par);
+            if (MODE != FDX_PRE_RAW && c == 0) {
+                scale = scales[par * TILE_ROWS + r];
+                scale_f = (float)scale;
+                fast = __all(rowok[par * TILE_ROWS + r] != 0);
+            }
+            if (MODE == FDX_PRE_RAW || fast) consume(c, last_tag, std::true_type{});
+            else consume(c, last_tag, std::false_type{});
+            if (NWL == 0) sums_step(c, par);
+            buf ^= 1;
+        };
+        // raw: MFMAs interleaved with the last block's gather.  Log modes: afterwards - the gather is bound by the vector ALU
+        // there, and the 16 accumulator registers held through it would spill.
+        constexpr bool INTERLEAVE = MODE == FDX_PRE_RAW;
+        for (int c = 0; c + 1 < a.NBLK; ++c) block(c, std::false_type{});
+        block(a.NBLK - 1, std::integral_constant<bool, INTERLEAVE>{});
+        if (!INTERLEAVE) {
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t) accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][t], acc[j], accm[t], 0, 0, 0);
                 sq = fma(acc[j], acc[j], sq);
             }
         }
-        // ---- the NW partial tiles are added in a fixed order through LDS (the buffer of the block just consumed).  With
-        // 16 waves the upper half first hands its tiles to the lower half (wave w + 8 -> wave w), which halves the footprint.
-        constexpr int NR = NW == 16 ? 8 : NW;                                // partial tiles that reach the final sum
-        constexpr int TS = TT * 4 * 64;
+        par ^= 1;
+        if (NWL == 0) {
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) rowp[k] = rown[k];
+        }
+        // ---- the partial tiles are added in a fixed order through LDS (the buffer of the block just consumed) and stored
         double* red = reinterpret_cast<double*>(smem + (size_t)(buf ^ 1) * stage_bytes);   // [NR][TS] + [NR][64]
         double* red_sq = red + (size_t)NR * TS;
-        lds_barrier();                                                       // the last block's buffer is free
-        if (NW == 16) {
-            if (wave >= 8) {
+        lds_barrier();                                                      // the last block's buffer is free
+        if (PAIR) {
+            if (wave >= NR) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) red[(size_t)(wave - 8) * TS + (t * 4 + rr) * 64 + lane] = accm[t][rr];
-                red_sq[(wave - 8) * 64 + lane] = sq;
+                    for (int rr = 0; rr < 4; ++rr) red[(size_t)(wave - NR) * TS + (t * 4 + rr) * 64 + lane] = accm[t][rr];
+                red_sq[(wave - NR) * 64 + lane] = sq;
             }
             lds_barrier();
-            if (wave < 8) {
+            if (wave < NR) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
 #pragma unroll
@@ -291,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tile_sketch_kernel(
         }
         lds_barrier();
         const long long s0 = tile * TILE_ROWS;
-        for (int o = tid; o < TS; o += NT) {
+        for (int o = tid; o < TS; o += NWC * 64) {
             double sum = 0.0;
 #pragma unroll
             for (int v = 0; v < NR; ++v) sum += red[(size_t)v * TS + o];                  // fixed order: deterministic
@@ -307,7 +434,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tile_sketch_kernel(
                 for (int qq = 0; qq < 4; ++qq) sum += red_sq[v * 64 + qq * 16 + tid];
             row_sumsq[s0 + tid] = sum;
         }
-        // the top-of-block barrier of the next tile orders these reads before the next DMA into this buffer
+        // the first barrier of the next tile orders these reads before the next DMA into this buffer
     }
 }
 
@@ -316,7 +443,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tile_sketch_kernel(
 struct TilePlanDevice {
     TilePlanHost h;
     DevBuf w, off, len, ent_base, slot_bucket;
-    int NW = 0, JW = 0, RS = 0;
+    int NWC = 0, NWL = 0, JW = 0, RS = 0;
     size_t lds = 0;
 };
 
@@ -346,14 +473,22 @@ static const double* log_table_dev(hipStream_t st) {   // -log of every 8-bit re
     return tabs[dev];
 }
 
-static int tile_waves() {   // waves per workgroup: 16 unless FDX_TILE_WAVES=8
-    const char* e = getenv("FDX_TILE_WAVES");
-    return (e && atoi(e) == 8) ? 8 : 16;
+// Wave split of a workgroup: consumers x groups per consumer + loaders.  Raw: 12 + 4 (measured at 1M x 2000 x 30: 1.92 ms
+// against 2.05 ms self-staged and 2.25 ms with 14 + 2).  Log modes: 16 self-staging waves - the table-driven log1p makes
+// the gather ALU-bound and idle loader waves cost more than they save (4.3 ms against 6.4 ms with 12 + 4).
+// FDX_TILE_CFG=12 / 16 / 8 forces 12 + 4 / 16 + 0 / 8 + 2 (tuning experiments).
+struct TileCfg { int NWC, NWL, JW; };
+static TileCfg tile_cfg(int mode) {
+    const char* e = getenv("FDX_TILE_CFG");
+    const int v = e ? atoi(e) : (mode == FDX_PRE_RAW ? 12 : 16);
+    if (v == 16) return TileCfg{16, 0, 8};
+    if (v == 8) return TileCfg{8, 2, 16};
+    return TileCfg{12, 4, 11};
 }
 
 static size_t tile_lds_bytes(int RS, int NE, int mode) {
     const size_t NEp = ((size_t)NE + 7) & ~(size_t)7;
-    return 2 * (size_t)TILE_ROWS * RS + NEp * 10 + 2 * TILE_ROWS * 8 + (mode != FDX_PRE_RAW ? (size_t)LOG_TAB_N * 8 : 0);
+    return 2 * (size_t)TILE_ROWS * RS + NEp * 10 + 2 * TILE_ROWS * (8 + 4) + (mode != FDX_PRE_RAW ? (size_t)LOG_TAB_N * 8 : 0);
 }
 
 // Builds (once per SketchPlan and input type) the schedule for the largest column block that fits the LDS.
@@ -363,31 +498,28 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     if (sp.tile_tried[key]) return sp.tile[key].get();
     sp.tile_tried[key] = true;
     const bool dbg = getenv("FDX_DEBUG") != nullptr;
-    if (dbg) std::fprintf(stderr, "[fdx] tile plan: G=%d d=%d K=%d scatter_ok=%d host=%zu\n", sp.G, sp.d, K, (int)sp.scatter_ok, sp.host_bucket.size());
     if (!sp.scatter_ok || sp.host_bucket.empty()) return nullptr;
-    const int NW = tile_waves();
+    const TileCfg cfg = tile_cfg(mode);
     const int TT = (K + 15) / 16;
-    const int JW = NW == 16 ? 8 : 16;
-    if (sp.d > 4 * NW * JW || TT > 2 || TT < 1) return nullptr;
-    const size_t red_bytes = (size_t)(NW == 16 ? 8 : NW) * (TT * 4 * 64 + 64) * 8;   // the kernel's reduction area
+    if (sp.d > 4 * cfg.NWC * cfg.JW || TT > 2 || TT < 1) return nullptr;
+    const size_t red_bytes = (size_t)(cfg.NWC > 8 ? cfg.NWC / 2 : cfg.NWC) * (TT * 4 * 64 + 64) * 8;   // the kernel's reduction area
     const int unit = 1024 / sz;                                             // genes per 1 KB piece
-    const int gb_max = (int)round_up(sp.G, unit);
     std::unique_ptr<TilePlanDevice> best;
-    for (int GB = gb_max; GB >= unit; GB -= unit) {
+    for (int GB = (int)round_up(sp.G, unit); GB >= unit; GB -= unit) {
         const int RS = GB * sz + TILE_ROW_PAD;
         if ((size_t)TILE_ROWS * RS < red_bytes) break;
         // cheap bound before building: the tables hold at least G entries
         if (tile_lds_bytes(RS, sp.G, mode) > 160 * 1024) continue;
         auto cand = std::make_unique<TilePlanDevice>();
-        if (!build_tile_plan(sp.host_bucket.data(), sp.host_w.data(), sp.G, sp.d, NW, JW, GB, &cand->h)) return nullptr;
-        cand->NW = NW; cand->JW = JW; cand->RS = RS;
+        if (!build_tile_plan(sp.host_bucket.data(), sp.host_w.data(), sp.G, sp.d, cfg.NWC, cfg.JW, GB, &cand->h)) return nullptr;
+        cand->NWC = cfg.NWC; cand->NWL = cfg.NWL; cand->JW = cfg.JW; cand->RS = RS;
         cand->lds = tile_lds_bytes(RS, cand->h.NE, mode);
-        if (dbg) std::fprintf(stderr, "[fdx] tile plan: GB=%d blocks=%d NE=%d steps=%d lds=%zu\n", GB, cand->h.NBLK, cand->h.NE, cand->h.steps, cand->lds);
+        if (dbg) std::fprintf(stderr, "[fdx] tile plan: G=%d d=%d waves=%d+%d GB=%d blocks=%d NE=%d steps=%d lds=%zu\n", sp.G, sp.d, cfg.NWC,
+                              cfg.NWL, GB, cand->h.NBLK, cand->h.NE, cand->h.steps, cand->lds);
         if (cand->lds > 160 * 1024) continue;
         best = std::move(cand);
         break;
     }
-    if (dbg) std::fprintf(stderr, "[fdx] tile plan: %s\n", best ? "ok" : "no block size fits");
     if (!best) return nullptr;
     TilePlanDevice& t = *best;
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
@@ -395,8 +527,13 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
         FDX_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
         return 0;
     };
-    std::vector<unsigned char> len_pad(t.h.len);
-    len_pad.resize(t.h.len.size() + 16, 0);                                 // the kernel reads lengths 8 at a time
+    // group lengths, 8 to a 64-bit word: rows of JW_PAD(JW) bytes
+    const int jp = JW_PAD(t.JW);
+    std::vector<unsigned char> len_pad((size_t)t.NWC * t.h.NBLK * jp + 16, 0);
+    for (int wv = 0; wv < t.NWC; ++wv)
+        for (int c = 0; c < t.h.NBLK; ++c)
+            for (int j = 0; j < t.JW; ++j)
+                len_pad[((size_t)wv * t.h.NBLK + c) * jp + j] = t.h.len[((size_t)wv * t.h.NBLK + c) * t.JW + j];
     if (up(t.w, t.h.w.data(), t.h.w.size() * 8) || up(t.off, t.h.off.data(), t.h.off.size() * 2) ||
         up(t.len, len_pad.data(), len_pad.size()) || up(t.ent_base, t.h.ent_base.data(), t.h.ent_base.size() * 4) ||
         up(t.slot_bucket, t.h.slot_bucket.data(), t.h.slot_bucket.size() * 4))
@@ -433,28 +570,30 @@ struct TileLaunch {
     const double* log_tab;
 };
 
-template <typename T, int MODE, int NW, int JW>
+template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hipStream_t st) {
-    const void* kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, NW, JW, 1> : (const void*)tile_sketch_kernel<T, MODE, NW, JW, 2>;
+    const void* kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 1>
+                               : (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 2>;
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
                     (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab};
-    FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3(NW * 64), args, lds, st));
+    FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3((NWC + NWL) * 64), args, lds, st));
     return 0;
 }
 
 template <typename T, int MODE>
-static int launch_tile_nw(const TileLaunch& L, int NW, int TT, size_t lds, int grid, hipStream_t st) {
-    if (NW == 16) return launch_tile_tt<T, MODE, 16, 8>(L, TT, lds, grid, st);
-    return launch_tile_tt<T, MODE, 8, 16>(L, TT, lds, grid, st);
+static int launch_tile_cfg(const TileLaunch& L, int NWC, int TT, size_t lds, int grid, hipStream_t st) {
+    if (NWC == 16) return launch_tile_tt<T, MODE, 16, 0, 8>(L, TT, lds, grid, st);
+    if (NWC == 8) return launch_tile_tt<T, MODE, 8, 2, 16>(L, TT, lds, grid, st);
+    return launch_tile_tt<T, MODE, 12, 4, 11>(L, TT, lds, grid, st);
 }
 
 template <typename T>
-static int launch_tile_mode(const TileLaunch& L, int mode, int NW, int TT, size_t lds, int grid, hipStream_t st) {
+static int launch_tile_mode(const TileLaunch& L, int mode, int NWC, int TT, size_t lds, int grid, hipStream_t st) {
     switch (mode) {
-        case FDX_PRE_RAW: return launch_tile_nw<T, FDX_PRE_RAW>(L, NW, TT, lds, grid, st);
-        case FDX_PRE_LOG_CPM: return launch_tile_nw<T, FDX_PRE_LOG_CPM>(L, NW, TT, lds, grid, st);
-        case FDX_PRE_LOG_CPM_SPARSE: return launch_tile_nw<T, FDX_PRE_LOG_CPM_SPARSE>(L, NW, TT, lds, grid, st);
+        case FDX_PRE_RAW: return launch_tile_cfg<T, FDX_PRE_RAW>(L, NWC, TT, lds, grid, st);
+        case FDX_PRE_LOG_CPM: return launch_tile_cfg<T, FDX_PRE_LOG_CPM>(L, NWC, TT, lds, grid, st);
+        case FDX_PRE_LOG_CPM_SPARSE: return launch_tile_cfg<T, FDX_PRE_LOG_CPM_SPARSE>(L, NWC, TT, lds, grid, st);
         default: return fail(FDX_ERR_INVALID, "tile sketch: unknown preprocess mode");
     }
 }
@@ -482,8 +621,8 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
     const int grid = (int)std::min<long long>(n_tiles, 256);
     const int TT = (K + 15) / 16;
-    if (dtype == FDX_F32) return launch_tile_mode<float>(L, mode, t->NW, TT, t->lds, grid, st);
-    return launch_tile_mode<double>(L, mode, t->NW, TT, t->lds, grid, st);
+    if (dtype == FDX_F32) return launch_tile_mode<float>(L, mode, t->NWC, TT, t->lds, grid, st);
+    return launch_tile_mode<double>(L, mode, t->NWC, TT, t->lds, grid, st);
 }
 
 }  // namespace fdx
