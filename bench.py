@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: spots/sec to convergence of FlashDeconv.fit_transform on synthetic N x G x K data.
 
-    python bench.py --gpus 1 --steps K --warmup W        (N > 1 is launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
+
+One rank per GPU.  Under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is one of
+the N ranks; started from a bare shell with --gpus N > 1 it spawns the N ranks itself (fresh child processes, before
+anything has touched a GPU) and relays rank 0's line.
 
 A "step" is one complete fit (graph build -> preprocess + CountSketch -> H -> BCD solve to the reference's stopping rule
 -> proportions) from inputs resident in HBM to proportions_ resident in HBM.  Workload = BASELINE.json configs[2]:
 1M spots x 2000 genes x 30 types, sketch_dim 512, k_neighbors 6, Gaussian/raw family (SURVEY.md §8d family A), Y stored
-float32, all arithmetic float64.  With --gpus N the same 1M-spot job is sharded over N ranks (strong scaling).
+float32, all arithmetic float64.  --scaling strong (default, BASELINE.json configs[3]): the same 1M-spot job sharded over
+the N ranks.  --scaling weak: N x 1M spots, 1M per rank.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      - dominant kernel of the step vs the HBM roofline (algorithmic bytes / hipEvent-measured duration)
@@ -25,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+METRIC = "spots/sec to convergence (1M x 2000 x 30)"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -39,6 +45,8 @@ def parse():
     ap.add_argument("--sketch-dim", type=int, default=512)
     ap.add_argument("--family", choices=["gaussian", "counts", "both", "sparse", "all"], default="all")
     ap.add_argument("--sparse-genes", type=int, default=20000, help="columns of the CSR family's matrix (HVG picks ~--genes of them)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the --spots job sharded over N ranks (configs[3]); weak = N x --spots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     return ap.parse_args()
@@ -132,17 +140,29 @@ def alg_bytes(n, G, K, s_y, nnz, n_slices_width_rows, T):
     return sketch, sweep
 
 
+TRAFFIC_PROFILE = "profiles/r02_traffic.json"
+
+
 def pmc_traffic(kernel, shape):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE of this same command, gfx950 correction applied); None for other workloads."""
+    """HBM bytes per launch of `kernel` from the committed PMC pass (TRAFFIC_PROFILE: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE of this same command on an earlier run of the same build, gfx950 correction applied) - measured then, not
+    in this run; None for other workloads or a kernel the profile does not hold."""
     if shape != (1_000_000, 2000, 30, 512):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            k = json.load(f)["kernels"].get(kernel)
+        with open(os.path.join(ROOT, TRAFFIC_PROFILE)) as f:
+            kernels = json.load(f)["kernels"]
+        k = kernels.get(kernel) or next((v for name, v in kernels.items() if name.startswith(kernel)), None)
         return int(k["hbm_bytes_corrected"]) if k else None
     except (OSError, ValueError, KeyError):
         return None
+
+
+def sketch_kernel_name(mode, K):
+    """Kernel that serves the sketch -> H stage of the bench shapes (csrc/tile_kernels.cpp: tile_cfg)."""
+    cfg = os.environ.get("FDX_TILE_CFG")
+    nwc, nwl, jw = {"12": (12, 4, 11), "16": (16, 0, 8), "8": (8, 2, 16)}.get(cfg, (12, 4, 11) if mode == 0 else (16, 0, 8))
+    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d>" % (mode, nwc, nwl, jw, -(-K // 16))
 
 
 def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
@@ -186,8 +206,34 @@ def cpu_baseline(n_cpu, G, K, d, seed=0):
                       f"{dt:.1f} s wall (numpy/scipy stages single-threaded as in the reference, C/OpenMP BCD sweep on {cores} threads)"}
 
 
+def spawn_ranks(n_ranks):
+    """--gpus N > 1 from a bare shell: start the N ranks as fresh child processes (this process never initialises a GPU),
+    relay their output, exit with the worst return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a.gpus)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -252,7 +298,7 @@ def main():
         else:
             if stage["gram_ms"] == 0.0:                # fused sketch -> H kernel: ONE launch reads all of Y, writes only H
                 bytes_launch, ms_launch = sk_bytes, sk_ms
-                kname = "fdx::sketch_contract_kernel<float, %d, true, 16, %d, %d>" % (0 if fam == "gaussian" else 1, -(-d // 256), -(-K // 16))
+                kname = sketch_kernel_name(0 if fam == "gaussian" else 1, K)
             else:
                 bytes_launch, ms_launch = sk_bytes / n_chunks, sk_ms / n_chunks
                 kname = "fdx::sketch_rows_scatter_kernel<float, %d, true>" % (0 if fam == "gaussian" else 1)
@@ -262,6 +308,7 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, (n, G, K, d)),
+                         "traffic_source": TRAFFIC_PROFILE + " (PMC pass of an earlier run of this build, not this run)",
                          "alg_bytes_per_launch": int(bytes_launch), "ms_per_launch": round(ms_launch, 4)},
             "steps": steps,
         }
@@ -274,9 +321,9 @@ def main():
         return
     r = results[main_fam]
     line = {
-        "metric": "spots/sec to convergence (1M x 2000 x 30)", "value": r["value"], "unit": "spots/s", "n_gpus": 1,
+        "metric": METRIC, "value": r["value"], "unit": "spots/s", "n_gpus": 1,
         "steps": r["steps"], "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n} spots x {G} genes x {K} types, sketch_dim {d}, k_neighbors 6, "
                                f"{'gaussian/raw' if main_fam == 'gaussian' else 'count-like/log_cpm'} family, Y float32 in HBM, "
                                f"tol 1e-4, max_iter 100", "n_iterations": r["n_iterations"], "converged": r["converged"]},

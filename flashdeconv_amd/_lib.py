@@ -109,6 +109,16 @@ SIGNATURES = {
     "fdx_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "fdx_stream_sync": (c_int, [c_void_p]),
     "fdx_sketch": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_i64, p_i32, p_double, c_i32, c_i32, p_double]),
+    "fdx_comm_unique_id": (c_int, [c_void_p]),
+    "fdx_comm_init": (c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p)]),
+    "fdx_local_world_create": (c_int, [c_i32, ctypes.POINTER(c_void_p)]),
+    "fdx_local_world_destroy": (c_int, [c_void_p]),
+    "fdx_comm_init_local": (c_int, [c_void_p, c_i32, ctypes.POINTER(c_void_p)]),
+    "fdx_comm_destroy": (c_int, [c_void_p]),
+    "fdx_comm_info": (c_int, [c_void_p, p_i32, p_i32]),
+    "fdx_comm_allreduce_sum_dev": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
+    "fdx_sharded_solve_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_double, c_double, c_double, c_i32,
+                                      c_void_p, c_void_p, c_i64, ctypes.POINTER(SolveInfo), p_double, p_i32, c_void_p]),
     "fdx_tile_schedule": (c_int, [p_i32, p_double, c_i32, c_i32, c_i32, c_i32, c_i32, p_i32, p_i32, c_void_p, p_i32, p_double,
                                   c_void_p, c_i64]),
     "fdx_column_sums": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_double]),

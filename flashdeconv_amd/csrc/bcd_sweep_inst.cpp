@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
     double* __restrict__ beta_out, const unsigned short* __restrict__ ell_local, const int* __restrict__ slice_off,
     const int* __restrict__ deg, const int* __restrict__ tile_halo, const int* __restrict__ tile_hcnt,
     unsigned long long* __restrict__ stats, double* __restrict__ rel_change, const double lambda, const double rho,
-    const double tol, const int ldh, const int ld_, const int n, const int S, const int it) {
+    const double tol, const int ldh, const int ld_, const int n, const int S, const int it,
+    const int* __restrict__ tile_list) {
+    // tile_list != NULL: the grid covers the listed tiles only (sharded solve: boundary tiles first, interior tiles while
+    // the halo is on the wire); NULL: all tiles, XCD-contiguous remap.
     // OBJ = true turns the same traversal into the objective evaluation (core/solver.py:269-284): no update, no store;
     // `rel_change` then receives the per-block partial sums (cross, quad, spatial, l1) at [4*block + o].
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [KC][S]: 256 own | halo | zero slot
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
         if (blockIdx.x == 0 && tid == 0) rel_change[it - 1] = rc;
         if (rc < tol) return;          // uniform over the whole grid
     }
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = tile_list ? tile_list[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);
     const bool real = (tile * 256 + tid) < n;
     const int i = min(tile * 256 + tid, n - 1);   // lanes past the last spot mirror spot n-1
     const size_t ld = (size_t)ld_;
@@ -284,11 +287,16 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
             if (a.objective)
                 hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
                                    a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it);
-            else
+                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr);
+            else if (a.tile_list) {
+                if (a.n_list > 0)
+                    hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false>), dim3(a.n_list), dim3(256), lds, st, a.H, a.XtX,
+                                       a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, a.tile_list);
+            } else
                 hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
                                    a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it);
+                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr);
             return;
         }
     }

@@ -1,0 +1,474 @@
+// Native spot-sharded BCD solve: the per-iteration loop of the multi-GPU path in C++, on RCCL directly.
+//
+// The reference has no distributed code; what makes sharding legal is that the sweep is Jacobi across spots
+// (flashdeconv/core/solver.py:157-166 reads only the previous iterate), so any partition gives the unsharded bits.
+// Rank r owns one contiguous range of the Morton order plus a read-only halo (fdx_graph_localize).  Per iteration:
+//   1. sweep the BOUNDARY tiles (those holding a row some peer needs),
+//   2. pack their rows per peer (one kernel), send / receive them with grouped ncclSend / ncclRecv on the communication
+//      stream (xGMI is point-to-point: a few hundred KB per peer, no bulk collective), unpack into the halo columns,
+//   3. meanwhile sweep the INTERIOR tiles on the compute stream,
+//   4. ncclAllReduce(max) of the iteration's 128 convergence slots, so the next sweep's on-device stopping test sees the
+//      global statistics and every rank takes the same decision (core/solver.py:395-397, 407-413).
+// RCCL is loaded with dlopen on first use: libfdx.so itself links nothing but the HIP runtime.
+//
+// Transports: RCCL (one process per GPU), and an in-process one (several host threads of one process act as ranks on ONE
+// GPU, device copies through a shared mailbox) that lets the tests run this very loop without N GPUs.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "fdx_graph.h"
+#include "fdx_internal.h"
+#include "fdx_kernels.h"
+#include "solver.h"
+
+using namespace fdx;
+
+namespace {
+
+// ---- RCCL entry points, resolved at run time ------------------------------------------------------------------------
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+const RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return;
+#define FDX_SYM(f) api.f = reinterpret_cast<decltype(api.f)>(dlsym(h, "nccl" #f))
+        FDX_SYM(GetUniqueId); FDX_SYM(CommInitRank); FDX_SYM(CommDestroy); FDX_SYM(GroupStart); FDX_SYM(GroupEnd);
+        FDX_SYM(Send); FDX_SYM(Recv); FDX_SYM(AllReduce); FDX_SYM(GetErrorString);
+#undef FDX_SYM
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv &&
+                 api.AllReduce && api.GetErrorString;
+    });
+    return api.ok ? &api : nullptr;
+}
+
+#define FDX_NCCL(expr)                                                                                       \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != ncclSuccess) return ::fdx::fail(FDX_ERR_HIP, std::string(#expr) + ": " + rccl()->GetErrorString(_r)); \
+    } while (0)
+
+// ---- in-process world (tests): W host threads, one GPU ----------------------------------------------------------------
+struct LocalWorld {
+    int W = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long long generation = 0;
+    std::vector<const void*> ptr;                   // mailbox: one pointer per rank
+    std::vector<std::vector<long long>> off;        // mailbox: per rank, element offsets per destination (W + 1)
+    std::vector<std::vector<unsigned long long>> host;   // mailbox for the reductions
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const long long gen = generation;
+        if (++arrived == W) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
+}  // namespace
+
+struct fdx_local_world {
+    LocalWorld w;
+};
+
+struct fdx_comm {
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;          // RCCL transport
+    LocalWorld* local = nullptr;        // in-process transport
+    hipStream_t side = nullptr;         // communication stream (halo traffic beside the interior sweep)
+    hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+};
+
+namespace {
+
+// ---- halo pack / unpack ---------------------------------------------------------------------------------------------------
+// Send staging: for peer r the (K, cnt_r) block starts at K * send_off[r]; recv staging likewise with recv_off.
+__global__ void halo_pack_kernel(const double* __restrict__ beta, long long ld, int K, const int* __restrict__ send_idx,
+                                 const int* __restrict__ send_off, int world, int total, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    int r = 0;
+    while (r + 1 < world && j >= send_off[r + 1]) ++r;
+    const int base = send_off[r], cnt = send_off[r + 1] - base;
+    const int i = send_idx[j];
+    double* o = out + (size_t)K * base + (j - base);
+    for (int k = 0; k < K; ++k) o[(size_t)k * cnt] = beta[(size_t)k * ld + i];
+}
+
+__global__ void halo_unpack_kernel(double* __restrict__ beta, long long ld, int K, long long n_own, const int* __restrict__ recv_off,
+                                   int world, int total, const double* __restrict__ in) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    int r = 0;
+    while (r + 1 < world && j >= recv_off[r + 1]) ++r;
+    const int base = recv_off[r], cnt = recv_off[r + 1] - base;
+    const double* s = in + (size_t)K * base + (j - base);
+    for (int k = 0; k < K; ++k) beta[(size_t)k * ld + n_own + j] = s[(size_t)k * cnt];
+}
+
+// tiles (256 rows) that hold a row some peer needs, and the others
+int build_tile_lists(const fdx_graph& g, hipStream_t st) {
+    if (g.n_tiles_boundary >= 0) return 0;
+    const int total = g.send_off.empty() ? 0 : g.send_off.back();
+    std::vector<int> idx((size_t)total);
+    if (total) {
+        FDX_HIP(hipMemcpyAsync(idx.data(), g.send_idx.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<char> is_b((size_t)std::max(g.n_tiles, 1), 0);
+    for (int i : idx)
+        if (i >= 0 && i / 256 < g.n_tiles) is_b[(size_t)(i / 256)] = 1;
+    std::vector<int> tb, ti;
+    for (int t = 0; t < g.n_tiles; ++t) (is_b[(size_t)t] ? tb : ti).push_back(t);
+    FDX_TRY(g.tiles_boundary.alloc(std::max<size_t>(tb.size(), 1) * 4));
+    FDX_TRY(g.tiles_interior.alloc(std::max<size_t>(ti.size(), 1) * 4));
+    if (!tb.empty()) FDX_HIP(hipMemcpyAsync(g.tiles_boundary.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, st));
+    if (!ti.empty()) FDX_HIP(hipMemcpyAsync(g.tiles_interior.p, ti.data(), ti.size() * 4, hipMemcpyHostToDevice, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    g.n_tiles_boundary = (int)tb.size();
+    g.n_tiles_interior = (int)ti.size();
+    return 0;
+}
+
+// ---- transports ---------------------------------------------------------------------------------------------------------------
+// send / recv staging blocks per peer, all on stream `st`
+int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, double* recv, const std::vector<int>& recv_off, int K,
+             hipStream_t st) {
+    const int W = c->world;
+    if (c->nccl) {
+        const RcclApi* api = rccl();
+        FDX_NCCL(api->GroupStart());
+        for (int r = 0; r < W; ++r) {
+            const int nr = recv_off[(size_t)r + 1] - recv_off[(size_t)r];
+            if (r != c->rank && nr > 0)
+                FDX_NCCL(api->Recv(recv + (size_t)K * recv_off[(size_t)r], (size_t)K * nr, ncclDouble, r, c->nccl, st));
+        }
+        for (int r = 0; r < W; ++r) {
+            const int ns = send_off[(size_t)r + 1] - send_off[(size_t)r];
+            if (r != c->rank && ns > 0)
+                FDX_NCCL(api->Send(send + (size_t)K * send_off[(size_t)r], (size_t)K * ns, ncclDouble, r, c->nccl, st));
+        }
+        FDX_NCCL(api->GroupEnd());
+        return 0;
+    }
+    if (c->local) {
+        LocalWorld& w = *c->local;
+        FDX_HIP(hipStreamSynchronize(st));                        // my send staging is complete
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.ptr[(size_t)c->rank] = send;
+            w.off[(size_t)c->rank].assign(send_off.begin(), send_off.end());
+        }
+        w.barrier();
+        for (int q = 0; q < W; ++q) {
+            const int nr = recv_off[(size_t)q + 1] - recv_off[(size_t)q];
+            if (q == c->rank || nr == 0) continue;
+            const double* src = static_cast<const double*>(w.ptr[(size_t)q]) + (size_t)K * w.off[(size_t)q][(size_t)c->rank];
+            const long long ns = w.off[(size_t)q][(size_t)c->rank + 1] - w.off[(size_t)q][(size_t)c->rank];
+            FDX_REQUIRE(ns == nr, "sharded solve: send and receive lists of two ranks disagree");
+            FDX_HIP(hipMemcpyAsync(recv + (size_t)K * recv_off[(size_t)q], src, (size_t)K * nr * 8, hipMemcpyDeviceToDevice, st));
+        }
+        FDX_HIP(hipStreamSynchronize(st));
+        w.barrier();                                              // nobody overwrites its staging before all have copied
+        return 0;
+    }
+    return 0;
+}
+
+// element-wise max / sum over the ranks of `count` 64-bit words on the device
+int allreduce(fdx_comm* c, void* buf, int count, bool is_max, hipStream_t st) {
+    if (c->world == 1 && !c->nccl) return 0;
+    if (c->nccl) {
+        const RcclApi* api = rccl();
+        if (is_max) FDX_NCCL(api->AllReduce(buf, buf, (size_t)count, ncclUint64, ncclMax, c->nccl, st));
+        else FDX_NCCL(api->AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->nccl, st));
+        return 0;
+    }
+    if (c->local) {
+        LocalWorld& w = *c->local;
+        std::vector<unsigned long long> mine((size_t)count);
+        FDX_HIP(hipMemcpyAsync(mine.data(), buf, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.host[(size_t)c->rank] = mine;
+        }
+        w.barrier();
+        std::vector<unsigned long long> out((size_t)count, 0ULL);
+        if (is_max) {
+            for (int q = 0; q < w.W; ++q)
+                for (int i = 0; i < count; ++i) out[(size_t)i] = std::max(out[(size_t)i], w.host[(size_t)q][(size_t)i]);
+        } else {
+            std::vector<double> acc((size_t)count, 0.0);
+            for (int q = 0; q < w.W; ++q)                              // rank order: every rank gets the same bits
+                for (int i = 0; i < count; ++i) {
+                    double v;
+                    std::memcpy(&v, &w.host[(size_t)q][(size_t)i], 8);
+                    acc[(size_t)i] += v;
+                }
+            std::memcpy(out.data(), acc.data(), (size_t)count * 8);
+        }
+        w.barrier();                                              // everybody has read the mailbox
+        FDX_HIP(hipMemcpyAsync(buf, out.data(), (size_t)count * 8, hipMemcpyHostToDevice, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    return 0;
+}
+
+int comm_streams(fdx_comm* c) {
+    if (c->side) return 0;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) != hipSuccess)
+        FDX_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    FDX_HIP(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+    FDX_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdx_comm_unique_id(void* id_out_128) {
+    FDX_REQUIRE(id_out_128 != nullptr, "fdx_comm_unique_id: null output");
+    const RcclApi* api = rccl();
+    FDX_REQUIRE(api != nullptr, "fdx_comm_unique_id: librccl.so could not be loaded");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    FDX_NCCL(api->GetUniqueId(&id));
+    std::memcpy(id_out_128, &id, sizeof(id));
+    return 0;
+}
+
+int fdx_comm_init(const void* id_128, int32_t rank, int32_t world, fdx_comm** out) {
+    FDX_REQUIRE(id_128 && out && world >= 1 && rank >= 0 && rank < world, "fdx_comm_init: bad arguments");
+    const RcclApi* api = rccl();
+    FDX_REQUIRE(api != nullptr, "fdx_comm_init: librccl.so could not be loaded");
+    ncclUniqueId id;
+    std::memcpy(&id, id_128, sizeof(id));
+    auto* c = new fdx_comm();
+    c->rank = rank;
+    c->world = world;
+    const ncclResult_t r = api->CommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(FDX_ERR_HIP, std::string("ncclCommInitRank: ") + api->GetErrorString(r));
+    }
+    *out = c;
+    return 0;
+}
+
+int fdx_local_world_create(int32_t world, fdx_local_world** out) {
+    FDX_REQUIRE(out && world >= 1, "fdx_local_world_create: bad arguments");
+    auto* w = new fdx_local_world();
+    w->w.W = world;
+    w->w.ptr.assign((size_t)world, nullptr);
+    w->w.off.assign((size_t)world, {});
+    w->w.host.assign((size_t)world, {});
+    *out = w;
+    return 0;
+}
+
+int fdx_local_world_destroy(fdx_local_world* w) {
+    delete w;
+    return 0;
+}
+
+int fdx_comm_init_local(fdx_local_world* w, int32_t rank, fdx_comm** out) {
+    FDX_REQUIRE(w && out && rank >= 0 && rank < w->w.W, "fdx_comm_init_local: bad arguments");
+    auto* c = new fdx_comm();
+    c->rank = rank;
+    c->world = w->w.W;
+    c->local = &w->w;
+    *out = c;
+    return 0;
+}
+
+int fdx_comm_destroy(fdx_comm* c) {
+    if (!c) return 0;
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
+    if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+    if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+    return 0;
+}
+
+int fdx_comm_info(const fdx_comm* c, int32_t* rank, int32_t* world) {
+    FDX_REQUIRE(c != nullptr, "fdx_comm_info: null communicator");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return 0;
+}
+
+int fdx_comm_allreduce_sum_dev(fdx_comm* c, double* buf_dev, int32_t count, void* stream) {
+    FDX_REQUIRE(c && buf_dev && count > 0, "fdx_comm_allreduce_sum_dev: bad arguments");
+    return allreduce(c, buf_dev, count, false, (hipStream_t)stream);
+}
+
+int fdx_sharded_solve_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, int32_t K,
+                          double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev, double* beta1_dev,
+                          int64_t ld, fdx_solve_info* info, double* rel_changes_out, int32_t* result_buffer, void* stream) {
+    FDX_REQUIRE(c && g && H_dev && XtX_dev && beta0_dev && beta1_dev && info && result_buffer, "fdx_sharded_solve_dev: null argument");
+    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_FAST, "fdx_sharded_solve_dev: K must be in 1..64 on the sharded path");
+    FDX_REQUIRE(ld >= g->n_total + 1, "fdx_sharded_solve_dev: ld must cover own + halo + zero row");
+    FDX_REQUIRE(max_iter >= 0, "fdx_sharded_solve_dev: max_iter must be >= 0");
+    FDX_REQUIRE(g->send_off.size() == (size_t)c->world + 1 && g->recv_off.size() == (size_t)c->world + 1,
+                "fdx_sharded_solve_dev: the graph was localized for a different number of ranks");
+    hipStream_t st = (hipStream_t)stream;
+    std::memset(info, 0, sizeof(*info));
+    *result_buffer = 0;
+    const int W = c->world;
+    const int total_send = g->send_off.back(), total_recv = g->recv_off.back();
+    FDX_TRY(comm_streams(c));
+
+    DevBuf stats, relchg, send_buf, recv_buf, soff, roff;
+    const int iters = std::max<int>(max_iter, 1);
+    FDX_TRY(stats.alloc((size_t)iters * 128 * 8));
+    FDX_TRY(relchg.alloc((size_t)iters * 8));
+    FDX_TRY(send_buf.alloc((size_t)std::max(total_send, 1) * K * 8));
+    FDX_TRY(recv_buf.alloc((size_t)std::max(total_recv, 1) * K * 8));
+    FDX_TRY(soff.alloc((size_t)(W + 1) * 4));
+    FDX_TRY(roff.alloc((size_t)(W + 1) * 4));
+    FDX_HIP(hipMemsetAsync(stats.p, 0, stats.bytes, st));
+    FDX_HIP(hipMemsetAsync(relchg.p, 0, relchg.bytes, st));
+    FDX_HIP(hipMemcpyAsync(soff.p, g->send_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
+    FDX_HIP(hipMemcpyAsync(roff.p, g->recv_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
+    FDX_TRY(solver_init_beta(beta0_dev, ld, g->n_total, K, st));             // beta0 = 1/K on own + halo (solver.py:372)
+    FDX_HIP(hipMemsetAsync(beta1_dev, 0, (size_t)K * ld * 8, st));
+    FDX_HIP(hipStreamSynchronize(st));                                        // the offset vectors are host objects of g
+
+    BcdSweepArgs a{};
+    a.H = H_dev; a.XtX = XtX_dev; a.ell = g->ell.as<int>(); a.slice_off = g->slice_off.as<int>(); a.deg = g->deg.as<int>();
+    a.stats = stats.as<unsigned long long>(); a.rel_change = relchg.as<double>();
+    a.lambda = lambda; a.rho = rho_eff; a.tol = tol; a.ldh = (int)ldh; a.ld = (int)ld; a.n = (int)g->n;
+    a.n_slices = g->n_slices; a.K = K;
+    const bool tiled = g->tiled && !getenv("FDX_NO_TILED");
+    if (tiled) {
+        a.tiled = 1; a.ell_local = g->ell_local.as<unsigned short>(); a.tile_halo = g->tile_halo.as<int>();
+        a.tile_hcnt = g->tile_hcnt.as<int>(); a.n_tiles = g->n_tiles; a.halo_max = g->halo_max;
+    }
+    // boundary-first ordering needs the tiled sweep (tile lists) and somebody to talk to
+    bool split = tiled && total_send > 0 && g->n > 0 && !getenv("FDX_NO_OVERLAP");
+    if (split) {
+        FDX_TRY(build_tile_lists(*g, st));
+        split = g->n_tiles_boundary > 0 && g->n_tiles_interior > 0;
+    }
+
+    std::vector<double> rc_host((size_t)iters, 0.0);
+    int done = 0, n_iter = 0, chunk = 4;
+    bool converged = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    FDX_HIP(hipEventCreate(&ev0));
+    FDX_HIP(hipEventCreate(&ev1));
+    double sweep_ms = 0.0;
+    double* beta[2] = {beta0_dev, beta1_dev};
+    auto run = [&]() -> int {
+        while (done < max_iter && !converged) {
+            const int end = std::min<int>(max_iter, done + chunk);
+            FDX_HIP(hipEventRecord(ev0, st));
+            for (int it = done; it < end; ++it) {
+                a.it = it;
+                a.beta_in = beta[it & 1];
+                a.beta_out = beta[(it + 1) & 1];
+                hipStream_t sx = st;                                          // stream of the halo traffic
+                if (g->n > 0) {
+                    if (split) {
+                        a.tile_list = g->tiles_boundary.as<int>(); a.n_list = g->n_tiles_boundary;
+                        FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));
+                    } else {
+                        a.tile_list = nullptr; a.n_list = 0;
+                        FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));
+                    }
+                }
+                if (total_send > 0) {
+                    hipLaunchKernelGGL(halo_pack_kernel, dim3(ceil_div(total_send, 256)), dim3(256), 0, st, a.beta_out, (long long)ld, K,
+                                       g->send_idx.as<int>(), soff.as<int>(), W, total_send, send_buf.as<double>());
+                    FDX_CHECK_LAUNCH();
+                }
+                if (split) {
+                    FDX_HIP(hipEventRecord(c->ev_packed, st));
+                    a.tile_list = g->tiles_interior.as<int>(); a.n_list = g->n_tiles_interior;
+                    FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));             // beside the halo traffic
+                    sx = c->side;
+                    FDX_HIP(hipStreamWaitEvent(sx, c->ev_packed, 0));
+                }
+                if (c->local || total_send > 0 || total_recv > 0)      // the in-process transport meets at barriers
+                    FDX_TRY(exchange(c, send_buf.as<double>(), g->send_off, recv_buf.as<double>(), g->recv_off, K, sx));
+                if (total_recv > 0) {
+                    hipLaunchKernelGGL(halo_unpack_kernel, dim3(ceil_div(total_recv, 256)), dim3(256), 0, sx, a.beta_out, (long long)ld, K,
+                                       (long long)g->n, roff.as<int>(), W, total_recv, recv_buf.as<double>());
+                    FDX_CHECK_LAUNCH();
+                }
+                if (split) {
+                    FDX_HIP(hipEventRecord(c->ev_halo, sx));
+                    FDX_HIP(hipStreamWaitEvent(st, c->ev_halo, 0));
+                }
+                FDX_TRY(allreduce(c, a.stats + (size_t)it * 128, 128, true, st));
+            }
+            FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, end - 1, st));
+            FDX_HIP(hipEventRecord(ev1, st));
+            FDX_HIP(hipMemcpyAsync(rc_host.data() + done, relchg.as<double>() + done, (size_t)(end - done) * 8, hipMemcpyDeviceToHost, st));
+            FDX_HIP(hipStreamSynchronize(st));
+            float ms = 0.f;
+            FDX_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+            sweep_ms += ms;
+            for (int it = done; it < end; ++it) {
+                n_iter = it + 1;
+                if (rc_host[(size_t)it] < tol) { converged = true; break; }   // solver.py:409-413
+            }
+            done = end;
+            chunk = std::min(chunk * 2, 32);
+        }
+        return 0;
+    };
+    const int rc = run();
+    (void)hipStreamSynchronize(st);
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (rc) return rc;
+    info->n_iterations = n_iter;
+    info->converged = converged ? 1 : 0;
+    info->final_change = n_iter > 0 ? rc_host[(size_t)n_iter - 1] : 0.0;
+    info->sweep_ms = sweep_ms;
+    *result_buffer = n_iter & 1;
+    if (rel_changes_out)
+        for (int i = 0; i < n_iter; ++i) rel_changes_out[i] = rc_host[(size_t)i];
+    return 0;
+}
+
+}  // extern "C"

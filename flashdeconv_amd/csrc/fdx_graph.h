@@ -40,4 +40,8 @@ struct fdx_graph {
     long long global_lo = 0;
     fdx::DevBuf halo_global, send_idx;
     std::vector<int> send_off, recv_off;
+    // tiles of the sweep that hold a row some peer needs (boundary) and the rest (interior), built on first use by the
+    // native sharded solve (comm.cpp): boundary tiles are swept first, their rows packed and sent while the interior runs
+    mutable fdx::DevBuf tiles_boundary, tiles_interior;
+    mutable int n_tiles_boundary = -1, n_tiles_interior = 0;
 };

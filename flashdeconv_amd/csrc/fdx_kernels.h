@@ -28,6 +28,8 @@ struct BcdSweepArgs {
     int halo_max = 0;
     int tiled = 0;
     int objective = 0;       // tiled kernel only: evaluate the objective partial sums instead of sweeping (see bcd_sweep_inst.cpp)
+    const int* tile_list = nullptr;   // tiled kernel only: sweep just these n_list tiles (sharded solve: boundary / interior)
+    int n_list = 0;
     unsigned long long* stats;  // (max_iter, 2, 64) per-iteration max slots (bit patterns of doubles >= 0)
     double* rel_change;      // (max_iter) rel_change per iteration, written by the following kernel
     double lambda;

@@ -248,9 +248,41 @@ class ShardedFlashDeconv:
         self.n_hvg, self.k_neighbors, self.spatial_method, self.radius = n_hvg, k_neighbors, spatial_method, radius
         self.max_iter, self.tol, self.preprocess, self.random_state = max_iter, tol, preprocess, random_state
         self.comm = comm if comm is not None else TorchComm(group)
+        self._native = None           # fdx_comm handle: the C++ / RCCL iteration loop (csrc/comm.cpp)
         self._full = self._local = None
         self.timings_ = {}
         self._profile = bool(os.environ.get("FDX_DIST_TIMING"))
+
+    def native_comm(self):
+        """libfdx's own RCCL communicator for the native iteration loop (fdx_sharded_solve_dev): rank 0 draws the
+        ncclUniqueId, torch.distributed ships the 128 bytes, every rank calls ncclCommInitRank through fdx_comm_init.
+        None when the process group is not an nccl one (the gloo tests use the Python loop) or FDX_PY_LOOP is set."""
+        import torch
+        if self._native is not None or os.environ.get("FDX_PY_LOOP"):
+            return self._native
+        dist = getattr(self.comm, "dist", None)
+        if dist is None or dist.get_backend(self.comm.group) != "nccl":
+            return None
+        lib = _lib.load()
+        ident = np.zeros(128, dtype=np.uint8)
+        if self.comm.rank == 0:
+            _lib.check(lib.fdx_comm_unique_id(ident.ctypes.data))
+        t = torch.from_numpy(ident).cuda()
+        dist.broadcast(t, src=dist.get_global_rank(self.comm.group, 0) if self.comm.group is not None else 0, group=self.comm.group)
+        ident = t.cpu().numpy()
+        h = ctypes.c_void_p()
+        _lib.check(lib.fdx_comm_init(ident.ctypes.data, self.comm.rank, self.comm.world, ctypes.byref(h)))
+        self._native = h
+        return self._native
+
+    def close(self):
+        if self._native is not None:
+            _lib.load().fdx_comm_destroy(self._native)
+            self._native = None
+        for g in (self._local, self._full):
+            if g is not None:
+                g.close()
+        self._local = self._full = None
 
     def _tick(self, name, t0):
         """Stage timing for tools/dist_probe.py (FDX_DIST_TIMING=1: synchronises, so only for diagnosis)."""
@@ -281,6 +313,7 @@ class ShardedFlashDeconv:
         for g in (self._local, self._full):
             if g is not None:
                 g.close()
+        self._local = self._full = None
         t0 = time.perf_counter()
         h = ctypes.c_void_p()
         self.bounds = shard_bounds(n, self.comm.world)
@@ -425,14 +458,31 @@ class ShardedFlashDeconv:
         rho_eff = float(self.rho_sparsity) * dmean                            # core/solver.py:359-360
         t0 = self._tick("scalars", t0)
         backend = HipBackend(self._local, H, ld, XtX, K)
-        solver = ShardedSolver(backend, self.comm, self._halo, K, ld, n_own, n_total, self.max_iter, self.tol)
-        if getattr(self, "time_sweeps", False):
-            solver.sweep_events = []
-        beta, info = solver.run(lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev), lam, rho_eff)
-        if solver.sweep_events:
-            torch.cuda.current_stream().synchronize()
-            real = solver.sweep_events[:info["n_iterations"]]                  # later launches are post-convergence no-ops
-            self.sweep_ms_ = [a.elapsed_time(b) for a, b in real]
+        native = self.native_comm()
+        if native is not None and not getattr(self, "time_sweeps", False):
+            # the whole iteration loop in C++ on RCCL: boundary tiles first, halo traffic beside the interior sweep
+            bufs = [torch.empty((K, ld), dtype=torch.float64, device=dev) for _ in range(2)]
+            sinfo = _lib.SolveInfo()
+            rel = np.zeros(max(int(self.max_iter), 1))
+            which = ctypes.c_int32(0)
+            _lib.check(lib.fdx_sharded_solve_dev(native, self._local.handle, ctypes.c_void_p(H.data_ptr()), ld,
+                                                 ctypes.c_void_p(XtX.data_ptr()), K, float(lam), float(rho_eff), float(self.tol),
+                                                 int(self.max_iter), ctypes.c_void_p(bufs[0].data_ptr()),
+                                                 ctypes.c_void_p(bufs[1].data_ptr()), ld, ctypes.byref(sinfo), _lib.ptr_f64(rel),
+                                                 ctypes.byref(which), st))
+            beta = bufs[which.value]
+            info = {"converged": bool(sinfo.converged), "n_iterations": int(sinfo.n_iterations),
+                    "final_change": float(sinfo.final_change), "rel_changes": [float(v) for v in rel[:sinfo.n_iterations]]}
+            self.sweep_loop_ms_ = float(sinfo.sweep_ms)
+        else:
+            solver = ShardedSolver(backend, self.comm, self._halo, K, ld, n_own, n_total, self.max_iter, self.tol)
+            if getattr(self, "time_sweeps", False):
+                solver.sweep_events = []
+            beta, info = solver.run(lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev), lam, rho_eff)
+            if solver.sweep_events:
+                torch.cuda.current_stream().synchronize()
+                real = solver.sweep_events[:info["n_iterations"]]              # later launches are post-convergence no-ops
+                self.sweep_ms_ = [a.elapsed_time(b) for a, b in real]
         t0 = self._tick("solve", t0)
         part = torch.from_numpy(backend.objective_partials(beta)).to(dev)
         self.comm.all_reduce_sum(part)
@@ -450,15 +500,17 @@ class ShardedFlashDeconv:
 
 
 def bench_main(a, rank, world, local_rank):
-    """bench.py --gpus N (N > 1): ONE job of N x --spots spots, sharded over the N ranks (weak scaling: every rank owns
-    --spots spots; coordinates are replicated, each rank holds only its own rows of Y)."""
+    """bench.py --gpus N (N > 1): ONE job sharded over the N ranks.  --scaling strong (default): the --spots job itself
+    (BASELINE.json configs[3]: 1M spots over N GPUs); --scaling weak: N x --spots spots, --spots per rank.  Coordinates are
+    replicated, each rank holds only its own rows of Y."""
     import json
     import time
     import torch
     import torch.distributed as dist
     import bench
     dev = torch.device("cuda", local_rank)
-    n, G, K, d = a.spots * world, a.genes, a.types, a.sketch_dim
+    weak = getattr(a, "scaling", "strong") == "weak"
+    n, G, K, d = (a.spots * world if weak else a.spots), a.genes, a.types, a.sketch_dim
     g = torch.Generator(device=dev)
     g.manual_seed(12345)                                        # identical coordinates and signatures on every rank
     coords = torch.rand(n, 2, generator=g, device=dev, dtype=torch.float64) * float(np.sqrt(n))
@@ -510,10 +562,11 @@ def bench_main(a, rank, world, local_rank):
     ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in the C stdio buffer: get it out BEFORE the result line
     if rank == 0:
         print(json.dumps({
-            "metric": "spots/sec to convergence (1M x 2000 x 30)", "value": n * a.steps / dt, "unit": "spots/s",
-            "spots_total": n, "spots_per_gpu": a.spots,
+            "metric": bench.METRIC if not weak else f"spots/sec to convergence ({world} x 1M x 2000 x 30, weak scaling)",
+            "value": n * a.steps / dt, "unit": "spots/s", "spots_total": n, "spots_per_gpu": n // world,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
             "config": {"workload": f"{n} spots x {G} genes x {K} types, sketch_dim {d}, k_neighbors 6, gaussian/raw family, "
                                    f"Y float32 in HBM, spots sharded over {world} GPUs (Morton ranges, RCCL halo exchange)",
                        "n_iterations": n_it, "converged": conv},

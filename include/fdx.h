@@ -276,6 +276,37 @@ int fdx_objective_partials_dev(const fdx_graph* g, const double* beta_dev, int64
 int fdx_normalize_dev(const double* beta_dev, int64_t ld, int64_t n, int32_t K, double* beta_out_dev, double* prop_out_dev,
                       void* stream);
 
+/* ---- native sharded solve: the per-iteration loop on RCCL directly (csrc/comm.cpp) -------------------------- *
+ * The reference has no distributed code; sharding spots is legal because the sweep is Jacobi across spots
+ * (core/solver.py:157-166 reads only the previous iterate).  One process per GPU:
+ *   rank 0:  fdx_comm_unique_id(id)  -> ship the 128 bytes to every rank (any side channel)
+ *   all:     fdx_comm_init(id, rank, world, &comm)          (ncclCommInitRank; librccl is loaded with dlopen here)
+ *            fdx_graph_localize(...) for `world` ranks, fdx_prepare_dev(...) for the own rows
+ *            fdx_sharded_solve_dev(comm, local_graph, H, XtX, ...)
+ * Per iteration: boundary tiles swept first, their rows packed (one kernel) and sent / received with grouped
+ * ncclSend / ncclRecv on a communication stream while the interior tiles are swept, halo unpacked (one kernel),
+ * ncclAllReduce(max) of the iteration's 128 convergence slots.  Same bits and iteration count as fdx_bcd_solve on the
+ * unsharded problem.  fdx_local_world_* / fdx_comm_init_local: the same loop with host threads of ONE process as ranks
+ * on one GPU (device copies through a shared mailbox) - for tests, no RCCL involved. */
+typedef struct fdx_comm fdx_comm;
+typedef struct fdx_local_world fdx_local_world;
+int fdx_comm_unique_id(void* id_out_128);
+int fdx_comm_init(const void* id_128, int32_t rank, int32_t world, fdx_comm** out);
+int fdx_local_world_create(int32_t world, fdx_local_world** out);
+int fdx_local_world_destroy(fdx_local_world* w);
+int fdx_comm_init_local(fdx_local_world* w, int32_t rank, fdx_comm** out);
+int fdx_comm_destroy(fdx_comm* comm);
+int fdx_comm_info(const fdx_comm* comm, int32_t* rank, int32_t* world);
+/* In-place sum over the ranks of `count` device doubles (YtY, objective partials, nnz, per-gene moment sums). */
+int fdx_comm_allreduce_sum_dev(fdx_comm* comm, double* buf_dev, int32_t count, void* stream);
+/* The bcd_solve loop (core/solver.py:385-413) over this rank's shard.  beta0_dev / beta1_dev: (K, ld) type-major buffers
+ * of the caller (initialised here: 1/K on own + halo, 0 on the pad); *result_buffer says which of the two holds the
+ * final abundances.  info: n_iterations, converged, final_change, sweep_ms; rel_changes_out: max_iter doubles or NULL. */
+int fdx_sharded_solve_dev(fdx_comm* comm, const fdx_graph* local, const double* H_dev, int64_t ldh, const double* XtX_dev,
+                          int32_t K, double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev,
+                          double* beta1_dev, int64_t ld, fdx_solve_info* info, double* rel_changes_out,
+                          int32_t* result_buffer, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

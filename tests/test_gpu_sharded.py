@@ -186,3 +186,154 @@ def test_sharded_class_world1_equals_flashdeconv():
         np.testing.assert_allclose(got2, ref2.proportions_, rtol=1e-9, atol=1e-12)
     finally:
         dist.destroy_process_group()
+
+
+def _native_shards(torch, coords_dev, Y_dev, X, W, d, K, mode, random_state=0):
+    """Cut the problem into W shards (replicated graph build + fdx_graph_localize), prepare H / XtX per shard."""
+    from flashdeconv_amd import _lib
+    from flashdeconv_amd.core.sketching import countsketch_tables
+    from flashdeconv_amd.distributed import shard_bounds
+    from flashdeconv_amd.utils.genes import compute_leverage_scores
+    lib = _lib.load()
+    dev = coords_dev.device
+    n, G = Y_dev.shape
+    bounds = shard_bounds(n, W)
+    h = ctypes.c_void_p()
+    _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(coords_dev.data_ptr()), n, 2, _lib.GRAPH_KNN, 6, 0.0, _st(torch), ctypes.byref(h)))
+    full = _lib.Graph(h.value)
+    lev = compute_leverage_scores(X)
+    bucket, weight = countsketch_tables(G, d, lev, random_state)
+    b32 = np.ascontiguousarray(bucket, dtype=np.int32)
+    Xc = np.ascontiguousarray(X, dtype=np.float64)
+    shards = []
+    for r in range(W):
+        hl = ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_localize(full.handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
+        g = _lib.Graph(hl.value)
+        n_own = int(bounds[r + 1] - bounds[r])
+        perm = torch.empty(max(n_own, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.fdx_graph_perm_dev(g.handle, ctypes.c_void_p(perm.data_ptr()), _st(torch)))
+        own = perm[:n_own].long()
+        nh = ctypes.c_int64(0)
+        _lib.check(lib.fdx_graph_halo_info(g.handle, ctypes.byref(nh), None, None))
+        n_total = n_own + int(nh.value)
+        ld = ((n_total + 1 + 63) // 64) * 64
+        Hm = torch.zeros((K, ld), dtype=torch.float64, device=dev)
+        XtX = torch.empty((K, K), dtype=torch.float64, device=dev)
+        XtX_h = np.empty((K, K))
+        part = ctypes.c_double(0.0)
+        # rows gathered through the shard's row map: Y stays whole, as on a rank that was handed only its own rows
+        own32 = own.to(torch.int32).contiguous()
+        code = _lib.FDX_F32 if Y_dev.dtype == torch.float32 else _lib.FDX_F64
+        _lib.check(lib.fdx_prepare_dev(ctypes.c_void_p(Y_dev.data_ptr()), code, n_own, G, G, ctypes.c_void_p(own32.data_ptr()),
+                                       _lib.ptr_f64(Xc), K, _lib.ptr_i32(b32), _lib.ptr_f64(weight), _lib.ptr_f64(weight), d, mode,
+                                       mode, ctypes.c_void_p(Hm.data_ptr()), ld, ctypes.c_void_p(XtX.data_ptr()),
+                                       _lib.ptr_f64(XtX_h), ctypes.byref(part), _st(torch)))
+        shards.append(dict(g=g, own=own, n_own=n_own, ld=ld, H=Hm, XtX=XtX, XtX_h=XtX_h,
+                           beta=[torch.empty((K, ld), dtype=torch.float64, device=dev) for _ in range(2)]))
+    return full, shards
+
+
+def _run_native_threads(torch, shards, K, lam, rho_eff, tol, max_iter):
+    """fdx_sharded_solve_dev on every shard at once: one host thread and one stream per rank."""
+    import threading
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    W = len(shards)
+    world = ctypes.c_void_p()
+    _lib.check(lib.fdx_local_world_create(W, ctypes.byref(world)))
+    torch.cuda.synchronize()
+    results, errors = [None] * W, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            S = shards[r]
+            comm = ctypes.c_void_p()
+            _lib.check(lib.fdx_comm_init_local(world, r, ctypes.byref(comm)))
+            stream = torch.cuda.Stream()
+            info = _lib.SolveInfo()
+            which = ctypes.c_int32(0)
+            rel = np.zeros(max(max_iter, 1))
+            rc = lib.fdx_sharded_solve_dev(comm, S["g"].handle, ctypes.c_void_p(S["H"].data_ptr()), S["ld"],
+                                           ctypes.c_void_p(S["XtX"].data_ptr()), K, lam, rho_eff, tol, max_iter,
+                                           ctypes.c_void_p(S["beta"][0].data_ptr()), ctypes.c_void_p(S["beta"][1].data_ptr()), S["ld"],
+                                           ctypes.byref(info), _lib.ptr_f64(rel), ctypes.byref(which),
+                                           ctypes.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                errors.append((r, lib.fdx_last_error()))
+            results[r] = (int(info.n_iterations), bool(info.converged), float(info.final_change), which.value, rel)
+            lib.fdx_comm_destroy(comm)
+        except Exception as e:                                   # noqa: BLE001 - reported below, the other ranks would hang
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a rank thread hangs"
+    lib.fdx_local_world_destroy(world)
+    assert not errors, errors
+    return results
+
+
+def _assemble(torch, shards, results, n, K):
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    dev = shards[0]["H"].device
+    beta = torch.zeros((n, K), dtype=torch.float64, device=dev)
+    for S, res in zip(shards, results):
+        out = torch.empty((S["n_own"], K), dtype=torch.float64, device=dev)
+        _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(S["beta"][res[3]].data_ptr()), S["ld"], S["n_own"], K,
+                                         ctypes.c_void_p(out.data_ptr()), None, _st(torch)))
+        beta[S["own"]] = out
+    torch.cuda.synchronize()
+    return beta
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("W", [2, 3, 5])
+def test_native_loop_thread_ranks_equal_single_gpu(W, overlap, monkeypatch):
+    import torch
+    from flashdeconv_amd import FlashDeconv, _lib
+    from flashdeconv_amd.distributed import diag_mean
+    if not overlap:
+        monkeypatch.setenv("FDX_NO_OVERLAP", "1")               # one sweep launch per iteration, halo on the compute stream
+    dev = torch.device("cuda", 0)
+    n, G, K, d = 6000, 300, 12, 64
+    Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 11)
+    coords = coords + np.random.RandomState(0).rand(n, 2) * 1e-3
+    ref = FlashDeconv(sketch_dim=d, max_iter=60, tol=1e-5).fit(Y, X, coords)
+    cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
+    Yt = torch.from_numpy(Y.astype(np.float32)).to(dev)
+    full, shards = _native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM)
+    lam, rho_eff = ref.lambda_used_, 0.01 * diag_mean(shards[0]["XtX_h"])
+    results = _run_native_threads(torch, shards, K, lam, rho_eff, 1e-5, 60)
+    for res in results:
+        assert res[0] == ref.info_["n_iterations"] and res[1] == ref.info_["converged"]
+        assert res[2] == results[0][2]                          # every rank saw the same global statistics
+    np.testing.assert_allclose(results[0][2], ref.info_["final_change"], rtol=1e-12)
+    assert np.array_equal(_assemble(torch, shards, results, n, K).cpu().numpy(), ref.beta_)
+
+
+def test_native_loop_8_ranks_at_1m_spots_config3():
+    """BASELINE configs[3]'s workload on one GPU: the 1M x 2000 x 30 job cut into 8 shards, every shard driven by the
+    native loop in its own thread; beta must equal the single-GPU fit bit for bit, in the same number of iterations."""
+    import torch
+    import bench
+    from flashdeconv_amd import FlashDeconv, _lib
+    from flashdeconv_amd.distributed import diag_mean
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of free HBM (1M x 2000 float32 plus eight shards' buffers)")
+    dev = torch.device("cuda", 0)
+    n, G, K, d, W = 1_000_000, 2000, 30, 512, 8
+    Y, X, coords = bench.gen_gaussian(torch, n, G, K, dev, 0)
+    ref = FlashDeconv(sketch_dim=d, preprocess="raw", n_hvg=G).fit(Y, X, coords, output="torch")
+    full, shards = _native_shards(torch, coords, Y, X, W, d, K, _lib.PRE_RAW)
+    lam, rho_eff = ref.lambda_used_, 0.01 * diag_mean(shards[0]["XtX_h"])
+    results = _run_native_threads(torch, shards, K, lam, rho_eff, 1e-4, 100)
+    assert all(res[0] == ref.info_["n_iterations"] and res[1] for res in results) and ref.info_["converged"]
+    got = _assemble(torch, shards, results, n, K)
+    assert torch.equal(got, ref.beta_)
