@@ -349,6 +349,10 @@ class FlashDeconv:
         self.timings_["graph_ms"] = (t_lev - t_graph) * 1e3
         self.timings_["select_ms"] = t_sel * 1e3      # gene statistics on the device + HVG/marker ranking on the host
         self.timings_["leverage_wait_ms"] = (t_done - t_lev) * 1e3
+        # the graph is built by its own call ahead of fdx_fit_dev, whose total_ms starts after it: one figure for the fit
+        self.timings_["device_ms"] = self.timings_["total_ms"]
+        self.timings_["total_ms"] = self.timings_["graph_ms"] + self.timings_["select_ms"] + self.timings_["leverage_wait_ms"] + \
+            self.timings_["device_ms"]
         self._fitted = True
         log(f"  Converged: {self.info_['converged']}")
         log(f"  Iterations: {self.info_['n_iterations']}")

@@ -14,8 +14,30 @@ from .. import _lib
 from ..utils.random import check_random_state
 
 
+_TABLE_CACHE = {}       # (G, d, seed, leverage bytes) -> (bucket, weight); integer seeds only (a stateless draw)
+
+
 def countsketch_tables(n_genes, sketch_dim, leverage_scores=None, random_state=None):
-    """(bucket int64[G], weight float64[G]) with Omega[g, bucket[g]] = weight[g]  (core/sketching.py:48-82)."""
+    """(bucket int64[G], weight float64[G]) with Omega[g, bucket[g]] = weight[g]  (core/sketching.py:48-82).
+    Repeated calls with the same integer seed and leverage scores return the (read-only) tables of the first call."""
+    key = None
+    if isinstance(random_state, (int, np.integer)) and not isinstance(random_state, bool):
+        lev_key = None if leverage_scores is None else np.ascontiguousarray(leverage_scores, dtype=np.float64).tobytes()
+        key = (int(n_genes), int(sketch_dim), int(random_state), lev_key)
+        hit = _TABLE_CACHE.get(key)
+        if hit is not None:
+            return hit
+    bucket, weight = _countsketch_tables(n_genes, sketch_dim, leverage_scores, random_state)
+    if key is not None:
+        bucket.setflags(write=False)
+        weight.setflags(write=False)
+        if len(_TABLE_CACHE) >= 16:
+            _TABLE_CACHE.pop(next(iter(_TABLE_CACHE)))
+        _TABLE_CACHE[key] = (bucket, weight)
+    return bucket, weight
+
+
+def _countsketch_tables(n_genes, sketch_dim, leverage_scores, random_state):
     rng = check_random_state(random_state)
     if leverage_scores is None:
         prob = np.ones(n_genes) / n_genes

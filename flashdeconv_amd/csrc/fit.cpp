@@ -212,14 +212,12 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     }
     tm.mark();  // 1
 
-    // ---- sketch plans (Omega tables come from the host: hash/sign from numpy's RandomState, core/sketching.py:58-59)
-    std::vector<long long> col_ptr;
-    std::vector<int> gene_idx;
-    std::vector<double> wy, wx;
-    FDX_TRY(build_csc_from_tables(bucket, weight_y, G, d, &col_ptr, &gene_idx, &wy));
-    SketchPlan plan_y, plan_x;
+    // ---- sketch plans (Omega tables come from the host: hash/sign from numpy's RandomState, core/sketching.py:58-59);
+    // shared through a content-keyed cache, so a repeated fit builds nothing
+    std::shared_ptr<SketchPlan> plan_y_p, plan_x_p;
     DevBuf dSlots, dBits;        // CSR source: per-column {weight, bucket} table over all G_all columns + "selected" bitmap
     int sel_words = 0;
+    for (int g_ = 0; g_ < G; ++g_) FDX_REQUIRE(bucket[g_] >= 0 && bucket[g_] < d, "fit: bucket index out of range");
     if (ysrc.csr) {
         const int G_all = ysrc.csr->G;
         FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(GeneSlotHost), "fit: gene slot layout mismatch");
@@ -240,14 +238,13 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
         FDX_HIP(hipStreamSynchronize(st));   // `slots` is a stack-scoped host buffer
     } else {
-        FDX_TRY(plan_y.build(col_ptr.data(), gene_idx.data(), wy.data(), G, d, st));
+        FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, st, &plan_y_p));
     }
-    {
-        std::vector<long long> cp2;
-        std::vector<int> gi2;
-        FDX_TRY(build_csc_from_tables(bucket, weight_x, G, d, &cp2, &gi2, &wx));
-        FDX_TRY(plan_x.build(cp2.data(), gi2.data(), wx.data(), G, d, st));
-    }
+    if (!ysrc.csr && weight_x == weight_y) plan_x_p = plan_y_p;
+    else FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, st, &plan_x_p));
+    SketchPlan plan_none;
+    const SketchPlan& plan_y = plan_y_p ? *plan_y_p : plan_none;
+    const SketchPlan& plan_x = *plan_x_p;
 
     // ---- X_sketch (K, d) and XtX (core/sketching.py:202-204, core/solver.py:346)
     const long long ld = round_up(n + 1, 64);
@@ -258,6 +255,14 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
     FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, prm->mode_x, plan_x.dev(), dXs.as<double>(), d, nullptr, st));
     FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, st));
+    // XtX goes to the host NOW, ahead of the big sketch kernel: lambda and the scaled rho are host scalars of the sweeps,
+    // and with them known early the solve is queued behind the sketch without the host waiting for it
+    std::vector<double> Gh((size_t)K * K);
+    hipEvent_t evG = nullptr;
+    FDX_HIP(hipEventCreateWithFlags(&evG, hipEventDisableTiming));
+    struct EvGuard { hipEvent_t e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evG_guard{evG};
+    FDX_HIP(hipMemcpyAsync(Gh.data(), dG.p, Gh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipEventRecord(evG, st));
 
     // ---- Y_sketch in solver order, chunked, contracted into H (K, ld) as it is produced
     FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
@@ -275,20 +280,15 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     FDX_HIP(hipMemsetAsync(dH.p, 0, dH.bytes, st));
     const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();
     double sketch_ms = 0.0, gram_ms = 0.0;
-    if (fused) {   // one kernel, no Y_sketch: rows -> LDS accumulators -> MFMA contraction -> H  (fused_kernels.cpp)
-        hipEvent_t e0, e1;
-        FDX_HIP(hipEventCreate(&e0));
-        FDX_HIP(hipEventCreate(&e1));
-        FDX_HIP(hipEventRecord(e0, st));
+    hipEvent_t eS0 = nullptr, eS1 = nullptr;     // around the fused kernel; read at the end of the fit, no wait here
+    struct EvGuard2 { hipEvent_t* a; hipEvent_t* b; ~EvGuard2() { if (*a) (void)hipEventDestroy(*a); if (*b) (void)hipEventDestroy(*b); } } eS_guard{&eS0, &eS1};
+    if (fused) {   // one kernel, no Y_sketch: rows -> LDS tile -> bucket sums -> MFMA contraction -> H  (tile_kernels.cpp)
+        FDX_HIP(hipEventCreate(&eS0));
+        FDX_HIP(hipEventCreate(&eS1));
+        FDX_HIP(hipEventRecord(eS0, st));
         FDX_TRY(launch_sketch_contract(Y_dev, y_dtype, ldy, row_map, n, G, d, prm->mode_y, plan_y.dev(), dXs.as<double>(), K,
                                        dH.as<double>(), ld, dRowSq.as<double>(), st));
-        FDX_HIP(hipEventRecord(e1, st));
-        FDX_HIP(hipStreamSynchronize(st));
-        float t = 0.f;
-        (void)hipEventElapsedTime(&t, e0, e1);
-        sketch_ms = t;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        FDX_HIP(hipEventRecord(eS1, st));
     } else {
         const int n_chunks = (int)((n + chunk - 1) / chunk);
         const int n_timed = std::min(n_chunks, 64);             // stage timing from up to 64 chunks, scaled
@@ -328,11 +328,11 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
     FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));   // YtY (core/solver.py:348)
-    std::vector<double> Gh((size_t)K * K);
     double YtY = 0.0;
-    FDX_HIP(hipMemcpyAsync(Gh.data(), dG.p, Gh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipMemcpyAsync(&YtY, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
+    // YtY only enters the objective: the verbose trace evaluates it inside the loop, otherwise it is read after the solve
+    if (prm->verbose) FDX_HIP(hipStreamSynchronize(st));
+    else FDX_HIP(hipEventSynchronize(evG));
     tm.mark();  // 2
     double diag_mean = 0.0;
     for (int k = 0; k < K; ++k) diag_mean += Gh[(size_t)k * K + k];
@@ -350,8 +350,17 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = K; p.YtY = YtY;
     p.lambda = lambda; p.rho_eff = prm->rho_sparsity * diag_mean; p.max_iter = prm->max_iter; p.tol = prm->tol;
     p.verbose = prm->verbose;
+    p.compute_objective = prm->verbose ? 1 : 0;
     SolveResult r;
-    FDX_TRY(solver_run(p, &r, st));
+    FDX_TRY(solver_run(p, &r, st));          // its chunked read-backs synchronise the stream: YtY has arrived after it
+    if (!prm->verbose) {
+        DevBuf objp, objo;
+        FDX_TRY(objp.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
+        FDX_TRY(objo.alloc(4 * sizeof(double)));
+        if (prm->max_iter == 0) FDX_HIP(hipStreamSynchronize(st));
+        FDX_TRY(solver_objective(*g, p.beta[r.result_buffer], ld, p.H, ld, p.XtX, K, YtY, lambda, p.rho_eff, objp.as<double>(),
+                                 objo.as<double>(), &r.final_objective, st));
+    }
     tm.mark();  // 3
     if (beta_out_dev || prop_out_dev)
         FDX_TRY(launch_normalize_export(p.beta[r.result_buffer], ld, row_map, (int)n, g->n_slices, K, beta_out_dev,
@@ -370,6 +379,11 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     info->YtY = YtY;
     info->nnz = g->nnz;
     info->graph_ms = tm.ms(0, 1);
+    if (eS0) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, eS0, eS1);
+        sketch_ms = t;
+    }
     info->sketch_ms = sketch_ms;
     info->gram_ms = gram_ms;
     info->solve_ms = tm.ms(2, 3);

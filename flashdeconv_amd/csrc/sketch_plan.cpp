@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -37,7 +39,7 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
         host_bucket = gb;
         host_w = gw;
     }
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kTileKeys; ++i) {
         tile[i].reset();
         tile_tried[i] = false;
     }
@@ -120,6 +122,80 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
     FDX_HIP(hipMemcpyAsync(group_off.p, goff.data(), goff.size() * sizeof(int), hipMemcpyHostToDevice, st));
     FDX_HIP(hipMemcpyAsync(slot_bucket.p, slot_b.data(), slot_b.size() * sizeof(int), hipMemcpyHostToDevice, st));
     FDX_HIP(hipStreamSynchronize(st));   // the host vectors die at scope exit
+    return 0;
+}
+
+namespace {
+struct CacheEntry {
+    int dev = 0, G = 0, d = 0;
+    unsigned long long hash = 0;
+    std::vector<int32_t> bucket;
+    std::vector<double> weight;
+    std::shared_ptr<SketchPlan> plan;
+};
+// Both live on the heap and are never destroyed: the plans own pooled device buffers, and at process exit the pool's own
+// statics (pool.cpp) may already be gone when this translation unit's would be torn down.
+std::mutex& g_cache_mu = *new std::mutex();
+std::vector<CacheEntry>& g_cache = *new std::vector<CacheEntry>();   // most recently used last
+constexpr size_t kCacheCap = 12;
+
+unsigned long long fnv1a(const void* p, size_t n, unsigned long long h) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) {
+        h ^= b[i];
+        h *= 1099511628211ULL;
+    }
+    return h;
+}
+}  // namespace
+
+int sketch_plan_cached(const int32_t* bucket, const double* weight, int G, int d, hipStream_t st, std::shared_ptr<SketchPlan>* out) {
+    FDX_REQUIRE(bucket && weight && G > 0 && d > 0 && out, "sketch plan: bad arguments");
+    int dev = 0;
+    FDX_HIP(hipGetDevice(&dev));
+    unsigned long long h = fnv1a(bucket, (size_t)G * 4, 1469598103934665603ULL);
+    h = fnv1a(weight, (size_t)G * 8, h);
+    const bool use_cache = !getenv("FDX_NO_PLAN_CACHE");
+    if (use_cache) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_cache.size(); ++i) {
+            CacheEntry& e = g_cache[i];
+            if (e.hash == h && e.dev == dev && e.G == G && e.d == d && std::memcmp(e.bucket.data(), bucket, (size_t)G * 4) == 0 &&
+                std::memcmp(e.weight.data(), weight, (size_t)G * 8) == 0) {
+                *out = e.plan;
+                std::rotate(g_cache.begin() + (long)i, g_cache.begin() + (long)i + 1, g_cache.end());
+                return 0;
+            }
+        }
+    }
+    // CSC form of Omega: genes ascending inside every bucket
+    std::vector<long long> col_ptr((size_t)d + 1, 0);
+    for (int g = 0; g < G; ++g) {
+        FDX_REQUIRE(bucket[g] >= 0 && bucket[g] < d, "sketch plan: bucket index out of range");
+        col_ptr[(size_t)bucket[g] + 1]++;
+    }
+    for (int c = 0; c < d; ++c) col_ptr[(size_t)c + 1] += col_ptr[(size_t)c];
+    std::vector<int> gene_idx((size_t)G);
+    std::vector<double> w((size_t)G);
+    std::vector<long long> cur(col_ptr.begin(), col_ptr.end() - 1);
+    for (int g = 0; g < G; ++g) {
+        const long long e = cur[(size_t)bucket[g]]++;
+        gene_idx[(size_t)e] = g;
+        w[(size_t)e] = weight[g];
+    }
+    auto plan = std::make_shared<SketchPlan>();
+    FDX_TRY(plan->build(col_ptr.data(), gene_idx.data(), w.data(), G, d, st));
+    *out = plan;
+    if (use_cache) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_cache.size() >= kCacheCap) g_cache.erase(g_cache.begin());
+        CacheEntry e;
+        e.dev = dev; e.G = G; e.d = d; e.hash = h;
+        e.bucket.assign(bucket, bucket + G);
+        e.weight.assign(weight, weight + G);
+        e.plan = plan;
+        g_cache.push_back(std::move(e));
+    }
     return 0;
 }
 

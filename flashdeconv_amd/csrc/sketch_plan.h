@@ -1,6 +1,7 @@
 // Host-built static schedule for the CountSketch gather (internal).
 #pragma once
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "fdx_internal.h"
@@ -19,11 +20,13 @@ struct SketchPlan {
     bool scatter_ok = false;
     DevBuf sched_gene, sched_w, group_off, slot_bucket, sched_pack, gene_w, gene_bucket;
     // per-gene form on the host (valid when scatter_ok) and the tile kernel's schedules built from it on first use,
-    // one per (input type, raw / log) pair (tile_kernels.cpp)
+    // one per (input type, raw / log, type tiles, wave split) (tile_kernels.cpp)
     std::vector<int> host_bucket;
     std::vector<double> host_w;
-    mutable std::shared_ptr<TilePlanDevice> tile[4];
-    mutable bool tile_tried[4] = {false, false, false, false};
+    static constexpr int kTileKeys = 24;     // (input type, raw / log, type tiles, wave split)
+    mutable std::shared_ptr<TilePlanDevice> tile[kTileKeys];
+    mutable bool tile_tried[kTileKeys] = {};
+    mutable std::mutex tile_mu;              // plans are shared through the cache: schedules are built under this lock
     SketchPlanDev dev() const {
         SketchPlanDev p;
         p.sched_gene = sched_gene.as<int>();
@@ -45,5 +48,11 @@ struct SketchPlan {
     // A CountSketch has exactly one entry per gene; any sparse Omega works (project_to_sketch accepts one).
     int build(const long long* col_ptr, const int* gene_idx, const double* weight, int G_, int d_, hipStream_t st);
 };
+
+// CountSketch plans by content: `bucket` (G int32) and `weight` (G doubles) of the per-gene tables (core/sketching.py:58-82).
+// A fit rebuilds the same Omega every time it is called with the same genes, seed and leverage scores; the plans (CSC
+// form, device tables, the tile kernel's schedule with its ~0.5 ms greedy packing) are kept in a small per-process cache
+// and shared.  The returned plan stays valid while the caller holds the pointer, whatever the cache evicts.
+int sketch_plan_cached(const int32_t* bucket, const double* weight, int G, int d, hipStream_t st, std::shared_ptr<SketchPlan>* out);
 
 }  // namespace fdx

@@ -494,14 +494,18 @@ static size_t tile_lds_bytes(int RS, int NE, int mode) {
 // Builds (once per SketchPlan and input type) the schedule for the largest column block that fits the LDS.
 static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int mode, int K, hipStream_t st) {
     const int sz = dtype == FDX_F32 ? 4 : 8;
-    const int key = (dtype == FDX_F32 ? 0 : 1) * 2 + (mode != FDX_PRE_RAW ? 1 : 0);
+    const TileCfg cfg = tile_cfg(mode);
+    const int TT = (K + 15) / 16;
+    if (TT > 2 || TT < 1) return nullptr;
+    const int key = ((((dtype == FDX_F32 ? 0 : 1) * 2 + (mode != FDX_PRE_RAW ? 1 : 0)) * 2 + (TT - 1)) * 3) +
+                    (cfg.NWC == 12 ? 0 : cfg.NWC == 16 ? 1 : 2);
+    static_assert(SketchPlan::kTileKeys == 24, "key space of the schedules");
+    std::lock_guard<std::mutex> lock(sp.tile_mu);
     if (sp.tile_tried[key]) return sp.tile[key].get();
     sp.tile_tried[key] = true;
     const bool dbg = getenv("FDX_DEBUG") != nullptr;
     if (!sp.scatter_ok || sp.host_bucket.empty()) return nullptr;
-    const TileCfg cfg = tile_cfg(mode);
-    const int TT = (K + 15) / 16;
-    if (sp.d > 4 * cfg.NWC * cfg.JW || TT > 2 || TT < 1) return nullptr;
+    if (sp.d > 4 * cfg.NWC * cfg.JW) return nullptr;
     const size_t red_bytes = (size_t)(cfg.NWC > 8 ? cfg.NWC / 2 : cfg.NWC) * (TT * 4 * 64 + 64) * 8;   // the kernel's reduction area
     const int unit = 1024 / sz;                                             // genes per 1 KB piece
     std::unique_ptr<TilePlanDevice> best;
