@@ -376,11 +376,46 @@ def golden_objective():
     save("objective.npz", **out)
 
 
+def golden_lattice():
+    """Regular lattices (Visium-HD / Stereo-seq bins are a square lattice, Visium a hexagonal one): on a square lattice with
+    k = 6 EVERY spot has a tie at the k-th neighbour (4 at distance 1, two of the four at sqrt 2), which the reference
+    resolves by cKDTree's traversal order (utils/graph.py:60-81).  Adjacency and a complete fit per lattice."""
+    print("lattices: square 30x30, hex 28x28 (k=6 and spatial_method='grid')")
+    out = {}
+    sq = np.stack(np.meshgrid(np.arange(30.0), np.arange(30.0), indexing="ij"), axis=-1).reshape(-1, 2)
+    hx = []
+    for r in range(28):
+        for c in range(28):
+            hx.append((c + 0.5 * (r & 1), r * np.sqrt(3.0) / 2.0))
+    hx = np.asarray(hx)
+    sets = {"square_k6": (sq, "knn"), "square_grid": (sq, "grid"), "hex_k6": (hx, "knn"), "hex_grid": (hx, "grid"),
+            "square100_k6": (sq * 100.0, "knn")}
+    out["names"] = np.array(list(sets.keys()))
+    for name, (coords, method) in sets.items():
+        n = coords.shape[0]
+        Y, X, _, _ = datagen.count_like(n, 400, 5, 0.1, 17)
+        m = FlashDeconv(sketch_dim=64, preprocess="log_cpm", n_hvg=2000, spatial_method=method, k_neighbors=6, max_iter=30,
+                        random_state=0, verbose=False)
+        with np.errstate(all="ignore"):
+            m.fit(Y, X, coords)
+        ip, ix, _ = csr_parts(m.adjacency_)
+        out[f"{name}_coords"] = coords
+        out[f"{name}_method"] = np.array(method)
+        out[f"{name}_indptr"] = ip
+        out[f"{name}_indices"] = ix
+        out[f"{name}_beta"] = m.beta_
+        out[f"{name}_props"] = m.proportions_
+        out[f"{name}_lambda"] = np.array(m.lambda_used_)
+        out[f"{name}_n_iter"] = np.array(m.info_["n_iterations"])
+        out[f"{name}_seed"] = np.array(17)
+    save("lattice.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(omega=golden_omega, leverage=golden_leverage, graphs=golden_graphs, solver=golden_solver,
                 objective=golden_objective, fits=golden_fits,
-                fits_sparse=golden_fits_sparse)
+                fits_sparse=golden_fits_sparse, lattice=golden_lattice)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -318,3 +318,48 @@ def test_tl_deconvolve_anndata_surface():
     assert "fdx" in st.obsm and "fdx_dominant" in st.obs and "fdx_params" in st.uns
     with pytest.raises(ValueError, match="not found in adata_ref.obs"):
         fd.tl.deconvolve(st, ref, cell_type_key="nope")
+
+
+def _lattice_case(name):
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("lattice.npz")
+    coords = g[f"{name}_coords"]
+    Y, X, _, _ = datagen.count_like(coords.shape[0], 400, 5, 0.1, int(g[f"{name}_seed"]))
+    m = FlashDeconv(sketch_dim=64, preprocess="log_cpm", n_hvg=2000, spatial_method=str(g[f"{name}_method"]), k_neighbors=6,
+                    max_iter=30).fit(Y, X, coords)
+    A = m.adjacency_
+    same_graph = np.array_equal(A.indptr, g[f"{name}_indptr"]) and np.array_equal(A.indices, g[f"{name}_indices"])
+    return m, g, same_graph
+
+
+@pytest.mark.parametrize("name", ["square_grid", "hex_grid"])
+def test_lattice_without_ties_matches_reference(name):
+    """Regular lattices where the neighbour sets are unambiguous: spatial_method='grid' (radius 1.5 x the nearest
+    neighbour distance: the 8 / 6 surrounding bins) on square and hexagonal lattices.  Adjacency index-exact, abundances
+    at the usual tolerance."""
+    m, g, same_graph = _lattice_case(name)
+    assert same_graph
+    assert m.info_["n_iterations"] == int(g[f"{name}_n_iter"])
+    np.testing.assert_allclose(m.lambda_used_, float(g[f"{name}_lambda"]), rtol=1e-10)
+    assert rel_fro(m.beta_, g[f"{name}_beta"]) < 1e-8 and rel_fro(m.proportions_, g[f"{name}_props"]) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["square_k6", "square100_k6", "hex_k6"])
+def test_square_lattice_k6_tie_deviation_is_bounded(name):
+    """k = 6 on a square lattice: every spot has four neighbours at distance 1 and must pick two of the four at sqrt(2).
+    The reference inherits cKDTree's traversal order there (an effectively arbitrary pair per spot, degrees 6-10 after the
+    union symmetrisation); this implementation takes the two lowest spot indices (degree 8 in the interior).  Both are
+    k-NN graphs of the same points; they differ, and so do lambda (through the mean degree) and the abundances: measured
+    4.5e-4 (square), 3.1e-4 (hexagonal: ties only along the border) relative Frobenius in the proportions.  That is the size
+    of the reference's own dependence on the ORDER in which the same spots are listed (4.9e-4 - 5.2e-4 / 2.1e-4 - 2.6e-4:
+    tests/test_oracle.py::test_lattice_ties_make_the_reference_depend_on_spot_order), which bounds what any tie rule other
+    than a bit-for-bit cKDTree emulation can achieve.  DESIGN.md §4."""
+    m, g, same_graph = _lattice_case(name)
+    assert not same_graph                                            # if this ever holds, tighten the test above instead
+    A = m.adjacency_
+    assert (A != A.T).nnz == 0 and A.diagonal().sum() == 0
+    deg = np.diff(A.indptr)
+    assert deg.min() >= 6                                            # still a k-NN graph: every spot keeps >= k neighbours
+    gap_p, gap_b = rel_fro(m.proportions_, g[f"{name}_props"]), rel_fro(m.beta_, g[f"{name}_beta"])
+    print(f"lattice tie deviation {name}: proportions {gap_p:.3e} beta {gap_b:.3e} lambda {m.lambda_used_:.6g} vs {float(g[name + '_lambda']):.6g}")
+    assert gap_p < 8e-4 and gap_b < 8e-4

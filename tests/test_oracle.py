@@ -245,3 +245,25 @@ def test_project_loops_definition():
     b, w = orc.countsketch_omega(90, 16, None, 4)
     Ys, _ = orc.project(Yt, rs.rand(3, 90), b, w, 16)
     np.testing.assert_allclose(orc.project_loops(Yt, b, w, 16), Ys, rtol=1e-13)
+
+
+def test_lattice_ties_make_the_reference_depend_on_spot_order():
+    """On a square lattice with k = 6 every spot has a tie at the k-th neighbour (4 at distance 1, two of four at sqrt 2)
+    and the reference takes whatever cKDTree's traversal yields (utils/graph.py:60-81).  Listing the same spots in another
+    order therefore changes the reference's OWN graph and result - by 5e-4 relative Frobenius in the proportions, more than
+    the 1e-4 parity budget.  This pins that number: it is the yardstick for the GPU path's documented deviation on
+    lattices (tests/test_gpu_fit.py::test_square_lattice_k6_tie_deviation_is_bounded, DESIGN.md §4)."""
+    g = load_golden("lattice.npz")
+    for name, lo, hi in (("square_k6", 2e-4, 2e-3), ("hex_k6", 5e-5, 1e-3)):
+        coords = g[f"{name}_coords"]
+        n = coords.shape[0]
+        Y, X, _, _ = datagen.count_like(n, 400, 5, 0.1, int(g[f"{name}_seed"]))
+        kw = dict(sketch_dim=64, preprocess_method="log_cpm", n_hvg=2000, max_iter=30, graph="kdtree")
+        base = orc.fit(Y, X, coords, **kw)
+        assert rel_fro(base["proportions"], g[f"{name}_props"]) < 1e-12            # the oracle IS the reference here
+        p = np.random.RandomState(1).permutation(n)
+        o = orc.fit(Y[p], X, coords[p], **kw)
+        P = np.empty_like(o["proportions"])
+        P[p] = o["proportions"]
+        gap = rel_fro(P, g[f"{name}_props"])
+        assert lo < gap < hi, (name, gap)
