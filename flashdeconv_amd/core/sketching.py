@@ -87,8 +87,15 @@ def project_to_sketch(Y_tilde, X_tilde, Omega):
     n_genes = Y_tilde.shape[1]
     col_ptr, gene_idx, weight, d = _omega_csc(Omega, n_genes)
     if sparse.issparse(Y_tilde):
-        raise NotImplementedError("sparse Y input is handled by FlashDeconv.fit (CSR path); densify for project_to_sketch")
-    Ys = _project_dense(Y_tilde, col_ptr, gene_idx, weight, d)
+        # reference core/sketching.py:194-199: Y_tilde @ Omega, densified.  The seam takes host arrays, so the row blocks are
+        # densified on their way to the device kernel (the fit itself keeps CSR input sparse in HBM: csrc/csr_kernels.cpp).
+        Yc = Y_tilde.tocsr()
+        Ys = np.empty((Yc.shape[0], d), dtype=np.float64)
+        step = max(1, (1 << 26) // max(n_genes, 1))
+        for r0 in range(0, Yc.shape[0], step):
+            Ys[r0:r0 + step] = _project_dense(np.asarray(Yc[r0:r0 + step].todense(), dtype=np.float64), col_ptr, gene_idx, weight, d)
+    else:
+        Ys = _project_dense(Y_tilde, col_ptr, gene_idx, weight, d)
     Xs = _project_dense(np.asarray(X_tilde, dtype=np.float64), col_ptr, gene_idx, weight, d)
     return Ys, Xs
 

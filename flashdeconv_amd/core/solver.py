@@ -1,9 +1,12 @@
 """Host side of the BCD solver: same names and argument meaning as the reference's
 ``flashdeconv/core/solver.py``; the arithmetic runs in libfdx.so on the GPU.
 
-    bcd_solve              <- core/solver.py:287-428   (fdx_bcd_solve)
-    normalize_proportions  <- core/solver.py:431-452
-    precompute_* / compute_objective are exposed through ``flashdeconv_amd.core.kernels`` for tests.
+    soft_threshold          <- core/solver.py:18-26
+    precompute_gram_matrix  <- core/solver.py:187-201   (fdx_gram_xty)
+    precompute_XtY          <- core/solver.py:204-223   (fdx_gram_xty)
+    compute_objective       <- core/solver.py:226-284   (fdx_objective)
+    bcd_solve               <- core/solver.py:287-428   (fdx_bcd_solve)
+    normalize_proportions   <- core/solver.py:431-452
 """
 import ctypes
 
@@ -11,6 +14,60 @@ import numpy as np
 from scipy import sparse
 
 from .. import _lib
+
+
+def soft_threshold(x, threshold):
+    """sign(x) * max(|x| - threshold, 0) (core/solver.py:18-26).  A scalar helper of the reference's kernels, kept for its
+    tests; on the device it is fused into the sweep (csrc/bcd_sweep_inst.cpp)."""
+    x = np.asarray(x, dtype=np.float64)
+    out = np.sign(x) * np.maximum(np.abs(x) - threshold, 0.0)
+    return float(out) if out.ndim == 0 else out
+
+
+def precompute_gram_matrix(X_sketch):
+    """XtX = X_sketch X_sketch^T, (K, K) (core/solver.py:187-201)."""
+    X_sketch = _lib.as_f64(X_sketch)
+    K, d = X_sketch.shape
+    _lib.require_gpu()
+    out = np.empty((K, K), dtype=np.float64)
+    _lib.check(_lib.load().fdx_gram_xty(_lib.ptr_f64(X_sketch), None, 0, d, K, _lib.ptr_f64(out), None))
+    return out
+
+
+def precompute_XtY(X_sketch, Y_sketch):
+    """H = X_sketch Y_sketch^T, (K, N) C-order as in the reference (core/solver.py:204-223)."""
+    X_sketch, Y_sketch = _lib.as_f64(X_sketch), _lib.as_f64(Y_sketch)
+    K, d = X_sketch.shape
+    n = Y_sketch.shape[0]
+    if Y_sketch.shape[1] != d:
+        raise ValueError(f"Sketch dimension mismatch: Y_sketch has {Y_sketch.shape[1]}, X_sketch has {d}")
+    out = np.empty((K, n), dtype=np.float64)
+    if n:
+        _lib.require_gpu()
+        _lib.check(_lib.load().fdx_gram_xty(_lib.ptr_f64(X_sketch), _lib.ptr_f64(Y_sketch), n, d, K, None, _lib.ptr_f64(out)))
+    return out
+
+
+def compute_objective(beta, H, XtX, YtY, L, lambda_, rho):
+    """0.5 (YtY - 2 sum(beta * H^T) + sum(beta^T beta * XtX)) + 0.5 lambda sum(beta * (L beta)) + rho sum|beta|
+    (core/solver.py:226-284).  L is the un-normalised Laplacian D - A (core/spatial.py:70-73); its off-diagonal structure
+    is the graph the device kernel walks."""
+    beta, H, XtX = _lib.as_f64(beta), _lib.as_f64(H), _lib.as_f64(XtX)
+    n, K = beta.shape
+    L = sparse.csr_matrix(L)
+    A = L.copy().tolil()
+    A.setdiag(0)
+    A = A.tocsr()
+    A.eliminate_zeros()
+    _lib.require_gpu()
+    graph = _lib.Graph.from_csr(A.indptr, A.indices, n)
+    try:
+        out = ctypes.c_double(0.0)
+        _lib.check(_lib.load().fdx_objective(graph.handle, _lib.ptr_f64(beta), _lib.ptr_f64(H), _lib.ptr_f64(XtX), n, K,
+                                             float(YtY), float(lambda_), float(rho), ctypes.byref(out)))
+    finally:
+        graph.close()
+    return float(out.value)
 
 
 def _graph_from_adjacency(A, n_spots):

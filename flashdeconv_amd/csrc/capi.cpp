@@ -347,3 +347,61 @@ int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sk
 }
 
 }  // extern "C"
+
+// ---- function-level seams of core/solver.py the reference's tests import (tests/test_solver.py:7-14) -----------------------
+// precompute_gram_matrix (core/solver.py:187-201) and precompute_XtY (:204-223): XtX = Xs Xs^T, H = Xs Ys^T (K, n) row-major.
+extern "C" int fdx_gram_xty(const double* X_sketch, const double* Y_sketch, int64_t n, int32_t d, int32_t K, double* XtX_out,
+                            double* H_out) {
+    FDX_REQUIRE(X_sketch && K > 0 && d > 0 && n >= 0, "fdx_gram_xty: bad arguments");
+    FDX_REQUIRE(XtX_out || H_out, "fdx_gram_xty: nothing to compute");
+    FDX_REQUIRE(!H_out || n == 0 || Y_sketch, "fdx_gram_xty: null Y_sketch");
+    hipStream_t st = nullptr;
+    DevBuf dX, dY, dG, dH;
+    FDX_TRY(dX.alloc((size_t)K * d * sizeof(double)));
+    FDX_HIP(hipMemcpyAsync(dX.p, X_sketch, (size_t)K * d * sizeof(double), hipMemcpyHostToDevice, st));
+    if (XtX_out) {
+        FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
+        FDX_TRY(launch_xyt(dX.as<double>(), dX.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, st));
+        FDX_HIP(hipMemcpyAsync(XtX_out, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (H_out && n > 0) {
+        const long long ld = round_up(n, 64);
+        FDX_TRY(dY.alloc((size_t)n * d * sizeof(double)));
+        FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
+        FDX_HIP(hipMemcpyAsync(dY.p, Y_sketch, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, st));
+        FDX_TRY(launch_xyt(dX.as<double>(), dY.as<double>(), d, n, d, K, dH.as<double>(), ld, nullptr, st));
+        FDX_HIP(hipMemcpy2DAsync(H_out, (size_t)n * sizeof(double), dH.p, (size_t)ld * sizeof(double), (size_t)n * sizeof(double),
+                                 (size_t)K, hipMemcpyDeviceToHost, st));
+    }
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// compute_objective (core/solver.py:226-284): 0.5 (YtY - 2 <beta, H^T> + <beta^T beta, XtX>) + 0.5 lambda <beta, L beta>
+// + rho |beta|_1 with L = D - A of the graph's structure.  beta (n, K) row-major, H (K, n) row-major, both on the host.
+extern "C" int fdx_objective(const fdx_graph* g, const double* beta, const double* H, const double* XtX, int64_t n, int32_t K,
+                             double YtY, double lambda, double rho, double* obj_out) {
+    FDX_REQUIRE(g && beta && H && XtX && obj_out && n > 0 && K > 0, "fdx_objective: bad arguments");
+    FDX_REQUIRE(g->n == n && g->identity_order, "fdx_objective: needs a graph over the same n spots in the caller's order (fdx_graph_from_csr)");
+    hipStream_t st = nullptr;
+    const long long ld = round_up(n + 1, 64);
+    std::vector<double> bt((size_t)K * ld, 0.0), ht((size_t)K * ld, 0.0);
+    for (long long i = 0; i < n; ++i)
+        for (int k = 0; k < K; ++k) {
+            bt[(size_t)k * ld + i] = beta[(size_t)i * K + k];
+            ht[(size_t)k * ld + i] = H[(size_t)k * n + i];
+        }
+    DevBuf dB, dH, dG, dPart, dOut;
+    FDX_TRY(dB.alloc(bt.size() * sizeof(double)));
+    FDX_TRY(dH.alloc(ht.size() * sizeof(double)));
+    FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
+    FDX_TRY(dPart.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
+    FDX_TRY(dOut.alloc(4 * sizeof(double)));
+    FDX_HIP(hipMemcpyAsync(dB.p, bt.data(), bt.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_HIP(hipMemcpyAsync(dH.p, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_HIP(hipMemcpyAsync(dG.p, XtX, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice, st));
+    if (K <= FDX_MAX_K_FAST || true)
+        FDX_TRY(solver_objective(*g, dB.as<double>(), ld, dH.as<double>(), ld, dG.as<double>(), K, YtY, lambda, rho, dPart.as<double>(),
+                                 dOut.as<double>(), obj_out, st));
+    return 0;
+}

@@ -592,6 +592,20 @@ __global__ __launch_bounds__(256) void gather_columns_kernel(const T* __restrict
     }
 }
 
+// The same gather for rows too long to stage (more than 160 KB: a dense float64 whole transcriptome): one wave per row reads
+// Y[r, idx[j]] directly.  idx is ascending, so consecutive lanes touch the same or neighbouring cache lines.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_columns_direct_kernel(const T* __restrict__ Y, long long ldy, long long n,
+                                                                    const int* __restrict__ idx, int Gs, T* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long r = wave0; r < n; r += stride) {
+        const T* y = Y + (size_t)r * ldy;
+        for (int j = lane; j < Gs; j += 64) out[(size_t)r * Gs + j] = y[idx[j]];
+    }
+}
+
 int launch_gene_moments(const void* Y, int dtype, long long ldy, long long n, int G, double* scale, double* partials,
                         double* mean, double* var, hipStream_t st) {
     if (G <= 0 || n <= 0) return fail(FDX_ERR_INVALID, "gene moments: empty matrix");
@@ -621,7 +635,17 @@ int launch_gather_columns(const void* Y, int dtype, long long ldy, long long n, 
     int waves = 4;
     while (waves > 1 && (size_t)G * esz * waves > 64 * 1024) waves >>= 1;
     const size_t lds = (size_t)G * esz * waves;
-    if (lds > 160 * 1024) return fail(FDX_ERR_UNSUPPORTED, "gather columns: one gene row does not fit in LDS");
+    if (lds > 160 * 1024) {   // one row does not fit in LDS: direct gather
+        const int blocks = (int)std::min<long long>((n + 3) / 4, 256LL * 8);
+        if (dtype == FDX_F32)
+            hipLaunchKernelGGL(gather_columns_direct_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)Y, ldy, n, idx, Gs, (float*)out);
+        else if (dtype == FDX_F64)
+            hipLaunchKernelGGL(gather_columns_direct_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)Y, ldy, n, idx, Gs, (double*)out);
+        else
+            return fail(FDX_ERR_INVALID, "gather columns: dtype must be FDX_F32 or FDX_F64");
+        FDX_CHECK_LAUNCH();
+        return 0;
+    }
     const int blocks = (int)std::min<long long>((n + waves - 1) / waves, 256LL * 8);
     if (dtype == FDX_F32) {
         if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute((const void*)gather_columns_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -149,6 +149,16 @@ int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sk
                   int32_t K, double lambda, double rho, int32_t max_iter, double tol, int32_t verbose,
                   double* beta_out, double* objectives_out, double* rel_changes_out, fdx_solve_info* info);
 
+/* Function-level seams of the solver the reference's own tests import (tests/test_solver.py:7-14):
+ *   fdx_gram_xty  <- precompute_gram_matrix (core/solver.py:187-201) and precompute_XtY (:204-223): XtX = Xs Xs^T (K, K),
+ *                    H = Xs Ys^T (K, n) row-major; either output may be NULL.  Host arrays, f64 MFMA on the device.
+ *   fdx_objective <- compute_objective (core/solver.py:226-284) for host beta (n, K) / H (K, n) and a graph built with
+ *                    fdx_graph_from_csr from the structure of A (L = D - A); rho is passed as given (already scaled). */
+int fdx_gram_xty(const double* X_sketch, const double* Y_sketch, int64_t n, int32_t d, int32_t K, double* XtX_out,
+                 double* H_out);
+int fdx_objective(const fdx_graph* g, const double* beta, const double* H, const double* XtX, int64_t n, int32_t K,
+                  double YtY, double lambda, double rho, double* obj_out);
+
 /* ---- whole fit (replaces steps 2-6 of FlashDeconv.fit, core/deconv.py:326-398) -------------------------- */
 #define FDX_GRAPH_KNN 0
 #define FDX_GRAPH_RADIUS 1

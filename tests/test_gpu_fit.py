@@ -363,3 +363,22 @@ def test_square_lattice_k6_tie_deviation_is_bounded(name):
     gap_p, gap_b = rel_fro(m.proportions_, g[f"{name}_props"]), rel_fro(m.beta_, g[f"{name}_beta"])
     print(f"lattice tie deviation {name}: proportions {gap_p:.3e} beta {gap_b:.3e} lambda {m.lambda_used_:.6g} vs {float(g[name + '_lambda']):.6g}")
     assert gap_p < 8e-4 and gap_b < 8e-4
+
+
+def test_dense_whole_transcriptome_float64_gene_subset():
+    """A dense float64 matrix over ~35000 genes (a row is 280 KB, more than the LDS holds): the gene subset Y[:, gene_idx]
+    (core/deconv.py:321) takes the direct-gather kernel; the fit must equal the same fit on the pre-selected columns."""
+    from flashdeconv_amd import FlashDeconv
+    rs = np.random.RandomState(5)
+    n, G_all, K = 300, 35000, 4
+    Y = np.zeros((n, G_all))
+    live = np.sort(rs.choice(G_all, 1500, replace=False))
+    Y[:, live] = rs.poisson(3.0, size=(n, len(live)))
+    X = np.exp(rs.randn(K, G_all) * 0.3)
+    X[:, live] *= np.exp(rs.randn(K, len(live)))
+    coords = rs.rand(n, 2) * 20
+    kw = dict(sketch_dim=64, n_hvg=600, n_markers_per_type=20, max_iter=15)
+    a = FlashDeconv(**kw).fit(Y, X, coords)
+    assert 600 <= len(a.gene_idx_) < G_all
+    b = FlashDeconv(**dict(kw, n_hvg=len(a.gene_idx_))).fit(Y[:, a.gene_idx_], X[:, a.gene_idx_], coords)
+    assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < 1e-12

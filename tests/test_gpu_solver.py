@@ -130,3 +130,59 @@ def test_medium_size_convergence_path(fdx):
     got, ginfo = fdx.bcd_solve(Ys, Xs, A, lambda_=0.1, rho=0.01, max_iter=100, tol=1e-4)
     assert ginfo["n_iterations"] == winfo["n_iterations"] and ginfo["converged"] == winfo["converged"]
     assert rel_fro(got, want) < TOL
+
+
+# ---- the function-level seams the reference's own tests import (reference tests/test_solver.py:7-14, :22-35, :233-292)
+def test_soft_threshold_matches_reference_semantics():
+    from flashdeconv_amd.core.solver import soft_threshold
+    assert soft_threshold(3.0, 1.0) == 2.0 and soft_threshold(-3.0, 1.0) == -2.0
+    assert soft_threshold(0.5, 1.0) == 0.0 and soft_threshold(-0.5, 1.0) == 0.0 and soft_threshold(0.0, 0.0) == 0.0
+    np.testing.assert_array_equal(soft_threshold(np.array([2.0, -0.2, -5.0]), 0.5), np.array([1.5, -0.0, -4.5]))
+
+
+@pytest.mark.parametrize("name", ["fit_counts_100x500x5_d64.npz", "fit_gauss_800x2000x20.npz", "fit_counts_600x1000x30.npz"])
+def test_stage_outputs_of_the_fit_goldens(name):
+    """Every intermediate the reference's fit produced, not only the final beta: Y_sketch / X_sketch through sketch_data,
+    XtX and H through precompute_gram_matrix / precompute_XtY, the abundances after exactly 1, 2 and 10 sweeps, and the
+    objective identity on the final state."""
+    from flashdeconv_amd.core.sketching import sketch_data
+    from flashdeconv_amd.core.solver import bcd_solve, compute_objective, precompute_gram_matrix, precompute_XtY
+    g = load_golden(name)
+    Xsk = g["X_sketch"]
+    XtX = precompute_gram_matrix(Xsk)
+    np.testing.assert_allclose(XtX, g["XtX"], rtol=1e-12, atol=1e-12 * np.abs(g["XtX"]).max())
+    if "Y" in g.files:                                       # inputs stored: re-create the reference's Y_tilde on the host
+        Y, X = g["Y"].astype(np.float64), g["X"]
+        Yt = np.log1p(Y / (Y.sum(axis=1, keepdims=True) + 1e-10) * 1e4)
+        Xt = np.log1p(X / (X.sum(axis=1, keepdims=True) + 1e-10) * 1e4)
+        Ys, Xs, Om = sketch_data(Yt, Xt, sketch_dim=Xsk.shape[1], leverage_scores=g["leverage"], random_state=0)
+        assert np.array_equal(Om.tocsr().indices, g["omega_bucket"])
+        np.testing.assert_allclose(Om.tocsr().data, g["omega_data"], rtol=1e-14)
+        assert rel_fro(Xs, Xsk) < 1e-13 and rel_fro(Ys[:8], g["Y_sketch_head"]) < 1e-13
+        np.testing.assert_allclose((Ys ** 2).sum(axis=1), g["Y_sketch_rowsq"], rtol=1e-12)
+        H = precompute_XtY(Xs, Ys)
+        assert H.shape == g["H"].shape and rel_fro(H, g["H"]) < 1e-13
+        n = Ys.shape[0]
+        A = sparse.csr_matrix((np.ones(len(g["indices"])), g["indices"], g["indptr"]), shape=(n, n))
+        for t in (1, 2, 10):
+            if f"beta_it{t}" in g.files:
+                b, info = bcd_solve(Ys, Xs, A, lambda_=float(g["lambda_used"]), rho=0.01, max_iter=t, tol=1e-30)
+                assert info["n_iterations"] == t and rel_fro(b, g[f"beta_it{t}"]) < 1e-9, t
+        # objective identity (reference tests/test_solver.py:233-292): the seam on the golden state equals the fit's report
+        L = sparse.diags(np.asarray(A.sum(axis=1)).ravel()) - A
+        rho_eff = 0.01 * float(np.mean(np.diag(g["XtX"])))
+        obj = compute_objective(g["beta"], g["H"], g["XtX"], float(g["YtY"]), L, float(g["lambda_used"]), rho_eff)
+        np.testing.assert_allclose(obj, float(g["final_objective"]), rtol=1e-9)
+
+
+def test_project_to_sketch_accepts_sparse_y():
+    # reference core/sketching.py:194-199 (sparse Y_tilde is multiplied and densified)
+    from flashdeconv_amd.core.sketching import build_countsketch_matrix, project_to_sketch
+    rs = np.random.RandomState(3)
+    Yd = rs.poisson(0.3, size=(257, 300)).astype(np.float64)
+    X = rs.rand(4, 300)
+    Om = build_countsketch_matrix(300, 32, rs.rand(300), 7)
+    a, xa = project_to_sketch(sparse.csr_matrix(Yd), X, Om)
+    b, xb = project_to_sketch(Yd, X, Om)
+    assert np.array_equal(a, b) and np.array_equal(xa, xb)
+    np.testing.assert_allclose(a, Yd @ Om.toarray(), rtol=1e-12, atol=1e-12)
