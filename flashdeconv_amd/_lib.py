@@ -338,26 +338,39 @@ class CsrOnDevice:
                    int(indptr[-1]) if len(indptr) else 0, G, sorted_rows=1 if Y.has_sorted_indices else 0)
         return self
 
+    # Structure checks of torch CSR tensors already seen, keyed by the identity of their index tensors (storage pointer,
+    # torch's in-place version counter, sizes): a second fit on the same tensor does not scan its 10^9 indices again.  An
+    # in-place edit of the indices bumps the version counter and is checked anew.
+    _checked = {}
+
     @classmethod
     def from_torch(cls, Y):
         import torch
         n, G = Y.shape
-        crow = Y.crow_indices().to(torch.int64).contiguous()
-        col = Y.col_indices().to(torch.int32).contiguous()
+        crow0, col0 = Y.crow_indices(), Y.col_indices()
+        crow = crow0.to(torch.int64).contiguous()
+        col = col0.to(torch.int32).contiguous()
         val = Y.values()
         if val.dtype not in (torch.float32, torch.float64):
             val = val.to(torch.float32)
         val = val.contiguous()
         self = cls()
         self._keep = [crow, col, val]
+        key = None
+        if crow is crow0 or crow.data_ptr() == crow0.data_ptr():
+            if col.data_ptr() == col0.data_ptr():   # zero-copy views of the caller's tensors: identity is meaningful
+                key = (crow0.data_ptr(), col0.data_ptr(), crow0._version, col0._version, int(n), int(G), int(val.numel()))
         self._fill(crow.data_ptr(), col.data_ptr(), val.data_ptr(), FDX_F32 if val.dtype == torch.float32 else FDX_F64,
-                   n, int(val.numel()), G)
+                   n, int(val.numel()), G, check_key=key)
         return self
 
-    def _fill(self, indptr, indices, data, dtype, n, nnz, G, sorted_rows=1):
+    def _fill(self, indptr, indices, data, dtype, n, nnz, G, sorted_rows=1, check_key=None):
         v = self.view
         v.indptr, v.indices, v.data, v.dtype, v.n, v.nnz, v.G = indptr, indices, data, dtype, int(n), int(nnz), int(G)
         v.sorted_rows = int(sorted_rows)            # claim, verified on the device
+        if check_key is not None and check_key in CsrOnDevice._checked:
+            v.sorted_rows = CsrOnDevice._checked[check_key]
+            return
         try:
             try:
                 check(load().fdx_csr_check_dev(ctypes.byref(v), None))
@@ -369,6 +382,10 @@ class CsrOnDevice:
         except Exception:
             self.free()
             raise
+        if check_key is not None:
+            if len(CsrOnDevice._checked) >= 8:
+                CsrOnDevice._checked.pop(next(iter(CsrOnDevice._checked)))
+            CsrOnDevice._checked[check_key] = int(v.sorted_rows)
 
     def gene_moments(self, want_colsum=False):
         """(mean, var, colsum) per column: utils/genes.py:52-83; colsum (raw column sums, for "pearson") on request."""

@@ -199,12 +199,17 @@ class FlashDeconv:
                 # subset (utils/genes.py:135-145, 330) - no pass over Y needed.
                 gene_idx = np.arange(G_all, dtype=np.intp)
             else:
-                if csr is not None:
-                    mean, var, csr_colsum = csr.gene_moments(want_colsum=self.preprocess == "pearson")
-                else:
-                    mean, var = _genes.gene_moments_device(y_ptr, y_code, n, G_all, G_all)
-                hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
-                markers, _ = _genes.select_markers(X, n_markers=self.n_markers_per_type)
+                # the marker table depends on X only: a helper thread ranks it while the device reduces Y to its per-gene
+                # moments (the C call releases the GIL)
+                import concurrent.futures
+                with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+                    fut = pool.submit(_genes.select_markers, X, self.n_markers_per_type)
+                    if csr is not None:
+                        mean, var, csr_colsum = csr.gene_moments(want_colsum=self.preprocess == "pearson")
+                    else:
+                        mean, var = _genes.gene_moments_device(y_ptr, y_code, n, G_all, G_all)
+                    hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
+                    markers, _ = fut.result()
                 gene_idx = np.union1d(hvg, markers).astype(np.intp)                  # utils/genes.py:330
                 if len(gene_idx) == 0:
                     raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")

@@ -1,18 +1,17 @@
-// Fused preprocess + CountSketch + H contraction:  H = X_sketch * f(Y) Omega ^T  without ever writing Y_sketch.
+// Fused preprocess + CountSketch + H contraction with LDS atomics:  H = X_sketch * f(Y) Omega ^T  without writing Y_sketch.
 //
-// Replaces the pair  sketch_rows_scatter_kernel -> xyt_split_kernel  (flashdeconv/core/deconv.py:177-197,
-// core/sketching.py:160-206, core/solver.py:205-223) for the common shape (a CountSketch, sketch_dim <= 512 and a
-// multiple of 16, K <= 32).  The two-kernel form writes the (N, d) float64 sketch and reads it back: 8.6 GB of HBM
-// traffic per million spots at d = 512, more than the 8 GB of Y itself.  Here a workgroup of 8 waves works on GROUPS of
-// 16 consecutive spots (solver order):
-//   scatter phase   wave w streams the rows of spots 2w and 2w+1 of the group from HBM straight into registers and adds
+// The first fused form of the stage (flashdeconv/core/deconv.py:177-197, core/sketching.py:160-206,
+// core/solver.py:205-223), kept as the alternative behind FDX_NO_TILE=1 and for the shapes the tile kernel
+// (tile_kernels.cpp: atomic-free, 1.9 ms against 2.9 ms at 1M x 2000 x 30) does not take: row lengths that are not a whole
+// number of 16-byte vectors.  launch_sketch_contract() dispatches: tile kernel when its schedule exists, else this one.
+// A 16-wave workgroup works on GROUPS of 16 consecutive spots (solver order):
+//   scatter phase   wave w streams the row of spot w of the group from HBM straight into registers and adds
 //                   weight * f(y) into that spot's d-entry accumulator row in LDS (ds_add_f64; per-gene {weight, bucket}
 //                   table in LDS) - exactly the arithmetic of sketch_rows_scatter_kernel; ||row||^2 goes to row_sumsq;
 //   contract phase  the 16 x d block now sitting in LDS is the B operand of v_mfma_f64_16x16x4_f64; as in
-//                   xyt_split_kernel the contraction index is split over the 8 waves, each holding its slice of X_sketch
-//                   as register-resident A operands, and the 8 partial tiles are summed in wave order through LDS.
-// The MFMA sequence and the reduction order are those of xyt_split_kernel, so H has the same bits as the two-kernel path
-// (asserted in tests).  STATUS: correct but not faster yet - see fused_sketch_contract_ok() - hence opt-in.
+//                   xyt_split_kernel the contraction index is split over the waves, each holding its slice of X_sketch
+//                   as register-resident A operands, and the partial tiles are summed in wave order through LDS.
+// Bound by the LDS atomics (ds_add_f64 on random buckets: ~5-way bank conflicts, see profiles/r02_pmc_counters.md).
 #include <algorithm>
 #include <cstdlib>
 

@@ -242,8 +242,11 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         if (c + 1 < a.NBLK) issue_stage(rowp, c + 1, buf ^ 1);
         else if (has_next) issue_stage(rown, 0, buf ^ 1);
     };
+    // Row sums of the next tile as LATE as possible (the wave's k-th pair of rows in block NBLK-1-k, counted from the end):
+    // the sums read the rows from HBM, the DMA of the next tile re-reads them 0 - 1 tile periods later, and the closer the
+    // two reads the more of the second one the XCD's 4 MB L2 still holds (32 CUs x 128 KB of rows per tile period).
     auto sums_step = [&](int c, int par) {
-        if (MODE != FDX_PRE_RAW && has_next) scale_rows(rown, c, a.NBLK, par ^ 1);
+        if (MODE != FDX_PRE_RAW && has_next) scale_rows(rown, a.NBLK - 1 - c, a.NBLK, par ^ 1);
     };
     if (NWL == 0 || wave >= NWC) {
         load_rows(tile, rowp);
