@@ -18,6 +18,12 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
+    // An error return unwinds through DevBuf destructors, which hand their blocks back to the pool while kernels queued
+    // by this call may still be running on the caller's or the library's side streams.  Errors are rare: drain the device
+    // here, so that no block is ever recycled under a kernel in flight (argument errors are raised before any launch, but
+    // a drain on an idle device costs microseconds).
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
     return code;
 }
 }  // namespace fdx
@@ -26,7 +32,7 @@ using namespace fdx;
 
 extern "C" {
 
-int fdx_version(void) { return 100; }  // 0.1.0
+int fdx_version(void) { return 200; }  // 0.2.0
 
 const char* fdx_last_error(void) { return g_last_error.c_str(); }
 

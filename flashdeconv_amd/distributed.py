@@ -243,6 +243,11 @@ class ShardedFlashDeconv:
     def __init__(self, sketch_dim=512, lambda_spatial="auto", rho_sparsity=0.01, n_hvg=2000, k_neighbors=6,
                  spatial_method="knn", radius=None, max_iter=100, tol=1e-4, preprocess="log_cpm", random_state=0,
                  group=None, comm=None, n_markers_per_type=50):
+        # the reference's constructor checks and messages (core/deconv.py:105-124), through the single-GPU estimator
+        from .core.deconv import FlashDeconv
+        self._proto = FlashDeconv(sketch_dim=sketch_dim, lambda_spatial=lambda_spatial, rho_sparsity=rho_sparsity, n_hvg=n_hvg,
+                                  n_markers_per_type=n_markers_per_type, spatial_method=spatial_method, k_neighbors=k_neighbors,
+                                  radius=radius, max_iter=max_iter, tol=tol, preprocess=preprocess, random_state=random_state)
         self.n_markers_per_type = n_markers_per_type
         self.sketch_dim, self.lambda_spatial, self.rho_sparsity = sketch_dim, lambda_spatial, rho_sparsity
         self.n_hvg, self.k_neighbors, self.spatial_method, self.radius = n_hvg, k_neighbors, spatial_method, radius
@@ -332,20 +337,27 @@ class ShardedFlashDeconv:
             try:
                 self.comm.all_gather_rows(nbr, cnt, self.bounds)
             except Exception:
-                nbr[:lo], nbr[hi:], cnt[:lo], cnt[hi:] = -1, -1, 0, 0      # never hand unwritten rows to the kernels
+                # a failed collective leaves the ranks out of step: release the plan (it owns device buffers; its rows of
+                # the other ranks stay marked empty) without letting a second error mask the first, and re-raise
+                nbr[:lo], nbr[hi:], cnt[:lo], cnt[hi:] = -1, -1, 0, 0
+                dead = ctypes.c_void_p()
+                lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi, st,
+                                                 ctypes.byref(dead))
+                if dead.value:
+                    _lib.Graph(dead.value).close()
                 raise
-            finally:
-                t0 = self._tick("plan_gather", t0)
-                _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()),
-                                                            ctypes.c_void_p(cnt.data_ptr()), lo, hi, st, ctypes.byref(h)))
+            t0 = self._tick("plan_gather", t0)
+            _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()),
+                                                        ctypes.c_void_p(cnt.data_ptr()), lo, hi, st, ctypes.byref(h)))
             self._full = _lib.Graph(h.value)
             own_nnz = torch.tensor([float(self._full.info()[1])], dtype=torch.float64, device=coords.device)
             self.comm.all_reduce_sum(own_nnz)                               # nnz of the whole graph (auto lambda)
             self.nnz_total = int(round(float(own_nnz.item())))
         else:
-            method = _lib.GRAPH_KNN if self.spatial_method == "knn" else _lib.GRAPH_RADIUS
-            _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, method, k,
-                                               float(self.radius or 0.0), st, ctypes.byref(h)))
+            # replicated build; "radius" / "grid" resolve their radius exactly as FlashDeconv does (utils/graph.py:163-212)
+            method, gk, gradius = self._proto._graph_request(coords, None)
+            _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, method, gk, float(gradius), st,
+                                               ctypes.byref(h)))
             self._full = _lib.Graph(h.value)
             self.nnz_total = self._full.info()[1]
         t0 = self._tick("plan_build", t0)
@@ -373,6 +385,11 @@ class ShardedFlashDeconv:
     def fit_transform(self, Y_own, X):
         import torch
         from .core.sketching import countsketch_tables
+        # Every libfdx call of this driver is enqueued on torch's CURRENT stream, except the gene statistics and the column
+        # gather (G > n_hvg), which use the legacy default stream: under a non-default, non-blocking torch stream those two
+        # would not be ordered after the producer of Y_own, so that combination is refused rather than raced.
+        if Y_own.shape[1] > self.n_hvg and torch.cuda.current_stream() != torch.cuda.default_stream():
+            raise RuntimeError("ShardedFlashDeconv with gene selection active must run on torch's default stream")
         from .utils.genes import compute_leverage_scores
         lib = _lib.load()
         dev = Y_own.device
