@@ -239,6 +239,10 @@ def main():
         a.spots, a.genes, a.types, a.sketch_dim, a.family, a.no_cpu_baseline = 1_250_000, 5000, 50, 1024, "gaussian", True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a.gpus)
+    if os.environ.get("FDX_BENCH_SPAWN_ECHO"):      # launcher self-test (tests/test_host.py): report the rank environment
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+                         | {"gpus": a.gpus, "scaling": a.scaling}))
+        return
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -226,3 +226,26 @@ def test_tile_schedule_replays_to_the_countsketch(G, d, NW, JW, GB):
     if G >= 1000 and nblk <= 5:
         assert steps * 4 <= 1.35 * inside.sum(), (steps * 4, inside.sum())
         assert wave_max * NW <= 1.15 * steps
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE) must start N ranks itself - one fresh process per GPU,
+    before anything touches a GPU - and relay rank 0's line.  FDX_BENCH_SPAWN_ECHO makes the ranks report their
+    environment instead of benchmarking."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FDX_BENCH_SPAWN_ECHO"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--scaling", "weak"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["RANK"] == "0" and line["LOCAL_RANK"] == "0" and line["WORLD_SIZE"] == "3" and line["MASTER_ADDR"] == "127.0.0.1"
+    assert line["gpus"] == 3 and line["scaling"] == "weak" and int(line["MASTER_PORT"]) > 0
+    # under torch.distributed.run the environment is already there: no second level of processes
+    env2 = dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True,
+                         timeout=120)
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["RANK"] == "1" and line["WORLD_SIZE"] == "2" and line["scaling"] == "strong"
