@@ -41,6 +41,9 @@ constexpr int TILE_ROWS = 16;
 constexpr int TILE_ROW_PAD = 16;          // bytes between staged rows: a 16-byte shift keeps the DMA destination aligned
 constexpr int LOG_TAB_N = 1921;           // 15 binades x 128 + 1 reciprocals in [2^-15, 1]
 constexpr int LOG_TAB_BASE = 14336;       // (bits of 2^-15) >> 16
+// The table sits at a FIXED place, the top of the 160 KB: its address is then (rounded reciprocal bits >> 13) plus a
+// compile-time constant that fits the 16-bit offset field of ds_read_b64 - no base add, no index mask per element.
+constexpr int LOG_TAB_LDS = 160 * 1024 - LOG_TAB_N * 8;
 
 // Scalars of a launch.  The arrays are separate __restrict__ kernel parameters: only then may the compiler fetch the
 // wave-uniform ones (row_map, ent_base, len_tab) with scalar loads.  As vector loads they would sit in vmcnt behind the
@@ -51,6 +54,17 @@ struct TileArgs {
     int NE, GB, NBLK, RS, jw_used;
 };
 
+// d = a * b + c as one VOP3 instruction with the addend in its own register
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return fma(a, b, c);
+#endif
+}
+
 // log1p(x) for x in [0, 32000): see the header.  logt[i] = -log(c_i), c_i the reciprocal with bit pattern
 // (LOG_TAB_BASE + i) << 16.  uf: 1 + x to float accuracy (only the 8-bit reciprocal is taken from it).
 __device__ __forceinline__ double tile_log1p_core(double x, float uf, const double* logt) {
@@ -58,10 +72,14 @@ __device__ __forceinline__ double tile_log1p_core(double x, float uf, const doub
     bits = (bits + 0x8000u) & 0xFFFF0000u;                   // reciprocal rounded to 8 significant bits
     const double inv = (double)__uint_as_float(bits);
     const double r = fma(x, inv, inv - 1.0);                 // (1 + x) * inv - 1 with one rounding (inv - 1 is exact)
-    const double t = *reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(logt - LOG_TAB_BASE) + ((bits >> 16) << 3));
-    double p = fma(r, -1.0 / 6.0, 0.2);
+    (void)logt;   // the dynamic LDS segment starts at LDS address 0 (no static __shared__ in these kernels): absolute address
+    typedef const double __attribute__((address_space(3))) * lds_cdouble_p;
+    const double t = *(lds_cdouble_p)(size_t)((bits >> 13) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8));
+    // Horner steps whose addend is a non-inline constant: written as three-operand v_fma_f64.  Left to the compiler they
+    // become v_mov_b64 (constant -> destination) + v_fmac_f64, two instructions where one does.
+    double p = fma3(r, -1.0 / 6.0, 0.2);
     p = fma(r, p, -0.25);
-    p = fma(r, p, 1.0 / 3.0);
+    p = fma3(r, p, 1.0 / 3.0);
     p = fma(r, p, -0.5);
     p = fma(r, p, 1.0);
     return fma(r, p, t);
@@ -137,7 +155,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     unsigned short* off_l = reinterpret_cast<unsigned short*>(w_l + NEp);
     double* scales = reinterpret_cast<double*>(off_l + NEp);               // [2][16] scale of a row (log modes)
     int* rowok = reinterpret_cast<int*>(scales + 2 * TILE_ROWS);           // [2][16] every log argument of the row in the fast range
-    double* logt = reinterpret_cast<double*>(rowok + 2 * TILE_ROWS);       // [LOG_TAB_N] (log modes)
+    double* logt = reinterpret_cast<double*>(smem + LOG_TAB_LDS);          // [LOG_TAB_N] (log modes), fixed place: see LOG_TAB_LDS
     for (int i = tid; i < a.NE; i += NT) {
         w_l[i] = w_tab[i];
         off_l[i] = off_tab[i];
@@ -186,7 +204,18 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         const V* src0 = reinterpret_cast<const V*>(r0);
         const V* src1 = reinterpret_cast<const V*>(r1);
         double p0 = 0.0, p1 = 0.0;
-        T mx0 = (T)0, mx1 = (T)0, mn0 = (T)0, mn1 = (T)0;
+        // extremes without compare-select pairs: max by v_max, "some element negative" by OR-ing the raw bits (the sign bit
+        // survives; NaN / Inf show up in the sum)
+        T mx0 = (T)0, mx1 = (T)0;
+        unsigned long long sg0 = 0ULL, sg1 = 0ULL;
+        auto bits_of = [](T v) -> unsigned long long {
+            if constexpr (sizeof(T) == 4) return (unsigned long long)__float_as_uint((float)v) << 32;
+            else return (unsigned long long)__double_as_longlong((double)v);
+        };
+        auto vmax = [](T a_, T b_) -> T {
+            if constexpr (sizeof(T) == 4) return (T)fmaxf((float)a_, (float)b_);
+            else return (T)fmax((double)a_, (double)b_);
+        };
         for (int v0 = 0; v0 < nvec; v0 += 512) {
             V x0[8], x1[8];
 #pragma unroll
@@ -203,19 +232,19 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 if (v < nvec) {
 #pragma unroll
                     for (int e = 0; e < PER; ++e) {
-                        if (r0) { p0 += (double)x0[u][e]; mx0 = x0[u][e] > mx0 ? x0[u][e] : mx0; mn0 = x0[u][e] < mn0 ? x0[u][e] : mn0; }
-                        if (TWO && r1) { p1 += (double)x1[u][e]; mx1 = x1[u][e] > mx1 ? x1[u][e] : mx1; mn1 = x1[u][e] < mn1 ? x1[u][e] : mn1; }
+                        if (r0) { p0 += (double)x0[u][e]; mx0 = vmax(mx0, x0[u][e]); sg0 |= bits_of(x0[u][e]); }
+                        if (TWO && r1) { p1 += (double)x1[u][e]; mx1 = vmax(mx1, x1[u][e]); sg1 |= bits_of(x1[u][e]); }
                     }
                 }
             }
         }
         // NaN / Inf anywhere in the row makes the sum, hence the scale, NaN or 0 * Inf below: the test fails
         const double s0 = tile_row_scale<MODE>(wave_sum(p0));
-        const bool ok0 = wave_max((double)mx0) * s0 < 32000.0 && -wave_max(-(double)mn0) >= 0.0;
+        const bool ok0 = wave_max((double)mx0) * s0 < 32000.0 && !__any((long long)sg0 < 0);
         if (lane == 0 && r0) { out_scale[i0] = s0; out_ok[i0] = ok0 ? 1 : 0; }
         if (TWO && r1) {
             const double s1 = tile_row_scale<MODE>(wave_sum(p1));
-            const bool ok1 = wave_max((double)mx1) * s1 < 32000.0 && -wave_max(-(double)mn1) >= 0.0;
+            const bool ok1 = wave_max((double)mx1) * s1 < 32000.0 && !__any((long long)sg1 < 0);
             if (lane == 0) { out_scale[i1] = s1; out_ok[i1] = ok1 ? 1 : 0; }
         }
     };
@@ -491,7 +520,10 @@ static TileCfg tile_cfg(int mode) {
 
 static size_t tile_lds_bytes(int RS, int NE, int mode) {
     const size_t NEp = ((size_t)NE + 7) & ~(size_t)7;
-    return 2 * (size_t)TILE_ROWS * RS + NEp * 10 + 2 * TILE_ROWS * (8 + 4) + (mode != FDX_PRE_RAW ? (size_t)LOG_TAB_N * 8 : 0);
+    const size_t below = 2 * (size_t)TILE_ROWS * RS + NEp * 10 + 2 * TILE_ROWS * (8 + 4);
+    if (mode == FDX_PRE_RAW) return below;
+    // log modes: the table has a fixed place at the top of the 160 KB (LOG_TAB_LDS); everything else must end below it
+    return below <= (size_t)LOG_TAB_LDS ? (size_t)160 * 1024 : (size_t)161 * 1024;
 }
 
 // Builds (once per SketchPlan and input type) the schedule for the largest column block that fits the LDS.
