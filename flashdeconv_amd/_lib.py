@@ -109,6 +109,8 @@ SIGNATURES = {
     "fdx_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "fdx_stream_sync": (c_int, [c_void_p]),
     "fdx_sketch": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_i64, p_i32, p_double, c_i32, c_i32, p_double]),
+    "fdx_prepare_csr_dev": (c_int, [ctypes.POINTER(CsrView), p_i32, c_i32, p_double, c_i32, p_i32, p_double, p_double, c_i32, c_i32,
+                                    c_i32, c_void_p, c_i64, c_void_p, p_double, ctypes.POINTER(c_double), c_void_p]),
     "fdx_gram_xty": (c_int, [p_double, p_double, c_i64, c_i32, c_i32, p_double, p_double]),
     "fdx_objective": (c_int, [c_void_p, p_double, p_double, p_double, c_i64, c_i32, c_double, c_double, c_double, p_double]),
     "fdx_comm_unique_id": (c_int, [c_void_p]),

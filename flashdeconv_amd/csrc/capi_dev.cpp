@@ -1,6 +1,7 @@
 // Device-pointer C-ABI building blocks used by the spot-sharded multi-GPU driver (see include/fdx.h).
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <vector>
 
 #include "fdx_graph.h"
@@ -171,6 +172,69 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
     if (XtX_out_host)
         FDX_HIP(hipMemcpyAsync(XtX_out_host, XtX_out_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
+    if (YtY_partial_out) *YtY_partial_out = yty;
+    return 0;
+}
+
+// The same for a CSR shard (core/deconv.py:181-188 sparse log-CPM rule, core/sketching.py:194-199): the own rows stay
+// sparse in HBM; gene_idx selects G of the matrix's columns (NULL = all, in order).
+int fdx_prepare_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t G, const double* X, int32_t K,
+                        const int32_t* bucket, const double* weight_y, const double* weight_x, int32_t d, int32_t mode_y,
+                        int32_t mode_x, double* H_out_dev, int64_t ldh, double* XtX_out_dev, double* XtX_out_host,
+                        double* YtY_partial_out, void* stream) {
+    FDX_REQUIRE(Y != nullptr && Y->n >= 0 && Y->G > 0, "fdx_prepare_csr_dev: bad matrix");
+    FDX_REQUIRE(Y->dtype == FDX_F32 || Y->dtype == FDX_F64, "fdx_prepare_csr_dev: dtype must be FDX_F32 or FDX_F64");
+    FDX_REQUIRE(G > 0 && K > 0 && d > 0 && (gene_idx || G == Y->G), "fdx_prepare_csr_dev: bad shape");
+    FDX_REQUIRE(X && bucket && weight_y && weight_x && H_out_dev && XtX_out_dev, "fdx_prepare_csr_dev: null array");
+    FDX_REQUIRE(mode_y == FDX_PRE_RAW || mode_y == FDX_PRE_LOG_CPM_SPARSE, "fdx_prepare_csr_dev: mode_y must be FDX_PRE_RAW or FDX_PRE_LOG_CPM_SPARSE");
+    const long long n = Y->n;
+    FDX_REQUIRE(ldh >= n, "fdx_prepare_csr_dev: leading dimension too small");
+    hipStream_t st = (hipStream_t)stream;
+    struct Slot { double w; int bucket; int pad; };
+    FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(Slot), "fdx_prepare_csr_dev: gene slot layout mismatch");
+    const int G_all = Y->G;
+    std::vector<Slot> slots((size_t)G_all, Slot{0.0, -1, 0});
+    for (int j = 0; j < G; ++j) {
+        const int c = gene_idx ? gene_idx[j] : j;
+        FDX_REQUIRE(c >= 0 && c < G_all, "fdx_prepare_csr_dev: gene index out of range");
+        FDX_REQUIRE(slots[(size_t)c].bucket < 0, "fdx_prepare_csr_dev: duplicate gene index");
+        FDX_REQUIRE(bucket[j] >= 0 && bucket[j] < d, "fdx_prepare_csr_dev: bucket index out of range");
+        slots[(size_t)c] = Slot{weight_y[j], bucket[j], 0};
+    }
+    const int sel_words = (G_all + 31) / 32;
+    std::vector<unsigned> bits((size_t)sel_words, 0u);
+    for (int c = 0; c < G_all; ++c)
+        if (slots[(size_t)c].bucket >= 0) bits[(size_t)c >> 5] |= 1u << (c & 31);
+    DevBuf dSlots, dBits, dX, dXs, dYs, dRowSq, dSum;
+    FDX_TRY(dSlots.alloc(slots.size() * sizeof(Slot)));
+    FDX_TRY(dBits.alloc(bits.size() * sizeof(unsigned)));
+    FDX_HIP(hipMemcpyAsync(dSlots.p, slots.data(), slots.size() * sizeof(Slot), hipMemcpyHostToDevice, st));
+    FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    std::shared_ptr<SketchPlan> plan_x;
+    FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, st, &plan_x));
+    FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
+    FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
+    FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, plan_x->dev(), dXs.as<double>(), d, nullptr, st));
+    FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, XtX_out_dev, K, nullptr, st));
+    double yty = 0.0;
+    if (n > 0) {
+        const long long chunk = std::min<long long>(n, 1LL << 18);
+        FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
+        FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
+        FDX_TRY(dSum.alloc(sizeof(double)));
+        for (long long r0 = 0; r0 < n; r0 += chunk) {
+            const long long nr = std::min(chunk, n - r0);
+            FDX_TRY(launch_sketch_csr((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, nullptr, r0, nr, d, mode_y, dSlots.p,
+                                      dBits.as<unsigned>(), sel_words, dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
+            FDX_TRY(launch_xyt(dXs.as<double>(), dYs.as<double>(), d, nr, d, K, H_out_dev + r0, ldh, nullptr, st));
+        }
+        FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));
+        FDX_HIP(hipMemcpyAsync(&yty, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (XtX_out_host)
+        FDX_HIP(hipMemcpyAsync(XtX_out_host, XtX_out_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));      // the host tables above are stack objects
     if (YtY_partial_out) *YtY_partial_out = yty;
     return 0;
 }

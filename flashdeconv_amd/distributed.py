@@ -396,6 +396,8 @@ class ShardedFlashDeconv:
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         X = np.ascontiguousarray(X, dtype=np.float64)
         K, G = X.shape
+        if _lib.is_torch_sparse_csr(Y_own):
+            return self._fit_transform_csr(Y_own, X)
         if Y_own.dtype not in (torch.float32, torch.float64):
             Y_own = Y_own.to(torch.float32)
         Y_own = Y_own.contiguous()
@@ -464,7 +466,82 @@ class ShardedFlashDeconv:
                                        int(self.sketch_dim), mode_y, mode_x, ctypes.c_void_p(H.data_ptr()), ld,
                                        ctypes.c_void_p(XtX.data_ptr()), _lib.ptr_f64(XtX_h), ctypes.byref(yty), st))
         t0 = self._tick("prepare", t0)
-        t = torch.tensor([yty.value], dtype=torch.float64, device=dev)
+        return self._solve_shard(H, XtX, XtX_h, yty.value, K, ld)
+
+    def _fit_transform_csr(self, Y_own, X):
+        """CSR shard (the own rows as a CUDA torch.sparse_csr tensor; reference core/deconv.py:181-188, utils/genes.py:52-83):
+        the rows stay sparse in HBM, gene statistics are all-reduced, selected columns are filtered inside the sketch kernel."""
+        import torch
+        from .core.sketching import countsketch_tables
+        from .utils import genes as _genes
+        from .utils.genes import compute_leverage_scores
+        lib = _lib.load()
+        dev = Y_own.device
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        K, G_all = X.shape
+        assert tuple(Y_own.shape) == (self.n_own, G_all)
+        if self.preprocess not in ("log_cpm", "raw", "pearson"):
+            raise ValueError(f"Unknown preprocess method: {self.preprocess}. Choose from 'log_cpm', 'pearson', or 'raw'.")
+        csr = _lib.CsrOnDevice.from_torch(Y_own)
+        try:
+            self.gene_idx_ = np.arange(G_all, dtype=np.intp)
+            colsum = None
+            if G_all > self.n_hvg or self.preprocess == "pearson":
+                sums = torch.zeros((3, G_all), dtype=torch.float64, device=dev)
+                if self.n_own:
+                    mean_r, var_r, col_r = csr.gene_moments(want_colsum=True)
+                    sums[0], sums[1] = combine_moment_sums(mean_r, var_r, self.n_own, dev)
+                    sums[2] = torch.from_numpy(col_r).to(dev)
+                self.comm.all_reduce_sum(sums)
+                colsum = sums[2].cpu().numpy()
+                if G_all > self.n_hvg:
+                    mean, var = moments_from_sums(sums[0].cpu().numpy(), sums[1].cpu().numpy(), self.n_total_spots)
+                    hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
+                    markers, _ = _genes.select_markers(X, n_markers=self.n_markers_per_type)
+                    self.gene_idx_ = np.union1d(hvg, markers).astype(np.intp)
+                    if len(self.gene_idx_) == 0:
+                        raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
+            Xs = np.ascontiguousarray(X[:, self.gene_idx_])
+            G = Xs.shape[1]
+            job, self._lev_job = getattr(self, "_lev_job", None), None
+            lev = job[1].result() if (job is not None and job[0].shape == Xs.shape and np.array_equal(job[0], Xs)) else compute_leverage_scores(Xs)
+            bucket, weight = countsketch_tables(G, self.sketch_dim, lev, self.random_state)
+            weight_y = weight_x = weight
+            mode_y = mode_x = _lib.PRE_RAW
+            if self.preprocess == "log_cpm":
+                mode_y, mode_x = _lib.PRE_LOG_CPM_SPARSE, _lib.PRE_LOG_CPM
+            elif self.preprocess == "pearson":
+                mu_y = colsum[self.gene_idx_] / self.n_total_spots + 1e-6
+                mu_x = Xs.mean(axis=0) + 1e-6
+                weight_y = weight / np.sqrt(mu_y + mu_y ** 2 / 100.0)
+                weight_x = weight / np.sqrt(mu_x + mu_x ** 2 / 100.0)
+            n_own, n_total = self.n_own, self.n_own + self.n_halo
+            ld = ((n_total + 1 + 63) // 64) * 64
+            H = torch.zeros((K, ld), dtype=torch.float64, device=dev)
+            XtX = torch.empty((K, K), dtype=torch.float64, device=dev)
+            XtX_h = np.empty((K, K))
+            yty = ctypes.c_double(0.0)
+            gi32 = np.ascontiguousarray(self.gene_idx_, dtype=np.int32)
+            b32 = np.ascontiguousarray(bucket, dtype=np.int32)
+            wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
+            _lib.check(lib.fdx_prepare_csr_dev(ctypes.byref(csr.view), _lib.ptr_i32(gi32), G, _lib.ptr_f64(Xs), K, _lib.ptr_i32(b32),
+                                               _lib.ptr_f64(wy), _lib.ptr_f64(wx), int(self.sketch_dim), mode_y, mode_x,
+                                               ctypes.c_void_p(H.data_ptr()), ld, ctypes.c_void_p(XtX.data_ptr()), _lib.ptr_f64(XtX_h),
+                                               ctypes.byref(yty), st))
+        finally:
+            csr.free()
+        return self._solve_shard(H, XtX, XtX_h, yty.value, K, ld)
+
+    def _solve_shard(self, H, XtX, XtX_h, yty_part, K, ld):
+        """Everything after H / XtX exist for the own rows: global YtY, lambda, the sharded BCD solve, the objective,
+        normalisation (core/deconv.py:358-398)."""
+        import torch
+        lib = _lib.load()
+        dev = H.device
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        n_own, n_total = self.n_own, self.n_own + self.n_halo
+        t0 = time.perf_counter()
+        t = torch.tensor([yty_part], dtype=torch.float64, device=dev)
         self.comm.all_reduce_sum(t)
         YtY = float(t.item())
         dmean = diag_mean(XtX_h)

@@ -270,6 +270,13 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
                     const double* X, int32_t K, const int32_t* bucket, const double* weight_y, const double* weight_x,
                     int32_t d, int32_t mode_y, int32_t mode_x, double* H_out_dev, int64_t ldh, double* XtX_out_dev,
                     double* XtX_out_host, double* YtY_partial_out, void* stream);
+/* The same for a shard kept sparse in HBM (scipy.sparse / torch CSR input: core/deconv.py:181-188, core/sketching.py:194-199):
+ * Y = the own rows as an fdx_csr_view, gene_idx = the G selected columns (NULL = all); mode_y FDX_PRE_RAW or
+ * FDX_PRE_LOG_CPM_SPARSE. */
+int fdx_prepare_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t G, const double* X, int32_t K,
+                        const int32_t* bucket, const double* weight_y, const double* weight_x, int32_t d, int32_t mode_y,
+                        int32_t mode_x, double* H_out_dev, int64_t ldh, double* XtX_out_dev, double* XtX_out_host,
+                        double* YtY_partial_out, void* stream);
 /* beta[k*ld + i] = 1/K for i < n_fill, 0 beyond (core/solver.py:372 plus the zero pad row). */
 int fdx_init_beta_dev(double* beta_dev, int64_t ld, int64_t n_fill, int32_t K, void* stream);
 /* One BCD sweep of the own spots of `g` (core/solver.py:104-184).  stats_dev: (max_iter, 128) uint64 slots zeroed by

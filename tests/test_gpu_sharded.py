@@ -184,6 +184,23 @@ def test_sharded_class_world1_equals_flashdeconv():
         got2[own2.cpu().numpy()] = P2.cpu().numpy()
         assert m2.info_["n_iterations"] == ref2.info_["n_iterations"]
         np.testing.assert_allclose(got2, ref2.proportions_, rtol=1e-9, atol=1e-12)
+        # the same shard handed over as CSR rows: statistics, selection and the sketch all read the sparse rows
+        import scipy.sparse as sp
+        for pre in ("log_cpm", "pearson", "raw"):
+            kw3 = dict(kw, preprocess=pre)
+            ref3 = FlashDeconv(**kw3).fit(sp.csr_matrix(Yc), Xc, cc)
+            m3 = ShardedFlashDeconv(**kw3)
+            own3 = m3.plan(torch.from_numpy(cc).to(dev))
+            S = sp.csr_matrix(Yc[own3.cpu().numpy()].astype(np.float32))
+            Yt = torch.sparse_csr_tensor(torch.from_numpy(S.indptr.astype(np.int64)), torch.from_numpy(S.indices.astype(np.int64)),
+                                         torch.from_numpy(S.data), size=S.shape).to(dev)
+            P3 = m3.fit_transform(Yt, Xc)
+            assert np.array_equal(m3.gene_idx_, ref3.gene_idx_), pre
+            got3 = np.zeros((3000, 6))
+            got3[own3.cpu().numpy()] = P3.cpu().numpy()
+            assert m3.info_["n_iterations"] == ref3.info_["n_iterations"], pre
+            np.testing.assert_allclose(got3, ref3.proportions_, rtol=1e-9, atol=1e-12, err_msg=pre)
+            np.testing.assert_allclose(m3.info_["final_objective"], ref3.info_["final_objective"], rtol=1e-10, err_msg=pre)
     finally:
         dist.destroy_process_group()
 
