@@ -125,6 +125,7 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_i64, ctypes.POINTER(SolveInfo), p_double, p_i32, c_void_p]),
     "fdx_tile_schedule": (c_int, [p_i32, p_double, c_i32, c_i32, c_i32, c_i32, c_i32, p_i32, p_i32, c_void_p, p_i32, p_double,
                                   c_void_p, c_i64]),
+    "fdx_rowreg_schedule": (c_int, [p_i32, p_double, c_i32, c_i32, p_i32, p_i32, p_i32, p_double, c_void_p, c_void_p, c_i64]),
     "fdx_column_sums": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_double]),
     "fdx_graph_build_knn": (c_int, [p_double, c_i64, c_i32, c_i32, ctypes.POINTER(c_void_p)]),
     "fdx_graph_build_radius": (c_int, [p_double, c_i64, c_i32, c_double, ctypes.POINTER(c_void_p)]),

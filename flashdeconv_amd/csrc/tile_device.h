@@ -1,0 +1,86 @@
+// Device helpers shared by the tile kernel (tile_kernels.cpp) and the row-register kernel (rowreg_kernels.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_math.h"
+#include "fdx_internal.h"
+
+namespace fdx {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TILE_ROWS = 16;
+constexpr int LOG_TAB_N = 1921;           // 15 binades x 128 + 1 reciprocals in [2^-15, 1]
+constexpr int LOG_TAB_BASE = 14336;       // (bits of 2^-15) >> 16
+// The table sits at a FIXED place, the top of the 160 KB: its address is then (rounded reciprocal bits >> 13) plus a
+// compile-time constant that fits the 16-bit offset field of ds_read_b64 - no base add, no index mask per element.
+constexpr int LOG_TAB_LDS = 160 * 1024 - LOG_TAB_N * 8;
+
+// d = a * b + c as one VOP3 instruction with the addend in its own register
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return fma(a, b, c);
+#endif
+}
+
+// log1p(x) for x in [0, 32000): see the header.  logt[i] = -log(c_i), c_i the reciprocal with bit pattern
+// (LOG_TAB_BASE + i) << 16.  uf: 1 + x to float accuracy (only the 8-bit reciprocal is taken from it).
+__device__ __forceinline__ double tile_log1p_core(double x, float uf, const double* logt) {
+    unsigned bits = __float_as_uint(__builtin_amdgcn_rcpf(uf));
+    bits = (bits + 0x8000u) & 0xFFFF0000u;                   // reciprocal rounded to 8 significant bits
+    const double inv = (double)__uint_as_float(bits);
+    const double r = fma(x, inv, inv - 1.0);                 // (1 + x) * inv - 1 with one rounding (inv - 1 is exact)
+    (void)logt;   // the dynamic LDS segment starts at LDS address 0 (no static __shared__ in these kernels): absolute address
+    typedef const double __attribute__((address_space(3))) * lds_cdouble_p;
+    const double t = *(lds_cdouble_p)(size_t)((bits >> 13) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8));
+    // Horner steps whose addend is a non-inline constant: written as three-operand v_fma_f64.  Left to the compiler they
+    // become v_mov_b64 (constant -> destination) + v_fmac_f64, two instructions where one does.
+    double p = fma3(r, -1.0 / 6.0, 0.2);
+    p = fma(r, p, -0.25);
+    p = fma3(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r, p, 1.0);
+    return fma(r, p, t);
+}
+__device__ __forceinline__ double tile_log1p_fast(double x, const double* logt) { return tile_log1p_core(x, 1.0f + (float)x, logt); }
+// the same for y * scale with y already a float: 1 + x comes from one float fma
+__device__ __forceinline__ double tile_log1p_scaled(float y, double scale, float scale_f, const double* logt) {
+    return tile_log1p_core((double)y * scale, fmaf(y, scale_f, 1.0f), logt);
+}
+__device__ __forceinline__ double tile_log1p_scaled(double y, double scale, float, const double* logt) {
+    const double x = y * scale;
+    return tile_log1p_core(x, 1.0f + (float)x, logt);
+}
+// Anything outside the fast range (negative, NaN, huge) takes the library function, as the reference would.  Kept out of
+// line: inlined into every gather loop it costs registers on the path that matters.
+static __device__ __attribute__((noinline)) double tile_log1p_slow(double x) { return log1p(x); }
+__device__ __forceinline__ double tile_log1p(double x, const double* logt) {
+    if (__builtin_expect(!(x >= 0.0) || !(x < 32000.0), 0)) return tile_log1p_slow(x);
+    return tile_log1p_fast(x, logt);
+}
+
+// the same with the library function inlined (no call: a call site makes the caller spill its live registers around it)
+__device__ __forceinline__ double tile_log1p_general(double x, const double* logt) {
+    if (__builtin_expect(!(x >= 0.0) || !(x < 32000.0), 0)) return log1p(x);
+    return tile_log1p_fast(x, logt);
+}
+
+// scale of one row for the log modes
+template <int MODE> __device__ __forceinline__ double tile_row_scale(double sum) {
+    if (MODE == FDX_PRE_LOG_CPM) return (1.0 / (sum + 1e-10)) * 1e4;          // y / (rowsum + 1e-10) * 1e4   (deconv.py:190)
+    if (sum == 0.0) sum = 1.0;                                               // lib_size[lib_size == 0] = 1  (deconv.py:183-185)
+    return 1e4 / sum;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the LDS-DMA
+// pieces of the next block, which are meant to stay in flight across the reduction at the end of a tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// -log of every 8-bit reciprocal in [2^-15, 1] (LOG_TAB_N doubles), one copy per device; NULL on failure
+const double* log_table_dev(hipStream_t st);
+
+}  // namespace fdx

@@ -31,19 +31,12 @@
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
 #include "sketch_plan.h"
+#include "tile_device.h"
 #include "tile_plan.h"
 
 namespace fdx {
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-constexpr int TILE_ROWS = 16;
 constexpr int TILE_ROW_PAD = 16;          // bytes between staged rows: a 16-byte shift keeps the DMA destination aligned
-constexpr int LOG_TAB_N = 1921;           // 15 binades x 128 + 1 reciprocals in [2^-15, 1]
-constexpr int LOG_TAB_BASE = 14336;       // (bits of 2^-15) >> 16
-// The table sits at a FIXED place, the top of the 160 KB: its address is then (rounded reciprocal bits >> 13) plus a
-// compile-time constant that fits the 16-bit offset field of ds_read_b64 - no base add, no index mask per element.
-constexpr int LOG_TAB_LDS = 160 * 1024 - LOG_TAB_N * 8;
 
 // Scalars of a launch.  The arrays are separate __restrict__ kernel parameters: only then may the compiler fetch the
 // wave-uniform ones (row_map, ent_base, len_tab) with scalar loads.  As vector loads they would sit in vmcnt behind the
@@ -53,53 +46,6 @@ struct TileArgs {
     int G, d, K;
     int NE, GB, NBLK, RS, jw_used;
 };
-
-// d = a * b + c as one VOP3 instruction with the addend in its own register
-__device__ __forceinline__ double fma3(double a, double b, double c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-#else
-    return fma(a, b, c);
-#endif
-}
-
-// log1p(x) for x in [0, 32000): see the header.  logt[i] = -log(c_i), c_i the reciprocal with bit pattern
-// (LOG_TAB_BASE + i) << 16.  uf: 1 + x to float accuracy (only the 8-bit reciprocal is taken from it).
-__device__ __forceinline__ double tile_log1p_core(double x, float uf, const double* logt) {
-    unsigned bits = __float_as_uint(__builtin_amdgcn_rcpf(uf));
-    bits = (bits + 0x8000u) & 0xFFFF0000u;                   // reciprocal rounded to 8 significant bits
-    const double inv = (double)__uint_as_float(bits);
-    const double r = fma(x, inv, inv - 1.0);                 // (1 + x) * inv - 1 with one rounding (inv - 1 is exact)
-    (void)logt;   // the dynamic LDS segment starts at LDS address 0 (no static __shared__ in these kernels): absolute address
-    typedef const double __attribute__((address_space(3))) * lds_cdouble_p;
-    const double t = *(lds_cdouble_p)(size_t)((bits >> 13) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8));
-    // Horner steps whose addend is a non-inline constant: written as three-operand v_fma_f64.  Left to the compiler they
-    // become v_mov_b64 (constant -> destination) + v_fmac_f64, two instructions where one does.
-    double p = fma3(r, -1.0 / 6.0, 0.2);
-    p = fma(r, p, -0.25);
-    p = fma3(r, p, 1.0 / 3.0);
-    p = fma(r, p, -0.5);
-    p = fma(r, p, 1.0);
-    return fma(r, p, t);
-}
-__device__ __forceinline__ double tile_log1p_fast(double x, const double* logt) { return tile_log1p_core(x, 1.0f + (float)x, logt); }
-// the same for y * scale with y already a float: 1 + x comes from one float fma
-__device__ __forceinline__ double tile_log1p_scaled(float y, double scale, float scale_f, const double* logt) {
-    return tile_log1p_core((double)y * scale, fmaf(y, scale_f, 1.0f), logt);
-}
-__device__ __forceinline__ double tile_log1p_scaled(double y, double scale, float, const double* logt) {
-    const double x = y * scale;
-    return tile_log1p_core(x, 1.0f + (float)x, logt);
-}
-// Anything outside the fast range (negative, NaN, huge) takes the library function, as the reference would.  Kept out of
-// line: inlined into every gather loop it costs registers on the path that matters.
-__device__ __attribute__((noinline)) double tile_log1p_slow(double x) { return log1p(x); }
-__device__ __forceinline__ double tile_log1p(double x, const double* logt) {
-    if (__builtin_expect(!(x >= 0.0) || !(x < 32000.0), 0)) return tile_log1p_slow(x);
-    return tile_log1p_fast(x, logt);
-}
 
 template <typename T> struct TileVec;
 template <> struct TileVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
@@ -111,19 +57,8 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_base) 
                                      (void __attribute__((address_space(3)))*)lds_base, 16, 0, 0);
 }
 
-// scale of one row for the log modes
-template <int MODE> __device__ __forceinline__ double tile_row_scale(double sum) {
-    if (MODE == FDX_PRE_LOG_CPM) return (1.0 / (sum + 1e-10)) * 1e4;          // y / (rowsum + 1e-10) * 1e4   (deconv.py:190)
-    if (sum == 0.0) sum = 1.0;                                               // lib_size[lib_size == 0] = 1  (deconv.py:183-185)
-    return 1e4 / sum;
-}
-
 // group lengths are stored 8 to a 64-bit word: JW rounded up
 __host__ __device__ constexpr int JW_PAD(int jw) { return (jw + 7) & ~7; }
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the LDS-DMA
-// pieces of the next block, which are meant to stay in flight across the reduction at the end of a tile.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Waves of a workgroup: NWC consumers (they own the bucket slots: gather, MFMA, reduction) and NWL loaders (they only
 // stage: a wave that issues vector-memory instructions sits at the issue port while the memory pipeline takes a CU's
@@ -135,9 +70,13 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     const TileArgs a, const T* __restrict__ Yp, const int* __restrict__ row_map, const double* __restrict__ Xs,
     double* __restrict__ H, double* __restrict__ row_sumsq, const double* __restrict__ w_tab,
     const unsigned short* __restrict__ off_tab, const unsigned char* __restrict__ len_tab,
-    const int* __restrict__ ent_base, const int* __restrict__ slot_bucket, const double* __restrict__ log_tab) {
+    const int* __restrict__ ent_base, const int* __restrict__ slot_bucket, const double* __restrict__ log_tab,
+    const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename TileVec<T>::type V;
+    // list mode (tile_list != NULL): only the *tile_count tiles listed are worked on - the tiles the row-register kernel
+    // (rowreg_kernels.cpp) leaves to this kernel's general log1p; usually none, so look before copying any table
+    if (tile_list && (long long)blockIdx.x >= (long long)*tile_count) return;
     constexpr int PER = 16 / sizeof(T);
     constexpr int NT = (NWC + NWL) * 64;
     constexpr int NWS = NWL > 0 ? NWL : NWC;                                // waves that stage
@@ -162,9 +101,10 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     }
     if (MODE != FDX_PRE_RAW)
         for (int i = tid; i < LOG_TAB_N; i += NT) logt[i] = log_tab[i];
-    const long long n_tiles = (a.n + TILE_ROWS - 1) / TILE_ROWS;
-    long long tile = blockIdx.x;
+    const long long n_tiles = tile_list ? (long long)*tile_count : (a.n + TILE_ROWS - 1) / TILE_ROWS;
+    long long tile = blockIdx.x;                                            // position in the list, or the tile itself
     if (tile >= n_tiles) return;
+    auto tile_id = [&](long long t) -> long long { return tile_list ? (long long)tile_list[t] : t; };
 
     // ---- staging (loader waves, or every wave when NWL = 0): wave lw stages rows lw, lw + NWS, ...
     const int lw = NWL > 0 ? wave - NWC : wave;
@@ -172,9 +112,10 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
 #pragma unroll
         for (int k = 0; k < RPL; ++k) {
             const int rr = lw + NWS * k;
-            const long long sp = t * TILE_ROWS + rr;
             rp[k] = nullptr;
-            if (rr < TILE_ROWS && t < n_tiles && sp < a.n) {
+            if (rr >= TILE_ROWS || t >= n_tiles) continue;
+            const long long sp = tile_id(t) * TILE_ROWS + rr;
+            if (sp < a.n) {
                 const long long row = row_map ? (long long)row_map[sp] : sp;
                 rp[k] = Yp + (size_t)row * (size_t)a.ldy;
             }
@@ -449,7 +390,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             red_sq[wave * 64 + lane] = sq;
         }
         lds_barrier();
-        const long long s0 = tile * TILE_ROWS;
+        const long long s0 = tile_id(tile) * TILE_ROWS;
         for (int o = tid; o < TS; o += NWC * 64) {
             double sum = 0.0;
 #pragma unroll
@@ -479,7 +420,7 @@ struct TilePlanDevice {
     size_t lds = 0;
 };
 
-static const double* log_table_dev(hipStream_t st) {   // -log of every 8-bit reciprocal in [2^-15, 1], one copy per device
+const double* log_table_dev(hipStream_t st) {   // -log of every 8-bit reciprocal in [2^-15, 1], one copy per device
     static std::mutex mu;
     static double* tabs[64] = {};
     int dev = 0;
@@ -607,6 +548,8 @@ struct TileLaunch {
     const int* ent_base;
     const int* slot_bucket;
     const double* log_tab;
+    const int* tile_list;
+    const int* tile_count;
 };
 
 template <typename T, int MODE, int NWC, int NWL, int JW>
@@ -615,7 +558,8 @@ static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hip
                                : (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 2>;
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
-                    (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab};
+                    (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab,
+                    (void*)&L.tile_list, (void*)&L.tile_count};
     FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3((NWC + NWL) * 64), args, lds, st));
     return 0;
 }
@@ -641,7 +585,7 @@ static int launch_tile_mode(const TileLaunch& L, int mode, int NWC, int TT, size
 // Call only when tile_sketch_ok(...) holds.
 int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
-                       hipStream_t st) {
+                       hipStream_t st, const int* tile_list, const int* tile_count) {
     if (n <= 0) return 0;
     const TilePlanDevice* t = plan.owner ? tile_plan_for(*plan.owner, dtype, mode, K, st) : nullptr;
     if (!t) return fail(FDX_ERR_INVALID, "tile sketch: no schedule for this shape");
@@ -653,6 +597,7 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     L.w_tab = t->w.as<double>(); L.off_tab = t->off.as<unsigned short>(); L.len_tab = t->len.as<unsigned char>();
     L.ent_base = t->ent_base.as<int>(); L.slot_bucket = t->slot_bucket.as<int>();
     L.log_tab = nullptr;
+    L.tile_list = tile_list; L.tile_count = tile_list ? tile_count : nullptr;
     if (mode != FDX_PRE_RAW) {
         L.log_tab = log_table_dev(st);
         if (!L.log_tab) return fail(FDX_ERR_HIP, "tile sketch: log table upload failed");

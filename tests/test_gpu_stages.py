@@ -202,3 +202,37 @@ def test_log_cpm_transform_accuracy():
         # the row sum is reduced in a different order on the device (~1e-16 relative on the scale)
         np.testing.assert_allclose(out, want, rtol=2e-14, atol=0)
         assert np.all(out[5] == 0.0)
+
+
+@pytest.mark.parametrize("n,G,K,d,mode", [(1000, 2000, 30, 512, "log_cpm"), (333, 1996, 12, 512, "log_cpm"),
+                                          (517, 2048, 7, 500, "log_cpm"), (400, 520, 20, 64, "log_cpm"),
+                                          (1000, 1200, 17, 256, "log_cpm")])
+def test_row_register_kernel_matches_the_tile_kernel_and_the_oracle(n, G, K, d, mode, monkeypatch):
+    """The opt-in single-read log path (csrc/rowreg_kernels.cpp, FDX_ROWREG=1): float32 counts, spot counts that are not
+    whole tiles, gene counts that are not whole 256-gene blocks, rows with negative / NaN entries (left to the tile kernel
+    through the redo list).  Against the oracle fit and against the default (tile kernel) fit."""
+    import datagen
+    import fdx_oracle as orc
+    from flashdeconv_amd import FlashDeconv
+    Y, X, coords, _ = datagen.count_like(n, G, K, seed=n + G)
+    Y = Y.astype(np.float32)
+    kw = dict(sketch_dim=d, preprocess=mode, n_hvg=G, max_iter=15, random_state=3)
+    want = orc.fit(Y, X, coords, sketch_dim=d, preprocess_method=mode, n_hvg=G, max_iter=15, random_state=3)
+    a = FlashDeconv(**kw).fit(Y, X, coords)
+    monkeypatch.setenv("FDX_ROWREG", "1")
+    b = FlashDeconv(**kw).fit(Y, X, coords)
+    assert b.info_["n_iterations"] == want["info"]["n_iterations"]
+    # float32 input: the reference computes log-CPM in float32, the device in float64 (DESIGN.md section 4, deviation ii)
+    assert rel_fro(b.beta_, want["beta"]) < 1e-5
+    assert rel_fro(b.beta_, a.beta_) < 1e-11
+    # rows outside the fast range of the table-driven log1p: the tile kernel recomputes their tiles
+    Yb = Y.copy()
+    Yb[7, 3] = -2.0
+    Yb[n - 1, G - 1] = np.nan
+    Yb[n // 2, 11] = -0.25
+    b2 = FlashDeconv(**kw).fit(Yb, X, coords)
+    monkeypatch.delenv("FDX_ROWREG")
+    a2 = FlashDeconv(**kw).fit(Yb, X, coords)
+    fin = np.isfinite(a2.beta_)
+    assert np.array_equal(np.isfinite(b2.beta_), fin)
+    assert rel_fro(b2.beta_[fin], a2.beta_[fin]) < 1e-11

@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from flashdeconv_amd import FlashDeconv  # noqa: E402
 
-SWITCHES = ("FDX_TILE_CFG", "FDX_NO_TILE", "FDX_FUSED", "FDX_NO_FUSED")
+SWITCHES = ("FDX_TILE_CFG", "FDX_NO_TILE", "FDX_FUSED", "FDX_NO_FUSED", "FDX_ROWREG")
 
 
 def main():
@@ -22,7 +22,7 @@ def main():
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 30
     d = int(sys.argv[4]) if len(sys.argv) > 4 else 512
     dev = torch.device("cuda:0")
-    variants = [("tile", {}), ("tile12+4", {"FDX_TILE_CFG": "12"}), ("tile16+0", {"FDX_TILE_CFG": "16"}), ("tile8+2", {"FDX_TILE_CFG": "8"}),
+    variants = [("tile", {}), ("rowreg", {"FDX_ROWREG": "1"}), ("tile12+4", {"FDX_TILE_CFG": "12"}), ("tile16+0", {"FDX_TILE_CFG": "16"}), ("tile8+2", {"FDX_TILE_CFG": "8"}),
                 ("atomic", {"FDX_NO_TILE": "1", "FDX_FUSED": "1"}), ("two-kernel", {"FDX_NO_FUSED": "1"})]
     only = os.environ.get("FDX_PROBE_VARIANTS")
     if only:
