@@ -64,14 +64,17 @@ __host__ __device__ constexpr int JW_PAD(int jw) { return (jw + 7) & ~7; }
 // stage: a wave that issues vector-memory instructions sits at the issue port while the memory pipeline takes a CU's
 // ~50 KB block over thousands of cycles, so staging from the consumers stalls them).  NWL = 0: the consumers stage
 // themselves - better for the log modes, where the gather is bound by the vector ALU and every wave is needed for it.
-// JW: groups per consumer wave, TT: 16-type tiles.
-template <typename T, int MODE, int NWC, int NWL, int JW, int TT>
+// JW: groups per consumer wave, TT: 16-type tiles.  AVL2 (the wide form: up to 64 cell types, sketch_dim up to 1024): the
+// wave's slice of X_sketch does not stay in registers as MFMA A operands (JW x TT of them would not fit beside the bucket
+// sums) - each group's TT operands are fetched from a copy of X_sketch laid out in operand order (tile_xa_kernel; it
+// stays in L2) when the group's gather starts, and have landed when its sums are final.
+template <typename T, int MODE, int NWC, int NWL, int JW, int TT, bool AVL2>
 __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch_kernel(
     const TileArgs a, const T* __restrict__ Yp, const int* __restrict__ row_map, const double* __restrict__ Xs,
     double* __restrict__ H, double* __restrict__ row_sumsq, const double* __restrict__ w_tab,
     const unsigned short* __restrict__ off_tab, const unsigned char* __restrict__ len_tab,
     const int* __restrict__ ent_base, const int* __restrict__ slot_bucket, const double* __restrict__ log_tab,
-    const int* __restrict__ tile_list, const int* __restrict__ tile_count) {
+    const int* __restrict__ tile_list, const int* __restrict__ tile_count, const double* __restrict__ XA) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename TileVec<T>::type V;
     // list mode (tile_list != NULL): only the *tile_count tiles listed are worked on - the tiles the row-register kernel
@@ -81,10 +84,13 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     constexpr int NT = (NWC + NWL) * 64;
     constexpr int NWS = NWL > 0 ? NWL : NWC;                                // waves that stage
     constexpr int RPL = (TILE_ROWS + NWS - 1) / NWS;                        // rows a staging wave handles
-    constexpr int NR = NWC > 8 ? NWC / 2 : NWC;                             // partial tiles that reach the final sum
-    constexpr bool PAIR = NWC > 8;                                         // wave w + NR hands its tile to wave w first
+    constexpr bool PAIR = NWC > 8 || AVL2;                                 // wave w + NR hands its tile to wave w first
+    constexpr int NR = PAIR ? NWC / 2 : NWC;                               // partial tiles that reach the final sum
     static_assert(!PAIR || NWC % 2 == 0, "paired reduction needs an even number of consumer waves");
-    constexpr int TS = TT * 4 * 64;
+    static_assert(TT == 1 || TT == 2 || TT == 4, "type tiles: 1, 2 or 4");
+    constexpr int TH = TT > 2 ? 2 : TT;                                     // type tiles per round of the final reduction
+    constexpr int ROUNDS = TT / TH;
+    constexpr int TS = TH * 4 * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -240,9 +246,11 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             par ^= 1;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) rowp[k] = rown[k];
-            lds_barrier();                                                  // the consumers' reduction
-            if (PAIR) lds_barrier();
-            lds_barrier();
+            for (int rd = 0; rd < ROUNDS; ++rd) {                            // the consumers' reduction
+                lds_barrier();
+                if (PAIR) lds_barrier();
+                lds_barrier();
+            }
         }
         return;
     }
@@ -250,9 +258,13 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     // ==================================================================================================== consumer wave
     // this wave's slice of X_sketch as MFMA A operands: A[m = type r][k = q] = X_sketch[type, bucket of slot (w, j, q)];
     // unconditional loads (index clamped, value selected) and one wait, so nothing of this is pending in the tile loop
-    double av[JW][TT];
+    double av[AVL2 ? 1 : JW][TT];
+    // AVL2: operand (j, t) of this wave at xu[(j * TT + t) * 64 + lane] - a uniform base per operand plus the lane, so that
+    // the loads take scalar bases (128 per-lane 64-bit addresses would be hoisted out of the tile loop and spilled)
+    const double* xu = XA + ((size_t)wave * JW * TT) * 64;
+    unsigned lane8 = (unsigned)lane * 8u;
 #pragma unroll
-    for (int j = 0; j < JW; ++j) {
+    for (int j = 0; j < (AVL2 ? 0 : JW); ++j) {
         const int b = slot_bucket[(wave * JW + j) * 4 + q];
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -265,6 +277,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     if (NWL > 0) __builtin_amdgcn_s_waitcnt(0x0f70);
     int buf = 0, par = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
+        if (AVL2) asm volatile("" : "+v"(lane8));                           // the operand addresses are formed where they are used
         if (NWL == 0) {
             has_next = tile + gridDim.x < n_tiles;
             load_rows(tile + gridDim.x, rown);
@@ -302,6 +315,12 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
 #pragma unroll
             for (int j = 0; j < JW; ++j) {
                 const int len = (int)((lens[j >> 3] >> ((j & 7) * 8)) & 0xffULL);
+                double an[TT];
+                if (LAST && AVL2) {
+                    __builtin_amdgcn_sched_barrier(0);                       // the operand loads of later groups stay with their groups
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) an[t] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
+                }
                 int t = 0;
                 for (; t + 2 <= len; t += 2) {                            // two steps per trip: the register sets swap roles
                     const double wb = w_l[p + 4];
@@ -325,7 +344,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 }
                 if (LAST) {
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][t], acc[j], accm[t], 0, 0, 0);
+                    for (int t = 0; t < TT; ++t)
+                        accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(AVL2 ? an[t] : av[AVL2 ? 0 : j][t], acc[j], accm[t], 0, 0, 0);
                     sq = fma(acc[j], acc[j], sq);
                 }
             }
@@ -352,8 +372,15 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         if (!INTERLEAVE) {
 #pragma unroll
             for (int j = 0; j < JW; ++j) {
+                double an[TT];
+                if (AVL2) {
+                    if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);    // at most four groups' operands in flight
 #pragma unroll
-                for (int t = 0; t < TT; ++t) accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][t], acc[j], accm[t], 0, 0, 0);
+                    for (int t = 0; t < TT; ++t) an[t] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
+                }
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(AVL2 ? an[t] : av[AVL2 ? 0 : j][t], acc[j], accm[t], 0, 0, 0);
                 sq = fma(acc[j], acc[j], sq);
             }
         }
@@ -362,50 +389,54 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
 #pragma unroll
             for (int k = 0; k < RPL; ++k) rowp[k] = rown[k];
         }
-        // ---- the partial tiles are added in a fixed order through LDS (the buffer of the block just consumed) and stored
+        // ---- the partial tiles are added in a fixed order through LDS (the buffer of the block just consumed) and stored,
+        // TH type tiles per round (the area must fit a stage buffer)
         double* red = reinterpret_cast<double*>(smem + (size_t)(buf ^ 1) * stage_bytes);   // [NR][TS] + [NR][64]
         double* red_sq = red + (size_t)NR * TS;
-        lds_barrier();                                                      // the last block's buffer is free
-        if (PAIR) {
-            if (wave >= NR) {
+        const long long s0 = tile_id(tile) * TILE_ROWS;
 #pragma unroll
-                for (int t = 0; t < TT; ++t)
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            lds_barrier();                                                  // the last block's buffer / the previous round's sums are free
+            if (PAIR) {
+                if (wave >= NR) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) red[(size_t)(wave - NR) * TS + (t * 4 + rr) * 64 + lane] = accm[t][rr];
-                red_sq[(wave - NR) * 64 + lane] = sq;
+                    for (int t = 0; t < TH; ++t)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) red[(size_t)(wave - NR) * TS + (t * 4 + rr) * 64 + lane] = accm[rd * TH + t][rr];
+                    if (rd == 0) red_sq[(wave - NR) * 64 + lane] = sq;
+                }
+                lds_barrier();
+                if (wave < NR) {
+#pragma unroll
+                    for (int t = 0; t < TH; ++t)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) red[(size_t)wave * TS + (t * 4 + rr) * 64 + lane] += accm[rd * TH + t][rr];
+                    if (rd == 0) red_sq[wave * 64 + lane] += sq;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < TH; ++t)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) red[(size_t)wave * TS + (t * 4 + rr) * 64 + lane] = accm[rd * TH + t][rr];
+                if (rd == 0) red_sq[wave * 64 + lane] = sq;
             }
             lds_barrier();
-            if (wave < NR) {
+            for (int o = tid; o < TS; o += NWC * 64) {
+                double sum = 0.0;
 #pragma unroll
-                for (int t = 0; t < TT; ++t)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) red[(size_t)wave * TS + (t * 4 + rr) * 64 + lane] += accm[t][rr];
-                red_sq[wave * 64 + lane] += sq;
+                for (int v = 0; v < NR; ++v) sum += red[(size_t)v * TS + o];              // fixed order: deterministic
+                const int l = o & 63, tr = o >> 6;
+                const int type = (rd * TH + (tr >> 2)) * 16 + (l >> 4) + 4 * (tr & 3);
+                const long long sp = s0 + (l & 15);
+                if (type < a.K && sp < a.n) H[(size_t)type * a.ldh + sp] = sum;
             }
-        } else {
+            if (rd == 0 && row_sumsq && tid < TILE_ROWS && s0 + tid < a.n) {
+                double sum = 0.0;
+                for (int v = 0; v < NR; ++v)
 #pragma unroll
-            for (int t = 0; t < TT; ++t)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) red[(size_t)wave * TS + (t * 4 + rr) * 64 + lane] = accm[t][rr];
-            red_sq[wave * 64 + lane] = sq;
-        }
-        lds_barrier();
-        const long long s0 = tile_id(tile) * TILE_ROWS;
-        for (int o = tid; o < TS; o += NWC * 64) {
-            double sum = 0.0;
-#pragma unroll
-            for (int v = 0; v < NR; ++v) sum += red[(size_t)v * TS + o];                  // fixed order: deterministic
-            const int l = o & 63, tr = o >> 6;
-            const int type = (tr >> 2) * 16 + (l >> 4) + 4 * (tr & 3);
-            const long long sp = s0 + (l & 15);
-            if (type < a.K && sp < a.n) H[(size_t)type * a.ldh + sp] = sum;
-        }
-        if (row_sumsq && tid < TILE_ROWS && s0 + tid < a.n) {
-            double sum = 0.0;
-            for (int v = 0; v < NR; ++v)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) sum += red_sq[v * 64 + qq * 16 + tid];
-            row_sumsq[s0 + tid] = sum;
+                    for (int qq = 0; qq < 4; ++qq) sum += red_sq[v * 64 + qq * 16 + tid];
+                row_sumsq[s0 + tid] = sum;
+            }
         }
         // the first barrier of the next tile orders these reads before the next DMA into this buffer
     }
@@ -416,7 +447,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
 struct TilePlanDevice {
     TilePlanHost h;
     DevBuf w, off, len, ent_base, slot_bucket;
-    int NWC = 0, NWL = 0, JW = 0, RS = 0;
+    int NWC = 0, NWL = 0, JW = 0, RS = 0, TT = 0;
+    bool wide = false;
     size_t lds = 0;
 };
 
@@ -450,13 +482,19 @@ const double* log_table_dev(hipStream_t st) {   // -log of every 8-bit reciproca
 // against 2.05 ms self-staged and 2.25 ms with 14 + 2).  Log modes: 16 self-staging waves - the table-driven log1p makes
 // the gather ALU-bound and idle loader waves cost more than they save (4.3 ms against 6.4 ms with 12 + 4).
 // FDX_TILE_CFG=12 / 16 / 8 forces 12 + 4 / 16 + 0 / 8 + 2 (tuning experiments).
-struct TileCfg { int NWC, NWL, JW; };
-static TileCfg tile_cfg(int mode) {
+// Wide form (33..64 cell types, or more buckets than the narrow split owns): twice the groups per wave, four type tiles,
+// MFMA A operands from the L2-resident operand copy of X_sketch (AVL2).
+struct TileCfg { int NWC, NWL, JW, TT; bool wide; };
+static TileCfg tile_cfg(int mode, int K, int d) {
     const char* e = getenv("FDX_TILE_CFG");
     const int v = e ? atoi(e) : (mode == FDX_PRE_RAW ? 12 : 16);
-    if (v == 16) return TileCfg{16, 0, 8};
-    if (v == 8) return TileCfg{8, 2, 16};
-    return TileCfg{12, 4, 11};
+    TileCfg c = v == 16 ? TileCfg{16, 0, 8, 0, false} : v == 8 ? TileCfg{8, 2, 16, 0, false} : TileCfg{12, 4, 11, 0, false};
+    c.TT = (K + 15) / 16;
+    if (K > 32 || d > 4 * c.NWC * c.JW) {
+        // eight consumer waves: 256 registers each hold 32 bucket sums, four type tiles and the gather's pipeline
+        c = mode == FDX_PRE_RAW ? TileCfg{12, 4, 22, 4, true} : TileCfg{8, 0, 32, 4, true};
+    }
+    return c;
 }
 
 static size_t tile_lds_bytes(int RS, int NE, int mode) {
@@ -470,20 +508,23 @@ static size_t tile_lds_bytes(int RS, int NE, int mode) {
 // Builds (once per SketchPlan and input type) the schedule for the largest column block that fits the LDS.
 static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int mode, int K, hipStream_t st) {
     const int sz = dtype == FDX_F32 ? 4 : 8;
-    const TileCfg cfg = tile_cfg(mode);
-    const int TT = (K + 15) / 16;
-    if (TT > 2 || TT < 1) return nullptr;
-    const int key = ((((dtype == FDX_F32 ? 0 : 1) * 2 + (mode != FDX_PRE_RAW ? 1 : 0)) * 2 + (TT - 1)) * 3) +
-                    (cfg.NWC == 12 ? 0 : cfg.NWC == 16 ? 1 : 2);
-    static_assert(SketchPlan::kTileKeys == 24, "key space of the schedules");
+    const TileCfg cfg = tile_cfg(mode, K, sp.d);
+    const int TT = cfg.TT;
+    if (K < 1 || K > 64 || (!cfg.wide && TT > 2)) return nullptr;
+    const int key = cfg.wide ? 24 + ((dtype == FDX_F32 ? 0 : 1) * 2 + (mode != FDX_PRE_RAW ? 1 : 0))
+                             : ((((dtype == FDX_F32 ? 0 : 1) * 2 + (mode != FDX_PRE_RAW ? 1 : 0)) * 2 + (TT - 1)) * 3) +
+                                   (cfg.NWC == 12 ? 0 : cfg.NWC == 16 ? 1 : 2);
+    static_assert(SketchPlan::kTileKeys == 28, "key space of the schedules");
     std::lock_guard<std::mutex> lock(sp.tile_mu);
     if (sp.tile_tried[key]) return sp.tile[key].get();
     sp.tile_tried[key] = true;
     const bool dbg = getenv("FDX_DEBUG") != nullptr;
     if (!sp.scatter_ok || sp.host_bucket.empty()) return nullptr;
     if (sp.d > 4 * cfg.NWC * cfg.JW) return nullptr;
-    const size_t red_bytes = (size_t)(cfg.NWC > 8 ? cfg.NWC / 2 : cfg.NWC) * (TT * 4 * 64 + 64) * 8;   // the kernel's reduction area
-    const int unit = 1024 / sz;                                             // genes per 1 KB piece
+    const size_t red_bytes = (size_t)(cfg.NWC > 8 || cfg.wide ? cfg.NWC / 2 : cfg.NWC) * (std::min(TT, 2) * 4 * 64 + 64) * 8;   // the kernel's reduction area
+    // block sizes tried: whole 1 KB pieces; the wide form's tables leave less room, and an eighth of a piece more or less decides
+    // whether 5000 genes take 7 blocks or 10 (21 % more lockstep padding)
+    const int unit = (cfg.wide ? 128 : 1024) / sz;
     std::unique_ptr<TilePlanDevice> best;
     for (int GB = (int)round_up(sp.G, unit); GB >= unit; GB -= unit) {
         const int RS = GB * sz + TILE_ROW_PAD;
@@ -492,7 +533,7 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
         if (tile_lds_bytes(RS, sp.G, mode) > 160 * 1024) continue;
         auto cand = std::make_unique<TilePlanDevice>();
         if (!build_tile_plan(sp.host_bucket.data(), sp.host_w.data(), sp.G, sp.d, cfg.NWC, cfg.JW, GB, &cand->h)) return nullptr;
-        cand->NWC = cfg.NWC; cand->NWL = cfg.NWL; cand->JW = cfg.JW; cand->RS = RS;
+        cand->NWC = cfg.NWC; cand->NWL = cfg.NWL; cand->JW = cfg.JW; cand->RS = RS; cand->TT = TT; cand->wide = cfg.wide;
         cand->lds = tile_lds_bytes(RS, cand->h.NE, mode);
         if (dbg) std::fprintf(stderr, "[fdx] tile plan: G=%d d=%d waves=%d+%d GB=%d blocks=%d NE=%d steps=%d lds=%zu\n", sp.G, sp.d, cfg.NWC,
                               cfg.NWL, GB, cand->h.NBLK, cand->h.NE, cand->h.steps, cand->lds);
@@ -523,13 +564,26 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     return sp.tile[key].get();
 }
 
+// X_sketch rearranged into MFMA A operands for the wide form: XA[((w * JW + j) * TT + t) * 64 + lane] =
+// X_sketch[type = 16 t + (lane & 15), bucket of slot (w, j, lane >> 4)], 0 where there is no such type or bucket.
+__global__ void tile_xa_kernel(const double* __restrict__ Xs, const int* __restrict__ slot_bucket, int K, int d, int n_groups,
+                               int TT, double* __restrict__ XA) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_groups * TT * 64) return;
+    const int lane = i & 63, t = (i >> 6) % TT, wj = (i >> 6) / TT;
+    const int b = slot_bucket[wj * 4 + (lane >> 4)];
+    const int type = t * 16 + (lane & 15);
+    XA[i] = (b >= 0 && type < K) ? Xs[(size_t)type * d + b] : 0.0;
+}
+
 bool tile_sketch_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan,
                     hipStream_t st) {
     if (getenv("FDX_NO_TILE") || !plan.owner) return false;
     if (dtype != FDX_F32 && dtype != FDX_F64) return false;
     if (mode != FDX_PRE_RAW && mode != FDX_PRE_LOG_CPM && mode != FDX_PRE_LOG_CPM_SPARSE) return false;
     const int sz = dtype == FDX_F32 ? 4 : 8;
-    if (K <= 0 || K > 32 || G <= 0 || d <= 0) return false;
+    if (K <= 0 || K > 64 || G <= 0 || d <= 0) return false;
+    if ((K > 32 || d > 512) && getenv("FDX_NO_TILE_WIDE")) return false;
     // whole 16-byte vectors only: row starts and row lengths multiples of 16 bytes
     if (((size_t)G * sz) % 16 != 0 || ((size_t)ldy * sz) % 16 != 0 || (reinterpret_cast<uintptr_t>(Y) & 15) != 0) return false;
     return tile_plan_for(*plan.owner, dtype, mode, K, st) != nullptr;
@@ -550,22 +604,38 @@ struct TileLaunch {
     const double* log_tab;
     const int* tile_list;
     const int* tile_count;
+    const double* XA;
 };
 
 template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hipStream_t st) {
-    const void* kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 1>
-                               : (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 2>;
+    const void* kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 1, false>
+                               : (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 2, false>;
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
                     (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab,
-                    (void*)&L.tile_list, (void*)&L.tile_count};
+                    (void*)&L.tile_list, (void*)&L.tile_count, (void*)&L.XA};
+    FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3((NWC + NWL) * 64), args, lds, st));
+    return 0;
+}
+
+template <typename T, int MODE, int NWC, int NWL, int JW>
+static int launch_tile_wide(const TileLaunch& L, size_t lds, int grid, hipStream_t st) {
+    const void* kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true>;
+    if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
+                    (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab,
+                    (void*)&L.tile_list, (void*)&L.tile_count, (void*)&L.XA};
     FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3((NWC + NWL) * 64), args, lds, st));
     return 0;
 }
 
 template <typename T, int MODE>
 static int launch_tile_cfg(const TileLaunch& L, int NWC, int TT, size_t lds, int grid, hipStream_t st) {
+    if (TT == 4) {
+        if constexpr (MODE == FDX_PRE_RAW) return launch_tile_wide<T, MODE, 12, 4, 22>(L, lds, grid, st);
+        else return launch_tile_wide<T, MODE, 8, 0, 32>(L, lds, grid, st);
+    }
     if (NWC == 16) return launch_tile_tt<T, MODE, 16, 0, 8>(L, TT, lds, grid, st);
     if (NWC == 8) return launch_tile_tt<T, MODE, 8, 2, 16>(L, TT, lds, grid, st);
     return launch_tile_tt<T, MODE, 12, 4, 11>(L, TT, lds, grid, st);
@@ -604,9 +674,18 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     }
     const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
     const int grid = (int)std::min<long long>(n_tiles, 256);
-    const int TT = (K + 15) / 16;
-    if (dtype == FDX_F32) return launch_tile_mode<float>(L, mode, t->NWC, TT, t->lds, grid, st);
-    return launch_tile_mode<double>(L, mode, t->NWC, TT, t->lds, grid, st);
+    DevBuf xa;                                                              // wide form: X_sketch in operand order
+    L.XA = nullptr;
+    if (t->wide) {
+        const int n_groups = t->NWC * t->JW;
+        FDX_TRY(xa.alloc((size_t)n_groups * t->TT * 64 * sizeof(double)));
+        hipLaunchKernelGGL(tile_xa_kernel, dim3(ceil_div((long long)n_groups * t->TT * 64, 256)), dim3(256), 0, st, Xs,
+                           t->slot_bucket.as<int>(), K, d, n_groups, t->TT, xa.as<double>());
+        FDX_CHECK_LAUNCH();
+        L.XA = xa.as<double>();
+    }
+    if (dtype == FDX_F32) return launch_tile_mode<float>(L, mode, t->NWC, t->TT, t->lds, grid, st);
+    return launch_tile_mode<double>(L, mode, t->NWC, t->TT, t->lds, grid, st);
 }
 
 }  // namespace fdx

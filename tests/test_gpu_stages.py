@@ -236,3 +236,31 @@ def test_row_register_kernel_matches_the_tile_kernel_and_the_oracle(n, G, K, d, 
     fin = np.isfinite(a2.beta_)
     assert np.array_equal(np.isfinite(b2.beta_), fin)
     assert rel_fro(b2.beta_[fin], a2.beta_[fin]) < 1e-11
+
+
+@pytest.mark.parametrize("n,G,K,d,mode,dtype", [(700, 1200, 40, 1024, "raw", np.float32), (333, 3000, 50, 700, "log_cpm", np.float32),
+                                                (500, 2000, 20, 1024, "raw", np.float64), (413, 1500, 64, 512, "log_cpm", np.float64),
+                                                (600, 5000, 50, 1024, "raw", np.float32), (257, 900, 33, 96, "pearson", np.float32)])
+def test_wide_tile_kernel_matches_the_two_kernel_path_and_the_oracle(n, G, K, d, mode, dtype, monkeypatch):
+    """The wide form of the tile kernel (csrc/tile_kernels.cpp, AVL2: 33..64 cell types or sketch_dim above what the narrow
+    wave split owns - BASELINE configs[4] is 50 types, d = 1024): MFMA A operands fetched per group from the operand-order
+    copy of X_sketch, four type tiles reduced in two rounds.  Against the oracle and against the two-kernel path
+    (FDX_NO_TILE_WIDE=1: scatter sketch + split-d contraction)."""
+    import datagen
+    import fdx_oracle as orc
+    from flashdeconv_amd import FlashDeconv
+    if mode == "raw":
+        Y, X, coords, _ = datagen.gaussian_raw(n, G, K, seed=n + K)
+    else:
+        Y, X, coords, _ = datagen.count_like(n, G, K, seed=n + K)
+    Y = Y.astype(dtype)
+    kw = dict(sketch_dim=d, preprocess=mode, n_hvg=G, max_iter=12, random_state=5)
+    want = orc.fit(Y, X, coords, sketch_dim=d, preprocess_method=mode, n_hvg=G, max_iter=12, random_state=5)
+    a = FlashDeconv(**kw).fit(Y, X, coords)
+    monkeypatch.setenv("FDX_NO_TILE_WIDE", "1")
+    b = FlashDeconv(**kw).fit(Y, X, coords)
+    assert a.info_["n_iterations"] == want["info"]["n_iterations"] == b.info_["n_iterations"]
+    tol = 1e-8 if dtype == np.float64 or mode == "raw" else 1e-5       # float32 log-CPM: DESIGN.md section 4, deviation (ii)
+    assert rel_fro(a.beta_, want["beta"]) < tol
+    assert rel_fro(a.beta_, b.beta_) < 1e-11
+    assert rel_fro(a.proportions_, b.proportions_) < 1e-11
