@@ -611,6 +611,11 @@ template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hipStream_t st) {
     const void* kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 1, false>
                                : (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 2, false>;
+    // log modes, 16 self-staging waves: operands from the L2 copy as in the wide form - the 32 registers they would occupy
+    // are what the 128-register budget lacks for the log1p chains (22 spills with them; 4.23 -> 4.1 ms).  Raw (12 + 4) keeps
+    // them in registers: 2.34 ms with the fetches against 1.98 ms.
+    if (L.XA && MODE != FDX_PRE_RAW && NWC == 16)
+        kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true>;
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
                     (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab,
@@ -676,7 +681,7 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     const int grid = (int)std::min<long long>(n_tiles, 256);
     DevBuf xa;                                                              // wide form: X_sketch in operand order
     L.XA = nullptr;
-    if (t->wide) {
+    if (t->wide || (mode != FDX_PRE_RAW && t->NWC == 16 && !getenv("FDX_TILE_NO_AVL2"))) {
         const int n_groups = t->NWC * t->JW;
         FDX_TRY(xa.alloc((size_t)n_groups * t->TT * 64 * sizeof(double)));
         hipLaunchKernelGGL(tile_xa_kernel, dim3(ceil_div((long long)n_groups * t->TT * 64, 256)), dim3(256), 0, st, Xs,
