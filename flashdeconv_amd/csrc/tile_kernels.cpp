@@ -151,17 +151,12 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         const V* src0 = reinterpret_cast<const V*>(r0);
         const V* src1 = reinterpret_cast<const V*>(r1);
         double p0 = 0.0, p1 = 0.0;
-        // extremes without compare-select pairs: max by v_max, "some element negative" by OR-ing the raw bits (the sign bit
-        // survives; NaN / Inf show up in the sum)
-        T mx0 = (T)0, mx1 = (T)0;
+        // "some element negative" by OR-ing the raw bits (the sign bit survives); NaN / Inf show up in the sum.  With every
+        // element >= 0 the log argument y * 1e4 / sum cannot exceed 1e4, inside the fast range: no maximum is needed.
         unsigned long long sg0 = 0ULL, sg1 = 0ULL;
         auto bits_of = [](T v) -> unsigned long long {
             if constexpr (sizeof(T) == 4) return (unsigned long long)__float_as_uint((float)v) << 32;
             else return (unsigned long long)__double_as_longlong((double)v);
-        };
-        auto vmax = [](T a_, T b_) -> T {
-            if constexpr (sizeof(T) == 4) return (T)fmaxf((float)a_, (float)b_);
-            else return (T)fmax((double)a_, (double)b_);
         };
         for (int v0 = 0; v0 < nvec; v0 += 512) {
             V x0[8], x1[8];
@@ -179,19 +174,20 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 if (v < nvec) {
 #pragma unroll
                     for (int e = 0; e < PER; ++e) {
-                        if (r0) { p0 += (double)x0[u][e]; mx0 = vmax(mx0, x0[u][e]); sg0 |= bits_of(x0[u][e]); }
-                        if (TWO && r1) { p1 += (double)x1[u][e]; mx1 = vmax(mx1, x1[u][e]); sg1 |= bits_of(x1[u][e]); }
+                        if (r0) { p0 += (double)x0[u][e]; sg0 |= bits_of(x0[u][e]); }
+                        if (TWO && r1) { p1 += (double)x1[u][e]; sg1 |= bits_of(x1[u][e]); }
                     }
                 }
             }
         }
-        // NaN / Inf anywhere in the row makes the sum, hence the scale, NaN or 0 * Inf below: the test fails
-        const double s0 = tile_row_scale<MODE>(wave_sum(p0));
-        const bool ok0 = wave_max((double)mx0) * s0 < 32000.0 && !__any((long long)sg0 < 0);
+        const double sum0 = wave_sum(p0);
+        const double s0 = tile_row_scale<MODE>(sum0);
+        const bool ok0 = fabs(sum0) <= 1.7e308 && !__any((long long)sg0 < 0);        // false for a NaN / Inf sum
         if (lane == 0 && r0) { out_scale[i0] = s0; out_ok[i0] = ok0 ? 1 : 0; }
         if (TWO && r1) {
-            const double s1 = tile_row_scale<MODE>(wave_sum(p1));
-            const bool ok1 = wave_max((double)mx1) * s1 < 32000.0 && !__any((long long)sg1 < 0);
+            const double sum1 = wave_sum(p1);
+            const double s1 = tile_row_scale<MODE>(sum1);
+            const bool ok1 = fabs(sum1) <= 1.7e308 && !__any((long long)sg1 < 0);
             if (lane == 0) { out_scale[i1] = s1; out_ok[i1] = ok1 ? 1 : 0; }
         }
     };
