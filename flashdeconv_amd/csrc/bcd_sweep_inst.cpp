@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void bcd_sweep_kernel(
 // served by ds_read_b64 from tile-local slots - ~0.5 global gathers per spot and type instead of ~11.  Arithmetic and
 // summation order are identical to bcd_sweep_kernel, so both variants produce the same bits.
 template <int K, int KC, bool OBJ>
-__global__ __launch_bounds__(256) void bcd_sweep_tiled_kernel(
+__global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_kernel(
     const double* __restrict__ H, const double* __restrict__ XtX, const double* __restrict__ beta_in,
     double* __restrict__ beta_out, const unsigned short* __restrict__ ell_local, const int* __restrict__ slice_off,
     const int* __restrict__ deg, const int* __restrict__ tile_halo, const int* __restrict__ tile_hcnt,
