@@ -161,11 +161,15 @@ def pmc_traffic(kernel, shape):
         return None
 
 
-def sketch_kernel_name(mode, K):
-    """Kernel that serves the sketch -> H stage of the bench shapes (csrc/tile_kernels.cpp: tile_cfg)."""
+def sketch_kernel_name(mode, K, d=512):
+    """Kernel that serves the sketch -> H stage of the bench shapes (csrc/tile_kernels.cpp: tile_cfg): template arguments
+    <input type, preprocess, consumer waves, loader waves, groups per wave, type tiles, A operands from L2>."""
     cfg = os.environ.get("FDX_TILE_CFG")
     nwc, nwl, jw = {"12": (12, 4, 11), "16": (16, 0, 8), "8": (8, 2, 16)}.get(cfg, (12, 4, 11) if mode == 0 else (16, 0, 8))
-    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d>" % (mode, nwc, nwl, jw, -(-K // 16))
+    tt, avl2 = -(-K // 16), mode != 0 and nwc == 16
+    if K > 32 or d > 4 * nwc * jw:                 # wide form
+        (nwc, nwl, jw), tt, avl2 = ((12, 4, 22) if mode == 0 else (8, 0, 32)), 4, True
+    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d, %s>" % (mode, nwc, nwl, jw, tt, "true" if avl2 else "false")
 
 
 def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
@@ -307,7 +311,7 @@ def main():
         else:
             if stage["gram_ms"] == 0.0:                # fused sketch -> H kernel: ONE launch reads all of Y, writes only H
                 bytes_launch, ms_launch = sk_bytes, sk_ms
-                kname = sketch_kernel_name(0 if fam == "gaussian" else 1, K)
+                kname = sketch_kernel_name(0 if fam == "gaussian" else 1, K, d)
             else:
                 bytes_launch, ms_launch = sk_bytes / n_chunks, sk_ms / n_chunks
                 kname = "fdx::sketch_rows_scatter_kernel<float, %d, true>" % (0 if fam == "gaussian" else 1)
