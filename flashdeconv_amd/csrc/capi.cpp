@@ -193,7 +193,7 @@ int fdx_graph_build_radius(const double* coords, int64_t n, int32_t dim, double 
     DevBuf dc;
     FDX_TRY(upload_coords(coords, n, dim, &dc));
     fdx_graph* g = new fdx_graph();
-    const int rc = graph_build_radius(dc.as<double>(), n, dim, radius, g, nullptr);
+    const int rc = graph_build_radius(dc.as<double>(), n, dim, radius, 0, n, g, nullptr);
     if (rc) { delete g; return rc; }
     *out = g;
     return 0;

@@ -44,8 +44,20 @@ int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_
     fdx_graph* g = new fdx_graph();
     int rc;
     if (method == FDX_GRAPH_KNN) rc = graph_build_knn(coords_dev, n, dim, k, g, (hipStream_t)stream);
-    else if (method == FDX_GRAPH_RADIUS) rc = graph_build_radius(coords_dev, n, dim, radius, g, (hipStream_t)stream);
+    else if (method == FDX_GRAPH_RADIUS) rc = graph_build_radius(coords_dev, n, dim, radius, 0, n, g, (hipStream_t)stream);
     else rc = fail(FDX_ERR_INVALID, "fdx_graph_build_dev: unknown method");
+    if (rc) { delete g; return rc; }
+    *out = g;
+    return 0;
+}
+
+int fdx_graph_build_radius_rows_dev(const double* coords_dev, int64_t n, int32_t dim, double radius, int64_t lo, int64_t hi,
+                                    void* stream, fdx_graph** out) {
+    FDX_REQUIRE(out != nullptr, "fdx_graph_build_radius_rows_dev: null output");
+    *out = nullptr;
+    FDX_REQUIRE(n == 0 || coords_dev != nullptr, "fdx_graph_build_radius_rows_dev: null coords");
+    fdx_graph* g = new fdx_graph();
+    const int rc = graph_build_radius(coords_dev, n, dim, radius, lo, hi, g, (hipStream_t)stream);
     if (rc) { delete g; return rc; }
     *out = g;
     return 0;

@@ -206,7 +206,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         g = new fdx_graph();
         int rc = (prm->graph_method == FDX_GRAPH_KNN)
                      ? graph_build_knn(coords_dev, n, dim, prm->k_neighbors, g, st)
-                     : graph_build_radius(coords_dev, n, dim, prm->radius, g, st);
+                     : graph_build_radius(coords_dev, n, dim, prm->radius, 0, n, g, st);
         if (rc) { delete g; return rc; }
         *graph_inout = g;
     }

@@ -15,7 +15,9 @@ int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, l
                          hipStream_t st);
 void graph_plan_destroy(fdx_graph_plan* plan);
 int graph_plan_kk(const fdx_graph_plan* plan);
-int graph_build_radius(const double* d_coords, long long n, int dim, double radius, fdx_graph* g, hipStream_t st);
+// rows [lo, hi) (solver positions) of the radius graph, the others left empty; [0, n) = the whole graph
+int graph_build_radius(const double* d_coords, long long n, int dim, double radius, long long lo, long long hi, fdx_graph* g,
+                       hipStream_t st);
 // distance of every point to its nearest other point (caller's order); used by the "grid" method (graph.py:163-167)
 int graph_nearest_distance(const double* d_coords, long long n, int dim, double* d_out, hipStream_t st);
 // CSR in the caller's labels; device outputs indptr (n+1) int64, indices (nnz) int32 ascending per row

@@ -239,9 +239,14 @@ template <int PASS>
 __global__ __launch_bounds__(128) void radius_kernel(const double* __restrict__ sc, const int* __restrict__ cstart,
                                                      const int* __restrict__ cend, long long n, GridParams gp,
                                                      double radius, int R, int* __restrict__ cnt,
-                                                     const int* __restrict__ off, int* __restrict__ nbr) {
+                                                     const int* __restrict__ off, int* __restrict__ nbr, long long lo,
+                                                     long long hi) {
     const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (p >= n) return;
+    if (p < lo || p >= hi) {                                               // a shard builds its own rows; the others stay empty
+        if (!PASS) cnt[p] = 0;
+        return;
+    }
     const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
     const double pc[3] = {px, py, pz};
     int c[3];
@@ -822,10 +827,15 @@ int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_gra
     return rc;
 }
 
-int graph_build_radius(const double* d_coords, long long n, int dim, double radius, fdx_graph* g, hipStream_t st) {
+// Rows [lo, hi) (solver positions) of the radius graph; the other rows are left empty.  A radius graph is symmetric by
+// construction (graph.py:115-121), so a shard's own rows need nothing from the other shards.
+int graph_build_radius(const double* d_coords, long long n, int dim, double radius, long long lo, long long hi, fdx_graph* g,
+                       hipStream_t st) {
     FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
     FDX_REQUIRE(n >= 0 && n < 0x7fffff00LL, "graph: n out of range");
     FDX_REQUIRE(radius > 0.0 && std::isfinite(radius), "graph: radius must be positive");
+    FDX_REQUIRE(0 <= lo && lo <= hi && hi <= n, "graph: bad row range");
+    FDX_REQUIRE(lo % 64 == 0, "graph: a shard must start on a 64-row slice boundary");
     if (n <= 1) return empty_graph(n, g, st);
     BinnedPoints b;
     FDX_TRY(bin_points(d_coords, n, dim, 1.0, radius, &b, st));   // cell edge >= radius: one shell suffices
@@ -839,7 +849,7 @@ int graph_build_radius(const double* d_coords, long long n, int dim, double radi
     FDX_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes, st));
     const int nb = ceil_div(n, 128);
     hipLaunchKernelGGL(radius_kernel<0>, dim3(nb), dim3(128), 0, st, b.sc.as<double>(), b.cstart.as<int>(), b.cend.as<int>(), n,
-                       b.gp, radius, R, cnt.as<int>(), (const int*)nullptr, (int*)nullptr);
+                       b.gp, radius, R, cnt.as<int>(), (const int*)nullptr, (int*)nullptr, lo, hi);
     FDX_CHECK_LAUNCH();
     FDX_TRY(exclusive_scan_int(cnt.as<int>(), g->row_extra.as<int>(), n + 1, st, tmp));
     int total = 0;
@@ -848,7 +858,7 @@ int graph_build_radius(const double* d_coords, long long n, int dim, double radi
     FDX_REQUIRE(total >= 0, "graph: radius graph has too many edges");
     FDX_TRY(g->rows.alloc((size_t)std::max(total, 1) * 4));
     hipLaunchKernelGGL(radius_kernel<1>, dim3(nb), dim3(128), 0, st, b.sc.as<double>(), b.cstart.as<int>(), b.cend.as<int>(), n,
-                       b.gp, radius, R, (int*)nullptr, g->row_extra.as<int>(), g->rows.as<int>());
+                       b.gp, radius, R, (int*)nullptr, g->row_extra.as<int>(), g->rows.as<int>(), lo, hi);
     FDX_CHECK_LAUNCH();
     hipLaunchKernelGGL(sort_rows_kernel, dim3(nb), dim3(128), 0, st, g->rows.as<int>(), g->row_extra.as<int>(), g->perm.as<int>(), n);
     FDX_CHECK_LAUNCH();

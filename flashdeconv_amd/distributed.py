@@ -354,12 +354,22 @@ class ShardedFlashDeconv:
             self.comm.all_reduce_sum(own_nnz)                               # nnz of the whole graph (auto lambda)
             self.nnz_total = int(round(float(own_nnz.item())))
         else:
-            # replicated build; "radius" / "grid" resolve their radius exactly as FlashDeconv does (utils/graph.py:163-212)
+            # "radius" / "grid" resolve their radius exactly as FlashDeconv does (utils/graph.py:163-212)
             method, gk, gradius = self._proto._graph_request(coords, None)
-            _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, method, gk, float(gradius), st,
-                                               ctypes.byref(h)))
-            self._full = _lib.Graph(h.value)
-            self.nnz_total = self._full.info()[1]
+            if method == _lib.GRAPH_RADIUS and self.comm.world > 1 and n >= 2:
+                # sharded build: a radius graph is symmetric by construction, the own rows need no exchange
+                lo, hi = int(self.bounds[self.comm.rank]), int(self.bounds[self.comm.rank + 1])
+                _lib.check(lib.fdx_graph_build_radius_rows_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, float(gradius), lo, hi, st,
+                                                               ctypes.byref(h)))
+                self._full = _lib.Graph(h.value)
+                own_nnz = torch.tensor([float(self._full.info()[1])], dtype=torch.float64, device=coords.device)
+                self.comm.all_reduce_sum(own_nnz)                           # nnz of the whole graph (auto lambda)
+                self.nnz_total = int(round(float(own_nnz.item())))
+            else:
+                _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, method, gk, float(gradius), st,
+                                                   ctypes.byref(h)))
+                self._full = _lib.Graph(h.value)
+                self.nnz_total = self._full.info()[1]
         t0 = self._tick("plan_build", t0)
         self.n_total_spots = n
         hl = ctypes.c_void_p()

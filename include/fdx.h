@@ -248,6 +248,12 @@ int fdx_fit_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t G, c
 /* Graph from coordinates already on the device (method FDX_GRAPH_KNN / FDX_GRAPH_RADIUS). */
 int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t method, int32_t k, double radius,
                         void* stream, fdx_graph** out);
+/* Spot shards, radius / grid graphs (utils/graph.py:84-212): rows [lo, hi) (solver positions, lo a multiple of 64) of the
+ * radius graph, all other rows left empty - the shard's part of fdx_graph_build_dev(FDX_GRAPH_RADIUS).  A radius graph is
+ * symmetric by construction (query_pairs, graph.py:115-121), so a shard's own rows need nothing from the other shards; the
+ * result goes to fdx_graph_localize like the one of fdx_graph_from_knn_lists_dev. */
+int fdx_graph_build_radius_rows_dev(const double* coords_dev, int64_t n, int32_t dim, double radius, int64_t lo, int64_t hi,
+                                    void* stream, fdx_graph** out);
 /* The same k-NN graph in two phases, so that a spot shard builds only its own rows (utils/graph.py:25-83):
  *   1. knn_lists: every rank bins ALL coordinates (replicated; the Morton order fixes the solver positions) and finds
  *      the k nearest neighbours of solver positions [lo, hi) only.  Rows [lo, hi) of nbr_dev (n x kk int32 solver

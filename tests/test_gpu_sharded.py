@@ -354,3 +354,75 @@ def test_native_loop_8_ranks_at_1m_spots_config3():
     assert all(res[0] == ref.info_["n_iterations"] and res[1] for res in results) and ref.info_["converged"]
     got = _assemble(torch, shards, results, n, K)
     assert torch.equal(got, ref.beta_)
+
+
+@pytest.mark.parametrize("W", [2, 3])
+@pytest.mark.parametrize("method", ["radius", "grid"])
+def test_sharded_radius_build_equals_the_replicated_one(W, method):
+    """Radius / grid graphs for spot shards (fdx_graph_build_radius_rows_dev): every rank builds rows [lo, hi) only - a radius
+    graph is symmetric by construction, nothing is exchanged.  The localized shard (own spots, halo, send lists, degrees)
+    must be the one cut from the replicated graph, the own edge counts must add up to the whole graph, and a sweep on the
+    shard must give the bits of a sweep on the shard of the replicated graph."""
+    import torch
+    from flashdeconv_amd import FlashDeconv, _lib
+    from flashdeconv_amd.distributed import shard_bounds
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n = 5000
+    rs = np.random.RandomState(W)
+    side = int(np.ceil(np.sqrt(n)))
+    coords = np.stack([np.arange(n) % side, np.arange(n) // side], axis=1).astype(np.float64) + rs.rand(n, 2) * 0.2
+    proto = FlashDeconv(spatial_method=method, radius=1.3 if method == "radius" else None)
+    cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
+    gm, gk, gradius = proto._graph_request(cd, None)
+    assert gm == _lib.GRAPH_RADIUS
+    h = ctypes.c_void_p()
+    _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, gm, gk, float(gradius), _st(torch), ctypes.byref(h)))
+    full = _lib.Graph(h.value)
+    bounds = shard_bounds(n, W)
+    nnz_sum = 0
+    for r in range(W):
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        hp = ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_build_radius_rows_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, float(gradius), lo, hi, _st(torch),
+                                                       ctypes.byref(hp)))
+        part = _lib.Graph(hp.value)
+        nnz_sum += part.info()[1]
+        locs = []
+        for g in (full, part):
+            hl = ctypes.c_void_p()
+            _lib.check(lib.fdx_graph_localize(g.handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
+            loc = _lib.Graph(hl.value)
+            n_own = hi - lo
+            perm = torch.empty(max(n_own, 1), dtype=torch.int32, device=dev)
+            _lib.check(lib.fdx_graph_perm_dev(loc.handle, ctypes.c_void_p(perm.data_ptr()), _st(torch)))
+            nh = ctypes.c_int64(0)
+            sc, rc = np.zeros(W, dtype=np.int32), np.zeros(W, dtype=np.int32)
+            _lib.check(lib.fdx_graph_halo_info(loc.handle, ctypes.byref(nh), _lib.ptr_i32(sc), _lib.ptr_i32(rc)))
+            sidx = torch.empty(max(int(sc.sum()), 1), dtype=torch.int32, device=dev)
+            _lib.check(lib.fdx_graph_send_indices_dev(loc.handle, ctypes.c_void_p(sidx.data_ptr()), _st(torch)))
+            torch.cuda.synchronize()
+            locs.append((loc.info(), perm.cpu().numpy()[:n_own], int(nh.value), sc, rc, sidx.cpu().numpy()[:int(sc.sum())], loc))
+        a, b = locs
+        assert a[0] == b[0] and a[2] == b[2]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+        # one sweep on both shards: same bits
+        K = 5
+        n_total = (hi - lo) + a[2]
+        ld = ((n_total + 1 + 63) // 64) * 64
+        g1 = torch.Generator(device=dev).manual_seed(r)
+        Hm = torch.rand((K, ld), dtype=torch.float64, device=dev, generator=g1)
+        XtX = torch.eye(K, dtype=torch.float64, device=dev) * 2.0 + 0.1
+        outs = []
+        from flashdeconv_amd.distributed import HipBackend
+        for loc in (a[6], b[6]):
+            be = HipBackend(loc, Hm, ld, XtX, K)
+            beta = [torch.zeros((K, ld), dtype=torch.float64, device=dev) for _ in range(2)]
+            be.init_beta(beta[0], n_total)
+            stats = torch.zeros((4, 128), dtype=torch.float64, device=dev)
+            rel = torch.zeros(4, dtype=torch.float64, device=dev)
+            be.sweep(0, beta[0], beta[1], 0.3, 0.01, 1e-9, stats, rel)
+            torch.cuda.synchronize()
+            outs.append(beta[1].cpu().numpy()[:, :hi - lo].copy())
+        assert np.array_equal(outs[0], outs[1])
+    assert nnz_sum == full.info()[1]
