@@ -327,3 +327,18 @@ def test_rowreg_schedule_replays_to_the_countsketch(G, d):
         if bucket[g] >= 0:
             want[:, bucket[g]] += weight[g] * y[:, g]
     assert np.allclose(sk, want, rtol=1e-12, atol=1e-12)
+
+
+def test_schedule_builders_under_address_and_ub_sanitizers():
+    """`make -C flashdeconv_amd/csrc asan-host`: the pure-host schedule builders (tile_plan.cpp) compiled with g++
+    -fsanitize=address,undefined and replayed on a range of shapes (GPU AddressSanitizer is not available on the build pool)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++") or not shutil.which("make"):
+        pytest.skip("no g++ / make")
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "flashdeconv_amd", "csrc"), "asan-host"], capture_output=True, text=True,
+                       timeout=300)
+    if r.returncode != 0 and ("cannot find -lasan" in r.stderr or "libasan" in r.stderr):
+        pytest.skip("no sanitizer runtime")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok under the sanitizers" in r.stdout
