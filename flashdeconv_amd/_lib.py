@@ -73,6 +73,8 @@ SIGNATURES = {
     "fdx_fit_csr_dev": (c_int, [ctypes.POINTER(CsrView), p_i32, c_i32, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
                                 c_i32, ctypes.POINTER(FitParams), ctypes.POINTER(c_void_p), c_void_p, c_void_p, p_double,
                                 p_double, ctypes.POINTER(FitInfo), c_void_p]),
+    "fdx_type_sums_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p]),
+    "fdx_type_sums_csr_dev": (c_int, [ctypes.POINTER(CsrView), c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p]),
     "fdx_graph_build_radius_rows_dev": (c_int, [c_void_p, c_i64, c_i32, c_double, c_i64, c_i64, c_void_p, ctypes.POINTER(c_void_p)]),
     "fdx_graph_knn_lists_dev": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i64, c_i64, c_void_p, c_void_p, c_void_p,
                                         ctypes.POINTER(c_void_p)]),

@@ -1,10 +1,69 @@
 """Duck-typed AnnData helpers with the reference's behaviour (``flashdeconv/io/loader.py:15-311``).
 
 Nothing here is on the hot path: it pulls matrices out of AnnData-like objects (``.X``, ``.layers``, ``.obsm``, ``.obs``,
-``.var_names``, ``.obs_names``, ``.n_obs``) and writes the result back.  Out of scope to accelerate.
+``.var_names``, ``.obs_names``, ``.n_obs``) and writes the result back.  Matrices that already live on the GPU (CUDA
+``torch`` tensors, dense or ``sparse_csr``) stay there: the per-cell-type signatures are formed by
+``fdx_type_sums_dev`` / ``fdx_type_sums_csr_dev``, the gene alignment is a device-side column selection, and the spot matrix
+goes to ``FlashDeconv.fit`` as the tensor it is - only the K x G signature table and the result come to the host.
 """
+import ctypes
+
 import numpy as np
 from scipy import sparse
+
+from .. import _lib
+
+
+def _is_cuda_tensor(x):
+    return type(x).__module__.split(".")[0] == "torch" and getattr(x, "is_cuda", False)
+
+
+def _type_sums_device(expr, codes, K, mean):
+    """(K, G) float64 signatures of a CUDA tensor (dense or sparse_csr): rows added per type in ascending row order."""
+    import torch
+    lib = _lib.load()
+    n, G = expr.shape
+    order = np.argsort(codes, kind="stable").astype(np.int32)                 # cells by type, ascending row inside a type
+    off = np.concatenate([[0], np.cumsum(np.bincount(codes, minlength=K))]).astype(np.int32)
+    dev = expr.device
+    rows_d = torch.from_numpy(order).to(dev)
+    off_d = torch.from_numpy(off).to(dev)
+    X = torch.empty((K, G), dtype=torch.float64, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if _lib.is_torch_sparse_csr(expr):
+        csr = _lib.CsrOnDevice.from_torch(expr)
+        try:
+            _lib.check(lib.fdx_type_sums_csr_dev(ctypes.byref(csr.view), ctypes.c_void_p(rows_d.data_ptr()),
+                                                 ctypes.c_void_p(off_d.data_ptr()), K, 1 if mean else 0,
+                                                 ctypes.c_void_p(X.data_ptr()), st))
+            torch.cuda.synchronize(dev)
+        finally:
+            csr.free()
+    else:
+        Yd = expr if expr.dtype in (torch.float32, torch.float64) else expr.to(torch.float64)
+        Yd = Yd.contiguous()
+        _lib.check(lib.fdx_type_sums_dev(ctypes.c_void_p(Yd.data_ptr()), _lib.FDX_F32 if Yd.dtype == torch.float32 else _lib.FDX_F64,
+                                         n, G, G, ctypes.c_void_p(rows_d.data_ptr()), ctypes.c_void_p(off_d.data_ptr()), K,
+                                         1 if mean else 0, ctypes.c_void_p(X.data_ptr()), st))
+    return X.cpu().numpy()
+
+
+def _select_columns_device(Y, idx):
+    """Y[:, idx] for a CUDA tensor, on the device.  sparse_csr: entries of other columns dropped, columns renumbered (the
+    rows of the result are in general not column-sorted; the CSR kernels take that)."""
+    import torch
+    dev = Y.device
+    if not _lib.is_torch_sparse_csr(Y):
+        return Y.index_select(1, torch.as_tensor(np.asarray(idx, dtype=np.int64), device=dev))
+    n, G = Y.shape
+    lut = torch.full((G,), -1, dtype=torch.int64, device=dev)
+    lut[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=dev)] = torch.arange(len(idx), dtype=torch.int64, device=dev)
+    crow, col, val = Y.crow_indices().to(torch.int64), Y.col_indices().to(torch.int64), Y.values()
+    new_col = lut[col]
+    keep = new_col >= 0
+    kept_before = torch.zeros(col.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(keep.to(torch.int64), 0, out=kept_before[1:])
+    return torch.sparse_csr_tensor(kept_before[crow], new_col[keep].to(torch.int32), val[keep], size=(n, len(idx)), device=dev)
 
 
 def load_spatial_data(adata, layer=None, coord_key="spatial"):
@@ -31,6 +90,9 @@ def load_reference(adata_ref, cell_type_key="cell_type", layer=None, method="mea
     if method not in ("mean", "sum"):
         raise ValueError(f"Unknown aggregation method: {method}")
     labels = np.array(adata_ref.obs[cell_type_key])
+    if _is_cuda_tensor(expr):                                               # the matrix stays on the GPU
+        names, codes = np.unique(labels, return_inverse=True)
+        return _type_sums_device(expr, codes.ravel(), len(names), method == "mean"), names, np.array(adata_ref.var_names)
     names = np.unique(labels)
     X = np.zeros((len(names), expr.shape[1]), dtype=np.float64)
     for i, name in enumerate(names):
@@ -52,6 +114,8 @@ def align_genes(Y, X, genes_spatial, genes_ref):
         first_r.setdefault(g, i)
     si = np.array([first_s[g] for g in common])
     ri = np.array([first_r[g] for g in common])
+    if _is_cuda_tensor(Y):
+        return _select_columns_device(Y, si), X[:, ri], common
     return Y[:, si], X[:, ri], common
 
 

@@ -241,6 +241,15 @@ int fdx_fit_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t G, c
                     int32_t dim, const fdx_fit_params* params, fdx_graph** graph_inout, double* beta_out_dev,
                     double* prop_out_dev, double* objectives_out, double* rel_changes_out, fdx_fit_info* info, void* stream);
 
+/* Per-cell-type signatures from a single-cell reference resident on the device (io/loader.py:114-135 load_reference):
+ * X[k, :] = sum (mean = 0) or mean (mean = 1) over the cells of type k.  rows_dev: int32[n] the cell rows sorted by type and,
+ * inside a type, ascending (a stable sort of the host-side labels); type_off_dev: int32[K + 1] the ranges of the types in
+ * rows_dev.  Rows are added in that order (numpy's axis-0 order) in float64.  X_out_dev: (K, G) float64 on the device. */
+int fdx_type_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, int64_t ldy, const int32_t* rows_dev,
+                      const int32_t* type_off_dev, int32_t K, int32_t mean, double* X_out_dev, void* stream);
+int fdx_type_sums_csr_dev(const fdx_csr_view* Y, const int32_t* rows_dev, const int32_t* type_off_dev, int32_t K, int32_t mean,
+                          double* X_out_dev, void* stream);
+
 /* ---- device-pointer building blocks (spot-sharded multi-GPU driver, flashdeconv_amd/distributed.py) ------- *
  * One process per GPU; the host side (torch.distributed over RCCL) owns the buffers and the halo exchange, these
  * entry points only enqueue kernels on `stream`.  Same reference lines as the single-GPU entries above.           */

@@ -382,3 +382,49 @@ def test_dense_whole_transcriptome_float64_gene_subset():
     assert 600 <= len(a.gene_idx_) < G_all
     b = FlashDeconv(**dict(kw, n_hvg=len(a.gene_idx_))).fit(Y[:, a.gene_idx_], X[:, a.gene_idx_], coords)
     assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["dense", "csr"])
+def test_tl_deconvolve_with_matrices_resident_on_the_gpu(kind):
+    """an AnnData whose matrices are CUDA tensors (dense or sparse_csr) goes through tl.deconvolve
+    without coming back to the host - per-type signatures by fdx_type_sums(_csr)_dev, gene alignment as a device-side column
+    selection, the spot tensor straight into FlashDeconv.fit.  Same result as the host path on the same data."""
+    import torch
+    import flashdeconv_amd as fd
+    from flashdeconv_amd.io import load_reference, prepare_data
+    g = load_golden("fit_counts_100x500x5_d64.npz")
+    Y, X, coords = g["Y"].astype(np.float64), g["X"], g["coords"]
+    rs = np.random.RandomState(1)
+    genes_st = np.array([f"g{i}" for i in range(500)])
+    genes_ref = np.array([f"g{i}" for i in range(30, 530)])[::-1]            # partial overlap, other order
+    labels = rs.permutation(np.repeat([f"type{k}" for k in range(5)], [9, 3, 14, 1, 13]))
+    kidx = np.array([int(s[4:]) for s in labels])
+    cells = rs.poisson(X[kidx][:, ::-1].repeat(1, axis=0)[:, :500] * 3.0).astype(np.float64)
+    cells[rs.rand(*cells.shape) < 0.6] = 0.0
+    dev = torch.device("cuda", 0)
+
+    def on_device(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return t.to_sparse_csr() if kind == "csr" else t
+
+    host_in = (lambda a: sparse.csr_matrix(a)) if kind == "csr" else (lambda a: a)
+    ref_h = _FakeAnnData(host_in(cells), genes_ref, [f"c{i}" for i in range(40)], obs={"celltype": labels})
+    st_h = _FakeAnnData(host_in(Y), genes_st, [f"s{i}" for i in range(100)], obsm={"spatial": coords})
+    ref_d = _FakeAnnData(on_device(cells), genes_ref, [f"c{i}" for i in range(40)], obs={"celltype": labels})
+    st_d = _FakeAnnData(on_device(Y), genes_st, [f"s{i}" for i in range(100)], obsm={"spatial": coords})
+    for method in ("mean", "sum"):
+        Xh, nh, _ = load_reference(ref_h, cell_type_key="celltype", method=method)
+        Xd, nd, _ = load_reference(ref_d, cell_type_key="celltype", method=method)
+        assert list(nh) == list(nd)
+        np.testing.assert_allclose(Xd, Xh, rtol=1e-13, atol=0)
+    Yh, Xh, _, _, genes_h = prepare_data(st_h, ref_h, cell_type_key="celltype")
+    Yd, Xd, _, _, genes_d = prepare_data(st_d, ref_d, cell_type_key="celltype")
+    assert list(genes_h) == list(genes_d) and len(genes_d) == 470 and Yd.is_cuda
+    Yd_dense = Yd.to_dense() if kind == "csr" else Yd
+    assert np.array_equal(Yd_dense.cpu().numpy(), Yh.toarray() if kind == "csr" else Yh)
+    assert fd.tl.deconvolve(st_h, ref_h, cell_type_key="celltype", sketch_dim=64, k_neighbors=4) is None
+    assert fd.tl.deconvolve(st_d, ref_d, cell_type_key="celltype", sketch_dim=64, k_neighbors=4) is None
+    Ph, Pd = st_h.obsm["flashdeconv"], st_d.obsm["flashdeconv"]
+    assert list(Ph.columns) == list(Pd.columns)
+    assert rel_fro(Pd.values, Ph.values) < 1e-9
+    assert st_d.uns["flashdeconv_params"]["n_genes_used"] == st_h.uns["flashdeconv_params"]["n_genes_used"]
