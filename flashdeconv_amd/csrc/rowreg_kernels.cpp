@@ -216,9 +216,9 @@ __global__ __launch_bounds__(RR_NW * 64, RR_NW / 4) void rowreg_sketch_kernel(
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const unsigned bits = (__float_as_uint(rc[e]) + 0x8000u) & 0xFFFF0000u;      // reciprocal of 1 + x, 8 significant bits
+                const unsigned bits = (__float_as_uint(rc[e]) + LOG_TAB_ROUND) & LOG_TAB_MASK;   // reciprocal of 1 + x, rounded to the table's bits
                 const double inv = (double)__uint_as_float(bits);
-                ti[e] = (bits >> 13) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8);
+                ti[e] = (bits >> (LOG_TAB_SHIFT - 3)) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8);
                 rr[e] = fma((double)y[e] * scale, inv, inv - 1.0);                           // (1 + x) * inv - 1 with one rounding
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(RR_NW * 64, RR_NW / 4) void rowreg_sketch_kernel(
             const double2_t w01 = reinterpret_cast<const double2_t*>(wv_l)[2 * v], w23 = reinterpret_cast<const double2_t*>(wv_l)[2 * v + 1];
             const uint4_t en = reinterpret_cast<const uint4_t*>(ent_l)[v];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pp[e] = fma3(rr[e], -1.0 / 6.0, 0.2);
+            for (int e = 0; e < 4; ++e) pp[e] = LOG_TAB_MB == 7 ? fma3(rr[e], -1.0 / 6.0, 0.2) : fma3(rr[e], fma3(rr[e], 1.0 / 7.0, -1.0 / 6.0), 0.2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) pp[e] = fma(rr[e], pp[e], -0.25);
 #pragma unroll

@@ -10,11 +10,20 @@ namespace fdx {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int TILE_ROWS = 16;
-constexpr int LOG_TAB_N = 1921;           // 15 binades x 128 + 1 reciprocals in [2^-15, 1]
-constexpr int LOG_TAB_BASE = 14336;       // (bits of 2^-15) >> 16
-// The table sits at a FIXED place, the top of the 160 KB: its address is then (rounded reciprocal bits >> 13) plus a
+// Table-driven log1p: 1 + x is reduced by a reciprocal rounded to LOG_TAB_MB explicit mantissa bits, taken from a table of
+// -log(reciprocal) over 15 binades, to 1 + r with |r| <= 2^-(LOG_TAB_MB + 1); a polynomial of degree LOG_TAB_MB == 7 ? 6 : 7
+// in r finishes it (truncation below 2^-56).  6 bits: 961 entries = 7.7 KB instead of 15.4 KB and one more fma per element -
+// the 7.7 KB are what lets the tile kernel stage 2000 float32 genes in two column blocks instead of three (a third fewer
+// group prologues and tails, 4 % less lockstep padding).
+constexpr int LOG_TAB_MB = 6;
+constexpr int LOG_TAB_SHIFT = 23 - LOG_TAB_MB;                    // bits of the float reciprocal below the table index
+constexpr int LOG_TAB_N = 15 * (1 << LOG_TAB_MB) + 1;             // reciprocals in [2^-15, 1]
+constexpr int LOG_TAB_BASE = 112 << LOG_TAB_MB;                   // (bits of 2^-15) >> LOG_TAB_SHIFT
+constexpr unsigned LOG_TAB_ROUND = 1u << (LOG_TAB_SHIFT - 1);
+constexpr unsigned LOG_TAB_MASK = ~((1u << LOG_TAB_SHIFT) - 1u);
+// The table sits at a FIXED place, the top of the 160 KB: its address is then (rounded reciprocal bits >> (SHIFT - 3)) plus a
 // compile-time constant that fits the 16-bit offset field of ds_read_b64 - no base add, no index mask per element.
-constexpr int LOG_TAB_LDS = 160 * 1024 - LOG_TAB_N * 8;
+constexpr int LOG_TAB_LDS = 160 * 1024 - ((LOG_TAB_N * 8 + 15) & ~15);
 
 // d = a * b + c as one VOP3 instruction with the addend in its own register
 __device__ __forceinline__ double fma3(double a, double b, double c) {
@@ -28,18 +37,24 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
 }
 
 // log1p(x) for x in [0, 32000): see the header.  logt[i] = -log(c_i), c_i the reciprocal with bit pattern
-// (LOG_TAB_BASE + i) << 16.  uf: 1 + x to float accuracy (only the 8-bit reciprocal is taken from it).
+// (LOG_TAB_BASE + i) << LOG_TAB_SHIFT.  uf: 1 + x to float accuracy (only the rounded reciprocal is taken from it).
 __device__ __forceinline__ double tile_log1p_core(double x, float uf, const double* logt) {
     unsigned bits = __float_as_uint(__builtin_amdgcn_rcpf(uf));
-    bits = (bits + 0x8000u) & 0xFFFF0000u;                   // reciprocal rounded to 8 significant bits
+    bits = (bits + LOG_TAB_ROUND) & LOG_TAB_MASK;            // reciprocal rounded to LOG_TAB_MB + 1 significant bits
     const double inv = (double)__uint_as_float(bits);
     const double r = fma(x, inv, inv - 1.0);                 // (1 + x) * inv - 1 with one rounding (inv - 1 is exact)
     (void)logt;   // the dynamic LDS segment starts at LDS address 0 (no static __shared__ in these kernels): absolute address
     typedef const double __attribute__((address_space(3))) * lds_cdouble_p;
-    const double t = *(lds_cdouble_p)(size_t)((bits >> 13) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8));
+    const double t = *(lds_cdouble_p)(size_t)((bits >> (LOG_TAB_SHIFT - 3)) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8));
     // Horner steps whose addend is a non-inline constant: written as three-operand v_fma_f64.  Left to the compiler they
     // become v_mov_b64 (constant -> destination) + v_fmac_f64, two instructions where one does.
-    double p = fma3(r, -1.0 / 6.0, 0.2);
+    double p;
+    if (LOG_TAB_MB == 7) {
+        p = fma3(r, -1.0 / 6.0, 0.2);
+    } else {
+        p = fma3(r, 1.0 / 7.0, -1.0 / 6.0);
+        p = fma3(r, p, 0.2);
+    }
     p = fma(r, p, -0.25);
     p = fma3(r, p, 1.0 / 3.0);
     p = fma(r, p, -0.5);
@@ -80,7 +95,7 @@ template <int MODE> __device__ __forceinline__ double tile_row_scale(double sum)
 // pieces of the next block, which are meant to stay in flight across the reduction at the end of a tile.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// -log of every 8-bit reciprocal in [2^-15, 1] (LOG_TAB_N doubles), one copy per device; NULL on failure
+// -log of every table reciprocal in [2^-15, 1] (LOG_TAB_N doubles), one copy per device; NULL on failure
 const double* log_table_dev(hipStream_t st);
 
 }  // namespace fdx

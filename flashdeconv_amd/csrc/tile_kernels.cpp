@@ -17,9 +17,9 @@
 //               The NW partial 16 x 16 type tiles are added in wave order through LDS (deterministic) and stored to H.
 //   log-CPM     needs the row sum before the first element can be transformed: each wave sums one or two rows of the
 //               NEXT tile from registers (plain global loads, which also pull the rows into L2 / Infinity Cache ahead of
-//               the DMA) while the current tile is consumed.  log1p is table driven: 1 + x is reduced by an 8-bit
-//               reciprocal (v_rcp_f32) to 1 + r with |r| <= 2^-8, log1p(x) = T[reciprocal] + r - r^2/2 + ... - r^6/6
-//               (~20 instructions instead of ~45; < 3 ulp).
+//               the DMA) while the current tile is consumed.  log1p is table driven: 1 + x is reduced by a 7-bit
+//               reciprocal (v_rcp_f32) to 1 + r with |r| <= 2^-7, log1p(x) = T[reciprocal] + r - r^2/2 + ... + r^7/7
+//               (~21 instructions instead of ~45; < 3 ulp; tile_device.h).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -448,7 +448,7 @@ struct TilePlanDevice {
     size_t lds = 0;
 };
 
-const double* log_table_dev(hipStream_t st) {   // -log of every 8-bit reciprocal in [2^-15, 1], one copy per device
+const double* log_table_dev(hipStream_t st) {   // -log of every table reciprocal in [2^-15, 1], one copy per device
     static std::mutex mu;
     static double* tabs[64] = {};
     int dev = 0;
@@ -457,7 +457,7 @@ const double* log_table_dev(hipStream_t st) {   // -log of every 8-bit reciproca
     if (!tabs[dev]) {
         std::vector<double> t((size_t)LOG_TAB_N);
         for (int i = 0; i < LOG_TAB_N; ++i) {
-            const unsigned bits = (unsigned)(LOG_TAB_BASE + i) << 16;
+            const unsigned bits = (unsigned)(LOG_TAB_BASE + i) << LOG_TAB_SHIFT;
             float c;
             std::memcpy(&c, &bits, 4);
             t[(size_t)i] = (double)(-logl((long double)c));
