@@ -185,7 +185,7 @@ __global__ __launch_bounds__(RR_NW * 64, RR_NW / 4) void rowreg_sketch_kernel(
 #undef FDX_RR_FENCE
         const double s = tile_row_scale<MODE>(rr_wave_sum(p));
         // NaN / Inf anywhere in the row makes the sum, hence the scale, NaN or 0 * Inf: the test fails
-        ok = (double)rr_wave_max(mx) * s < 32000.0 && !__any((int)sg < 0);
+        ok = (double)rr_wave_max(mx) * s < 32000.0 && s > 1e-14 && !__any((int)sg < 0);
         scale = s;
     };
 
@@ -207,19 +207,20 @@ __global__ __launch_bounds__(RR_NW * 64, RR_NW / 4) void rowreg_sketch_kernel(
             // and every element then waits out its own table read and its own chain of dependent f64 operations.  The
             // gene tables (weight, place in the image) are read with the log table, behind the argument reduction.
             typedef const double __attribute__((address_space(3))) * lds_cdouble_p;
-            const float sf = (float)scale;
+            const double scale_s = scale * FDX_LOG_DOWN;                      // tile_device.h: the reciprocal is formed of (1 + x) * 2^-65
+            const float sf = (float)scale_s;
             float rc[4];
             double rr[4], tt[4], pp[4];
             unsigned ti[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rc[e] = __builtin_amdgcn_rcpf(fmaf(y[e], sf, 1.0f));
+            for (int e = 0; e < 4; ++e) rc[e] = __builtin_amdgcn_rcpf(fmaf(y[e], sf, FDX_LOG_DOWN_F));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned bits = (__float_as_uint(rc[e]) + LOG_TAB_ROUND) & LOG_TAB_MASK;   // reciprocal of 1 + x, rounded to the table's bits
                 const double inv = (double)__uint_as_float(bits);
                 ti[e] = (bits >> (LOG_TAB_SHIFT - 3)) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8);
-                rr[e] = fma((double)y[e] * scale, inv, inv - 1.0);                           // (1 + x) * inv - 1 with one rounding
+                rr[e] = fma((double)y[e] * scale_s, inv, fma(FDX_LOG_DOWN, inv, -1.0));      // (1 + x) * c - 1 with one rounding
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

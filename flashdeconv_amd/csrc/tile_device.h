@@ -18,12 +18,19 @@ constexpr int TILE_ROWS = 16;
 constexpr int LOG_TAB_MB = 6;
 constexpr int LOG_TAB_SHIFT = 23 - LOG_TAB_MB;                    // bits of the float reciprocal below the table index
 constexpr int LOG_TAB_N = 15 * (1 << LOG_TAB_MB) + 1;             // reciprocals in [2^-15, 1]
-constexpr int LOG_TAB_BASE = 112 << LOG_TAB_MB;                   // (bits of 2^-15) >> LOG_TAB_SHIFT
+// The reciprocal is formed of (1 + x) * 2^-65, not of 1 + x: its exponent field then starts at 177 instead of 112, which puts
+// (table address - index bytes of the first entry) inside the 16-bit offset field of ds_read_b64 with the table at the top of
+// the LDS.  The scaling is free: it is folded into the row's scale (and undone inside the fma that forms r).
+constexpr int LOG_TAB_EXP_SHIFT = 65;
+constexpr int LOG_TAB_BASE = (112 + LOG_TAB_EXP_SHIFT) << LOG_TAB_MB;   // (bits of 2^(65 - 15)) >> LOG_TAB_SHIFT
 constexpr unsigned LOG_TAB_ROUND = 1u << (LOG_TAB_SHIFT - 1);
 constexpr unsigned LOG_TAB_MASK = ~((1u << LOG_TAB_SHIFT) - 1u);
 // The table sits at a FIXED place, the top of the 160 KB: its address is then (rounded reciprocal bits >> (SHIFT - 3)) plus a
 // compile-time constant that fits the 16-bit offset field of ds_read_b64 - no base add, no index mask per element.
 constexpr int LOG_TAB_LDS = 160 * 1024 - ((LOG_TAB_N * 8 + 15) & ~15);
+static_assert(LOG_TAB_LDS - LOG_TAB_BASE * 8 >= 0 && LOG_TAB_LDS - LOG_TAB_BASE * 8 <= 65535, "log table offset must fit ds_read's offset field");
+#define FDX_LOG_DOWN 0x1p-65
+#define FDX_LOG_DOWN_F 0x1p-65f
 
 // d = a * b + c as one VOP3 instruction with the addend in its own register
 __device__ __forceinline__ double fma3(double a, double b, double c) {
@@ -36,52 +43,67 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
 #endif
 }
 
-// log1p(x) for x in [0, 32000): see the header.  logt[i] = -log(c_i), c_i the reciprocal with bit pattern
-// (LOG_TAB_BASE + i) << LOG_TAB_SHIFT.  uf: 1 + x to float accuracy (only the rounded reciprocal is taken from it).
-__device__ __forceinline__ double tile_log1p_core(double x, float uf, const double* logt) {
-    unsigned bits = __float_as_uint(__builtin_amdgcn_rcpf(uf));
+// The polynomial's non-inline coefficients as register values the compiler cannot re-create: written as literals they are
+// re-materialised (v_mov_b64 from scalar registers) at every use - four extra instructions per two elements in the gather loop.
+struct LogConsts { double c7, c6, c5, c3; };
+__device__ __forceinline__ LogConsts log_consts() {
+    LogConsts c{1.0 / 7.0, -1.0 / 6.0, 0.2, 1.0 / 3.0};
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(c.c7), "+v"(c.c6), "+v"(c.c5), "+v"(c.c3));
+#endif
+    return c;
+}
+
+// log1p(x) for x in [0, 32000): see the header.  logt[i] = -log(c_i), c_i = 2^-65 x the value with bit pattern
+// (LOG_TAB_BASE + i) << LOG_TAB_SHIFT.  xs = x * 2^-65; ufs = (1 + x) * 2^-65 to float accuracy (only the rounded
+// reciprocal is taken from it).
+__device__ __forceinline__ double tile_log1p_core(double xs, float ufs, const LogConsts& lc) {
+    unsigned bits = __float_as_uint(__builtin_amdgcn_rcpf(ufs));
     bits = (bits + LOG_TAB_ROUND) & LOG_TAB_MASK;            // reciprocal rounded to LOG_TAB_MB + 1 significant bits
-    const double inv = (double)__uint_as_float(bits);
-    const double r = fma(x, inv, inv - 1.0);                 // (1 + x) * inv - 1 with one rounding (inv - 1 is exact)
-    (void)logt;   // the dynamic LDS segment starts at LDS address 0 (no static __shared__ in these kernels): absolute address
+    const double inv = (double)__uint_as_float(bits);        // 2^65 / (1 + x), rounded
+    const double r = fma(xs, inv, fma(FDX_LOG_DOWN, inv, -1.0));   // (1 + x) * c - 1 with one rounding (c - 1 is exact)
+    // the dynamic LDS segment starts at LDS address 0 (no static __shared__ in these kernels): absolute address
     typedef const double __attribute__((address_space(3))) * lds_cdouble_p;
     const double t = *(lds_cdouble_p)(size_t)((bits >> (LOG_TAB_SHIFT - 3)) + (unsigned)(LOG_TAB_LDS - LOG_TAB_BASE * 8));
-    // Horner steps whose addend is a non-inline constant: written as three-operand v_fma_f64.  Left to the compiler they
-    // become v_mov_b64 (constant -> destination) + v_fmac_f64, two instructions where one does.
+    // Horner steps whose addend is not an inline constant: three-operand v_fma_f64 on registers (left to the compiler they
+    // become v_mov_b64 (constant -> destination) + v_fmac_f64)
     double p;
     if (LOG_TAB_MB == 7) {
-        p = fma3(r, -1.0 / 6.0, 0.2);
+        p = fma3(r, lc.c6, lc.c5);
     } else {
-        p = fma3(r, 1.0 / 7.0, -1.0 / 6.0);
-        p = fma3(r, p, 0.2);
+        p = fma3(r, lc.c7, lc.c6);
+        p = fma3(r, p, lc.c5);
     }
     p = fma(r, p, -0.25);
-    p = fma3(r, p, 1.0 / 3.0);
+    p = fma3(r, p, lc.c3);
     p = fma(r, p, -0.5);
     p = fma(r, p, 1.0);
     return fma(r, p, t);
 }
-__device__ __forceinline__ double tile_log1p_fast(double x, const double* logt) { return tile_log1p_core(x, 1.0f + (float)x, logt); }
-// the same for y * scale with y already a float: 1 + x comes from one float fma
-__device__ __forceinline__ double tile_log1p_scaled(float y, double scale, float scale_f, const double* logt) {
-    return tile_log1p_core((double)y * scale, fmaf(y, scale_f, 1.0f), logt);
+__device__ __forceinline__ double tile_log1p_fast(double x, const LogConsts& lc) {
+    const double xs = x * FDX_LOG_DOWN;
+    return tile_log1p_core(xs, (float)xs + FDX_LOG_DOWN_F, lc);
 }
-__device__ __forceinline__ double tile_log1p_scaled(double y, double scale, float, const double* logt) {
-    const double x = y * scale;
-    return tile_log1p_core(x, 1.0f + (float)x, logt);
+// the same for y * scale with y already a float: (1 + x) * 2^-65 comes from one float fma.  scale_s = scale * 2^-65.
+__device__ __forceinline__ double tile_log1p_scaled(float y, double scale_s, float scale_sf, const LogConsts& lc) {
+    return tile_log1p_core((double)y * scale_s, fmaf(y, scale_sf, FDX_LOG_DOWN_F), lc);
+}
+__device__ __forceinline__ double tile_log1p_scaled(double y, double scale_s, float, const LogConsts& lc) {
+    const double xs = y * scale_s;
+    return tile_log1p_core(xs, (float)xs + FDX_LOG_DOWN_F, lc);
 }
 // Anything outside the fast range (negative, NaN, huge) takes the library function, as the reference would.  Kept out of
 // line: inlined into every gather loop it costs registers on the path that matters.
 static __device__ __attribute__((noinline)) double tile_log1p_slow(double x) { return log1p(x); }
-__device__ __forceinline__ double tile_log1p(double x, const double* logt) {
+__device__ __forceinline__ double tile_log1p(double x, const LogConsts& lc) {
     if (__builtin_expect(!(x >= 0.0) || !(x < 32000.0), 0)) return tile_log1p_slow(x);
-    return tile_log1p_fast(x, logt);
+    return tile_log1p_fast(x, lc);
 }
 
 // the same with the library function inlined (no call: a call site makes the caller spill its live registers around it)
-__device__ __forceinline__ double tile_log1p_general(double x, const double* logt) {
+__device__ __forceinline__ double tile_log1p_general(double x, const LogConsts& lc) {
     if (__builtin_expect(!(x >= 0.0) || !(x < 32000.0), 0)) return log1p(x);
-    return tile_log1p_fast(x, logt);
+    return tile_log1p_fast(x, lc);
 }
 
 // scale of one row for the log modes

@@ -182,12 +182,13 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         }
         const double sum0 = wave_sum(p0);
         const double s0 = tile_row_scale<MODE>(sum0);
-        const bool ok0 = fabs(sum0) <= 1.7e308 && !__any((long long)sg0 < 0);        // false for a NaN / Inf sum
+        const bool ok0 = fabs(sum0) <= 1e18 && !__any((long long)sg0 < 0);           // false for a NaN / Inf sum; above 1e18 the
+                                                                                  // scale * 2^-65 would leave the float range
         if (lane == 0 && r0) { out_scale[i0] = s0; out_ok[i0] = ok0 ? 1 : 0; }
         if (TWO && r1) {
             const double sum1 = wave_sum(p1);
             const double s1 = tile_row_scale<MODE>(sum1);
-            const bool ok1 = fabs(sum1) <= 1.7e308 && !__any((long long)sg1 < 0);
+            const bool ok1 = fabs(sum1) <= 1e18 && !__any((long long)sg1 < 0);
             if (lane == 0) { out_scale[i1] = s1; out_ok[i1] = ok1 ? 1 : 0; }
         }
     };
@@ -271,6 +272,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         }
     }
     if (NWL > 0) __builtin_amdgcn_s_waitcnt(0x0f70);
+    const LogConsts lc = log_consts();
     int buf = 0, par = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
         if (AVL2) asm volatile("" : "+v"(lane8));                           // the operand addresses are formed where they are used
@@ -286,7 +288,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         for (int t = 0; t < TT; ++t) accm[t] = double4_t{0.0, 0.0, 0.0, 0.0};
         double sq = 0.0;
         double scale = 1.0;
-        float scale_f = 1.0f;
+        double scale_s = FDX_LOG_DOWN;                                      // scale * 2^-65 (tile_device.h)
+        float scale_sf = FDX_LOG_DOWN_F;
         bool fast = true;
         // One column block: software pipeline over the flat entry stream - weight and value of the current step in
         // registers, the offset of the step after next already fetched, so a step costs one LDS round trip, not two.
@@ -305,8 +308,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             unsigned offn = off_l[p + 4];
             auto f = [&](T yy) -> double {
                 if (MODE == FDX_PRE_RAW) return (double)yy;
-                if (FAST) return tile_log1p_scaled(yy, scale, scale_f, logt);
-                return tile_log1p((double)yy * scale, logt);
+                if (FAST) return tile_log1p_scaled(yy, scale_s, scale_sf, lc);
+                return tile_log1p((double)yy * scale, lc);
             };
 #pragma unroll
             for (int j = 0; j < JW; ++j) {
@@ -352,7 +355,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             if (NWL == 0) stage_step(c, buf, par);
             if (MODE != FDX_PRE_RAW && c == 0) {
                 scale = scales[par * TILE_ROWS + r];
-                scale_f = (float)scale;
+                scale_s = scale * FDX_LOG_DOWN;
+                scale_sf = (float)scale_s;
                 fast = __all(rowok[par * TILE_ROWS + r] != 0);
             }
             if (MODE == FDX_PRE_RAW || fast) consume(c, last_tag, std::true_type{});
@@ -458,9 +462,9 @@ const double* log_table_dev(hipStream_t st) {   // -log of every table reciproca
         std::vector<double> t((size_t)LOG_TAB_N);
         for (int i = 0; i < LOG_TAB_N; ++i) {
             const unsigned bits = (unsigned)(LOG_TAB_BASE + i) << LOG_TAB_SHIFT;
-            float c;
+            float c;                                                        // 2^65 x the reciprocal
             std::memcpy(&c, &bits, 4);
-            t[(size_t)i] = (double)(-logl((long double)c));
+            t[(size_t)i] = (double)(-logl((long double)c) + (long double)LOG_TAB_EXP_SHIFT * 0.693147180559945309417232121458176568L);
         }
         double* p = nullptr;
         if (hipMalloc(&p, t.size() * sizeof(double)) != hipSuccess) return nullptr;
@@ -610,8 +614,10 @@ static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hip
     // log modes, 16 self-staging waves: operands from the L2 copy as in the wide form - the 32 registers they would occupy
     // are what the 128-register budget lacks for the log1p chains (22 spills with them; 4.23 -> 4.1 ms).  Raw (12 + 4) keeps
     // them in registers: 2.34 ms with the fetches against 1.98 ms.
-    if (L.XA && MODE != FDX_PRE_RAW && NWC == 16)
-        kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true>;
+    if constexpr (MODE != FDX_PRE_RAW && NWC == 16) {
+        if (L.XA)
+            kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true>;
+    }
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
                     (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab,
