@@ -277,7 +277,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     const long long chunk = std::min<long long>(n, chunk_rows);
     const bool fused = !ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, prm->mode_y, plan_y.dev());
     if (!fused) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
-    FDX_HIP(hipMemsetAsync(dH.p, 0, dH.bytes, st));
+    FDX_TRY(solver_zero_pad(dH.as<double>(), ld, n, K, st));   // columns of real spots are all written by the sketch -> H stage
     const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();
     double sketch_ms = 0.0, gram_ms = 0.0;
     hipEvent_t eS0 = nullptr, eS1 = nullptr;     // around the fused kernel; read at the end of the fit, no wait here

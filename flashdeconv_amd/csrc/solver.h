@@ -40,6 +40,8 @@ struct SolveResult {
 };
 
 int solver_init_beta(double* beta, long long ld, long long n_fill, int K, hipStream_t st);
+// zero the pad columns [n_used, ld) of a type-major (K, ld) array
+int solver_zero_pad(double* b, long long ld, long long n_used, int K, hipStream_t st);
 // The four sums of the objective on the device (out4_dev); the sharded driver all-reduces them across ranks.
 int solver_objective_partials(const fdx_graph& g, const double* beta, long long ld, const double* H, long long ldh,
                               const double* XtX, int K, double* scratch_partials, double* out4_dev, hipStream_t st);
