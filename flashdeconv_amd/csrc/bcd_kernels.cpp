@@ -126,7 +126,7 @@ int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scra
 
 int launch_bcd_objective_tiled(const BcdSweepArgs& a0, double* partials, hipStream_t st) {
     if (!a0.tiled || a0.K < 1 || a0.K > FDX_MAX_K_FAST) return 1;
-    const int KC = a0.K < 8 ? a0.K : 8;   // = sweep_chunk(K)
+    const int KC = a0.K < 8 ? a0.K : 8;   // upper bound of sweep_chunk(K)
     if ((size_t)KC * (256 + a0.halo_max + 1) * sizeof(double) > 64 * 1024) return 1;
     BcdSweepArgs a = a0;
     a.objective = 1;

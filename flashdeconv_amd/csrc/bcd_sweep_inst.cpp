@@ -36,8 +36,18 @@
 
 namespace fdx {
 
-// cell types per chunk (8: measured best at K=30 on MI355X; 10 costs a wave of occupancy)
-constexpr int sweep_chunk(int K) { return K < 8 ? K : 8; }
+// Cell types per chunk.  The K abundances of a spot are registers (2 K), every type of the chunk adds 6 more (neighbour sum,
+// H value, halo value in flight), and 168 registers are the limit for three waves per SIMD, which is what decides the speed:
+// K = 40 at 1M spots takes 417 us with chunks of 8 (171 registers, two waves) and 269 us with chunks of 5 (167).  The
+// table is the largest chunk that stays within 168 registers, per K, from tools/sweep_regs.py (compile and count; timings
+// of neighbouring chunk sizes on MI355X agree with that rule for K = 30 ... 38); from K = 52 on nothing fits and the
+// chunk of 8 at two waves is kept.
+constexpr int sweep_chunk(int K) {
+#ifdef FDX_KC_OVERRIDE                       // tools/sweep_regs.py: register count per (K, chunk)
+    return K < FDX_KC_OVERRIDE ? K : FDX_KC_OVERRIDE;
+#endif
+    return K < 8 ? K : K <= 28 ? 8 : K <= 31 ? 7 : K == 32 ? 8 : K <= 35 ? 6 : K <= 40 ? 5 : K <= 44 ? 4 : K <= 48 ? 3 : K <= 51 ? 2 : 8;
+}
 
 template <int K, int KC>
 __global__ __launch_bounds__(256) void bcd_sweep_kernel(
@@ -171,11 +181,24 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
     // tile-local neighbour slots of this spot: the first 16 live in registers for all chunks (two 16-bit slots per VGPR),
     // wider slices (rare) read the rest from memory
     unsigned slots[8];
+    // all 16 loads go out together whatever the slice width (the table is padded by 16 rows, graph_kernels.cpp); entries
+    // past the width belong to the next slice and are never used
 #pragma unroll
     for (int m2 = 0; m2 < 8; ++m2) {
-        const unsigned lo = (2 * m2 < w) ? (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2) * 64]) : 0u;
-        const unsigned hi = (2 * m2 + 1 < w) ? (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2 + 1) * 64]) : 0u;
+        const unsigned lo = (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2) * 64]);
+        const unsigned hi = (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2 + 1) * 64]);
         slots[m2] = lo | (hi << 16);
+    }
+    // Software pipeline over the chunks: what chunk c+1 needs from global memory - the old values of the first 256 halo
+    // spots (hv, one per thread) and the spot's own H values (hreg) - is requested during the coordinate steps of chunk
+    // c, two loads after each step, into the registers that step has just finished with (its neighbour sum and its H
+    // value): halo values in the first half of the chunk (they are written to LDS right after it), H in the second half
+    // (used after the next gather).  No load is waited for where it is issued.
+    double hv[KC], hreg[KC];
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+        hv[q] = beta_in[q * ld + hidx0];                                           // threads past Ht read spot 0: harmless
+        hreg[q] = __builtin_nontemporal_load(&H[q * (size_t)ldh + i]);             // streamed once per sweep: keep L2 for beta_in (halo re-use)
     }
 
     double dmax = 0.0, amax = 0.0;
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
         if (tid < Ht) {
 #pragma unroll
             for (int q = 0; q < KC; ++q)
-                if (kc + q < K) lds[q * S + 256 + tid] = beta_in[(kc + q) * ld + hidx0];
+                if (kc + q < K) lds[q * S + 256 + tid] = hv[q];
         }
         for (int h = tid + 256; h < Ht; h += 256) {
             const int j = halo[h];
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
         for (int q = 0; q < KC; ++q) {
             const int k = kc + q;
             if (k < K) {
-                const double h = __builtin_nontemporal_load(&H[k * (size_t)ldh + i]);   // streamed once per sweep: keep L2 for beta_in (halo re-use)
+                const double h = hreg[q];
                 const double* g = XtX + k * K;
                 double r0 = 0.0, r1 = 0.0;
 #pragma unroll
@@ -238,17 +261,29 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
                     o_quad = fma(old, r0 + r1, o_quad);
                     o_spat = fma(old, (double)dg * old - c[q], o_spat);
                     o_l1 += fabs(old);
-                    continue;
+                    asm volatile("" : "+v"(o_quad));   // pins this type's K products here: nothing else orders them in this variant, and sunk to the end they keep all of XtX live
+                } else {
+                    const double res = (h - (r0 + r1) + gkk * old) + lam_eff * c[q];
+                    const double den = gkk + lam_deg;
+                    const double st = res > rho ? res - rho : (res < -rho ? res + rho : 0.0);
+                    const double qv = fmax(0.0, st / den);
+                    const double nw = (den > 1e-10) ? qv : 0.0;
+                    dmax = fmax(dmax, fabs(nw - old));
+                    amax = fmax(amax, fabs(old));
+                    b[k] = nw;
+                    __builtin_nontemporal_store(nw, &beta_out[k * ld + i]);
                 }
-                const double res = (h - (r0 + r1) + gkk * old) + lam_eff * c[q];
-                const double den = gkk + lam_deg;
-                const double st = res > rho ? res - rho : (res < -rho ? res + rho : 0.0);
-                const double qv = fmax(0.0, st / den);
-                const double nw = (den > 1e-10) ? qv : 0.0;
-                dmax = fmax(dmax, fabs(nw - old));
-                amax = fmax(amax, fabs(old));
-                b[k] = nw;
-                __builtin_nontemporal_store(nw, &beta_out[k * ld + i]);
+            }
+            if (kc + KC < K) {                              // next chunk's loads 2q and 2q+1 (0..KC-1: halo, KC..2KC-1: H)
+#pragma unroll
+                for (int t = 2 * q; t < 2 * q + 2; ++t) {
+                    const int j = t < KC ? t : t - KC;
+                    if (kc + KC + j < K) {
+                        if (t < KC) hv[j] = beta_in[(kc + KC + j) * ld + hidx0];
+                        else hreg[j] = __builtin_nontemporal_load(&H[(kc + KC + j) * (size_t)ldh + i]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

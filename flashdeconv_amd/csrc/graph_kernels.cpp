@@ -621,7 +621,7 @@ static int build_tiles(fdx_graph* g, hipStream_t st) {
     if (g->n_tiles > 0 && g->ell_rows > 0) {
         FDX_TRY(g->tile_halo.alloc((size_t)g->n_tiles * FDX_TILE_HALO_CAP * 4));
         FDX_TRY(g->tile_hcnt.alloc((size_t)g->n_tiles * 4));
-        FDX_TRY(g->ell_local.alloc((size_t)g->ell_rows * 64 * 2));
+        FDX_TRY(g->ell_local.alloc(((size_t)g->ell_rows + 16) * 64 * 2));   // + 16 rows: the tiled sweep loads 16 rows per slice unconditionally
         hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, g->ell.as<int>(), g->deg.as<int>(),
                            g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
                            g->ell_local.as<unsigned short>());
