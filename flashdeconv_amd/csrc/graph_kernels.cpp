@@ -14,6 +14,7 @@
 //      ((dx*dx + dy*dy) + dz*dz, each rounded) and ties are broken by the lower original index.
 //   4. union symmetrisation: in-degree count, reverse lists, per-row sort by original index + unique.
 //   5. sliced ELL (slice = 64 consecutive sorted points = one wavefront of the BCD sweep).
+#include <chrono>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -137,6 +138,46 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const double* __rest
     rank[o] = (int)p;
 }
 
+// ---- binning without a sort (Morton key space of at most a few million bins): count per key, scan, place.
+// The order produced is the stable sort's: cells in Morton order, points of a cell by ascending index.
+// pass 1: key of every point, and its arrival number among the points of the same key (any order)
+__global__ __launch_bounds__(256) void cell_count_kernel(const double* __restrict__ coords, long long n, GridParams gp,
+                                                         unsigned* __restrict__ key32, int* __restrict__ arrival,
+                                                         int* __restrict__ count) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    int c[3] = {0, 0, 0};
+    for (int a = 0; a < gp.dim; ++a) c[a] = cell_coord(coords[(size_t)i * gp.dim + a], gp.mn[a], gp.inv_h[a], gp.nc[a]);
+    const unsigned k = (unsigned)morton_key(c, gp.dim);
+    key32[i] = k;
+    arrival[i] = atomicAdd(&count[k], 1);
+}
+// pass 2: the members of every key, contiguous, in arrival order
+__global__ __launch_bounds__(256) void cell_place_kernel(const unsigned* __restrict__ key32, const int* __restrict__ arrival,
+                                                         const int* __restrict__ start, long long n, int* __restrict__ members) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    members[start[key32[i]] + arrival[i]] = (int)i;
+}
+// pass 3: position of point i = start of its key + number of members with a smaller index (cells hold a handful of
+// points); writes everything the sorted order defines: perm, rank, sorted keys, sorted coordinate planes
+__global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict__ coords, const unsigned* __restrict__ key32,
+                                                        const int* __restrict__ start, const int* __restrict__ members,
+                                                        long long n, int dim, int* __restrict__ perm, int* __restrict__ rank,
+                                                        unsigned long long* __restrict__ skeys, double* __restrict__ sc) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = key32[i];
+    const int s = start[k], e = start[k + 1];
+    int below = 0;
+    for (int q = s; q < e; ++q) below += (members[q] < (int)i) ? 1 : 0;
+    const int p = s + below;
+    perm[p] = (int)i;
+    rank[i] = p;
+    skeys[p] = k;
+    for (int a = 0; a < 3; ++a) sc[(size_t)a * n + p] = (a < dim) ? coords[(size_t)i * dim + a] : 0.0;
+}
+
 // ------------------------------------------------------------------------------------------------ k-NN
 __device__ __forceinline__ double dist2_exact(double dx, double dy, double dz) {
     // sum of squares with every product and sum rounded (no fma contraction), as a host float64 loop computes it
@@ -151,7 +192,8 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
                                                   const int* __restrict__ cstart, const int* __restrict__ cend,
                                                   long long n, GridParams gp, int kk, int* __restrict__ nbr_out,
                                                   int* __restrict__ nbr_cnt, double* __restrict__ nn_dist,
-                                                  long long lo, long long hi) {
+                                                  long long lo, long long hi, int* __restrict__ indeg,
+                                                  int* __restrict__ arrival) {
     const long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;      // rows [lo, hi) of the sorted order
     if (p >= hi) return;
     const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
@@ -225,10 +267,15 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
         return;
     }
     // drop self (graph.py:70-74); if self is not among the kk nearest (coincident points) keep all kk, as the reference does
+    // indeg != NULL (whole graph in one piece): the symmetrisation's first pass rides along - every list entry counts
+    // itself into its target's in-degree, and the number it draws is its place in the target's reverse list
     int cnt = 0;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
-        if (s < kk && bq[s] >= 0 && bq[s] != (int)p) nbr_out[(size_t)p * kk + cnt++] = bq[s];
+        if (s < kk && bq[s] >= 0 && bq[s] != (int)p) {
+            if (indeg) arrival[(size_t)p * kk + cnt] = atomicAdd(&indeg[bq[s]], 1);
+            nbr_out[(size_t)p * kk + cnt++] = bq[s];
+        }
     for (int s = cnt; s < kk; ++s) nbr_out[(size_t)p * kk + s] = -1;
     nbr_cnt[p] = cnt;
 }
@@ -289,6 +336,15 @@ __global__ __launch_bounds__(256) void fill_reverse_kernel(const int* __restrict
         const int q = nbr[(size_t)p * kk + m];
         if (q >= lo && q < hi) rev[rev_off[q] + atomicAdd(&cursor[q], 1)] = (int)p;
     }
+}
+
+// the same with the places drawn by the k-NN kernel: plain stores
+__global__ __launch_bounds__(256) void fill_reverse_placed_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
+                                                                  const int* __restrict__ arrival, long long n, int kk,
+                                                                  const int* __restrict__ rev_off, int* __restrict__ rev) {
+    const long long p = blockIdx.x * 256LL + threadIdx.x;
+    if (p >= n) return;
+    for (int m = 0; m < nbr_cnt[p]; ++m) rev[rev_off[nbr[(size_t)p * kk + m]] + arrival[(size_t)p * kk + m]] = (int)p;
 }
 
 // Row p: candidates = out(p) U in(p) -> sorted by ORIGINAL index, duplicates removed, stored at ws[seg_off(p) ...].
@@ -493,6 +549,16 @@ __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// FDX_TRACE_HOST=1: host clock at the steps of a graph build (stderr), to see which calls the host spends its time in
+static void trace_host(const char* what) {
+    static const bool on = getenv("FDX_TRACE_HOST") != nullptr;
+    if (!on) return;
+    static auto t_prev = std::chrono::steady_clock::now();
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[fdx-host] +%7.1f us  %s\n", std::chrono::duration<double, std::micro>(t - t_prev).count(), what);
+    t_prev = t;
+}
+
 static int exclusive_scan_int(const int* in, int* out, long long count, hipStream_t st, DevBuf& tmp) {
     size_t bytes = 0;
     FDX_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)count, rocprim::plus<int>(), st));
@@ -566,7 +632,7 @@ static int make_grid(const double* d_coords, long long n, int dim, double target
 struct BinnedPoints {
     GridParams gp;
     DevBuf perm, rank, sc, cstart, cend;
-    DevBuf keys, vals, skeys, sort_tmp;   // sort temporaries: kept until the struct dies so that binning needs no final sync
+    DevBuf keys, vals, skeys, sort_tmp, count, start, scan_tmp;   // sort temporaries: kept until the struct dies so that binning needs no final sync
     long long n = 0;
     int n_cells = 0;
 };
@@ -575,6 +641,7 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
                       BinnedPoints* b, hipStream_t st) {
     b->n = n;
     FDX_TRY(make_grid(d_coords, n, dim, target_per_cell, min_h, &b->gp, st));
+    trace_host("bin: make_grid (bbox kernel + read-back)");
     b->n_cells = b->gp.nc[0] * b->gp.nc[1] * b->gp.nc[2];
     DevBuf& keys = b->keys;
     DevBuf& vals = b->vals;
@@ -588,27 +655,54 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     FDX_TRY(b->sc.alloc((size_t)n * 3 * sizeof(double)));
     FDX_TRY(b->cstart.alloc((size_t)b->n_cells * 4));
     FDX_TRY(b->cend.alloc((size_t)b->n_cells * 4));
+    trace_host("bin: allocations");
     const int nb = ceil_div(n, 256);
     typedef unsigned long long u64;
-    hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, st, d_coords, n, b->gp, keys.as<u64>(), vals.as<int>());
-    FDX_CHECK_LAUNCH();
     const int max_axis = std::max(b->gp.nc[0], std::max(b->gp.nc[1], b->gp.nc[2]));
     int axis_bits = 1;
     while ((1LL << axis_bits) < (long long)max_axis) ++axis_bits;
     const int bits = std::min(64, axis_bits * dim);      // significant bits of the Morton key
-    size_t bytes = 0;
-    FDX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.as<u64>(), skeys.as<u64>(), vals.as<int>(), b->perm.as<int>(),
-                                      (size_t)n, 0, (unsigned)bits, st));
-    FDX_TRY(tmp.alloc(bytes));
-    FDX_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.as<u64>(), skeys.as<u64>(), vals.as<int>(), b->perm.as<int>(),
-                                      (size_t)n, 0, (unsigned)bits, st));
     FDX_HIP(hipMemsetAsync(b->cstart.p, 0, b->cstart.bytes, st));
     FDX_HIP(hipMemsetAsync(b->cend.p, 0, b->cend.bytes, st));
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nb), dim3(256), 0, st, d_coords, b->perm.as<int>(), n, dim, b->sc.as<double>(), b->rank.as<int>());
-    FDX_CHECK_LAUNCH();
+    trace_host("bin: 2 memsets");
+    // Up to 4M keys (and no more than 8 per point) the order comes from counting instead of sorting: 6 launches instead of
+    // the ~30 of rocprim's sort at this size (1M points: 0.42 -> 0.1 ms); FDX_GRAPH_SORT=1 forces the sort.
+    if (bits <= 22 && (1LL << bits) <= 8 * n + 1024 && !getenv("FDX_GRAPH_SORT")) {
+        const long long bins = 1LL << bits;
+        FDX_TRY(tmp.alloc((size_t)n * 4));                        // members in arrival order (keys: 32-bit keys, vals: arrival numbers)
+        FDX_TRY(b->count.alloc((size_t)(bins + 1) * 4));
+        FDX_TRY(b->start.alloc((size_t)(bins + 1) * 4));
+        trace_host("bin: count/start alloc");
+        FDX_HIP(hipMemsetAsync(b->count.p, 0, b->count.bytes, st));
+        trace_host("bin: memset count");
+        hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(256), 0, st, d_coords, n, b->gp, keys.as<unsigned>(), vals.as<int>(),
+                           b->count.as<int>());
+        FDX_CHECK_LAUNCH();
+        trace_host("bin: count kernel");
+        FDX_TRY(exclusive_scan_int(b->count.as<int>(), b->start.as<int>(), bins + 1, st, b->scan_tmp));
+        trace_host("bin: scan");
+        hipLaunchKernelGGL(cell_place_kernel, dim3(nb), dim3(256), 0, st, keys.as<unsigned>(), vals.as<int>(), b->start.as<int>(), n,
+                           tmp.as<int>());
+        FDX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(256), 0, st, d_coords, keys.as<unsigned>(), b->start.as<int>(),
+                           tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), skeys.as<u64>(), b->sc.as<double>());
+        FDX_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, st, d_coords, n, b->gp, keys.as<u64>(), vals.as<int>());
+        FDX_CHECK_LAUNCH();
+        size_t bytes = 0;
+        FDX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.as<u64>(), skeys.as<u64>(), vals.as<int>(), b->perm.as<int>(),
+                                          (size_t)n, 0, (unsigned)bits, st));
+        FDX_TRY(tmp.alloc(bytes));
+        FDX_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.as<u64>(), skeys.as<u64>(), vals.as<int>(), b->perm.as<int>(),
+                                          (size_t)n, 0, (unsigned)bits, st));
+        hipLaunchKernelGGL(gather_sorted_kernel, dim3(nb), dim3(256), 0, st, d_coords, b->perm.as<int>(), n, dim, b->sc.as<double>(), b->rank.as<int>());
+        FDX_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(cell_range_kernel, dim3(nb), dim3(256), 0, st, skeys.as<u64>(), b->sc.as<double>(), n, b->gp,
                        b->cstart.as<int>(), b->cend.as<int>());
     FDX_CHECK_LAUNCH();
+    trace_host("bin: place/rank/range kernels");
     return 0;                            // no sync: the temporaries live in *b, whose owners synchronise before dropping it
 }
 
@@ -626,9 +720,11 @@ static int build_tiles(fdx_graph* g, hipStream_t st) {
                            g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
                            g->ell_local.as<unsigned short>());
         FDX_CHECK_LAUNCH();
+    trace_host("tiles: allocs + kernel");
         std::vector<int> hc((size_t)g->n_tiles);
         FDX_HIP(hipMemcpyAsync(hc.data(), g->tile_hcnt.p, hc.size() * 4, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipStreamSynchronize(st));
+    trace_host("tiles: read-back + sync");
         bool ok = true;
         int mx = 0;
         for (int v : hc) { if (v < 0) ok = false; mx = std::max(mx, v); }
@@ -649,6 +745,7 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     hipLaunchKernelGGL(slice_width_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, g->deg.as<int>(), n, g->n_slices, width.as<int>());
     FDX_CHECK_LAUNCH();
     FDX_TRY(exclusive_scan_int(width.as<int>(), g->slice_off.as<int>(), g->n_slices + 1, st, tmp));
+    trace_host("ell: width + scan");
     int total = 0;
     FDX_HIP(hipMemcpyAsync(&total, g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
     // nnz and max degree
@@ -663,9 +760,11 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     FDX_HIP(rocprim::reduce(nullptr, rb2, width.as<int>(), red.as<int>() + 2, 0, (size_t)g->n_slices, rocprim::maximum<int>(), st));
     if (rb2 > rtmp.bytes) FDX_TRY(rtmp.alloc(rb2));
     FDX_HIP(rocprim::reduce(rtmp.p, rb2, width.as<int>(), red.as<int>() + 2, 0, (size_t)g->n_slices, rocprim::maximum<int>(), st));
+    trace_host("ell: 2 reduces");
     long long h_red[2] = {0, 0};
     FDX_HIP(hipMemcpyAsync(h_red, red.p, 16, hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
+    trace_host("ell: read-back + sync");
     g->ell_rows = total;
     g->nnz = h_red[0];
     g->max_deg = (int)(h_red[1] & 0xffffffffLL);
@@ -673,6 +772,7 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     hipLaunchKernelGGL(fill_ell_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, ws, seg_stride, seg_extra,
                        g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>());
     FDX_CHECK_LAUNCH();
+    trace_host("ell: alloc + fill_ell");
     FDX_TRY(build_tiles(g, st));
     return 0;
 }
@@ -692,10 +792,10 @@ static int empty_graph(long long n, fdx_graph* g, hipStream_t st) {
 
 template <int KMAX>
 static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, long long lo,
-                             long long hi, hipStream_t st) {
+                             long long hi, hipStream_t st, int* indeg = nullptr, int* arrival = nullptr) {
     if (hi <= lo) return;
     hipLaunchKernelGGL(knn_kernel<KMAX>, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), perm,
-                       b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi);
+                       b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival);
 }
 
 template <int KMAX>
@@ -727,6 +827,7 @@ struct fdx_graph_plan {
     long long n = 0;
     int kk = 0;
     hipStream_t st = nullptr;      // stream the binning / k-NN kernels were queued on
+    fdx::DevBuf indeg, arrival;    // whole graph in one piece: in-degrees and reverse-list places from the k-NN kernel
     ~fdx_graph_plan() { (void)hipStreamSynchronize(st); }   // nothing may still read the buffers when they go back to the pool
 };
 namespace fdx {
@@ -753,10 +854,20 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     if (rc) { delete plan; return rc; }
     const BinnedPoints& b = plan->b;
     const int* perm = b.perm.as<int>();
-    if (kk <= 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st);
-    else if (kk <= 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st);
-    else if (kk <= 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st);
-    else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st);
+    int *indeg = nullptr, *arrival = nullptr;
+    if (lo == 0 && hi == n) {
+        rc = plan->indeg.alloc((size_t)(n + 1) * 4);
+        if (!rc) rc = plan->arrival.alloc((size_t)n * kk * 4);
+        if (rc) { delete plan; return rc; }
+        if (hipMemsetAsync(plan->indeg.p, 0, plan->indeg.bytes, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
+        indeg = plan->indeg.as<int>();
+        arrival = plan->arrival.as<int>();
+    }
+    if (kk <= 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival);
+    else if (kk <= 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival);
+    else if (kk <= 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival);
+    else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival);
+    trace_host("knn: kernel launched");
     if (hipGetLastError() != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: k-NN kernel launch failed"); }
     *out = plan;
     return 0;
@@ -776,15 +887,22 @@ int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, l
     g->rank.take(plan->b.rank);
     DevBuf indeg, rev_off, cursor, rev, tmp;
     // symmetrise: A + A^T, binary   (graph.py:80-81)
-    FDX_TRY(indeg.alloc((size_t)(n + 1) * 4));
-    FDX_TRY(rev_off.alloc((size_t)(n + 1) * 4));
-    FDX_TRY(cursor.alloc((size_t)n * 4));
-    FDX_HIP(hipMemsetAsync(indeg.p, 0, indeg.bytes, st));
-    FDX_HIP(hipMemsetAsync(cursor.p, 0, cursor.bytes, st));
     const int nb = ceil_div(n, 256);
-    hipLaunchKernelGGL(indegree_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, indeg.as<int>(), (int)lo, (int)hi);
-    FDX_CHECK_LAUNCH();
+    FDX_TRY(rev_off.alloc((size_t)(n + 1) * 4));
+    const bool placed = lo == 0 && hi == n && plan->indeg.p && plan->arrival.p;   // the k-NN kernel counted and placed already
+    if (placed) {
+        indeg.take(plan->indeg);
+    } else {
+        FDX_TRY(indeg.alloc((size_t)(n + 1) * 4));
+        FDX_TRY(cursor.alloc((size_t)n * 4));
+        FDX_HIP(hipMemsetAsync(indeg.p, 0, indeg.bytes, st));
+        FDX_HIP(hipMemsetAsync(cursor.p, 0, cursor.bytes, st));
+        trace_host("sym: allocs + 2 memsets");
+        hipLaunchKernelGGL(indegree_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, indeg.as<int>(), (int)lo, (int)hi);
+        FDX_CHECK_LAUNCH();
+    }
     FDX_TRY(exclusive_scan_int(indeg.as<int>(), rev_off.as<int>(), n + 1, st, tmp));
+    trace_host("sym: indegree + scan");
     if (lo == 0 && hi == n) {
         FDX_TRY(rev.alloc((size_t)n * kk * 4));          // whole graph: every list entry is a reverse edge - no read-back
     } else {
@@ -794,8 +912,12 @@ int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, l
         FDX_REQUIRE(total_in >= 0 && (long long)total_in <= n * (long long)kk, "graph: reverse edge count out of range");
         FDX_TRY(rev.alloc((size_t)std::max(total_in, 1) * 4));
     }
-    hipLaunchKernelGGL(fill_reverse_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, rev_off.as<int>(), cursor.as<int>(),
-                       rev.as<int>(), (int)lo, (int)hi);
+    if (placed)
+        hipLaunchKernelGGL(fill_reverse_placed_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, plan->arrival.as<int>(), n, kk,
+                           rev_off.as<int>(), rev.as<int>());
+    else
+        hipLaunchKernelGGL(fill_reverse_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, rev_off.as<int>(), cursor.as<int>(),
+                           rev.as<int>(), (int)lo, (int)hi);
     FDX_CHECK_LAUNCH();
     FDX_TRY(g->rows.alloc((size_t)n * kk * 2 * 4));     // capacity sum_p (kk + indeg[p]) <= 2*n*kk
     FDX_TRY(g->deg.alloc((size_t)n * 4));
@@ -805,6 +927,7 @@ int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, l
                            rev_off.as<int>(), g->perm.as<int>(), lo, hi, kk, g->rows.as<int>(), g->deg.as<int>());
         FDX_CHECK_LAUNCH();
     }
+    trace_host("sym: fill_reverse, merge_rows launched");
     g->row_stride = kk;
     g->row_extra.take(rev_off);   // keep: segment offsets
     FDX_TRY(finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), st));

@@ -2,7 +2,7 @@
 -DFDX_KC_OVERRIDE=KC (device code only, no GPU needed) and reads .vgpr_count / spills from the assembly.  168 registers are
 the limit for three waves per SIMD; sweep_chunk() in bcd_sweep_inst.cpp is tuned from this table.
 
-usage: python tools/sweep_regs.py K_LO K_HI KC [KC ...]"""
+usage: python tools/sweep_regs.py [--obj] K_LO K_HI KC [KC ...]"""
 import os, re, subprocess, sys, tempfile
 from concurrent.futures import ThreadPoolExecutor
 
@@ -18,11 +18,16 @@ def regs(K, KC):
                "--cuda-device-only", "-S", "bcd_sweep_inst.cpp", "-o", out]
         subprocess.run(cmd, cwd=SRC, check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
-    m = re.search(r"\.name:\s+_ZN3fdx22bcd_sweep_tiled_kernelILi%dELi%dELb0E.*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)" % (K, min(K, KC)), txt, re.S)
+    m = re.search(r"\.name:\s+_ZN3fdx22bcd_sweep_tiled_kernelILi%dELi%dELb%dE.*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)" % (K, min(K, KC), OBJ), txt, re.S)
     return K, KC, int(m.group(1)), int(m.group(2))
 
 
+OBJ = 0
+
 if __name__ == "__main__":
+    if "--obj" in sys.argv:                      # the objective variant of the kernel
+        OBJ = 1
+        sys.argv.remove("--obj")
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
     kcs = [int(a) for a in sys.argv[3:]]
     jobs = [(K, KC) for K in range(lo, hi + 1) for KC in kcs]
