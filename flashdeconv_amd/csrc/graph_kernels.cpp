@@ -730,6 +730,7 @@ static int build_tiles(fdx_graph* g, hipStream_t st) {
         for (int v : hc) { if (v < 0) ok = false; mx = std::max(mx, v); }
         g->tiled = ok;
         g->halo_max = mx;
+        if (getenv("FDX_TRACE_HOST")) std::fprintf(stderr, "[fdx-host] tiles: %d tiles, largest halo %d, tiled %d\n", g->n_tiles, mx, (int)ok);
     }
     return 0;
 }
