@@ -4,6 +4,7 @@ import csv, glob, json, os, sys, shutil
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+extra = " ".join(sys.argv[2:])            # bench.py arguments the round was profiled with (tools/profile_round.sh <tag> <args>)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", f"{tag}_prof")
 dst = os.path.join(ROOT, "profiles")
@@ -25,10 +26,14 @@ bench_line = open(os.path.join(src, "bench_trace.json")).read().strip().split("\
 with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as f:
     f.write(f"# {tag} - rocprofv3 kernel stats of the bench command\n\n")
     f.write("Command on the MI355X box: `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py --steps 3 "
-            "--warmup 1 --no-cpu-baseline` (tools/profile_round.sh).\n\n")
-    f.write("Workload: 1M spots x 2000 genes x 30 types, d = 512: gaussian/raw (1 warm-up + 3 timed fits), count-like/log_cpm "
-            "(1 + 2 fits, 100 sweeps each) and the CSR family (1M x 20000, 1 + 2 fits) in one process.  torch kernels "
-            "(at::, Cijk_) are the synthetic data generators, outside the timed region.\n\n")
+            f"--warmup 1 --no-cpu-baseline{' ' + extra if extra else ''}` (tools/profile_round.sh).\n\n")
+    if extra:
+        f.write(f"Workload: `bench.py {extra}` (see the bench line below).  torch kernels (at::, Cijk_) are the synthetic data "
+                "generators, outside the timed region.\n\n")
+    else:
+        f.write("Workload: 1M spots x 2000 genes x 30 types, d = 512: gaussian/raw (1 warm-up + 3 timed fits), count-like/log_cpm "
+                "(1 + 2 fits, 100 sweeps each) and the CSR family (1M x 20000, 1 + 2 fits) in one process.  torch kernels "
+                "(at::, Cijk_) are the synthetic data generators, outside the timed region.\n\n")
     f.write("bench.py line of this profiled run:\n\n```\n" + bench_line + "\n```\n\n")
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:60]:
@@ -67,7 +72,7 @@ json.dump({"note": "per-launch means over non no-op launches; hbm_bytes_correcte
 with open(os.path.join(dst, f"{tag}_pmc_traffic.md"), "w") as f:
     f.write(f"# {tag} - HBM traffic per launch from PMC counters (FETCH_SIZE, WRITE_SIZE)\n\n")
     f.write("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python3 bench.py --steps 1 --warmup 0 "
-            "--no-cpu-baseline --family both` (tools/profile_round.sh); per-launch means over the real (non no-op) launches; "
+            f"--no-cpu-baseline {extra if extra else '--family both'}` (tools/profile_round.sh); per-launch means over the real (non no-op) launches; "
             "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read "
             "(MI355X_MICROARCH.md, HBM section).\n\n")
     f.write("| kernel | launches | 2 x FETCH_SIZE (MB) | WRITE_SIZE (MB) | HBM bytes per launch (MB) |\n|---|---|---|---|---|\n")

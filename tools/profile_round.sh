@@ -1,13 +1,15 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): the three rocprofv3 passes behind profiles/rNN_*.  Usage: tools/profile_round.sh r01
+# Runs on the GPU box (gpurun): the three rocprofv3 passes behind profiles/rNN_*.  Usage: tools/profile_round.sh r01 [bench.py args]
+# (extra arguments select another workload for all three passes, e.g. `r02_config5 --config 5`).
 # Counters are collected in their own passes (kernel-trace only alongside), as the pool requires.
-tag=${1:-r01}
+tag=${1:-r01}; shift
+if [ $# -gt 0 ]; then pmc_args="$*"; else pmc_args="--family both"; fi
 out=/root/repo/gpurun_out/${tag}_prof
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_trace.json" 2> "$out/bench_trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --family both > "$out/bench_fetch.json" 2> "$out/bench_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --family both > "$out/bench_write.json" 2> "$out/bench_write.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$out/bench_trace.json" 2> "$out/bench_trace.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline $pmc_args > "$out/bench_fetch.json" 2> "$out/bench_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline $pmc_args > "$out/bench_write.json" 2> "$out/bench_write.err"
 # keep what the summaries need: stats + counter csvs (the full kernel traces are large)
 find "$out" -name "*kernel_trace.csv" -delete
 find "$out" -name "*agent_info.csv" -delete
