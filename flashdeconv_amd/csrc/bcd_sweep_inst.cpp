@@ -155,11 +155,9 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [KC][S]: 256 own | halo | zero slot
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    if (!OBJ && it > 0) {
-        const double rc = fold_rel_change(stats + (size_t)(it - 1) * 128, lane);
-        if (blockIdx.x == 0 && tid == 0) rel_change[it - 1] = rc;
-        if (rc < tol) return;          // uniform over the whole grid
-    }
+    // The tile's small tables are requested together with the previous sweep's statistics, ahead of the stopping rule: the
+    // addresses of everything else (slot table, halo values) depend on them, and behind the rule they would be a third
+    // round trip before the first chunk can be staged (a workgroup lives ~25 us; each exposed round trip is ~1 us of it).
     const int tile = tile_list ? tile_list[xcd_remap(blockIdx.x, gridDim.x)] : xcd_remap(blockIdx.x, gridDim.x);
     const bool real = (tile * 256 + tid) < n;
     const int i = min(tile * 256 + tid, n - 1);   // lanes past the last spot mirror spot n-1
@@ -169,15 +167,22 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
     const int w = slice_off[slice + 1] - w0;
     const int Ht = tile_hcnt[tile];
     const int* halo = tile_halo + (size_t)tile * FDX_TILE_HALO_CAP;
+    const int dg = deg[i];
+    int hidx0 = halo[tid];                        // the table has FDX_TILE_HALO_CAP >= 256 entries per tile; past Ht: unused
+    if (!OBJ && it > 0) {
+        const double rc = fold_rel_change(stats + (size_t)(it - 1) * 128, lane);
+        if (blockIdx.x == 0 && tid == 0) rel_change[it - 1] = rc;
+        asm volatile("" :: "v"(dg), "v"(hidx0), "s"(w0), "s"(w), "s"(Ht));   // keeps the loads above on this side of the branch
+        if (rc < tol) return;          // uniform over the whole grid
+    }
+    hidx0 = (tid < Ht) ? hidx0 : 0;
 
     double b[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) b[k] = beta_in[k * ld + i];
     const unsigned short* ell = ell_local + (size_t)w0 * 64 + (i & 63);
-    const int dg = deg[i];
     const double lam_deg = lambda * (double)dg;
     const double lam_eff = (dg > 0) ? lambda : 0.0;
-    const int hidx0 = (tid < Ht) ? halo[tid] : 0;
     // tile-local neighbour slots of this spot: the first 16 live in registers for all chunks (two 16-bit slots per VGPR),
     // wider slices (rare) read the rest from memory
     unsigned slots[8];
