@@ -46,7 +46,7 @@ constexpr int sweep_chunk(int K) {
 #ifdef FDX_KC_OVERRIDE                       // tools/sweep_regs.py: register count per (K, chunk)
     return K < FDX_KC_OVERRIDE ? K : FDX_KC_OVERRIDE;
 #endif
-    return K < 8 ? K : K <= 28 ? 8 : K <= 31 ? 7 : K == 32 ? 8 : K <= 35 ? 6 : K <= 40 ? 5 : K <= 44 ? 4 : K <= 48 ? 3 : K <= 51 ? 2 : 8;
+    return K < 8 ? K : K <= 29 ? 8 : K <= 33 ? 7 : K <= 37 ? 6 : K <= 41 ? 5 : K <= 45 ? 4 : K <= 49 ? 3 : K <= 51 ? 2 : 8;
 }
 
 template <int K, int KC>
@@ -135,6 +135,21 @@ __global__ __launch_bounds__(256) void bcd_sweep_kernel(
     }
 }
 
+// A type plane's base address as a scalar the compiler cannot fold back into a per-lane 64-bit address (it would: base + lane
+// offset first, plane stride added per access with vector adds): opaque in scalar registers, global address space kept.
+__device__ __forceinline__ const char __attribute__((address_space(1)))* plane_base(const double* p) {
+    unsigned long long v = (unsigned long long)p;
+    asm("" : "+s"(v));
+    return (const char __attribute__((address_space(1)))*)v;
+}
+
+// ... and the lane's 32-bit offset re-read where it is used: the global instructions take `scalar base + 32-bit lane offset`
+// only if the zero extension is visible in the same basic block (hoisted, it is a 64-bit value like any other).
+__device__ __forceinline__ unsigned lane_off(unsigned off) {
+    asm("" : "+v"(off));
+    return off;
+}
+
 // LDS-tiled variant (graphs built from coordinates): a workgroup owns a TILE of 256 consecutive Morton-ordered spots.
 // Per chunk of KC cell types the tile's own old abundances (from registers) and its halo (the neighbour positions outside
 // the tile, one coalesced-ish global gather per halo spot and type) are staged in LDS, and all neighbour sums are then
@@ -177,9 +192,14 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
     }
     hidx0 = (tid < Ht) ? hidx0 : 0;
 
+    // Addresses inside a type plane: uniform plane base (scalar registers, scalar arithmetic) + this lane's 32-bit byte
+    // offset - the form the global instructions take directly; 64-bit per-lane addresses cost two vector adds per access
+    // (six per coordinate step) and a register pair each.  The launcher guarantees 8 * ld < 4 GB.
+    const unsigned ioff = (unsigned)i * 8u, hoff = (unsigned)hidx0 * 8u;
+#define PLANE_AT(base, off) (*(const double __attribute__((address_space(1)))*)(plane_base(base) + lane_off(off)))
     double b[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) b[k] = beta_in[k * ld + i];
+    for (int k = 0; k < K; ++k) b[k] = PLANE_AT(beta_in + k * ld, ioff);
     const unsigned short* ell = ell_local + (size_t)w0 * 64 + (i & 63);
     const double lam_deg = lambda * (double)dg;
     const double lam_eff = (dg > 0) ? lambda : 0.0;
@@ -202,8 +222,8 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
     double hv[KC], hreg[KC];
 #pragma unroll
     for (int q = 0; q < KC; ++q) {
-        hv[q] = beta_in[q * ld + hidx0];                                           // threads past Ht read spot 0: harmless
-        hreg[q] = __builtin_nontemporal_load(&H[q * (size_t)ldh + i]);             // streamed once per sweep: keep L2 for beta_in (halo re-use)
+        hv[q] = PLANE_AT(beta_in + q * ld, hoff);                                  // threads past Ht read spot 0: harmless
+        hreg[q] = __builtin_nontemporal_load(&PLANE_AT(H + q * (size_t)ldh, ioff));             // streamed once per sweep: keep L2 for beta_in (halo re-use)
     }
 
     double dmax = 0.0, amax = 0.0;
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
                     dmax = fmax(dmax, fabs(nw - old));
                     amax = fmax(amax, fabs(old));
                     b[k] = nw;
-                    __builtin_nontemporal_store(nw, &beta_out[k * ld + i]);
+                    __builtin_nontemporal_store(nw, (double __attribute__((address_space(1)))*)(plane_base(beta_out + k * ld) + lane_off(ioff)));
                 }
             }
             if (kc + KC < K) {                              // next chunk's loads 2q and 2q+1 (0..KC-1: halo, KC..2KC-1: H)
@@ -284,8 +304,8 @@ __global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_
                 for (int t = 2 * q; t < 2 * q + 2; ++t) {
                     const int j = t < KC ? t : t - KC;
                     if (kc + KC + j < K) {
-                        if (t < KC) hv[j] = beta_in[(kc + KC + j) * ld + hidx0];
-                        else hreg[j] = __builtin_nontemporal_load(&H[(kc + KC + j) * (size_t)ldh + i]);
+                        if (t < KC) hv[j] = PLANE_AT(beta_in + (kc + KC + j) * ld, hoff);
+                        else hreg[j] = __builtin_nontemporal_load(&PLANE_AT(H + (kc + KC + j) * (size_t)ldh, ioff));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -323,7 +343,7 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
         constexpr int KC = sweep_chunk(K);
         const int S = 256 + a.halo_max + 1;
         const size_t lds = (size_t)KC * S * sizeof(double);
-        if (lds <= 64 * 1024) {
+        if (lds <= 64 * 1024 && (long long)a.ld * 8 < (1LL << 32) && (long long)a.ldh * 8 < (1LL << 32)) {
             if (a.objective)
                 hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
                                    a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
