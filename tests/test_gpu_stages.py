@@ -58,6 +58,55 @@ def test_radius_and_grid_vs_oracle():
     assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
 
 
+@pytest.mark.parametrize("case", ["uniform2d", "clustered2d", "duplicates", "line1d", "cube3d", "lattice"])
+def test_counting_order_is_the_stable_sort_order(case, monkeypatch):
+    """Solver order (cells in Morton order, points of a cell by ascending index): the counting path (count per key, scan,
+    rank within the cell) must give exactly the permutation of the stable radix sort it replaces (FDX_GRAPH_SORT=1), and the
+    same graph.  Duplicated points and a regular lattice put many points on one key / exactly on cell borders."""
+    import ctypes
+    import torch
+    from flashdeconv_amd import _lib
+    rs = np.random.RandomState(11)
+    n = 20000
+    if case == "uniform2d":
+        coords = rs.rand(n, 2) * 140.0
+    elif case == "clustered2d":
+        coords = np.concatenate([rs.randn(n // 2, 2) * 0.05, rs.rand(n - n // 2, 2) * np.array([900.0, 3.0])])
+    elif case == "duplicates":
+        base = rs.rand(n // 8, 2) * 50.0
+        coords = base[rs.randint(0, len(base), n)]
+    elif case == "line1d":
+        coords = rs.rand(n, 1) * 1e4
+    elif case == "cube3d":
+        coords = rs.rand(n, 3) * 27.0
+    else:
+        side = int(np.sqrt(n))
+        gx, gy = np.meshgrid(np.arange(side, dtype=np.float64), np.arange(side, dtype=np.float64))
+        coords = np.stack([gx.ravel(), gy.ravel()], 1)
+        coords = coords[rs.permutation(len(coords))]
+    n, dim = coords.shape
+    lib = _lib.load()
+    cd = torch.as_tensor(np.ascontiguousarray(coords), device="cuda:0")
+
+    def build():
+        h = ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(cd.data_ptr()), n, dim, _lib.GRAPH_KNN, 6, 0.0, None, ctypes.byref(h)))
+        g = _lib.Graph(h.value)
+        perm = torch.empty(n, dtype=torch.int32, device="cuda:0")
+        _lib.check(lib.fdx_graph_perm_dev(g.handle, ctypes.c_void_p(perm.data_ptr()), None))
+        torch.cuda.synchronize()
+        indptr, indices = g.to_csr_arrays()
+        g.close()
+        return perm.cpu().numpy(), indptr, indices
+
+    p_count, ip_c, ix_c = build()
+    monkeypatch.setenv("FDX_GRAPH_SORT", "1")
+    p_sort, ip_s, ix_s = build()
+    assert np.array_equal(np.sort(p_count), np.arange(n))
+    assert np.array_equal(p_count, p_sort)
+    assert np.array_equal(ip_c, ip_s) and np.array_equal(ix_c, ix_s)
+
+
 def test_graph_errors():
     from flashdeconv_amd.utils import graph as G
     with pytest.raises(ValueError, match="coords must be 2D"):
