@@ -6,13 +6,15 @@
 // and hands the result to the solver in the sliced-ELL layout of fdx_graph.h.
 //
 // Pipeline (all on the stream, one small D2H for the bounding box):
-//   1. bounding box -> uniform grid with ~2 points per cell.
-//   2. stable radix sort of (Morton code of the cell, original index) (rocPRIM) -> perm / rank; points inside a cell
-//      keep caller order, and any 256 consecutive sorted points form a compact patch (small tile halo in the BCD sweep).
+//   1. bounding box -> uniform grid with ~4 points per cell (k-NN; radius graphs: cell edge >= radius).
+//   2. order by (Morton code of the cell, original index) -> perm / rank: count per key, scan, rank within the cell
+//      (rocPRIM's stable radix sort above 4M keys; same order either way).  Points inside a cell keep caller order,
+//      and any 256 consecutive sorted points form a compact patch (small tile halo in the BCD sweep).
 //   3. exact k-NN: one lane per point scans the cells of growing Chebyshev shells until the k+1-th best squared distance
 //      is provably inside the scanned block.  Squared distances are evaluated in float64 WITHOUT fma contraction
 //      ((dx*dx + dy*dy) + dz*dz, each rounded) and ties are broken by the lower original index.
-//   4. union symmetrisation: in-degree count, reverse lists, per-row sort by original index + unique.
+//   4. union symmetrisation: in-degree count (inside the k-NN kernel for whole-graph builds), reverse lists, per-row sort
+//      by original index + unique.
 //   5. sliced ELL (slice = 64 consecutive sorted points = one wavefront of the BCD sweep).
 #include <chrono>
 #include <cstring>
