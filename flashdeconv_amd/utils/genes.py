@@ -124,14 +124,26 @@ def _hvg_from_moments(mean, var, n_top, min_mean, max_mean, min_disp):
     disp = np.zeros(G)
     pos = mean[mean > 0]
     if len(pos) >= 2:
-        edges = np.unique(np.percentile(pos, np.linspace(0, 100, 21)))
+        # np.percentile selects order statistics: on the sorted vector it returns the same bits and skips its 21-way partition
+        edges = np.unique(np.percentile(np.sort(pos), np.linspace(0, 100, 21)))
         if len(edges) >= 2:
-            which = np.clip(np.digitize(mean, edges) - 1, 0, len(edges) - 2)
-            for b in range(len(edges) - 1):
-                m = which == b
-                if m.sum() > 1:
-                    v = var[m]
-                    disp[m] = (v - v.mean()) / (v.std() + 1e-10)
+            # np.digitize(mean, edges) = number of edges <= mean (NaN sorts past the last edge): 21 vector compares
+            below = np.zeros(G, dtype=np.int64)
+            for e in edges:
+                below += mean >= e
+            below[np.isnan(mean)] = len(edges)
+            which = np.clip(below - 1, 0, len(edges) - 2).astype(np.uint8)
+            # one stable sort by bin instead of a boolean mask per bin: a bin's slice lists its genes in ascending index
+            # order, i.e. var[order[s:e]] is the very array var[which == b] - same mean, same std, bit for bit
+            order = np.argsort(which, kind="stable")
+            ends = np.cumsum(np.bincount(which, minlength=len(edges) - 1))
+            var_by_bin = var[order]
+            s0 = 0
+            for e0 in ends:
+                if e0 - s0 > 1:
+                    v = var_by_bin[s0:e0]
+                    disp[order[s0:e0]] = (v - v.mean()) / (v.std() + 1e-10)
+                s0 = e0
     ok = np.flatnonzero((mean >= min_mean) & (mean <= max_mean) & (disp >= min_disp))
     if len(ok) < n_top:
         pick = np.argsort(disp)[::-1][:n_top]
