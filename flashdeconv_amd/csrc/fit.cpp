@@ -352,7 +352,28 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     p.verbose = prm->verbose;
     p.compute_objective = prm->verbose ? 1 : 0;
     SolveResult r;
+    // The export of the result (type-major solver order -> row-major caller order, 0.25 ms at 1M x 30) and the objective pass
+    // (0.2 ms) both only read the final abundances: the export goes to the library's side stream (idle here - the leverage
+    // job was collected before this call) and runs beside the objective pass instead of after it.
+    struct SideDrain { hipStream_t s = nullptr; ~SideDrain() { if (s) (void)hipStreamSynchronize(s); } } side_drain;   // before the buffers above are released
+    hipEvent_t evSolved = nullptr, evExported = nullptr;
+    struct EvGuard3 { hipEvent_t* a; hipEvent_t* b; ~EvGuard3() { if (*a) (void)hipEventDestroy(*a); if (*b) (void)hipEventDestroy(*b); } } evX_guard{&evSolved, &evExported};
     FDX_TRY(solver_run(p, &r, st));          // its chunked read-backs synchronise the stream: YtY has arrived after it
+    bool exported = false;
+    if ((beta_out_dev || prop_out_dev) && !prm->verbose && !getenv("FDX_NO_EXPORT_OVERLAP")) {
+        hipStream_t side = leverage_side_stream();
+        if (side && side != st) {
+            FDX_HIP(hipEventCreateWithFlags(&evSolved, hipEventDisableTiming));
+            FDX_HIP(hipEventCreateWithFlags(&evExported, hipEventDisableTiming));
+            FDX_HIP(hipEventRecord(evSolved, st));
+            FDX_HIP(hipStreamWaitEvent(side, evSolved, 0));
+            side_drain.s = side;
+            FDX_TRY(launch_normalize_export(p.beta[r.result_buffer], ld, row_map, (int)n, g->n_slices, K, beta_out_dev,
+                                            prop_out_dev, side));
+            FDX_HIP(hipEventRecord(evExported, side));
+            exported = true;
+        }
+    }
     if (!prm->verbose) {
         DevBuf objp, objo;
         FDX_TRY(objp.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
@@ -362,7 +383,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
                                  objo.as<double>(), &r.final_objective, st));
     }
     tm.mark();  // 3
-    if (beta_out_dev || prop_out_dev)
+    if (exported) FDX_HIP(hipStreamWaitEvent(st, evExported, 0));
+    else if (beta_out_dev || prop_out_dev)
         FDX_TRY(launch_normalize_export(p.beta[r.result_buffer], ld, row_map, (int)n, g->n_slices, K, beta_out_dev,
                                         prop_out_dev, st));
     tm.mark();  // 4
