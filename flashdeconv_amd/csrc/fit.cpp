@@ -212,6 +212,31 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     }
     tm.mark();  // 1
 
+    // ---- beta0 = 1/K (core/solver.py:372) and the cleared pad rows: nothing depends on anything here, so the two fills go to the
+    // library's side stream now and run while the host prepares the sketch (plans, X upload) instead of between sketch and sweeps
+    const long long ld = round_up(n + 1, 64);
+    DevBuf dB0, dB1;
+    struct SideDrain { hipStream_t s = nullptr; ~SideDrain() { if (s) (void)hipStreamSynchronize(s); } } side_drain;   // before buffers are released
+    hipEvent_t evInit = nullptr;
+    struct EvGuard0 { hipEvent_t* e; ~EvGuard0() { if (*e) (void)hipEventDestroy(*e); } } evInit_guard{&evInit};
+    FDX_TRY(dB0.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
+    hipStream_t side = getenv("FDX_NO_SIDE_STREAM") ? nullptr : leverage_side_stream();
+    if (side == st) side = nullptr;
+    if (side) {
+        // the blocks may have been recycled from work queued on `st` (the graph build just before): order the side stream behind it
+        hipEvent_t evTop = nullptr;
+        FDX_HIP(hipEventCreateWithFlags(&evTop, hipEventDisableTiming));
+        struct EvOnce { hipEvent_t e; ~EvOnce() { (void)hipEventDestroy(e); } } evTop_guard{evTop};
+        FDX_HIP(hipEventRecord(evTop, st));
+        FDX_HIP(hipStreamWaitEvent(side, evTop, 0));
+        side_drain.s = side;
+        FDX_TRY(solver_init_beta(dB0.as<double>(), ld, g->n_total, K, side));
+        FDX_TRY(solver_zero_pad(dB1.as<double>(), ld, g->n_total, K, side));
+        FDX_HIP(hipEventCreateWithFlags(&evInit, hipEventDisableTiming));
+        FDX_HIP(hipEventRecord(evInit, side));
+    }
+
     // ---- sketch plans (Omega tables come from the host: hash/sign from numpy's RandomState, core/sketching.py:58-59);
     // shared through a content-keyed cache, so a repeated fit builds nothing
     std::shared_ptr<SketchPlan> plan_y_p, plan_x_p;
@@ -247,8 +272,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     const SketchPlan& plan_x = *plan_x_p;
 
     // ---- X_sketch (K, d) and XtX (core/sketching.py:202-204, core/solver.py:346)
-    const long long ld = round_up(n + 1, 64);
-    DevBuf dX, dXs, dG, dH, dB0, dB1, dYs, dRowSq, dSum;
+    DevBuf dX, dXs, dG, dH, dYs, dRowSq, dSum;
     FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
     FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
     FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
@@ -266,8 +290,6 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
 
     // ---- Y_sketch in solver order, chunked, contracted into H (K, ld) as it is produced
     FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
-    FDX_TRY(dB0.alloc((size_t)K * ld * sizeof(double)));
-    FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
     FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
     FDX_TRY(dSum.alloc(sizeof(double)));
     // Y_sketch is produced and consumed in chunks of 256k rows (1 GB at d = 512): measured on MI355X, smaller chunks
@@ -355,19 +377,20 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     // The export of the result (type-major solver order -> row-major caller order, 0.25 ms at 1M x 30) and the objective pass
     // (0.2 ms) both only read the final abundances: the export goes to the library's side stream (idle here - the leverage
     // job was collected before this call) and runs beside the objective pass instead of after it.
-    struct SideDrain { hipStream_t s = nullptr; ~SideDrain() { if (s) (void)hipStreamSynchronize(s); } } side_drain;   // before the buffers above are released
     hipEvent_t evSolved = nullptr, evExported = nullptr;
     struct EvGuard3 { hipEvent_t* a; hipEvent_t* b; ~EvGuard3() { if (*a) (void)hipEventDestroy(*a); if (*b) (void)hipEventDestroy(*b); } } evX_guard{&evSolved, &evExported};
+    if (evInit) {
+        p.init_beta = 0;                     // done on the side stream at the top
+        FDX_HIP(hipStreamWaitEvent(st, evInit, 0));
+    }
     FDX_TRY(solver_run(p, &r, st));          // its chunked read-backs synchronise the stream: YtY has arrived after it
     bool exported = false;
     if ((beta_out_dev || prop_out_dev) && !prm->verbose && !getenv("FDX_NO_EXPORT_OVERLAP")) {
-        hipStream_t side = leverage_side_stream();
-        if (side && side != st) {
+        if (side) {
             FDX_HIP(hipEventCreateWithFlags(&evSolved, hipEventDisableTiming));
             FDX_HIP(hipEventCreateWithFlags(&evExported, hipEventDisableTiming));
             FDX_HIP(hipEventRecord(evSolved, st));
             FDX_HIP(hipStreamWaitEvent(side, evSolved, 0));
-            side_drain.s = side;
             FDX_TRY(launch_normalize_export(p.beta[r.result_buffer], ld, row_map, (int)n, g->n_slices, K, beta_out_dev,
                                             prop_out_dev, side));
             FDX_HIP(hipEventRecord(evExported, side));
