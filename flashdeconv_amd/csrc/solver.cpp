@@ -121,41 +121,75 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
         a.tile_hcnt = g.tile_hcnt.as<int>(); a.n_tiles = g.n_tiles; a.halo_max = g.halo_max;
     }
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    FDX_HIP(hipEventCreate(&ev0));
-    FDX_HIP(hipEventCreate(&ev1));
+    // per chunk: events around its sweeps (alternating pairs: the next chunk's first sweeps are queued before this chunk's
+    // timing is read) and one after the trace copy the host waits on
+    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evCopy = nullptr;
+    struct EvGuard { hipEvent_t* e[5]; ~EvGuard() { for (auto* q : e) if (*q) (void)hipEventDestroy(*q); } } ev_guard{{&ev0[0], &ev0[1], &ev1[0], &ev1[1], &evCopy}};
+    for (int j = 0; j < 2; ++j) {
+        FDX_HIP(hipEventCreate(&ev0[j]));
+        FDX_HIP(hipEventCreate(&ev1[j]));
+    }
+    FDX_HIP(hipEventCreateWithFlags(&evCopy, hipEventDisableTiming));
     double sweep_ms_acc = 0.0;   // GPU time of the queued sweeps only (host read-back gaps between chunks excluded)
 
-    std::vector<double> rc_host((size_t)std::max(max_iter, 1), 0.0);
+    // the trace lands in pinned host memory: a copy into pageable memory returns only when it has been done, i.e. it would make
+    // the host wait for the chunk before it can queue anything behind it
+    struct Pinned { double* p = nullptr; size_t cap = 0; ~Pinned() { if (p) (void)hipHostFree(p); } };
+    static thread_local Pinned pinned;
+    const size_t rc_count = (size_t)std::max(max_iter, 1);
+    if (pinned.cap < rc_count) {
+        if (pinned.p) (void)hipHostFree(pinned.p);
+        pinned.p = nullptr; pinned.cap = 0;
+        FDX_HIP(hipHostMalloc((void**)&pinned.p, std::max<size_t>(rc_count, 1024) * sizeof(double), hipHostMallocDefault));
+        pinned.cap = std::max<size_t>(rc_count, 1024);
+    }
+    double* rc_host = pinned.p;
+    for (size_t j = 0; j < rc_count; ++j) rc_host[j] = 0.0;
     int done = 0;          // iterations whose rel_change is known on the host
     int n_iter = 0;
     bool converged = false;
     int chunk = p.first_chunk > 0 ? p.first_chunk : 4;
+    // The host reads the rel_change trace once per chunk; so that the device does not idle during that round trip (~45 us,
+    // a quarter of a sweep, per chunk) the first sweeps of the NEXT chunk are queued before the host waits: if this chunk
+    // converged they are no-ops like every sweep past convergence (device-side stopping rule), otherwise they are simply early.
+    const int n_ahead = (p.verbose || getenv("FDX_NO_SWEEP_AHEAD")) ? 0 : 2;
+    int queued_ahead = 0;  // sweeps of the current chunk that were queued during the previous chunk's read-back
+    int ci = 0;            // chunk counter (event pair = ci & 1)
     // verbose objective trace: evaluated on the NEW buffer at it % 10 == 0 or it == max_iter-1 (solver.py:399-404)
     std::vector<std::pair<int, double>> trace;
+    auto queue_sweep = [&](int it) -> int {
+        a.it = it;
+        a.beta_in = p.beta[it & 1];
+        a.beta_out = p.beta[(it + 1) & 1];
+        FDX_TRY(launch_bcd_sweep(a, generic_scratch.as<double>(), scratch_ld, st));
+        if (p.verbose && (it % 10 == 0 || it == max_iter - 1)) {
+            double obj = 0.0;  // synchronous; verbose mode trades speed for the trace, as the reference does
+            FDX_TRY(solver_objective(g, a.beta_out, p.ld, p.H, p.ldh, p.XtX, K, p.YtY, p.lambda, p.rho_eff,
+                                     obj_partials.as<double>(), obj_out.as<double>(), &obj, st));
+            trace.emplace_back(it, obj);
+        }
+        return 0;
+    };
     while (done < max_iter && !converged) {
         const int end = std::min(max_iter, done + chunk);
-        FDX_HIP(hipEventRecord(ev0, st));
-        for (int it = done; it < end; ++it) {
-            a.it = it;
-            a.beta_in = p.beta[it & 1];
-            a.beta_out = p.beta[(it + 1) & 1];
-            FDX_TRY(launch_bcd_sweep(a, generic_scratch.as<double>(), scratch_ld, st));
-            if (p.verbose && (it % 10 == 0 || it == max_iter - 1)) {
-                double obj = 0.0;  // synchronous; verbose mode trades speed for the trace, as the reference does
-                FDX_TRY(solver_objective(g, a.beta_out, p.ld, p.H, p.ldh, p.XtX, K, p.YtY, p.lambda, p.rho_eff,
-                                         obj_partials.as<double>(), obj_out.as<double>(), &obj, st));
-                trace.emplace_back(it, obj);
-            }
-        }
+        const int pair = ci & 1;
+        if (queued_ahead == 0) FDX_HIP(hipEventRecord(ev0[pair], st));          // otherwise recorded ahead of the early sweeps
+        for (int it = done + queued_ahead; it < end; ++it) FDX_TRY(queue_sweep(it));
         FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, end - 1, st));
-        FDX_HIP(hipEventRecord(ev1, st));
-        FDX_HIP(hipMemcpyAsync(rc_host.data() + done, relchg.as<double>() + done, (size_t)(end - done) * sizeof(double),
+        FDX_HIP(hipEventRecord(ev1[pair], st));
+        FDX_HIP(hipMemcpyAsync(rc_host + done, relchg.as<double>() + done, (size_t)(end - done) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
-        FDX_HIP(hipStreamSynchronize(st));
+        FDX_HIP(hipEventRecord(evCopy, st));
+        int ahead = 0;
+        if (end < max_iter && n_ahead > 0) {
+            ahead = std::min(n_ahead, max_iter - end);
+            FDX_HIP(hipEventRecord(ev0[pair ^ 1], st));
+            for (int it = end; it < end + ahead; ++it) FDX_TRY(queue_sweep(it));
+        }
+        FDX_HIP(hipEventSynchronize(evCopy));
         {
             float ms_chunk = 0.f;
-            FDX_HIP(hipEventElapsedTime(&ms_chunk, ev0, ev1));
+            FDX_HIP(hipEventElapsedTime(&ms_chunk, ev0[pair], ev1[pair]));
             sweep_ms_acc += ms_chunk;
         }
         for (int it = done; it < end; ++it) {
@@ -163,17 +197,17 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
             if (rc_host[it] < p.tol) { converged = true; break; }   // solver.py:409-413
         }
         done = end;
-        chunk = std::min(chunk * 2, 32);
+        queued_ahead = ahead;
+        chunk = std::max(std::min(chunk * 2, 32), ahead);
+        ++ci;
     }
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     res->sweep_ms = sweep_ms_acc;
 
     res->n_iterations = n_iter;                        // iteration + 1 (solver.py:422); 0 when max_iter == 0
     res->converged = converged ? 1 : 0;
     res->final_change = n_iter > 0 ? rc_host[n_iter - 1] : 0.0;
     res->result_buffer = n_iter & 1;                   // sweep `it` writes buffer (it+1)&1
-    res->rel_changes.assign(rc_host.begin(), rc_host.begin() + n_iter);
+    res->rel_changes.assign(rc_host, rc_host + n_iter);
     for (auto& t : trace)
         if (t.first < n_iter) { res->objective_iters.push_back(t.first); res->objectives.push_back(t.second); }
     if (p.compute_objective)
