@@ -49,6 +49,9 @@ inline hipError_t last_launch_error() { return hipGetLastError(); }
 int pool_alloc(size_t bytes, void** p, size_t* cap);
 void pool_free(void* p, size_t cap);
 void pool_trim();   // return every cached block to the driver
+// Thread-local pinned host scratch, a few grow-only slots: the target of asynchronous device-to-host copies (into pageable
+// memory hipMemcpyAsync returns only when the copy has been done, i.e. the host waits for everything queued before it).
+void* pinned_scratch(int slot, size_t bytes);   // nullptr on failure; slot 0..7
 
 struct DevBuf {
     void* p = nullptr;

@@ -281,11 +281,12 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, st));
     // XtX goes to the host NOW, ahead of the big sketch kernel: lambda and the scaled rho are host scalars of the sweeps,
     // and with them known early the solve is queued behind the sketch without the host waiting for it
-    std::vector<double> Gh((size_t)K * K);
+    double* Gh = (double*)pinned_scratch(0, (size_t)K * K * sizeof(double));   // pinned: the copy below must not hold the host back
+    FDX_REQUIRE(Gh != nullptr, "fit: pinned host buffer");
     hipEvent_t evG = nullptr;
     FDX_HIP(hipEventCreateWithFlags(&evG, hipEventDisableTiming));
     struct EvGuard { hipEvent_t e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evG_guard{evG};
-    FDX_HIP(hipMemcpyAsync(Gh.data(), dG.p, Gh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipMemcpyAsync(Gh, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipEventRecord(evG, st));
 
     // ---- Y_sketch in solver order, chunked, contracted into H (K, ld) as it is produced
@@ -350,8 +351,10 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
     FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));   // YtY (core/solver.py:348)
-    double YtY = 0.0;
-    FDX_HIP(hipMemcpyAsync(&YtY, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    double* YtY_h = (double*)pinned_scratch(1, sizeof(double));   // pinned: the host runs ahead and queues the solve behind the sketch
+    FDX_REQUIRE(YtY_h != nullptr, "fit: pinned host buffer");
+    *YtY_h = 0.0;
+    FDX_HIP(hipMemcpyAsync(YtY_h, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
     // YtY only enters the objective: the verbose trace evaluates it inside the loop, otherwise it is read after the solve
     if (prm->verbose) FDX_HIP(hipStreamSynchronize(st));
     else FDX_HIP(hipEventSynchronize(evG));
@@ -369,7 +372,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     // ---- solve
     SolveProblem p;
     p.graph = g; p.H = dH.as<double>(); p.ldh = ld; p.XtX = dG.as<double>();
-    p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = K; p.YtY = YtY;
+    p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = K; p.YtY = prm->verbose ? *YtY_h : 0.0;   // verbose: the stream was synchronised above
     p.lambda = lambda; p.rho_eff = prm->rho_sparsity * diag_mean; p.max_iter = prm->max_iter; p.tol = prm->tol;
     p.verbose = prm->verbose;
     p.compute_objective = prm->verbose ? 1 : 0;
@@ -402,7 +405,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         FDX_TRY(objp.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
         FDX_TRY(objo.alloc(4 * sizeof(double)));
         if (prm->max_iter == 0) FDX_HIP(hipStreamSynchronize(st));
-        FDX_TRY(solver_objective(*g, p.beta[r.result_buffer], ld, p.H, ld, p.XtX, K, YtY, lambda, p.rho_eff, objp.as<double>(),
+        FDX_TRY(solver_objective(*g, p.beta[r.result_buffer], ld, p.H, ld, p.XtX, K, *YtY_h, lambda, p.rho_eff, objp.as<double>(),
                                  objo.as<double>(), &r.final_objective, st));
     }
     tm.mark();  // 3
@@ -421,7 +424,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     info->solve.sweep_ms = r.sweep_ms;
     info->lambda_used = lambda;
     info->rho_effective = p.rho_eff;
-    info->YtY = YtY;
+    info->YtY = *YtY_h;
     info->nnz = g->nnz;
     info->graph_ms = tm.ms(0, 1);
     if (eS0) {

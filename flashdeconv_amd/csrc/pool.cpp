@@ -1,4 +1,6 @@
 // Caching device allocator behind DevBuf (see fdx_internal.h).
+#include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -61,6 +63,28 @@ void pool_free(void* p, size_t /*cap*/) {
     if (it == g_live.end()) return;    // not ours (or already returned)
     g_free[it->second].push_back(p);
     g_live.erase(it);
+}
+
+void* pinned_scratch(int slot, size_t bytes) {
+    static const bool pageable = getenv("FDX_PAGEABLE_READBACK") != nullptr;   // diagnostic: what the copies cost without pinning
+    struct Slot {
+        void* p = nullptr; size_t cap = 0; bool pinned = true;
+        void drop() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
+        ~Slot() { drop(); }
+    };
+    static thread_local Slot slots[8];
+    if (slot < 0 || slot >= 8) return nullptr;
+    Slot& s = slots[slot];
+    if (s.cap < bytes) {
+        s.drop();
+        const size_t want = std::max<size_t>(bytes, 4096);
+        s.pinned = !pageable;
+        if (pageable) s.p = malloc(want);
+        else if (hipHostMalloc(&s.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); s.p = nullptr; }
+        if (!s.p) return nullptr;
+        s.cap = want;
+    }
+    return s.p;
 }
 
 void pool_trim() {

@@ -134,16 +134,9 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
 
     // the trace lands in pinned host memory: a copy into pageable memory returns only when it has been done, i.e. it would make
     // the host wait for the chunk before it can queue anything behind it
-    struct Pinned { double* p = nullptr; size_t cap = 0; ~Pinned() { if (p) (void)hipHostFree(p); } };
-    static thread_local Pinned pinned;
     const size_t rc_count = (size_t)std::max(max_iter, 1);
-    if (pinned.cap < rc_count) {
-        if (pinned.p) (void)hipHostFree(pinned.p);
-        pinned.p = nullptr; pinned.cap = 0;
-        FDX_HIP(hipHostMalloc((void**)&pinned.p, std::max<size_t>(rc_count, 1024) * sizeof(double), hipHostMallocDefault));
-        pinned.cap = std::max<size_t>(rc_count, 1024);
-    }
-    double* rc_host = pinned.p;
+    double* rc_host = (double*)pinned_scratch(2, rc_count * sizeof(double));
+    if (!rc_host) return fail(FDX_ERR_HIP, "solver: pinned host buffer");
     for (size_t j = 0; j < rc_count; ++j) rc_host[j] = 0.0;
     int done = 0;          // iterations whose rel_change is known on the host
     int n_iter = 0;
