@@ -338,24 +338,32 @@ __global__ __launch_bounds__(512) void lev_eigen_kernel(const double* __restrict
     if (*done) return;
     extern __shared__ __attribute__((aligned(16))) double s_gram[];
     __shared__ int s_rot, s_first;
-    double (*C)[65] = reinterpret_cast<double (*)[65]>(s_gram);
-    double (*V)[65] = reinterpret_cast<double (*)[65]>(s_gram + 64 * 65);
-    double* cs = s_gram + 2 * 64 * 65;
+    __shared__ int s_partner[64];
+    __shared__ double s_own[64], s_oth[64];
+    // C and V twice: a round reads one copy and writes the other, so the two-sided update C <- J^T C J and V <- V J of all
+    // disjoint pairs is ONE phase (element (i, j) from the four entries C[{i, r_i}][{j, r_j}]) instead of a column phase and a
+    // row phase with a barrier between them - the kernel is nothing but barrier latency (K = 50: 49 rounds x ~7 sweeps)
+    typedef double (*Mat)[65];
+    auto Cbuf = [&](int b) { return reinterpret_cast<Mat>(s_gram + b * 64 * 65); };
+    auto Vbuf = [&](int b) { return reinterpret_cast<Mat>(s_gram + (2 + b) * 64 * 65); };
+    double* cs = s_gram + 4 * 64 * 65;
     const int tid = threadIdx.x;
     for (int e = tid; e < K * K; e += 512) {
         double acc = 0.0;
         for (int b = 0; b < n_blocks; ++b) acc += part[(size_t)b * K * K + e];
-        C[e / K][e % K] = acc;
-        V[e / K][e % K] = (e / K == e % K) ? 1.0 : 0.0;
+        Cbuf(0)[e / K][e % K] = acc;
+        Vbuf(0)[e / K][e % K] = (e / K == e % K) ? 1.0 : 0.0;
     }
     if (tid == 0) s_first = 0;
     __syncthreads();
-    if (tid < K) cs[128 + tid] = C[tid][tid];                             // ||a_j||^2 of the incoming columns
+    if (tid < K) cs[128 + tid] = Cbuf(0)[tid][tid];                         // ||a_j||^2 of the incoming columns
     const int Kq = (K + 1) & ~1, npair = Kq / 2;
+    int cur = 0;
     for (int sw = 0; sw < 12; ++sw) {
         if (tid == 0) s_rot = 0;
         __syncthreads();
         for (int r = 0; r < Kq - 1; ++r) {
+            Mat C = Cbuf(cur), V = Vbuf(cur), Cn = Cbuf(cur ^ 1), Vn = Vbuf(cur ^ 1);
             if (tid < npair) {
                 int p, q;
                 if (tid == 0) { p = Kq - 1; q = r; } else { p = (r + tid) % (Kq - 1); q = (r - tid + (Kq - 1)) % (Kq - 1); }
@@ -371,42 +379,37 @@ __global__ __launch_bounds__(512) void lev_eigen_kernel(const double* __restrict
                         s_rot = 1;
                         s_first = 1;
                     }
+                    // x'_p = c x_p - sn x_q ,  x'_q = sn x_p + c x_q : own coefficient, partner, partner's coefficient
+                    s_partner[p] = q; s_own[p] = c; s_oth[p] = -sn;
+                    s_partner[q] = p; s_own[q] = c; s_oth[q] = sn;
+                } else if (p < K) {                                       // odd K: p sits this round out
+                    s_partner[p] = p; s_own[p] = 1.0; s_oth[p] = 0.0;
                 }
-                cs[2 * tid] = c; cs[2 * tid + 1] = sn;
             }
             __syncthreads();
-            for (int e = tid; e < npair * K; e += 512) {                  // columns p,q of C and V
-                const int m = e / K, k = e - m * K;
-                int p, q;
-                if (m == 0) { p = Kq - 1; q = r; } else { p = (r + m) % (Kq - 1); q = (r - m + (Kq - 1)) % (Kq - 1); }
-                if (p > q) { const int t = p; p = q; q = t; }
-                if (q >= K) continue;
-                const double c = cs[2 * m], sn = cs[2 * m + 1];
-                const double ckp = C[k][p], ckq = C[k][q];
-                C[k][p] = c * ckp - sn * ckq;
-                C[k][q] = sn * ckp + c * ckq;
-                const double vkp = V[k][p], vkq = V[k][q];
-                V[k][p] = c * vkp - sn * vkq;
-                V[k][q] = sn * vkp + c * vkq;
+            {   // lane = column j (its pair data read once), wave w takes rows w, w + 8, ... (row data is wave-uniform)
+                const int j = tid & 63;
+                if (j < K) {
+                    const int rj = s_partner[j];
+                    const double cj = s_own[j], tj = s_oth[j];
+                    for (int i = tid >> 6; i < K; i += 8) {
+                        const int ri = s_partner[i];
+                        const double ci = s_own[i], ti = s_oth[i];
+                        const double t_i = cj * C[i][j] + tj * C[i][rj];  // column step, rows i and r_i
+                        const double t_r = cj * C[ri][j] + tj * C[ri][rj];
+                        Cn[i][j] = ci * t_i + ti * t_r;                   // row step
+                        Vn[i][j] = cj * V[i][j] + tj * V[i][rj];
+                    }
+                }
             }
             __syncthreads();
-            for (int e = tid; e < npair * K; e += 512) {                  // rows p,q of C
-                const int m = e / K, k = e - m * K;
-                int p, q;
-                if (m == 0) { p = Kq - 1; q = r; } else { p = (r + m) % (Kq - 1); q = (r - m + (Kq - 1)) % (Kq - 1); }
-                if (p > q) { const int t = p; p = q; q = t; }
-                if (q >= K) continue;
-                const double c = cs[2 * m], sn = cs[2 * m + 1];
-                const double cpk = C[p][k], cqk = C[q][k];
-                C[p][k] = c * cpk - sn * cqk;
-                C[q][k] = sn * cpk + c * cqk;
-            }
-            __syncthreads();
+            cur ^= 1;
         }
         const int any = s_rot;
         __syncthreads();
         if (!any) break;
     }
+    Mat V = Vbuf(cur);
     if (!s_first) {                      // nothing to rotate: the columns are orthogonal, their norms are the answer
         if (tid < K) sig2[tid] = cs[128 + tid];
         if (tid == 0) *done = 1;
@@ -486,7 +489,7 @@ static int launch_leverage_multi(const double* X, int K, int G, double reg, doub
     double* bsum = V + (size_t)K * K;
     int* done = sweeps + 6;                                               // sweeps: 8 ints, [0] = passes, [6] = done flag
     FDX_HIP(hipMemsetAsync(sweeps, 0, 8 * sizeof(int), st));
-    constexpr size_t kLds = (2 * 64 * 65 + 64 + 128 + 64) * sizeof(double);
+    constexpr size_t kLds = (4 * 64 * 65 + 64 + 128 + 64) * sizeof(double);   // C and V twice (lev_eigen_kernel), rotation scratch
     FDX_HIP(hipFuncSetAttribute((const void*)lev_eigen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
     hipLaunchKernelGGL(lev_centre_kernel, dim3(gb), dim3(256), 0, st, X, K, G, work);
     for (int pass = 0; pass < LEV_PASSES; ++pass) {
