@@ -210,6 +210,7 @@ int fdx_nearest_distance(const double* coords, int64_t n, int32_t dim, double* d
 }
 
 int fdx_graph_export_csr(const fdx_graph* g, int64_t* indptr, int32_t* indices) {
+    FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g != nullptr && indptr != nullptr, "fdx_graph_export_csr: null argument");
     FDX_REQUIRE(g->nnz == 0 || indices != nullptr, "fdx_graph_export_csr: null indices");
     DevBuf dp, di;
@@ -228,6 +229,7 @@ int fdx_graph_destroy(fdx_graph* g) {
 }
 
 int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_deg) {
+    FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g != nullptr, "fdx_graph_info: null graph");
     if (n) *n = g->n;
     if (nnz) *nnz = g->nnz;
@@ -278,6 +280,7 @@ int fdx_column_sums(const void* Y, int32_t dtype, int64_t n, int32_t G, double* 
 int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sketch, int64_t n, int32_t d, int32_t K,
                   double lambda, double rho, int32_t max_iter, double tol, int32_t verbose, double* beta_out,
                   double* objectives_out, double* rel_changes_out, fdx_solve_info* info) {
+    FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(info != nullptr, "fdx_bcd_solve: null info");
     std::memset(info, 0, sizeof(*info));
     FDX_REQUIRE(n >= 0 && K >= 0 && d >= 0, "fdx_bcd_solve: negative size");
@@ -387,6 +390,7 @@ extern "C" int fdx_gram_xty(const double* X_sketch, const double* Y_sketch, int6
 // + rho |beta|_1 with L = D - A of the graph's structure.  beta (n, K) row-major, H (K, n) row-major, both on the host.
 extern "C" int fdx_objective(const fdx_graph* g, const double* beta, const double* H, const double* XtX, int64_t n, int32_t K,
                              double YtY, double lambda, double rho, double* obj_out) {
+    FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g && beta && H && XtX && obj_out && n > 0 && K > 0, "fdx_objective: bad arguments");
     FDX_REQUIRE(g->n == n && g->identity_order, "fdx_objective: needs a graph over the same n spots in the caller's order (fdx_graph_from_csr)");
     hipStream_t st = nullptr;

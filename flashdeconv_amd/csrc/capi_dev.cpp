@@ -90,12 +90,14 @@ int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, c
 }
 
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream) {
+    FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g && (g->n == 0 || perm_out_dev), "fdx_graph_perm_dev: null argument");
     return graph_copy_perm(g, perm_out_dev, (hipStream_t)stream);
 }
 
 int fdx_graph_localize(const fdx_graph* full, int32_t n_ranks, const int64_t* bounds, int32_t my_rank, void* stream,
                        fdx_graph** local) {
+    FDX_TRY(fdx::graph_meta_sync(full));
     FDX_REQUIRE(full && bounds && local, "fdx_graph_localize: null argument");
     FDX_REQUIRE(n_ranks >= 1 && my_rank >= 0 && my_rank < n_ranks, "fdx_graph_localize: bad rank");
     FDX_REQUIRE(bounds[0] == 0 && bounds[n_ranks] == full->n, "fdx_graph_localize: bounds must cover [0, n]");
@@ -259,6 +261,7 @@ int fdx_init_beta_dev(double* beta_dev, int64_t ld, int64_t n_fill, int32_t K, v
 int fdx_bcd_sweep_dev(const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, const double* beta_in,
                       double* beta_out, int64_t ld, int32_t K, double lambda, double rho_eff, double tol, int32_t it,
                       void* stats_dev, double* rel_change_dev, void* stream) {
+    FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g && H_dev && XtX_dev && beta_in && beta_out && stats_dev && rel_change_dev, "fdx_bcd_sweep_dev: null argument");
     FDX_REQUIRE(ld >= g->n_total + 1, "fdx_bcd_sweep_dev: ld must cover own + halo + zero row");
     FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_FAST, "fdx_bcd_sweep_dev: K must be in 1..64 on the sharded path");
@@ -283,6 +286,7 @@ int fdx_bcd_fold_dev(void* stats_dev, double* rel_change_dev, int32_t it, void* 
 
 int fdx_objective_partials_dev(const fdx_graph* g, const double* beta_dev, int64_t ld, const double* H_dev, int64_t ldh,
                                const double* XtX_dev, int32_t K, double* out4_host, void* stream) {
+    FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g && beta_dev && H_dev && XtX_dev && out4_host, "fdx_objective_partials_dev: null argument");
     hipStream_t st = (hipStream_t)stream;
     out4_host[0] = out4_host[1] = out4_host[2] = out4_host[3] = 0.0;

@@ -343,6 +343,7 @@ int fdx_sharded_solve_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, 
                           double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev, double* beta1_dev,
                           int64_t ld, fdx_solve_info* info, double* rel_changes_out, int32_t* result_buffer, void* stream) {
     FDX_REQUIRE(c && g && H_dev && XtX_dev && beta0_dev && beta1_dev && info && result_buffer, "fdx_sharded_solve_dev: null argument");
+    FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_FAST, "fdx_sharded_solve_dev: K must be in 1..64 on the sharded path");
     FDX_REQUIRE(ld >= g->n_total + 1, "fdx_sharded_solve_dev: ld must cover own + halo + zero row");
     FDX_REQUIRE(max_iter >= 0, "fdx_sharded_solve_dev: max_iter must be >= 0");

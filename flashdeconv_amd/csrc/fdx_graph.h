@@ -44,4 +44,20 @@ struct fdx_graph {
     // native sharded solve (comm.cpp): boundary tiles are swept first, their rows packed and sent while the interior runs
     mutable fdx::DevBuf tiles_boundary, tiles_interior;
     mutable int n_tiles_boundary = -1, n_tiles_interior = 0;
+    // Deferred completion (whole-graph k-NN build, graph_kernels.cpp): every kernel of the build is queued without a host
+    // round trip - the ELL is allocated for ell_cap_rows (an upper bound the kernels respect) - and the numbers only the device
+    // knows (ell_rows, nnz, max_deg, halo_max, tiled) arrive in pinned memory behind meta_event.  graph_meta_sync() waits for
+    // them (and rebuilds the ELL with its exact size if the bound was too small); every consumer of a graph calls it first.
+    mutable bool meta_pending = false;
+    mutable hipEvent_t meta_event = nullptr;
+    mutable long long* meta_host = nullptr;      // pinned: [0] ell rows, [1] nnz, [2] max slice width, [3] max halo | bad-tile flag << 32
+    mutable hipStream_t meta_stream = nullptr;
+    long long ell_cap_rows = 0;
+    mutable fdx::DevBuf keep_nbr, keep_cnt;      // inputs of the queued kernels, released by graph_meta_sync
+    mutable struct fdx_graph_plan* keep_plan = nullptr;
+    ~fdx_graph();
 };
+
+namespace fdx {
+int graph_meta_sync(const fdx_graph* g);         // no-op unless a deferred build is outstanding
+}

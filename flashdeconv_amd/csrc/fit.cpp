@@ -362,6 +362,9 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     double diag_mean = 0.0;
     for (int k = 0; k < K; ++k) diag_mean += Gh[(size_t)k * K + k];
     diag_mean /= (double)K;
+    // a graph whose build was only queued (graph_kernels.cpp, deferred completion) has long finished behind the sketch: take over
+    // its counts before lambda and the sweep launches need them
+    FDX_TRY(graph_meta_sync(g));
     // auto_tune_lambda (core/spatial.py:181-190): alpha * mean(diag XtX) / max(mean degree, 1), alpha = 0.005
     double lambda = prm->lambda_spatial;
     if (prm->lambda_auto) {

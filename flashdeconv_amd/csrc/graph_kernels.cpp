@@ -435,10 +435,11 @@ __global__ __launch_bounds__(256) void slice_width_kernel(const int* __restrict_
 __global__ __launch_bounds__(256) void fill_ell_kernel(const int* __restrict__ ws, int seg_stride,
                                                        const int* __restrict__ seg_extra, const int* __restrict__ deg,
                                                        const int* __restrict__ slice_off, long long n, int n_slices,
-                                                       int pad, int* __restrict__ ell) {
+                                                       int pad, int* __restrict__ ell, long long cap_rows) {
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n_slices) return;
+    if ((long long)slice_off[n_slices] > cap_rows) return;      // deferred build with too small a bound: rebuilt later
     const long long i = (long long)s * 64 + lane;
     const int w0 = slice_off[s], w = slice_off[s + 1] - w0;
     const int dg = (i < n) ? deg[i] : 0;
@@ -477,7 +478,9 @@ constexpr int TILE_HASH = 2048;
 __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ ell, const int* __restrict__ deg,
                                                         const int* __restrict__ slice_off, long long n,
                                                         int* __restrict__ tile_halo, int* __restrict__ tile_hcnt,
-                                                        unsigned short* __restrict__ ell_local) {
+                                                        unsigned short* __restrict__ ell_local, long long cap_rows,
+                                                        int* __restrict__ summary /* [0] largest halo, [1] some tile failed */) {
+    if ((long long)slice_off[(n + 63) >> 6] > cap_rows) return;
     __shared__ int tab[TILE_HASH];
     __shared__ int list[FDX_TILE_HALO_CAP];
     __shared__ int s_cnt, s_over;
@@ -510,9 +513,10 @@ __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ 
     __syncthreads();
     const int H = s_cnt;
     if (H > FDX_TILE_HALO_CAP || s_over) {      // irregular graph: this tile cannot use the LDS path
-        if (tid == 0) tile_hcnt[tile] = -1;
+        if (tid == 0) { tile_hcnt[tile] = -1; if (summary) atomicOr(summary + 1, 1); }
         return;
     }
+    if (tid == 0 && summary) atomicMax(summary, H);
     int P = 1;
     while (P < H) P <<= 1;
     for (int s = H + tid; s < P; s += 256) list[s] = 0x7fffffff;
@@ -720,7 +724,7 @@ static int build_tiles(fdx_graph* g, hipStream_t st) {
         FDX_TRY(g->ell_local.alloc(((size_t)g->ell_rows + 16) * 64 * 2));   // + 16 rows: the tiled sweep loads 16 rows per slice unconditionally
         hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, g->ell.as<int>(), g->deg.as<int>(),
                            g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
-                           g->ell_local.as<unsigned short>());
+                           g->ell_local.as<unsigned short>(), (long long)g->ell_rows, (int*)nullptr);
         FDX_CHECK_LAUNCH();
     trace_host("tiles: allocs + kernel");
         std::vector<int> hc((size_t)g->n_tiles);
@@ -738,7 +742,9 @@ static int build_tiles(fdx_graph* g, hipStream_t st) {
 }
 
 // deg + row segments -> sliced ELL inside g (pad index = n_total)
-static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* seg_extra, hipStream_t st) {
+// defer: nothing is read back here - the ELL gets room for `W_CAP` entries per row on average (the kernels stop at that bound),
+// the tile tables are built behind it and the counts travel to pinned memory behind g->meta_event (graph_meta_sync).
+static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* seg_extra, hipStream_t st, bool defer = false) {
     const long long n = g->n;
     g->n_slices = (int)((n + 63) / 64);
     DevBuf width, tmp;
@@ -749,8 +755,6 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     FDX_CHECK_LAUNCH();
     FDX_TRY(exclusive_scan_int(width.as<int>(), g->slice_off.as<int>(), g->n_slices + 1, st, tmp));
     trace_host("ell: width + scan");
-    int total = 0;
-    FDX_HIP(hipMemcpyAsync(&total, g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
     // nnz and max degree
     size_t rb = 0;
     DevBuf red, rtmp;
@@ -764,6 +768,44 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     if (rb2 > rtmp.bytes) FDX_TRY(rtmp.alloc(rb2));
     FDX_HIP(rocprim::reduce(rtmp.p, rb2, width.as<int>(), red.as<int>() + 2, 0, (size_t)g->n_slices, rocprim::maximum<int>(), st));
     trace_host("ell: 2 reduces");
+    if (defer) {
+        constexpr int W_CAP = 24;                     // slice widths of a k = 6 graph are 9-12; a wider graph is rebuilt exactly
+        const long long cap = (long long)g->n_slices * W_CAP;
+        g->ell_cap_rows = cap;
+        g->n_tiles = (int)((n + 255) / 256);
+        DevBuf summary;
+        FDX_TRY(summary.alloc(8));
+        FDX_HIP(hipMemsetAsync(summary.p, 0, 8, st));
+        FDX_TRY(g->ell.alloc((size_t)std::max<long long>(cap, 1) * 64 * 4));
+        FDX_TRY(g->tile_halo.alloc((size_t)std::max(g->n_tiles, 1) * FDX_TILE_HALO_CAP * 4));
+        FDX_TRY(g->tile_hcnt.alloc((size_t)std::max(g->n_tiles, 1) * 4));
+        FDX_TRY(g->ell_local.alloc(((size_t)cap + 16) * 64 * 2));
+        hipLaunchKernelGGL(fill_ell_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, ws, seg_stride, seg_extra,
+                           g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>(), cap);
+        FDX_CHECK_LAUNCH();
+        if (g->n_tiles > 0) {
+            hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, g->ell.as<int>(), g->deg.as<int>(),
+                               g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
+                               g->ell_local.as<unsigned short>(), cap, summary.as<int>());
+            FDX_CHECK_LAUNCH();
+        }
+        if (!g->meta_host) g->meta_host = (long long*)pinned_block_get();
+        FDX_REQUIRE(g->meta_host != nullptr, "graph: pinned host block");
+        if (!g->meta_event) FDX_HIP(hipEventCreateWithFlags(&g->meta_event, hipEventDisableTiming));
+        for (int j = 0; j < 8; ++j) g->meta_host[j] = 0;
+        // [0] low word: ell rows; [1] nnz; [2] low word: max slice width; [3] low word: largest halo, high word: failed-tile flag
+        FDX_HIP(hipMemcpyAsync(&g->meta_host[0], g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipMemcpyAsync(&g->meta_host[1], red.p, 16, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipMemcpyAsync(&g->meta_host[3], summary.p, 8, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipEventRecord(g->meta_event, st));
+        g->meta_stream = st;
+        g->meta_pending = true;
+        g->ell_rows = 0; g->nnz = 0; g->max_deg = 0; g->tiled = false; g->halo_max = 0;   // until graph_meta_sync
+        trace_host("ell: deferred build queued");
+        return 0;
+    }
+    int total = 0;
+    FDX_HIP(hipMemcpyAsync(&total, g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
     long long h_red[2] = {0, 0};
     FDX_HIP(hipMemcpyAsync(h_red, red.p, 16, hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
@@ -773,7 +815,8 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     g->max_deg = (int)(h_red[1] & 0xffffffffLL);
     FDX_TRY(g->ell.alloc((size_t)std::max<long long>(g->ell_rows, 1) * 64 * 4));
     hipLaunchKernelGGL(fill_ell_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, ws, seg_stride, seg_extra,
-                       g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>());
+                       g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>(),
+                       (long long)g->ell_rows);
     FDX_CHECK_LAUNCH();
     trace_host("ell: alloc + fill_ell");
     FDX_TRY(build_tiles(g, st));
@@ -833,6 +876,12 @@ struct fdx_graph_plan {
     fdx::DevBuf indeg, arrival;    // whole graph in one piece: in-degrees and reverse-list places from the k-NN kernel
     ~fdx_graph_plan() { (void)hipStreamSynchronize(st); }   // nothing may still read the buffers when they go back to the pool
 };
+fdx_graph::~fdx_graph() {
+    if (meta_pending && meta_event) (void)hipEventSynchronize(meta_event);   // queued kernels still write into the buffers below
+    if (keep_plan) { delete keep_plan; keep_plan = nullptr; }
+    if (meta_event) (void)hipEventDestroy(meta_event);
+    if (meta_host) fdx::pinned_block_put(meta_host);
+}
 namespace fdx {
 
 int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long long lo, long long hi, int* nbr, int* cnt,
@@ -879,8 +928,8 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
 void graph_plan_destroy(fdx_graph_plan* plan) { delete plan; }
 int graph_plan_kk(const fdx_graph_plan* plan) { return plan->kk; }
 
-int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, long long lo, long long hi, fdx_graph* g,
-                         hipStream_t st) {
+static int graph_from_knn_lists_impl(fdx_graph_plan* plan, const int* nbr, const int* cnt, long long lo, long long hi, fdx_graph* g,
+                                     hipStream_t st, bool defer) {
     const long long n = plan->n;
     const int kk = plan->kk;
     FDX_REQUIRE(0 <= lo && lo <= hi && hi <= n, "graph: bad row range");
@@ -933,8 +982,37 @@ int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, l
     trace_host("sym: fill_reverse, merge_rows launched");
     g->row_stride = kk;
     g->row_extra.take(rev_off);   // keep: segment offsets
-    FDX_TRY(finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), st));
-    FDX_HIP(hipStreamSynchronize(st));
+    FDX_TRY(finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), st, defer));
+    if (!defer) FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, long long lo, long long hi, fdx_graph* g,
+                         hipStream_t st) {
+    return graph_from_knn_lists_impl(plan, nbr, cnt, lo, hi, g, st, false);
+}
+
+// Waits for a deferred build (finish_ell) and takes over what only the device knew.  Cheap no-op otherwise.
+int graph_meta_sync(const fdx_graph* gc) {
+    if (!gc || !gc->meta_pending) return 0;
+    fdx_graph* g = const_cast<fdx_graph*>(gc);
+    FDX_HIP(hipEventSynchronize(g->meta_event));
+    g->meta_pending = false;
+    // the queued kernels are done: their inputs can go
+    g->keep_nbr.release();
+    g->keep_cnt.release();
+    if (g->keep_plan) { graph_plan_destroy(g->keep_plan); g->keep_plan = nullptr; }
+    const long long rows = g->meta_host[0] & 0xffffffffLL;
+    g->nnz = g->meta_host[1];
+    g->max_deg = (int)(g->meta_host[2] & 0xffffffffLL);
+    if (rows > g->ell_cap_rows) {                     // the bound was too small (hubs): build the ELL again with its exact size
+        trace_host("meta: ELL bound too small, rebuilding");
+        return finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), g->meta_stream, false);
+    }
+    g->ell_rows = rows;
+    g->halo_max = (int)(g->meta_host[3] & 0xffffffffLL);
+    g->tiled = g->n_tiles > 0 && rows > 0 && (g->meta_host[3] >> 32) == 0;
+    if (getenv("FDX_TRACE_HOST")) std::fprintf(stderr, "[fdx-host] meta: rows %lld of %lld, nnz %lld, largest halo %d, tiled %d\n", rows, g->ell_cap_rows, g->nnz, g->halo_max, (int)g->tiled);
     return 0;
 }
 
@@ -952,7 +1030,16 @@ int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_gra
     FDX_TRY(cnt.alloc((size_t)n * 4));
     fdx_graph_plan* plan = nullptr;
     FDX_TRY(graph_knn_lists(d_coords, n, dim, k, 0, n, nbr.as<int>(), cnt.as<int>(), &plan, st));
-    const int rc = graph_from_knn_lists(plan, nbr.as<int>(), cnt.as<int>(), 0, n, g, st);
+    // Whole graph in one piece: the rest is queued without a host round trip (FDX_GRAPH_SYNC=1: built to the end here); the
+    // lists and the binned points stay with the graph until graph_meta_sync has seen the kernels finish.
+    const bool defer = !getenv("FDX_GRAPH_SYNC");
+    const int rc = graph_from_knn_lists_impl(plan, nbr.as<int>(), cnt.as<int>(), 0, n, g, st, defer);
+    if (rc == 0 && defer && g->meta_pending) {
+        g->keep_nbr.take(nbr);
+        g->keep_cnt.take(cnt);
+        g->keep_plan = plan;
+        return 0;
+    }
     delete plan;
     return rc;
 }

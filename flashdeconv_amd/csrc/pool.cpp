@@ -65,6 +65,25 @@ void pool_free(void* p, size_t /*cap*/) {
     g_live.erase(it);
 }
 
+// 64-byte pinned blocks for objects that outlive a call (a graph's deferred counts): hipHostMalloc / hipHostFree cost hundreds of
+// microseconds each, so the blocks are recycled through a process-wide list and never returned.
+static std::mutex g_pin_mu;
+static std::vector<void*> g_pin_free;
+void* pinned_block_get() {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (!g_pin_free.empty()) { void* p = g_pin_free.back(); g_pin_free.pop_back(); return p; }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void pinned_block_put(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_free.push_back(p);
+}
+
 void* pinned_scratch(int slot, size_t bytes) {
     static const bool pageable = getenv("FDX_PAGEABLE_READBACK") != nullptr;   // diagnostic: what the copies cost without pinning
     struct Slot {
