@@ -769,8 +769,11 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     FDX_HIP(rocprim::reduce(rtmp.p, rb2, width.as<int>(), red.as<int>() + 2, 0, (size_t)g->n_slices, rocprim::maximum<int>(), st));
     trace_host("ell: 2 reduces");
     if (defer) {
-        constexpr int W_CAP = 24;                     // slice widths of a k = 6 graph are 9-12; a wider graph is rebuilt exactly
-        const long long cap = (long long)g->n_slices * W_CAP;
+        // room per row: three times the list length, at least 24 (slice widths of a k = 6 graph are 9-12), at most 96; a graph
+        // that needs more (hubs) is rebuilt with its exact size by graph_meta_sync
+        const int w_cap = getenv("FDX_GRAPH_WCAP") ? std::max(1, atoi(getenv("FDX_GRAPH_WCAP")))        // tests: force the rebuild
+                                                : std::min(96, std::max(24, 3 * std::max(seg_stride, 1) + 3));
+        const long long cap = (long long)g->n_slices * w_cap;
         g->ell_cap_rows = cap;
         g->n_tiles = (int)((n + 255) / 256);
         DevBuf summary;

@@ -107,6 +107,30 @@ def test_counting_order_is_the_stable_sort_order(case, monkeypatch):
     assert np.array_equal(ip_c, ip_s) and np.array_equal(ix_c, ix_s)
 
 
+def test_deferred_graph_build_and_its_rebuild_path(monkeypatch):
+    """Whole-graph k-NN builds queue everything behind the bounding box and hand the counts over later (graph_meta_sync); if the
+    ELL bound was too small the ELL is rebuilt with its exact size.  All three ways - deferred, deferred with a bound of one entry
+    per row (always too small), built to the end - must give the reference graph, and the same fit."""
+    from flashdeconv_amd.utils import graph as G
+    from flashdeconv_amd import FlashDeconv
+    rs = np.random.RandomState(21)
+    coords = rs.rand(5000, 2) * 70.0
+    want = orc.knn_graph_kdtree(coords, 6)
+    Y, X = datagen.gaussian_raw(5000, 120, 5, seed=3)[:2]
+    fits = []
+    for env in ({}, {"FDX_GRAPH_WCAP": "1"}, {"FDX_GRAPH_SYNC": "1"}):
+        for k in ("FDX_GRAPH_WCAP", "FDX_GRAPH_SYNC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        A = G.build_knn_graph(coords, k=6)
+        assert np.array_equal(A.indptr, want.indptr) and np.array_equal(A.indices, want.indices), env
+        m = FlashDeconv(sketch_dim=64, preprocess="raw", max_iter=15).fit(Y, X, coords)
+        fits.append((m.beta_.copy(), m.info_["n_iterations"], m.lambda_used_))
+    for b, it, lam in fits[1:]:
+        assert np.array_equal(b, fits[0][0]) and it == fits[0][1] and lam == fits[0][2]
+
+
 def test_graph_errors():
     from flashdeconv_amd.utils import graph as G
     with pytest.raises(ValueError, match="coords must be 2D"):
