@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void fill_reverse_placed_kernel(const int* __r
 // sorting makes the result deterministic.
 __global__ __launch_bounds__(128) void merge_rows_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
                                                          const int* __restrict__ rev, const int* __restrict__ rev_off,
-                                                         const int* __restrict__ perm, long long lo, long long hi, int kk,
+                                                         const int* __restrict__ perm, const int* __restrict__ rank,
+                                                         long long lo, long long hi, int kk,
                                                          int* __restrict__ ws, int* __restrict__ deg) {
     const long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (p >= hi) return;
@@ -362,25 +363,26 @@ __global__ __launch_bounds__(128) void merge_rows_kernel(const int* __restrict__
     const int n_out = nbr_cnt[p], n_in = rev_off[p + 1] - rev_off[p];
     const int m = n_out + n_in;
     constexpr int CAP = 32;
-    __shared__ long long keys[CAP * 128];            // keys[a * 128 + tid]: a thread's slots are 128 apart -> conflict-free
+    __shared__ int keys[CAP * 128];                  // keys[a * 128 + tid]: a thread's slots are 128 apart -> conflict-free
     if (m <= CAP) {
-        // common case: sort (original index, position) keys in LDS and write the row ONCE.  (An in-place insertion sort
-        // in global memory costs a 64-byte write per 4-byte move - measured 2 GB written for 100 MB - and a private
-        // key[] array is dynamically indexed, i.e. scratch memory: 3.5 ms at 8M spots.)
-        long long* key = keys + threadIdx.x;
-        for (int t = 0; t < n_out; ++t) { const int v = nbr[(size_t)p * kk + t]; key[t * 128] = ((long long)perm[v] << 32) | (unsigned)v; }
-        for (int t = 0; t < n_in; ++t) { const int v = rev[rev_off[p] + t]; key[(n_out + t) * 128] = ((long long)perm[v] << 32) | (unsigned)v; }
+        // common case: sort the ORIGINAL indices (a bijection of the positions: rank[] leads back) in LDS and write the row
+        // ONCE.  (An in-place insertion sort in global memory costs a 64-byte write per 4-byte move - measured 2 GB written
+        // for 100 MB - and a private key[] array is dynamically indexed, i.e. scratch memory: 3.5 ms at 8M spots.  32-bit
+        // keys: 16 KB per workgroup, twice the resident workgroups of the (original index, position) pairs used before.)
+        int* key = keys + threadIdx.x;
+        for (int t = 0; t < n_out; ++t) key[t * 128] = perm[nbr[(size_t)p * kk + t]];
+        for (int t = 0; t < n_in; ++t) key[(n_out + t) * 128] = perm[rev[rev_off[p] + t]];
         for (int a = 1; a < m; ++a) {
-            const long long kv = key[a * 128];
+            const int kv = key[a * 128];
             int b = a - 1;
             while (b >= 0 && key[b * 128] > kv) { key[(b + 1) * 128] = key[b * 128]; --b; }
             key[(b + 1) * 128] = kv;
         }
         int u = 0;
-        long long prev = -1;
+        int prev = -1;
         for (int a = 0; a < m; ++a) {
-            const long long kv = key[a * 128];
-            if (a == 0 || kv != prev) seg[u++] = (int)(kv & 0xffffffffLL);
+            const int kv = key[a * 128];
+            if (a == 0 || kv != prev) seg[u++] = rank[kv];
             prev = kv;
         }
         deg[p] = u;
@@ -979,7 +981,7 @@ static int graph_from_knn_lists_impl(fdx_graph_plan* plan, const int* nbr, const
     if (lo > 0 || hi < n) FDX_HIP(hipMemsetAsync(g->deg.p, 0, g->deg.bytes, st));
     if (hi > lo) {
         hipLaunchKernelGGL(merge_rows_kernel, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, nbr, cnt, rev.as<int>(),
-                           rev_off.as<int>(), g->perm.as<int>(), lo, hi, kk, g->rows.as<int>(), g->deg.as<int>());
+                           rev_off.as<int>(), g->perm.as<int>(), g->rank.as<int>(), lo, hi, kk, g->rows.as<int>(), g->deg.as<int>());
         FDX_CHECK_LAUNCH();
     }
     trace_host("sym: fill_reverse, merge_rows launched");
