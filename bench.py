@@ -161,6 +161,21 @@ def pmc_traffic(kernel, shape):
         return None
 
 
+def sweep_chunk(K):
+    """Cell types per chunk of the tiled sweep: mirror of sweep_chunk() in csrc/bcd_sweep_inst.cpp (second template argument
+    of bcd_sweep_tiled_kernel; tests/test_host.py checks the two against each other)."""
+    if K < 8:
+        return K
+    for bound, kc in ((29, 8), (33, 7), (37, 6), (41, 5), (45, 4), (49, 3), (51, 2)):
+        if K <= bound:
+            return kc
+    return 8
+
+
+def sweep_kernel_name(K):
+    return "fdx::bcd_sweep_tiled_kernel<%d, %d, false>" % (K, sweep_chunk(K))
+
+
 def sketch_kernel_name(mode, K, d=512):
     """Kernel that serves the sketch -> H stage of the bench shapes (csrc/tile_kernels.cpp: tile_cfg): template arguments
     <input type, preprocess, consumer waves, loader waves, groups per wave, type tiles, A operands from L2>."""
@@ -307,7 +322,7 @@ def main():
         n_chunks = -(-n // (1 << 18))                 # the sketch kernel is launched once per 262144-row chunk (fit.cpp)
         if dom == "bcd_sweep":
             bytes_launch, ms_launch = sw_bytes, sweep_ms
-            kname = "fdx::bcd_sweep_tiled_kernel<%d, 8, false>" % K
+            kname = sweep_kernel_name(K)
         else:
             if stage["gram_ms"] == 0.0:                # fused sketch -> H kernel: ONE launch reads all of Y, writes only H
                 bytes_launch, ms_launch = sk_bytes, sk_ms

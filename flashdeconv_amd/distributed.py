@@ -659,7 +659,7 @@ def bench_main(a, rank, world, local_rank):
         own_nnz = int(model._full.info()[1])
         alg = 3 * model.n_own * K * 8 + (own_nnz + model.n_own + 1) * 4
         ach = alg / (sweep_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "fdx::bcd_sweep_tiled_kernel<%d, 8, false>" % K, "achieved": round(ach, 1),
+        roof = {"bound": "hbm", "kernel": bench.sweep_kernel_name(K), "achieved": round(ach, 1),
                 "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / bench.HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": int(alg), "ms_per_launch": round(sweep_ms, 4), "rank": 0}
     dist.destroy_process_group()

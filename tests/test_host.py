@@ -342,3 +342,28 @@ def test_schedule_builders_under_address_and_ub_sanitizers():
         pytest.skip("no sanitizer runtime")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok under the sanitizers" in r.stdout
+
+
+def test_bench_sweep_chunk_mirrors_the_kernel_table():
+    """bench.py names the sweep kernel of the roofline line; its chunk table must be the one in csrc/bcd_sweep_inst.cpp."""
+    import re
+    import bench
+    src = open(os.path.join(ROOT, "flashdeconv_amd", "csrc", "bcd_sweep_inst.cpp")).read()
+    m = re.search(r"return K < 8 \? K : ([^;]+);", src)
+    assert m, "sweep_chunk() not found"
+    expr = m.group(1)
+
+    def c_table(K):
+        e = expr
+        while True:
+            mm = re.match(r"\s*K (<=|==) (\d+) \? (\d+) : (.*)", e)
+            if not mm:
+                return int(e.strip())
+            op, b, v, rest = mm.group(1), int(mm.group(2)), int(mm.group(3)), mm.group(4)
+            if (op == "<=" and K <= b) or (op == "==" and K == b):
+                return v
+            e = rest
+
+    for K in range(1, 65):
+        want = K if K < 8 else c_table(K)
+        assert bench.sweep_chunk(K) == want, K
