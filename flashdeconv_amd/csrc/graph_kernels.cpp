@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ 
         if (tid == 0) { tile_hcnt[tile] = -1; if (summary) atomicOr(summary + 1, 1); }
         return;
     }
-    if (tid == 0 && summary) atomicMax(summary, H);
+    if (tid == 0 && summary && H > __builtin_nontemporal_load(summary)) atomicMax(summary, H);   // a glance first: one address for 4000 tiles
     int P = 1;
     while (P < H) P <<= 1;
     for (int s = H + tid; s < P; s += 256) list[s] = 0x7fffffff;
