@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict
     perm[p] = (int)i;
     rank[i] = p;
     skeys[p] = k;
-    for (int a = 0; a < 3; ++a) sc[(size_t)a * n + p] = (a < dim) ? coords[(size_t)i * dim + a] : 0.0;
+    for (int a = 0; a < dim; ++a) sc[(size_t)a * n + p] = coords[(size_t)i * dim + a];   // planes past dim: zeroed by the caller (one contiguous fill)
 }
 
 // ------------------------------------------------------------------------------------------------ k-NN
@@ -692,6 +692,7 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
         hipLaunchKernelGGL(cell_place_kernel, dim3(nb), dim3(256), 0, st, keys.as<unsigned>(), vals.as<int>(), b->start.as<int>(), n,
                            tmp.as<int>());
         FDX_CHECK_LAUNCH();
+        if (dim < 3) FDX_HIP(hipMemsetAsync(b->sc.as<double>() + (size_t)dim * n, 0, (size_t)(3 - dim) * n * sizeof(double), st));
         hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(256), 0, st, d_coords, keys.as<unsigned>(), b->start.as<int>(),
                            tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), skeys.as<u64>(), b->sc.as<double>());
         FDX_CHECK_LAUNCH();
