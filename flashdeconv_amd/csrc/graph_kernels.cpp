@@ -103,6 +103,24 @@ __device__ __forceinline__ unsigned long long morton_key(const int c[3], int dim
     if (dim == 2) return spread_bits_2((unsigned)c[0]) | (spread_bits_2((unsigned)c[1]) << 1);
     return spread_bits_3((unsigned)c[0]) | (spread_bits_3((unsigned)c[1]) << 1) | (spread_bits_3((unsigned)c[2]) << 2);
 }
+__device__ __forceinline__ unsigned compact_bits_2(unsigned long long v) {                 // 0a0b0c0d -> abcd
+    v &= 0x5555555555555555ULL;
+    v = (v | (v >> 1)) & 0x3333333333333333ULL;
+    v = (v | (v >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | (v >> 4)) & 0x00ff00ff00ff00ffULL;
+    v = (v | (v >> 8)) & 0x0000ffff0000ffffULL;
+    v = (v | (v >> 16)) & 0x00000000ffffffffULL;
+    return (unsigned)v;
+}
+__device__ __forceinline__ unsigned compact_bits_3(unsigned long long v) {                 // every third bit -> 21 bits
+    v &= 0x1249249249249249ULL;
+    v = (v | (v >> 2)) & 0x10c30c30c30c30c3ULL;
+    v = (v | (v >> 4)) & 0x100f00f00f00f00fULL;
+    v = (v | (v >> 8)) & 0x1f0000ff0000ffULL;
+    v = (v | (v >> 16)) & 0x1f00000000ffffULL;
+    v = (v | (v >> 32)) & 0x1fffffULL;
+    return (unsigned)v;
+}
 
 __global__ __launch_bounds__(256) void cell_key_kernel(const double* __restrict__ coords, long long n, GridParams gp,
                                                        unsigned long long* __restrict__ keys, int* __restrict__ vals) {
@@ -162,11 +180,11 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const unsigned* __restr
     members[start[key32[i]] + arrival[i]] = (int)i;
 }
 // pass 3: position of point i = start of its key + number of members with a smaller index (cells hold a handful of
-// points); writes everything the sorted order defines: perm, rank, sorted keys, sorted coordinate planes
+// points); writes everything the sorted order defines: perm, rank, sorted coordinate planes
 __global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict__ coords, const unsigned* __restrict__ key32,
                                                         const int* __restrict__ start, const int* __restrict__ members,
                                                         long long n, int dim, int* __restrict__ perm, int* __restrict__ rank,
-                                                        unsigned long long* __restrict__ skeys, double* __restrict__ sc) {
+                                                        double* __restrict__ sc) {
     const long long i = blockIdx.x * 256LL + threadIdx.x;
     if (i >= n) return;
     const unsigned k = key32[i];
@@ -176,8 +194,24 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict
     const int p = s + below;
     perm[p] = (int)i;
     rank[i] = p;
-    skeys[p] = k;
     for (int a = 0; a < dim; ++a) sc[(size_t)a * n + p] = coords[(size_t)i * dim + a];   // planes past dim: zeroed by the caller (one contiguous fill)
+}
+
+// pass 4: the cell table (row-major cell id -> [start, end) of the sorted order) straight from the key starts: an occupied
+// key IS a cell, its Morton code gives the cell coordinates back
+__global__ __launch_bounds__(256) void cell_table_kernel(const int* __restrict__ start, long long bins, GridParams gp,
+                                                         int* __restrict__ cstart, int* __restrict__ cend) {
+    const long long k = blockIdx.x * 256LL + threadIdx.x;
+    if (k >= bins) return;
+    const int s0 = start[k], s1 = start[k + 1];
+    if (s1 <= s0) return;
+    int c[3] = {0, 0, 0};
+    if (gp.dim == 1) c[0] = (int)k;
+    else if (gp.dim == 2) { c[0] = (int)compact_bits_2((unsigned long long)k); c[1] = (int)compact_bits_2((unsigned long long)k >> 1); }
+    else { c[0] = (int)compact_bits_3((unsigned long long)k); c[1] = (int)compact_bits_3((unsigned long long)k >> 1); c[2] = (int)compact_bits_3((unsigned long long)k >> 2); }
+    const int id = c[0] * gp.stride[0] + c[1] * gp.stride[1] + c[2] * gp.stride[2];
+    cstart[id] = s0;
+    cend[id] = s1;
 }
 
 // ------------------------------------------------------------------------------------------------ k-NN
@@ -694,8 +728,13 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
         FDX_CHECK_LAUNCH();
         if (dim < 3) FDX_HIP(hipMemsetAsync(b->sc.as<double>() + (size_t)dim * n, 0, (size_t)(3 - dim) * n * sizeof(double), st));
         hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(256), 0, st, d_coords, keys.as<unsigned>(), b->start.as<int>(),
-                           tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), skeys.as<u64>(), b->sc.as<double>());
+                           tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), b->sc.as<double>());
         FDX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(cell_table_kernel, dim3(ceil_div(bins, 256)), dim3(256), 0, st, b->start.as<int>(), bins, b->gp,
+                           b->cstart.as<int>(), b->cend.as<int>());
+        FDX_CHECK_LAUNCH();
+        trace_host("bin: place/rank/table kernels");
+        return 0;                        // no sync: the temporaries live in *b, whose owners synchronise before dropping it
     } else {
         hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, st, d_coords, n, b->gp, keys.as<u64>(), vals.as<int>());
         FDX_CHECK_LAUNCH();
