@@ -128,8 +128,8 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_i64, ctypes.POINTER(SolveInfo), p_double, p_i32, c_void_p]),
     "fdx_tile_schedule": (c_int, [p_i32, p_double, c_i32, c_i32, c_i32, c_i32, c_i32, p_i32, p_i32, c_void_p, p_i32, p_double,
                                   c_void_p, c_i64]),
-    "fdx_rowreg_schedule": (c_int, [p_i32, p_double, c_i32, c_i32, p_i32, p_i32, p_i32, p_double, c_void_p, c_void_p, c_i64]),
     "fdx_column_sums": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_double]),
+    "fdx_log1p_f32": (c_int, [c_void_p, ctypes.c_float, c_i64, c_void_p]),
     "fdx_graph_build_knn": (c_int, [p_double, c_i64, c_i32, c_i32, ctypes.POINTER(c_void_p)]),
     "fdx_graph_build_radius": (c_int, [p_double, c_i64, c_i32, c_double, ctypes.POINTER(c_void_p)]),
     "fdx_nearest_distance": (c_int, [p_double, c_i64, c_i32, p_double]),
@@ -344,10 +344,31 @@ class CsrOnDevice:
                    int(indptr[-1]) if len(indptr) else 0, G, sorted_rows=1 if Y.has_sorted_indices else 0)
         return self
 
-    # Structure checks of torch CSR tensors already seen, keyed by the identity of their index tensors (storage pointer,
-    # torch's in-place version counter, sizes): a second fit on the same tensor does not scan its 10^9 indices again.  An
-    # in-place edit of the indices bumps the version counter and is checked anew.
+    # Structure checks of torch CSR tensors already seen: a second fit on the SAME tensor object does not scan its 10^9
+    # indices again.  An entry is bound to the live tensor object (a weak reference; the entry goes when the tensor is
+    # collected, so neither its id nor the addresses of its index tensors - which the sparse tensor keeps alive - can be
+    # taken over by another matrix while the entry exists) and to torch's in-place version counters of the index tensors.
+    # Writes that bypass torch (dlpack, raw pointers) are not seen: whoever does that owns the consequences.
     _checked = {}
+
+    @classmethod
+    def _checked_lookup(cls, Y, crow0, col0, shape_key):
+        ent = cls._checked.get(id(Y))
+        if ent is None or ent[0]() is not Y or ent[1] != (crow0._version, col0._version) + shape_key:
+            return None
+        return ent[2]
+
+    @classmethod
+    def _checked_store(cls, Y, crow0, col0, shape_key, sorted_rows):
+        import weakref
+        key = id(Y)
+        try:
+            ref = weakref.ref(Y, lambda _r, k=key: cls._checked.pop(k, None))
+        except TypeError:
+            return
+        if len(cls._checked) >= 8:
+            cls._checked.pop(next(iter(cls._checked)))
+        cls._checked[key] = (ref, (crow0._version, col0._version) + shape_key, int(sorted_rows))
 
     @classmethod
     def from_torch(cls, Y):
@@ -362,20 +383,21 @@ class CsrOnDevice:
         val = val.contiguous()
         self = cls()
         self._keep = [crow, col, val]
-        key = None
-        if crow is crow0 or crow.data_ptr() == crow0.data_ptr():
-            if col.data_ptr() == col0.data_ptr():   # zero-copy views of the caller's tensors: identity is meaningful
-                key = (crow0.data_ptr(), col0.data_ptr(), crow0._version, col0._version, int(n), int(G), int(val.numel()))
+        shape_key = (int(n), int(G), int(val.numel()), crow.data_ptr(), col.data_ptr())
+        zero_copy = crow.data_ptr() == crow0.data_ptr() and col.data_ptr() == col0.data_ptr()
+        known = cls._checked_lookup(Y, crow0, col0, shape_key) if zero_copy else None
         self._fill(crow.data_ptr(), col.data_ptr(), val.data_ptr(), FDX_F32 if val.dtype == torch.float32 else FDX_F64,
-                   n, int(val.numel()), G, check_key=key)
+                   n, int(val.numel()), G, known_sorted=known)
+        if zero_copy and known is None:
+            cls._checked_store(Y, crow0, col0, shape_key, self.view.sorted_rows)
         return self
 
-    def _fill(self, indptr, indices, data, dtype, n, nnz, G, sorted_rows=1, check_key=None):
+    def _fill(self, indptr, indices, data, dtype, n, nnz, G, sorted_rows=1, known_sorted=None):
         v = self.view
         v.indptr, v.indices, v.data, v.dtype, v.n, v.nnz, v.G = indptr, indices, data, dtype, int(n), int(nnz), int(G)
         v.sorted_rows = int(sorted_rows)            # claim, verified on the device
-        if check_key is not None and check_key in CsrOnDevice._checked:
-            v.sorted_rows = CsrOnDevice._checked[check_key]
+        if known_sorted is not None:                # this very tensor object, unmodified, passed the check before
+            v.sorted_rows = int(known_sorted)
             return
         try:
             try:
@@ -388,10 +410,6 @@ class CsrOnDevice:
         except Exception:
             self.free()
             raise
-        if check_key is not None:
-            if len(CsrOnDevice._checked) >= 8:
-                CsrOnDevice._checked.pop(next(iter(CsrOnDevice._checked)))
-            CsrOnDevice._checked[check_key] = int(v.sorted_rows)
 
     def gene_moments(self, want_colsum=False):
         """(mean, var, colsum) per column: utils/genes.py:52-83; colsum (raw column sums, for "pearson") on request."""

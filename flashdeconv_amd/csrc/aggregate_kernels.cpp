@@ -62,6 +62,7 @@ int fdx_type_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, int32_t G, in
     FDX_REQUIRE(n >= 0 && G > 0 && K > 0 && ldy >= G, "fdx_type_sums_dev: bad shape");
     FDX_REQUIRE(dtype == FDX_F32 || dtype == FDX_F64, "fdx_type_sums_dev: dtype must be FDX_F32 or FDX_F64");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     const dim3 grid((unsigned)ceil_div(G, 256), (unsigned)K);
     if (dtype == FDX_F32)
         hipLaunchKernelGGL(type_sums_dense_kernel<float>, grid, dim3(256), 0, st, (const float*)Y_dev, (long long)ldy, rows_dev,
@@ -79,6 +80,7 @@ int fdx_type_sums_csr_dev(const fdx_csr_view* Y, const int32_t* rows_dev, const 
     FDX_REQUIRE(Y->G > 0 && K > 0, "fdx_type_sums_csr_dev: bad shape");
     FDX_REQUIRE(Y->dtype == FDX_F32 || Y->dtype == FDX_F64, "fdx_type_sums_csr_dev: dtype must be FDX_F32 or FDX_F64");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     if (Y->dtype == FDX_F32)
         hipLaunchKernelGGL(type_sums_csr_kernel<float>, dim3((unsigned)K), dim3(256), 0, st, (const long long*)Y->indptr, Y->indices,
                            (const float*)Y->data, rows_dev, type_off_dev, Y->G, mean, X_out_dev);

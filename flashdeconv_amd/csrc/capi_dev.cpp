@@ -38,6 +38,7 @@ extern "C" {
 
 int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t method, int32_t k, double radius,
                         void* stream, fdx_graph** out) {
+    PoolStream pool_stream((hipStream_t)stream);
     FDX_REQUIRE(out != nullptr, "fdx_graph_build_dev: null output");
     *out = nullptr;
     FDX_REQUIRE(n == 0 || coords_dev != nullptr, "fdx_graph_build_dev: null coords");
@@ -53,6 +54,7 @@ int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_
 
 int fdx_graph_build_radius_rows_dev(const double* coords_dev, int64_t n, int32_t dim, double radius, int64_t lo, int64_t hi,
                                     void* stream, fdx_graph** out) {
+    PoolStream pool_stream((hipStream_t)stream);
     FDX_REQUIRE(out != nullptr, "fdx_graph_build_radius_rows_dev: null output");
     *out = nullptr;
     FDX_REQUIRE(n == 0 || coords_dev != nullptr, "fdx_graph_build_radius_rows_dev: null coords");
@@ -65,6 +67,7 @@ int fdx_graph_build_radius_rows_dev(const double* coords_dev, int64_t n, int32_t
 
 int fdx_graph_knn_lists_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t k, int64_t lo, int64_t hi,
                             int32_t* nbr_dev, int32_t* cnt_dev, void* stream, fdx_graph_plan** plan) {
+    PoolStream pool_stream((hipStream_t)stream);
     FDX_REQUIRE(plan != nullptr, "fdx_graph_knn_lists_dev: null output");
     *plan = nullptr;
     FDX_REQUIRE(coords_dev && nbr_dev && cnt_dev, "fdx_graph_knn_lists_dev: null argument");
@@ -73,6 +76,7 @@ int fdx_graph_knn_lists_dev(const double* coords_dev, int64_t n, int32_t dim, in
 
 int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, const int32_t* cnt_dev, int64_t lo, int64_t hi,
                                  void* stream, fdx_graph** out) {
+    PoolStream pool_stream((hipStream_t)stream);
     FDX_REQUIRE(plan != nullptr, "fdx_graph_from_knn_lists_dev: null plan");
     int rc = 0;
     fdx_graph* g = nullptr;
@@ -90,6 +94,7 @@ int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, c
 }
 
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream) {
+    PoolStream pool_stream((hipStream_t)stream);
     FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g && (g->n == 0 || perm_out_dev), "fdx_graph_perm_dev: null argument");
     return graph_copy_perm(g, perm_out_dev, (hipStream_t)stream);
@@ -97,6 +102,7 @@ int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream) 
 
 int fdx_graph_localize(const fdx_graph* full, int32_t n_ranks, const int64_t* bounds, int32_t my_rank, void* stream,
                        fdx_graph** local) {
+    PoolStream pool_stream((hipStream_t)stream);
     FDX_TRY(fdx::graph_meta_sync(full));
     FDX_REQUIRE(full && bounds && local, "fdx_graph_localize: null argument");
     FDX_REQUIRE(n_ranks >= 1 && my_rank >= 0 && my_rank < n_ranks, "fdx_graph_localize: bad rank");
@@ -144,6 +150,7 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
     FDX_REQUIRE(X && bucket && weight_y && weight_x && H_out_dev && XtX_out_dev, "fdx_prepare_dev: null array");
     FDX_REQUIRE(ldh >= n && ldy >= G, "fdx_prepare_dev: leading dimension too small");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     std::vector<long long> cp;
     std::vector<int> gi;
     std::vector<double> w;
@@ -204,6 +211,7 @@ int fdx_prepare_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t 
     const long long n = Y->n;
     FDX_REQUIRE(ldh >= n, "fdx_prepare_csr_dev: leading dimension too small");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     struct Slot { double w; int bucket; int pad; };
     FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(Slot), "fdx_prepare_csr_dev: gene slot layout mismatch");
     const int G_all = Y->G;
@@ -289,6 +297,7 @@ int fdx_objective_partials_dev(const fdx_graph* g, const double* beta_dev, int64
     FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g && beta_dev && H_dev && XtX_dev && out4_host, "fdx_objective_partials_dev: null argument");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     out4_host[0] = out4_host[1] = out4_host[2] = out4_host[3] = 0.0;
     if (g->n == 0) return 0;
     DevBuf part, out;
@@ -315,6 +324,7 @@ extern "C" int fdx_gene_moments_dev(const void* Y_dev, int32_t dtype, int64_t n,
                                     double* var_out_host, void* stream) {
     FDX_REQUIRE(Y_dev && mean_out_host && var_out_host && n > 0 && G > 0, "fdx_gene_moments_dev: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     DevBuf scale, part, mean, var;
     FDX_TRY(scale.alloc((size_t)n * 8));
     FDX_TRY(part.alloc((size_t)column_sums_parts(n) * 2 * G * 8));
@@ -332,6 +342,7 @@ extern "C" int fdx_gather_columns_dev(const void* Y_dev, int32_t dtype, int64_t 
     FDX_REQUIRE(n >= 0 && G > 0 && G_sel > 0 && idx_host && (n == 0 || (Y_dev && out_dev)), "fdx_gather_columns_dev: bad arguments");
     for (int j = 0; j < G_sel; ++j) FDX_REQUIRE(idx_host[j] >= 0 && idx_host[j] < G, "fdx_gather_columns_dev: column index out of range");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     DevBuf di;
     FDX_TRY(di.alloc((size_t)G_sel * 4));
     FDX_HIP(hipMemcpyAsync(di.p, idx_host, (size_t)G_sel * 4, hipMemcpyHostToDevice, st));

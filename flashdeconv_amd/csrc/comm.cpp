@@ -350,6 +350,7 @@ int fdx_sharded_solve_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, 
     FDX_REQUIRE(g->send_off.size() == (size_t)c->world + 1 && g->recv_off.size() == (size_t)c->world + 1,
                 "fdx_sharded_solve_dev: the graph was localized for a different number of ranks");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     std::memset(info, 0, sizeof(*info));
     *result_buffer = 0;
     const int W = c->world;

@@ -44,10 +44,22 @@ inline hipError_t last_launch_error() { return hipGetLastError(); }
 
 // ---- device scratch buffer (RAII) ---------------------------------------------------------------
 // Caching device allocator (pool.cpp): hipMalloc/hipFree cost 0.1-several ms and hipFree synchronises the device, so
-// scratch blocks are recycled through per-device free lists keyed by a rounded capacity.  A recycled block is only
-// ever handed to work queued later on the caller's stream, which orders it after the block's previous users.
+// scratch blocks are recycled through per-device free lists keyed by a rounded capacity.
+// Stream ordering: every entry point that queues work on a stream names it (PoolStream); a block remembers the stream of
+// the entry point that allocated it, and a later owner on a different stream is ordered behind the work queued there
+// (pool.cpp).  Buffers handed to a library side stream inside an entry point are covered by that entry's own events /
+// drains before they are released; error returns drain the device (capi.cpp: fail()).
 int pool_alloc(size_t bytes, void** p, size_t* cap);
+hipStream_t pool_set_stream(hipStream_t s);      // returns the previous one
+struct PoolStream {
+    hipStream_t prev;
+    explicit PoolStream(hipStream_t s) : prev(pool_set_stream(s)) {}
+    ~PoolStream() { pool_set_stream(prev); }
+    PoolStream(const PoolStream&) = delete;
+    PoolStream& operator=(const PoolStream&) = delete;
+};
 void pool_free(void* p, size_t cap);
+void pool_mark_idle(void* p);                    // the owner has waited for all work on the block: no ordering on reuse
 void pool_trim();   // return every cached block to the driver
 // Thread-local pinned host scratch, a few grow-only slots: the target of asynchronous device-to-host copies (into pageable
 // memory hipMemcpyAsync returns only when the copy has been done, i.e. the host waits for everything queued before it).
@@ -77,6 +89,7 @@ struct DevBuf {
         cap = 0;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    void mark_idle() { pool_mark_idle(p); }
     void take(DevBuf& o) {   // move ownership
         release();
         p = o.p;

@@ -76,12 +76,7 @@ bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, in
 bool tile_sketch_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan, hipStream_t st);
 int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
-                       hipStream_t st, const int* tile_list = nullptr, const int* tile_count = nullptr);
-// row-register kernel (rowreg_kernels.cpp): log modes on float32 rows of up to 2048 genes, every row read once
-bool rowreg_sketch_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan, hipStream_t st);
-int launch_rowreg_sketch(const void* Y, long long ldy, const int* row_map, long long n, int G, int d, int mode,
-                         const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
-                         hipStream_t st);
+                       hipStream_t st);
 int launch_sketch_contract(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                            const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
                            hipStream_t st);

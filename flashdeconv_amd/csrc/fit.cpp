@@ -94,6 +94,7 @@ extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double 
     job->K = K;
     job->G = G;
     job->st = leverage_side_stream();
+    PoolStream pool_stream(job->st);
     auto run = [&]() -> int {
         FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
         FDX_TRY(job->dW.alloc((size_t)K * G * sizeof(double)));
@@ -130,6 +131,8 @@ extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) {
     rc = run();
     const hipError_t e = hipStreamSynchronize(job->st);   // always drain before the buffers go back to the pool
     if (!rc && e != hipSuccess) rc = fail(FDX_ERR_HIP, hipGetErrorString(e));
+    if (e == hipSuccess)              // nothing of the job is in flight any more: the blocks may follow any stream
+        for (DevBuf* b : {&job->dX, &job->dW, &job->dS, &job->dL, &job->dDbg, &job->dScratch}) b->mark_idle();
     if (!rc && getenv("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
         std::fprintf(stderr, "[fdx] leverage: K=%d G=%d passes/sweeps=%d converged=%d\n", job->K, job->G, dbg[0], dbg[6]);
     delete job;
@@ -148,6 +151,7 @@ extern "C" int fdx_column_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, 
     FDX_REQUIRE(dtype == FDX_F32 || dtype == FDX_F64, "fdx_column_sums_dev: dtype must be FDX_F32 or FDX_F64");
     FDX_REQUIRE(n >= 0 && G > 0 && sums_out_host && (n == 0 || Y_dev), "fdx_column_sums_dev: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     DevBuf dPart, dOut;
     FDX_TRY(dPart.alloc((size_t)column_sums_parts(n) * G * sizeof(double)));
     FDX_TRY(dOut.alloc((size_t)G * sizeof(double)));
@@ -193,6 +197,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     FDX_REQUIRE(d > 0, "fdx_fit_dev: sketch_dim must be positive");
     FDX_REQUIRE(prm->max_iter >= 0, "fdx_fit_dev: max_iter must be non-negative");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     StageTimer tm(st);
     tm.mark();  // 0
 
@@ -475,6 +480,7 @@ static int csr_view_ok(const fdx_csr_view* Y, const char* who) {
 extern "C" int fdx_csr_check_dev(const fdx_csr_view* Y, void* stream) {
     FDX_TRY(csr_view_ok(Y, "fdx_csr_check_dev"));
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     DevBuf flag;
     FDX_TRY(flag.alloc(sizeof(int)));
     FDX_TRY(launch_csr_check((const long long*)Y->indptr, Y->indices, Y->n, Y->nnz, Y->G, Y->sorted_rows, flag.as<int>(), st));
@@ -491,6 +497,7 @@ extern "C" int fdx_csr_gene_moments_dev(const fdx_csr_view* Y, double* mean_out_
     FDX_TRY(csr_view_ok(Y, "fdx_csr_gene_moments_dev"));
     FDX_REQUIRE(Y->n > 0, "fdx_csr_gene_moments_dev: empty matrix");
     hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
     const size_t G = (size_t)Y->G;
     DevBuf scale, part, out, cursor;
     const int ns = colsum_out_host ? 3 : 2;

@@ -219,7 +219,6 @@ size_t fused_lds_bytes(int G, int d, int K) {
 bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan,
                               hipStream_t st) {
     if (getenv("FDX_NO_FUSED")) return false;
-    if (rowreg_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st)) return true;
     if (tile_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st)) return true;
     // History: an 8-wave version (two rows per wave, 120 KB of LDS) lost to the two-kernel path (3.8 vs 3.5 ms): all waves
     // move through scatter / barrier / MFMA / reduce together, so HBM idled outside the scatter phase and two waves per SIMD
@@ -287,8 +286,6 @@ int launch_sketch_contract(const void* Y, int dtype, long long ldy, const int* r
                            const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
                            hipStream_t st) {
     if (n <= 0) return 0;
-    if (rowreg_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st))
-        return launch_rowreg_sketch(Y, ldy, row_map, n, G, d, mode, plan, Xs, K, H, ldh, row_sumsq, st);
     if (tile_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st))
         return launch_tile_sketch(Y, dtype, ldy, row_map, n, G, d, mode, plan, Xs, K, H, ldh, row_sumsq, st);
     if ((reinterpret_cast<uintptr_t>(Xs) & 31) != 0) return fail(FDX_ERR_INVALID, "fused sketch: X_sketch must be 32-byte aligned");

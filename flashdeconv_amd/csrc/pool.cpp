@@ -11,8 +11,16 @@ namespace fdx {
 
 namespace {
 std::mutex g_mu;
-std::map<std::pair<int, size_t>, std::vector<void*>> g_free;   // (device, capacity) -> cached blocks
-std::map<void*, std::pair<int, size_t>> g_live;                 // block -> (device, capacity)
+// A cached block remembers the stream its last owner queued work on (the stream of the entry point that allocated it,
+// PoolStream below).  Handing it to work on the SAME stream needs nothing - stream order puts the new user behind the old
+// one.  Handing it to ANOTHER stream makes that stream wait for everything queued on the old one so far (an event recorded
+// there at that moment: later than the free, so conservative, and free of charge on the common same-stream path).
+struct Cached { void* p; hipStream_t last; };
+struct Live { int dev; size_t cap; hipStream_t stream; };
+std::map<std::pair<int, size_t>, std::vector<Cached>> g_free;   // (device, capacity) -> cached blocks
+std::map<void*, Live> g_live;                                   // block -> owner
+thread_local hipStream_t t_stream = nullptr;                    // stream of the entry point running on this thread
+const hipStream_t kIdleStream = reinterpret_cast<hipStream_t>(~(uintptr_t)0);   // owner's work known complete: anyone may follow
 
 size_t capacity_class(size_t n) {
     if (n <= (1u << 20)) {                 // small: next power of two, at least 256 B
@@ -23,20 +31,48 @@ size_t capacity_class(size_t n) {
     const size_t gran = n <= (64u << 20) ? (1u << 20) : (16u << 20);   // large: 1 MiB / 16 MiB granules
     return (n + gran - 1) / gran * gran;
 }
+
+// `to` waits for the work queued on `from` up to now; the device is drained instead when `from` cannot take an event any
+// more (a caller's stream that has been destroyed since)
+void order_after(hipStream_t from, hipStream_t to) {
+    thread_local hipEvent_t ev[64] = {};
+    int dev = 0;
+    bool ok = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (ok && !ev[dev]) ok = hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) == hipSuccess;
+    if (ok) ok = hipEventRecord(ev[dev], from) == hipSuccess && hipStreamWaitEvent(to, ev[dev], 0) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+    }
+}
 }  // namespace
+
+hipStream_t pool_set_stream(hipStream_t s) {
+    const hipStream_t prev = t_stream;
+    t_stream = s;
+    return prev;
+}
 
 int pool_alloc(size_t bytes, void** p, size_t* cap) {
     int dev = 0;
     FDX_HIP(hipGetDevice(&dev));
     const size_t c = capacity_class(bytes);
+    const hipStream_t mine = t_stream;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
+        std::unique_lock<std::mutex> lk(g_mu);
         auto it = g_free.find({dev, c});
         if (it != g_free.end() && !it->second.empty()) {
-            *p = it->second.back();
-            it->second.pop_back();
+            std::vector<Cached>& v = it->second;
+            size_t pick = v.size() - 1;
+            for (size_t i = v.size(); i-- > 0;)                  // a block last used on this stream (or known idle), if there is one
+                if (v[i].last == mine || v[i].last == kIdleStream) { pick = i; break; }
+            const Cached b = v[pick];
+            v.erase(v.begin() + (long)pick);
+            *p = b.p;
             *cap = c;
-            g_live[*p] = {dev, c};
+            g_live[*p] = Live{dev, c, mine};
+            lk.unlock();
+            if (b.last != mine && b.last != kIdleStream && !getenv("FDX_POOL_NO_ORDER")) order_after(b.last, mine);
             return 0;
         }
     }
@@ -52,8 +88,15 @@ int pool_alloc(size_t bytes, void** p, size_t* cap) {
     }
     *cap = c;
     std::lock_guard<std::mutex> lk(g_mu);
-    g_live[*p] = {dev, c};
+    g_live[*p] = Live{dev, c, mine};
     return 0;
+}
+
+void pool_mark_idle(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_live.find(p);
+    if (it != g_live.end()) it->second.stream = kIdleStream;
 }
 
 void pool_free(void* p, size_t /*cap*/) {
@@ -61,7 +104,7 @@ void pool_free(void* p, size_t /*cap*/) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_live.find(p);
     if (it == g_live.end()) return;    // not ours (or already returned)
-    g_free[it->second].push_back(p);
+    g_free[{it->second.dev, it->second.cap}].push_back(Cached{p, it->second.stream});
     g_live.erase(it);
 }
 
@@ -109,7 +152,7 @@ void* pinned_scratch(int slot, size_t bytes) {
 void pool_trim() {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& kv : g_free) {
-        for (void* q : kv.second) (void)hipFree(q);
+        for (const Cached& q : kv.second) (void)hipFree(q.p);      // hipFree waits for the device: nothing is in flight after it
         kv.second.clear();
     }
 }

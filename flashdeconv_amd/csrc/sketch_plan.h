@@ -10,7 +10,6 @@
 namespace fdx {
 
 struct TilePlanDevice;   // tile_kernels.cpp
-struct RowregPlanDevice; // rowreg_kernels.cpp
 
 struct SketchPlan {
     int G = 0, d = 0;
@@ -27,8 +26,6 @@ struct SketchPlan {
     static constexpr int kTileKeys = 28;     // (input type, raw / log, type tiles, wave split) + the wide form (input type, raw / log)
     mutable std::shared_ptr<TilePlanDevice> tile[kTileKeys];
     mutable bool tile_tried[kTileKeys] = {};
-    mutable std::shared_ptr<RowregPlanDevice> rowreg;   // schedule of the row-register kernel, built on first use
-    mutable bool rowreg_tried = false;
     mutable std::mutex tile_mu;              // plans are shared through the cache: schedules are built under this lock
     SketchPlanDev dev() const {
         SketchPlanDev p;

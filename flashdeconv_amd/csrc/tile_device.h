@@ -1,4 +1,4 @@
-// Device helpers shared by the tile kernel (tile_kernels.cpp) and the row-register kernel (rowreg_kernels.cpp).
+// Device helpers of the tile kernel (tile_kernels.cpp).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -92,6 +92,28 @@ __device__ __forceinline__ double tile_log1p_scaled(double y, double scale_s, fl
     const double xs = y * scale_s;
     return tile_log1p_core(xs, (float)xs + FDX_LOG_DOWN_F, lc);
 }
+// float32 input: the reference itself evaluates log1p(Y / rowsum * 1e4) in float32 there (numpy dtype rules, core/deconv.py:
+// 190-191), so a float32-class transform is all the path has to deliver - 7 vector instructions instead of ~20 f64 ones.
+//   u = fl(1 + x);  log1p(x) = log(u) + log(1 + d / u),  d = x - (u - 1) exactly the rounding error of u (both
+//   subtractions are exact);  log(u) = ln2 * v_log_f32(u) (1 ulp);  d / u to first order with 1 / u ~ the float whose bits
+//   are 0x7F000000 - bits(u): exact at the powers of two - in particular at u = 1, where the term IS the result
+//   (x < 2^-24) -, at most 12.5 % too large in between, on a term that is at most 2^-24 of u.
+// Without the d term the error is 2^-24 ABSOLUTE, i.e. unbounded relative to log1p(x) ~ x for small x; with it the result
+// is within ~3 ulp of float32 everywhere on [0, 32000).  CORR = false drops the term (measurement only).
+template <bool CORR> __device__ __forceinline__ float tile_log1p_f32(float y, float s) {
+#pragma clang fp contract(off)
+    const float x = y * s;
+    const float u = x + 1.0f;
+    const float l = __builtin_amdgcn_logf(u);                      // v_log_f32: log2(u), u >= 1
+    float res = l * 0.693147180559945309f;
+    if (CORR) {
+        const float d = x - (u - 1.0f);
+        const float g = __uint_as_float(0x7F000000u - __float_as_uint(u));   // ~ 1 / u
+        res = __builtin_fmaf(d, g, res);
+    }
+    return res;
+}
+
 // Anything outside the fast range (negative, NaN, huge) takes the library function, as the reference would.  Kept out of
 // line: inlined into every gather loop it costs registers on the path that matters.
 static __device__ __attribute__((noinline)) double tile_log1p_slow(double x) { return log1p(x); }
@@ -99,6 +121,9 @@ __device__ __forceinline__ double tile_log1p(double x, const LogConsts& lc) {
     if (__builtin_expect(!(x >= 0.0) || !(x < 32000.0), 0)) return tile_log1p_slow(x);
     return tile_log1p_fast(x, lc);
 }
+
+// any argument, without the table (the general path of the float32 kernels): device_math.h's fdlibm-style log1p
+static __device__ __attribute__((noinline)) double tile_log1p_any(double x) { return fast_log1p(x); }
 
 // the same with the library function inlined (no call: a call site makes the caller spill its live registers around it)
 __device__ __forceinline__ double tile_log1p_general(double x, const LogConsts& lc) {

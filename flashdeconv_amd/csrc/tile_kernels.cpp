@@ -68,18 +68,19 @@ __host__ __device__ constexpr int JW_PAD(int jw) { return (jw + 7) & ~7; }
 // wave's slice of X_sketch does not stay in registers as MFMA A operands (JW x TT of them would not fit beside the bucket
 // sums) - each group's TT operands are fetched from a copy of X_sketch laid out in operand order (tile_xa_kernel; it
 // stays in L2) when the group's gather starts, and have landed when its sums are final.
-template <typename T, int MODE, int NWC, int NWL, int JW, int TT, bool AVL2>
+// LOGV (float32 input, log modes): 0 = the float64 table chain, 1 / 2 = float32-class log1p without / with the correction of
+// the rounding of 1 + x (tile_device.h: tile_log1p_f32).
+// ABL: timing-only ablations (FDX_TILE_ABL; wrong results for 1 and 3): 1 = no row sums after the first tile, 2 = MFMAs
+// interleaved with the last block's gather as in raw mode, 3 = no operand fetches.
+template <typename T, int MODE, int NWC, int NWL, int JW, int TT, bool AVL2, int LOGV = 0, int ABL = 0>
 __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch_kernel(
     const TileArgs a, const T* __restrict__ Yp, const int* __restrict__ row_map, const double* __restrict__ Xs,
     double* __restrict__ H, double* __restrict__ row_sumsq, const double* __restrict__ w_tab,
     const unsigned short* __restrict__ off_tab, const unsigned char* __restrict__ len_tab,
     const int* __restrict__ ent_base, const int* __restrict__ slot_bucket, const double* __restrict__ log_tab,
-    const int* __restrict__ tile_list, const int* __restrict__ tile_count, const double* __restrict__ XA) {
+    const double* __restrict__ XA) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename TileVec<T>::type V;
-    // list mode (tile_list != NULL): only the *tile_count tiles listed are worked on - the tiles the row-register kernel
-    // (rowreg_kernels.cpp) leaves to this kernel's general log1p; usually none, so look before copying any table
-    if (tile_list && (long long)blockIdx.x >= (long long)*tile_count) return;
     constexpr int PER = 16 / sizeof(T);
     constexpr int NT = (NWC + NWL) * 64;
     constexpr int NWS = NWL > 0 ? NWL : NWC;                                // waves that stage
@@ -105,12 +106,12 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         w_l[i] = w_tab[i];
         off_l[i] = off_tab[i];
     }
-    if (MODE != FDX_PRE_RAW)
+    constexpr bool F32LOG = LOGV != 0 && sizeof(T) == 4 && MODE != FDX_PRE_RAW;   // float32-class log1p: no table, no float64 chain
+    if (MODE != FDX_PRE_RAW && !F32LOG)
         for (int i = tid; i < LOG_TAB_N; i += NT) logt[i] = log_tab[i];
-    const long long n_tiles = tile_list ? (long long)*tile_count : (a.n + TILE_ROWS - 1) / TILE_ROWS;
-    long long tile = blockIdx.x;                                            // position in the list, or the tile itself
+    const long long n_tiles = (a.n + TILE_ROWS - 1) / TILE_ROWS;
+    long long tile = blockIdx.x;
     if (tile >= n_tiles) return;
-    auto tile_id = [&](long long t) -> long long { return tile_list ? (long long)tile_list[t] : t; };
 
     // ---- staging (loader waves, or every wave when NWL = 0): wave lw stages rows lw, lw + NWS, ...
     const int lw = NWL > 0 ? wave - NWC : wave;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             const int rr = lw + NWS * k;
             rp[k] = nullptr;
             if (rr >= TILE_ROWS || t >= n_tiles) continue;
-            const long long sp = tile_id(t) * TILE_ROWS + rr;
+            const long long sp = t * TILE_ROWS + rr;
             if (sp < a.n) {
                 const long long row = row_map ? (long long)row_map[sp] : sp;
                 rp[k] = Yp + (size_t)row * (size_t)a.ldy;
@@ -182,13 +183,14 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         }
         const double sum0 = wave_sum(p0);
         const double s0 = tile_row_scale<MODE>(sum0);
-        const bool ok0 = fabs(sum0) <= 1e18 && !__any((long long)sg0 < 0);           // false for a NaN / Inf sum; above 1e18 the
-                                                                                  // scale * 2^-65 would leave the float range
+        // false for a NaN / Inf sum; above 1e18 the scale * 2^-65 would leave the float range, below 1e-30 the scale itself
+        auto sum_ok = [](double s) { return fabs(s) <= 1e18 && (s == 0.0 || fabs(s) >= 1e-30); };
+        const bool ok0 = sum_ok(sum0) && !__any((long long)sg0 < 0);
         if (lane == 0 && r0) { out_scale[i0] = s0; out_ok[i0] = ok0 ? 1 : 0; }
         if (TWO && r1) {
             const double sum1 = wave_sum(p1);
             const double s1 = tile_row_scale<MODE>(sum1);
-            const bool ok1 = fabs(sum1) <= 1e18 && !__any((long long)sg1 < 0);
+            const bool ok1 = sum_ok(sum1) && !__any((long long)sg1 < 0);
             if (lane == 0) { out_scale[i1] = s1; out_ok[i1] = ok1 ? 1 : 0; }
         }
     };
@@ -219,7 +221,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     // the sums read the rows from HBM, the DMA of the next tile re-reads them 0 - 1 tile periods later, and the closer the
     // two reads the more of the second one the XCD's 4 MB L2 still holds (32 CUs x 128 KB of rows per tile period).
     auto sums_step = [&](int c, int par) {
-        if (MODE != FDX_PRE_RAW && has_next) scale_rows(rown, a.NBLK - 1 - c, a.NBLK, par ^ 1);
+        if (MODE != FDX_PRE_RAW && has_next && ABL != 1) scale_rows(rown, a.NBLK - 1 - c, a.NBLK, par ^ 1);
     };
     if (NWL == 0 || wave >= NWC) {
         load_rows(tile, rowp);
@@ -272,7 +274,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         }
     }
     if (NWL > 0) __builtin_amdgcn_s_waitcnt(0x0f70);
-    const LogConsts lc = log_consts();
+    LogConsts lc{};
+    if constexpr (!F32LOG) lc = log_consts();
     int buf = 0, par = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
         if (AVL2) asm volatile("" : "+v"(lane8));                           // the operand addresses are formed where they are used
@@ -290,6 +293,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         double scale = 1.0;
         double scale_s = FDX_LOG_DOWN;                                      // scale * 2^-65 (tile_device.h)
         float scale_sf = FDX_LOG_DOWN_F;
+        float scale_f = 1.0f;
         bool fast = true;
         // One column block: software pipeline over the flat entry stream - weight and value of the current step in
         // registers, the offset of the step after next already fetched, so a step costs one LDS round trip, not two.
@@ -308,8 +312,13 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             unsigned offn = off_l[p + 4];
             auto f = [&](T yy) -> double {
                 if (MODE == FDX_PRE_RAW) return (double)yy;
-                if (FAST) return tile_log1p_scaled(yy, scale_s, scale_sf, lc);
-                return tile_log1p((double)yy * scale, lc);
+                if constexpr (F32LOG) {
+                    if (FAST) return (double)tile_log1p_f32<LOGV == 2>((float)yy, scale_f);
+                    return tile_log1p_any((double)yy * scale);
+                } else {
+                    if (FAST) return tile_log1p_scaled(yy, scale_s, scale_sf, lc);
+                    return tile_log1p((double)yy * scale, lc);
+                }
             };
 #pragma unroll
             for (int j = 0; j < JW; ++j) {
@@ -318,7 +327,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 if (LAST && AVL2) {
                     __builtin_amdgcn_sched_barrier(0);                       // the operand loads of later groups stay with their groups
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) an[t] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
+                    for (int t = 0; t < TT; ++t) an[t] = ABL == 3 ? 1.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
                 }
                 int t = 0;
                 for (; t + 2 <= len; t += 2) {                            // two steps per trip: the register sets swap roles
@@ -355,8 +364,12 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             if (NWL == 0) stage_step(c, buf, par);
             if (MODE != FDX_PRE_RAW && c == 0) {
                 scale = scales[par * TILE_ROWS + r];
-                scale_s = scale * FDX_LOG_DOWN;
-                scale_sf = (float)scale_s;
+                if constexpr (F32LOG) {
+                    scale_f = (float)scale;
+                } else {
+                    scale_s = scale * FDX_LOG_DOWN;
+                    scale_sf = (float)scale_s;
+                }
                 fast = __all(rowok[par * TILE_ROWS + r] != 0);
             }
             if (MODE == FDX_PRE_RAW || fast) consume(c, last_tag, std::true_type{});
@@ -366,7 +379,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         };
         // raw: MFMAs interleaved with the last block's gather.  Log modes: afterwards - the gather is bound by the vector ALU
         // there, and the 16 accumulator registers held through it would spill.
-        constexpr bool INTERLEAVE = MODE == FDX_PRE_RAW;
+        constexpr bool INTERLEAVE = MODE == FDX_PRE_RAW || ABL == 2;
         for (int c = 0; c + 1 < a.NBLK; ++c) block(c, std::false_type{});
         block(a.NBLK - 1, std::integral_constant<bool, INTERLEAVE>{});
         if (!INTERLEAVE) {
@@ -376,7 +389,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 if (AVL2) {
                     if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);    // at most four groups' operands in flight
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) an[t] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
+                    for (int t = 0; t < TT; ++t) an[t] = ABL == 3 ? 1.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
                 }
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
@@ -393,7 +406,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         // TH type tiles per round (the area must fit a stage buffer)
         double* red = reinterpret_cast<double*>(smem + (size_t)(buf ^ 1) * stage_bytes);   // [NR][TS] + [NR][64]
         double* red_sq = red + (size_t)NR * TS;
-        const long long s0 = tile_id(tile) * TILE_ROWS;
+        const long long s0 = tile * TILE_ROWS;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             lds_barrier();                                                  // the last block's buffer / the previous round's sums are free
@@ -602,10 +615,13 @@ struct TileLaunch {
     const int* ent_base;
     const int* slot_bucket;
     const double* log_tab;
-    const int* tile_list;
-    const int* tile_count;
     const double* XA;
 };
+
+static int tile_logv() {
+    const char* e = getenv("FDX_TILE_LOGV");
+    return e ? atoi(e) : 2;
+}
 
 template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hipStream_t st) {
@@ -617,11 +633,30 @@ static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hip
     if constexpr (MODE != FDX_PRE_RAW && NWC == 16) {
         if (L.XA)
             kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true>;
+        if constexpr (std::is_same<T, float>::value) {
+            // float32 rows: float32-class log1p (tile_device.h); FDX_TILE_LOGV=0 goes back to the float64 chain
+            const int logv = tile_logv();
+            if (logv == 2)
+                kern = L.XA ? (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true, 2> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2>)
+                            : (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 2> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 2>);
+            if (const char* e = getenv("FDX_TILE_ABL")) {
+                if constexpr (MODE == FDX_PRE_LOG_CPM) {
+                    if (L.XA && TT == 2 && logv == 2) {
+                        const int abl = atoi(e);
+                        if (abl == 1) kern = (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2, 1>;
+                        if (abl == 2) kern = (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2, 2>;
+                        if (abl == 3) kern = (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2, 3>;
+                    }
+                }
+            } else if (logv == 1)
+                kern = L.XA ? (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true, 1> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 1>)
+                            : (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 1> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 1>);
+        }
     }
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
                     (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab,
-                    (void*)&L.tile_list, (void*)&L.tile_count, (void*)&L.XA};
+                    (void*)&L.XA};
     FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3((NWC + NWL) * 64), args, lds, st));
     return 0;
 }
@@ -629,10 +664,13 @@ static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hip
 template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_wide(const TileLaunch& L, size_t lds, int grid, hipStream_t st) {
     const void* kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true>;
+    if constexpr (MODE != FDX_PRE_RAW && std::is_same<T, float>::value) {
+        if (tile_logv() != 0) kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true, 2>;
+    }
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
                     (void*)&L.off_tab, (void*)&L.len_tab, (void*)&L.ent_base, (void*)&L.slot_bucket, (void*)&L.log_tab,
-                    (void*)&L.tile_list, (void*)&L.tile_count, (void*)&L.XA};
+                    (void*)&L.XA};
     FDX_HIP(hipLaunchKernel(kern, dim3(grid), dim3((NWC + NWL) * 64), args, lds, st));
     return 0;
 }
@@ -662,7 +700,7 @@ static int launch_tile_mode(const TileLaunch& L, int mode, int NWC, int TT, size
 // Call only when tile_sketch_ok(...) holds.
 int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
-                       hipStream_t st, const int* tile_list, const int* tile_count) {
+                       hipStream_t st) {
     if (n <= 0) return 0;
     const TilePlanDevice* t = plan.owner ? tile_plan_for(*plan.owner, dtype, mode, K, st) : nullptr;
     if (!t) return fail(FDX_ERR_INVALID, "tile sketch: no schedule for this shape");
@@ -674,7 +712,6 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     L.w_tab = t->w.as<double>(); L.off_tab = t->off.as<unsigned short>(); L.len_tab = t->len.as<unsigned char>();
     L.ent_base = t->ent_base.as<int>(); L.slot_bucket = t->slot_bucket.as<int>();
     L.log_tab = nullptr;
-    L.tile_list = tile_list; L.tile_count = tile_list ? tile_count : nullptr;
     if (mode != FDX_PRE_RAW) {
         L.log_tab = log_table_dev(st);
         if (!L.log_tab) return fail(FDX_ERR_HIP, "tile sketch: log table upload failed");
@@ -683,7 +720,11 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     const int grid = (int)std::min<long long>(n_tiles, 256);
     DevBuf xa;                                                              // wide form: X_sketch in operand order
     L.XA = nullptr;
-    if (t->wide || (mode != FDX_PRE_RAW && t->NWC == 16 && !getenv("FDX_TILE_NO_AVL2"))) {
+    // narrow log modes: the float64 chain needs the registers the operands would take (operand copy in L2, fetched per
+    // group); the float32-class chain leaves room for them (127 registers, no spills; the fetches cost 0.5 ms per 1M spots)
+    const bool f32log = dtype == FDX_F32 && mode != FDX_PRE_RAW && tile_logv() != 0;
+    const bool narrow_avl2 = mode != FDX_PRE_RAW && t->NWC == 16 && (f32log ? getenv("FDX_TILE_AVL2") != nullptr : !getenv("FDX_TILE_NO_AVL2"));
+    if (t->wide || narrow_avl2) {
         const int n_groups = t->NWC * t->JW;
         FDX_TRY(xa.alloc((size_t)n_groups * t->TT * 64 * sizeof(double)));
         hipLaunchKernelGGL(tile_xa_kernel, dim3(ceil_div((long long)n_groups * t->TT * 64, 256)), dim3(256), 0, st, Xs,
@@ -696,6 +737,29 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
 }
 
 }  // namespace fdx
+
+// include/fdx.h: the float32-class log1p of the tile kernel on a host array (accuracy tests)
+namespace fdx {
+__global__ void log1p_f32_probe_kernel(const float* __restrict__ y, float scale, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = tile_log1p_f32<true>(y[i], scale);
+}
+}  // namespace fdx
+
+extern "C" int fdx_log1p_f32(const float* y, float scale, int64_t n, float* out) {
+    using namespace fdx;
+    FDX_REQUIRE(n >= 0 && (n == 0 || (y && out)), "fdx_log1p_f32: null argument");
+    if (n == 0) return 0;
+    DevBuf in, res;
+    FDX_TRY(in.alloc((size_t)n * 4));
+    FDX_TRY(res.alloc((size_t)n * 4));
+    FDX_HIP(hipMemcpy(in.p, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(log1p_f32_probe_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, nullptr, in.as<float>(), scale,
+                       (long long)n, res.as<float>());
+    FDX_CHECK_LAUNCH();
+    FDX_HIP(hipMemcpy(out, res.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 // include/fdx.h: the schedule the tile kernel would use, so tests can replay it on the host (no device call).
 extern "C" int fdx_tile_schedule(const int32_t* gene_bucket, const double* gene_w, int32_t G, int32_t d, int32_t NW,

@@ -140,72 +140,4 @@ bool build_tile_plan(const int* gene_bucket, const double* gene_w, int G, int d,
     return true;
 }
 
-bool build_rowreg_plan(const int* gene_bucket, const double* gene_w, int G, int d, int NW, int JW, RowregPlanHost* out) {
-    constexpr int GB = RowregPlanHost::kBlockGenes;
-    if (JW > 16) return false;
-    TilePlanHost tp;
-    if (!build_tile_plan(gene_bucket, gene_w, G, d, NW, JW, GB, &tp)) return false;
-    RowregPlanHost& p = *out;
-    p = RowregPlanHost();
-    p.G = G; p.d = d; p.NW = NW; p.JW = JW; p.NBLK = tp.NBLK; p.steps = tp.steps;
-    p.slot_bucket = tp.slot_bucket;
-    const int NBLK = tp.NBLK;
-    // first step of every wave in every block's slot image
-    std::vector<int> base((size_t)NBLK * NW, 0), wsteps((size_t)NBLK * NW, 0);
-    for (int c = 0; c < NBLK; ++c) {
-        int s = 0;
-        for (int w = 0; w < NW; ++w) {
-            int n = 0;
-            for (int j = 0; j < JW; ++j) n += tp.len[((size_t)w * NBLK + c) * JW + j];
-            base[(size_t)c * NW + w] = s;
-            wsteps[(size_t)c * NW + w] = n;
-            s += n;
-        }
-        p.Smax = std::max(p.Smax, s);
-    }
-    const unsigned dump = (unsigned)p.Smax * 512u;
-    p.gene_w.assign((size_t)NBLK * GB, 0.0);
-    p.gene_ent.assign((size_t)NBLK * GB, dump);
-    p.blk_tab.assign((size_t)NBLK * NW * 8, 0);
-    p.pad_line.clear();
-    for (int c = 0; c < NBLK; ++c) {
-        std::vector<unsigned> pads;
-        for (int w = 0; w < NW; ++w) {
-            int e = tp.ent_base[(size_t)w * (NBLK + 1) + c];
-            int s = base[(size_t)c * NW + w];
-            for (int j = 0; j < JW; ++j) {
-                const int L = tp.len[((size_t)w * NBLK + c) * JW + j];
-                for (int t = 0; t < L; ++t, ++s)
-                    for (int q = 0; q < 4; ++q, ++e) {
-                        const unsigned line = (unsigned)s * 512u + (unsigned)q * 128u;
-                        const int g = tp.gene[(size_t)e];
-                        if (g < 0) { pads.push_back(line); continue; }
-                        if (g / GB != c) return false;
-                        p.gene_w[(size_t)g] = tp.w[(size_t)e];
-                        p.gene_ent[(size_t)g] = line + 8u * (unsigned)((4 * (j & 3) + q) & 15);
-                    }
-            }
-            if (e != tp.ent_base[(size_t)w * (NBLK + 1) + c + 1]) return false;
-        }
-        // the pad lines of the block, dealt to the waves in rounds of 4 lines (one store instruction zeroes 4 lines x 16 rows)
-        const int rounds = ((int)pads.size() + 4 * NW - 1) / (4 * NW);
-        pads.resize((size_t)rounds * 4 * NW, dump);
-        for (int w = 0; w < NW; ++w) {
-            int* bt = &p.blk_tab[((size_t)c * NW + w) * 8];
-            bt[0] = base[(size_t)c * NW + w] * 512;
-            bt[1] = (int)p.pad_line.size() + w * rounds * 4;
-            bt[2] = rounds;
-            bt[3] = wsteps[(size_t)c * NW + w];
-            unsigned char lens[16] = {};
-            for (int j = 0; j < JW; ++j) lens[j] = tp.len[((size_t)w * NBLK + c) * JW + j];
-            for (int k = 0; k < 4; ++k)
-                bt[4 + k] = (int)((unsigned)lens[4 * k] | ((unsigned)lens[4 * k + 1] << 8) | ((unsigned)lens[4 * k + 2] << 16) |
-                                  ((unsigned)lens[4 * k + 3] << 24));
-        }
-        p.pad_line.insert(p.pad_line.end(), pads.begin(), pads.end());
-    }
-    if (p.pad_line.empty()) p.pad_line.push_back(dump);
-    return true;
-}
-
 }  // namespace fdx

@@ -29,27 +29,5 @@ struct TilePlanHost {
 // may be shorter).  Returns false when the shape cannot be scheduled (more than 4*NW*JW buckets, a group longer than 255).
 bool build_tile_plan(const int* gene_bucket, const double* gene_w, int G, int d, int NW, int JW, int GB, TilePlanHost* out);
 
-// Schedule of the row-register kernel (rowreg_kernels.cpp; log modes, float32 rows of up to 2048 genes).  The same bucket
-// groups and lockstep lengths as the tile kernel's, with column blocks of 256 genes (one 16-byte vector per lane), but
-// seen from the PRODUCER: the wave that holds a row in registers transforms it and stores weight * log1p(..) of gene g
-// where the consumer lane will read it - the "slot image" of a block: step s of the block (waves, groups, steps in that
-// order) is 4 lines of 128 bytes (q = 0..3), and row r of line (s, q) of group j sits at 8-byte position
-// (r + 4 (j & 3) + q) mod 16 of the line (bank spreading for the producers' scattered stores; the consumers read whole
-// lines).  Lines without a gene ("pad lines", the lockstep padding) are zeroed by the producers every block.
-struct RowregPlanHost {
-    static constexpr int kBlockGenes = 256;
-    int G = 0, d = 0, NW = 0, JW = 0, NBLK = 0;
-    int Smax = 0;                            // steps of the largest block: a slot image is Smax * 512 bytes + one dump line
-    int steps = 0;                           // all blocks
-    std::vector<int> slot_bucket;            // (NW, JW, 4)
-    // (NBLK, NW, 8) ints: [0] byte offset of the wave's first step in the block's slot image, [1] first entry of the wave's
-    // share of the pad list, [2] rounds of 4 pad lines in that share, [3] steps of the wave in the block, [4..7] the JW <= 16
-    // group lengths, one byte each
-    std::vector<int> blk_tab;
-    std::vector<double> gene_w;              // (NBLK * 256): Omega weight, 0 for genes outside Omega and past G
-    std::vector<unsigned> gene_ent;          // (NBLK * 256): byte offset of the gene's line in the slot image + 8 * position of row 0
-    std::vector<unsigned> pad_line;          // byte offsets of the pad lines, per block and wave share, padded with the dump line
-};
-bool build_rowreg_plan(const int* gene_bucket, const double* gene_w, int G, int d, int NW, int JW, RowregPlanHost* out);
 
 }  // namespace fdx

@@ -75,15 +75,11 @@ int fdx_sketch(const void* Y, int32_t dtype, int64_t n, int32_t G, const int64_t
 int fdx_tile_schedule(const int32_t* gene_bucket, const double* gene_w, int32_t G, int32_t d, int32_t NW, int32_t JW,
                       int32_t GB, int32_t* dims_out, int32_t* slot_bucket_out, uint8_t* len_out, int32_t* ent_base_out,
                       double* w_out, uint16_t* off_out, int64_t cap_entries);
-/* Host-only inspection of the schedule of the row-register kernel (csrc/rowreg_kernels.cpp; the log-CPM preprocess of
- * core/deconv.py:177-197 fused with the CountSketch of core/sketching.py:160-206 for float32 rows of up to 2048 genes):
- * the same bucket groups as fdx_tile_schedule with 8 waves x 16 groups and column blocks of 256 genes, expressed as the
- * "slot image" the producers write and the consumers read.  dims_out[4] = {blocks, steps of the largest block, steps,
- * pad-list entries}; with slot_bucket_out non-NULL the tables are returned: slot_bucket (8*16*4), blk_tab (blocks*8*8),
- * gene_w / gene_ent (blocks*256), pad_line (cap_pad = its capacity).  No device call is made. */
-int fdx_rowreg_schedule(const int32_t* gene_bucket, const double* gene_w, int32_t G, int32_t d, int32_t* dims_out,
-                        int32_t* slot_bucket_out, int32_t* blk_tab_out, double* gene_w_out, uint32_t* gene_ent_out,
-                        uint32_t* pad_line_out, int64_t cap_pad);
+/* out[i] = log1p(y[i] * scale) exactly as the fused sketch kernel evaluates the log-CPM transform (core/deconv.py:190-191)
+ * for FLOAT32 rows with every argument in [0, 32000): float32-class (the reference computes this step in float32 for
+ * float32 input, numpy dtype rules), v_log_f32 plus a first-order correction of the rounding of 1 + x.  Host arrays;
+ * accuracy tests call this, nothing else does. */
+int fdx_log1p_f32(const float* y, float scale, int64_t n, float* out);
 /* Per-gene column sums of a host (n, G) matrix (pearson's mean: core/deconv.py:207-214). */
 int fdx_column_sums(const void* Y, int32_t dtype, int64_t n, int32_t G, double* sums_out);
 

@@ -150,6 +150,48 @@ def test_csr_gene_moments_and_validation():
         _lib.CsrOnDevice.from_scipy(bad)
 
 
+def test_csr_structure_check_is_cached_per_tensor_object_only():
+    """The cached verdict of fdx_csr_check_dev belongs to one live tensor object: a different CSR tensor of the same shape
+    and entry count - even one that the caching allocator places at the freed tensor's addresses - is checked itself,
+    and an in-place edit of the indices through torch invalidates the entry."""
+    import gc
+    import torch
+    from flashdeconv_amd import _lib
+    rs = np.random.RandomState(4)
+    Yd = (rs.poisson(0.4, size=(300, 400)) * (rs.rand(300, 400) < 0.3)).astype(np.float32)
+    good = torch.from_numpy(Yd).cuda().to_sparse_csr()
+    a = _lib.CsrOnDevice.from_torch(good)
+    assert id(good) in _lib.CsrOnDevice._checked
+    b = _lib.CsrOnDevice.from_torch(good)                      # second use of the same object: served from the cache
+    assert b.view.sorted_rows == a.view.sorted_rows == 1
+    crow, col, val = good.crow_indices().clone(), good.col_indices().clone(), good.values().clone()
+    addr = (good.crow_indices().data_ptr(), good.col_indices().data_ptr())
+    del a, b, good
+    gc.collect()
+    assert not _lib.CsrOnDevice._checked                       # the entry died with the tensor
+    col_bad = col.clone()
+    col_bad[7] = 400                                           # column out of range
+    bad = torch.sparse_csr_tensor(crow, col_bad, val, size=(300, 400))
+    with pytest.raises(_lib.FdxError, match="malformed"):
+        _lib.CsrOnDevice.from_torch(bad)
+    del bad, col_bad
+    # same-address reuse: allocate until the allocator hands the old index block out again (usually at once)
+    for _ in range(4):
+        c2 = col.clone()
+        if c2.data_ptr() == addr[1]:
+            break
+    c2[3] = -1
+    again = torch.sparse_csr_tensor(crow.clone(), c2, val, size=(300, 400))
+    with pytest.raises(_lib.FdxError, match="malformed"):
+        _lib.CsrOnDevice.from_torch(again)
+    # in-place edit through torch: the version counter moves, the check runs again and fails
+    ok = torch.sparse_csr_tensor(crow, col, val, size=(300, 400))
+    _lib.CsrOnDevice.from_torch(ok)
+    ok.col_indices()[11] = 4000
+    with pytest.raises(_lib.FdxError, match="malformed"):
+        _lib.CsrOnDevice.from_torch(ok)
+
+
 @pytest.mark.parametrize("pre,dtype", [("raw", np.float32), ("log_cpm", np.float32), ("log_cpm", np.float64), ("pearson", np.float32)])
 def test_fused_sketch_contraction_equals_two_kernel_path(pre, dtype, monkeypatch):
     """sketch_contract_kernel (rows -> LDS accumulators -> MFMA -> H, no Y_sketch) against the scatter-sketch + xyt_split
@@ -168,7 +210,10 @@ def test_fused_sketch_contraction_equals_two_kernel_path(pre, dtype, monkeypatch
     b = FlashDeconv(**kw).fit(Y, X, coords)
     assert a.timings_["gram_ms"] == 0.0 and b.timings_["gram_ms"] > 0.0          # the two paths really ran
     assert np.array_equal(a.beta_, a2.beta_)                                      # deterministic
-    assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < 1e-12
+    # float32 rows under log-CPM: the tile kernel evaluates a float32-class log1p (as the reference does for float32 input),
+    # the two-kernel path the float64 one - float32 rounding apart, not float64 rounding
+    tol = 1e-5 if (pre == "log_cpm" and dtype == np.float32) else 1e-12
+    assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < tol
 
 
 def test_fit_gauss_1000_config1_miniature():
@@ -381,7 +426,10 @@ def test_dense_whole_transcriptome_float64_gene_subset():
     a = FlashDeconv(**kw).fit(Y, X, coords)
     assert 600 <= len(a.gene_idx_) < G_all
     b = FlashDeconv(**dict(kw, n_hvg=len(a.gene_idx_))).fit(Y[:, a.gene_idx_], X[:, a.gene_idx_], coords)
-    assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < 1e-12
+    # float32 rows under log-CPM: the tile kernel evaluates a float32-class log1p (as the reference does for float32 input),
+    # the two-kernel path the float64 one - float32 rounding apart, not float64 rounding
+    tol = 1e-5 if (pre == "log_cpm" and dtype == np.float32) else 1e-12
+    assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < tol
 
 
 @pytest.mark.parametrize("kind", ["dense", "csr"])

@@ -251,84 +251,6 @@ def test_bench_spawns_its_own_ranks():
     assert line["RANK"] == "1" and line["WORLD_SIZE"] == "2" and line["scaling"] == "strong"
 
 
-@pytest.mark.parametrize("G,d", [(2000, 512), (2048, 512), (1000, 500), (300, 64), (40, 7), (1500, 128)])
-def test_rowreg_schedule_replays_to_the_countsketch(G, d):
-    """The row-register kernel's slot images (csrc/tile_plan.cpp: build_rowreg_plan), replayed on the host as the kernel
-    uses them: the producers store weight * f(y) of every gene of a 256-gene block at the gene's line / row position and
-    zero the pad lines, the consumers read whole lines step by step - the sums must be f(Y) @ Omega, every byte a
-    consumer reads must have been written in the same block, and no two genes may share a place."""
-    import fdx_oracle as orc
-    from flashdeconv_amd import _lib
-    lib = _lib.load()
-    NW, JW = 16, 8
-    rs = np.random.RandomState(G + d)
-    bucket, weight = orc.countsketch_omega(G, d, rs.rand(G), 3)
-    bucket = bucket.astype(np.int32)
-    if G > 50:
-        bucket[::37] = -1
-    dims = np.zeros(4, dtype=np.int32)
-    _lib.check(lib.fdx_rowreg_schedule(_lib.ptr_i32(bucket), _lib.ptr_f64(weight), G, d, _lib.ptr_i32(dims),
-                                       None, None, None, None, None, 0))
-    nblk, smax, steps, n_pad = (int(x) for x in dims)
-    assert nblk == -(-G // 256)
-    slot = np.zeros(NW * JW * 4, dtype=np.int32)
-    blk = np.zeros(nblk * NW * 8, dtype=np.int32)
-    gw = np.zeros(nblk * 256)
-    ent = np.zeros(nblk * 256, dtype=np.uint32)
-    pad = np.zeros(n_pad, dtype=np.uint32)
-    _lib.check(lib.fdx_rowreg_schedule(_lib.ptr_i32(bucket), _lib.ptr_f64(weight), G, d, _lib.ptr_i32(dims), _lib.ptr_i32(slot),
-                                       _lib.ptr_i32(blk), _lib.ptr_f64(gw), ent.ctypes.data, pad.ctypes.data, n_pad))
-    slot = slot.reshape(NW, JW, 4)
-    blk = blk.reshape(nblk, NW, 8)
-    assert np.array_equal(np.sort(slot[slot >= 0]), np.arange(d))
-    dump = smax * 512
-    y = rs.randn(16, G)                                        # 16 rows of a tile
-    sk = np.zeros((16, d))
-    for c in range(nblk):
-        image = np.full((smax * 512 + 128) // 8, np.nan)       # a fresh image per block: reads of unwritten places show up
-        written = np.zeros(image.size, dtype=int)
-        for g in range(c * 256, (c + 1) * 256):                # producers
-            e = int(ent[g])
-            line, sigma = e & ~127, (e & 127) // 8
-            if g >= G or bucket[g] < 0:
-                assert line == dump and gw[g] == 0.0
-                continue
-            assert gw[g] == weight[g] and line < dump
-            for r in range(16):
-                at = (line + ((r + sigma) & 15) * 8) // 8
-                image[at] = gw[g] * y[r, g]
-                written[at] += 1
-        for wv in range(NW):                                   # ... and their shares of the pad lines
-            p0, rounds = int(blk[c, wv, 1]), int(blk[c, wv, 2])
-            for ln in pad[p0:p0 + 4 * rounds]:
-                if int(ln) == dump:
-                    continue
-                for r in range(16):
-                    image[(int(ln) + r * 8) // 8] = 0.0
-                    written[(int(ln) + r * 8) // 8] += 1
-        assert written.max() <= 1
-        for wv in range(NW):                                   # consumers
-            p = int(blk[c, wv, 0])
-            lens = blk[c, wv, 4:8].astype(np.uint32).view(np.uint8)
-            assert int(lens[:JW].sum()) == int(blk[c, wv, 3])
-            for j in range(JW):
-                for _ in range(int(lens[j])):
-                    for q in range(4):
-                        for r in range(16):
-                            v = image[(p + q * 128 + ((r + 4 * (j & 3) + q) & 15) * 8) // 8]
-                            assert not np.isnan(v)
-                            if slot[wv, j, q] >= 0:
-                                sk[r, slot[wv, j, q]] += v
-                            else:
-                                assert v == 0.0
-                    p += 512
-    want = np.zeros((16, d))
-    for g in range(G):
-        if bucket[g] >= 0:
-            want[:, bucket[g]] += weight[g] * y[:, g]
-    assert np.allclose(sk, want, rtol=1e-12, atol=1e-12)
-
-
 def test_schedule_builders_under_address_and_ub_sanitizers():
     """`make -C flashdeconv_amd/csrc asan-host`: the pure-host schedule builders (tile_plan.cpp) compiled with g++
     -fsanitize=address,undefined and replayed on a range of shapes (GPU AddressSanitizer is not available on the build pool)."""
