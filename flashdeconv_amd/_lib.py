@@ -220,6 +220,7 @@ def ptr_i32(a):
 
 FDX_F32, FDX_F64 = 0, 1
 PRE_RAW, PRE_LOG_CPM, PRE_LOG_CPM_SPARSE = 0, 1, 2
+PRE_F64_MATH = 0x100     # float32 storage of values the reference would transform in float64 (integer input)
 
 
 def as_device_matrix(Y):

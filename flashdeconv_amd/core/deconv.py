@@ -173,6 +173,7 @@ class FlashDeconv:
             if G_all == 0:
                 raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
             csr = None
+            y_f64_math = False
             if sparse.issparse(Y) or _lib.is_torch_sparse_csr(Y):
                 # sparse stays sparse in HBM: gene statistics, log-CPM and the sketch read the stored entries only
                 csr = _lib.CsrOnDevice.from_scipy(Y) if sparse.issparse(Y) else _lib.CsrOnDevice.from_torch(Y)
@@ -181,13 +182,20 @@ class FlashDeconv:
             elif _is_torch_cuda(Y):
                 import torch
                 if Y.dtype not in (torch.float32, torch.float64):
-                    Y = Y.to(torch.float32)
+                    # integer counts: float32 holds them exactly below 2**24 (checked, as on the host path); numpy would
+                    # promote them to float64 in the reference, so the transform keeps float64 accuracy (PRE_F64_MATH)
+                    y_f64_math = not Y.dtype.is_floating_point
+                    small = Y.dtype in (torch.uint8, torch.int8, torch.int16, torch.bool, torch.float16, torch.bfloat16)
+                    exact = small or Y.numel() == 0 or bool((Y.abs().max() < (1 << 24)).item())
+                    Y = Y.to(torch.float32 if exact else torch.float64)
                 Y = Y.contiguous()
                 y_ptr, y_code = ctypes.c_void_p(Y.data_ptr()), (_lib.FDX_F32 if Y.dtype == torch.float32 else _lib.FDX_F64)
                 y_sparse_rule = False
             else:
                 y_sparse_rule = False
-                Yh, y_code = _lib.as_device_matrix(np.asarray(Y))
+                Yh = np.asarray(Y)
+                y_f64_math = Yh.dtype.kind in "iub"
+                Yh, y_code = _lib.as_device_matrix(Yh)
                 ybuf = _DeviceBuffer.from_host(Yh)
                 owned.append(ybuf)
                 y_ptr = ybuf.ptr
@@ -281,6 +289,8 @@ class FlashDeconv:
 
             prm = _lib.FitParams()
             prm.sketch_dim = int(self.sketch_dim)
+            if y_f64_math and csr is None and y_code == _lib.FDX_F32:
+                mode_y |= _lib.PRE_F64_MATH
             prm.mode_y, prm.mode_x = mode_y, mode_x
             prm.k_neighbors = int(self.k_neighbors)
             prm.max_iter, prm.tol, prm.verbose = int(self.max_iter), float(self.tol), 1 if self.verbose else 0

@@ -143,8 +143,10 @@ int fdx_graph_send_indices_dev(const fdx_graph* local, int32_t* idx_out_dev, voi
 
 int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, int64_t ldy, const int32_t* row_map_dev,
                     const double* X, int32_t K, const int32_t* bucket, const double* weight_y, const double* weight_x,
-                    int32_t d, int32_t mode_y, int32_t mode_x, double* H_out_dev, int64_t ldh, double* XtX_out_dev,
+                    int32_t d, int32_t mode_y_in, int32_t mode_x, double* H_out_dev, int64_t ldh, double* XtX_out_dev,
                     double* XtX_out_host, double* YtY_partial_out, void* stream) {
+    const int32_t mode_y = mode_y_in & 0xff;
+    TileF64Math f64_math((mode_y_in & FDX_PRE_F64_MATH) != 0);
     FDX_REQUIRE(y_dtype == FDX_F32 || y_dtype == FDX_F64, "fdx_prepare_dev: Y dtype must be FDX_F32 or FDX_F64");
     FDX_REQUIRE(n >= 0 && G > 0 && K > 0 && d > 0, "fdx_prepare_dev: bad shape");
     FDX_REQUIRE(X && bucket && weight_y && weight_x && H_out_dev && XtX_out_dev, "fdx_prepare_dev: null array");

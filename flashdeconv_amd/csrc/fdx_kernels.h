@@ -72,6 +72,12 @@ int launch_sketch_rows(const void* Y, int dtype, long long ldy, const int* row_m
 // fused sketch + H contraction (fused_kernels.cpp)
 bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan,
                               hipStream_t st = nullptr);
+// FDX_PRE_F64_MATH of the entry point running on this thread: float32 rows keep the float64 log1p chain (tile_kernels.cpp)
+struct TileF64Math {
+    bool prev;
+    explicit TileF64Math(bool on);
+    ~TileF64Math();
+};
 // tile kernel (tile_kernels.cpp): atomic-free form of the same contraction, preferred when its schedule fits
 bool tile_sketch_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan, hipStream_t st);
 int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,

@@ -181,9 +181,13 @@ struct GeneSlotHost {   // layout of csr_kernels.cpp's GeneSlot
 
 int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t K, const int32_t* bucket,
              const double* weight_y, const double* weight_x, const double* coords_dev, int32_t dim,
-             const fdx_fit_params* prm, fdx_graph** graph_inout, double* beta_out_dev, double* prop_out_dev,
+             const fdx_fit_params* prm_in, fdx_graph** graph_inout, double* beta_out_dev, double* prop_out_dev,
              double* objectives_out, double* rel_changes_out, fdx_fit_info* info, void* stream) {
-    FDX_REQUIRE(info != nullptr && prm != nullptr && graph_inout != nullptr, "fdx_fit_dev: null argument");
+    FDX_REQUIRE(info != nullptr && prm_in != nullptr && graph_inout != nullptr, "fdx_fit_dev: null argument");
+    fdx_fit_params prm_local = *prm_in;
+    prm_local.mode_y &= 0xff;
+    const fdx_fit_params* prm = &prm_local;
+    TileF64Math f64_math((prm_in->mode_y & FDX_PRE_F64_MATH) != 0);
     std::memset(info, 0, sizeof(*info));
     const void* Y_dev = ysrc.dense;
     const int32_t y_dtype = ysrc.csr ? ysrc.csr->dtype : ysrc.dtype;

@@ -70,8 +70,9 @@ __host__ __device__ constexpr int JW_PAD(int jw) { return (jw + 7) & ~7; }
 // stays in L2) when the group's gather starts, and have landed when its sums are final.
 // LOGV (float32 input, log modes): 0 = the float64 table chain, 1 / 2 = float32-class log1p without / with the correction of
 // the rounding of 1 + x (tile_device.h: tile_log1p_f32).
-// ABL: timing-only ablations (FDX_TILE_ABL; wrong results for 1 and 3): 1 = no row sums after the first tile, 2 = MFMAs
-// interleaved with the last block's gather as in raw mode, 3 = no operand fetches.
+// ABL = 4 (experiment; DEFSUM below): a row's sum is formed at the start of its tile - the columns of block 0 from the
+// staged copy in LDS, the rest from registers whose loads were issued before the previous tile's reduction - instead of
+// from a synchronous second read of the whole row.
 template <typename T, int MODE, int NWC, int NWL, int JW, int TT, bool AVL2, int LOGV = 0, int ABL = 0>
 __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch_kernel(
     const TileArgs a, const T* __restrict__ Yp, const int* __restrict__ row_map, const double* __restrict__ Xs,
@@ -92,6 +93,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     constexpr int TH = TT > 2 ? 2 : TT;                                     // type tiles per round of the final reduction
     constexpr int ROUNDS = TT / TH;
     constexpr int TS = TH * 4 * 64;
+    // one row per wave, at most two column blocks of at most four 1 KB pieces each (the host checks the shape)
+    constexpr bool DEFSUM = ABL == 4 && MODE != FDX_PRE_RAW && NWL == 0 && NWC == TILE_ROWS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -211,6 +214,50 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     const T* rowp[RPL];
     const T* rown[RPL];
     bool has_next = false;
+    // DEFSUM: vectors v_first .. nvec - 1 of the wave's row (the columns past block 0), four per lane
+    const int v_first = min(a.GB, a.G) / PER;
+    V xr[DEFSUM ? 4 : 1];
+    auto issue_rest = [&](const T* row) {
+        const V* src = reinterpret_cast<const V*>(row) + v_first;
+#pragma unroll
+        for (int u = 0; u < (DEFSUM ? 4 : 0); ++u) {
+            const int v = u * 64 + lane;
+            if (v_first + v < nvec) xr[u] = src[v];
+        }
+    };
+    // block 0 of the tile has landed in `base`: the wave's row sum in scale_two's order (per-lane partials over ascending
+    // vectors, butterfly), scale and range flag to LDS
+    auto tile_row_sum = [&](const unsigned char* base, bool present, int par) {
+        double p0 = 0.0;
+        unsigned long long sg0 = 0ULL;
+        auto add = [&](const V& x) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                p0 += (double)x[e];
+                if constexpr (sizeof(T) == 4) sg0 |= (unsigned long long)__float_as_uint((float)x[e]) << 32;
+                else sg0 |= (unsigned long long)__double_as_longlong((double)x[e]);
+            }
+        };
+        if (present) {
+            const V* l = reinterpret_cast<const V*>(base + wave * a.RS);
+            V xl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = u * 64 + lane;
+                if (v < v_first) xl[u] = l[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u * 64 + lane < v_first) add(xl[u]);
+#pragma unroll
+            for (int u = 0; u < (DEFSUM ? 4 : 0); ++u)
+                if (v_first + u * 64 + lane < nvec) add(xr[u]);
+        }
+        const double sum0 = wave_sum(p0);
+        const double s0 = tile_row_scale<MODE>(sum0);
+        const bool ok0 = !present || (fabs(sum0) <= 1e18 && (sum0 == 0.0 || fabs(sum0) >= 1e-30) && !__any((long long)sg0 < 0));
+        if (lane == 0) { scales[par * TILE_ROWS + wave] = s0; rowok[par * TILE_ROWS + wave] = ok0 ? 1 : 0; }
+    };
     // one block step of a staging wave: block c of the current tile has landed; stage the next block, sum a share of the
     // next tile's rows
     auto stage_step = [&](int c, int buf, int par) {
@@ -221,12 +268,13 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     // the sums read the rows from HBM, the DMA of the next tile re-reads them 0 - 1 tile periods later, and the closer the
     // two reads the more of the second one the XCD's 4 MB L2 still holds (32 CUs x 128 KB of rows per tile period).
     auto sums_step = [&](int c, int par) {
-        if (MODE != FDX_PRE_RAW && has_next && ABL != 1) scale_rows(rown, a.NBLK - 1 - c, a.NBLK, par ^ 1);
+        if (MODE != FDX_PRE_RAW && has_next && !DEFSUM) scale_rows(rown, a.NBLK - 1 - c, a.NBLK, par ^ 1);
     };
     if (NWL == 0 || wave >= NWC) {
         load_rows(tile, rowp);
         issue_stage(rowp, 0, 0);
-        if (MODE != FDX_PRE_RAW) scale_rows(rowp, 0, 1, 0);
+        if (DEFSUM) { if (rowp[0]) issue_rest(rowp[0]); }
+        else if (MODE != FDX_PRE_RAW) scale_rows(rowp, 0, 1, 0);
     }
 
     if (NWL > 0 && wave >= NWC) {
@@ -327,7 +375,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 if (LAST && AVL2) {
                     __builtin_amdgcn_sched_barrier(0);                       // the operand loads of later groups stay with their groups
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) an[t] = ABL == 3 ? 1.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
+                    for (int t = 0; t < TT; ++t) an[t] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
                 }
                 int t = 0;
                 for (; t + 2 <= len; t += 2) {                            // two steps per trip: the register sets swap roles
@@ -362,6 +410,10 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             if (NWL == 0) __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): this wave's pieces of block c have landed
             lds_barrier();                                                  // everybody's have (the loaders waited for theirs)
             if (NWL == 0) stage_step(c, buf, par);
+            if (DEFSUM && c == 0) {
+                tile_row_sum(smem + (size_t)buf * stage_bytes, rowp[0] != nullptr, par);
+                lds_barrier();
+            }
             if (MODE != FDX_PRE_RAW && c == 0) {
                 scale = scales[par * TILE_ROWS + r];
                 if constexpr (F32LOG) {
@@ -379,7 +431,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         };
         // raw: MFMAs interleaved with the last block's gather.  Log modes: afterwards - the gather is bound by the vector ALU
         // there, and the 16 accumulator registers held through it would spill.
-        constexpr bool INTERLEAVE = MODE == FDX_PRE_RAW || ABL == 2;
+        constexpr bool INTERLEAVE = MODE == FDX_PRE_RAW;
         for (int c = 0; c + 1 < a.NBLK; ++c) block(c, std::false_type{});
         block(a.NBLK - 1, std::integral_constant<bool, INTERLEAVE>{});
         if (!INTERLEAVE) {
@@ -389,7 +441,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 if (AVL2) {
                     if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);    // at most four groups' operands in flight
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) an[t] = ABL == 3 ? 1.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
+                    for (int t = 0; t < TT; ++t) an[t] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8);
                 }
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
@@ -397,6 +449,11 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 sq = fma(acc[j], acc[j], sq);
             }
         }
+        // DEFSUM: the part of the wave's next row that lies beyond column block 0, requested now; it has landed when the
+        // next tile starts (tile_row_sum)
+        if (DEFSUM) __builtin_amdgcn_sched_barrier(0);      // not above the MFMAs: the bucket sums must be dead first
+        if (DEFSUM && has_next && rown[0]) issue_rest(rown[0]);
+        if (DEFSUM) __builtin_amdgcn_sched_barrier(0);
         par ^= 1;
         if (NWL == 0) {
 #pragma unroll
@@ -618,7 +675,12 @@ struct TileLaunch {
     const double* XA;
 };
 
+static thread_local bool t_f64_math = false;
+TileF64Math::TileF64Math(bool on) : prev(t_f64_math) { t_f64_math = on; }
+TileF64Math::~TileF64Math() { t_f64_math = prev; }
+
 static int tile_logv() {
+    if (t_f64_math) return 0;
     const char* e = getenv("FDX_TILE_LOGV");
     return e ? atoi(e) : 2;
 }
@@ -640,18 +702,16 @@ static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hip
                 kern = L.XA ? (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true, 2> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2>)
                             : (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 2> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 2>);
             if (const char* e = getenv("FDX_TILE_ABL")) {
-                if constexpr (MODE == FDX_PRE_LOG_CPM) {
-                    if (L.XA && TT == 2 && logv == 2) {
-                        const int abl = atoi(e);
-                        if (abl == 1) kern = (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2, 1>;
-                        if (abl == 2) kern = (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2, 2>;
-                        if (abl == 3) kern = (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2, 3>;
-                    }
-                }
+                if (!L.XA && logv == 2 && atoi(e) == 4 && L.a.NBLK <= 2 && L.a.GB * 4 <= 4096 && (L.a.G - L.a.GB) * 4 <= 4096)
+                    kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 2, 4> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 2, 4>;
             } else if (logv == 1)
                 kern = L.XA ? (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true, 1> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 1>)
                             : (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 1> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 1>);
         }
+    }
+    if constexpr (MODE != FDX_PRE_RAW && NWC == 12 && std::is_same<T, float>::value) {
+        if (tile_logv() != 0)
+            kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 12, 4, 11, 1, false, 2> : (const void*)tile_sketch_kernel<T, MODE, 12, 4, 11, 2, false, 2>;
     }
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,

@@ -42,6 +42,10 @@ extern "C" {
 #define FDX_PRE_RAW 0
 #define FDX_PRE_LOG_CPM 1       /* dense rule: log1p(y / (rowsum + 1e-10) * 1e4)   (core/deconv.py:190-191) */
 #define FDX_PRE_LOG_CPM_SPARSE 2 /* sparse rule: rowsum 0 -> 1, log1p on stored values (core/deconv.py:183-188) */
+/* OR-ed into the mode of a dense FDX_F32 matrix whose values are float32 in STORAGE only (integer counts converted
+ * exactly): numpy promotes integer input to float64 in core/deconv.py:190-191, so the transform must stay float64-accurate.
+ * Without the flag float32 rows get a float32-class log1p, which is what the reference computes for float32 input. */
+#define FDX_PRE_F64_MATH 0x100
 
 int fdx_version(void);
 const char* fdx_last_error(void);

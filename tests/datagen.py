@@ -82,3 +82,51 @@ def sketched_problem(n_spots, n_types, sketch_dim, seed=42, noise=0.1):
     Ys = mix(B, Xs) + noise * rs.randn(n_spots, sketch_dim)
     coords = rs.rand(n_spots, 2)
     return Ys, Xs, coords, B
+
+
+class FakeAnnData:
+    """Duck-typed AnnData: exactly the attributes the reference's io/loader.py and tl/_deconvolve.py touch (SURVEY.md
+    section 8c: .X, .layers, .obsm, .obs, .var_names, .obs_names, .n_obs, .uns, .copy()) - anndata itself is not installed."""
+
+    def __init__(self, X, var_names, obs_names, obs=None, obsm=None, layers=None):
+        import pandas as pd
+        self.X, self.var_names, self.obs_names = X, np.array(var_names), np.array(obs_names)
+        self.obs = pd.DataFrame(obs or {}, index=self.obs_names)
+        self.obsm, self.layers, self.uns = dict(obsm or {}), dict(layers or {}), {}
+        self.n_obs = X.shape[0]
+
+    def copy(self):
+        c = FakeAnnData(self.X.copy(), self.var_names, self.obs_names, obsm=dict(self.obsm), layers=dict(self.layers))
+        c.obs = self.obs.copy()
+        return c
+
+
+def anndata_case(seed=11):
+    """The AnnData-surface problem behind tests/golden/anndata_*.npz: 120 spots x 520 spatial genes, a single-cell
+    reference of 73 cells x 500 genes in REVERSED gene order with a partial overlap (470 shared genes), one duplicated gene
+    name on each side (first occurrence wins, io/loader.py:181-188), five cell types with 9 / 3 / 21 / 1 / 39 cells in
+    shuffled order, ~60 % zeros in the cells.  Returns plain arrays; `anndata_objects` wraps them."""
+    Y, X, coords, _ = count_like(120, 520, 5, 0.1, seed)
+    rs = np.random.RandomState(seed + 1)
+    genes_st = np.array([f"g{i:04d}" for i in range(520)])
+    genes_ref = np.array([f"g{i:04d}" for i in range(50, 550)])[::-1].copy()
+    genes_st[7] = genes_st[3]                                   # duplicate names: the first occurrence is the one used
+    genes_ref[11] = genes_ref[470]
+    labels = rs.permutation(np.repeat(["T cell", "B cell", "myeloid", "rare", "stroma"], [9, 3, 21, 1, 39]))
+    names = np.array(["T cell", "B cell", "myeloid", "rare", "stroma"])
+    kidx = np.array([int(np.where(names == s)[0][0]) for s in labels])
+    # signature of reference gene j = signature of the spatial gene with the same (original) number, where there is one
+    num = np.array([int(g[1:]) for g in np.array([f"g{i:04d}" for i in range(50, 550)])[::-1]])
+    sig = np.where(num[None, :] < 520, X[:, np.minimum(num, 519)], 2.0)
+    cells = rs.poisson(sig[kidx] * 3.0).astype(np.float64)
+    cells[rs.rand(*cells.shape) < 0.6] = 0.0
+    return dict(Y=Y.astype(np.float64), coords=coords, genes_st=genes_st, genes_ref=genes_ref, labels=labels, cells=cells,
+                obs_st=np.array([f"spot{i}" for i in range(120)]), obs_ref=np.array([f"cell{i}" for i in range(73)]))
+
+
+def anndata_objects(case, wrap=lambda a: a):
+    """(adata_st, adata_ref) of `anndata_case`; `wrap` turns the two matrices into the container under test (identity,
+    scipy CSR, CUDA tensor ...)."""
+    st = FakeAnnData(wrap(case["Y"]), case["genes_st"], case["obs_st"], obsm={"spatial": case["coords"]})
+    ref = FakeAnnData(wrap(case["cells"]), case["genes_ref"], case["obs_ref"], obs={"celltype": case["labels"]})
+    return st, ref

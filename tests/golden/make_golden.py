@@ -411,11 +411,63 @@ def golden_lattice():
     save("lattice.npz", **out)
 
 
+def golden_anndata():
+    """The AnnData surface: the reference's io.load_reference (mean and sum), io.prepare_data /
+    align_genes and tl.deconvolve run on a duck-typed AnnData (anndata is not installed; the loader only touches the
+    attributes datagen.FakeAnnData has) with partial gene overlap, reversed gene order, duplicated gene names, unequal
+    cells per type and, in the second file, scipy CSR matrices.  Stored: signatures, aligned gene lists and matrices, the
+    obsm values, the dominant labels and the 15 uns keys."""
+    import json
+    from flashdeconv import tl
+    from flashdeconv.io import align_genes, load_reference, load_spatial_data, prepare_data
+    print("anndata surface: 120 spots x 520 genes, 73 reference cells x 500 genes, dense and CSR")
+    case = datagen.anndata_case(11)
+    for kind, wrap in (("dense", lambda a: a), ("csr", lambda a: sparse.csr_matrix(a))):
+        st, ref = datagen.anndata_objects(case, wrap)
+        out = {}
+        for method in ("mean", "sum"):
+            Xm, names, genes_ref = load_reference(ref, cell_type_key="celltype", method=method)
+            out[f"X_{method}"] = Xm
+        out["type_names"] = np.array([str(s) for s in names])
+        Y0, coords0, genes_st = load_spatial_data(st)
+        Ya, Xa, common = align_genes(Y0, out["X_mean"], genes_st, genes_ref)
+        Yp, Xp, coords, names_p, genes_p = prepare_data(st, ref, cell_type_key="celltype")
+        assert list(genes_p) == list(common) and np.array_equal(Xp, Xa)
+        out["common_genes"] = np.array([str(s) for s in common])
+        out["Y_aligned"] = np.asarray(Ya.todense()) if sparse.issparse(Ya) else np.asarray(Ya)
+        out["X_aligned"] = Xa
+        with np.errstate(all="ignore"):
+            res = tl.deconvolve(st, ref, cell_type_key="celltype", sketch_dim=64, k_neighbors=4, n_hvg=300,
+                                n_markers_per_type=20, copy=True)
+            assert tl.deconvolve(st, ref, cell_type_key="celltype", sketch_dim=64, preprocess="pearson", spatial_method="radius",
+                                 radius=1.6, key_added="alt") is None
+        P = res.obsm["flashdeconv"]
+        out["obsm"] = P.values
+        out["obsm_columns"] = np.array([str(c) for c in P.columns])
+        out["obsm_index"] = np.array([str(c) for c in P.index])
+        dom = res.obs["flashdeconv_dominant"]
+        out["dominant"] = np.array([str(c) for c in dom])
+        out["dominant_categories"] = np.array([str(c) for c in dom.cat.categories])
+        prm = dict(res.uns["flashdeconv_params"])
+        prm["converged"] = bool(prm["converged"])
+        prm["n_iterations"] = int(prm["n_iterations"])
+        prm["cell_type_names"] = [str(s) for s in prm["cell_type_names"]]
+        out["uns_json"] = np.array(json.dumps(prm, sort_keys=True))
+        out["alt_obsm"] = st.obsm["alt"].values
+        prm2 = dict(st.uns["alt_params"])
+        prm2["converged"] = bool(prm2["converged"]); prm2["n_iterations"] = int(prm2["n_iterations"])
+        prm2["cell_type_names"] = [str(s) for s in prm2["cell_type_names"]]
+        out["alt_uns_json"] = np.array(json.dumps(prm2, sort_keys=True))
+        out["alt_dominant"] = np.array([str(c) for c in st.obs["alt_dominant"]])
+        out["input_sha256"] = np.array(datagen.sha256_arrays(case["Y"], case["cells"], case["coords"]))
+        save(f"anndata_{kind}.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(omega=golden_omega, leverage=golden_leverage, graphs=golden_graphs, solver=golden_solver,
                 objective=golden_objective, fits=golden_fits,
-                fits_sparse=golden_fits_sparse, lattice=golden_lattice)
+                fits_sparse=golden_fits_sparse, lattice=golden_lattice, anndata=golden_anndata)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

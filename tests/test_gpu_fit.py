@@ -159,7 +159,10 @@ def test_csr_structure_check_is_cached_per_tensor_object_only():
     from flashdeconv_amd import _lib
     rs = np.random.RandomState(4)
     Yd = (rs.poisson(0.4, size=(300, 400)) * (rs.rand(300, 400) < 0.3)).astype(np.float32)
-    good = torch.from_numpy(Yd).cuda().to_sparse_csr()
+    t = torch.from_numpy(Yd).cuda().to_sparse_csr()
+    # int32 columns: the layout the library uses in place (int64 columns are copied on every use and always checked)
+    good = torch.sparse_csr_tensor(t.crow_indices(), t.col_indices().to(torch.int32), t.values(), size=(300, 400))
+    del t
     a = _lib.CsrOnDevice.from_torch(good)
     assert id(good) in _lib.CsrOnDevice._checked
     b = _lib.CsrOnDevice.from_torch(good)                      # second use of the same object: served from the cache
@@ -323,20 +326,7 @@ def test_fit_with_gene_selection_active():
     assert m.summary()["n_genes_used"] == len(g["gene_idx"]) < 600
 
 
-class _FakeAnnData:
-    """Duck-typed AnnData: exactly the attributes io/loader.py and tl/_deconvolve.py touch."""
-
-    def __init__(self, X, var_names, obs_names, obs=None, obsm=None, layers=None):
-        import pandas as pd
-        self.X, self.var_names, self.obs_names = X, np.array(var_names), np.array(obs_names)
-        self.obs = pd.DataFrame(obs or {}, index=self.obs_names)
-        self.obsm, self.layers, self.uns = dict(obsm or {}), dict(layers or {}), {}
-        self.n_obs = X.shape[0]
-
-    def copy(self):
-        c = _FakeAnnData(self.X.copy(), self.var_names, self.obs_names, obsm=dict(self.obsm), layers=dict(self.layers))
-        c.obs = self.obs.copy()
-        return c
+_FakeAnnData = datagen.FakeAnnData
 
 
 def test_tl_deconvolve_anndata_surface():
@@ -476,3 +466,66 @@ def test_tl_deconvolve_with_matrices_resident_on_the_gpu(kind):
     assert list(Ph.columns) == list(Pd.columns)
     assert rel_fro(Pd.values, Ph.values) < 1e-9
     assert st_d.uns["flashdeconv_params"]["n_genes_used"] == st_h.uns["flashdeconv_params"]["n_genes_used"]
+
+
+@pytest.mark.parametrize("kind", ["dense", "csr"])
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_anndata_surface_against_the_reference_goldens(kind, where):
+    """SURVEY.md section 8 f4, pinned to the reference: io.load_reference (mean / sum), io.prepare_data / align_genes and
+    tl.deconvolve of the reference were run on the duck-typed AnnData of datagen.anndata_case (tests/golden/make_golden.py:
+    golden_anndata) - partial gene overlap, reversed gene order, duplicated gene names, unequal cells per type, dense and
+    scipy-CSR matrices.  Here the same objects go through flashdeconv_amd's host path (numpy / scipy matrices) and device
+    path (CUDA tensors, dense / sparse_csr) and must give the reference's obsm / obs / uns
+    (flashdeconv/io/loader.py:73-258, flashdeconv/tl/_deconvolve.py:116-174)."""
+    import json
+    import torch
+    import flashdeconv_amd as fd
+    from flashdeconv_amd.io import load_reference, prepare_data
+    g = load_golden(f"anndata_{kind}.npz")
+    case = datagen.anndata_case(11)
+    assert datagen.sha256_arrays(case["Y"], case["cells"], case["coords"]) == str(g["input_sha256"])
+    dev = torch.device("cuda", 0)
+    if where == "host":
+        wrap = (lambda a: sparse.csr_matrix(a)) if kind == "csr" else (lambda a: a)
+    else:
+        def wrap(a):
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            return t.to_sparse_csr() if kind == "csr" else t
+    st, ref = datagen.anndata_objects(case, wrap)
+    for method in ("mean", "sum"):
+        Xm, names, _ = load_reference(ref, cell_type_key="celltype", method=method)
+        assert [str(s) for s in names] == list(g["type_names"])
+        np.testing.assert_allclose(Xm, g[f"X_{method}"], rtol=1e-13, atol=0)
+    Ya, Xa, _, _, genes = prepare_data(st, ref, cell_type_key="celltype")
+    assert [str(s) for s in genes] == list(g["common_genes"]) and len(genes) == 469
+    np.testing.assert_allclose(Xa, g["X_aligned"], rtol=1e-13, atol=0)
+    if where == "device":
+        Ya = (Ya.to_dense() if kind == "csr" else Ya).cpu().numpy()
+    elif kind == "csr":
+        Ya = Ya.toarray()
+    assert np.array_equal(np.asarray(Ya), g["Y_aligned"])
+    res = fd.tl.deconvolve(st, ref, cell_type_key="celltype", sketch_dim=64, k_neighbors=4, n_hvg=300, n_markers_per_type=20,
+                           copy=True)
+    P = res.obsm["flashdeconv"]
+    assert [str(c) for c in P.columns] == list(g["obsm_columns"]) and [str(c) for c in P.index] == list(g["obsm_index"])
+    assert rel_fro(P.values, g["obsm"]) < 1e-8
+    dom = res.obs["flashdeconv_dominant"]
+    assert [str(c) for c in dom] == list(g["dominant"]) and [str(c) for c in dom.cat.categories] == list(g["dominant_categories"])
+
+    def same_params(got, want_json):
+        want = json.loads(str(want_json))
+        got = dict(got)
+        assert sorted(got) == sorted(want) and len(got) == 15
+        for k, w in want.items():
+            if k == "lambda_spatial":
+                np.testing.assert_allclose(float(got[k]), w, rtol=1e-10)
+            elif k == "cell_type_names":
+                assert [str(s) for s in got[k]] == w
+            else:
+                assert got[k] == w, (k, got[k], w)
+    same_params(res.uns["flashdeconv_params"], g["uns_json"])
+    assert fd.tl.deconvolve(st, ref, cell_type_key="celltype", sketch_dim=64, preprocess="pearson", spatial_method="radius",
+                            radius=1.6, key_added="alt") is None
+    assert rel_fro(st.obsm["alt"].values, g["alt_obsm"]) < 1e-8
+    assert [str(c) for c in st.obs["alt_dominant"]] == list(g["alt_dominant"])
+    same_params(st.uns["alt_params"], g["alt_uns_json"])

@@ -267,3 +267,30 @@ def test_lattice_ties_make_the_reference_depend_on_spot_order():
         P[p] = o["proportions"]
         gap = rel_fro(P, g[f"{name}_props"])
         assert lo < gap < hi, (name, gap)
+
+
+@pytest.mark.parametrize("kind", ["dense", "csr"])
+def test_anndata_loaders_on_the_host_match_the_reference(kind):
+    """io.load_reference / prepare_data / align_genes of the package (pure host code for numpy / scipy matrices; no GPU)
+    against what the reference's io/loader.py:73-194,261-311 returned for the same duck-typed AnnData (golden_anndata)."""
+    from scipy import sparse
+    import datagen
+    from flashdeconv_amd.io import align_genes, load_reference, load_spatial_data, prepare_data
+    g = load_golden(f"anndata_{kind}.npz")
+    case = datagen.anndata_case(11)
+    assert datagen.sha256_arrays(case["Y"], case["cells"], case["coords"]) == str(g["input_sha256"])
+    wrap = (lambda a: sparse.csr_matrix(a)) if kind == "csr" else (lambda a: a)
+    st, ref = datagen.anndata_objects(case, wrap)
+    for method in ("mean", "sum"):
+        Xm, names, genes_ref = load_reference(ref, cell_type_key="celltype", method=method)
+        assert [str(s) for s in names] == list(g["type_names"])
+        np.testing.assert_allclose(Xm, g[f"X_{method}"], rtol=1e-14, atol=0)
+    Y0, coords, genes_st = load_spatial_data(st)
+    Ya, Xa, common = align_genes(Y0, g["X_mean"], genes_st, genes_ref)
+    assert [str(s) for s in common] == list(g["common_genes"])
+    assert np.array_equal(Ya.toarray() if kind == "csr" else Ya, g["Y_aligned"]) and np.array_equal(Xa, g["X_aligned"])
+    Yp, Xp, cp, names_p, genes_p = prepare_data(st, ref, cell_type_key="celltype")
+    assert [str(s) for s in genes_p] == list(g["common_genes"]) and np.array_equal(cp, case["coords"])
+    assert np.array_equal(Yp.toarray() if kind == "csr" else Yp, g["Y_aligned"])
+    with pytest.raises(ValueError, match="No common genes"):
+        align_genes(Y0, g["X_mean"], genes_st, np.array(["nope"] * len(genes_ref)))
