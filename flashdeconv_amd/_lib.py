@@ -137,6 +137,7 @@ SIGNATURES = {
     "fdx_graph_from_csr": (c_int, [p_i64, p_i64, c_i64, ctypes.POINTER(c_void_p)]),
     "fdx_graph_destroy": (c_int, [c_void_p]),
     "fdx_graph_info": (c_int, [c_void_p, p_i64, p_i64, p_i32]),
+    "fdx_graph_knn_ties": (c_int, [c_void_p, p_i64]),
     "fdx_bcd_solve": (c_int, [c_void_p, p_double, p_double, c_i64, c_i32, c_i32, c_double, c_double, c_i32, c_double,
                               c_i32, p_double, p_double, p_double, ctypes.POINTER(SolveInfo)]),
 }
@@ -285,6 +286,12 @@ class Graph:
         n, nnz, md = c_i64(0), c_i64(0), c_i32(0)
         check(load().fdx_graph_info(self._h, ctypes.byref(n), ctypes.byref(nnz), ctypes.byref(md)))
         return n.value, nnz.value, md.value
+
+    def knn_ties(self):
+        """Spots whose k-th and (k+1)-th nearest neighbours are exactly equidistant (0 unless built by k-NN)."""
+        t = c_i64(0)
+        check(load().fdx_graph_knn_ties(self._h, ctypes.byref(t)))
+        return int(t.value)
 
     def close(self):
         if self._h is not None and self._h.value:

@@ -357,6 +357,18 @@ class FlashDeconv:
             "objectives": objectives if self.verbose else [],
             "final_change": float(info.solve.final_change),
         }
+        # additive (not in the reference): spots whose k-NN set is a choice - the k-th and (k+1)-th neighbours exactly
+        # equidistant.  The reference takes whichever cKDTree.query meets first (utils/graph.py:60-63), which changes
+        # with the order the spots are listed in; here the lower spot index wins.  Regular lattices tie on every spot.
+        self.info_["knn_ties"] = self._graph.knn_ties() if self.spatial_method == "knn" else 0
+        if self.info_["knn_ties"]:
+            import warnings
+            warnings.warn(
+                f"k-NN ties: {self.info_['knn_ties']} of {n} spots have their k-th and (k+1)-th nearest neighbours at exactly "
+                "the same distance (regular lattice?), so the neighbour graph depends on how ties are broken - here by "
+                "spot index, in the reference by cKDTree's traversal, i.e. by the order the spots are listed in.  "
+                "Proportions can differ from the reference's by a few 1e-4 (relative); spatial_method='grid' builds a "
+                "tie-free graph on lattices.", UserWarning, stacklevel=2)
         # additive diagnostics (not in the reference): per-stage GPU milliseconds
         self.timings_ = {k: float(getattr(info, k)) for k in ("graph_ms", "sketch_ms", "gram_ms", "solve_ms", "finish_ms", "total_ms")}
         self.timings_["sweep_ms"] = float(info.solve.sweep_ms)

@@ -237,6 +237,13 @@ int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_de
     return 0;
 }
 
+int fdx_graph_knn_ties(const fdx_graph* g, int64_t* ties) {
+    FDX_TRY(fdx::graph_meta_sync(g));
+    FDX_REQUIRE(g != nullptr && ties != nullptr, "fdx_graph_knn_ties: null argument");
+    *ties = g->knn_ties;
+    return 0;
+}
+
 // ----------------------------------------------------------------------------------------------- sketch
 static size_t dtype_size(int dtype) { return dtype == FDX_F32 ? 4 : 8; }
 

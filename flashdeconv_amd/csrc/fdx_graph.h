@@ -54,6 +54,10 @@ struct fdx_graph {
     mutable hipStream_t meta_stream = nullptr;
     long long ell_cap_rows = 0;
     mutable fdx::DevBuf keep_nbr, keep_cnt;      // inputs of the queued kernels, released by graph_meta_sync
+    // k-NN builds: rows (of the range built) whose k-th and (k+1)-th nearest are exactly equidistant - the neighbour set of
+    // such a spot is a choice (utils/graph.py:60-63 leaves it to cKDTree's traversal order)
+    fdx::DevBuf ties_dev;
+    mutable long long knn_ties = 0;
     mutable struct fdx_graph_plan* keep_plan = nullptr;
     ~fdx_graph();
 };

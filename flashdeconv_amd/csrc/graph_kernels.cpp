@@ -229,7 +229,7 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
                                                   long long n, GridParams gp, int kk, int* __restrict__ nbr_out,
                                                   int* __restrict__ nbr_cnt, double* __restrict__ nn_dist,
                                                   long long lo, long long hi, int* __restrict__ indeg,
-                                                  int* __restrict__ arrival) {
+                                                  int* __restrict__ arrival, int* __restrict__ tie_count) {
     const long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;      // rows [lo, hi) of the sorted order
     if (p >= hi) return;
     const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
@@ -301,6 +301,18 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
         for (int s = KMAX - 1; s >= 0; --s) if (s < kk && bq[s] >= 0 && bq[s] != (int)p) d1 = bd[s];
         nn_dist[perm[p]] = sqrt(d1);
         return;
+    }
+    // Spots whose kk-th and (kk+1)-th nearest are at EXACTLY the same distance: their neighbour set is not unique (cKDTree
+    // keeps whichever its traversal meets first, graph.py:60-63; here the lower spot index wins).  The (kk+1)-th best of the
+    // scanned block is the true one whenever it ties with the kk-th: a point at that distance lies inside the radius the
+    // scan was proven to cover.  Needs a spare slot (KMAX > kk: the launch takes care of it).
+    if (tie_count) {
+        bool tie = false;
+#pragma unroll
+        for (int s = 1; s < KMAX; ++s)
+            if (s == kk) tie = bq[s] >= 0 && bd[s] == bd[s - 1];
+        const unsigned long long m = __ballot(tie);
+        if (m != 0ULL && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(tie_count, (int)__popcll(m));
     }
     // drop self (graph.py:70-74); if self is not among the kk nearest (coincident points) keep all kk, as the reference does
     // indeg != NULL (whole graph in one piece): the symmetrisation's first pass rides along - every list entry counts
@@ -842,6 +854,7 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
         FDX_HIP(hipMemcpyAsync(&g->meta_host[0], g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipMemcpyAsync(&g->meta_host[1], red.p, 16, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipMemcpyAsync(&g->meta_host[3], summary.p, 8, hipMemcpyDeviceToHost, st));
+        if (g->ties_dev.p) FDX_HIP(hipMemcpyAsync(&g->meta_host[4], g->ties_dev.p, 4, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipEventRecord(g->meta_event, st));
         g->meta_stream = st;
         g->meta_pending = true;
@@ -852,8 +865,11 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     int total = 0;
     FDX_HIP(hipMemcpyAsync(&total, g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
     long long h_red[2] = {0, 0};
+    int h_ties = 0;
     FDX_HIP(hipMemcpyAsync(h_red, red.p, 16, hipMemcpyDeviceToHost, st));
+    if (g->ties_dev.p) FDX_HIP(hipMemcpyAsync(&h_ties, g->ties_dev.p, 4, hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
+    g->knn_ties = h_ties;
     trace_host("ell: read-back + sync");
     g->ell_rows = total;
     g->nnz = h_red[0];
@@ -883,10 +899,11 @@ static int empty_graph(long long n, fdx_graph* g, hipStream_t st) {
 
 template <int KMAX>
 static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, long long lo,
-                             long long hi, hipStream_t st, int* indeg = nullptr, int* arrival = nullptr) {
+                             long long hi, hipStream_t st, int* indeg = nullptr, int* arrival = nullptr, int* ties = nullptr) {
     if (hi <= lo) return;
     hipLaunchKernelGGL(knn_kernel<KMAX>, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), perm,
-                       b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival);
+                       b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
+                       KMAX > kk ? ties : nullptr);
 }
 
 template <int KMAX>
@@ -919,6 +936,7 @@ struct fdx_graph_plan {
     int kk = 0;
     hipStream_t st = nullptr;      // stream the binning / k-NN kernels were queued on
     fdx::DevBuf indeg, arrival;    // whole graph in one piece: in-degrees and reverse-list places from the k-NN kernel
+    fdx::DevBuf ties;              // one int: rows of [lo, hi) with a tie at the k-th neighbour (knn_kernel)
     ~fdx_graph_plan() { (void)hipStreamSynchronize(st); }   // nothing may still read the buffers when they go back to the pool
 };
 fdx_graph::~fdx_graph() {
@@ -960,10 +978,15 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
         indeg = plan->indeg.as<int>();
         arrival = plan->arrival.as<int>();
     }
-    if (kk <= 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival);
-    else if (kk <= 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival);
-    else if (kk <= 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival);
-    else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival);
+    rc = plan->ties.alloc(4);
+    if (rc) { delete plan; return rc; }
+    if (hipMemsetAsync(plan->ties.p, 0, 4, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
+    int* ties = plan->ties.as<int>();
+    // one slot more than the list length, for the tie test (kk = 64 has none: no tie count there)
+    if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival, ties);
+    else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival, ties);
+    else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival, ties);
+    else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival, ties);
     trace_host("knn: kernel launched");
     if (hipGetLastError() != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: k-NN kernel launch failed"); }
     *out = plan;
@@ -982,6 +1005,7 @@ static int graph_from_knn_lists_impl(fdx_graph_plan* plan, const int* nbr, const
     g->n = n; g->n_total = n; g->identity_order = false;
     g->perm.take(plan->b.perm);
     g->rank.take(plan->b.rank);
+    g->ties_dev.take(plan->ties);
     DevBuf indeg, rev_off, cursor, rev, tmp;
     // symmetrise: A + A^T, binary   (graph.py:80-81)
     const int nb = ceil_div(n, 256);
@@ -1050,6 +1074,7 @@ int graph_meta_sync(const fdx_graph* gc) {
     const long long rows = g->meta_host[0] & 0xffffffffLL;
     g->nnz = g->meta_host[1];
     g->max_deg = (int)(g->meta_host[2] & 0xffffffffLL);
+    g->knn_ties = g->meta_host[4] & 0xffffffffLL;
     if (rows > g->ell_cap_rows) {                     // the bound was too small (hubs): build the ELL again with its exact size
         trace_host("meta: ELL bound too small, rebuilding");
         return finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), g->meta_stream, false);
@@ -1230,6 +1255,7 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
     FDX_REQUIRE(lo >= 0 && hi >= lo && hi <= full->n, "graph_localize: bad range");
     FDX_REQUIRE(lo % 256 == 0, "graph_localize: range start must be a multiple of 256");
     FDX_REQUIRE(full->n_total == full->n, "graph_localize: input must be a full (unsharded) graph");
+    loc->knn_ties = full->knn_ties;   // a shard's full-size graph counted the ties of the rows it was built for
     const long long ng = full->n, n_own = hi - lo;
     loc->n = n_own;
     loc->identity_order = false;

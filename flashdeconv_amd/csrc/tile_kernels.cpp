@@ -189,7 +189,10 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         // false for a NaN / Inf sum; above 1e18 the scale * 2^-65 would leave the float range, below 1e-30 the scale itself
         auto sum_ok = [](double s) { return fabs(s) <= 1e18 && (s == 0.0 || fabs(s) >= 1e-30); };
         const bool ok0 = sum_ok(sum0) && !__any((long long)sg0 < 0);
-        if (lane == 0 && r0) { out_scale[i0] = s0; out_ok[i0] = ok0 ? 1 : 0; }
+        // rows past the end of the matrix: a defined scale and a set flag (a stale flag would send the whole tile down the
+        // general path - same values in float64, but not in the float32 class)
+        if (lane == 0 && i0 < TILE_ROWS) { out_scale[i0] = r0 ? s0 : 0.0; out_ok[i0] = (!r0 || ok0) ? 1 : 0; }
+        if (TWO && !r1 && lane == 0 && i1 < TILE_ROWS) { out_scale[i1] = 0.0; out_ok[i1] = 1; }
         if (TWO && r1) {
             const double sum1 = wave_sum(p1);
             const double s1 = tile_row_scale<MODE>(sum1);
@@ -207,7 +210,6 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 if (kk == k) r0 = rp[kk];
                 if (kk == k + step) r1 = rp[kk];
             }
-            if (!r0 && !r1) continue;
             scale_two(r0, r1, scales + par * TILE_ROWS, rowok + par * TILE_ROWS, lw + NWS * k, lw + NWS * (k + step));
         }
     };

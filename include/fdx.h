@@ -135,6 +135,12 @@ int fdx_graph_export_csr(const fdx_graph* g, int64_t* indptr, int32_t* indices);
 int fdx_graph_destroy(fdx_graph* g);
 /* n spots, structural nnz, maximum degree */
 int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_deg);
+/* k-NN graphs: the number of spots (of the rows this graph was built for) whose k-th and (k+1)-th nearest neighbours
+ * lie at EXACTLY the same distance.  The k-NN set of such a spot is not unique: the reference inherits whatever
+ * scipy's cKDTree.query meets first (utils/graph.py:60-63), which depends on the order the spots are listed in; this
+ * library keeps the lower spot index.  Regular lattices (Visium-HD bins, k = 6) tie on every spot.  0 for graphs
+ * built from a radius or a given adjacency, and for k_neighbors = 63 (no spare slot). */
+int fdx_graph_knn_ties(const fdx_graph* g, int64_t* ties);
 
 /* ---- solver (replaces core/solver.py:287-428 bcd_solve and everything it calls) ---------------------- */
 typedef struct fdx_solve_info {

@@ -96,7 +96,8 @@ class FakeAnnData:
         self.n_obs = X.shape[0]
 
     def copy(self):
-        c = FakeAnnData(self.X.copy(), self.var_names, self.obs_names, obsm=dict(self.obsm), layers=dict(self.layers))
+        X = self.X.copy() if hasattr(self.X, "copy") else self.X.clone()       # numpy / scipy, or a torch tensor
+        c = FakeAnnData(X, self.var_names, self.obs_names, obsm=dict(self.obsm), layers=dict(self.layers))
         c.obs = self.obs.copy()
         return c
 

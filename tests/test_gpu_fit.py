@@ -372,7 +372,11 @@ def test_lattice_without_ties_matches_reference(name):
     """Regular lattices where the neighbour sets are unambiguous: spatial_method='grid' (radius 1.5 x the nearest
     neighbour distance: the 8 / 6 surrounding bins) on square and hexagonal lattices.  Adjacency index-exact, abundances
     at the usual tolerance."""
-    m, g, same_graph = _lattice_case(name)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                               # spatial_method='grid': no ties, no warning
+        m, g, same_graph = _lattice_case(name)
+    assert m.info_["knn_ties"] == 0
     assert same_graph
     assert m.info_["n_iterations"] == int(g[f"{name}_n_iter"])
     np.testing.assert_allclose(m.lambda_used_, float(g[f"{name}_lambda"]), rtol=1e-10)
@@ -389,7 +393,9 @@ def test_square_lattice_k6_tie_deviation_is_bounded(name):
     of the reference's own dependence on the ORDER in which the same spots are listed (4.9e-4 - 5.2e-4 / 2.1e-4 - 2.6e-4:
     tests/test_oracle.py::test_lattice_ties_make_the_reference_depend_on_spot_order), which bounds what any tie rule other
     than a bit-for-bit cKDTree emulation can achieve.  DESIGN.md §4."""
-    m, g, same_graph = _lattice_case(name)
+    with pytest.warns(UserWarning, match="k-NN ties"):               # the deviation is announced, not silent
+        m, g, same_graph = _lattice_case(name)
+    assert m.info_["knn_ties"] > 0.5 * m.n_spots_ * (name != "hex_k6")  # square: nearly every spot; hexagonal: the border
     assert not same_graph                                            # if this ever holds, tighten the test above instead
     A = m.adjacency_
     assert (A != A.T).nnz == 0 and A.diagonal().sum() == 0
@@ -397,7 +403,10 @@ def test_square_lattice_k6_tie_deviation_is_bounded(name):
     assert deg.min() >= 6                                            # still a k-NN graph: every spot keeps >= k neighbours
     gap_p, gap_b = rel_fro(m.proportions_, g[f"{name}_props"]), rel_fro(m.beta_, g[f"{name}_beta"])
     print(f"lattice tie deviation {name}: proportions {gap_p:.3e} beta {gap_b:.3e} lambda {m.lambda_used_:.6g} vs {float(g[name + '_lambda']):.6g}")
-    assert gap_p < 8e-4 and gap_b < 8e-4
+    # measured (MI355X, this build) + 10 %: square 4.5e-4, hexagonal 3.1e-4; the contract is 1e-4 - this is the documented
+    # deviation, asserted so that it cannot grow unnoticed
+    bound = {"square_k6": 5.0e-4, "square100_k6": 5.0e-4, "hex_k6": 3.5e-4}[name]
+    assert gap_p < bound and gap_b < bound, (name, gap_p, gap_b)
 
 
 def test_dense_whole_transcriptome_float64_gene_subset():
@@ -416,10 +425,7 @@ def test_dense_whole_transcriptome_float64_gene_subset():
     a = FlashDeconv(**kw).fit(Y, X, coords)
     assert 600 <= len(a.gene_idx_) < G_all
     b = FlashDeconv(**dict(kw, n_hvg=len(a.gene_idx_))).fit(Y[:, a.gene_idx_], X[:, a.gene_idx_], coords)
-    # float32 rows under log-CPM: the tile kernel evaluates a float32-class log1p (as the reference does for float32 input),
-    # the two-kernel path the float64 one - float32 rounding apart, not float64 rounding
-    tol = 1e-5 if (pre == "log_cpm" and dtype == np.float32) else 1e-12
-    assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < tol
+    assert a.info_["n_iterations"] == b.info_["n_iterations"] and rel_fro(a.beta_, b.beta_) < 1e-12
 
 
 @pytest.mark.parametrize("kind", ["dense", "csr"])
@@ -497,7 +503,7 @@ def test_anndata_surface_against_the_reference_goldens(kind, where):
         assert [str(s) for s in names] == list(g["type_names"])
         np.testing.assert_allclose(Xm, g[f"X_{method}"], rtol=1e-13, atol=0)
     Ya, Xa, _, _, genes = prepare_data(st, ref, cell_type_key="celltype")
-    assert [str(s) for s in genes] == list(g["common_genes"]) and len(genes) == 469
+    assert [str(s) for s in genes] == list(g["common_genes"]) and len(genes) == 470
     np.testing.assert_allclose(Xa, g["X_aligned"], rtol=1e-13, atol=0)
     if where == "device":
         Ya = (Ya.to_dense() if kind == "csr" else Ya).cpu().numpy()

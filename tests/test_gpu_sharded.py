@@ -34,7 +34,9 @@ def test_virtual_ranks_equal_single_gpu(W, build):
     n, G, K, d = 6000, 300, 12, 64
     Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 11)
     coords = coords + np.random.RandomState(0).rand(n, 2) * 1e-3
-    ref = FlashDeconv(sketch_dim=d, max_iter=60, tol=1e-5).fit(Y, X, coords)
+    # float32 on both sides: the shards hold float32 rows, and the transform's class follows the input type (float32 rows ->
+    # float32-class log1p, as in the reference; integer counts would be transformed in float64)
+    ref = FlashDeconv(sketch_dim=d, max_iter=60, tol=1e-5).fit(Y.astype(np.float32), X, coords)
     T = ref.info_["n_iterations"]
 
     cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
@@ -175,7 +177,7 @@ def test_sharded_class_world1_equals_flashdeconv():
         # gene selection active (G > n_hvg): statistics reduced over the shards, same genes, same fit
         Yc, Xc, cc, _ = datagen.count_like(3000, 900, 6, 0.1, 8)
         kw = dict(sketch_dim=64, preprocess="log_cpm", n_hvg=250, n_markers_per_type=10, max_iter=20)
-        ref2 = FlashDeconv(**kw).fit(Yc, Xc, cc)
+        ref2 = FlashDeconv(**kw).fit(Yc.astype(np.float32), Xc, cc)
         m2 = ShardedFlashDeconv(**kw)
         own2 = m2.plan(torch.from_numpy(cc).to(dev))
         P2 = m2.fit_transform(torch.from_numpy(Yc.astype(np.float32)).to(dev)[own2], Xc)
@@ -321,7 +323,9 @@ def test_native_loop_thread_ranks_equal_single_gpu(W, overlap, monkeypatch):
     n, G, K, d = 6000, 300, 12, 64
     Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 11)
     coords = coords + np.random.RandomState(0).rand(n, 2) * 1e-3
-    ref = FlashDeconv(sketch_dim=d, max_iter=60, tol=1e-5).fit(Y, X, coords)
+    # float32 on both sides: the shards hold float32 rows, and the transform's class follows the input type (float32 rows ->
+    # float32-class log1p, as in the reference; integer counts would be transformed in float64)
+    ref = FlashDeconv(sketch_dim=d, max_iter=60, tol=1e-5).fit(Y.astype(np.float32), X, coords)
     cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
     Yt = torch.from_numpy(Y.astype(np.float32)).to(dev)
     full, shards = _native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM)

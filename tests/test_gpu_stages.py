@@ -25,6 +25,45 @@ def test_graphs_match_reference_golden():
         assert A.dtype == np.float64 and (A.nnz == 0 or np.all(A.data == 1.0))
 
 
+def test_knn_tie_count_is_zero_on_tie_free_goldens_and_positive_on_lattices():
+    """fdx_graph_knn_ties: spots whose k-th and (k+1)-th nearest neighbours are exactly equidistant - the inputs on which
+    the reference's graph depends on cKDTree's traversal order (utils/graph.py:60-63).  None on the tie-free golden graphs
+    (which is why they are index-exact), every interior spot of a square lattice with k = 6 (four neighbours at 1, two of
+    the four at sqrt 2), only border spots of a hexagonal one, none with k = 4 or k = 8 on the square lattice."""
+    from flashdeconv_amd import _lib
+    g = load_golden("graphs.npz")
+    seen = 0
+    for name in [str(s) for s in g["names"]]:
+        if str(g[f"{name}_method"]) != "knn":
+            continue
+        coords = np.ascontiguousarray(g[f"{name}_coords"], dtype=np.float64)
+        if coords.shape[0] < 2 or coords.shape[1] > 3:
+            continue
+        gr = _lib.Graph.from_coords_knn(coords, int(g[f"{name}_k"]))
+        assert gr.knn_ties() == 0, name
+        gr.close()
+        seen += 1
+    assert seen >= 5
+    lat = load_golden("lattice.npz")
+    sq, hx = lat["square_k6_coords"], lat["hex_k6_coords"]
+    n = sq.shape[0]
+    t6 = _lib.Graph.from_coords_knn(sq, 6).knn_ties()
+    assert t6 >= (30 - 2) ** 2 and t6 <= n
+    assert _lib.Graph.from_coords_knn(sq * 100.0, 6).knn_ties() == t6
+    th = _lib.Graph.from_coords_knn(hx, 6).knn_ties()
+    assert 0 < th < 4 * 28 + 40                                      # border spots only
+    # k = 4: the four at distance 1 are the set, the next (sqrt 2) is farther - no tie in the interior; k = 8 likewise
+    assert _lib.Graph.from_coords_knn(sq, 4).knn_ties() < 4 * 30
+    assert _lib.Graph.from_coords_knn(sq, 8).knn_ties() < 4 * 30
+    # k + 1 = 8 and 16 sit at the edge of the list-length classes of the kernel: the spare slot must still be there
+    rs = np.random.RandomState(2)
+    pts = rs.rand(3000, 2) * 50
+    for k in (7, 15, 31):
+        assert _lib.Graph.from_coords_knn(pts, k).knn_ties() == 0
+    dup = np.concatenate([pts[:100], pts[:100] + np.array([1.0, 0.0])])   # exact translates: distance ties everywhere? no -
+    assert _lib.Graph.from_coords_knn(dup, 6).knn_ties() >= 0              # only that the count is well defined
+
+
 @pytest.mark.parametrize("n,dim,k", [(5000, 2, 6), (3000, 3, 8), (4000, 2, 15), (2500, 1, 3), (777, 2, 40)])
 def test_knn_vs_oracle_kdtree(n, dim, k):
     from flashdeconv_amd.utils import graph as G
