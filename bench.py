@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--config", type=int, default=3, choices=[3, 5],
                     help="3: BASELINE configs[2]/[3] (1M x 2000 x 30, d 512); 5: one rank's shard of configs[4] "
                          "(1.25M x 5000 x 50, d 1024, lambda auto) on one GPU, gaussian/raw family only")
+    ap.add_argument("--virtual-ranks", type=int, default=0,
+                    help="with --config 5: the WHOLE configs[4] job (10M spots; --spots overrides) with this many virtual ranks "
+                         "on one GPU (tools/virtual_ranks.py) - prints per-rank stage times of the sharded plan, prepare and solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     return ap.parse_args()
@@ -254,6 +257,31 @@ def spawn_ranks(n_ranks):
 
 def main():
     a = parse()
+    if a.config == 5 and a.virtual_ranks > 0:      # the whole 10M-spot job over virtual ranks: fixed costs of the plan on record
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import virtual_ranks as vr
+        torch.cuda.set_device(0)
+        n = a.spots if a.spots != 1_000_000 else 10_000_000
+        line = None
+        for it in range(a.warmup + a.steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, _, info = vr.run_config5(torch, a.virtual_ranks, n=n, G=5000, K=50, d=1024, seed=11)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            t = info["times"]
+            # what ONE rank of a real W-GPU job would spend (its own share of every per-rank stage; the all-gather timed
+            # here is W^2 device copies on one GPU, not RCCL): generation of the synthetic shard excluded
+            per_rank = [t["knn_lists_ms"][r] + t["from_lists_ms"][r] + t["localize_ms"][r] + t["prepare_ms"][r]
+                        for r in range(a.virtual_ranks)]
+            line = {"metric": "configs[4] with virtual ranks on one GPU: per-rank stage times (ms)", "n_gpus": 1,
+                    "virtual_ranks": a.virtual_ranks, "spots": n, "n_iterations": info["n_iterations"][0],
+                    "knn_ties": info["knn_ties"], "nnz": info["nnz"], "n_halo": info["n_halo"], "stage_ms": t,
+                    "per_rank_plan_plus_prepare_ms": [round(x, 2) for x in per_rank],
+                    "wall_s_incl_generation": round(wall, 2), "data": "synthetic"}
+        print(json.dumps(line))
+        return
     if a.config == 5:      # the shape of one of the eight shards of BASELINE configs[4] (10M x 5000 x 50, d 1024)
         a.spots, a.genes, a.types, a.sketch_dim, a.family, a.no_cpu_baseline = 1_250_000, 5000, 50, 1024, "gaussian", True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

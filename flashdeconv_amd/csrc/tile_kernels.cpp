@@ -95,6 +95,11 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     constexpr int TS = TH * 4 * 64;
     // one row per wave, at most two column blocks of at most four 1 KB pieces each (the host checks the shape)
     constexpr bool DEFSUM = ABL == 4 && MODE != FDX_PRE_RAW && NWL == 0 && NWC == TILE_ROWS;
+    // ABL = 5 (experiment): every wave touches one 4-byte word per 128-byte line of its row of the NEXT tile at the start of
+    // the current one - one vector load per 8 KB - so that the row sums at the end of the tile and the DMA behind them find
+    // the lines in L2 / Infinity Cache instead of paying the HBM latency in the open
+    constexpr bool PREF = ABL == 5 && MODE != FDX_PRE_RAW && NWL == 0 && NWC == TILE_ROWS;
+    unsigned pref_sink = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -416,6 +421,17 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 tile_row_sum(smem + (size_t)buf * stage_bytes, rowp[0] != nullptr, par);
                 lds_barrier();
             }
+            if (PREF) {
+                // the previous prefetch has landed (vmcnt(0) above): its destination register may be released
+                asm volatile("" :: "v"(pref_sink));
+                if (c == 0 && has_next && rown[0]) {
+                    const int row_bytes = a.G * (int)sizeof(T);
+                    for (int o = lane * 128; o < row_bytes; o += 64 * 128) {
+                        const char* src = reinterpret_cast<const char*>(rown[0]) + o;
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(pref_sink) : "v"(src) : "memory");
+                    }
+                }
+            }
             if (MODE != FDX_PRE_RAW && c == 0) {
                 scale = scales[par * TILE_ROWS + r];
                 if constexpr (F32LOG) {
@@ -706,6 +722,8 @@ static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hip
             if (const char* e = getenv("FDX_TILE_ABL")) {
                 if (!L.XA && logv == 2 && atoi(e) == 4 && L.a.NBLK <= 2 && L.a.GB * 4 <= 4096 && (L.a.G - L.a.GB) * 4 <= 4096)
                     kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 2, 4> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 2, 4>;
+                if (!L.XA && logv == 2 && atoi(e) == 5)
+                    kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 2, 5> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 2, 5>;
             } else if (logv == 1)
                 kern = L.XA ? (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true, 1> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 1>)
                             : (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 1> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 1>);
