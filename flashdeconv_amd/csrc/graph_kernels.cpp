@@ -982,11 +982,23 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     if (rc) { delete plan; return rc; }
     if (hipMemsetAsync(plan->ties.p, 0, 4, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
     int* ties = plan->ties.as<int>();
-    // one slot more than the list length, for the tie test (kk = 64 has none: no tie count there)
-    if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival, ties);
-    else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival, ties);
-    else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival, ties);
-    else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, lo, hi, st, indeg, arrival, ties);
+    // one slot more than the list length, for the tie test (kk = 64 has none: no tie count there).
+    // Large ranges go out as a few launches instead of one: the kernel fills the device for hundreds of microseconds, and the
+    // leverage passes on the library's side stream (32 workgroups each, latency-bound) were waiting for it to drain - 330 us
+    // for a 9 us kernel at 1M spots; between two launches their workgroups get in.  Not more than a few: a workgroup of the
+    // kernel lives ~120-150 us whatever the grid (latency-bound lanes), so a piece that does not fill every CU's wave slots
+    // costs a full round all the same (1M spots, wall per fit: 1 piece 5.31-5.41 ms, 2-4 pieces 5.18-5.26, 8 pieces 5.56).
+    const long long rows = hi - lo;
+    const int pieces_env = getenv("FDX_KNN_PIECES") ? atoi(getenv("FDX_KNN_PIECES")) : 0;
+    const int pieces = pieces_env > 0 ? pieces_env : (int)std::min<long long>(4, std::max<long long>(1, (rows + 160000) / 320000));
+    const long long step = ((rows + pieces - 1) / pieces + 127) / 128 * 128;
+    for (long long a = lo; a < hi; a += step) {
+        const long long e = std::min(hi, a + step);
+        if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties);
+        else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties);
+        else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties);
+        else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties);
+    }
     trace_host("knn: kernel launched");
     if (hipGetLastError() != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: k-NN kernel launch failed"); }
     *out = plan;

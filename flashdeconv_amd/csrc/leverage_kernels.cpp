@@ -357,21 +357,36 @@ __global__ __launch_bounds__(512) void lev_eigen_kernel(const double* __restrict
     if (tid == 0) s_first = 0;
     __syncthreads();
     if (tid < K) cs[128 + tid] = Cbuf(0)[tid][tid];                         // ||a_j||^2 of the incoming columns
-    const int Kq = (K + 1) & ~1, npair = Kq / 2;
+    const int Kq = (K + 1) & ~1, npair = Kq / 2, M = Kq - 1;
     int cur = 0;
+    const int j = tid & 63, w8 = tid >> 6;
     for (int sw = 0; sw < 12; ++sw) {
         if (tid == 0) s_rot = 0;
         __syncthreads();
-        for (int r = 0; r < Kq - 1; ++r) {
+        for (int r = 0; r < M; ++r) {
             Mat C = Cbuf(cur), V = Vbuf(cur), Cn = Cbuf(cur ^ 1), Vn = Vbuf(cur ^ 1);
             if (tid < npair) {
+                // round-robin pairing without divisions: both sums stay below 2 M
                 int p, q;
-                if (tid == 0) { p = Kq - 1; q = r; } else { p = (r + tid) % (Kq - 1); q = (r - tid + (Kq - 1)) % (Kq - 1); }
+                if (tid == 0) { p = M; q = r; }
+                else {
+                    p = r + tid; if (p >= M) p -= M;
+                    q = r - tid + M; if (q >= M) q -= M;
+                }
                 if (p > q) { const int t = p; p = q; q = t; }
                 double c = 1.0, sn = 0.0;
                 if (q < K) {
                     const double cpq = C[p][q], cpp = C[p][p], cqq = C[q][q];
-                    if (fabs(cpq) > 1e-14 * sqrt(fabs(cpp * cqq)) && cpq != 0.0) {
+                    // Rotate when |c_pq| > 1e-14 sqrt(c_pp c_qq) (compared as squares) - the criterion that gives the small
+                    // singular values their relative accuracy - AND |c_pq| > 1e-15 max(c_pp, c_qq): the updates of this
+                    // kernel round at eps x the LARGER diagonal entry, so below that an off-diagonal entry is noise that no
+                    // rotation of this pass can remove (a pair with c_qq < 1e-4 c_pp - always present: centring makes one
+                    // direction null - never met the first test alone, and every pass ran all 12 sweeps).  What is left is
+                    // taken up by the next pass, which forms C afresh from the rotated columns.
+                    // First sweep of a pass: C is fresh from the columns, accurate to a few eps - floor 1e-15.  Later sweeps
+                    // carry the rounding of ~K updates per entry - floor 1e-13.
+                    const double big = fmax(fabs(cpp), fabs(cqq));
+                    if (cpq * cpq > 1e-28 * fabs(cpp * cqq) && fabs(cpq) > (sw == 0 ? 1e-15 : 1e-13) * big) {
                         const double theta = (cqq - cpp) / (2.0 * cpq);
                         const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
                         c = 1.0 / sqrt(1.0 + t * t);
@@ -387,18 +402,35 @@ __global__ __launch_bounds__(512) void lev_eigen_kernel(const double* __restrict
                 }
             }
             __syncthreads();
-            {   // lane = column j (its pair data read once), wave w takes rows w, w + 8, ... (row data is wave-uniform)
-                const int j = tid & 63;
-                if (j < K) {
-                    const int rj = s_partner[j];
-                    const double cj = s_own[j], tj = s_oth[j];
-                    for (int i = tid >> 6; i < K; i += 8) {
-                        const int ri = s_partner[i];
-                        const double ci = s_own[i], ti = s_oth[i];
-                        const double t_i = cj * C[i][j] + tj * C[i][rj];  // column step, rows i and r_i
-                        const double t_r = cj * C[ri][j] + tj * C[ri][rj];
-                        Cn[i][j] = ci * t_i + ti * t_r;                   // row step
-                        Vn[i][j] = cj * V[i][j] + tj * V[i][rj];
+            // lane = column j (its pair data read once), wave w takes rows w, w + 8, ... (row data is wave-uniform); the rows
+            // of a wave are independent: their reads are issued together (up to eight rows: K <= 64)
+            if (j < K) {
+                const int rj = s_partner[j];
+                const double cj = s_own[j], tj = s_oth[j];
+                constexpr int RW = 8;
+                int ri[RW];
+                double ci[RW], ti[RW], a0[RW], a1[RW], a2[RW], a3[RW], v0[RW], v1[RW];
+#pragma unroll
+                for (int u = 0; u < RW; ++u) {
+                    const int i = w8 + 8 * u;
+                    if (i < K) { ri[u] = s_partner[i]; ci[u] = s_own[i]; ti[u] = s_oth[i]; }
+                }
+#pragma unroll
+                for (int u = 0; u < RW; ++u) {
+                    const int i = w8 + 8 * u;
+                    if (i < K) {
+                        a0[u] = C[i][j]; a1[u] = C[i][rj]; a2[u] = C[ri[u]][j]; a3[u] = C[ri[u]][rj];
+                        v0[u] = V[i][j]; v1[u] = V[i][rj];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RW; ++u) {
+                    const int i = w8 + 8 * u;
+                    if (i < K) {
+                        const double t_i = cj * a0[u] + tj * a1[u];           // column step, rows i and r_i
+                        const double t_r = cj * a2[u] + tj * a3[u];
+                        Cn[i][j] = ci[u] * t_i + ti[u] * t_r;                 // row step
+                        Vn[i][j] = cj * v0[u] + tj * v1[u];
                     }
                 }
             }
