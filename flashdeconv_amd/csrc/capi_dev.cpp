@@ -244,10 +244,15 @@ int fdx_prepare_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t 
     double yty = 0.0;
     if (n > 0) {
         const long long chunk = std::min<long long>(n, 1LL << 18);
-        FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
+        const bool csr_fused = csr_contract_ok(d, K, sel_words);       // the same choice as fit_impl: sharded = unsharded bits
+        if (!csr_fused) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
         FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
         FDX_TRY(dSum.alloc(sizeof(double)));
-        for (long long r0 = 0; r0 < n; r0 += chunk) {
+        if (csr_fused)
+            FDX_TRY(launch_sketch_csr_contract((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, nullptr, n, d, mode_y,
+                                               dSlots.p, dBits.as<unsigned>(), sel_words, dXs.as<double>(), K, H_out_dev, ldh,
+                                               dRowSq.as<double>(), st));
+        for (long long r0 = 0; r0 < n && !csr_fused; r0 += chunk) {
             const long long nr = std::min(chunk, n - r0);
             FDX_TRY(launch_sketch_csr((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, nullptr, r0, nr, d, mode_y, dSlots.p,
                                       dBits.as<unsigned>(), sel_words, dYs.as<double>(), d, dRowSq.as<double>() + r0, st));

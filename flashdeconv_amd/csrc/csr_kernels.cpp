@@ -191,6 +191,227 @@ int launch_sketch_csr(const long long* indptr, const int* indices, const void* d
 
 size_t csr_gene_slot_bytes() { return sizeof(GeneSlot); }
 
+// ------------------------------------------------------------------------------------------------ fused CSR sketch -> H
+// H = X_sketch * (f(Y) Omega)^T for CSR rows without Y_sketch in HBM (core/deconv.py:181-188, core/sketching.py:194-199,
+// core/solver.py:205-223 in one pass).  The two-kernel path writes every sketched row (d doubles = 4 KB at d = 512) and
+// reads it back for the contraction - 8.2 GB beside 11.5 GB of input at 1M spots x 1438 stored entries.  Here a 16-wave
+// workgroup takes GROUPS of 16 consecutive spots (solver order):
+//   gather     wave w walks the CSR row of spot w exactly as sketch_csr_kernel does (bitmap filter, {weight, bucket} gather,
+//              ds_add_f64 into the spot's d-entry accumulator row in LDS); ||row||^2 goes to row_sumsq;
+//   contract   the 16 x d block in LDS is the B operand of v_mfma_f64_16x16x4_f64, the contraction index split over the
+//              16 waves (X_sketch slices as register-resident A operands), partial 16 x 16 type tiles added in wave order
+//              through LDS and stored to H - the contract phase of sketch_contract_kernel (fused_kernels.cpp).
+// The rows of a group have different lengths and meet at a barrier: the group costs its longest row.
+typedef double csr_double4_t __attribute__((ext_vector_type(4)));
+constexpr int CSRF_PAD = 16;     // doubles of padding per accumulator row (conflict-free B-operand reads)
+
+template <typename T, int MODE, int NB, int TT>
+__global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
+    const long long* __restrict__ indptr, const int* __restrict__ indices, const T* __restrict__ data,
+    const int* __restrict__ row_map, long long n, int d, const GeneSlot* __restrict__ table,
+    const unsigned* __restrict__ sel_bits, int sel_words, const double* __restrict__ Xs, int K, double* __restrict__ Hout,
+    long long ldh, double* __restrict__ row_sumsq, int no_table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int R = 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rs = d + CSRF_PAD;
+    double* rows = reinterpret_cast<double*>(smem);                       // [16][rs]; re-used as red[16][TT*4*64]
+    const int region = max(R * rs, R * TT * 4 * 64);
+    double* tabs = rows + region;                                         // [16][64] per-wave log1p tables
+    unsigned* bits = reinterpret_cast<unsigned*>(tabs + R * 64);          // [sel_words]
+    double* red = rows;
+    for (int j = tid; j < sel_words; j += R * 64) bits[j] = sel_bits[j];
+    const int r = lane & 15, q = lane >> 4;
+    double a[NB][TT][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int c0 = (wave * NB + b) * 16 + 4 * q;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int type = t * 16 + r;
+            const bool ok = type < K && c0 < d;
+            const csr_double4_t v = ok ? *reinterpret_cast<const csr_double4_t*>(Xs + (size_t)type * d + c0) : csr_double4_t{0.0, 0.0, 0.0, 0.0};
+            a[b][t][0] = v.x; a[b][t][1] = v.y; a[b][t][2] = v.z; a[b][t][3] = v.w;
+        }
+    }
+    __syncthreads();
+    double* acc = rows + (size_t)wave * rs;
+    double* tab = tabs + (size_t)wave * 64;
+    const long long n_groups = (n + R - 1) / R;
+    long long grp = blockIdx.x;
+    long long beg = 0, end = 0;
+    if (grp < n_groups && grp * R + wave < n) {
+        const long long p0 = grp * R + wave;
+        const long long row = row_map ? (long long)row_map[p0] : p0;
+        beg = indptr[row];
+        end = indptr[row + 1];
+    }
+    for (; grp < n_groups; grp += gridDim.x) {
+        const long long s0 = grp * R;
+        const long long p = s0 + wave;
+        long long nbeg = 0, nend = 0;                                     // extents of this wave's row of the next group, early
+        {
+            const long long pn = (grp + gridDim.x) * R + wave;
+            if (grp + gridDim.x < n_groups && pn < n) {
+                const long long nrow = row_map ? (long long)row_map[pn] : pn;
+                nbeg = indptr[nrow];
+                nend = indptr[nrow + 1];
+            }
+        }
+        for (int c = lane; c < d; c += 64) acc[c] = 0.0;
+        if (p < n) {                                                      // wave-uniform: spots past the end stay zero
+            double scale = 1.0;
+            bool use_tab = false;
+            CsrGroup<T> cur, nxt;
+            if (MODE != FDX_PRE_RAW) {  // library size over the SELECTED genes (the subset is taken first, deconv.py:321)
+                double s = 0.0, mx = 0.0;
+                csr_load_group(cur, indices, data, beg, end, lane);
+                for (long long q0 = beg; q0 < end; q0 += 256) {
+                    csr_load_group(nxt, indices, data, q0 + 256, end, lane);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u)) {
+                            s += (double)cur.y[u];
+                            mx = fmax(mx, (double)cur.y[u]);
+                        }
+                    cur = nxt;
+                }
+                s = wave_sum(s);
+                scale = 10000.0 / (s == 0.0 ? 1.0 : s);                    // deconv.py:183-185
+                use_tab = !no_table && wave_max(mx) < 64.0;
+                if (use_tab) log1p_table_fill(tab, scale, lane);
+            }
+            csr_load_group(cur, indices, data, beg, end, lane);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                            // zeroing done before the adds
+            for (long long q0 = beg; q0 < end; q0 += 256) {
+                GeneSlot e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    e[u].bucket = -1;
+                    if (cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u)) e[u] = table[cur.c[u]];
+                }
+                csr_load_group(nxt, indices, data, q0 + 256, end, lane);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (e[u].bucket >= 0) {
+                        double v = (double)cur.y[u];
+                        if (MODE != FDX_PRE_RAW) v = log1p_scaled(v, scale, tab, use_tab);
+                        lds_add(acc + e[u].bucket, e[u].w * v);
+                    }
+                }
+                cur = nxt;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (row_sumsq) {
+                double sq = 0.0;
+                for (int c = lane; c < d; c += 64) {
+                    const double v = acc[c];
+                    sq = fma(v, v, sq);
+                }
+                sq = wave_sum(sq);
+                if (lane == 0) row_sumsq[p] = sq;
+            }
+        }
+        __syncthreads();                                                  // the 16 x d block is complete
+        csr_double4_t accm[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) accm[t] = csr_double4_t{0.0, 0.0, 0.0, 0.0};
+        const double* yrow_l = rows + (size_t)r * rs;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c0 = (wave * NB + b) * 16 + 4 * q;
+            const csr_double4_t bv = (c0 < d) ? *reinterpret_cast<const csr_double4_t*>(yrow_l + c0) : csr_double4_t{0.0, 0.0, 0.0, 0.0};
+            const double x[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b][t][s], x[s], accm[t], 0, 0, 0);
+        }
+        __syncthreads();                                                  // every wave has read its B operands: rows -> red
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[(size_t)wave * (TT * 4 * 64) + (t * 4 + rr) * 64 + lane] = accm[t][rr];
+        __syncthreads();
+        for (int o = tid; o < TT * 4 * 64; o += R * 64) {
+            double sum = 0.0;
+#pragma unroll
+            for (int v = 0; v < R; ++v) sum += red[(size_t)v * (TT * 4 * 64) + o];   // wave order: deterministic
+            const int l = o & 63, tr = o >> 6;
+            const int type = (tr >> 2) * 16 + (l >> 4) + 4 * (tr & 3);
+            const long long sp = s0 + (l & 15);
+            if (type < K && sp < n) Hout[(size_t)type * ldh + sp] = sum;
+        }
+        __syncthreads();                                                  // red is rows again for the next group
+        beg = nbeg;
+        end = nend;
+    }
+}
+
+static size_t csr_contract_lds(int d, int TT, int sel_words) {
+    const size_t region = std::max<size_t>(16 * ((size_t)d + CSRF_PAD), (size_t)16 * TT * 4 * 64);
+    return region * 8 + 16 * 64 * 8 + (size_t)sel_words * 4;
+}
+
+// shapes the fused kernel takes: the A operands of a wave (NB x TT x 4 doubles) must fit beside the gather's registers
+bool csr_contract_ok(int d, int K, int sel_words) {
+    if (getenv("FDX_CSR_NO_FUSED")) return false;
+    if (d <= 0 || K <= 0 || K > 64 || d % 4 != 0) return false;
+    const int NB = (d + 255) / 256, TT = (K + 15) / 16;
+    if (NB * TT > 4) return false;
+    return csr_contract_lds(d, TT, sel_words) <= 160 * 1024;
+}
+
+template <typename T, int MODE>
+static int launch_csr_contract_m(const long long* indptr, const int* indices, const T* data, const int* row_map, long long n, int d,
+                                 const void* table, const unsigned* sel_bits, int sel_words, const double* Xs, int K, double* H,
+                                 long long ldh, double* row_sumsq, hipStream_t st) {
+    const int NB = (d + 255) / 256, TT = (K + 15) / 16;
+    const size_t lds = csr_contract_lds(d, TT, sel_words);
+    const int grid = (int)std::min<long long>((n + 15) / 16, 256);
+    const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
+    auto launch = [&](auto kern) -> int {
+        if (lds > 64 * 1024)
+            FDX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, indptr, indices, data, row_map, n, d, (const GeneSlot*)table,
+                           sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, no_table);
+        FDX_CHECK_LAUNCH();
+        return 0;
+    };
+    if (NB == 1 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 1, 1>);
+    if (NB == 1 && TT == 2) return launch(sketch_csr_contract_kernel<T, MODE, 1, 2>);
+    if (NB == 1 && TT == 3) return launch(sketch_csr_contract_kernel<T, MODE, 1, 3>);
+    if (NB == 1 && TT == 4) return launch(sketch_csr_contract_kernel<T, MODE, 1, 4>);
+    if (NB == 2 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 2, 1>);
+    if (NB == 2 && TT == 2) return launch(sketch_csr_contract_kernel<T, MODE, 2, 2>);
+    if (NB == 3 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 3, 1>);
+    if (NB == 4 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 4, 1>);
+    return fail(FDX_ERR_UNSUPPORTED, "sketch (CSR, fused): shape not instantiated");
+}
+
+// H[:, 0..n) (type-major, row stride ldh) and row_sumsq[0..n) for the n spots listed by row_map (NULL = rows 0..n-1).
+// Call only when csr_contract_ok(...) holds; Xs must be 32-byte aligned.
+int launch_sketch_csr_contract(const long long* indptr, const int* indices, const void* data, int dtype, const int* row_map,
+                               long long n, int d, int mode, const void* table, const unsigned* sel_bits, int sel_words,
+                               const double* Xs, int K, double* H, long long ldh, double* row_sumsq, hipStream_t st) {
+    if (n <= 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(Xs) & 31) != 0) return fail(FDX_ERR_INVALID, "sketch (CSR, fused): X_sketch must be 32-byte aligned");
+    const bool raw = mode == FDX_PRE_RAW;
+    if (!raw && mode != FDX_PRE_LOG_CPM_SPARSE && mode != FDX_PRE_LOG_CPM) return fail(FDX_ERR_INVALID, "sketch (CSR, fused): unknown preprocess mode");
+    if (dtype == FDX_F32) {
+        const float* y = (const float*)data;
+        return raw ? launch_csr_contract_m<float, FDX_PRE_RAW>(indptr, indices, y, row_map, n, d, table, sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, st)
+                   : launch_csr_contract_m<float, FDX_PRE_LOG_CPM_SPARSE>(indptr, indices, y, row_map, n, d, table, sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, st);
+    }
+    if (dtype == FDX_F64) {
+        const double* y = (const double*)data;
+        return raw ? launch_csr_contract_m<double, FDX_PRE_RAW>(indptr, indices, y, row_map, n, d, table, sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, st)
+                   : launch_csr_contract_m<double, FDX_PRE_LOG_CPM_SPARSE>(indptr, indices, y, row_map, n, d, table, sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, st);
+    }
+    return fail(FDX_ERR_INVALID, "sketch (CSR, fused): dtype must be FDX_F32 or FDX_F64");
+}
+
 // ------------------------------------------------------------------------------------------------ gene statistics
 // z = log1p(y * 1e4 / max(lib, 1)) for every stored entry, then per gene sum z, sum z^2 (and sum y for "pearson").
 // Per-gene sums over a row-major sparse matrix are a scatter; global f64 atomics on ~30k addresses run at ~30 G adds/s

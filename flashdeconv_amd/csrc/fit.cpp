@@ -307,7 +307,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     long long chunk_rows = 1LL << 18;
     if (const char* e = getenv("FDX_FIT_CHUNK")) chunk_rows = std::max<long long>(64, atoll(e));
     const long long chunk = std::min<long long>(n, chunk_rows);
-    const bool fused = !ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, prm->mode_y, plan_y.dev());
+    const bool csr_fused = ysrc.csr && csr_contract_ok(d, K, sel_words);
+    const bool fused = csr_fused || (!ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, prm->mode_y, plan_y.dev()));
     if (!fused) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
     FDX_TRY(solver_zero_pad(dH.as<double>(), ld, n, K, st));   // columns of real spots are all written by the sketch -> H stage
     const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();
@@ -318,6 +319,11 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         FDX_HIP(hipEventCreate(&eS0));
         FDX_HIP(hipEventCreate(&eS1));
         FDX_HIP(hipEventRecord(eS0, st));
+        if (csr_fused)     // CSR rows -> LDS accumulators -> MFMA contraction -> H  (csr_kernels.cpp)
+            FDX_TRY(launch_sketch_csr_contract((const long long*)ysrc.csr->indptr, ysrc.csr->indices, ysrc.csr->data, y_dtype,
+                                               row_map, n, d, prm->mode_y, dSlots.p, dBits.as<unsigned>(), sel_words,
+                                               dXs.as<double>(), K, dH.as<double>(), ld, dRowSq.as<double>(), st));
+        else
         FDX_TRY(launch_sketch_contract(Y_dev, y_dtype, ldy, row_map, n, G, d, prm->mode_y, plan_y.dev(), dXs.as<double>(), K,
                                        dH.as<double>(), ld, dRowSq.as<double>(), st));
         FDX_HIP(hipEventRecord(eS1, st));
