@@ -124,6 +124,16 @@ int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scra
     return 0;
 }
 
+// Will launch_bcd_sweep run the LDS-tiled kernel for these arguments?  (The tile lists of the sharded solve are only
+// honoured by that kernel: the global-gather fallback sweeps every spot.)  Mirrors launch_k in bcd_sweep_inst.cpp with the
+// upper bound of sweep_chunk(K) - a conservative "no" costs the boundary / interior overlap, never correctness.
+bool bcd_sweep_uses_tiles(const BcdSweepArgs& a) {
+    if (!a.tiled || a.K < 1 || a.K > FDX_MAX_K_FAST) return false;
+    const int KC = a.K < 8 ? a.K : 8;
+    return (size_t)KC * (256 + a.halo_max + 1) * sizeof(double) <= 64 * 1024 && (long long)a.ld * 8 < (1LL << 32) &&
+           (long long)a.ldh * 8 < (1LL << 32);
+}
+
 int launch_bcd_objective_tiled(const BcdSweepArgs& a0, double* partials, hipStream_t st) {
     if (!a0.tiled || a0.K < 1 || a0.K > FDX_MAX_K_FAST) return 1;
     const int KC = a0.K < 8 ? a0.K : 8;   // upper bound of sweep_chunk(K)

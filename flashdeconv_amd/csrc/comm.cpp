@@ -82,16 +82,25 @@ struct LocalWorld {
     std::vector<const void*> ptr;                   // mailbox: one pointer per rank
     std::vector<std::vector<long long>> off;        // mailbox: per rank, element offsets per destination (W + 1)
     std::vector<std::vector<unsigned long long>> host;   // mailbox for the reductions
-    void barrier() {
+    bool aborted = false;                           // a rank left its loop on an error: nobody waits for it any more
+    // false when the world was aborted (by this or another rank): the caller returns an error instead of waiting for ever
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const long long gen = generation;
         if (++arrived == W) {
             arrived = 0;
             ++generation;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            cv.wait(lk, [&] { return generation != gen || aborted; });
         }
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
     }
 };
 
@@ -189,7 +198,7 @@ int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, 
             w.ptr[(size_t)c->rank] = send;
             w.off[(size_t)c->rank].assign(send_off.begin(), send_off.end());
         }
-        w.barrier();
+        FDX_REQUIRE(w.barrier(), "sharded solve: another rank failed");
         for (int q = 0; q < W; ++q) {
             const int nr = recv_off[(size_t)q + 1] - recv_off[(size_t)q];
             if (q == c->rank || nr == 0) continue;
@@ -199,7 +208,7 @@ int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, 
             FDX_HIP(hipMemcpyAsync(recv + (size_t)K * recv_off[(size_t)q], src, (size_t)K * nr * 8, hipMemcpyDeviceToDevice, st));
         }
         FDX_HIP(hipStreamSynchronize(st));
-        w.barrier();                                              // nobody overwrites its staging before all have copied
+        FDX_REQUIRE(w.barrier(), "sharded solve: another rank failed");   // nobody overwrites its staging before all have copied
         return 0;
     }
     return 0;
@@ -223,7 +232,7 @@ int allreduce(fdx_comm* c, void* buf, int count, bool is_max, hipStream_t st) {
             std::lock_guard<std::mutex> lk(w.mu);
             w.host[(size_t)c->rank] = mine;
         }
-        w.barrier();
+        FDX_REQUIRE(w.barrier(), "sharded solve: another rank failed");
         std::vector<unsigned long long> out((size_t)count, 0ULL);
         if (is_max) {
             for (int q = 0; q < w.W; ++q)
@@ -238,7 +247,7 @@ int allreduce(fdx_comm* c, void* buf, int count, bool is_max, hipStream_t st) {
                 }
             std::memcpy(out.data(), acc.data(), (size_t)count * 8);
         }
-        w.barrier();                                              // everybody has read the mailbox
+        FDX_REQUIRE(w.barrier(), "sharded solve: another rank failed");   // everybody has read the mailbox
         FDX_HIP(hipMemcpyAsync(buf, out.data(), (size_t)count * 8, hipMemcpyHostToDevice, st));
         FDX_HIP(hipStreamSynchronize(st));
         return 0;
@@ -384,7 +393,7 @@ int fdx_sharded_solve_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, 
         a.tile_hcnt = g->tile_hcnt.as<int>(); a.n_tiles = g->n_tiles; a.halo_max = g->halo_max;
     }
     // boundary-first ordering needs the tiled sweep (tile lists) and somebody to talk to
-    bool split = tiled && total_send > 0 && g->n > 0 && !getenv("FDX_NO_OVERLAP");
+    bool split = tiled && bcd_sweep_uses_tiles(a) && total_send > 0 && g->n > 0 && !getenv("FDX_NO_OVERLAP");
     if (split) {
         FDX_TRY(build_tile_lists(*g, st));
         split = g->n_tiles_boundary > 0 && g->n_tiles_interior > 0;
@@ -458,6 +467,7 @@ int fdx_sharded_solve_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, 
         return 0;
     };
     const int rc = run();
+    if (rc && c->local) c->local->abort();     // the other thread ranks leave their barriers with an error instead of hanging
     (void)hipStreamSynchronize(st);
     if (c->side) (void)hipStreamSynchronize(c->side);
     (void)hipEventDestroy(ev0);

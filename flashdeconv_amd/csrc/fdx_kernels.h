@@ -106,6 +106,7 @@ int launch_normalize_export(const double* beta, long long ld, const int* perm, i
 
 // ---- bcd_kernels.cpp
 int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scratch_ld, hipStream_t st);
+bool bcd_sweep_uses_tiles(const BcdSweepArgs& a);   // tile lists are honoured only then
 // objective through the tiled traversal; returns 1 if not applicable (caller falls back to the generic kernel)
 int launch_bcd_objective_tiled(const BcdSweepArgs& a, double* partials /* (n_tiles, 4) */, hipStream_t st);
 int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, int it, hipStream_t st);

@@ -219,6 +219,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         if (rc) { delete g; return rc; }
         *graph_inout = g;
     }
+    // a deferred build (graph_kernels.cpp) queued on ANOTHER stream: everything below reads the graph's arrays (perm first)
+    if (g->meta_pending && g->meta_event && g->meta_stream != st) FDX_HIP(hipStreamWaitEvent(st, g->meta_event, 0));
     tm.mark();  // 1
 
     // ---- beta0 = 1/K (core/solver.py:372) and the cleared pad rows: nothing depends on anything here, so the two fills go to the

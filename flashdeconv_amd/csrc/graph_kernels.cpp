@@ -937,7 +937,10 @@ struct fdx_graph_plan {
     hipStream_t st = nullptr;      // stream the binning / k-NN kernels were queued on
     fdx::DevBuf indeg, arrival;    // whole graph in one piece: in-degrees and reverse-list places from the k-NN kernel
     fdx::DevBuf ties;              // one int: rows of [lo, hi) with a tie at the k-th neighbour (knn_kernel)
-    ~fdx_graph_plan() { (void)hipStreamSynchronize(st); }   // nothing may still read the buffers when they go back to the pool
+    bool kernels_done = false;     // set by graph_meta_sync: the graph's meta event (recorded behind every kernel that reads
+                                   // the plan) has completed - no stream sync needed, which would also wait for whatever the
+                                   // caller queued behind the build (the sketch kernel of the fit)
+    ~fdx_graph_plan() { if (!kernels_done) (void)hipStreamSynchronize(st); }   // nothing may still read the buffers when they go back to the pool
 };
 fdx_graph::~fdx_graph() {
     if (meta_pending && meta_event) (void)hipEventSynchronize(meta_event);   // queued kernels still write into the buffers below
@@ -1082,7 +1085,7 @@ int graph_meta_sync(const fdx_graph* gc) {
     // the queued kernels are done: their inputs can go
     g->keep_nbr.release();
     g->keep_cnt.release();
-    if (g->keep_plan) { graph_plan_destroy(g->keep_plan); g->keep_plan = nullptr; }
+    if (g->keep_plan) { g->keep_plan->kernels_done = true; graph_plan_destroy(g->keep_plan); g->keep_plan = nullptr; }
     const long long rows = g->meta_host[0] & 0xffffffffLL;
     g->nnz = g->meta_host[1];
     g->max_deg = (int)(g->meta_host[2] & 0xffffffffLL);

@@ -260,7 +260,9 @@ int fdx_type_sums_csr_dev(const fdx_csr_view* Y, const int32_t* rows_dev, const 
  * One process per GPU; the host side (torch.distributed over RCCL) owns the buffers and the halo exchange, these
  * entry points only enqueue kernels on `stream`.  Same reference lines as the single-GPU entries above.           */
 
-/* Graph from coordinates already on the device (method FDX_GRAPH_KNN / FDX_GRAPH_RADIUS). */
+/* Graph from coordinates already on the device (method FDX_GRAPH_KNN / FDX_GRAPH_RADIUS).  A k-NN build may return with its
+ * last kernels still queued on `stream`; every entry point that takes the graph waits for them (the fit entries order their
+ * own stream behind the build when it differs). */
 int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t method, int32_t k, double radius,
                         void* stream, fdx_graph** out);
 /* Spot shards, radius / grid graphs (utils/graph.py:84-212): rows [lo, hi) (solver positions, lo a multiple of 64) of the
