@@ -229,7 +229,7 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
                                                   long long n, GridParams gp, int kk, int* __restrict__ nbr_out,
                                                   int* __restrict__ nbr_cnt, double* __restrict__ nn_dist,
                                                   long long lo, long long hi, int* __restrict__ indeg,
-                                                  int* __restrict__ arrival, int* __restrict__ tie_count) {
+                                                  int* __restrict__ arrival, int* __restrict__ tie_count, int gp_no_batch) {
     const long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;      // rows [lo, hi) of the sorted order
     if (p >= hi) return;
     const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
@@ -241,8 +241,92 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; bq[s] = -1; }
 
+    // insertion of one candidate (sorted by (distance, caller index): the result does not depend on the visiting order)
+    auto consider = [&](double d2, int oi, int q) {
+        if (lex_less(d2, oi, bd[KMAX - 1], bi[KMAX - 1])) {
+            bd[KMAX - 1] = d2; bi[KMAX - 1] = oi; bq[KMAX - 1] = q;
+#pragma unroll
+            for (int s = KMAX - 1; s > 0; --s) {
+                if (lex_less(bd[s], bi[s], bd[s - 1], bi[s - 1])) {
+                    const double td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
+                    const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
+                    const int tq = bq[s]; bq[s] = bq[s - 1]; bq[s - 1] = tq;
+                }
+            }
+        }
+    };
+    // done when the kk-th best is provably inside the block of cells within R of c
+    auto covered = [&](int R) -> bool {
+        bool covers_all = true;
+        double safe = INFINITY;
+        for (int a = 0; a < gp.dim; ++a) {
+            const double slack = 1e-12 * (fabs(pc[a]) + gp.h[a] * (double)gp.nc[a]);
+            if (c[a] - R > 0) {
+                covers_all = false;
+                safe = fmin(safe, pc[a] - (gp.mn[a] + (double)(c[a] - R) * gp.h[a]) - slack);
+            }
+            if (c[a] + R < gp.nc[a] - 1) {
+                covers_all = false;
+                safe = fmin(safe, (gp.mn[a] + (double)(c[a] + R + 1) * gp.h[a]) - pc[a] - slack);
+            }
+        }
+        if (covers_all) return true;
+        // bd[] holds the KMAX best; the kk-th best is bd[kk-1] (selected without dynamic register indexing)
+        double kth = INFINITY;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) if (s == kk - 1) kth = bd[s];
+        return safe > 0.0 && kth < safe * safe;
+    };
+
     const int maxR = max(gp.nc[0], max(gp.nc[1], gp.nc[2]));
-    for (int R = 0; R <= maxR; ++R) {
+    int R_first = 0;
+    bool done = false;
+    if (KMAX <= 16 && gp.dim <= 2 && !gp_no_batch) {
+        // Shells 0 and 1 together (one and two dimensions: the 3 x 3 block of cells, ~36 candidates at ~4 points per cell -
+        // with k <= 8 that block always suffices), as a FLAT candidate list served in batches: the cell extents of all nine
+        // cells in one round trip, then the coordinates of BATCH candidates per round trip.  The shell loop below walks
+        // cell by cell and candidate by candidate, two dependent loads deep each time - ~45 round trips to L2 per point,
+        // which is what the kernel's 300-450 us at 1M points were.
+        int cs[9], ce[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int x = c[0] + (j % 3) - 1, y = c[1] + (j / 3) - 1;
+            const bool ok = x >= 0 && x < gp.nc[0] && y >= 0 && y < gp.nc[1];
+            const int cell = ok ? x * gp.stride[0] + y * gp.stride[1] : 0;
+            cs[j] = ok ? cstart[cell] : 0;
+            ce[j] = ok ? cend[cell] : 0;
+        }
+        int pre[10];
+        pre[0] = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) pre[j + 1] = pre[j] + (ce[j] - cs[j]);
+        const int total = pre[9];
+        constexpr int BATCH = 8;
+        for (int base = 0; base < total; base += BATCH) {
+            int qv[BATCH], ov[BATCH];
+            double xv[BATCH], yv[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u;
+                int q = -1;
+#pragma unroll
+                for (int j = 0; j < 9; ++j)
+                    if (idx >= pre[j] && idx < pre[j + 1]) q = cs[j] + (idx - pre[j]);
+                qv[u] = q;
+                if (q >= 0) {
+                    xv[u] = sc[q];
+                    yv[u] = sc[(size_t)n + q];
+                    ov[u] = perm[q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (qv[u] >= 0) consider(dist2_exact(xv[u] - px, yv[u] - py, 0.0), ov[u], qv[u]);   // planes past dim are zero
+        }
+        done = covered(1);
+        R_first = 2;
+    }
+    for (int R = R_first; R <= maxR && !done; ++R) {
         // visit the shell max_a |dc_a| == R of the cell block around c
         const int lo0 = max(0, c[0] - R), hi0 = min(gp.nc[0] - 1, c[0] + R);
         const int lo1 = max(0, c[1] - R), hi1 = min(gp.nc[1] - 1, c[1] + R);
@@ -257,43 +341,11 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
                     }
                     const int cell = x * gp.stride[0] + y * gp.stride[1] + z * gp.stride[2];
                     const int s0 = cstart[cell], s1 = cend[cell];
-                    for (int q = s0; q < s1; ++q) {
-                        const double d2 = dist2_exact(sc[q] - px, sc[(size_t)n + q] - py, sc[2 * (size_t)n + q] - pz);
-                        const int oi = perm[q];
-                        if (lex_less(d2, oi, bd[KMAX - 1], bi[KMAX - 1])) {
-                            bd[KMAX - 1] = d2; bi[KMAX - 1] = oi; bq[KMAX - 1] = q;
-#pragma unroll
-                            for (int s = KMAX - 1; s > 0; --s) {
-                                if (lex_less(bd[s], bi[s], bd[s - 1], bi[s - 1])) {
-                                    const double td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
-                                    const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
-                                    const int tq = bq[s]; bq[s] = bq[s - 1]; bq[s - 1] = tq;
-                                }
-                            }
-                        }
-                    }
+                    for (int q = s0; q < s1; ++q)
+                        consider(dist2_exact(sc[q] - px, sc[(size_t)n + q] - py, sc[2 * (size_t)n + q] - pz), perm[q], q);
                 }
             }
-        // done when the kk-th best is provably inside the scanned block
-        bool covers_all = true;
-        double safe = INFINITY;
-        for (int a = 0; a < gp.dim; ++a) {
-            const double slack = 1e-12 * (fabs(pc[a]) + gp.h[a] * (double)gp.nc[a]);
-            if (c[a] - R > 0) {
-                covers_all = false;
-                safe = fmin(safe, pc[a] - (gp.mn[a] + (double)(c[a] - R) * gp.h[a]) - slack);
-            }
-            if (c[a] + R < gp.nc[a] - 1) {
-                covers_all = false;
-                safe = fmin(safe, (gp.mn[a] + (double)(c[a] + R + 1) * gp.h[a]) - pc[a] - slack);
-            }
-        }
-        if (covers_all) break;
-        // bd[] holds the KMAX best; the kk-th best is bd[kk-1] (selected without dynamic register indexing)
-        double kth = INFINITY;
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) if (s == kk - 1) kth = bd[s];
-        if (safe > 0.0 && kth < safe * safe) break;
+        done = covered(R);
     }
     if (nn_dist) {   // distance to the nearest OTHER point (entry 0 is self unless points coincide)
         double d1 = INFINITY;
@@ -903,7 +955,7 @@ static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int
     if (hi <= lo) return;
     hipLaunchKernelGGL(knn_kernel<KMAX>, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), perm,
                        b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
-                       KMAX > kk ? ties : nullptr);
+                       KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0);
 }
 
 template <int KMAX>
