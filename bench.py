@@ -146,7 +146,7 @@ def alg_bytes(n, G, K, s_y, nnz, n_slices_width_rows, T):
     return sketch, sweep
 
 
-TRAFFIC_PROFILE = "profiles/r02_traffic.json"
+TRAFFIC_PROFILE = "profiles/r03_traffic.json"
 
 
 def pmc_traffic(kernel, shape):
@@ -181,13 +181,18 @@ def sweep_kernel_name(K):
 
 def sketch_kernel_name(mode, K, d=512):
     """Kernel that serves the sketch -> H stage of the bench shapes (csrc/tile_kernels.cpp: tile_cfg): template arguments
-    <input type, preprocess, consumer waves, loader waves, groups per wave, type tiles, A operands from L2>."""
+    <input type, preprocess, consumer waves, loader waves, groups per wave, type tiles, A operands from L2, log1p class
+    (2 = float32-class for float32 rows), experiment switch>."""
     cfg = os.environ.get("FDX_TILE_CFG")
     nwc, nwl, jw = {"12": (12, 4, 11), "16": (16, 0, 8), "8": (8, 2, 16)}.get(cfg, (12, 4, 11) if mode == 0 else (16, 0, 8))
-    tt, avl2 = -(-K // 16), mode != 0 and nwc == 16
+    logv = 0 if (mode == 0 or os.environ.get("FDX_TILE_LOGV") == "0") else 2
+    tt = -(-K // 16)
+    avl2 = mode != 0 and nwc == 16 and (logv == 0 or bool(os.environ.get("FDX_TILE_AVL2")))
+    if nwc != 16 and nwc != 12:
+        logv = 0
     if K > 32 or d > 4 * nwc * jw:                 # wide form
         (nwc, nwl, jw), tt, avl2 = ((12, 4, 22) if mode == 0 else (8, 0, 32)), 4, True
-    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d, %s>" % (mode, nwc, nwl, jw, tt, "true" if avl2 else "false")
+    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d, %s, %d, 0>" % (mode, nwc, nwl, jw, tt, "true" if avl2 else "false", logv)
 
 
 def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):

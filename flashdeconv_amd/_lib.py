@@ -138,6 +138,7 @@ SIGNATURES = {
     "fdx_graph_destroy": (c_int, [c_void_p]),
     "fdx_graph_info": (c_int, [c_void_p, p_i64, p_i64, p_i32]),
     "fdx_graph_knn_ties": (c_int, [c_void_p, p_i64]),
+    "fdx_ckdtree_knn": (c_int, [p_double, c_i64, c_i32, c_i32, c_void_p, c_void_p]),
     "fdx_bcd_solve": (c_int, [c_void_p, p_double, p_double, c_i64, c_i32, c_i32, c_double, c_double, c_i32, c_double,
                               c_i32, p_double, p_double, p_double, ctypes.POINTER(SolveInfo)]),
 }

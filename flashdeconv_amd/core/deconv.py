@@ -67,7 +67,7 @@ class FlashDeconv:
 
     def __init__(self, sketch_dim=512, lambda_spatial="auto", rho_sparsity=0.01, n_hvg=2000, n_markers_per_type=50,
                  spatial_method="knn", k_neighbors=6, radius=None, max_iter=100, tol=1e-4, preprocess="log_cpm",
-                 random_state=0, verbose=False):
+                 random_state=0, verbose=False, knn_ties="index"):
         if sketch_dim <= 0:
             raise ValueError(f"sketch_dim must be positive, got {sketch_dim}")
         if k_neighbors < 0:
@@ -101,6 +101,11 @@ class FlashDeconv:
         self.preprocess = preprocess
         self.random_state = random_state
         self.verbose = verbose
+        # additive (not in the reference): how exactly equidistant candidates for the k-th neighbour are taken - "index":
+        # ascending spot index (device rule; a warning reports them), "ckdtree": as the reference's cKDTree query does
+        if knn_ties not in ("index", "ckdtree"):
+            raise ValueError(f"knn_ties must be 'index' or 'ckdtree', got {knn_ties}")
+        self.knn_ties = knn_ties
 
         self.beta_ = None
         self.proportions_ = None
@@ -256,6 +261,19 @@ class FlashDeconv:
             gh = ctypes.c_void_p()
             _lib.check(lib.fdx_graph_build_dev(c_ptr, n, dim, g_method, g_k, g_radius, None, ctypes.byref(gh)))
             self._graph = _lib.Graph(gh.value)
+            n_ties = 0
+            if self.spatial_method == "knn" and self.knn_ties == "ckdtree":
+                # the reference's tie order, on request: only when the device build met ties (this question waits for the
+                # build, which otherwise completes behind the sketch) the lists come from the host restatement of scipy's
+                # tree (csrc/kdtree_order.cpp) and the graph is rebuilt from the reference's own adjacency
+                n_ties = self._graph.knn_ties()
+                if n_ties:
+                    from ..utils.graph import ckdtree_knn_adjacency
+                    ch = coords_host if coords_host is not None else coords.detach().cpu().numpy().astype(np.float64)
+                    A = ckdtree_knn_adjacency(ch, int(self.k_neighbors))
+                    self._graph.close()
+                    self._graph = _lib.Graph.from_csr(A.indptr, A.indices, n)
+                    self._adjacency = A
             t_lev = time.perf_counter()
             leverage = lev_job.result()
             t_done = time.perf_counter()
@@ -360,15 +378,17 @@ class FlashDeconv:
         # additive (not in the reference): spots whose k-NN set is a choice - the k-th and (k+1)-th neighbours exactly
         # equidistant.  The reference takes whichever cKDTree.query meets first (utils/graph.py:60-63), which changes
         # with the order the spots are listed in; here the lower spot index wins.  Regular lattices tie on every spot.
-        self.info_["knn_ties"] = self._graph.knn_ties() if self.spatial_method == "knn" else 0
-        if self.info_["knn_ties"]:
+        resolved = self.spatial_method == "knn" and self.knn_ties == "ckdtree"
+        self.info_["knn_ties"] = (n_ties if resolved else self._graph.knn_ties()) if self.spatial_method == "knn" else 0
+        if self.info_["knn_ties"] and not resolved:
             import warnings
             warnings.warn(
                 f"k-NN ties: {self.info_['knn_ties']} of {n} spots have their k-th and (k+1)-th nearest neighbours at exactly "
                 "the same distance (regular lattice?), so the neighbour graph depends on how ties are broken - here by "
                 "spot index, in the reference by cKDTree's traversal, i.e. by the order the spots are listed in.  "
-                "Proportions can differ from the reference's by a few 1e-4 (relative); spatial_method='grid' builds a "
-                "tie-free graph on lattices.", UserWarning, stacklevel=2)
+                "Proportions can differ from the reference's by a few 1e-4 (relative); knn_ties='ckdtree' reproduces the "
+                "reference's choice (host-side, seconds at a million spots), spatial_method='grid' builds a tie-free graph "
+                "on lattices.", UserWarning, stacklevel=2)
         # additive diagnostics (not in the reference): per-stage GPU milliseconds
         self.timings_ = {k: float(getattr(info, k)) for k in ("graph_ms", "sketch_ms", "gram_ms", "solve_ms", "finish_ms", "total_ms")}
         self.timings_["sweep_ms"] = float(info.solve.sweep_ms)

@@ -1,0 +1,261 @@
+// Which of several EXACTLY equidistant points does the reference's k-nearest-neighbour query return?
+//
+// flashdeconv/utils/graph.py:60-63 builds `cKDTree(coords)` and calls `tree.query(coords, k = k + 1)`; on a regular lattice
+// (Visium-HD bins: four neighbours at distance 1, four at sqrt 2, k = 6) the k-th neighbour is one of several at the same
+// distance, and which ones come back is decided by nothing but the order in which scipy's tree visits the points.  The
+// device build (graph_kernels.cpp) breaks such ties by spot index; with knn_ties="ckdtree" the Python driver asks this file
+// instead whenever fdx_graph_knn_ties() reports ties, and gets the reference's neighbour lists index for index.
+//
+// This is a host restatement of the published algorithm of scipy.spatial.cKDTree (third-party dependency of the reference,
+// scipy >= 1.7 per its pyproject; checked here against scipy 1.15.3, the version of the build container) for exactly that
+// call: tree construction with the constructor's defaults (leafsize 16, compact_nodes, balanced_tree) and the k-nearest
+// query with p = 2, eps = 0, no distance bound.  What has to be reproduced is ORDER, so the restatement keeps every
+// order-defining detail:
+//   build   - recursive; bounds of a node recomputed from its points; split dimension = largest spread (first wins);
+//             median by std::nth_element over the node's index range, compared by the coordinate alone, at
+//             position n/2; split value = coordinate of that element; then a Hoare-style pass moving "< split" left and
+//             ">= split" right (on a lattice many points equal the split: they all go right); empty-side repair by the
+//             minimum / maximum element; children [start, p) and [p, end).  The index array after all of this is the order
+//             in which a leaf's points are tested.  (std::nth_element is libstdc++'s introselect here as in scipy's
+//             manylinux wheels.)
+//   query   - best-first over nodes with scipy's own binary heap (strict comparisons: ties keep insertion structure),
+//             near child followed directly, far child pushed when its distance <= the current k-th distance; a leaf's
+//             points are tested in index-array order and accepted when d < bound (strict), the bound being the k-th
+//             distance once k neighbours are known - so among equidistant candidates the ones met FIRST stay.
+//             Squared distances accumulated coordinate by coordinate from zero, side distances updated incrementally
+//             (min_distance += new - old) exactly as the library does, because equality decides here.
+// tests/test_host.py compares this entry with scipy itself (index arrays of the tree and query results) on lattices,
+// duplicated points, random clouds in 1-3 dimensions - no GPU involved.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "fdx_internal.h"
+
+namespace fdx {
+namespace {
+
+struct KdNode {
+    long long split_dim = -1;     // -1: leaf
+    double split = 0.0;
+    long long start = 0, end = 0;
+    long long less = -1, greater = -1;
+};
+
+struct KdTree {
+    const double* data = nullptr;
+    long long n = 0;
+    int m = 0;
+    long long leafsize = 16;
+    std::vector<long long> indices;
+    std::vector<KdNode> nodes;
+    std::vector<double> maxes, mins;   // of the whole data set
+};
+
+long long kd_build(KdTree& t, long long start, long long end, double* maxes, double* mins) {
+    const int m = t.m;
+    const double* data = t.data;
+    long long* indices = t.indices.data();
+    t.nodes.emplace_back();
+    const long long node_index = (long long)t.nodes.size() - 1;
+    t.nodes[(size_t)node_index].start = start;
+    t.nodes[(size_t)node_index].end = end;
+    if (end - start <= t.leafsize) return node_index;                 // leaf
+    // compact nodes: bounds from the node's own points
+    for (int i = 0; i < m; ++i) maxes[i] = mins[i] = data[indices[start] * m + i];
+    for (long long j = start + 1; j < end; ++j)
+        for (int i = 0; i < m; ++i) {
+            const double v = data[indices[j] * m + i];
+            maxes[i] = maxes[i] > v ? maxes[i] : v;
+            mins[i] = mins[i] < v ? mins[i] : v;
+        }
+    int d = 0;
+    double size = 0.0;
+    for (int i = 0; i < m; ++i)
+        if (maxes[i] - mins[i] > size) { d = i; size = maxes[i] - mins[i]; }
+    if (maxes[d] == mins[d]) return node_index;                       // all points identical: leaf
+    // median split (balanced tree)
+    const long long half = (end - start) / 2;
+    // the comparator of scipy 1.15.3 is the coordinate alone (no index tie-break: checked against the library's index array
+    // on lattices - with one the leaves come out in another order), so equal coordinates fall where introselect leaves them
+    auto cmp = [data, m, d](long long a, long long b) { return data[a * m + d] < data[b * m + d]; };
+    std::nth_element(indices + start, indices + start + half, indices + end, cmp);
+    double split = data[indices[start + half] * m + d];
+    long long p = start, q = end - 1;
+    while (p <= q) {
+        if (data[indices[p] * m + d] < split) ++p;
+        else if (data[indices[q] * m + d] >= split) --q;
+        else { std::swap(indices[p], indices[q]); ++p; --q; }
+    }
+    if (p == start) {                                                 // nothing below the split: the minimum goes left alone
+        long long j = start;
+        split = data[indices[j] * m + d];
+        for (long long i = start + 1; i < end; ++i)
+            if (data[indices[i] * m + d] < split) { j = i; split = data[indices[j] * m + d]; }
+        std::swap(indices[start], indices[j]);
+        p = start + 1;
+    } else if (p == end) {                                            // nothing at or above it: the maximum goes right alone
+        long long j = end - 1;
+        split = data[indices[j] * m + d];
+        for (long long i = start; i < end - 1; ++i)
+            if (data[indices[i] * m + d] > split) { j = i; split = data[indices[j] * m + d]; }
+        std::swap(indices[end - 1], indices[j]);
+        p = end - 1;
+    }
+    const long long less = kd_build(t, start, p, maxes, mins);
+    const long long greater = kd_build(t, p, end, maxes, mins);
+    KdNode& nd = t.nodes[(size_t)node_index];                         // (the vector may have moved)
+    nd.split_dim = d;
+    nd.split = split;
+    nd.less = less;
+    nd.greater = greater;
+    return node_index;
+}
+
+// scipy's heap (ckdtree/src/ordered.h): binary min-heap on `priority`, strict comparisons
+struct HeapItem {
+    double priority;
+    long long payload;
+};
+struct Heap {
+    std::vector<HeapItem> h;
+    long long n = 0;
+    void push(const HeapItem& item) {
+        ++n;
+        if ((long long)h.size() < n) h.resize((size_t)(2 * h.size() + 1));
+        long long i = n - 1;
+        h[(size_t)i] = item;
+        while (i > 0 && h[(size_t)i].priority < h[(size_t)((i - 1) / 2)].priority) {
+            std::swap(h[(size_t)((i - 1) / 2)], h[(size_t)i]);
+            i = (i - 1) / 2;
+        }
+    }
+    const HeapItem& peek() const { return h[0]; }
+    void remove() {
+        h[0] = h[(size_t)(n - 1)];
+        --n;
+        const long long nn = n;
+        long long i = 0, j = 1, k = 2;
+        while ((j < nn && h[(size_t)i].priority > h[(size_t)j].priority) || (k < nn && h[(size_t)i].priority > h[(size_t)k].priority)) {
+            const long long l = (k < nn && h[(size_t)j].priority > h[(size_t)k].priority) ? k : j;
+            std::swap(h[(size_t)l], h[(size_t)i]);
+            i = l;
+            j = 2 * i + 1;
+            k = 2 * i + 2;
+        }
+    }
+    HeapItem pop() {
+        const HeapItem it = h[0];
+        remove();
+        return it;
+    }
+};
+
+struct NodeInfo {
+    long long node;
+    double min_distance;
+    double side[3];
+};
+
+void kd_query_one(const KdTree& t, const double* x, int kmax, int64_t* out_idx, std::vector<NodeInfo>& pool, Heap& q,
+                  Heap& neighbors) {
+    const int m = t.m;
+    pool.clear();
+    q.n = 0;
+    neighbors.n = 0;
+    double upper = HUGE_VAL;
+    pool.push_back(NodeInfo{0, 0.0, {0.0, 0.0, 0.0}});
+    {
+        NodeInfo& r = pool[0];
+        for (int i = 0; i < m; ++i) {
+            // distance from x to the interval [min, max] of the whole data set, to the power p = 2
+            double sd = std::max(0.0, std::max(t.mins[(size_t)i] - x[i], x[i] - t.maxes[(size_t)i]));
+            sd = sd * sd;
+            r.min_distance += sd - r.side[i];
+            r.side[i] = sd;
+        }
+    }
+    long long cur = 0;                                                // index into pool
+    for (;;) {
+        const KdNode& nd = t.nodes[(size_t)pool[(size_t)cur].node];
+        if (nd.split_dim == -1) {
+            for (long long i = nd.start; i < nd.end; ++i) {
+                const double* y = t.data + t.indices[(size_t)i] * m;
+                double d = 0.0;
+                for (int a = 0; a < m; ++a) {
+                    const double diff = y[a] - x[a];
+                    d += diff * diff;
+                }
+                if (d < upper) {
+                    if (neighbors.n == kmax) neighbors.remove();
+                    neighbors.push(HeapItem{-d, t.indices[(size_t)i]});
+                    if (neighbors.n == kmax) upper = -neighbors.peek().priority;
+                }
+            }
+            if (q.n == 0) break;
+            cur = q.pop().payload;
+        } else {
+            if (pool[(size_t)cur].min_distance > upper) break;         // the nearest remaining cell is too far: done
+            pool.push_back(pool[(size_t)cur]);                         // ni2 = copy of ni1 (side distances included)
+            long long far = (long long)pool.size() - 1;
+            const int sd_dim = (int)nd.split_dim;
+            double side_distance;
+            if (x[sd_dim] < nd.split) {
+                pool[(size_t)cur].node = nd.less;
+                pool[(size_t)far].node = nd.greater;
+                side_distance = nd.split - x[sd_dim];
+            } else {
+                pool[(size_t)cur].node = nd.greater;
+                pool[(size_t)far].node = nd.less;
+                side_distance = x[sd_dim] - nd.split;
+            }
+            side_distance = side_distance * side_distance;
+            NodeInfo& f = pool[(size_t)far];
+            f.min_distance += side_distance - f.side[sd_dim];
+            f.side[sd_dim] = side_distance;
+            if (pool[(size_t)cur].min_distance > pool[(size_t)far].min_distance) std::swap(cur, far);   // ni1 = the closer one
+            if (pool[(size_t)far].min_distance <= upper) q.push(HeapItem{pool[(size_t)far].min_distance, far});
+        }
+    }
+    // neighbours, nearest first (heap order decides among equal distances, as in the library)
+    const long long nnb = neighbors.n;
+    std::vector<HeapItem> sorted((size_t)kmax);
+    for (long long i = neighbors.n - 1; i >= 0; --i) sorted[(size_t)i] = neighbors.pop();
+    for (int i = 0; i < kmax; ++i) out_idx[i] = i < nnb ? sorted[(size_t)i].payload : -1;
+}
+
+}  // namespace
+}  // namespace fdx
+
+// include/fdx.h
+extern "C" int fdx_ckdtree_knn(const double* coords, int64_t n, int32_t dim, int32_t kk, int64_t* idx_out, int64_t* tree_indices_out) {
+    using namespace fdx;
+    FDX_REQUIRE(coords && idx_out && n >= 1 && dim >= 1 && dim <= 3 && kk >= 1, "fdx_ckdtree_knn: bad arguments");
+    KdTree t;
+    t.data = coords;
+    t.n = n;
+    t.m = dim;
+    t.indices.resize((size_t)n);
+    for (long long i = 0; i < n; ++i) t.indices[(size_t)i] = i;
+    t.maxes.assign((size_t)dim, 0.0);
+    t.mins.assign((size_t)dim, 0.0);
+    for (int a = 0; a < dim; ++a) t.maxes[(size_t)a] = t.mins[(size_t)a] = coords[a];
+    for (long long i = 1; i < n; ++i)
+        for (int a = 0; a < dim; ++a) {
+            const double v = coords[i * dim + a];
+            t.maxes[(size_t)a] = std::max(t.maxes[(size_t)a], v);
+            t.mins[(size_t)a] = std::min(t.mins[(size_t)a], v);
+        }
+    t.nodes.reserve((size_t)(2 * (n / 8) + 16));
+    std::vector<double> mx(t.maxes), mn(t.mins);
+    kd_build(t, 0, n, mx.data(), mn.data());
+    if (tree_indices_out) std::memcpy(tree_indices_out, t.indices.data(), (size_t)n * sizeof(int64_t));
+    std::vector<NodeInfo> pool;
+    Heap q, nb;
+    q.h.resize(12);
+    nb.h.resize((size_t)kk);
+    for (long long i = 0; i < n; ++i) kd_query_one(t, coords + i * dim, kk, idx_out + i * kk, pool, q, nb);
+    return 0;
+}

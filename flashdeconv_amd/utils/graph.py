@@ -8,7 +8,9 @@
     coords_to_adjacency  <- utils/graph.py:175-212
 
 Coordinates with 1, 2 or 3 columns are supported on the device.  On exactly tied distances (regular lattices) the
-k-th neighbour is chosen by the lower spot index, whereas the reference inherits cKDTree's traversal order.
+k-th neighbour is chosen by the lower spot index, whereas the reference inherits cKDTree's traversal order;
+``ties="ckdtree"`` reproduces that order (``ckdtree_knn_adjacency``: a host restatement of scipy's tree, used only when
+the device build reports ties).
 """
 import numpy as np
 from scipy import sparse
@@ -37,7 +39,36 @@ def knn_graph_handle(coords, k=6):
     return _lib.Graph.from_coords_knn(coords, k)
 
 
-def build_knn_graph(coords, k=6, include_self=False):
+def ckdtree_knn_lists(coords, k):
+    """(n, k + 1) neighbour indices exactly as ``cKDTree(coords).query(coords, k=k+1)`` returns them (utils/graph.py:60-63),
+    ties included: libfdx's host restatement of scipy's tree build and traversal order (csrc/kdtree_order.cpp)."""
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    n, dim = coords.shape
+    kk = min(int(k), n - 1) + 1
+    idx = np.empty((n, kk), dtype=np.int64)
+    _lib.check(_lib.load().fdx_ckdtree_knn(_lib.ptr_f64(coords), n, dim, kk, idx.ctypes.data, None))
+    return idx
+
+
+def ckdtree_knn_adjacency(coords, k):
+    """The reference's k-NN adjacency from those lists: self dropped, ones, A + A^T, binary (utils/graph.py:66-81)."""
+    idx = ckdtree_knn_lists(coords, k)
+    n, kk = idx.shape
+    rows = np.repeat(np.arange(n), kk)
+    cols = idx.ravel()
+    keep = rows != cols
+    A = sparse.csr_matrix((np.ones(int(keep.sum())), (rows[keep], cols[keep])), shape=(n, n))
+    A = (A + A.T).tocsr()
+    A.data[:] = 1.0
+    A.sort_indices()
+    return A
+
+
+def build_knn_graph(coords, k=6, include_self=False, ties="index"):
+    """``ties``: "index" - equidistant candidates for the k-th place are taken by ascending spot index (device rule);
+    "ckdtree" - as the reference's cKDTree query takes them (only looked at when the device build found ties)."""
+    if ties not in ("index", "ckdtree"):
+        raise ValueError(f"Unknown ties rule: {ties}. Choose from 'index', 'ckdtree'.")
     coords = np.asarray(coords, dtype=np.float64)
     _validate_coords(coords)
     n = coords.shape[0]
@@ -47,7 +78,10 @@ def build_knn_graph(coords, k=6, include_self=False):
         return sparse.csr_matrix((n, n), dtype=np.float64)
     g = knn_graph_handle(coords, k)
     try:
-        A = _to_csr(g, n)
+        if ties == "ckdtree" and g.knn_ties() > 0:
+            A = ckdtree_knn_adjacency(coords, k)
+        else:
+            A = _to_csr(g, n)
     finally:
         g.close()
     if include_self:

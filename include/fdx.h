@@ -141,6 +141,13 @@ int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_de
  * library keeps the lower spot index.  Regular lattices (Visium-HD bins, k = 6) tie on every spot.  0 for graphs
  * built from a radius or a given adjacency, and for k_neighbors = 63 (no spare slot). */
 int fdx_graph_knn_ties(const fdx_graph* g, int64_t* ties);
+/* The neighbour lists the REFERENCE gets on such inputs: a host restatement of scipy.spatial.cKDTree(coords) with the
+ * constructor's defaults followed by tree.query(coords, k = kk) with p = 2 (utils/graph.py:60-63), reproducing the order in
+ * which the library meets equidistant points - hence which of them it returns.  coords: HOST (n, dim) row-major f64,
+ * dim 1..3; idx_out: HOST (n, kk) int64, row i = the kk nearest of point i (itself included), nearest first, -1 padded
+ * when n < kk; tree_indices_out: optional HOST int64[n], the tree's index array (tests compare it with scipy's).  Pure
+ * host code, serial, O(n log n): for the opt-in knn_ties="ckdtree" of the Python driver when fdx_graph_knn_ties() > 0. */
+int fdx_ckdtree_knn(const double* coords, int64_t n, int32_t dim, int32_t kk, int64_t* idx_out, int64_t* tree_indices_out);
 
 /* ---- solver (replaces core/solver.py:287-428 bcd_solve and everything it calls) ---------------------- */
 typedef struct fdx_solve_info {

@@ -355,6 +355,37 @@ def test_tl_deconvolve_anndata_surface():
         fd.tl.deconvolve(st, ref, cell_type_key="nope")
 
 
+@pytest.mark.parametrize("name", ["square_k6", "hex_k6", "square100_k6"])
+def test_lattice_k6_with_the_reference_tie_order_is_exact(name):
+    """knn_ties="ckdtree": on lattices where the k-th neighbour is tied (square: every spot) the neighbour lists come from
+    the host restatement of scipy's cKDTree order (csrc/kdtree_order.cpp) - the adjacency is then the reference's index
+    for index and the fit agrees at the usual 1e-8 (the device's own tie rule leaves 4.5e-4 / 3.1e-4, see below).  No
+    warning in this mode; the tie count stays in info_."""
+    import warnings
+    from flashdeconv_amd import FlashDeconv
+    g = load_golden("lattice.npz")
+    coords = g[f"{name}_coords"]
+    Y, X, _, _ = datagen.count_like(coords.shape[0], 400, 5, 0.1, int(g[f"{name}_seed"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m = FlashDeconv(sketch_dim=64, preprocess="log_cpm", n_hvg=2000, spatial_method="knn", k_neighbors=6, max_iter=30,
+                        knn_ties="ckdtree").fit(Y, X, coords)
+    A = m.adjacency_
+    assert np.array_equal(A.indptr, g[f"{name}_indptr"]) and np.array_equal(A.indices, g[f"{name}_indices"])
+    assert m.info_["knn_ties"] > 0 and m.info_["n_iterations"] == int(g[f"{name}_n_iter"])
+    np.testing.assert_allclose(m.lambda_used_, float(g[f"{name}_lambda"]), rtol=1e-10)
+    assert rel_fro(m.beta_, g[f"{name}_beta"]) < 1e-8 and rel_fro(m.proportions_, g[f"{name}_props"]) < 1e-8
+    # a tie-free input is untouched by the option: the device graph stays
+    rs = np.random.RandomState(1)
+    c2 = rs.rand(500, 2) * 22
+    Y2, X2, _, _ = datagen.count_like(500, 300, 4, 0.1, 2)
+    a = FlashDeconv(sketch_dim=32, max_iter=10, knn_ties="ckdtree").fit(Y2, X2, c2)
+    b = FlashDeconv(sketch_dim=32, max_iter=10).fit(Y2, X2, c2)
+    assert a.info_["knn_ties"] == 0 and np.array_equal(a.beta_, b.beta_)
+    with pytest.raises(ValueError, match="knn_ties"):
+        FlashDeconv(knn_ties="lapack")
+
+
 def _lattice_case(name):
     from flashdeconv_amd import FlashDeconv
     g = load_golden("lattice.npz")

@@ -289,3 +289,43 @@ def test_bench_sweep_chunk_mirrors_the_kernel_table():
     for K in range(1, 65):
         want = K if K < 8 else c_table(K)
         assert bench.sweep_chunk(K) == want, K
+
+
+@pytest.mark.parametrize("case", ["square", "square_scaled", "hex", "cube3d", "random2d", "random3d", "line", "duplicates",
+                                  "square_shuffled", "rect_large"])
+def test_ckdtree_order_restatement_matches_scipy(case):
+    """fdx_ckdtree_knn (csrc/kdtree_order.cpp) is a host restatement of scipy.spatial.cKDTree's build and k-nearest query
+    ORDER - what decides the reference's neighbour graph when distances tie exactly (flashdeconv/utils/graph.py:60-63).
+    Against scipy itself: the tree's index array and the query result, index for index and in the same order, on lattices
+    (every k-th neighbour tied), duplicated points, shuffled spot order and tie-free clouds.  Pure host code: no GPU."""
+    from scipy.spatial import cKDTree
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(3)
+    sq = np.stack(np.meshgrid(np.arange(30.0), np.arange(30.0), indexing="ij"), -1).reshape(-1, 2)
+    coords, kk = {
+        "square": (sq, 7),
+        "square_scaled": (sq * 100.0 + 0.25, 7),
+        "hex": (np.array([(c + 0.5 * (r & 1), r * np.sqrt(3.0) / 2.0) for r in range(28) for c in range(28)]), 7),
+        "cube3d": (np.stack(np.meshgrid(*[np.arange(11.0)] * 3, indexing="ij"), -1).reshape(-1, 3), 9),
+        "random2d": (rs.rand(4000, 2) * 60.0, 7),
+        "random3d": (rs.rand(2500, 3) * 9.0, 16),
+        "line": (rs.rand(400, 1), 3),
+        "duplicates": (np.concatenate([rs.rand(300, 2), rs.rand(100, 2).repeat(3, axis=0)]), 5),
+        "square_shuffled": (sq[rs.permutation(len(sq))], 7),
+        "rect_large": (np.stack(np.meshgrid(np.arange(211.0), np.arange(97.0), indexing="ij"), -1).reshape(-1, 2), 7),
+    }[case]
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    n, dim = coords.shape
+    got = np.empty((n, kk), dtype=np.int64)
+    order = np.empty(n, dtype=np.int64)
+    _lib.check(lib.fdx_ckdtree_knn(_lib.ptr_f64(coords), n, dim, kk, got.ctypes.data, order.ctypes.data))
+    tree = cKDTree(coords)
+    _, want = tree.query(coords, k=kk)
+    assert np.array_equal(order, tree.indices)
+    assert np.array_equal(got, want)
+    # and the adjacency the reference builds from it (utils/graph.py:66-81)
+    from flashdeconv_amd.utils.graph import ckdtree_knn_adjacency
+    import fdx_oracle as orc
+    A, B = ckdtree_knn_adjacency(coords, kk - 1), orc.knn_graph_kdtree(coords, kk - 1)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
