@@ -256,6 +256,7 @@ class ShardedFlashDeconv:
         self._native = None           # fdx_comm handle: the C++ / RCCL iteration loop (csrc/comm.cpp)
         self._full = self._local = None
         self.timings_ = {}
+        self.knn_ties_ = 0
         self._profile = bool(os.environ.get("FDX_DIST_TIMING"))
 
     def native_comm(self):
@@ -307,6 +308,7 @@ class ShardedFlashDeconv:
         from .utils.genes import LeverageJob
         lib = _lib.load()
         self._lev_job = None
+        self.knn_ties_ = 0
         if X is not None:
             Xj = np.ascontiguousarray(X, dtype=np.float64)
             if Xj.shape[1] <= self.n_hvg:
@@ -350,9 +352,12 @@ class ShardedFlashDeconv:
             _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()),
                                                         ctypes.c_void_p(cnt.data_ptr()), lo, hi, st, ctypes.byref(h)))
             self._full = _lib.Graph(h.value)
-            own_nnz = torch.tensor([float(self._full.info()[1])], dtype=torch.float64, device=coords.device)
-            self.comm.all_reduce_sum(own_nnz)                               # nnz of the whole graph (auto lambda)
-            self.nnz_total = int(round(float(own_nnz.item())))
+            # nnz of the whole graph (auto lambda) and, in the same all-reduce, the spots whose k-th neighbour is tied
+            own_nnz = torch.tensor([float(self._full.info()[1]), float(self._full.knn_ties())], dtype=torch.float64,
+                                   device=coords.device)
+            self.comm.all_reduce_sum(own_nnz)
+            tot = own_nnz.cpu().numpy()
+            self.nnz_total, self.knn_ties_ = int(round(float(tot[0]))), int(round(float(tot[1])))
         else:
             # "radius" / "grid" resolve their radius exactly as FlashDeconv does (utils/graph.py:163-212)
             method, gk, gradius = self._proto._graph_request(coords, None)
@@ -370,7 +375,14 @@ class ShardedFlashDeconv:
                                                    ctypes.byref(h)))
                 self._full = _lib.Graph(h.value)
                 self.nnz_total = self._full.info()[1]
+                self.knn_ties_ = self._full.knn_ties() if method == _lib.GRAPH_KNN else 0
         t0 = self._tick("plan_build", t0)
+        if getattr(self, "knn_ties_", 0) and self.comm.rank == 0:
+            import warnings
+            warnings.warn(f"k-NN ties: {self.knn_ties_} of {n} spots have their k-th and (k+1)-th nearest neighbours at exactly the "
+                          "same distance (regular lattice?): the neighbour graph depends on how ties are broken - here by spot "
+                          "index, in the reference by cKDTree's traversal order.  spatial_method='grid' builds a tie-free graph "
+                          "on lattices.", UserWarning, stacklevel=2)
         self.n_total_spots = n
         hl = ctypes.c_void_p()
         _lib.check(lib.fdx_graph_localize(self._full.handle, self.comm.world, _lib.ptr_i64(self.bounds), self.comm.rank, st,
