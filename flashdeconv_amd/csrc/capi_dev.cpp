@@ -13,27 +13,6 @@
 
 using namespace fdx;
 
-namespace {
-int csc_from_tables(const int32_t* bucket, const double* weight, int G, int d, std::vector<long long>* col_ptr,
-                    std::vector<int>* gene_idx, std::vector<double>* w) {
-    col_ptr->assign((size_t)d + 1, 0);
-    for (int g = 0; g < G; ++g) {
-        FDX_REQUIRE(bucket[g] >= 0 && bucket[g] < d, "bucket index out of range");
-        (*col_ptr)[(size_t)bucket[g] + 1]++;
-    }
-    for (int c = 0; c < d; ++c) (*col_ptr)[(size_t)c + 1] += (*col_ptr)[(size_t)c];
-    gene_idx->assign((size_t)G, 0);
-    w->assign((size_t)G, 0.0);
-    std::vector<long long> cur(col_ptr->begin(), col_ptr->end() - 1);
-    for (int g = 0; g < G; ++g) {
-        const long long e = cur[(size_t)bucket[g]]++;
-        (*gene_idx)[(size_t)e] = g;
-        (*w)[(size_t)e] = weight[g];
-    }
-    return 0;
-}
-}  // namespace
-
 extern "C" {
 
 int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t method, int32_t k, double radius,

@@ -99,19 +99,15 @@ __device__ __forceinline__ double tile_log1p_scaled(double y, double scale_s, fl
 //   are 0x7F000000 - bits(u): exact at the powers of two - in particular at u = 1, where the term IS the result
 //   (x < 2^-24) -, at most 12.5 % too large in between, on a term that is at most 2^-24 of u.
 // Without the d term the error is 2^-24 ABSOLUTE, i.e. unbounded relative to log1p(x) ~ x for small x; with it the result
-// is within ~3 ulp of float32 everywhere on [0, 32000).  CORR = false drops the term (measurement only).
-template <bool CORR> __device__ __forceinline__ float tile_log1p_f32(float y, float s) {
+// is within ~3 ulp of float32 everywhere on [0, 32000).
+__device__ __forceinline__ float tile_log1p_f32(float y, float s) {
 #pragma clang fp contract(off)
     const float x = y * s;
     const float u = x + 1.0f;
     const float l = __builtin_amdgcn_logf(u);                      // v_log_f32: log2(u), u >= 1
-    float res = l * 0.693147180559945309f;
-    if (CORR) {
-        const float d = x - (u - 1.0f);
-        const float g = __uint_as_float(0x7F000000u - __float_as_uint(u));   // ~ 1 / u
-        res = __builtin_fmaf(d, g, res);
-    }
-    return res;
+    const float d = x - (u - 1.0f);
+    const float g = __uint_as_float(0x7F000000u - __float_as_uint(u));   // ~ 1 / u
+    return __builtin_fmaf(d, g, l * 0.693147180559945309f);
 }
 
 // Anything outside the fast range (negative, NaN, huge) takes the library function, as the reference would.  Kept out of

@@ -68,12 +68,8 @@ __host__ __device__ constexpr int JW_PAD(int jw) { return (jw + 7) & ~7; }
 // wave's slice of X_sketch does not stay in registers as MFMA A operands (JW x TT of them would not fit beside the bucket
 // sums) - each group's TT operands are fetched from a copy of X_sketch laid out in operand order (tile_xa_kernel; it
 // stays in L2) when the group's gather starts, and have landed when its sums are final.
-// LOGV (float32 input, log modes): 0 = the float64 table chain, 1 / 2 = float32-class log1p without / with the correction of
-// the rounding of 1 + x (tile_device.h: tile_log1p_f32).
-// ABL = 4 (experiment; DEFSUM below): a row's sum is formed at the start of its tile - the columns of block 0 from the
-// staged copy in LDS, the rest from registers whose loads were issued before the previous tile's reduction - instead of
-// from a synchronous second read of the whole row.
-template <typename T, int MODE, int NWC, int NWL, int JW, int TT, bool AVL2, int LOGV = 0, int ABL = 0>
+// LOGV (float32 input, log modes): 0 = the float64 table chain, 2 = the float32-class log1p (tile_device.h: tile_log1p_f32).
+template <typename T, int MODE, int NWC, int NWL, int JW, int TT, bool AVL2, int LOGV = 0>
 __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch_kernel(
     const TileArgs a, const T* __restrict__ Yp, const int* __restrict__ row_map, const double* __restrict__ Xs,
     double* __restrict__ H, double* __restrict__ row_sumsq, const double* __restrict__ w_tab,
@@ -93,13 +89,6 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     constexpr int TH = TT > 2 ? 2 : TT;                                     // type tiles per round of the final reduction
     constexpr int ROUNDS = TT / TH;
     constexpr int TS = TH * 4 * 64;
-    // one row per wave, at most two column blocks of at most four 1 KB pieces each (the host checks the shape)
-    constexpr bool DEFSUM = ABL == 4 && MODE != FDX_PRE_RAW && NWL == 0 && NWC == TILE_ROWS;
-    // ABL = 5 (experiment): every wave touches one 4-byte word per 128-byte line of its row of the NEXT tile at the start of
-    // the current one - one vector load per 8 KB - so that the row sums at the end of the tile and the DMA behind them find
-    // the lines in L2 / Infinity Cache instead of paying the HBM latency in the open
-    constexpr bool PREF = ABL == 5 && MODE != FDX_PRE_RAW && NWL == 0 && NWC == TILE_ROWS;
-    unsigned pref_sink = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -221,50 +210,6 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     const T* rowp[RPL];
     const T* rown[RPL];
     bool has_next = false;
-    // DEFSUM: vectors v_first .. nvec - 1 of the wave's row (the columns past block 0), four per lane
-    const int v_first = min(a.GB, a.G) / PER;
-    V xr[DEFSUM ? 4 : 1];
-    auto issue_rest = [&](const T* row) {
-        const V* src = reinterpret_cast<const V*>(row) + v_first;
-#pragma unroll
-        for (int u = 0; u < (DEFSUM ? 4 : 0); ++u) {
-            const int v = u * 64 + lane;
-            if (v_first + v < nvec) xr[u] = src[v];
-        }
-    };
-    // block 0 of the tile has landed in `base`: the wave's row sum in scale_two's order (per-lane partials over ascending
-    // vectors, butterfly), scale and range flag to LDS
-    auto tile_row_sum = [&](const unsigned char* base, bool present, int par) {
-        double p0 = 0.0;
-        unsigned long long sg0 = 0ULL;
-        auto add = [&](const V& x) {
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                p0 += (double)x[e];
-                if constexpr (sizeof(T) == 4) sg0 |= (unsigned long long)__float_as_uint((float)x[e]) << 32;
-                else sg0 |= (unsigned long long)__double_as_longlong((double)x[e]);
-            }
-        };
-        if (present) {
-            const V* l = reinterpret_cast<const V*>(base + wave * a.RS);
-            V xl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int v = u * 64 + lane;
-                if (v < v_first) xl[u] = l[v];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u * 64 + lane < v_first) add(xl[u]);
-#pragma unroll
-            for (int u = 0; u < (DEFSUM ? 4 : 0); ++u)
-                if (v_first + u * 64 + lane < nvec) add(xr[u]);
-        }
-        const double sum0 = wave_sum(p0);
-        const double s0 = tile_row_scale<MODE>(sum0);
-        const bool ok0 = !present || (fabs(sum0) <= 1e18 && (sum0 == 0.0 || fabs(sum0) >= 1e-30) && !__any((long long)sg0 < 0));
-        if (lane == 0) { scales[par * TILE_ROWS + wave] = s0; rowok[par * TILE_ROWS + wave] = ok0 ? 1 : 0; }
-    };
     // one block step of a staging wave: block c of the current tile has landed; stage the next block, sum a share of the
     // next tile's rows
     auto stage_step = [&](int c, int buf, int par) {
@@ -275,13 +220,12 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     // the sums read the rows from HBM, the DMA of the next tile re-reads them 0 - 1 tile periods later, and the closer the
     // two reads the more of the second one the XCD's 4 MB L2 still holds (32 CUs x 128 KB of rows per tile period).
     auto sums_step = [&](int c, int par) {
-        if (MODE != FDX_PRE_RAW && has_next && !DEFSUM) scale_rows(rown, a.NBLK - 1 - c, a.NBLK, par ^ 1);
+        if (MODE != FDX_PRE_RAW && has_next) scale_rows(rown, a.NBLK - 1 - c, a.NBLK, par ^ 1);
     };
     if (NWL == 0 || wave >= NWC) {
         load_rows(tile, rowp);
         issue_stage(rowp, 0, 0);
-        if (DEFSUM) { if (rowp[0]) issue_rest(rowp[0]); }
-        else if (MODE != FDX_PRE_RAW) scale_rows(rowp, 0, 1, 0);
+        if (MODE != FDX_PRE_RAW) scale_rows(rowp, 0, 1, 0);
     }
 
     if (NWL > 0 && wave >= NWC) {
@@ -368,7 +312,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             auto f = [&](T yy) -> double {
                 if (MODE == FDX_PRE_RAW) return (double)yy;
                 if constexpr (F32LOG) {
-                    if (FAST) return (double)tile_log1p_f32<LOGV == 2>((float)yy, scale_f);
+                    if (FAST) return (double)tile_log1p_f32((float)yy, scale_f);
                     return tile_log1p_any((double)yy * scale);
                 } else {
                     if (FAST) return tile_log1p_scaled(yy, scale_s, scale_sf, lc);
@@ -417,21 +361,6 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             if (NWL == 0) __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): this wave's pieces of block c have landed
             lds_barrier();                                                  // everybody's have (the loaders waited for theirs)
             if (NWL == 0) stage_step(c, buf, par);
-            if (DEFSUM && c == 0) {
-                tile_row_sum(smem + (size_t)buf * stage_bytes, rowp[0] != nullptr, par);
-                lds_barrier();
-            }
-            if (PREF) {
-                // the previous prefetch has landed (vmcnt(0) above): its destination register may be released
-                asm volatile("" :: "v"(pref_sink));
-                if (c == 0 && has_next && rown[0]) {
-                    const int row_bytes = a.G * (int)sizeof(T);
-                    for (int o = lane * 128; o < row_bytes; o += 64 * 128) {
-                        const char* src = reinterpret_cast<const char*>(rown[0]) + o;
-                        asm volatile("global_load_dword %0, %1, off" : "=v"(pref_sink) : "v"(src) : "memory");
-                    }
-                }
-            }
             if (MODE != FDX_PRE_RAW && c == 0) {
                 scale = scales[par * TILE_ROWS + r];
                 if constexpr (F32LOG) {
@@ -467,11 +396,6 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 sq = fma(acc[j], acc[j], sq);
             }
         }
-        // DEFSUM: the part of the wave's next row that lies beyond column block 0, requested now; it has landed when the
-        // next tile starts (tile_row_sum)
-        if (DEFSUM) __builtin_amdgcn_sched_barrier(0);      // not above the MFMAs: the bucket sums must be dead first
-        if (DEFSUM && has_next && rown[0]) issue_rest(rown[0]);
-        if (DEFSUM) __builtin_amdgcn_sched_barrier(0);
         par ^= 1;
         if (NWL == 0) {
 #pragma unroll
@@ -707,31 +631,19 @@ template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hipStream_t st) {
     const void* kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 1, false>
                                : (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 2, false>;
-    // log modes, 16 self-staging waves: operands from the L2 copy as in the wide form - the 32 registers they would occupy
-    // are what the 128-register budget lacks for the log1p chains (22 spills with them; 4.23 -> 4.1 ms).  Raw (12 + 4) keeps
-    // them in registers: 2.34 ms with the fetches against 1.98 ms.
+    // log modes, 16 self-staging waves.  float64 chain (float64 rows, integer counts, FDX_TILE_LOGV=0): operands from the L2
+    // copy as in the wide form - the 32 registers they would occupy are what the 128-register budget lacks for the log1p
+    // chains (22 spills with them; 4.23 -> 4.1 ms).  float32-class chain (float32 rows): no table, no polynomial constants -
+    // the operands fit back into registers (127 VGPRs, no spills: 3.08 -> 2.87 ms); FDX_TILE_AVL2=1 fetches them all the
+    // same.  Raw (12 + 4) keeps them in registers: 2.34 ms with the fetches against 1.98 ms.
     if constexpr (MODE != FDX_PRE_RAW && NWC == 16) {
         if (L.XA)
             kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true>;
         if constexpr (std::is_same<T, float>::value) {
-            // float32 rows: float32-class log1p (tile_device.h); FDX_TILE_LOGV=0 goes back to the float64 chain
-            const int logv = tile_logv();
-            if (logv == 2)
+            if (tile_logv() != 0)
                 kern = L.XA ? (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true, 2> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 2>)
                             : (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 2> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 2>);
-            if (const char* e = getenv("FDX_TILE_ABL")) {
-                if (!L.XA && logv == 2 && atoi(e) == 4 && L.a.NBLK <= 2 && L.a.GB * 4 <= 4096 && (L.a.G - L.a.GB) * 4 <= 4096)
-                    kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 2, 4> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 2, 4>;
-                if (!L.XA && logv == 2 && atoi(e) == 5)
-                    kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 2, 5> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 2, 5>;
-            } else if (logv == 1)
-                kern = L.XA ? (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, true, 1> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, true, 1>)
-                            : (TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 1, false, 1> : (const void*)tile_sketch_kernel<T, MODE, 16, 0, 8, 2, false, 1>);
         }
-    }
-    if constexpr (MODE != FDX_PRE_RAW && NWC == 12 && std::is_same<T, float>::value) {
-        if (tile_logv() != 0)
-            kern = TT == 1 ? (const void*)tile_sketch_kernel<T, MODE, 12, 4, 11, 1, false, 2> : (const void*)tile_sketch_kernel<T, MODE, 12, 4, 11, 2, false, 2>;
     }
     if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&L.a, (void*)&L.Y, (void*)&L.row_map, (void*)&L.Xs, (void*)&L.H, (void*)&L.row_sumsq, (void*)&L.w_tab,
@@ -822,7 +734,7 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
 namespace fdx {
 __global__ void log1p_f32_probe_kernel(const float* __restrict__ y, float scale, long long n, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = tile_log1p_f32<true>(y[i], scale);
+    if (i < n) out[i] = tile_log1p_f32(y[i], scale);
 }
 }  // namespace fdx
 

@@ -563,9 +563,7 @@ class ShardedFlashDeconv:
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         n_own, n_total = self.n_own, self.n_own + self.n_halo
         t0 = time.perf_counter()
-        t = torch.tensor([yty_part], dtype=torch.float64, device=dev)
-        self.comm.all_reduce_sum(t)
-        YtY = float(t.item())
+        # YtY only enters the final objective: its sum over the ranks rides in the objective's all-reduce at the end
         dmean = diag_mean(XtX_h)
         if self.lambda_spatial == "auto":                                     # core/spatial.py:181-190
             lam = 0.005 * dmean / max(self.nnz_total / max(self.n_total_spots, 1), 1.0)
@@ -600,16 +598,17 @@ class ShardedFlashDeconv:
                 real = solver.sweep_events[:info["n_iterations"]]              # later launches are post-convergence no-ops
                 self.sweep_ms_ = [a.elapsed_time(b) for a, b in real]
         t0 = self._tick("solve", t0)
-        part = torch.from_numpy(backend.objective_partials(beta)).to(dev)
-        self.comm.all_reduce_sum(part)
-        c = part.cpu().numpy()
-        info["final_objective"] = float(0.5 * (YtY - 2.0 * c[0] + c[1]) + 0.5 * lam * c[2] + rho_eff * c[3])
-        info["objectives"] = []
+        # the export is queued first: the objective's read-back below then waits for both (one host wait instead of two)
         self.beta_ = torch.empty((n_own, K), dtype=torch.float64, device=dev)
         self.proportions_ = torch.empty((n_own, K), dtype=torch.float64, device=dev)
         _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(beta.data_ptr()), ld, n_own, K, ctypes.c_void_p(self.beta_.data_ptr()),
                                          ctypes.c_void_p(self.proportions_.data_ptr()), st))
-        torch.cuda.current_stream().synchronize()
+        part = torch.from_numpy(np.concatenate([backend.objective_partials(beta), [yty_part]])).to(dev)
+        self.comm.all_reduce_sum(part)                                        # objective partials and YtY in one collective
+        c = part.cpu().numpy()
+        YtY = float(c[4])
+        info["final_objective"] = float(0.5 * (YtY - 2.0 * c[0] + c[1]) + 0.5 * lam * c[2] + rho_eff * c[3])
+        info["objectives"] = []
         self._tick("finish", t0)
         self.lambda_used_, self.info_ = lam, info
         return self.proportions_
