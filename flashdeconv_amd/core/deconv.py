@@ -8,6 +8,7 @@ Inputs may be NumPy arrays, SciPy sparse matrices, or CUDA (HIP) ``torch`` tenso
 ``output="torch"`` the fitted arrays stay on the device as well.
 """
 import ctypes
+import os
 import time
 
 import numpy as np
@@ -231,7 +232,10 @@ class FlashDeconv:
             G = len(gene_idx)
             log(f"  Selected {G} genes (HVG + markers)")
             Xsel = np.ascontiguousarray(X[:, gene_idx])
-            lev_job = _genes.LeverageJob(Xsel)     # side stream; collected after the graph build below
+            # The leverage SVD (side stream) runs beside the graph build.  Its job is set up AFTER the build call has queued its
+            # kernels: the graph chain is the longer of the two (~1.0 against ~0.55 ms at 1M spots), so the ~0.09 ms of host
+            # work of the set-up (buffers, upload of X, 17 launches) must not sit in front of it.  FDX_LEV_FIRST=1: old order.
+            lev_job = _genes.LeverageJob(Xsel) if os.environ.get("FDX_LEV_FIRST") else None
             if G != G_all and csr is None:          # Y[:, gene_idx] (core/deconv.py:321) as a compact device matrix
                 sub = _DeviceBuffer(n * G * (4 if y_code == _lib.FDX_F32 else 8))
                 owned.append(sub)
@@ -260,6 +264,8 @@ class FlashDeconv:
             self._adjacency = None
             gh = ctypes.c_void_p()
             _lib.check(lib.fdx_graph_build_dev(c_ptr, n, dim, g_method, g_k, g_radius, None, ctypes.byref(gh)))
+            if lev_job is None:
+                lev_job = _genes.LeverageJob(Xsel)
             self._graph = _lib.Graph(gh.value)
             n_ties = 0
             if self.spatial_method == "knn" and self.knn_ties == "ckdtree":

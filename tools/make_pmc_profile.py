@@ -28,7 +28,7 @@ def mean_big(xs):                                    # drop no-op launches (post
     return sum(keep) / len(keep)
 
 
-want = [k for k in vals if any(s in k for s in ("tile_sketch", "rowreg_sketch", "pair_sketch", "sketch_contract", "xyt_split", "bcd_sweep_tiled", "sketch_rows_scatter", "sketch_csr"))]
+want = [k for k in vals if any(s in k for s in ("tile_sketch", "sketch_contract", "xyt_split", "bcd_sweep_tiled", "sketch_rows_scatter", "sketch_csr", "csr_moments", "knn_kernel", "lev_eigen", "merge_rows", "normalize_export"))]
 want.sort(key=lambda k: -mean_big(dur.get(k, [0])) * len(dur.get(k, [])))
 out = os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.md")
 with open(out, "w") as f:

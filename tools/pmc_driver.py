@@ -26,6 +26,12 @@ def main():
             m.fit(Y, X, coords, output="torch")
         print(fam, {k: round(v, 3) for k, v in m.timings_.items()}, flush=True)
         del Y
+    if os.environ.get("PMC_WITH_CSR", "1") != "0" and n >= 100_000:     # the CSR family: gene statistics + fused sketch -> H
+        Y, X, coords = bench.gen_sparse(torch, n, 20000, K, dev, seed=0)
+        for _ in range(2):
+            m = FlashDeconv(sketch_dim=d, preprocess="log_cpm", n_hvg=G, max_iter=5)
+            m.fit(Y, X, coords, output="torch")
+        print("sparse_csr", {k: round(v, 3) for k, v in m.timings_.items()}, flush=True)
 
 
 if __name__ == "__main__":

@@ -15,4 +15,10 @@ for set in "$A" "$B" "$C"; do
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/pass$i" -- python3 /root/repo/tools/pmc_driver.py "$@" > "$out/pass$i.log" 2>&1
 done
 find "$out" -name "*agent_info.csv" -delete
+# keep the rows of the library's kernels only (the torch data generators dispatch thousands of kernels: 20 MB per pass, and
+# gpurun copies at most 64 MB back)
+for f in $(find "$out" -name "*counter_collection.csv" -o -name "*kernel_trace.csv"); do
+  head -1 "$f" > "$f.tmp"; grep "fdx::" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"
+done
+for l in "$out"/pass*.log; do echo "== $l"; grep -v "rocprofv3\|Opened result" "$l" | tail -3; done
 du -sh "$out"; find "$out" -type f | head
