@@ -116,8 +116,12 @@ int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, in
 namespace fdx {
 // ---- leverage_kernels.cpp
 size_t leverage_scratch_doubles(int K, int G);
+// route: the Jacobi SVD passes, or the Cholesky-QR route (no SVD; sweeps[7] = 1 when it stands, 2 when its pivots refused
+// the matrix and the caller must run the SVD route)
+constexpr int LEV_ROUTE_SVD = 0, LEV_ROUTE_QR = 1;
+bool leverage_qr_applies(int K, int G);
 int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
-                    double* scratch, hipStream_t st);
+                    double* scratch, hipStream_t st, int route = LEV_ROUTE_SVD);
 }  // namespace fdx
 
 namespace fdx {

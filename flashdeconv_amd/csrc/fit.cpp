@@ -64,7 +64,8 @@ int build_csc_from_tables(const int32_t* bucket, const double* weight, int G, in
 struct fdx_leverage_job {
     DevBuf dX, dW, dS, dL, dDbg, dScratch;
     std::vector<double> hX;   // the caller may drop X once begin returns
-    int K = 0, G = 0;
+    int K = 0, G = 0, route = LEV_ROUTE_SVD;
+    double reg = 0.0;
     hipStream_t st = nullptr;
 };
 
@@ -104,8 +105,10 @@ extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double 
         job->hX.assign(X, X + (size_t)K * G);
         FDX_HIP(hipMemcpyAsync(job->dX.p, job->hX.data(), (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, job->st));
         FDX_TRY(job->dScratch.alloc(leverage_scratch_doubles(K, G) * sizeof(double)));
+        job->reg = regularization;
+        job->route = leverage_qr_applies(K, G) ? LEV_ROUTE_QR : LEV_ROUTE_SVD;
         FDX_TRY(launch_leverage(job->dX.as<double>(), K, G, regularization, job->dW.as<double>(), job->dS.as<double>(),
-                                job->dL.as<double>(), job->dDbg.as<int>(), job->dScratch.as<double>(), job->st));
+                                job->dL.as<double>(), job->dDbg.as<int>(), job->dScratch.as<double>(), job->st, job->route));
         return 0;
     };
     const int rc = run();
@@ -129,12 +132,23 @@ extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) {
         return 0;
     };
     rc = run();
-    const hipError_t e = hipStreamSynchronize(job->st);   // always drain before the buffers go back to the pool
+    hipError_t e = hipStreamSynchronize(job->st);   // always drain before the buffers go back to the pool
+    if (!rc && e == hipSuccess && job->route == LEV_ROUTE_QR && dbg[7] != 1) {
+        // the Cholesky-QR route refused the matrix (rank-deficient or cond above ~3e4): the Jacobi SVD passes, as before
+        PoolStream pool_stream(job->st);
+        job->route = LEV_ROUTE_SVD;
+        rc = launch_leverage(job->dX.as<double>(), job->K, job->G, job->reg, job->dW.as<double>(), job->dS.as<double>(),
+                             job->dL.as<double>(), job->dDbg.as<int>(), job->dScratch.as<double>(), job->st, LEV_ROUTE_SVD);
+        if (!rc) rc = run();
+        e = hipStreamSynchronize(job->st);
+        if (!rc) dbg[5] = 1;                                   // for the debug line: fell back
+    }
     if (!rc && e != hipSuccess) rc = fail(FDX_ERR_HIP, hipGetErrorString(e));
     if (e == hipSuccess)              // nothing of the job is in flight any more: the blocks may follow any stream
         for (DevBuf* b : {&job->dX, &job->dW, &job->dS, &job->dL, &job->dDbg, &job->dScratch}) b->mark_idle();
     if (!rc && getenv("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
-        std::fprintf(stderr, "[fdx] leverage: K=%d G=%d passes/sweeps=%d converged=%d\n", job->K, job->G, dbg[0], dbg[6]);
+        std::fprintf(stderr, "[fdx] leverage: K=%d G=%d route=%s passes/sweeps=%d converged=%d\n", job->K, job->G,
+                     job->route == LEV_ROUTE_QR ? "cholesky-qr" : "jacobi-svd", dbg[0], dbg[6]);
     delete job;
     return rc;
 }

@@ -150,11 +150,12 @@ __global__ __launch_bounds__(256) void cell_range_kernel(const unsigned long lon
 // sorted coordinate planes sc[a*n + p] and rank[perm[p]] = p
 __global__ __launch_bounds__(256) void gather_sorted_kernel(const double* __restrict__ coords, const int* __restrict__ perm,
                                                             long long n, int dim, double* __restrict__ sc,
-                                                            int* __restrict__ rank) {
+                                                            int* __restrict__ rank, double2* __restrict__ sc2) {
     const long long p = blockIdx.x * 256LL + threadIdx.x;
     if (p >= n) return;
     const int o = perm[p];
     for (int a = 0; a < 3; ++a) sc[(size_t)a * n + p] = (a < dim) ? coords[(size_t)o * dim + a] : 0.0;
+    if (sc2) sc2[p] = make_double2(coords[(size_t)o * dim], dim > 1 ? coords[(size_t)o * dim + 1] : 0.0);
     rank[o] = (int)p;
 }
 
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const unsigned* __restr
 __global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict__ coords, const unsigned* __restrict__ key32,
                                                         const int* __restrict__ start, const int* __restrict__ members,
                                                         long long n, int dim, int* __restrict__ perm, int* __restrict__ rank,
-                                                        double* __restrict__ sc) {
+                                                        double* __restrict__ sc, double2* __restrict__ sc2) {
     const long long i = blockIdx.x * 256LL + threadIdx.x;
     if (i >= n) return;
     const unsigned k = key32[i];
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict
     perm[p] = (int)i;
     rank[i] = p;
     for (int a = 0; a < dim; ++a) sc[(size_t)a * n + p] = coords[(size_t)i * dim + a];   // planes past dim: zeroed by the caller (one contiguous fill)
+    if (sc2) sc2[p] = make_double2(coords[(size_t)i * dim], dim > 1 ? coords[(size_t)i * dim + 1] : 0.0);   // (x, y) pairs: one 16-byte gather per k-NN candidate
 }
 
 // pass 4: the cell table (row-major cell id -> [start, end) of the sorted order) straight from the key starts: an occupied
@@ -216,15 +218,35 @@ __global__ __launch_bounds__(256) void cell_table_kernel(const int* __restrict__
 
 // ------------------------------------------------------------------------------------------------ k-NN
 __device__ __forceinline__ double dist2_exact(double dx, double dy, double dz) {
-    // sum of squares with every product and sum rounded (no fma contraction), as a host float64 loop computes it
-    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+    // sum of squares with every product and sum rounded, as a host float64 loop computes it: no fma contraction (the
+    // compiler's default for device code, and __dmul_rn / __dadd_rn are plain operators to it)
+#pragma clang fp contract(off)
+    const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return (xx + yy) + zz;
 }
 
-__device__ __forceinline__ bool lex_less(double d1, int i1, double d2, int i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
+// one slot of an ascending list: (slot, carried) <- (min, max).  Distances are never NaN, and the plain instructions spare
+// the canonicalising v_max_f64 x, x that fmin / fmax put in front of every slot value coming out of a loop.
+__device__ __forceinline__ void minmax_f64(double& slot, double& carried) {
+    double lo, hi;
+    asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(slot), "v"(carried));
+    slot = lo;
+    carried = hi;
+}
 
-// kk = k+1 nearest INCLUDING self (cKDTree.query(coords, k+1), graph.py:63); nbr_out has stride kk, -1 padded.
-template <int KMAX>
-__global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc, const int* __restrict__ perm,
+// kk = k+1 nearest INCLUDING self (cKDTree.query(coords, k+1), graph.py:63); nbr_out has stride kk, -1 padded, entries in
+// no particular order (the symmetrisation sorts rows by original index).
+//
+// What the kernel waits for is its gathers (SQ counters: waves parked on s_waitcnt 68 % of their life, VALU issuing 15 %): a
+// wave's 64 lanes look into ~16 different cell neighbourhoods, so every load instruction is ~20 cache lines for the texture
+// path.  Hence: ONE gather per candidate (the (x, y) pair from sc2; the caller index perm[q] is not loaded at all), and a
+// per-lane list of (squared distance, position) ordered by DISTANCE ONLY - among equal distances the first met stays ahead.
+// That list holds the right neighbour SET unless the kk-th and (kk+1)-th distances are equal; waves where some lane has such
+// a tie walk the candidates a second time and give the places at the threshold distance to the lowest caller indices (the
+// rule of the (distance, index) order).  A list slot costs v_min_f64 + v_max_f64 + one compare + two selects.
+template <int KMAX, int BATCH>
+__global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc, const double2* __restrict__ sc2,
+                                                  const int* __restrict__ perm, const int* __restrict__ rank,
                                                   const int* __restrict__ cstart, const int* __restrict__ cend,
                                                   long long n, GridParams gp, int kk, int* __restrict__ nbr_out,
                                                   int* __restrict__ nbr_cnt, double* __restrict__ nn_dist,
@@ -237,24 +259,11 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     int c[3];
     for (int a = 0; a < 3; ++a) c[a] = (a < gp.dim) ? cell_coord(pc[a], gp.mn[a], gp.inv_h[a], gp.nc[a]) : 0;
     double bd[KMAX];
-    int bi[KMAX], bq[KMAX];
+    int bq[KMAX];
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; bq[s] = -1; }
+    for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bq[s] = -1; }
+    const bool skip_self = nn_dist != nullptr;            // nearest OTHER point: self never enters the list
 
-    // insertion of one candidate (sorted by (distance, caller index): the result does not depend on the visiting order)
-    auto consider = [&](double d2, int oi, int q) {
-        if (lex_less(d2, oi, bd[KMAX - 1], bi[KMAX - 1])) {
-            bd[KMAX - 1] = d2; bi[KMAX - 1] = oi; bq[KMAX - 1] = q;
-#pragma unroll
-            for (int s = KMAX - 1; s > 0; --s) {
-                if (lex_less(bd[s], bi[s], bd[s - 1], bi[s - 1])) {
-                    const double td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
-                    const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
-                    const int tq = bq[s]; bq[s] = bq[s - 1]; bq[s - 1] = tq;
-                }
-            }
-        }
-    };
     // done when the kk-th best is provably inside the block of cells within R of c
     auto covered = [&](int R) -> bool {
         bool covers_all = true;
@@ -271,63 +280,56 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
             }
         }
         if (covers_all) return true;
-        // bd[] holds the KMAX best; the kk-th best is bd[kk-1] (selected without dynamic register indexing)
-        double kth = INFINITY;
+        double kth = INFINITY;                            // bd[kk-1] without dynamic register indexing
 #pragma unroll
-        for (int s = 0; s < KMAX; ++s) if (s == kk - 1) kth = bd[s];
+        for (int s = 0; s < KMAX; ++s) if (s == (skip_self ? 0 : kk - 1)) kth = bd[s];
         return safe > 0.0 && kth < safe * safe;
     };
 
-    const int maxR = max(gp.nc[0], max(gp.nc[1], gp.nc[2]));
-    int R_first = 0;
-    bool done = false;
-    if (KMAX <= 16 && gp.dim <= 2 && !gp_no_batch) {
-        // Shells 0 and 1 together (one and two dimensions: the 3 x 3 block of cells, ~36 candidates at ~4 points per cell -
-        // with k <= 8 that block always suffices), as a FLAT candidate list served in batches: the cell extents of all nine
-        // cells in one round trip, then the coordinates of BATCH candidates per round trip.  The shell loop below walks
-        // cell by cell and candidate by candidate, two dependent loads deep each time - ~45 round trips to L2 per point,
-        // which is what the kernel's 300-450 us at 1M points were.
-        int cs[9], ce[9];
+    // Shells 0 and 1 together (one and two dimensions: the 3 x 3 block of cells, ~36 candidates at ~4 points per cell - with
+    // k <= 8 that block always suffices), as a FLAT candidate list served in batches of BATCH gathers per round trip
+    // (walking cell by cell and candidate by candidate is two dependent loads deep each time: ~45 round trips per point).
+    // The nine cells' (first position, count) sit in LDS, one column per lane: the walk steps through them with a running
+    // cell number, and a register array indexed by it is nine selects per candidate.  A lane only ever reads its own column -
+    // no barrier anywhere.
+    const bool use_block = KMAX <= 16 && gp.dim <= 2 && sc2 != nullptr && !gp_no_batch;
+    __shared__ int s_cs[9][128], s_cn[9][128];
+    const int tid = threadIdx.x;
+    int total = 0;
+    if (use_block) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int x = c[0] + (j % 3) - 1, y = c[1] + (j / 3) - 1;
             const bool ok = x >= 0 && x < gp.nc[0] && y >= 0 && y < gp.nc[1];
             const int cell = ok ? x * gp.stride[0] + y * gp.stride[1] : 0;
-            cs[j] = ok ? cstart[cell] : 0;
-            ce[j] = ok ? cend[cell] : 0;
+            const int a = ok ? cstart[cell] : 0, b = ok ? cend[cell] : 0;
+            s_cs[j][tid] = a;
+            s_cn[j][tid] = b - a;
+            total += b - a;
         }
-        int pre[10];
-        pre[0] = 0;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) pre[j + 1] = pre[j] + (ce[j] - cs[j]);
-        const int total = pre[9];
-        constexpr int BATCH = 8;
+    }
+    auto walk_block = [&](auto&& f) {
+        int j = -1, rem = 0, q = 0;
         for (int base = 0; base < total; base += BATCH) {
-            int qv[BATCH], ov[BATCH];
-            double xv[BATCH], yv[BATCH];
+            int qv[BATCH];
+            double2 xy[BATCH];
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-                const int idx = base + u;
-                int q = -1;
-#pragma unroll
-                for (int j = 0; j < 9; ++j)
-                    if (idx >= pre[j] && idx < pre[j + 1]) q = cs[j] + (idx - pre[j]);
-                qv[u] = q;
-                if (q >= 0) {
-                    xv[u] = sc[q];
-                    yv[u] = sc[(size_t)n + q];
-                    ov[u] = perm[q];
+                qv[u] = -1;
+                if (base + u < total) {
+                    while (rem == 0) { ++j; q = s_cs[j][tid]; rem = s_cn[j][tid]; }   // base + u < total: a non-empty cell is ahead
+                    qv[u] = q++;
+                    --rem;
+                    xy[u] = sc2[qv[u]];
                 }
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u)
-                if (qv[u] >= 0) consider(dist2_exact(xv[u] - px, yv[u] - py, 0.0), ov[u], qv[u]);   // planes past dim are zero
+                if (qv[u] >= 0) f(qv[u], dist2_exact(xy[u].x - px, xy[u].y - py, 0.0));   // planes past dim are zero
         }
-        done = covered(1);
-        R_first = 2;
-    }
-    for (int R = R_first; R <= maxR && !done; ++R) {
-        // visit the shell max_a |dc_a| == R of the cell block around c
+    };
+    // the shell max_a |dc_a| == R of the cell block around c
+    auto walk_shell = [&](int R, auto&& f) {
         const int lo0 = max(0, c[0] - R), hi0 = min(gp.nc[0] - 1, c[0] + R);
         const int lo1 = max(0, c[1] - R), hi1 = min(gp.nc[1] - 1, c[1] + R);
         const int lo2 = max(0, c[2] - R), hi2 = min(gp.nc[2] - 1, c[2] + R);
@@ -342,38 +344,105 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
                     const int cell = x * gp.stride[0] + y * gp.stride[1] + z * gp.stride[2];
                     const int s0 = cstart[cell], s1 = cend[cell];
                     for (int q = s0; q < s1; ++q)
-                        consider(dist2_exact(sc[q] - px, sc[(size_t)n + q] - py, sc[2 * (size_t)n + q] - pz), perm[q], q);
+                        f(q, dist2_exact(sc[q] - px, sc[(size_t)n + q] - py, sc[2 * (size_t)n + q] - pz));
                 }
             }
-        done = covered(R);
-    }
-    if (nn_dist) {   // distance to the nearest OTHER point (entry 0 is self unless points coincide)
-        double d1 = INFINITY;
+    };
+
+    // ---- the walk: the KMAX nearest by distance
+    auto keep = [&](int q, double d2) {
+        if (skip_self && q == (int)p) return;
 #pragma unroll
-        for (int s = KMAX - 1; s >= 0; --s) if (s < kk && bq[s] >= 0 && bq[s] != (int)p) d1 = bd[s];
-        nn_dist[perm[p]] = sqrt(d1);
+        for (int s = 0; s < KMAX; ++s) {
+            const bool ahead = d2 < bd[s];                // equal: the slot's occupant stays
+            minmax_f64(bd[s], d2);
+            const int t = ahead ? q : bq[s];
+            q = ahead ? bq[s] : q;
+            bq[s] = t;
+        }
+    };
+    const int maxR = max(gp.nc[0], max(gp.nc[1], gp.nc[2]));
+    int R_first = 0, R_end = 0;                           // shells [R_first, R_end) were walked one by one
+    bool done = false;
+    if (use_block) {
+        walk_block(keep);
+        done = covered(1);
+        R_first = 2;
+    }
+    R_end = R_first;
+    for (int R = R_first; R <= maxR && !done; ++R) {
+        walk_shell(R, keep);
+        done = covered(R);
+        R_end = R + 1;
+    }
+    if (nn_dist) {
+        nn_dist[perm[p]] = sqrt(bd[0]);
         return;
+    }
+
+    // ---- the threshold: the kk-th smallest distance, how many list entries lie below it, and whether the (kk+1)-th equals it
+    double thr = INFINITY, next = INFINITY;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        if (s == kk - 1) thr = bd[s];
+        if (s == kk) next = bd[s];
     }
     // Spots whose kk-th and (kk+1)-th nearest are at EXACTLY the same distance: their neighbour set is not unique (cKDTree
     // keeps whichever its traversal meets first, graph.py:60-63; here the lower spot index wins).  The (kk+1)-th best of the
-    // scanned block is the true one whenever it ties with the kk-th: a point at that distance lies inside the radius the
-    // scan was proven to cover.  Needs a spare slot (KMAX > kk: the launch takes care of it).
+    // walked block is the true one whenever it ties with the kk-th: a point at that distance lies inside the radius the
+    // walk was proven to cover.  Needs a spare slot (KMAX > kk: the launch takes care of it); without one every lane takes
+    // the index-ordered route.
+    const bool tie = (KMAX > kk) ? (next == thr && thr < INFINITY) : true;
     if (tie_count) {
-        bool tie = false;
-#pragma unroll
-        for (int s = 1; s < KMAX; ++s)
-            if (s == kk) tie = bq[s] >= 0 && bd[s] == bd[s - 1];
         const unsigned long long m = __ballot(tie);
         if (m != 0ULL && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(tie_count, (int)__popcll(m));
     }
-    // drop self (graph.py:70-74); if self is not among the kk nearest (coincident points) keep all kk, as the reference does
-    // indeg != NULL (whole graph in one piece): the symmetrisation's first pass rides along - every list entry counts
-    // itself into its target's in-degree, and the number it draws is its place in the target's reverse list
+    if (__ballot(tie) != 0ULL) {
+        // second walk (every lane of the wave; a lane without a tie finds its own list again): entries below the threshold stay,
+        // the places at the threshold go to the lowest caller indices among ALL candidates at that distance
+        int below = 0;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) below += (s < kk && bd[s] < thr) ? 1 : 0;
+        const int at_thr = kk - below;
+        int tl[KMAX];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) tl[s] = 0x7fffffff;
+        auto ties = [&](int q, double d2) {
+            int v = 0x7fffffff;
+            if (d2 == thr) v = perm[q];
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const int t = min(tl[s], v);
+                v = max(tl[s], v);
+                tl[s] = t;
+            }
+        };
+        if (use_block) walk_block(ties);
+        for (int R = R_first; R < R_end; ++R) walk_shell(R, ties);
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+            if (s >= below && s < kk) {                   // slot s takes the (s - below)-th lowest index at the threshold
+                int o = 0x7fffffff;
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) if (t == s - below) o = tl[t];
+                bq[s] = (s - below < at_thr && o != 0x7fffffff) ? rank[o] : -1;
+            }
+    }
+
+    // ---- the neighbours.  Self is dropped (graph.py:70-74); if self is not among the kk nearest (coincident points) all kk
+    // stay, as in the reference.  indeg != NULL (whole graph in one piece): the symmetrisation's first pass rides along -
+    // every list entry counts itself into its target's in-degree, and the number it draws is its place in the target's
+    // reverse list (all counters asked at once: one round trip)
+    int arr[KMAX];
+    if (indeg) {
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) arr[s] = (s < kk && bq[s] >= 0 && bq[s] != (int)p) ? atomicAdd(&indeg[bq[s]], 1) : 0;
+    }
     int cnt = 0;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
         if (s < kk && bq[s] >= 0 && bq[s] != (int)p) {
-            if (indeg) arrival[(size_t)p * kk + cnt] = atomicAdd(&indeg[bq[s]], 1);
+            if (indeg) arrival[(size_t)p * kk + cnt] = arr[s];
             nbr_out[(size_t)p * kk + cnt++] = bq[s];
         }
     for (int s = cnt; s < kk; ++s) nbr_out[(size_t)p * kk + s] = -1;
@@ -737,7 +806,7 @@ static int make_grid(const double* d_coords, long long n, int dim, double target
 
 struct BinnedPoints {
     GridParams gp;
-    DevBuf perm, rank, sc, cstart, cend;
+    DevBuf perm, rank, sc, sc2, cstart, cend;      // sc2: (x, y) pairs of the sorted points, dim <= 2 only
     DevBuf keys, vals, skeys, sort_tmp, count, start, scan_tmp;   // sort temporaries: kept until the struct dies so that binning needs no final sync
     long long n = 0;
     int n_cells = 0;
@@ -759,6 +828,7 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     FDX_TRY(b->perm.alloc((size_t)n * 4));
     FDX_TRY(b->rank.alloc((size_t)n * 4));
     FDX_TRY(b->sc.alloc((size_t)n * 3 * sizeof(double)));
+    if (dim <= 2) FDX_TRY(b->sc2.alloc((size_t)n * 2 * sizeof(double)));
     FDX_TRY(b->cstart.alloc((size_t)b->n_cells * 4));
     FDX_TRY(b->cend.alloc((size_t)b->n_cells * 4));
     trace_host("bin: allocations");
@@ -792,7 +862,7 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
         FDX_CHECK_LAUNCH();
         if (dim < 3) FDX_HIP(hipMemsetAsync(b->sc.as<double>() + (size_t)dim * n, 0, (size_t)(3 - dim) * n * sizeof(double), st));
         hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(256), 0, st, d_coords, keys.as<unsigned>(), b->start.as<int>(),
-                           tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), b->sc.as<double>());
+                           tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), b->sc.as<double>(), b->sc2.as<double2>());
         FDX_CHECK_LAUNCH();
         hipLaunchKernelGGL(cell_table_kernel, dim3(ceil_div(bins, 256)), dim3(256), 0, st, b->start.as<int>(), bins, b->gp,
                            b->cstart.as<int>(), b->cend.as<int>());
@@ -808,7 +878,7 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
         FDX_TRY(tmp.alloc(bytes));
         FDX_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys.as<u64>(), skeys.as<u64>(), vals.as<int>(), b->perm.as<int>(),
                                           (size_t)n, 0, (unsigned)bits, st));
-        hipLaunchKernelGGL(gather_sorted_kernel, dim3(nb), dim3(256), 0, st, d_coords, b->perm.as<int>(), n, dim, b->sc.as<double>(), b->rank.as<int>());
+        hipLaunchKernelGGL(gather_sorted_kernel, dim3(nb), dim3(256), 0, st, d_coords, b->perm.as<int>(), n, dim, b->sc.as<double>(), b->rank.as<int>(), b->sc2.as<double2>());
         FDX_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(cell_range_kernel, dim3(nb), dim3(256), 0, st, skeys.as<u64>(), b->sc.as<double>(), n, b->gp,
@@ -953,9 +1023,22 @@ template <int KMAX>
 static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, long long lo,
                              long long hi, hipStream_t st, int* indeg = nullptr, int* arrival = nullptr, int* ties = nullptr) {
     if (hi <= lo) return;
-    hipLaunchKernelGGL(knn_kernel<KMAX>, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), perm,
-                       b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
-                       KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0);
+    // candidates per round trip: 4 leaves the kernel 77 registers (6 waves per SIMD), 6: 87 (5 waves), 8: 97 (4 waves);
+    // 1M spots, wall per fit: 4.69 / 4.84 / 4.88 ms
+    const int batch_env = getenv("FDX_KNN_BATCH") ? atoi(getenv("FDX_KNN_BATCH")) : 0;
+    const int batch = (KMAX <= 16 && (batch_env == 4 || batch_env == 6 || batch_env == 8)) ? batch_env : (KMAX <= 16 ? 4 : 8);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), b.sc2.as<double2>(), perm,
+                           b.rank.as<int>(), b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
+                           KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0);
+    };
+    if constexpr (KMAX <= 16) {
+        if (batch == 4) go(knn_kernel<KMAX, 4>);
+        else if (batch == 6) go(knn_kernel<KMAX, 6>);
+        else go(knn_kernel<KMAX, 8>);
+    } else {
+        go(knn_kernel<KMAX, 8>);
+    }
 }
 
 template <int KMAX>
@@ -1038,14 +1121,13 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     if (hipMemsetAsync(plan->ties.p, 0, 4, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
     int* ties = plan->ties.as<int>();
     // one slot more than the list length, for the tie test (kk = 64 has none: no tie count there).
-    // Large ranges go out as a few launches instead of one: the kernel fills the device for hundreds of microseconds, and the
-    // leverage passes on the library's side stream (32 workgroups each, latency-bound) were waiting for it to drain - 330 us
-    // for a 9 us kernel at 1M spots; between two launches their workgroups get in.  Not more than a few: a workgroup of the
-    // kernel lives ~120-150 us whatever the grid (latency-bound lanes), so a piece that does not fill every CU's wave slots
-    // costs a full round all the same (1M spots, wall per fit: 1 piece 5.31-5.41 ms, 2-4 pieces 5.18-5.26, 8 pieces 5.56).
+    // One launch (FDX_KNN_PIECES splits it: while the leverage scores still came from the Jacobi SVD passes on the library's
+    // side stream, 2-4 pieces let their small workgroups in between; the Cholesky-QR route is over before this kernel starts).
+    // Where the kernel's time goes at 1M spots (300 us): ~110 us are the 7M in-degree counters (returning atomics; measured
+    // with the counters taken out), the rest the walk - waves parked on its gathers two thirds of their life.
     const long long rows = hi - lo;
     const int pieces_env = getenv("FDX_KNN_PIECES") ? atoi(getenv("FDX_KNN_PIECES")) : 0;
-    const int pieces = pieces_env > 0 ? pieces_env : (int)std::min<long long>(4, std::max<long long>(1, (rows + 160000) / 320000));
+    const int pieces = pieces_env > 0 ? pieces_env : 1;
     const long long step = ((rows + pieces - 1) / pieces + 127) / 128 * 128;
     for (long long a = lo; a < hi; a += step) {
         const long long e = std::min(hi, a + step);

@@ -508,9 +508,222 @@ __global__ __launch_bounds__(256) void lev_normalise_kernel(double* __restrict__
     if (g < G) lev[g] = lev[g] / (total + reg);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast route for well-conditioned signature matrices: no SVD at all.
+//
+// With Xc^T = U S V^T, genes.py:281-285 is  lev_g = sum_j (xc_g . v_j)^2 / (s_j^2 + reg)  =  xc_g^T (Xc Xc^T + reg I)^-1 xc_g
+// over the directions with s_j > 0.  Centring makes 1/sqrt(K) an exact null vector of Xc; a Householder reflection that maps it
+// to e_K turns every centred gene column into z_g (K - 1 entries, the K-th is the rounding of a zero sum and is dropped: the
+// reference weights that direction with s^2 / (s^2 + reg) ~ 1e-20).  Then
+//   lev_g = || row g of Q ||^2,   A' = [Z^T ; sqrt(reg) I] = Q R   (G + m rows, m = K - 1 columns),
+// the leverage of the rows of a ridge-augmented tall matrix.  Q comes from CholeskyQR2: R1 = chol(A'^T A'), Q1 = A' R1^-1,
+// R2 = chol(Q1^T Q1), Q = Q1 R2^-1 - orthogonal to machine precision while cond(A')^2 eps << 1 (Yamamoto et al. 2015), i.e. the
+// small singular values are NOT squared away as they would be in a plain normal-equations solve.  The pivots of both
+// factorisations are watched: a pivot below 1e-9 of the largest diagonal entry (cond(A') above ~3e4: rank-deficient or badly
+// scaled signatures) sets status 2 and fdx_leverage_end runs the Jacobi SVD passes above instead.
+//
+// Three launches of (G / 64 + 1) workgroups: a stripe of 64 genes per workgroup plus one workgroup for the m ridge rows; the
+// last workgroup to finish a stage adds the per-stripe Gram matrices in stripe order (deterministic) and factorises in LDS.
+constexpr double LEV_PIVOT_TOL = 1e-9;
+
+struct LevQrShared {
+    double tile[64][LEV_STRIPE + 1];
+    double C[64][65];
+    double dpiv[64];
+    double thr;
+    int bad, last;
+};
+
+// lower Cholesky factor of the symmetric C (lower triangle used) in place; 256 threads; *bad when a pivot is too small
+__device__ void lev_chol_lds(LevQrShared& sh, int m) {
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        double mx = 0.0;
+        for (int i = 0; i < m; ++i) mx = fmax(mx, sh.C[i][i]);
+        sh.thr = mx * LEV_PIVOT_TOL;
+        sh.bad = !(mx > 0.0) || !(mx < 1e300);
+    }
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+        double d = sh.C[j][j];
+        if (!(d > sh.thr)) {                                              // also NaN
+            if (tid == 0) sh.bad = 1;
+            d = sh.thr > 0.0 ? sh.thr : 1.0;
+        }
+        if (tid == 0) sh.dpiv[j] = d;
+        const double inv = 1.0 / d;
+        const int r = m - 1 - j;
+        for (int e = tid; e < r * r; e += 256) {
+            const int i = j + 1 + e / r, k = j + 1 + e % r;
+            if (k <= i) sh.C[i][k] -= sh.C[i][j] * sh.C[k][j] * inv;     // column j itself is not written in step j
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < m * m; e += 256) {
+        const int i = e / m, j = e - i * m;
+        if (j > i) continue;
+        const double sd = sqrt(sh.dpiv[j]);
+        sh.C[i][j] = (i == j) ? sd : sh.C[i][j] / sd;
+    }
+    __syncthreads();
+}
+
+// tile[:, j] <- L^-1 tile[:, j] for the 64 columns of the stripe (L in sh.C, lane = column)
+__device__ void lev_forward_lds(LevQrShared& sh, int m) {
+    const int j = threadIdx.x;
+    if (j < LEV_STRIPE) {
+        for (int i = 0; i < m; ++i) {
+            double s0 = sh.tile[i][j], s1 = 0.0;
+            int k = 0;
+            for (; k + 1 < i; k += 2) {
+                s0 = fma(-sh.C[i][k], sh.tile[k][j], s0);
+                s1 = fma(-sh.C[i][k + 1], sh.tile[k + 1][j], s1);
+            }
+            if (k < i) s0 = fma(-sh.C[i][k], sh.tile[k][j], s0);
+            sh.tile[i][j] = (s0 + s1) / sh.C[i][i];
+        }
+    }
+    __syncthreads();
+}
+
+// STAGE 0: X -> Z (work), Gram of the stripes, L1.   STAGE 1: Z -> Q1 = L1^-1 Z (work, in place), Gram, L2.
+// STAGE 2: lev_g = |L2^-1 q1_g|^2 and the stripe sums.
+template <int STAGE>
+__global__ __launch_bounds__(256) void lev_qr_kernel(const double* __restrict__ X, int K, int G, double reg, double* work,
+                                                     double* part, const double* Lin, double* Lout, double* __restrict__ lev,
+                                                     double* __restrict__ bsum, int* counter, int* status) {
+    __shared__ LevQrShared sh;
+    const int tid = threadIdx.x, m = K - 1;
+    const int nb = (G + LEV_STRIPE - 1) / LEV_STRIPE;
+    const int b = blockIdx.x;                                             // b == nb: the ridge rows sqrt(reg) I
+    const int g0 = b * LEV_STRIPE;
+    if (STAGE == 0) {
+        if (b < nb) {
+            const int g = g0 + tid;
+            if (tid < LEV_STRIPE) {
+                if (g < G) {
+                    double mean = 0.0;
+                    for (int k = 0; k < K; ++k) mean += X[(size_t)k * G + g];
+                    mean /= (double)K;                                    // genes.py:264
+                    double s = 0.0;
+                    for (int k = 0; k < K; ++k) s += X[(size_t)k * G + g] - mean;
+                    const double rk = sqrt((double)K);
+                    const double xl = X[(size_t)m * G + g] - mean;
+                    const double shift = (s / rk + xl) / (rk + 1.0);      // Householder v = 1/sqrt(K) + e_K applied to xc
+                    for (int k = 0; k < m; ++k) {
+                        const double z = (X[(size_t)k * G + g] - mean) - shift;
+                        sh.tile[k][tid] = z;
+                        work[(size_t)k * G + g] = z;
+                    }
+                } else {
+                    for (int k = 0; k < m; ++k) sh.tile[k][tid] = 0.0;
+                }
+            }
+        } else {
+            for (int e = tid; e < m * LEV_STRIPE; e += 256) {
+                const int k = e / LEV_STRIPE, j = e - k * LEV_STRIPE;
+                sh.tile[k][j] = (k == j) ? sqrt(reg) : 0.0;
+            }
+        }
+        __syncthreads();
+    } else {
+        for (int e = tid; e < m * m; e += 256) sh.C[e / m][e % m] = Lin[e];
+        if (b < nb) {
+            for (int e = tid; e < m * LEV_STRIPE; e += 256) {
+                const int k = e / LEV_STRIPE, j = e - k * LEV_STRIPE;
+                sh.tile[k][j] = (g0 + j < G) ? work[(size_t)k * G + g0 + j] : 0.0;
+            }
+        } else {
+            for (int e = tid; e < m * LEV_STRIPE; e += 256) {
+                const int k = e / LEV_STRIPE, j = e - k * LEV_STRIPE;
+                sh.tile[k][j] = (k == j) ? sqrt(reg) : 0.0;
+            }
+        }
+        __syncthreads();
+        lev_forward_lds(sh, m);
+    }
+    if (STAGE == 2) {
+        double l = 0.0;
+        if (tid < LEV_STRIPE && g0 + tid < G) {
+            for (int k = 0; k < m; ++k) l = fma(sh.tile[k][tid], sh.tile[k][tid], l);
+            lev[g0 + tid] = l;
+        }
+        if (tid < 64) {                                                   // LEV_STRIPE == 64: one wavefront holds the stripe
+            l = wsum(l);
+            if (tid == 0) bsum[b] = l;
+        }
+        return;
+    }
+    if (STAGE == 1 && b < nb) {
+        for (int e = tid; e < m * LEV_STRIPE; e += 256) {
+            const int k = e / LEV_STRIPE, j = e - k * LEV_STRIPE;
+            if (g0 + j < G) work[(size_t)k * G + g0 + j] = sh.tile[k][j];
+        }
+    }
+    double* out = part + (size_t)b * m * m;
+    for (int e = tid; e < m * m; e += 256) {
+        const int p = e / m, q = e - p * m;
+        if (q > p) continue;                                              // lower triangle
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < LEV_STRIPE; j += 2) {
+            a0 = fma(sh.tile[p][j], sh.tile[q][j], a0);
+            a1 = fma(sh.tile[p][j + 1], sh.tile[q][j + 1], a1);
+        }
+        out[p * m + q] = a0 + a1;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) sh.last = (__hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!sh.last) return;
+    __threadfence();
+    const double* pin = part;                                             // written by other workgroups of this launch
+    for (int e = tid; e < m * m; e += 256) {
+        const int p = e / m, q = e - p * m;
+        if (q > p) continue;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int bb = 0; bb <= nb; ++bb)                                   // stripe order: deterministic
+            acc += __hip_atomic_load(&pin[(size_t)bb * m * m + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.C[p][q] = acc;
+    }
+    __syncthreads();
+    lev_chol_lds(sh, m);
+    for (int e = tid; e < m * m; e += 256) {
+        const int p = e / m, q = e - p * m;
+        Lout[e] = (q <= p) ? sh.C[p][q] : 0.0;
+    }
+    if (tid == 0) {
+        if (sh.bad) *status = 2;
+        else if (STAGE == 1 && *status == 0) *status = 1;
+    }
+}
+
+static int launch_leverage_qr(const double* X, int K, int G, double reg, double* work, double* lev, int* sweeps,
+                              double* scratch, hipStream_t st) {
+    const int nb = (G + LEV_STRIPE - 1) / LEV_STRIPE, gb = (G + 255) / 256, m = K - 1;
+    double* part = scratch;
+    double* L1 = part + (size_t)(nb + 1) * K * K;
+    double* L2 = L1 + (size_t)K * K;
+    double* bsum = L2 + (size_t)K * K;
+    (void)m;
+    FDX_HIP(hipMemsetAsync(sweeps, 0, 8 * sizeof(int), st));             // [4], [5]: arrival counters; [7]: 1 = done, 2 = refused
+    hipLaunchKernelGGL(lev_qr_kernel<0>, dim3(nb + 1), dim3(256), 0, st, X, K, G, reg, work, part, nullptr, L1, lev, bsum, sweeps + 5, sweeps + 7);
+    hipLaunchKernelGGL(lev_qr_kernel<1>, dim3(nb + 1), dim3(256), 0, st, X, K, G, reg, work, part, L1, L2, lev, bsum, sweeps + 4, sweeps + 7);
+    hipLaunchKernelGGL(lev_qr_kernel<2>, dim3(nb), dim3(256), 0, st, X, K, G, reg, work, part, L2, nullptr, lev, bsum, nullptr, sweeps + 7);
+    hipLaunchKernelGGL(lev_normalise_kernel, dim3(gb), dim3(256), 0, st, lev, G, bsum, nb, reg);
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+bool leverage_qr_applies(int K, int G) {
+    return K >= 2 && K <= 64 && G >= 1 && !getenv("FDX_LEV_NO_QR") && !getenv("FDX_LEV_ONE_WG");
+}
+
 size_t leverage_scratch_doubles(int K, int G) {
     const size_t nb = (size_t)(G + LEV_STRIPE - 1) / LEV_STRIPE;
-    return nb * K * K + (size_t)K * K + (size_t)(G + 255) / 256 + 16;
+    return (nb + 1) * K * K + 2 * (size_t)K * K + nb + 16;               // the larger of the two routes' layouts
 }
 
 static int launch_leverage_multi(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev,
@@ -540,8 +753,12 @@ static int launch_leverage_multi(const double* X, int K, int G, double reg, doub
 // X: device (K, G) row-major; work: device K*G doubles; sig2: device K doubles; lev: device G doubles; sweeps: 8 ints;
 // scratch: leverage_scratch_doubles(K, G) doubles
 int launch_leverage(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev, int* sweeps,
-                    double* scratch, hipStream_t st) {
+                    double* scratch, hipStream_t st, int route) {
     if (K <= 0 || G <= 0) return fail(FDX_ERR_INVALID, "leverage: empty reference matrix");
+    if (route == LEV_ROUTE_QR) {
+        if (!leverage_qr_applies(K, G) || !scratch) return fail(FDX_ERR_INVALID, "leverage: the Cholesky-QR route needs 2 <= K <= 64");
+        return launch_leverage_qr(X, K, G, reg, work, lev, sweeps, scratch, st);
+    }
     if (K <= 64 && K >= 2 && scratch && !getenv("FDX_LEV_ONE_WG"))
         return launch_leverage_multi(X, K, G, reg, work, sig2, lev, sweeps, scratch, st);
     constexpr size_t kLevLds = (2 * 64 * 65 + 64) * sizeof(double);   // Gram matrix, rotations, per-round (c, s) pairs

@@ -280,6 +280,24 @@ def test_leverage_multi_cu_path_vs_lapack_and_one_workgroup(K, G, cond, monkeypa
     np.testing.assert_allclose(got, one, rtol=2e-8 * max(1.0, cond / 1e4), atol=1e-15)
 
 
+def test_leverage_cholesky_qr_route_refuses_rank_deficient_signatures(capfd, monkeypatch):
+    """Two identical cell types (and a third that is their mean): the ridge-augmented Cholesky factorisation meets a pivot of
+    ~reg against a diagonal of ~1e3, refuses, and fdx_leverage_end runs the Jacobi SVD passes; the well-conditioned matrix
+    next to it stays on the fast route.  Both against LAPACK through the oracle."""
+    from flashdeconv_amd.utils.genes import compute_leverage_scores
+    rs = np.random.RandomState(4)
+    X = rs.gamma(2.0, 3.0, size=(12, 700))
+    monkeypatch.setenv("FDX_DEBUG", "1")
+    got = compute_leverage_scores(X)
+    assert "route=cholesky-qr" in capfd.readouterr().err
+    np.testing.assert_allclose(got, orc.leverage_scores(X), rtol=1e-10, atol=1e-16)
+    X[5] = X[2]
+    X[7] = 0.5 * (X[2] + X[3])
+    got = compute_leverage_scores(X)
+    assert "route=jacobi-svd" in capfd.readouterr().err
+    np.testing.assert_allclose(got, orc.leverage_scores(X), rtol=1e-8, atol=1e-15)
+
+
 def test_seed_reproducibility_and_errors():
     from flashdeconv_amd import FlashDeconv
     g = load_golden("fit_counts_100x500x5_d64.npz")
