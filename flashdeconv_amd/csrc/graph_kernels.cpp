@@ -186,14 +186,18 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict
                                                         const int* __restrict__ start, const int* __restrict__ members,
                                                         long long n, int dim, int* __restrict__ perm, int* __restrict__ rank,
                                                         double* __restrict__ sc, double2* __restrict__ sc2) {
-    const long long i = blockIdx.x * 256LL + threadIdx.x;
-    if (i >= n) return;
+    // thread t takes the point that ARRIVED at slot t: its sorted position lies in the same cell's range as t, so the writes of
+    // a wave (perm, the coordinate planes, the pairs) fall into one contiguous stretch - five scattered stores per point became
+    // two gathers (key, coordinates) and one scattered store (rank)
+    const long long t = blockIdx.x * 256LL + threadIdx.x;
+    if (t >= n) return;
+    const int i = members[t];
     const unsigned k = key32[i];
     const int s = start[k], e = start[k + 1];
     int below = 0;
-    for (int q = s; q < e; ++q) below += (members[q] < (int)i) ? 1 : 0;
+    for (int q = s; q < e; ++q) below += (members[q] < i) ? 1 : 0;
     const int p = s + below;
-    perm[p] = (int)i;
+    perm[p] = i;
     rank[i] = p;
     for (int a = 0; a < dim; ++a) sc[(size_t)a * n + p] = coords[(size_t)i * dim + a];   // planes past dim: zeroed by the caller (one contiguous fill)
     if (sc2) sc2[p] = make_double2(coords[(size_t)i * dim], dim > 1 ? coords[(size_t)i * dim + 1] : 0.0);   // (x, y) pairs: one 16-byte gather per k-NN candidate
@@ -588,16 +592,67 @@ __global__ __launch_bounds__(128) void sort_rows_kernel(int* __restrict__ nbr, c
 }
 
 // ------------------------------------------------------------------------------------------------ ELL
+// width[s] = widest row of slice s; per block the sum of its degrees and its widest slice (part[2b], part[2b + 1]).
+// (One atomic per slice on a single pair of counters was 370 us at 1M spots: 31k same-address atomics, ~12 ns each.)
+constexpr int SLICE_WIDTH_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void slice_width_kernel(const int* __restrict__ deg, long long n, int n_slices,
-                                                          int* __restrict__ width) {
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= n_slices) return;
-    const long long i = (long long)s * 64 + lane;
-    int w = (i < n) ? deg[i] : 0;
+                                                          int* __restrict__ width, long long* __restrict__ part) {
+    __shared__ long long s_sum[4];
+    __shared__ int s_max[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long tot = 0;
+    int wmax = 0;
+    for (int s = blockIdx.x * 4 + wv; s < n_slices; s += gridDim.x * 4) {
+        const long long i = (long long)s * 64 + lane;
+        const int d = (i < n) ? deg[i] : 0;
+        int w = d, sum = d;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) w = max(w, __shfl_xor(w, off, 64));
-    if (lane == 0) width[s] = w;
+        for (int off = 32; off > 0; off >>= 1) {
+            w = max(w, __shfl_xor(w, off, 64));
+            sum += __shfl_xor(sum, off, 64);
+        }
+        if (lane == 0) width[s] = w;
+        tot += sum;
+        wmax = max(wmax, w);
+    }
+    if (lane == 0) { s_sum[wv] = tot; s_max[wv] = wmax; }
+    __syncthreads();
+    if (threadIdx.x == 0 && part) {
+        part[2 * blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        part[2 * blockIdx.x + 1] = (long long)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    }
+}
+
+// red[0] = nnz, red[1] = widest slice, from the blocks' partials; with `meta` (a queued build): the numbers the host will ask
+// for, written straight into its pinned block (one launch instead of a copy each)
+__global__ __launch_bounds__(256) void graph_meta_kernel(const long long* __restrict__ part, int n_part, long long* __restrict__ red,
+                                                         const int* __restrict__ slice_off, int n_slices,
+                                                         const int* __restrict__ summary, const int* __restrict__ ties,
+                                                         long long* __restrict__ meta) {
+    __shared__ long long s_sum[256];
+    __shared__ int s_max[256];
+    long long tot = 0;
+    int wmax = 0;
+    for (int b = threadIdx.x; b < n_part; b += 256) { tot += part[2 * b]; wmax = max(wmax, (int)part[2 * b + 1]); }
+    s_sum[threadIdx.x] = tot;
+    s_max[threadIdx.x] = wmax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + s];
+            s_max[threadIdx.x] = max(s_max[threadIdx.x], s_max[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    red[0] = s_sum[0];
+    red[1] = (long long)s_max[0];
+    if (!meta) return;
+    meta[0] = (long long)slice_off[n_slices];
+    meta[1] = s_sum[0];
+    meta[2] = (long long)s_max[0];
+    meta[3] = (long long)(unsigned)summary[0] | ((long long)summary[1] << 32);
+    meta[4] = ties ? (long long)ties[0] : 0;
 }
 
 // seg_off(p) = p*seg_stride + seg_extra[p]   (k-NN: seg_stride = kk, seg_extra = rev_off; radius: stride 0, extra = off)
@@ -924,26 +979,20 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     const long long n = g->n;
     g->n_slices = (int)((n + 63) / 64);
     DevBuf width, tmp;
-    FDX_TRY(width.alloc((size_t)(g->n_slices + 1) * 4));
+    // width (n_slices + 1 ints), then - 16-byte aligned - red: [0] nnz, [1] widest slice; summary (2 ints, zeroed); the blocks'
+    // partials.  One block, one fill.
+    const int wblocks = std::min(SLICE_WIDTH_BLOCKS, std::max(1, ceil_div(g->n_slices, 4)));
+    const size_t red_at = ((size_t)(g->n_slices + 1) * 4 + 15) / 16 * 16;
+    FDX_TRY(width.alloc(red_at + 32 + (size_t)wblocks * 16));
     FDX_TRY(g->slice_off.alloc((size_t)(g->n_slices + 1) * 4));
-    FDX_HIP(hipMemsetAsync(width.p, 0, width.bytes, st));
-    hipLaunchKernelGGL(slice_width_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, g->deg.as<int>(), n, g->n_slices, width.as<int>());
+    FDX_HIP(hipMemsetAsync(width.p, 0, red_at + 32, st));
+    long long* red = reinterpret_cast<long long*>(static_cast<char*>(width.p) + red_at);
+    int* summary = reinterpret_cast<int*>(red + 2);
+    long long* part = red + 4;
+    hipLaunchKernelGGL(slice_width_kernel, dim3(wblocks), dim3(256), 0, st, g->deg.as<int>(), n, g->n_slices, width.as<int>(), part);
     FDX_CHECK_LAUNCH();
     FDX_TRY(exclusive_scan_int(width.as<int>(), g->slice_off.as<int>(), g->n_slices + 1, st, tmp));
-    trace_host("ell: width + scan");
-    // nnz and max degree
-    size_t rb = 0;
-    DevBuf red, rtmp;
-    FDX_TRY(red.alloc(16));
-    auto deg64 = rocprim::make_transform_iterator(g->deg.as<int>(), [] __device__(int v) { return (long long)v; });
-    FDX_HIP(rocprim::reduce(nullptr, rb, deg64, red.as<long long>(), 0LL, (size_t)n, rocprim::plus<long long>(), st));
-    FDX_TRY(rtmp.alloc(rb));
-    FDX_HIP(rocprim::reduce(rtmp.p, rb, deg64, red.as<long long>(), 0LL, (size_t)n, rocprim::plus<long long>(), st));
-    size_t rb2 = 0;
-    FDX_HIP(rocprim::reduce(nullptr, rb2, width.as<int>(), red.as<int>() + 2, 0, (size_t)g->n_slices, rocprim::maximum<int>(), st));
-    if (rb2 > rtmp.bytes) FDX_TRY(rtmp.alloc(rb2));
-    FDX_HIP(rocprim::reduce(rtmp.p, rb2, width.as<int>(), red.as<int>() + 2, 0, (size_t)g->n_slices, rocprim::maximum<int>(), st));
-    trace_host("ell: 2 reduces");
+    trace_host("ell: width + sums + scan");
     if (defer) {
         // room per row: three times the list length, at least 24 (slice widths of a k = 6 graph are 9-12), at most 96; a graph
         // that needs more (hubs) is rebuilt with its exact size by graph_meta_sync
@@ -952,9 +1001,6 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
         const long long cap = (long long)g->n_slices * w_cap;
         g->ell_cap_rows = cap;
         g->n_tiles = (int)((n + 255) / 256);
-        DevBuf summary;
-        FDX_TRY(summary.alloc(8));
-        FDX_HIP(hipMemsetAsync(summary.p, 0, 8, st));
         FDX_TRY(g->ell.alloc((size_t)std::max<long long>(cap, 1) * 64 * 4));
         FDX_TRY(g->tile_halo.alloc((size_t)std::max(g->n_tiles, 1) * FDX_TILE_HALO_CAP * 4));
         FDX_TRY(g->tile_hcnt.alloc((size_t)std::max(g->n_tiles, 1) * 4));
@@ -965,7 +1011,7 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
         if (g->n_tiles > 0) {
             hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, g->ell.as<int>(), g->deg.as<int>(),
                                g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
-                               g->ell_local.as<unsigned short>(), cap, summary.as<int>());
+                               g->ell_local.as<unsigned short>(), cap, summary);
             FDX_CHECK_LAUNCH();
         }
         if (!g->meta_host) g->meta_host = (long long*)pinned_block_get();
@@ -973,10 +1019,11 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
         if (!g->meta_event) FDX_HIP(hipEventCreateWithFlags(&g->meta_event, hipEventDisableTiming));
         for (int j = 0; j < 8; ++j) g->meta_host[j] = 0;
         // [0] low word: ell rows; [1] nnz; [2] low word: max slice width; [3] low word: largest halo, high word: failed-tile flag
-        FDX_HIP(hipMemcpyAsync(&g->meta_host[0], g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
-        FDX_HIP(hipMemcpyAsync(&g->meta_host[1], red.p, 16, hipMemcpyDeviceToHost, st));
-        FDX_HIP(hipMemcpyAsync(&g->meta_host[3], summary.p, 8, hipMemcpyDeviceToHost, st));
-        if (g->ties_dev.p) FDX_HIP(hipMemcpyAsync(&g->meta_host[4], g->ties_dev.p, 4, hipMemcpyDeviceToHost, st));
+        void* meta_dev = nullptr;
+        FDX_HIP(hipHostGetDevicePointer(&meta_dev, g->meta_host, 0));
+        hipLaunchKernelGGL(graph_meta_kernel, dim3(1), dim3(256), 0, st, part, wblocks, red, g->slice_off.as<int>(), g->n_slices, summary,
+                           g->ties_dev.as<int>(), (long long*)meta_dev);
+        FDX_CHECK_LAUNCH();
         FDX_HIP(hipEventRecord(g->meta_event, st));
         g->meta_stream = st;
         g->meta_pending = true;
@@ -984,11 +1031,13 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
         trace_host("ell: deferred build queued");
         return 0;
     }
+    hipLaunchKernelGGL(graph_meta_kernel, dim3(1), dim3(256), 0, st, part, wblocks, red, nullptr, 0, nullptr, nullptr, nullptr);
+    FDX_CHECK_LAUNCH();
     int total = 0;
     FDX_HIP(hipMemcpyAsync(&total, g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
     long long h_red[2] = {0, 0};
     int h_ties = 0;
-    FDX_HIP(hipMemcpyAsync(h_red, red.p, 16, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipMemcpyAsync(h_red, red, 16, hipMemcpyDeviceToHost, st));
     if (g->ties_dev.p) FDX_HIP(hipMemcpyAsync(&h_ties, g->ties_dev.p, 4, hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
     g->knn_ties = h_ties;
