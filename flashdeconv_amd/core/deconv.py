@@ -232,17 +232,6 @@ class FlashDeconv:
             G = len(gene_idx)
             log(f"  Selected {G} genes (HVG + markers)")
             Xsel = np.ascontiguousarray(X[:, gene_idx])
-            # The leverage SVD runs on the library's side stream beside the graph build.  Its job is set up FIRST: set up behind
-            # the build call, its pooled buffers (last used on the caller's stream) order the side stream behind everything the
-            # build has just queued - the SVD then starts when the graph is done (measured: the wait 0.6 -> 1.3 ms).
-            lev_job = _genes.LeverageJob(Xsel)
-            if G != G_all and csr is None:          # Y[:, gene_idx] (core/deconv.py:321) as a compact device matrix
-                sub = _DeviceBuffer(n * G * (4 if y_code == _lib.FDX_F32 else 8))
-                owned.append(sub)
-                gi32 = np.ascontiguousarray(gene_idx, dtype=np.int32)
-                _lib.check(lib.fdx_gather_columns_dev(y_ptr, y_code, n, G_all, G_all, _lib.ptr_i32(gi32), G, sub.ptr, None))
-                y_ptr = sub.ptr
-            ldy = G
             if _is_torch_cuda(coords):
                 import torch
                 cd = coords.to(torch.float64).contiguous()
@@ -254,10 +243,21 @@ class FlashDeconv:
                 owned.append(cbuf)
                 c_ptr = cbuf.ptr
             dim = int(coords.shape[1])
+            g_method, g_k, g_radius = self._graph_request(coords, coords_host)
+            # The leverage SVD runs on the library's side stream beside the graph build.  Its job is set up FIRST: set up behind
+            # the build call, its pooled buffers (last used on the caller's stream) order the side stream behind everything the
+            # build has just queued - the SVD then starts when the graph is done (measured: the wait 0.6 -> 1.3 ms).
+            lev_job = _genes.LeverageJob(Xsel)
+            if G != G_all and csr is None:          # Y[:, gene_idx] (core/deconv.py:321) as a compact device matrix
+                sub = _DeviceBuffer(n * G * (4 if y_code == _lib.FDX_F32 else 8))
+                owned.append(sub)
+                gi32 = np.ascontiguousarray(gene_idx, dtype=np.int32)
+                _lib.check(lib.fdx_gather_columns_dev(y_ptr, y_code, n, G_all, G_all, _lib.ptr_i32(gi32), G, sub.ptr, None))
+                y_ptr = sub.ptr
+            ldy = G
 
             # Step 4 runs here, under the leverage SVD (no data dependence between core/deconv.py:318 and :358)
             t_graph = time.perf_counter()
-            g_method, g_k, g_radius = self._graph_request(coords, coords_host)
             if self._graph is not None:
                 self._graph.close()
                 self._graph = None

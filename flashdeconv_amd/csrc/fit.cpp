@@ -237,83 +237,85 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     if (g->meta_pending && g->meta_event && g->meta_stream != st) FDX_HIP(hipStreamWaitEvent(st, g->meta_event, 0));
     tm.mark();  // 1
 
-    // ---- beta0 = 1/K (core/solver.py:372) and the cleared pad rows: nothing depends on anything here, so the two fills go to the
-    // library's side stream now and run while the host prepares the sketch (plans, X upload) instead of between sketch and sweeps
+    // ---- Everything that does not depend on the graph or on Y goes to the library's side stream and runs beside the graph build
+    // queued on the caller's stream just before: beta0 = 1/K (core/solver.py:372) and the cleared pad rows, the sketch tables
+    // (Omega comes from the host: hash/sign from numpy's RandomState, core/sketching.py:58-59; plans are shared through a
+    // content-keyed cache, so a repeated fit builds nothing), X, X_sketch (K, d) and XtX (core/sketching.py:202-204,
+    // core/solver.py:346).  The buffers are allocated with the side stream as their pool stream (a block last used elsewhere
+    // orders it behind that work); the caller's stream waits for ONE event before the sketch.  (Queued on the caller's stream
+    // these ~120 us of small launches and copies sat between the end of the graph build and the start of the sketch, and a new
+    // plan's table upload made the host wait for the whole graph build.)
     const long long ld = round_up(n + 1, 64);
-    DevBuf dB0, dB1;
+    DevBuf dB0, dB1, dX, dXs, dG, dSlots, dBits;   // dSlots, dBits (CSR source): per-column {weight, bucket} table over all G_all columns + "selected" bitmap
     struct SideDrain { hipStream_t s = nullptr; ~SideDrain() { if (s) (void)hipStreamSynchronize(s); } } side_drain;   // before buffers are released
+    // an early return leaves work on the caller's stream that uses the side-stream buffers above: wait for it before they go
+    struct AbortDrain { hipStream_t s; bool armed = true; ~AbortDrain() { if (armed) (void)hipStreamSynchronize(s); } } abort_drain{st};
     hipEvent_t evInit = nullptr;
     struct EvGuard0 { hipEvent_t* e; ~EvGuard0() { if (*e) (void)hipEventDestroy(*e); } } evInit_guard{&evInit};
-    FDX_TRY(dB0.alloc((size_t)K * ld * sizeof(double)));
-    FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
     hipStream_t side = getenv("FDX_NO_SIDE_STREAM") ? nullptr : leverage_side_stream();
     if (side == st) side = nullptr;
-    if (side) {
-        // the blocks may have been recycled from work queued on `st` (the graph build just before): order the side stream behind it
-        hipEvent_t evTop = nullptr;
-        FDX_HIP(hipEventCreateWithFlags(&evTop, hipEventDisableTiming));
-        struct EvOnce { hipEvent_t e; ~EvOnce() { (void)hipEventDestroy(e); } } evTop_guard{evTop};
-        FDX_HIP(hipEventRecord(evTop, st));
-        FDX_HIP(hipStreamWaitEvent(side, evTop, 0));
-        side_drain.s = side;
-        FDX_TRY(solver_init_beta(dB0.as<double>(), ld, g->n_total, K, side));
-        FDX_TRY(solver_zero_pad(dB1.as<double>(), ld, g->n_total, K, side));
-        FDX_HIP(hipEventCreateWithFlags(&evInit, hipEventDisableTiming));
-        FDX_HIP(hipEventRecord(evInit, side));
-    }
-
-    // ---- sketch plans (Omega tables come from the host: hash/sign from numpy's RandomState, core/sketching.py:58-59);
-    // shared through a content-keyed cache, so a repeated fit builds nothing
+    const hipStream_t xs = side ? side : st;
+    if (side) side_drain.s = side;
     std::shared_ptr<SketchPlan> plan_y_p, plan_x_p;
-    DevBuf dSlots, dBits;        // CSR source: per-column {weight, bucket} table over all G_all columns + "selected" bitmap
     int sel_words = 0;
     for (int g_ = 0; g_ < G; ++g_) FDX_REQUIRE(bucket[g_] >= 0 && bucket[g_] < d, "fit: bucket index out of range");
-    if (ysrc.csr) {
-        const int G_all = ysrc.csr->G;
-        FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(GeneSlotHost), "fit: gene slot layout mismatch");
-        std::vector<GeneSlotHost> slots((size_t)G_all, GeneSlotHost{0.0, -1, 0});
-        for (int j = 0; j < G; ++j) {
-            const int c = ysrc.gene_idx ? ysrc.gene_idx[j] : j;
-            FDX_REQUIRE(c >= 0 && c < G_all, "fdx_fit_csr_dev: gene index out of range");
-            FDX_REQUIRE(slots[(size_t)c].bucket < 0, "fdx_fit_csr_dev: duplicate gene index");
-            slots[(size_t)c] = GeneSlotHost{weight_y[j], bucket[j], 0};
-        }
-        sel_words = (G_all + 31) / 32;
-        std::vector<unsigned> bits((size_t)sel_words, 0u);
-        for (int c = 0; c < G_all; ++c)
-            if (slots[(size_t)c].bucket >= 0) bits[(size_t)c >> 5] |= 1u << (c & 31);
-        FDX_TRY(dSlots.alloc(slots.size() * sizeof(GeneSlotHost)));
-        FDX_TRY(dBits.alloc(bits.size() * sizeof(unsigned)));
-        FDX_HIP(hipMemcpyAsync(dSlots.p, slots.data(), slots.size() * sizeof(GeneSlotHost), hipMemcpyHostToDevice, st));
-        FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
-        FDX_HIP(hipStreamSynchronize(st));   // `slots` is a stack-scoped host buffer
-    } else {
-        FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, st, &plan_y_p));
-    }
-    if (!ysrc.csr && weight_x == weight_y) plan_x_p = plan_y_p;
-    else FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, st, &plan_x_p));
-    SketchPlan plan_none;
-    const SketchPlan& plan_y = plan_y_p ? *plan_y_p : plan_none;
-    const SketchPlan& plan_x = *plan_x_p;
-
-    // ---- X_sketch (K, d) and XtX (core/sketching.py:202-204, core/solver.py:346)
-    DevBuf dX, dXs, dG, dH, dYs, dRowSq, dSum;
-    FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
-    FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
-    FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
-    FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, prm->mode_x, plan_x.dev(), dXs.as<double>(), d, nullptr, st));
-    FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, st));
-    // XtX goes to the host NOW, ahead of the big sketch kernel: lambda and the scaled rho are host scalars of the sweeps,
-    // and with them known early the solve is queued behind the sketch without the host waiting for it
     double* Gh = (double*)pinned_scratch(0, (size_t)K * K * sizeof(double));   // pinned: the copy below must not hold the host back
     FDX_REQUIRE(Gh != nullptr, "fit: pinned host buffer");
     hipEvent_t evG = nullptr;
     FDX_HIP(hipEventCreateWithFlags(&evG, hipEventDisableTiming));
     struct EvGuard { hipEvent_t e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evG_guard{evG};
-    FDX_HIP(hipMemcpyAsync(Gh, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipEventRecord(evG, st));
+    {
+        PoolStream pool_xs(xs);
+        FDX_TRY(dB0.alloc((size_t)K * ld * sizeof(double)));
+        FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
+        if (side) {
+            FDX_TRY(solver_init_beta(dB0.as<double>(), ld, g->n_total, K, xs));
+            FDX_TRY(solver_zero_pad(dB1.as<double>(), ld, g->n_total, K, xs));
+        }
+        if (ysrc.csr) {
+            const int G_all = ysrc.csr->G;
+            FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(GeneSlotHost), "fit: gene slot layout mismatch");
+            std::vector<GeneSlotHost> slots((size_t)G_all, GeneSlotHost{0.0, -1, 0});
+            for (int j = 0; j < G; ++j) {
+                const int c = ysrc.gene_idx ? ysrc.gene_idx[j] : j;
+                FDX_REQUIRE(c >= 0 && c < G_all, "fdx_fit_csr_dev: gene index out of range");
+                FDX_REQUIRE(slots[(size_t)c].bucket < 0, "fdx_fit_csr_dev: duplicate gene index");
+                slots[(size_t)c] = GeneSlotHost{weight_y[j], bucket[j], 0};
+            }
+            sel_words = (G_all + 31) / 32;
+            std::vector<unsigned> bits((size_t)sel_words, 0u);
+            for (int c = 0; c < G_all; ++c)
+                if (slots[(size_t)c].bucket >= 0) bits[(size_t)c >> 5] |= 1u << (c & 31);
+            FDX_TRY(dSlots.alloc(slots.size() * sizeof(GeneSlotHost)));
+            FDX_TRY(dBits.alloc(bits.size() * sizeof(unsigned)));
+            FDX_HIP(hipMemcpyAsync(dSlots.p, slots.data(), slots.size() * sizeof(GeneSlotHost), hipMemcpyHostToDevice, xs));
+            FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, xs));
+            FDX_HIP(hipStreamSynchronize(xs));   // `slots` is a stack-scoped host buffer
+        } else {
+            FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, xs, &plan_y_p));
+        }
+        if (!ysrc.csr && weight_x == weight_y) plan_x_p = plan_y_p;
+        else FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, xs, &plan_x_p));
+        FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
+        FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
+        FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
+        FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, xs));
+        FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, prm->mode_x, plan_x_p->dev(), dXs.as<double>(), d, nullptr, xs));
+        FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, xs));
+        // XtX goes to the host NOW: lambda and the scaled rho are host scalars of the sweeps, and with them known early the solve
+        // is queued behind the sketch without the host waiting for it
+        FDX_HIP(hipMemcpyAsync(Gh, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, xs));
+        FDX_HIP(hipEventRecord(evG, xs));
+        if (side) {
+            FDX_HIP(hipEventCreateWithFlags(&evInit, hipEventDisableTiming));
+            FDX_HIP(hipEventRecord(evInit, side));
+            FDX_HIP(hipStreamWaitEvent(st, evInit, 0));          // tables, X_sketch, XtX, beta0: all behind this one
+        }
+    }
+    SketchPlan plan_none;
+    const SketchPlan& plan_y = plan_y_p ? *plan_y_p : plan_none;
 
+    DevBuf dH, dYs, dRowSq, dSum;
     // ---- Y_sketch in solver order, chunked, contracted into H (K, ld) as it is produced
     FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
     FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
@@ -449,6 +451,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
                                         prop_out_dev, st));
     tm.mark();  // 4
     FDX_HIP(hipStreamSynchronize(st));
+    abort_drain.armed = false;
 
     info->solve.converged = r.converged;
     info->solve.n_iterations = r.n_iterations;

@@ -17,6 +17,8 @@
 //      by original index + unique.
 //   5. sliced ELL (slice = 64 consecutive sorted points = one wavefront of the BCD sweep).
 #include <chrono>
+#include <memory>
+#include <mutex>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -69,6 +71,35 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const double* __restr
     if (threadIdx.x < 3) {
         part[(size_t)blockIdx.x * 6 + threadIdx.x] = smn[threadIdx.x][0];
         part[(size_t)blockIdx.x * 6 + 3 + threadIdx.x] = smx[threadIdx.x][0];
+    }
+}
+
+// the blocks' boxes folded into one, written where `out` points (the host's pinned block): no copy to wait for
+__global__ __launch_bounds__(256) void bbox_final_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    __shared__ double smn[3][256], smx[3][256];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
+    for (int b = threadIdx.x; b < nblk; b += 256)
+        for (int a = 0; a < 3; ++a) {
+            const double lo = part[(size_t)b * 6 + a], hi = part[(size_t)b * 6 + 3 + a];
+            bad = bad || lo != lo || hi != hi;           // fmin / fmax drop a NaN: carry it by hand
+            mn[a] = fmin(mn[a], lo);
+            mx[a] = fmax(mx[a], hi);
+        }
+    for (int a = 0; a < 3; ++a) { smn[a][threadIdx.x] = bad ? NAN : mn[a]; smx[a][threadIdx.x] = mx[a]; }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int a = 0; a < 3; ++a) {
+                const double x = smn[a][threadIdx.x], y = smn[a][threadIdx.x + s];
+                smn[a][threadIdx.x] = (x != x || y != y) ? NAN : fmin(x, y);
+                smx[a][threadIdx.x] = fmax(smx[a][threadIdx.x], smx[a][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) {
+        out[threadIdx.x] = smn[threadIdx.x][0];
+        out[3 + threadIdx.x] = smx[threadIdx.x][0];
     }
 }
 
@@ -806,26 +837,53 @@ static int exclusive_scan_i64(const int* in, long long* out, long long count, hi
     return 0;
 }
 
+// The bounding box is the one thing the host must read before it can queue the rest of a build (grid parameters size every
+// launch).  bbox_begin queues it - block partials, one workgroup folds them and writes the six numbers into a pinned block -
+// and make_grid waits for its event.  (Queueing it ahead of the fit's other host work - a hint entry the fit called before it
+// set up the leverage job - was tried: the box arrives earlier, the leverage scores later, the wall time is the same.)
+struct BboxJob {
+    const double* coords = nullptr;
+    long long n = 0;
+    int dim = 0, dev = 0;
+    hipEvent_t ev = nullptr;
+    double* host = nullptr;      // pinned_block_get(): mn[3], mx[3]
+    DevBuf part;
+    ~BboxJob() {
+        if (ev) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+        if (host) pinned_block_put(host);
+    }
+};
+
+static int bbox_begin(const double* d_coords, long long n, int dim, hipStream_t st, BboxJob* job) {
+    job->coords = d_coords; job->n = n; job->dim = dim;
+    FDX_HIP(hipGetDevice(&job->dev));
+    const int nblk = (int)std::min<long long>(1024, (n + 255) / 256);
+    FDX_TRY(job->part.alloc((size_t)nblk * 6 * sizeof(double)));
+    job->host = (double*)pinned_block_get();
+    FDX_REQUIRE(job->host != nullptr, "graph: pinned host block");
+    void* host_dev = nullptr;
+    FDX_HIP(hipHostGetDevicePointer(&host_dev, job->host, 0));
+    FDX_HIP(hipEventCreateWithFlags(&job->ev, hipEventDisableTiming));
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblk), dim3(256), 0, st, d_coords, n, dim, job->part.as<double>());
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, job->part.as<double>(), nblk, (double*)host_dev);
+    FDX_CHECK_LAUNCH();
+    FDX_HIP(hipEventRecord(job->ev, st));
+    return 0;
+}
+
 static int make_grid(const double* d_coords, long long n, int dim, double target_per_cell, double min_h,
                      GridParams* gp, hipStream_t st) {
-    const int nblk = (int)std::min<long long>(1024, (n + 255) / 256);
-    DevBuf part;
-    FDX_TRY(part.alloc((size_t)nblk * 6 * sizeof(double)));
-    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nblk), dim3(256), 0, st, d_coords, n, dim, part.as<double>());
-    FDX_CHECK_LAUNCH();
-    std::vector<double> h_part((size_t)nblk * 6);
-    FDX_HIP(hipMemcpyAsync(h_part.data(), part.p, h_part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
+    auto job = std::make_unique<BboxJob>();
+    FDX_TRY(bbox_begin(d_coords, n, dim, st, job.get()));
+    FDX_HIP(hipEventSynchronize(job->ev));
     double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     for (int a = 0; a < dim; ++a) {
-        mn[a] = INFINITY; mx[a] = -INFINITY;
-        for (int b = 0; b < nblk; ++b) {
-            mn[a] = std::min(mn[a], h_part[(size_t)b * 6 + a]);
-            mx[a] = std::max(mx[a], h_part[(size_t)b * 6 + 3 + a]);
-        }
+        mn[a] = job->host[a];
+        mx[a] = job->host[3 + a];
         if (!(std::isfinite(mn[a]) && std::isfinite(mx[a])))
             return fail(FDX_ERR_INVALID, "graph: coordinates contain NaN or infinity");
     }
+    job.reset();
     // cell edge from the occupied volume: ~target_per_cell points per cell over the axes with non-zero extent
     double vol = 1.0;
     int eff = 0;
