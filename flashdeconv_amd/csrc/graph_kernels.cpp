@@ -1520,6 +1520,9 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
     // halo = sorted unique set of the neighbour positions outside [lo, hi) that the own rows reference
     DevBuf tmp, counter, ext, ext_sorted, n_uniq, d_bounds, skeys, skeys_sorted, skeys_uniq;
     int n_halo = 0, n_send = 0;
+    const int s0 = (int)(lo >> 6);
+    int so2[2] = {0, 0};
+    bool have_so2 = false;
     FDX_TRY(counter.alloc(8));
     FDX_TRY(d_bounds.alloc((size_t)(n_ranks + 1) * 8));
     FDX_HIP(hipMemcpyAsync(d_bounds.p, bounds, (size_t)(n_ranks + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1531,6 +1534,11 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
         FDX_CHECK_LAUNCH();
         int n_ext = 0;
         FDX_HIP(hipMemcpyAsync(&n_ext, counter.p, 4, hipMemcpyDeviceToHost, st));
+        if (loc->n_slices > 0) {                         // the two slice offsets that bound the own rows ride in the same round trip
+            FDX_HIP(hipMemcpyAsync(&so2[0], full->slice_off.as<int>() + s0, 4, hipMemcpyDeviceToHost, st));
+            FDX_HIP(hipMemcpyAsync(&so2[1], full->slice_off.as<int>() + s0 + loc->n_slices, 4, hipMemcpyDeviceToHost, st));
+            have_so2 = true;
+        }
         FDX_HIP(hipStreamSynchronize(st));
         if (n_ext > 0) {
             FDX_TRY(ext.alloc((size_t)n_ext * 4));
@@ -1572,9 +1580,7 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
     if (!loc->halo_global.p) FDX_TRY(loc->halo_global.alloc(4));
     loc->n_total = n_own + n_halo;
     // local ELL / deg / perm
-    const int s0 = (int)(lo >> 6);
-    int so2[2] = {0, 0};                              // the two slice offsets that bound the own rows
-    if (loc->n_slices > 0) {
+    if (loc->n_slices > 0 && !have_so2) {
         FDX_HIP(hipMemcpyAsync(&so2[0], full->slice_off.as<int>() + s0, 4, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipMemcpyAsync(&so2[1], full->slice_off.as<int>() + s0 + loc->n_slices, 4, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipStreamSynchronize(st));
@@ -1594,12 +1600,20 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
     } else {
         FDX_HIP(hipMemsetAsync(loc->slice_off.p, 0, loc->slice_off.bytes, st));
     }
-    // nnz / max degree of the own rows (device reductions: a host loop over a 4 MB read-back was most of this function)
+    // Everything else the host needs arrives in ONE round trip (each used to have its own - seven synchronisations, ~0.2 ms for
+    // a strong-scaled rank whose whole sketch is 0.25 ms): nnz / widest row of the own rows, the tile tables' summary, the halo
+    // positions (recv lists) and the (peer, row) send keys, all into pinned memory.
     loc->nnz = 0;
     loc->max_deg = 0;
+    loc->n_tiles = (int)((n_own + 255) / 256);
+    loc->tiled = false;
+    loc->halo_max = 0;
+    const bool tiles = loc->n_tiles > 0 && loc->ell_rows > 0;
+    DevBuf red, rtmp;
+    FDX_TRY(red.alloc(32));                               // [0] nnz, [1] low word: max degree; summary: 2 ints at byte 16
+    FDX_HIP(hipMemsetAsync(red.p, 0, 32, st));
+    int* summary = red.as<int>() + 4;
     if (n_own > 0) {
-        DevBuf red, rtmp;
-        FDX_TRY(red.alloc(16));
         size_t rb = 0, rb2 = 0;
         auto deg64 = rocprim::make_transform_iterator(loc->deg.as<int>(), [] __device__(int v) { return (long long)v; });
         FDX_HIP(rocprim::reduce(nullptr, rb, deg64, red.as<long long>(), 0LL, (size_t)n_own, rocprim::plus<long long>(), st));
@@ -1607,27 +1621,44 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
         FDX_TRY(rtmp.alloc(std::max(rb, rb2)));
         FDX_HIP(rocprim::reduce(rtmp.p, rb, deg64, red.as<long long>(), 0LL, (size_t)n_own, rocprim::plus<long long>(), st));
         FDX_HIP(rocprim::reduce(rtmp.p, rb2, loc->deg.as<int>(), red.as<int>() + 2, 0, (size_t)n_own, rocprim::maximum<int>(), st));
-        long long h_red[2] = {0, 0};
-        FDX_HIP(hipMemcpyAsync(h_red, red.p, 16, hipMemcpyDeviceToHost, st));
-        FDX_HIP(hipStreamSynchronize(st));
+    }
+    if (tiles) {
+        FDX_TRY(loc->tile_halo.alloc((size_t)loc->n_tiles * FDX_TILE_HALO_CAP * 4));
+        FDX_TRY(loc->tile_hcnt.alloc((size_t)loc->n_tiles * 4));
+        FDX_TRY(loc->ell_local.alloc(((size_t)loc->ell_rows + 16) * 64 * 2));   // + 16 rows: the tiled sweep loads 16 rows per slice unconditionally
+        hipLaunchKernelGGL(tile_halo_kernel, dim3(loc->n_tiles), dim3(256), 0, st, loc->ell.as<int>(), loc->deg.as<int>(),
+                           loc->slice_off.as<int>(), n_own, loc->tile_halo.as<int>(), loc->tile_hcnt.as<int>(),
+                           loc->ell_local.as<unsigned short>(), (long long)loc->ell_rows, summary);
+        FDX_CHECK_LAUNCH();
+    }
+    const size_t hg_at = 64, hk_at = hg_at + ((size_t)n_halo * 4 + 63) / 64 * 64;
+    unsigned char* pin = (unsigned char*)pinned_scratch(3, hk_at + (size_t)n_send * 8 + 64);
+    FDX_REQUIRE(pin != nullptr, "graph_localize: pinned host buffer");
+    FDX_HIP(hipMemcpyAsync(pin, red.p, 32, hipMemcpyDeviceToHost, st));
+    if (n_halo) FDX_HIP(hipMemcpyAsync(pin + hg_at, loc->halo_global.p, (size_t)n_halo * 4, hipMemcpyDeviceToHost, st));
+    if (n_send) FDX_HIP(hipMemcpyAsync(pin + hk_at, skeys_uniq.p, (size_t)n_send * 8, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    {
+        const long long* h_red = (const long long*)pin;
+        const int* h_sum = (const int*)(pin + 16);
         loc->nnz = h_red[0];
         loc->max_deg = (int)(h_red[1] & 0xffffffffLL);
+        if (tiles) {
+            loc->tiled = h_sum[1] == 0;
+            loc->halo_max = h_sum[0];
+        }
     }
-    FDX_TRY(build_tiles(loc, st));
     // halo ownership (recv) and send lists per peer
     loc->recv_off.assign((size_t)n_ranks + 1, 0);
     loc->send_off.assign((size_t)n_ranks + 1, 0);
-    std::vector<int> hg((size_t)std::max(n_halo, 1));
-    if (n_halo) FDX_HIP(hipMemcpyAsync(hg.data(), loc->halo_global.p, (size_t)n_halo * 4, hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
+    const int* hg_p = (const int*)(pin + hg_at);
+    const unsigned long long* hk = (const unsigned long long*)(pin + hk_at);
+    struct { const int* p; const int* begin() const { return p; } } hg{hg_p};
     for (int r = 0; r < n_ranks; ++r) {
         const long long e = bounds[r + 1];
         loc->recv_off[(size_t)r + 1] = (int)(std::lower_bound(hg.begin(), hg.begin() + n_halo, (int)std::min<long long>(e, 0x7fffffff)) - hg.begin());
     }
     // send lists: the unique (peer, row) keys are already grouped by peer and ascending in the row
-    std::vector<unsigned long long> hk((size_t)std::max(n_send, 1));
-    if (n_send) FDX_HIP(hipMemcpyAsync(hk.data(), skeys_uniq.p, (size_t)n_send * 8, hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
     std::vector<int> all_send((size_t)n_send);
     {
         int at = 0;

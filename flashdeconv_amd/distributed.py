@@ -72,10 +72,12 @@ class TorchComm:
         self.world = dist.get_world_size(group)
 
     def all_reduce_max(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
 
     def all_reduce_sum(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def all_gather_rows(self, nbr, cnt, bounds):
         """Every rank has written rows [bounds[rank], bounds[rank+1]) of nbr (n, kk) / cnt (n); fill in the rows of the
@@ -598,14 +600,25 @@ class ShardedFlashDeconv:
                 real = solver.sweep_events[:info["n_iterations"]]              # later launches are post-convergence no-ops
                 self.sweep_ms_ = [a.elapsed_time(b) for a, b in real]
         t0 = self._tick("solve", t0)
-        # the export is queued first: the objective's read-back below then waits for both (one host wait instead of two)
+        # the export (reads the final abundances, writes two (n_own, K) matrices) runs on a side stream BESIDE the objective pass
+        # (reads the same abundances), as in the single-GPU fit; the objective's read-back then waits for both
         self.beta_ = torch.empty((n_own, K), dtype=torch.float64, device=dev)
         self.proportions_ = torch.empty((n_own, K), dtype=torch.float64, device=dev)
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
+        side.wait_stream(cur)
         _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(beta.data_ptr()), ld, n_own, K, ctypes.c_void_p(self.beta_.data_ptr()),
-                                         ctypes.c_void_p(self.proportions_.data_ptr()), st))
-        part = torch.from_numpy(np.concatenate([backend.objective_partials(beta), [yty_part]])).to(dev)
-        self.comm.all_reduce_sum(part)                                        # objective partials and YtY in one collective
-        c = part.cpu().numpy()
+                                         ctypes.c_void_p(self.proportions_.data_ptr()), ctypes.c_void_p(side.cuda_stream)))
+        part_h = np.concatenate([backend.objective_partials(beta), [yty_part]])
+        cur.wait_stream(side)
+        if self.comm.world > 1:
+            part = torch.from_numpy(part_h).to(dev)
+            self.comm.all_reduce_sum(part)                                    # objective partials and YtY in one collective
+            c = part.cpu().numpy()
+        else:
+            c = part_h
         YtY = float(c[4])
         info["final_objective"] = float(0.5 * (YtY - 2.0 * c[0] + c[1]) + 0.5 * lam * c[2] + rho_eff * c[3])
         info["objectives"] = []
