@@ -75,6 +75,38 @@ def test_knn_vs_oracle_kdtree(n, dim, k):
     assert (A != A.T).nnz == 0 and A.diagonal().sum() == 0
 
 
+@pytest.mark.parametrize("case", ["square", "hex", "cube", "line", "duplicates", "square_offset"])
+@pytest.mark.parametrize("k", [4, 6, 8, 12, 20, 40])
+def test_knn_tie_rule_is_distance_then_index(case, k):
+    """Inputs FULL of exact distance ties (lattices in 1-3 dimensions, repeated points): the neighbour lists must be those
+    of the brute-force oracle, whose stable argsort of the squared distances IS the documented rule - nearer first, lower
+    spot index among equals.  The list lengths 5 ... 41 go through every instantiation of the k-NN kernel (8 / 16 / 32 / 64
+    slots; the flat 3 x 3 walk and the shell walk), with and without a spare slot for the tie test."""
+    from flashdeconv_amd.utils import graph as G
+    rs = np.random.RandomState(k)
+    if case == "square":
+        gx, gy = np.meshgrid(np.arange(33.0), np.arange(31.0))
+        coords = np.stack([gx.ravel(), gy.ravel()], 1)
+    elif case == "square_offset":            # not exactly representable steps: ties only where the arithmetic says so
+        gx, gy = np.meshgrid(np.arange(30.0) * 0.1 + 1e3, np.arange(30.0) * 0.3 - 7.7)
+        coords = np.stack([gx.ravel(), gy.ravel()], 1)
+    elif case == "hex":
+        gx, gy = np.meshgrid(np.arange(30.0), np.arange(30.0))
+        coords = np.stack([(gx + 0.5 * (gy % 2)).ravel(), (gy * 0.5).ravel()], 1)
+    elif case == "cube":
+        g = np.meshgrid(np.arange(10.0), np.arange(9.0), np.arange(11.0))
+        coords = np.stack([a.ravel() for a in g], 1)
+    elif case == "line":
+        coords = np.arange(700.0)[:, None] * 0.5
+    else:
+        base = rs.rand(150, 2) * 12.0
+        coords = base[rs.randint(0, len(base), 900)]
+    coords = np.ascontiguousarray(coords[rs.permutation(len(coords))])
+    A = G.build_knn_graph(coords, k=k)
+    B = orc.knn_graph(coords, k)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+
+
 def test_knn_clustered_and_elongated():
     from flashdeconv_amd.utils import graph as G
     rs = np.random.RandomState(3)
