@@ -45,6 +45,7 @@ struct TileArgs {
     long long ldy, n, ldh;
     int G, d, K;
     int NE, GB, NBLK, RS, jw_used;
+    int NST;   // stage buffers: 2, or 3 (raw mode with loader waves: two blocks in flight while one is consumed)
 };
 
 template <typename T> struct TileVec;
@@ -55,6 +56,19 @@ template <> struct TileVec<double> { typedef double type __attribute__((ext_vect
 __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_base) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                      (void __attribute__((address_space(3)))*)lds_base, 16, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the instruction takes an immediate): waits until at most
+// min(n, 24) of this wave's vector-memory operations are outstanding - the OLDER ones have completed (loads return in order)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define FDX_VMCNT(N) case N: __builtin_amdgcn_s_waitcnt(0x0f70 | ((N) & 15) | (((N) >> 4) << 14)); break;
+    switch (n) {
+        FDX_VMCNT(0) FDX_VMCNT(1) FDX_VMCNT(2) FDX_VMCNT(3) FDX_VMCNT(4) FDX_VMCNT(5) FDX_VMCNT(6) FDX_VMCNT(7)
+        FDX_VMCNT(8) FDX_VMCNT(9) FDX_VMCNT(10) FDX_VMCNT(11) FDX_VMCNT(12) FDX_VMCNT(13) FDX_VMCNT(14) FDX_VMCNT(15)
+        FDX_VMCNT(16) FDX_VMCNT(17) FDX_VMCNT(18) FDX_VMCNT(19) FDX_VMCNT(20) FDX_VMCNT(21) FDX_VMCNT(22) FDX_VMCNT(23)
+        default: __builtin_amdgcn_s_waitcnt(0x0f70 | (24 & 15) | ((24 >> 4) << 14)); break;
+    }
+#undef FDX_VMCNT
 }
 
 // group lengths are stored 8 to a 64-bit word: JW rounded up
@@ -94,7 +108,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     const int r = lane & 15, q = lane >> 4;
     const int stage_bytes = TILE_ROWS * a.RS;
     const int NEp = (a.NE + 7) & ~7;
-    double* w_l = reinterpret_cast<double*>(smem + 2 * (size_t)stage_bytes);
+    const int NST = (NWL > 0 && MODE == FDX_PRE_RAW) ? a.NST : 2;
+    double* w_l = reinterpret_cast<double*>(smem + (size_t)NST * stage_bytes);
     unsigned short* off_l = reinterpret_cast<unsigned short*>(w_l + NEp);
     double* scales = reinterpret_cast<double*>(off_l + NEp);               // [2][16] scale of a row (log modes)
     int* rowok = reinterpret_cast<int*>(scales + 2 * TILE_ROWS);           // [2][16] every log argument of the row in the fast range
@@ -125,18 +140,22 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             }
         }
     };
-    auto issue_stage = [&](const T* const (&rp)[RPL], int c, int buf) {
+    auto issue_stage = [&](const T* const (&rp)[RPL], int c, int buf) -> int {   // returns the instructions issued (wave-uniform)
         const int gene0 = c * a.GB;
         const int bytes = (min(a.GB, a.G - gene0)) * (int)sizeof(T);
         unsigned char* base = smem + (size_t)buf * stage_bytes;
+        int issued = 0;
 #pragma unroll
         for (int k = 0; k < RPL; ++k) {
             if (!rp[k]) continue;                                           // row past the end: stale LDS, never stored
             const unsigned char* src = reinterpret_cast<const unsigned char*>(rp[k] + gene0) + lane * 16;
             unsigned char* dst = base + (lw + NWS * k) * a.RS;
-            for (int o = 0; o < bytes; o += 1024)
+            for (int o = 0; o < bytes; o += 1024) {
                 if (o + lane * 16 < bytes) dma16(src + o, dst + o);
+                ++issued;
+            }
         }
+        return issued;
     };
     // Row sums (log modes) in the scatter kernels' order (per-lane partials over ascending vectors, butterfly over the
     // wave), so every sketch path sees the same bits; with them the row's extremes, which tell whether every log argument
@@ -213,8 +232,8 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     // one block step of a staging wave: block c of the current tile has landed; stage the next block, sum a share of the
     // next tile's rows
     auto stage_step = [&](int c, int buf, int par) {
-        if (c + 1 < a.NBLK) issue_stage(rowp, c + 1, buf ^ 1);
-        else if (has_next) issue_stage(rown, 0, buf ^ 1);
+        if (c + 1 < a.NBLK) (void)issue_stage(rowp, c + 1, buf ^ 1);
+        else if (has_next) (void)issue_stage(rown, 0, buf ^ 1);
     };
     // Row sums of the next tile as LATE as possible (the wave's k-th pair of rows in block NBLK-1-k, counted from the end):
     // the sums read the rows from HBM, the DMA of the next tile re-reads them 0 - 1 tile periods later, and the closer the
@@ -222,24 +241,41 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     auto sums_step = [&](int c, int par) {
         if (MODE != FDX_PRE_RAW && has_next) scale_rows(rown, a.NBLK - 1 - c, a.NBLK, par ^ 1);
     };
+    int young = 0;                                                          // pieces of the youngest block in flight (loader waves)
     if (NWL == 0 || wave >= NWC) {
         load_rows(tile, rowp);
-        issue_stage(rowp, 0, 0);
+        young = issue_stage(rowp, 0, 0);
+        if (NST == 3) young = issue_stage(rowp, 1, 1);                     // the launcher gives three stages only to NBLK >= 2
         if (MODE != FDX_PRE_RAW) scale_rows(rowp, 0, 1, 0);
     }
 
     if (NWL > 0 && wave >= NWC) {
         // ================================================================================================ loader wave
+        // Ring of NST stage buffers: block s is consumed from buffer s % NST.  At the barrier that opens block s (block s has
+        // landed, block s - 1 is done with) the loaders request block s + NST - 1 into the buffer block s - 1 has left.  With
+        // three stages a request goes out while the previous one is still in flight: two blocks' worth of bytes under way
+        // instead of one (with two stages every block paid its full memory latency after the barrier).
         int buf = 0, par = 0;
         for (; tile < n_tiles; tile += gridDim.x) {
             has_next = tile + gridDim.x < n_tiles;
             load_rows(tile + gridDim.x, rown);
             for (int c = 0; c < a.NBLK; ++c) {
-                __builtin_amdgcn_s_waitcnt(0x0f70);                          // vmcnt(0): this wave's pieces of block c have landed
-                lds_barrier();                                              // everybody's have; the other buffer is free
-                stage_step(c, buf, par);
-                sums_step(c, par);
-                buf ^= 1;
+                if (NST == 3) wait_vmcnt_le(young);                          // everything OLDER than the youngest request: block c has landed
+                else __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0): this wave's pieces of block c have landed
+                lds_barrier();                                              // everybody's have; the buffer of block c - 1 is free
+                if (NST == 3) {
+                    const int cn = c + 2;
+                    int into = buf + 2;
+                    if (into >= 3) into -= 3;
+                    if (cn < a.NBLK) young = issue_stage(rowp, cn, into);
+                    else if (has_next) young = issue_stage(rown, cn - a.NBLK, into);
+                    else young = 0;
+                    buf = buf + 1 == 3 ? 0 : buf + 1;
+                } else {
+                    stage_step(c, buf, par);
+                    sums_step(c, par);
+                    buf ^= 1;
+                }
             }
             par ^= 1;
 #pragma unroll
@@ -374,7 +410,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             if (MODE == FDX_PRE_RAW || fast) consume(c, last_tag, std::true_type{});
             else consume(c, last_tag, std::false_type{});
             if (NWL == 0) sums_step(c, par);
-            buf ^= 1;
+            buf = buf + 1 == NST ? 0 : buf + 1;
         };
         // raw: MFMAs interleaved with the last block's gather.  Log modes: afterwards - the gather is bound by the vector ALU
         // there, and the 16 accumulator registers held through it would spill.
@@ -403,7 +439,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         }
         // ---- the partial tiles are added in a fixed order through LDS (the buffer of the block just consumed) and stored,
         // TH type tiles per round (the area must fit a stage buffer)
-        double* red = reinterpret_cast<double*>(smem + (size_t)(buf ^ 1) * stage_bytes);   // [NR][TS] + [NR][64]
+        double* red = reinterpret_cast<double*>(smem + (size_t)(buf == 0 ? NST - 1 : buf - 1) * stage_bytes);   // the block just consumed: [NR][TS] + [NR][64]
         double* red_sq = red + (size_t)NR * TS;
         const long long s0 = tile * TILE_ROWS;
 #pragma unroll
@@ -459,7 +495,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
 struct TilePlanDevice {
     TilePlanHost h;
     DevBuf w, off, len, ent_base, slot_bucket;
-    int NWC = 0, NWL = 0, JW = 0, RS = 0, TT = 0;
+    int NWC = 0, NWL = 0, JW = 0, RS = 0, TT = 0, NST = 2;
     bool wide = false;
     size_t lds = 0;
 };
@@ -509,9 +545,9 @@ static TileCfg tile_cfg(int mode, int K, int d) {
     return c;
 }
 
-static size_t tile_lds_bytes(int RS, int NE, int mode) {
+static size_t tile_lds_bytes(int RS, int NE, int mode, int NST = 2) {
     const size_t NEp = ((size_t)NE + 7) & ~(size_t)7;
-    const size_t below = 2 * (size_t)TILE_ROWS * RS + NEp * 10 + 2 * TILE_ROWS * (8 + 4);
+    const size_t below = (size_t)NST * TILE_ROWS * RS + NEp * 10 + 2 * TILE_ROWS * (8 + 4);
     if (mode == FDX_PRE_RAW) return below;
     // log modes: the table has a fixed place at the top of the 160 KB (LOG_TAB_LDS); everything else must end below it
     return below <= (size_t)LOG_TAB_LDS ? (size_t)160 * 1024 : (size_t)161 * 1024;
@@ -523,10 +559,19 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     const TileCfg cfg = tile_cfg(mode, K, sp.d);
     const int TT = cfg.TT;
     if (K < 1 || K > 64 || (!cfg.wide && TT > 2)) return nullptr;
-    const int key = cfg.wide ? 24 + ((dtype == FDX_F32 ? 0 : 1) * 2 + (mode != FDX_PRE_RAW ? 1 : 0))
+    const int key0 = cfg.wide ? 24 + ((dtype == FDX_F32 ? 0 : 1) * 2 + (mode != FDX_PRE_RAW ? 1 : 0))
                              : ((((dtype == FDX_F32 ? 0 : 1) * 2 + (mode != FDX_PRE_RAW ? 1 : 0)) * 2 + (TT - 1)) * 3) +
                                    (cfg.NWC == 12 ? 0 : cfg.NWC == 16 ? 1 : 2);
-    static_assert(SketchPlan::kTileKeys == 28, "key space of the schedules");
+    // Stage buffers: two.  FDX_TILE_NST=3 (raw mode with loader waves) makes it a ring of three - two column blocks in flight
+    // while one is consumed, smaller blocks (2000 float32 genes: 3 x 704 instead of 2 x 1024).  Measured at 1M x 2000: 1.88-1.95
+    // against 1.89-1.90 ms - the consumers' gather, not the bytes in flight, sets the block period; kept as a switch.
+    int NST = 2;
+    if (mode == FDX_PRE_RAW && cfg.NWL > 0) {
+        const char* e = getenv("FDX_TILE_NST");
+        NST = (e && atoi(e) == 3) ? 3 : 2;
+    }
+    const int key = key0 + (NST == 3 ? 28 : 0);
+    static_assert(SketchPlan::kTileKeys == 56, "key space of the schedules");
     std::lock_guard<std::mutex> lock(sp.tile_mu);
     if (sp.tile_tried[key]) return sp.tile[key].get();
     sp.tile_tried[key] = true;
@@ -536,19 +581,21 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     const size_t red_bytes = (size_t)(cfg.NWC > 8 || cfg.wide ? cfg.NWC / 2 : cfg.NWC) * (std::min(TT, 2) * 4 * 64 + 64) * 8;   // the kernel's reduction area
     // block sizes tried: whole 1 KB pieces; the wide form's tables leave less room, and an eighth of a piece more or less decides
     // whether 5000 genes take 7 blocks or 10 (21 % more lockstep padding)
-    const int unit = (cfg.wide ? 128 : 1024) / sz;
+    const int unit = (cfg.wide || NST == 3 ? 128 : 1024) / sz;
     std::unique_ptr<TilePlanDevice> best;
     for (int GB = (int)round_up(sp.G, unit); GB >= unit; GB -= unit) {
         const int RS = GB * sz + TILE_ROW_PAD;
         if ((size_t)TILE_ROWS * RS < red_bytes) break;
         // cheap bound before building: the tables hold at least G entries
-        if (tile_lds_bytes(RS, sp.G, mode) > 160 * 1024) continue;
+        const int nst = (NST == 3 && GB < sp.G) ? 3 : 2;                     // one block per tile: the ring's look-ahead needs two
+        if (tile_lds_bytes(RS, sp.G, mode, nst) > 160 * 1024) continue;
         auto cand = std::make_unique<TilePlanDevice>();
         if (!build_tile_plan(sp.host_bucket.data(), sp.host_w.data(), sp.G, sp.d, cfg.NWC, cfg.JW, GB, &cand->h)) return nullptr;
         cand->NWC = cfg.NWC; cand->NWL = cfg.NWL; cand->JW = cfg.JW; cand->RS = RS; cand->TT = TT; cand->wide = cfg.wide;
-        cand->lds = tile_lds_bytes(RS, cand->h.NE, mode);
-        if (dbg) std::fprintf(stderr, "[fdx] tile plan: G=%d d=%d waves=%d+%d GB=%d blocks=%d NE=%d steps=%d lds=%zu\n", sp.G, sp.d, cfg.NWC,
-                              cfg.NWL, GB, cand->h.NBLK, cand->h.NE, cand->h.steps, cand->lds);
+        cand->NST = (nst == 3 && cand->h.NBLK >= 2) ? 3 : 2;
+        cand->lds = tile_lds_bytes(RS, cand->h.NE, mode, nst);
+        if (dbg) std::fprintf(stderr, "[fdx] tile plan: G=%d d=%d waves=%d+%d stages=%d GB=%d blocks=%d NE=%d steps=%d lds=%zu\n", sp.G, sp.d, cfg.NWC,
+                              cfg.NWL, cand->NST, GB, cand->h.NBLK, cand->h.NE, cand->h.steps, cand->lds);
         if (cand->lds > 160 * 1024) continue;
         best = std::move(cand);
         break;
@@ -699,7 +746,7 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     TileLaunch L{};
     TileArgs& a = L.a;
     a.ldy = ldy; a.n = n; a.ldh = ldh; a.G = G; a.d = d; a.K = K;
-    a.NE = t->h.NE; a.GB = t->h.GB; a.NBLK = t->h.NBLK; a.RS = t->RS; a.jw_used = t->h.jw_used;
+    a.NE = t->h.NE; a.GB = t->h.GB; a.NBLK = t->h.NBLK; a.RS = t->RS; a.jw_used = t->h.jw_used; a.NST = t->NST;
     L.Y = Y; L.row_map = row_map; L.Xs = Xs; L.H = H; L.row_sumsq = row_sumsq;
     L.w_tab = t->w.as<double>(); L.off_tab = t->off.as<unsigned short>(); L.len_tab = t->len.as<unsigned char>();
     L.ent_base = t->ent_base.as<int>(); L.slot_bucket = t->slot_bucket.as<int>();

@@ -385,6 +385,25 @@ def test_float32_log_path_matches_the_oracle_and_the_float64_chain(n, G, K, d, m
     assert rel_fro(a2.beta_[fin], b2.beta_[fin]) < 1e-5
 
 
+@pytest.mark.parametrize("n,G,K,d,dtype", [(1000, 2000, 30, 512, np.float32), (333, 1996, 12, 512, np.float64),
+                                          (4097, 2400, 9, 300, np.float32), (50, 520, 3, 64, np.float32)])
+def test_three_stage_ring_of_the_raw_tile_kernel_gives_the_same_bits(n, G, K, d, dtype, monkeypatch):
+    """FDX_TILE_NST=3: the loader waves keep two column blocks in flight (ring of three stage buffers, smaller blocks).  The
+    schedule changes (other block boundaries), the sums per bucket do not: genes ascending inside a bucket either way."""
+    import datagen
+    from flashdeconv_amd import FlashDeconv
+    Y, X, coords, _ = datagen.count_like(n, G, K, seed=n + K)
+    Y = Y.astype(dtype)
+    kw = dict(sketch_dim=d, preprocess="raw", n_hvg=G, max_iter=10, random_state=1)
+    a = FlashDeconv(**kw).fit(Y, X, coords)
+    monkeypatch.setenv("FDX_TILE_NST", "3")
+    b = FlashDeconv(**kw).fit(Y, X, coords)
+    assert rel_fro(a.beta_, b.beta_) < 1e-13
+    monkeypatch.setenv("FDX_NO_FUSED", "1")
+    c = FlashDeconv(**kw).fit(Y, X, coords)
+    assert rel_fro(c.beta_, b.beta_) < 1e-13
+
+
 def test_float32_log1p_of_the_tile_kernel_is_float32_accurate():
     """fdx_log1p_f32 = the device function the tile kernel applies to float32 rows: within 4 float32 ulp of log1p over the
     whole fast range, including arguments far below one ulp of 1 (where log(1 + x) alone would lose everything)."""
