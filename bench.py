@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spots", type=int, default=1_000_000)
     ap.add_argument("--genes", type=int, default=2000)
     ap.add_argument("--types", type=int, default=30)
@@ -182,7 +182,7 @@ def sweep_kernel_name(K):
 def sketch_kernel_name(mode, K, d=512):
     """Kernel that serves the sketch -> H stage of the bench shapes (csrc/tile_kernels.cpp: tile_cfg): template arguments
     <input type, preprocess, consumer waves, loader waves, groups per wave, type tiles, A operands from L2, log1p class
-    (2 = float32-class for float32 rows), experiment switch>."""
+    (2 = float32-class for float32 rows)>."""
     cfg = os.environ.get("FDX_TILE_CFG")
     nwc, nwl, jw = {"12": (12, 4, 11), "16": (16, 0, 8), "8": (8, 2, 16)}.get(cfg, (12, 4, 11) if mode == 0 else (16, 0, 8))
     logv = 0 if (mode == 0 or os.environ.get("FDX_TILE_LOGV") == "0") else 2
@@ -192,7 +192,7 @@ def sketch_kernel_name(mode, K, d=512):
         logv = 0
     if K > 32 or d > 4 * nwc * jw:                 # wide form
         (nwc, nwl, jw), tt, avl2 = ((12, 4, 22) if mode == 0 else (8, 0, 32)), 4, True
-    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d, %s, %d, 0>" % (mode, nwc, nwl, jw, tt, "true" if avl2 else "false", logv)
+    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d, %s, %d>" % (mode, nwc, nwl, jw, tt, "true" if avl2 else "false", logv)
 
 
 def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
