@@ -526,26 +526,31 @@ __global__ __launch_bounds__(256) void lev_normalise_kernel(double* __restrict__
 // last workgroup to finish a stage adds the per-stripe Gram matrices in stripe order (deterministic) and factorises in LDS.
 constexpr double LEV_PIVOT_TOL = 1e-9;
 
+// MMAX: 64 (up to 64 cell types) or 128 (65 - 128).  The symmetric matrix / its factor is kept as a packed lower triangle: at 128 the
+// full square would be 132 KB beside the 66 KB stripe.
+template <int MMAX>
 struct LevQrShared {
-    double tile[64][LEV_STRIPE + 1];
-    double C[64][65];
-    double dpiv[64];
+    double tile[MMAX][LEV_STRIPE + 1];
+    double Cp[MMAX * (MMAX + 1) / 2];
+    double dpiv[MMAX];
     double thr;
     int bad, last;
+    __device__ __forceinline__ double& C(int i, int j) { return Cp[i * (i + 1) / 2 + j]; }   // j <= i
 };
 
 // lower Cholesky factor of the symmetric C (lower triangle used) in place; 256 threads; *bad when a pivot is too small
-__device__ void lev_chol_lds(LevQrShared& sh, int m) {
+template <int MMAX>
+__device__ void lev_chol_lds(LevQrShared<MMAX>& sh, int m) {
     const int tid = threadIdx.x;
     if (tid == 0) {
         double mx = 0.0;
-        for (int i = 0; i < m; ++i) mx = fmax(mx, sh.C[i][i]);
+        for (int i = 0; i < m; ++i) mx = fmax(mx, sh.C(i, i));
         sh.thr = mx * LEV_PIVOT_TOL;
         sh.bad = !(mx > 0.0) || !(mx < 1e300);
     }
     __syncthreads();
     for (int j = 0; j < m; ++j) {
-        double d = sh.C[j][j];
+        double d = sh.C(j, j);
         if (!(d > sh.thr)) {                                              // also NaN
             if (tid == 0) sh.bad = 1;
             d = sh.thr > 0.0 ? sh.thr : 1.0;
@@ -555,7 +560,7 @@ __device__ void lev_chol_lds(LevQrShared& sh, int m) {
         const int r = m - 1 - j;
         for (int e = tid; e < r * r; e += 256) {
             const int i = j + 1 + e / r, k = j + 1 + e % r;
-            if (k <= i) sh.C[i][k] -= sh.C[i][j] * sh.C[k][j] * inv;     // column j itself is not written in step j
+            if (k <= i) sh.C(i, k) -= sh.C(i, j) * sh.C(k, j) * inv;     // column j itself is not written in step j
         }
         __syncthreads();
     }
@@ -563,24 +568,25 @@ __device__ void lev_chol_lds(LevQrShared& sh, int m) {
         const int i = e / m, j = e - i * m;
         if (j > i) continue;
         const double sd = sqrt(sh.dpiv[j]);
-        sh.C[i][j] = (i == j) ? sd : sh.C[i][j] / sd;
+        sh.C(i, j) = (i == j) ? sd : sh.C(i, j) / sd;
     }
     __syncthreads();
 }
 
 // tile[:, j] <- L^-1 tile[:, j] for the 64 columns of the stripe (L in sh.C, lane = column)
-__device__ void lev_forward_lds(LevQrShared& sh, int m) {
+template <int MMAX>
+__device__ void lev_forward_lds(LevQrShared<MMAX>& sh, int m) {
     const int j = threadIdx.x;
     if (j < LEV_STRIPE) {
         for (int i = 0; i < m; ++i) {
             double s0 = sh.tile[i][j], s1 = 0.0;
             int k = 0;
             for (; k + 1 < i; k += 2) {
-                s0 = fma(-sh.C[i][k], sh.tile[k][j], s0);
-                s1 = fma(-sh.C[i][k + 1], sh.tile[k + 1][j], s1);
+                s0 = fma(-sh.C(i, k), sh.tile[k][j], s0);
+                s1 = fma(-sh.C(i, k + 1), sh.tile[k + 1][j], s1);
             }
-            if (k < i) s0 = fma(-sh.C[i][k], sh.tile[k][j], s0);
-            sh.tile[i][j] = (s0 + s1) / sh.C[i][i];
+            if (k < i) s0 = fma(-sh.C(i, k), sh.tile[k][j], s0);
+            sh.tile[i][j] = (s0 + s1) / sh.C(i, i);
         }
     }
     __syncthreads();
@@ -588,14 +594,15 @@ __device__ void lev_forward_lds(LevQrShared& sh, int m) {
 
 // STAGE 0: X -> Z (work), Gram of the stripes, L1.   STAGE 1: Z -> Q1 = L1^-1 Z (work, in place), Gram, L2.
 // STAGE 2: lev_g = |L2^-1 q1_g|^2 and the stripe sums.
-template <int STAGE>
+template <int STAGE, int MMAX>
 __global__ __launch_bounds__(256) void lev_qr_kernel(const double* __restrict__ X, int K, int G, double reg, double* work,
                                                      double* part, const double* Lin, double* Lout, double* __restrict__ lev,
                                                      double* __restrict__ bsum, int* counter, int* status) {
-    __shared__ LevQrShared sh;
+    __shared__ LevQrShared<MMAX> sh;
     const int tid = threadIdx.x, m = K - 1;
     const int nb = (G + LEV_STRIPE - 1) / LEV_STRIPE;
-    const int b = blockIdx.x;                                             // b == nb: the ridge rows sqrt(reg) I
+    const int nr = (m + LEV_STRIPE - 1) / LEV_STRIPE;                     // workgroups for the ridge rows sqrt(reg) I (64 rows each)
+    const int b = blockIdx.x;                                             // b >= nb: ridge rows
     const int g0 = b * LEV_STRIPE;
     if (STAGE == 0) {
         if (b < nb) {
@@ -622,12 +629,15 @@ __global__ __launch_bounds__(256) void lev_qr_kernel(const double* __restrict__ 
         } else {
             for (int e = tid; e < m * LEV_STRIPE; e += 256) {
                 const int k = e / LEV_STRIPE, j = e - k * LEV_STRIPE;
-                sh.tile[k][j] = (k == j) ? sqrt(reg) : 0.0;
+                sh.tile[k][j] = (k == (b - nb) * LEV_STRIPE + j) ? sqrt(reg) : 0.0;   // ridge rows 64 (b - nb) ...
             }
         }
         __syncthreads();
     } else {
-        for (int e = tid; e < m * m; e += 256) sh.C[e / m][e % m] = Lin[e];
+        for (int e = tid; e < m * m; e += 256) {
+            const int p = e / m, q = e - p * m;
+            if (q <= p) sh.C(p, q) = Lin[e];
+        }
         if (b < nb) {
             for (int e = tid; e < m * LEV_STRIPE; e += 256) {
                 const int k = e / LEV_STRIPE, j = e - k * LEV_STRIPE;
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(256) void lev_qr_kernel(const double* __restrict__ 
         } else {
             for (int e = tid; e < m * LEV_STRIPE; e += 256) {
                 const int k = e / LEV_STRIPE, j = e - k * LEV_STRIPE;
-                sh.tile[k][j] = (k == j) ? sqrt(reg) : 0.0;
+                sh.tile[k][j] = (k == (b - nb) * LEV_STRIPE + j) ? sqrt(reg) : 0.0;   // ridge rows 64 (b - nb) ...
             }
         }
         __syncthreads();
@@ -683,16 +693,16 @@ __global__ __launch_bounds__(256) void lev_qr_kernel(const double* __restrict__ 
         const int p = e / m, q = e - p * m;
         if (q > p) continue;
         double acc = 0.0;
-#pragma unroll 8
-        for (int bb = 0; bb <= nb; ++bb)                                   // stripe order: deterministic
+#pragma unroll 16
+        for (int bb = 0; bb < nb + nr; ++bb)                               // stripe order: deterministic
             acc += __hip_atomic_load(&pin[(size_t)bb * m * m + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh.C[p][q] = acc;
+        sh.C(p, q) = acc;
     }
     __syncthreads();
     lev_chol_lds(sh, m);
     for (int e = tid; e < m * m; e += 256) {
         const int p = e / m, q = e - p * m;
-        Lout[e] = (q <= p) ? sh.C[p][q] : 0.0;
+        Lout[e] = (q <= p) ? sh.C(p, q) : 0.0;
     }
     if (tid == 0) {
         if (sh.bad) *status = 2;
@@ -704,26 +714,32 @@ static int launch_leverage_qr(const double* X, int K, int G, double reg, double*
                               double* scratch, hipStream_t st) {
     const int nb = (G + LEV_STRIPE - 1) / LEV_STRIPE, gb = (G + 255) / 256, m = K - 1;
     double* part = scratch;
-    double* L1 = part + (size_t)(nb + 1) * K * K;
+    const int nr = (m + LEV_STRIPE - 1) / LEV_STRIPE;
+    double* L1 = part + (size_t)(nb + 2) * K * K;
     double* L2 = L1 + (size_t)K * K;
     double* bsum = L2 + (size_t)K * K;
-    (void)m;
     FDX_HIP(hipMemsetAsync(sweeps, 0, 8 * sizeof(int), st));             // [4], [5]: arrival counters; [7]: 1 = done, 2 = refused
-    hipLaunchKernelGGL(lev_qr_kernel<0>, dim3(nb + 1), dim3(256), 0, st, X, K, G, reg, work, part, nullptr, L1, lev, bsum, sweeps + 5, sweeps + 7);
-    hipLaunchKernelGGL(lev_qr_kernel<1>, dim3(nb + 1), dim3(256), 0, st, X, K, G, reg, work, part, L1, L2, lev, bsum, sweeps + 4, sweeps + 7);
-    hipLaunchKernelGGL(lev_qr_kernel<2>, dim3(nb), dim3(256), 0, st, X, K, G, reg, work, part, L2, nullptr, lev, bsum, nullptr, sweeps + 7);
+    if (m <= 63) {
+        hipLaunchKernelGGL((lev_qr_kernel<0, 64>), dim3(nb + nr), dim3(256), 0, st, X, K, G, reg, work, part, nullptr, L1, lev, bsum, sweeps + 5, sweeps + 7);
+        hipLaunchKernelGGL((lev_qr_kernel<1, 64>), dim3(nb + nr), dim3(256), 0, st, X, K, G, reg, work, part, L1, L2, lev, bsum, sweeps + 4, sweeps + 7);
+        hipLaunchKernelGGL((lev_qr_kernel<2, 64>), dim3(nb), dim3(256), 0, st, X, K, G, reg, work, part, L2, nullptr, lev, bsum, nullptr, sweeps + 7);
+    } else {                                                              // 65 - 128 cell types: the same with 128 rows (132 KB of LDS)
+        hipLaunchKernelGGL((lev_qr_kernel<0, 128>), dim3(nb + nr), dim3(256), 0, st, X, K, G, reg, work, part, nullptr, L1, lev, bsum, sweeps + 5, sweeps + 7);
+        hipLaunchKernelGGL((lev_qr_kernel<1, 128>), dim3(nb + nr), dim3(256), 0, st, X, K, G, reg, work, part, L1, L2, lev, bsum, sweeps + 4, sweeps + 7);
+        hipLaunchKernelGGL((lev_qr_kernel<2, 128>), dim3(nb), dim3(256), 0, st, X, K, G, reg, work, part, L2, nullptr, lev, bsum, nullptr, sweeps + 7);
+    }
     hipLaunchKernelGGL(lev_normalise_kernel, dim3(gb), dim3(256), 0, st, lev, G, bsum, nb, reg);
     FDX_CHECK_LAUNCH();
     return 0;
 }
 
 bool leverage_qr_applies(int K, int G) {
-    return K >= 2 && K <= 64 && G >= 1 && !getenv("FDX_LEV_NO_QR") && !getenv("FDX_LEV_ONE_WG");
+    return K >= 2 && K <= 128 && G >= 1 && !getenv("FDX_LEV_NO_QR") && !getenv("FDX_LEV_ONE_WG");
 }
 
 size_t leverage_scratch_doubles(int K, int G) {
     const size_t nb = (size_t)(G + LEV_STRIPE - 1) / LEV_STRIPE;
-    return (nb + 1) * K * K + 2 * (size_t)K * K + nb + 16;               // the larger of the two routes' layouts
+    return (nb + 2) * K * K + 2 * (size_t)K * K + nb + 16;               // the larger of the two routes' layouts
 }
 
 static int launch_leverage_multi(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev,
@@ -756,7 +772,7 @@ int launch_leverage(const double* X, int K, int G, double reg, double* work, dou
                     double* scratch, hipStream_t st, int route) {
     if (K <= 0 || G <= 0) return fail(FDX_ERR_INVALID, "leverage: empty reference matrix");
     if (route == LEV_ROUTE_QR) {
-        if (!leverage_qr_applies(K, G) || !scratch) return fail(FDX_ERR_INVALID, "leverage: the Cholesky-QR route needs 2 <= K <= 64");
+        if (!leverage_qr_applies(K, G) || !scratch) return fail(FDX_ERR_INVALID, "leverage: the Cholesky-QR route needs 2 <= K <= 128");
         return launch_leverage_qr(X, K, G, reg, work, lev, sweeps, scratch, st);
     }
     if (K <= 64 && K >= 2 && scratch && !getenv("FDX_LEV_ONE_WG"))

@@ -261,7 +261,8 @@ def test_leverage_scores_vs_reference():
         np.testing.assert_allclose(lev, g[f"{name}_lev"], rtol=1e-9, atol=1e-14, err_msg=str(name))
 
 
-@pytest.mark.parametrize("K,G,cond", [(30, 2000, 1e2), (50, 5000, 1e5), (64, 3000, 1e6), (7, 90, 1e3), (2, 50, 1.0), (33, 1000, 1e4)])
+@pytest.mark.parametrize("K,G,cond", [(30, 2000, 1e2), (50, 5000, 1e5), (64, 3000, 1e6), (7, 90, 1e3), (2, 50, 1.0), (33, 1000, 1e4),
+                                      (65, 700, 1e2), (100, 3000, 1e3), (128, 2100, 1e2)])
 def test_leverage_multi_cu_path_vs_lapack_and_one_workgroup(K, G, cond, monkeypatch):
     """The streaming Gram/eigen/rotate passes against LAPACK (the reference's gesdd route, via the oracle) and against
     the one-workgroup one-sided Jacobi kernel, on signature matrices with a prescribed condition number."""
