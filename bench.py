@@ -169,7 +169,7 @@ def sweep_chunk(K):
     of bcd_sweep_tiled_kernel; tests/test_host.py checks the two against each other)."""
     if K < 8:
         return K
-    for bound, kc in ((29, 8), (33, 7), (37, 6), (41, 5), (45, 4), (49, 3), (51, 2)):
+    for bound, kc in ((29, 8), (33, 7), (37, 6), (41, 5), (45, 4), (49, 3), (51, 2), (64, 8), (72, 6), (88, 4), (96, 2)):
         if K <= bound:
             return kc
     return 8

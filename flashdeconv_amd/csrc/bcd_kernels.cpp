@@ -107,13 +107,16 @@ bool bcd_sweep_dispatch_part2(const BcdSweepArgs&, hipStream_t);
 bool bcd_sweep_dispatch_part3(const BcdSweepArgs&, hipStream_t);
 bool bcd_sweep_dispatch_part4(const BcdSweepArgs&, hipStream_t);
 bool bcd_sweep_dispatch_part5(const BcdSweepArgs&, hipStream_t);
+bool bcd_sweep_dispatch_part6(const BcdSweepArgs&, hipStream_t);
+bool bcd_sweep_dispatch_part7(const BcdSweepArgs&, hipStream_t);
 
 int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scratch_ld, hipStream_t st) {
     if (a.n <= 0 || a.n_slices <= 0) return 0;
-    if (a.K >= 1 && a.K <= FDX_MAX_K_FAST) {
+    if (sweep_instantiated(a.K)) {
         const bool hit = bcd_sweep_dispatch_part0(a, st) || bcd_sweep_dispatch_part1(a, st) ||
                          bcd_sweep_dispatch_part2(a, st) || bcd_sweep_dispatch_part3(a, st) ||
-                         bcd_sweep_dispatch_part4(a, st) || bcd_sweep_dispatch_part5(a, st);
+                         bcd_sweep_dispatch_part4(a, st) || bcd_sweep_dispatch_part5(a, st) ||
+                         bcd_sweep_dispatch_part6(a, st) || bcd_sweep_dispatch_part7(a, st);
         if (!hit) return fail(FDX_ERR_INTERNAL, "bcd sweep dispatch failed");
     } else {
         if (!generic_scratch) return fail(FDX_ERR_INVALID, "generic BCD sweep needs a scratch buffer");
@@ -128,14 +131,14 @@ int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scra
 // honoured by that kernel: the global-gather fallback sweeps every spot.)  Mirrors launch_k in bcd_sweep_inst.cpp with the
 // upper bound of sweep_chunk(K) - a conservative "no" costs the boundary / interior overlap, never correctness.
 bool bcd_sweep_uses_tiles(const BcdSweepArgs& a) {
-    if (!a.tiled || a.K < 1 || a.K > FDX_MAX_K_FAST) return false;
+    if (!a.tiled || !sweep_instantiated(a.K)) return false;
     const int KC = a.K < 8 ? a.K : 8;
     return (size_t)KC * (256 + a.halo_max + 1) * sizeof(double) <= 64 * 1024 && (long long)a.ld * 8 < (1LL << 32) &&
            (long long)a.ldh * 8 < (1LL << 32);
 }
 
 int launch_bcd_objective_tiled(const BcdSweepArgs& a0, double* partials, hipStream_t st) {
-    if (!a0.tiled || a0.K < 1 || a0.K > FDX_MAX_K_FAST) return 1;
+    if (!a0.tiled || !sweep_instantiated(a0.K)) return 1;
     const int KC = a0.K < 8 ? a0.K : 8;   // upper bound of sweep_chunk(K)
     if ((size_t)KC * (256 + a0.halo_max + 1) * sizeof(double) > 64 * 1024) return 1;
     BcdSweepArgs a = a0;
@@ -143,7 +146,8 @@ int launch_bcd_objective_tiled(const BcdSweepArgs& a0, double* partials, hipStre
     a.rel_change = partials;
     a.it = 0;
     const bool hit = bcd_sweep_dispatch_part0(a, st) || bcd_sweep_dispatch_part1(a, st) || bcd_sweep_dispatch_part2(a, st) ||
-                     bcd_sweep_dispatch_part3(a, st) || bcd_sweep_dispatch_part4(a, st) || bcd_sweep_dispatch_part5(a, st);
+                     bcd_sweep_dispatch_part3(a, st) || bcd_sweep_dispatch_part4(a, st) || bcd_sweep_dispatch_part5(a, st) ||
+                     bcd_sweep_dispatch_part6(a, st) || bcd_sweep_dispatch_part7(a, st);
     if (!hit) return 1;
     FDX_CHECK_LAUNCH();
     return 0;

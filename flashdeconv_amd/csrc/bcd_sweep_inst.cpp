@@ -46,7 +46,10 @@ constexpr int sweep_chunk(int K) {
 #ifdef FDX_KC_OVERRIDE                       // tools/sweep_regs.py: register count per (K, chunk)
     return K < FDX_KC_OVERRIDE ? K : FDX_KC_OVERRIDE;
 #endif
-    return K < 8 ? K : K <= 29 ? 8 : K <= 33 ? 7 : K <= 37 ? 6 : K <= 41 ? 5 : K <= 45 ? 4 : K <= 49 ? 3 : K <= 51 ? 2 : 8;
+    // above 64 (the padded sizes of solver_padded_K) the kernel is held to 256 registers = two waves per SIMD up to 96 types: chunks
+    // of 6 / 4 / 4 / 2 at 72 / 80 / 88 / 96 (239 / 239 / 255 / 256 registers, no spills: tools/sweep_regs.py); 112 and 128 types run one
+    // wave per SIMD (2 K registers for the abundances alone; 150 - 380 spills)
+    return K < 8 ? K : K <= 29 ? 8 : K <= 33 ? 7 : K <= 37 ? 6 : K <= 41 ? 5 : K <= 45 ? 4 : K <= 49 ? 3 : K <= 51 ? 2 : K <= 64 ? 8 : K <= 72 ? 6 : K <= 88 ? 4 : K <= 96 ? 2 : 8;
 }
 
 template <int K, int KC>
@@ -156,7 +159,7 @@ __device__ __forceinline__ unsigned lane_off(unsigned off) {
 // served by ds_read_b64 from tile-local slots - ~0.5 global gathers per spot and type instead of ~11.  Arithmetic and
 // summation order are identical to bcd_sweep_kernel, so both variants produce the same bits.
 template <int K, int KC, bool OBJ>
-__global__ __launch_bounds__(256, (OBJ && K > 40) ? 2 : 1) void bcd_sweep_tiled_kernel(
+__global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <= 96)) ? 2 : 1) void bcd_sweep_tiled_kernel(
     const double* __restrict__ H, const double* __restrict__ XtX, const double* __restrict__ beta_in,
     double* __restrict__ beta_out, const unsigned short* __restrict__ ell_local, const int* __restrict__ slice_off,
     const int* __restrict__ deg, const int* __restrict__ tile_halo, const int* __restrict__ tile_hcnt,
@@ -366,10 +369,13 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
                        a.ld, a.n, a.n_slices, a.it);
 }
 
+#ifndef FDX_K_STEP
+#define FDX_K_STEP 1
+#endif
 template <int... Is>
 static bool dispatch_range(const BcdSweepArgs& a, hipStream_t st, std::integer_sequence<int, Is...>) {
     bool hit = false;
-    (void)std::initializer_list<int>{((a.K == FDX_K_LO + Is) ? (launch_k<FDX_K_LO + Is>(a, st), hit = true, 0) : 0)...};
+    (void)std::initializer_list<int>{((a.K == FDX_K_LO + Is * FDX_K_STEP) ? (launch_k<FDX_K_LO + Is * FDX_K_STEP>(a, st), hit = true, 0) : 0)...};
     return hit;
 }
 
@@ -377,7 +383,7 @@ static bool dispatch_range(const BcdSweepArgs& a, hipStream_t st, std::integer_s
 #define FDX_CAT(a, b) FDX_CAT2(a, b)
 bool FDX_CAT(bcd_sweep_dispatch_part, FDX_PART)(const BcdSweepArgs& a, hipStream_t st) {
     if (a.K < FDX_K_LO || a.K > FDX_K_HI) return false;
-    return dispatch_range(a, st, std::make_integer_sequence<int, FDX_K_HI - FDX_K_LO + 1>{});
+    return dispatch_range(a, st, std::make_integer_sequence<int, (FDX_K_HI - FDX_K_LO) / FDX_K_STEP + 1>{});
 }
 
 }  // namespace fdx

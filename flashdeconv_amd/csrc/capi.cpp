@@ -310,10 +310,12 @@ int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sk
     DevBuf dY, dX, dH, dG, dB0, dB1, dPart, dSum, dOut;
     FDX_TRY(dY.alloc((size_t)n * d * sizeof(double)));
     FDX_TRY(dX.alloc((size_t)K * d * sizeof(double)));
-    FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
+    const int KP = solver_padded_K(K);   // 65 - 128 cell types: planes of the next instantiated sweep, pad types all zero
+    DevBuf dGp;
+    FDX_TRY(dH.alloc((size_t)KP * ld * sizeof(double)));
     FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
-    FDX_TRY(dB0.alloc((size_t)K * ld * sizeof(double)));
-    FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dB0.alloc((size_t)KP * ld * sizeof(double)));
+    FDX_TRY(dB1.alloc((size_t)KP * ld * sizeof(double)));
     FDX_TRY(dPart.alloc((size_t)xyt_partials_count(n) * sizeof(double)));
     FDX_TRY(dSum.alloc(sizeof(double)));
     FDX_TRY(dOut.alloc((size_t)n * K * sizeof(double)));
@@ -333,9 +335,13 @@ int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sk
     for (int k = 0; k < K; ++k) diag_mean += G[(size_t)k * K + k];
     diag_mean /= (double)K;
 
+    if (KP != K) {
+        FDX_TRY(dGp.alloc((size_t)KP * KP * sizeof(double)));
+        FDX_TRY(solver_pad_square(dG.as<double>(), K, dGp.as<double>(), KP, st));
+    }
     SolveProblem p;
-    p.graph = g; p.H = dH.as<double>(); p.ldh = ld; p.XtX = dG.as<double>();
-    p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = K; p.YtY = YtY;
+    p.graph = g; p.H = dH.as<double>(); p.ldh = ld; p.XtX = KP != K ? dGp.as<double>() : dG.as<double>();
+    p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = KP; p.K_real = K; p.YtY = YtY;
     p.lambda = lambda; p.rho_eff = rho * diag_mean; p.max_iter = max_iter; p.tol = tol; p.verbose = verbose;
     SolveResult r;
     FDX_TRY(solver_run(p, &r, st));

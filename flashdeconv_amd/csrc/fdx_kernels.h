@@ -9,7 +9,19 @@
 
 namespace fdx {
 
-constexpr int FDX_MAX_K_FAST = 64;  // register-resident sweep kernels are instantiated for K = 1..64
+constexpr int FDX_MAX_K_FAST = 64;  // register-resident sweep kernels are instantiated for every K = 1..64 ...
+// ... and for 72, 80, 88 (two waves per SIMD), 96, 112, 128 (one wave: 2 K registers hold the abundances): a solve with 65-128
+// cell types runs the next of these with all-zero pad types (zero rows / columns of XtX, zero planes of H and beta: a pad type's
+// update is max(0, soft(0) / den) = 0, it adds nothing to any sum) - solver_padded_K; the generic kernel (abundances in a
+// per-lane slice of global memory, ~20 ms per sweep and 1M spots at K = 100) is left with K > 128.
+constexpr int FDX_MAX_K_PAD = 128;
+inline int solver_padded_K(int K) {
+    if (K <= FDX_MAX_K_FAST || K > FDX_MAX_K_PAD) return K;
+    for (int kp : {72, 80, 88, 96, 112, 128})
+        if (K <= kp) return kp;
+    return K;
+}
+inline bool sweep_instantiated(int K) { return K >= 1 && (K <= FDX_MAX_K_FAST || (K <= FDX_MAX_K_PAD && solver_padded_K(K) == K)); }
 
 // One BCD sweep over `n` spots (lane = spot, wave = 64-spot slice).
 struct BcdSweepArgs {

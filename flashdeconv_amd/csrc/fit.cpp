@@ -246,7 +246,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     // these ~120 us of small launches and copies sat between the end of the graph build and the start of the sketch, and a new
     // plan's table upload made the host wait for the whole graph build.)
     const long long ld = round_up(n + 1, 64);
-    DevBuf dB0, dB1, dX, dXs, dG, dSlots, dBits;   // dSlots, dBits (CSR source): per-column {weight, bucket} table over all G_all columns + "selected" bitmap
+    const int KP = solver_padded_K(K);             // 65 - 128 cell types: planes of the next instantiated sweep, pad types all zero
+    DevBuf dB0, dB1, dX, dXs, dG, dGp, dSlots, dBits;   // dSlots, dBits (CSR source): per-column {weight, bucket} table over all G_all columns + "selected" bitmap
     struct SideDrain { hipStream_t s = nullptr; ~SideDrain() { if (s) (void)hipStreamSynchronize(s); } } side_drain;   // before buffers are released
     // an early return leaves work on the caller's stream that uses the side-stream buffers above: wait for it before they go
     struct AbortDrain { hipStream_t s; bool armed = true; ~AbortDrain() { if (armed) (void)hipStreamSynchronize(s); } } abort_drain{st};
@@ -266,11 +267,11 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     struct EvGuard { hipEvent_t e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evG_guard{evG};
     {
         PoolStream pool_xs(xs);
-        FDX_TRY(dB0.alloc((size_t)K * ld * sizeof(double)));
-        FDX_TRY(dB1.alloc((size_t)K * ld * sizeof(double)));
+        FDX_TRY(dB0.alloc((size_t)KP * ld * sizeof(double)));
+        FDX_TRY(dB1.alloc((size_t)KP * ld * sizeof(double)));
         if (side) {
-            FDX_TRY(solver_init_beta(dB0.as<double>(), ld, g->n_total, K, xs));
-            FDX_TRY(solver_zero_pad(dB1.as<double>(), ld, g->n_total, K, xs));
+            FDX_TRY(solver_init_beta(dB0.as<double>(), ld, g->n_total, K, xs, KP));
+            FDX_TRY(solver_zero_pad(dB1.as<double>(), ld, g->n_total, KP, xs));
         }
         if (ysrc.csr) {
             const int G_all = ysrc.csr->G;
@@ -302,6 +303,10 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, xs));
         FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, prm->mode_x, plan_x_p->dev(), dXs.as<double>(), d, nullptr, xs));
         FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, xs));
+        if (KP != K) {
+            FDX_TRY(dGp.alloc((size_t)KP * KP * sizeof(double)));
+            FDX_TRY(solver_pad_square(dG.as<double>(), K, dGp.as<double>(), KP, xs));
+        }
         // XtX goes to the host NOW: lambda and the scaled rho are host scalars of the sweeps, and with them known early the solve
         // is queued behind the sketch without the host waiting for it
         FDX_HIP(hipMemcpyAsync(Gh, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, xs));
@@ -317,7 +322,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
 
     DevBuf dH, dYs, dRowSq, dSum;
     // ---- Y_sketch in solver order, chunked, contracted into H (K, ld) as it is produced
-    FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
+    FDX_TRY(dH.alloc((size_t)KP * ld * sizeof(double)));
+    if (KP != K) FDX_HIP(hipMemsetAsync(dH.as<double>() + (size_t)K * ld, 0, (size_t)(KP - K) * ld * sizeof(double), st));   // pad types
     FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
     FDX_TRY(dSum.alloc(sizeof(double)));
     // Y_sketch is produced and consumed in chunks of 256k rows (1 GB at d = 512): measured on MI355X, smaller chunks
@@ -407,8 +413,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
 
     // ---- solve
     SolveProblem p;
-    p.graph = g; p.H = dH.as<double>(); p.ldh = ld; p.XtX = dG.as<double>();
-    p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = K; p.YtY = prm->verbose ? *YtY_h : 0.0;   // verbose: the stream was synchronised above
+    p.graph = g; p.H = dH.as<double>(); p.ldh = ld; p.XtX = KP != K ? dGp.as<double>() : dG.as<double>();
+    p.beta[0] = dB0.as<double>(); p.beta[1] = dB1.as<double>(); p.ld = ld; p.K = KP; p.K_real = K; p.YtY = prm->verbose ? *YtY_h : 0.0;   // verbose: the stream was synchronised above
     p.lambda = lambda; p.rho_eff = prm->rho_sparsity * diag_mean; p.max_iter = prm->max_iter; p.tol = prm->tol;
     p.verbose = prm->verbose;
     p.compute_objective = prm->verbose ? 1 : 0;
@@ -441,7 +447,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         FDX_TRY(objp.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
         FDX_TRY(objo.alloc(4 * sizeof(double)));
         if (prm->max_iter == 0) FDX_HIP(hipStreamSynchronize(st));
-        FDX_TRY(solver_objective(*g, p.beta[r.result_buffer], ld, p.H, ld, p.XtX, K, *YtY_h, lambda, p.rho_eff, objp.as<double>(),
+        FDX_TRY(solver_objective(*g, p.beta[r.result_buffer], ld, p.H, ld, p.XtX, KP, *YtY_h, lambda, p.rho_eff, objp.as<double>(),
                                  objo.as<double>(), &r.final_objective, st));
     }
     tm.mark();  // 3

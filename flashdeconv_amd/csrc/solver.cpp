@@ -12,11 +12,19 @@
 
 namespace fdx {
 
-__global__ void fill_beta_kernel(double* b, long long ld, long long n_fill, int K, double value) {
+__global__ void fill_beta_kernel(double* b, long long ld, long long n_fill, int K, double value, int K_planes) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= ld) return;
     const double v = (i < n_fill) ? value : 0.0;  // pad rows (incl. the all-zero neighbour row) stay exactly 0
     for (int k = 0; k < K; ++k) b[(size_t)k * ld + i] = v;
+    for (int k = K; k < K_planes; ++k) b[(size_t)k * ld + i] = 0.0;   // pad types (solver_padded_K)
+}
+
+__global__ void pad_square_kernel(const double* __restrict__ A, int K, double* __restrict__ B, int KP) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KP * KP) return;
+    const int i = e / KP, j = e - i * KP;
+    B[e] = (i < K && j < K) ? A[i * K + j] : 0.0;
 }
 
 // zero the pad columns [n_used, ld) of a type-major (K, ld) array: everything below n_used is written by its producer
@@ -33,9 +41,15 @@ int solver_zero_pad(double* b, long long ld, long long n_used, int K, hipStream_
     return 0;
 }
 
-int solver_init_beta(double* beta, long long ld, long long n_fill, int K, hipStream_t st) {
+int solver_init_beta(double* beta, long long ld, long long n_fill, int K, hipStream_t st, int K_planes) {
     if (ld <= 0 || K <= 0) return 0;
-    hipLaunchKernelGGL(fill_beta_kernel, dim3(ceil_div(ld, 256)), dim3(256), 0, st, beta, ld, n_fill, K, 1.0 / (double)K);
+    hipLaunchKernelGGL(fill_beta_kernel, dim3(ceil_div(ld, 256)), dim3(256), 0, st, beta, ld, n_fill, K, 1.0 / (double)K, K_planes);
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+int solver_pad_square(const double* A, int K, double* B, int KP, hipStream_t st) {
+    hipLaunchKernelGGL(pad_square_kernel, dim3(ceil_div((long long)KP * KP, 256)), dim3(256), 0, st, A, K, B, KP);
     FDX_CHECK_LAUNCH();
     return 0;
 }
@@ -101,11 +115,11 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
     FDX_HIP(hipMemsetAsync(stats.p, 0, stats.bytes, st));
     FDX_HIP(hipMemsetAsync(relchg.p, 0, relchg.bytes, st));
     size_t scratch_ld = 0;
-    if (K > FDX_MAX_K_FAST) {
+    if (!sweep_instantiated(K)) {
         scratch_ld = (size_t)g.n_slices * 64;
         FDX_TRY(generic_scratch.alloc(scratch_ld * 2 * K * sizeof(double)));
     }
-    if (p.init_beta) FDX_TRY(solver_init_beta(p.beta[0], p.ld, g.n_total, K, st));   // beta0 = 1/K (solver.py:372)
+    if (p.init_beta) FDX_TRY(solver_init_beta(p.beta[0], p.ld, g.n_total, p.K_real > 0 ? p.K_real : K, st, K));   // beta0 = 1/K (solver.py:372)
     // the second buffer's pad rows must also read as zero
     // (only the pad: every real row is written by the first sweep before anything reads it - a memset of the whole
     // buffer was 30 us of a 6 ms fit)

@@ -15,7 +15,8 @@ struct SolveProblem {
     const double* XtX = nullptr;   // device (K, K)
     double* beta[2] = {nullptr, nullptr};  // device (K, ld) type-major double buffer
     long long ld = 0;
-    int K = 0;
+    int K = 0;                     // planes of H / beta, order of XtX (solver_padded_K of the cell types: pad types are all zero)
+    int K_real = 0;                // cell types (0: = K); beta0 = 1 / K_real on the first K_real planes
     double YtY = 0.0;
     double lambda = 0.0;
     double rho_eff = 0.0;          // rho * mean(diag XtX)
@@ -39,7 +40,8 @@ struct SolveResult {
     std::vector<double> rel_changes;
 };
 
-int solver_init_beta(double* beta, long long ld, long long n_fill, int K, hipStream_t st);
+int solver_init_beta(double* beta, long long ld, long long n_fill, int K, hipStream_t st, int K_planes = 0);   // K_planes > K: the rest zero
+int solver_pad_square(const double* A, int K, double* B, int KP, hipStream_t st);   // B (KP, KP) = A (K, K) bordered with zeros
 // zero the pad columns [n_used, ld) of a type-major (K, ld) array
 int solver_zero_pad(double* b, long long ld, long long n_used, int K, hipStream_t st);
 // The four sums of the objective on the device (out4_dev); the sharded driver all-reduces them across ranks.

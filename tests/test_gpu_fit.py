@@ -253,6 +253,22 @@ def test_fit_counts_600_k30():
     _check(m, g)
 
 
+@pytest.mark.parametrize("K,pre", [(70, "log_cpm"), (100, "raw"), (128, "log_cpm")])
+def test_fit_with_more_than_64_cell_types(K, pre):
+    """65-128 cell types: leverage scores on the Cholesky-QR route with the 128-row factor, sketch -> H by the two-kernel path, the
+    sweeps on the next padded instantiation (pad types stay exactly zero and never reach beta_ / proportions_)."""
+    from flashdeconv_amd import FlashDeconv
+    Y, X, coords, _ = datagen.count_like(900, 700, K, seed=K)
+    kw = dict(sketch_dim=256, preprocess=pre, n_hvg=2000, max_iter=15, random_state=2)
+    want = orc.fit(Y, X, coords, sketch_dim=256, preprocess_method=pre, n_hvg=2000, max_iter=15, random_state=2)
+    m = FlashDeconv(**kw).fit(Y, X, coords)
+    assert m.beta_.shape == (900, K) and m.proportions_.shape == (900, K)
+    assert m.info_["n_iterations"] == want["info"]["n_iterations"]
+    assert rel_fro(m.beta_, want["beta"]) < 1e-8
+    np.testing.assert_allclose(m.info_["final_objective"], want["info"]["final_objective"], rtol=1e-9)
+    np.testing.assert_allclose(m.proportions_.sum(1), 1.0, atol=1e-12)
+
+
 def test_leverage_scores_vs_reference():
     from flashdeconv_amd.utils.genes import compute_leverage_scores
     g = load_golden("leverage.npz")

@@ -53,6 +53,7 @@ def main():
                 best = t
         walls.sort()
         best["wall_min_ms"], best["wall_med_ms"] = walls[0], walls[len(walls) // 2]
+        best["n_iter"] = int(m.info_["n_iterations"])
         beta = m.beta_.double().cpu().numpy()
         if ref is None:
             ref = beta

@@ -35,4 +35,4 @@ if __name__ == "__main__":
         res = list(ex.map(lambda a: regs(*a), jobs))
     print("K  " + "  ".join(f"KC={kc:<3d}" for kc in kcs))
     for K in range(lo, hi + 1):
-        print(f"{K:<3d}" + "  ".join(f"{r[2]:4d}{'*' if r[3] else ' '} " for r in res if r[0] == K))
+        print(f"{K:<3d}" + "  ".join(f"{r[2]:4d}/{r[3]:<4d}" for r in res if r[0] == K))
