@@ -95,6 +95,134 @@ __global__ __launch_bounds__(256) void bcd_sweep_generic_kernel(BcdSweepArgs a, 
     }
 }
 
+// More than 64 cell types: the abundances of a 64-spot slice live in LDS (KP x 64 doubles, KP = K rounded up to 16; one workgroup =
+// one wave), each lane reading and writing only its own column - LDS as indexed per-lane storage, no barrier anywhere - and the
+// coordinate loop is ROLLED.  The register-resident kernels need every loop over the types unrolled (static register indices): K^2
+// FMAs of straight-line code, which leaves the 64 KB instruction cache at 72 types (0.41 ms per sweep and 500k spots at 64 types, 0.74
+// at 72), runs one wave per SIMD from 112 on (2 K registers for the abundances alone) and spills.  Here a sweep costs K^2
+// ds_read_b64 per spot and the code is the same few hundred bytes for every K.  Per 16 types: one row piece of XtX by scalar loads
+// (its rows are padded with zeros to KP, so nothing is clamped or predicated: a first version with per-element index clamps spent ten
+// scalar instructions per product), 16 LDS reads with immediate offsets, 16 FMAs in the two chains.  The neighbour values and H of type
+// k + 1 are requested before the products of type k.  Arithmetic and summation order are those of bcd_sweep_tiled_kernel (even / odd
+// residual association; four chains over the types mod 4 where that kernel has two); the pad types' products are fma(0, 0, r) = r.
+// (The arrays are separate __restrict__ parameters: only then does the compiler fetch the wave-uniform row of XtX with scalar loads.)
+__global__ __launch_bounds__(64) void bcd_sweep_lds_kernel(
+    const double* __restrict__ H, const double* __restrict__ Gp /* (K, KP) */, const double* __restrict__ beta_in,
+    double* __restrict__ beta_out, const int* __restrict__ ell_base, const int* __restrict__ slice_off, const int* __restrict__ deg,
+    unsigned long long* __restrict__ stats, double* __restrict__ rel_change, const double lambda, const double rho, const double tol,
+    const int ldh_, const int ld_, const int n, const int K, const int KP, const int it) {
+    extern __shared__ __attribute__((aligned(16))) double bl[];            // [KP][64]
+    const int lane = threadIdx.x;
+    if (it > 0) {
+        const double rc = fold_rel_change(stats + (size_t)(it - 1) * 128, lane);
+        if (blockIdx.x == 0 && lane == 0) rel_change[it - 1] = rc;
+        if (rc < tol) return;
+    }
+    const int slice = xcd_remap(blockIdx.x, gridDim.x);
+    const int i = min(slice * 64 + lane, n - 1);                            // lanes past the last spot mirror spot n-1
+    const bool active = slice * 64 + lane < n;
+    const size_t ld = (size_t)ld_, ldh = (size_t)ldh_;
+    const int w0 = slice_off[slice];
+    const int w = slice_off[slice + 1] - w0;                                // wave-uniform ELL width of this slice
+    const int* ell = ell_base + (size_t)w0 * 64 + (i & 63);
+    const int dg = deg[i];
+    const double lam_deg = lambda * (double)dg;
+    const double lam_eff = (dg > 0) ? lambda : 0.0;
+    int nbi[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) nbi[m] = (m < w) ? ell[(size_t)m * 64] : 0;
+    double* bcol = bl + lane;
+    for (int k = 0; k < K; ++k) bcol[k * 64] = beta_in[k * ld + i];
+    for (int k = K; k < KP; ++k) bcol[k * 64] = 0.0;
+    double nv[16], hn = H[i];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) nv[m] = (m < w) ? beta_in[nbi[m]] : 0.0;
+    double dmax = 0.0, amax = 0.0;
+    for (int k = 0; k < K; ++k) {
+        double c = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) if (m < w) c += nv[m];
+        for (int m = 16; m < w; ++m) c += beta_in[k * ld + ell[(size_t)m * 64]];
+        const double h = hn;
+        if (k + 1 < K) {                                                    // type k + 1: requested now, used in the next trip
+            const double* bn = beta_in + (size_t)(k + 1) * ld;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) nv[m] = (m < w) ? bn[nbi[m]] : 0.0;
+            hn = H[(size_t)(k + 1) * ldh + i];
+        }
+        const double* g = Gp + (size_t)k * KP;
+        // four chains (types mod 4) and the next 16 types' loads issued ahead of the current 16 products: one wave per SIMD is all
+        // the LDS leaves room for, so nothing else hides the LDS / scalar-load latency and the FMA chain's own
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+        double gs[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { gs[u] = g[u]; bv[u] = bcol[u * 64]; }
+        for (int j0 = 16; j0 < KP; j0 += 16) {
+            const double* gp = g + j0;
+            const double* bp = bcol + j0 * 64;
+            double gn[16], bn2[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gn[u] = gp[u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) bn2[u] = bp[u * 64];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                q0 = fma(gs[u], bv[u], q0);
+                q1 = fma(gs[u + 1], bv[u + 1], q1);
+                q2 = fma(gs[u + 2], bv[u + 2], q2);
+                q3 = fma(gs[u + 3], bv[u + 3], q3);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { gs[u] = gn[u]; bv[u] = bn2[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            q0 = fma(gs[u], bv[u], q0);
+            q1 = fma(gs[u + 1], bv[u + 1], q1);
+            q2 = fma(gs[u + 2], bv[u + 2], q2);
+            q3 = fma(gs[u + 3], bv[u + 3], q3);
+        }
+        const double r0 = q0 + q2, r1 = q1 + q3;
+        const double gkk = g[k];
+        const double old = bcol[k * 64];
+        const double res = (h - (r0 + r1) + gkk * old) + lam_eff * c;
+        const double den = gkk + lam_deg;
+        const double st = res > rho ? res - rho : (res < -rho ? res + rho : 0.0);
+        const double qv = fmax(0.0, st / den);
+        const double nw = (den > 1e-10) ? qv : 0.0;
+        dmax = fmax(dmax, fabs(nw - old));
+        amax = fmax(amax, fabs(old));
+        bcol[k * 64] = nw;
+        if (active) beta_out[k * ld + i] = nw;
+    }
+    dmax = wave_max(dmax);
+    amax = wave_max(amax);
+    if (lane == 0) {
+        unsigned long long* s = stats + (size_t)it * 128;
+        const int slot = slice & 63;
+        atomicMax(s + slot, (unsigned long long)__double_as_longlong(dmax));
+        atomicMax(s + 64 + slot, (unsigned long long)__double_as_longlong(amax));
+    }
+}
+
+__global__ void pad_rows_kernel(const double* __restrict__ A, int K, int KP, double* __restrict__ B) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= K * KP) return;
+    const int i = e / KP, j = e - i * KP;
+    B[e] = j < K ? A[i * K + j] : 0.0;
+}
+
+bool sweep_uses_lds(int K) {
+    return !sweep_instantiated(K) && (size_t)round_up(K, 16) * 512 <= 150 * 1024 && !getenv("FDX_SWEEP_GENERIC");
+}
+size_t sweep_lds_pad_doubles(int K) { return (size_t)K * round_up(K, 16); }
+int sweep_lds_prepare(const double* XtX, int K, double* padded, hipStream_t st) {
+    const int KP = (int)round_up(K, 16);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(ceil_div((long long)K * KP, 256)), dim3(256), 0, st, XtX, K, KP, padded);
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
 // Evaluates the stopping rule for the last queued sweep (no later sweep exists to do it).
 __global__ void bcd_fold_last_kernel(const unsigned long long* stats, double* rel_change, int it) {
     const double rc = fold_rel_change(stats + (size_t)it * 128, threadIdx.x & 63);
@@ -118,6 +246,13 @@ int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scra
                          bcd_sweep_dispatch_part4(a, st) || bcd_sweep_dispatch_part5(a, st) ||
                          bcd_sweep_dispatch_part6(a, st) || bcd_sweep_dispatch_part7(a, st);
         if (!hit) return fail(FDX_ERR_INTERNAL, "bcd sweep dispatch failed");
+    } else if (sweep_uses_lds(a.K)) {
+        if (!generic_scratch || scratch_ld != 0) return fail(FDX_ERR_INVALID, "LDS-resident BCD sweep needs the padded copy of XtX (sweep_lds_prepare)");
+        const int KP = (int)round_up(a.K, 16);
+        const size_t lds = (size_t)KP * 512;
+        if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute((const void*)bcd_sweep_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bcd_sweep_lds_kernel, dim3(a.n_slices), dim3(64), lds, st, a.H, generic_scratch, a.beta_in, a.beta_out, a.ell, a.slice_off,
+                           a.deg, a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, a.K, KP, a.it);
     } else {
         if (!generic_scratch) return fail(FDX_ERR_INVALID, "generic BCD sweep needs a scratch buffer");
         const int nblk = ceil_div(a.n_slices, 4);

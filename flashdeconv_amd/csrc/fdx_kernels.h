@@ -1,5 +1,6 @@
 // Internal launch interfaces between the kernel translation units and the C-ABI layer.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -10,20 +11,23 @@
 namespace fdx {
 
 constexpr int FDX_MAX_K_FAST = 64;  // register-resident sweep kernels are instantiated for every K = 1..64 ...
-// ... and for 72, 80, 88 (two waves per SIMD), 96, 112, 128 (one wave: 2 K registers hold the abundances): a solve with 65-128
-// cell types runs the next of these with all-zero pad types (zero rows / columns of XtX, zero planes of H and beta: a pad type's
-// update is max(0, soft(0) / den) = 0, it adds nothing to any sum) - solver_padded_K; the generic kernel (abundances in a
-// per-lane slice of global memory, ~20 ms per sweep and 1M spots at K = 100) is left with K > 128.
-constexpr int FDX_MAX_K_PAD = 128;
+// ... and for 72, 80, 88, 96 (256 registers: two waves per SIMD) and 112 (one wave): a solve with 65-112 cell types runs the next of
+// these with all-zero pad types (zero rows / columns of XtX, zero planes of H and beta: a pad type's update is
+// max(0, soft(0) / den) = 0, it adds nothing to any sum) - solver_padded_K.  Above 112 types the LDS-resident sweep takes over
+// (bcd_kernels.cpp: abundances of a 64-spot slice in LDS, rolled coordinate loop; K up to ~290), beyond that the generic kernel
+// (abundances in a per-lane slice of global memory).  Per sweep at 500k spots: 64 types 0.41 ms, 72: 0.74, 96: 1.30, 100 (-> 112): 3.9
+// (LDS form 4.3, generic ~10), 120: LDS 5.8 (a 128-type register instantiation: 6.2 with 300 spills).
+constexpr int FDX_MAX_K_PAD = 112;
 inline int solver_padded_K(int K) {
-    if (K <= FDX_MAX_K_FAST || K > FDX_MAX_K_PAD) return K;
-    for (int kp : {72, 80, 88, 96, 112, 128})
+    if (K <= FDX_MAX_K_FAST || K > FDX_MAX_K_PAD || getenv("FDX_NO_K_PAD")) return K;
+    for (int kp : {72, 80, 88, 96, 112})
         if (K <= kp) return kp;
     return K;
 }
-inline bool sweep_instantiated(int K) { return K >= 1 && (K <= FDX_MAX_K_FAST || (K <= FDX_MAX_K_PAD && solver_padded_K(K) == K)); }
+inline bool sweep_instantiated(int K) {
+    return K >= 1 && (K <= FDX_MAX_K_FAST || K == 72 || K == 80 || K == 88 || K == 96 || K == 112);
+}
 
-// One BCD sweep over `n` spots (lane = spot, wave = 64-spot slice).
 struct BcdSweepArgs {
     const double* H;         // (K, ldh) type-major: H[k*ldh + i] = <X_sketch[k], Y_sketch[i]>
     const double* XtX;       // (K, K) row-major Gram matrix
@@ -118,6 +122,12 @@ int launch_normalize_export(const double* beta, long long ld, const int* perm, i
 
 // ---- bcd_kernels.cpp
 int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scratch_ld, hipStream_t st);
+// More than 64 cell types, no register-resident instantiation: the LDS-resident sweep (bcd_kernels.cpp) while K x 64 doubles fit;
+// it reads XtX from a copy whose rows are padded with zeros to a multiple of 16 (sweep_lds_pad_doubles(K) doubles, filled by
+// sweep_lds_prepare) - launch_bcd_sweep then takes that copy as its scratch argument (scratch_ld = 0).
+bool sweep_uses_lds(int K);
+size_t sweep_lds_pad_doubles(int K);
+int sweep_lds_prepare(const double* XtX, int K, double* padded, hipStream_t st);
 bool bcd_sweep_uses_tiles(const BcdSweepArgs& a);   // tile lists are honoured only then
 // objective through the tiled traversal; returns 1 if not applicable (caller falls back to the generic kernel)
 int launch_bcd_objective_tiled(const BcdSweepArgs& a, double* partials /* (n_tiles, 4) */, hipStream_t st);

@@ -115,7 +115,10 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
     FDX_HIP(hipMemsetAsync(stats.p, 0, stats.bytes, st));
     FDX_HIP(hipMemsetAsync(relchg.p, 0, relchg.bytes, st));
     size_t scratch_ld = 0;
-    if (!sweep_instantiated(K)) {
+    if (sweep_uses_lds(K)) {                          // the LDS-resident sweep reads XtX with its rows padded to 16
+        FDX_TRY(generic_scratch.alloc(sweep_lds_pad_doubles(K) * sizeof(double)));
+        FDX_TRY(sweep_lds_prepare(p.XtX, K, generic_scratch.as<double>(), st));
+    } else if (!sweep_instantiated(K)) {
         scratch_ld = (size_t)g.n_slices * 64;
         FDX_TRY(generic_scratch.alloc(scratch_ld * 2 * K * sizeof(double)));
     }

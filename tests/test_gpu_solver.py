@@ -82,10 +82,10 @@ def test_run_to_run_bit_determinism(fdx):
     assert h[0] == h[1] == h[2]
 
 
-@pytest.mark.parametrize("K", [2, 8, 17, 31, 40, 50, 64, 65, 70, 72, 81, 90, 100, 112, 121, 128, 130])
+@pytest.mark.parametrize("K", [2, 8, 17, 31, 40, 50, 64, 65, 70, 72, 81, 90, 100, 112, 113, 121, 128, 130, 200, 300])
 def test_all_kernel_variants_vs_oracle(fdx, K):
-    """1-64 types: one register-resident instantiation each; 65-128: the next of 72 / 80 / 88 / 96 / 112 / 128 with all-zero pad types
-    (csrc/fdx_kernels.h: solver_padded_K); above 128 the generic kernel."""
+    """1-64 types: one register-resident instantiation each; 65-112: the next of 72 / 80 / 88 / 96 / 112 with all-zero pad types
+    (csrc/fdx_kernels.h: solver_padded_K); 113 to ~290: the LDS-resident sweep; 300: the generic kernel."""
     n, d = 700, 160
     Ys, Xs, coords, _ = datagen.sketched_problem(n, K, d, seed=K)
     A = orc.knn_graph_kdtree(coords * 30, 6)
