@@ -25,6 +25,8 @@
 // The NEXT sweep (or the finishing kernel) folds the 64 slots and evaluates
 //   rel_change = max_diff / (max_abs_old + 1e-10) < tol                       (solver.py:395-397,409)
 // on the device, so a converged solve turns the already-queued sweeps into no-ops without a host round trip.
+#include <algorithm>
+
 #include "bcd_device.h"
 
 namespace fdx {
@@ -270,6 +272,79 @@ bool bcd_sweep_uses_tiles(const BcdSweepArgs& a) {
     const int KC = a.K < 8 ? a.K : 8;
     return (size_t)KC * (256 + a.halo_max + 1) * sizeof(double) <= 64 * 1024 && (long long)a.ld * 8 < (1LL << 32) &&
            (long long)a.ldh * 8 < (1LL << 32);
+}
+
+// sum_i beta_i' G beta_i = sum_kj G[k][j] S[k][j] with S = B B' (B = beta, K x n): the quadratic term of the objective as ONE Gram
+// matrix of the abundances instead of K^2 products per spot inside the objective traversal (above 64 types).
+// v_mfma_f64_16x16x4_f64 with the SPOTS as contraction index: for a 16-type tile t the lane value
+// beta[16 t + (lane & 15)][s + (lane >> 4)] is at once the A operand (types on rows) and the B operand (types on columns) of every
+// tile pair t takes part in, so a step of 4 spots costs one load per type tile and one MFMA per tile pair a <= b.  The loads are
+// 32-byte pieces of 16 planes; consecutive steps take the other half of the same lines.  256 workgroups x 4 waves, slices of 64 spots
+// dealt round-robin - a fixed assignment, so the partial sums are reproducible; each workgroup contracts its S with G and leaves ONE
+// number in column 1 of its row of the objective's partials (the traversal left zeros there).
+template <int TT>
+__global__ __launch_bounds__(256) void beta_quad_kernel(const double* __restrict__ beta, long long ld, long long n, int K,
+                                                        const double* __restrict__ G, double* __restrict__ partials) {
+    __shared__ double s_part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = lane & 15, kq = lane >> 4;
+    constexpr int NP = TT * (TT + 1) / 2;
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    double4_t acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const long long n_slices = (n + 63) / 64;
+    for (long long sl = (long long)blockIdx.x * 4 + wave; sl < n_slices; sl += (long long)gridDim.x * 4) {
+        const long long s0 = sl * 64;
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const long long sp = s0 + ks * 4 + kq;
+            double v[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int type = t * 16 + tr;
+                v[t] = (type < K && sp < n) ? beta[(size_t)type * ld + sp] : 0.0;
+            }
+            int p = 0;
+#pragma unroll
+            for (int a = 0; a < TT; ++a)
+#pragma unroll
+                for (int b = a; b < TT; ++b, ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[a], v[b], acc[p], 0, 0, 0);
+        }
+    }
+    // C layout of the instruction: register rr of lane l is S[m = (l >> 4) + 4 rr][n = l & 15] of its tile pair
+    double q = 0.0;
+    int p = 0;
+#pragma unroll
+    for (int a = 0; a < TT; ++a)
+#pragma unroll
+        for (int b = a; b < TT; ++b, ++p) {
+            double t = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = a * 16 + kq + 4 * rr, col = b * 16 + tr;
+                if (row < K && col < K) t = fma(G[(size_t)row * K + col], acc[p][rr], t);
+            }
+            q += (a == b) ? t : 2.0 * t;                                 // S and G are symmetric: the pair (b, a) is the same sum
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    if (lane == 0) s_part[wave] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 4 + 1] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+int launch_beta_quad(const double* beta, long long ld, long long n, int K, const double* XtX, double* partials, int rows,
+                     hipStream_t st) {
+    FDX_REQUIRE(K >= 1 && K <= 112 && rows >= 1, "beta quad: 1 <= K <= 112");
+    if (n <= 0) return 0;
+    const int grid = (int)std::min<long long>(std::min(256, rows), (n + 255) / 256);
+    const int TT = (K + 15) / 16;
+#define FDX_BQ(T) case T: hipLaunchKernelGGL(beta_quad_kernel<T>, dim3(grid), dim3(256), 0, st, beta, ld, n, K, XtX, partials); break;
+    switch (TT) { FDX_BQ(1) FDX_BQ(2) FDX_BQ(3) FDX_BQ(4) FDX_BQ(5) FDX_BQ(6) FDX_BQ(7) default: return fail(FDX_ERR_INVALID, "beta quad: K"); }
+#undef FDX_BQ
+    FDX_CHECK_LAUNCH();
+    return 0;
 }
 
 int launch_bcd_objective_tiled(const BcdSweepArgs& a0, double* partials, hipStream_t st) {

@@ -158,7 +158,9 @@ __device__ __forceinline__ unsigned lane_off(unsigned off) {
 // the tile, one coalesced-ish global gather per halo spot and type) are staged in LDS, and all neighbour sums are then
 // served by ds_read_b64 from tile-local slots - ~0.5 global gathers per spot and type instead of ~11.  Arithmetic and
 // summation order are identical to bcd_sweep_kernel, so both variants produce the same bits.
-template <int K, int KC, bool OBJ>
+// QUAD = false (objective above 64 types): the quadratic term beta' XtX beta is left to launch_beta_quad - with the K products per type
+// the objective variant of the padded sizes spills at 256 registers (88: 7 ... 112: hundreds) and cost 1.7 x a sweep.
+template <int K, int KC, bool OBJ, bool QUAD = true>
 __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <= 96)) ? 2 : 1) void bcd_sweep_tiled_kernel(
     const double* __restrict__ H, const double* __restrict__ XtX, const double* __restrict__ beta_in,
     double* __restrict__ beta_out, const unsigned short* __restrict__ ell_local, const int* __restrict__ slice_off,
@@ -276,17 +278,19 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
                 const double h = hreg[q];
                 const double* g = XtX + k * K;
                 double r0 = 0.0, r1 = 0.0;
+                if (!OBJ || QUAD) {
 #pragma unroll
-                for (int j = 0; j + 1 < K; j += 2) {
-                    r0 = fma(g[j], b[j], r0);
-                    r1 = fma(g[j + 1], b[j + 1], r1);
+                    for (int j = 0; j + 1 < K; j += 2) {
+                        r0 = fma(g[j], b[j], r0);
+                        r1 = fma(g[j + 1], b[j + 1], r1);
+                    }
+                    if (K & 1) r0 = fma(g[K - 1], b[K - 1], r0);
                 }
-                if (K & 1) r0 = fma(g[K - 1], b[K - 1], r0);
-                const double gkk = g[k];
+                const double gkk = (!OBJ || QUAD) ? g[k] : 0.0;
                 const double old = b[k];
                 if (OBJ) {
                     o_cross = fma(old, h, o_cross);
-                    o_quad = fma(old, r0 + r1, o_quad);
+                    if (QUAD) o_quad = fma(old, r0 + r1, o_quad);
                     o_spat = fma(old, (double)dg * old - c[q], o_spat);
                     o_l1 += fabs(old);
                     asm volatile("" : "+v"(o_quad));   // pins this type's K products here: nothing else orders them in this variant, and sunk to the end they keep all of XtX live
@@ -347,10 +351,17 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
         const int S = 256 + a.halo_max + 1;
         const size_t lds = (size_t)KC * S * sizeof(double);
         if (lds <= 64 * 1024 && (long long)a.ld * 8 < (1LL << 32) && (long long)a.ldh * 8 < (1LL << 32)) {
-            if (a.objective)
-                hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
-                                   a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr);
+            if (a.objective) {
+                if constexpr (K > 64) {                    // always with skip_quad (solver.cpp): only that variant is instantiated
+                    hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true, false>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
+                                       a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr);
+                } else {
+                    hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
+                                       a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr);
+                }
+            }
             else if (a.tile_list) {
                 if (a.n_list > 0)
                     hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false>), dim3(a.n_list), dim3(256), lds, st, a.H, a.XtX,

@@ -44,6 +44,7 @@ struct BcdSweepArgs {
     int halo_max = 0;
     int tiled = 0;
     int objective = 0;       // tiled kernel only: evaluate the objective partial sums instead of sweeping (see bcd_sweep_inst.cpp)
+    int skip_quad = 0;       // objective above 64 types: the quadratic term is left to launch_beta_quad (Gram matrix of the abundances)
     const int* tile_list = nullptr;   // tiled kernel only: sweep just these n_list tiles (sharded solve: boundary / interior)
     int n_list = 0;
     unsigned long long* stats;  // (max_iter, 2, 64) per-iteration max slots (bit patterns of doubles >= 0)
@@ -132,6 +133,10 @@ bool bcd_sweep_uses_tiles(const BcdSweepArgs& a);   // tile lists are honoured o
 // objective through the tiled traversal; returns 1 if not applicable (caller falls back to the generic kernel)
 int launch_bcd_objective_tiled(const BcdSweepArgs& a, double* partials /* (n_tiles, 4) */, hipStream_t st);
 int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, int it, hipStream_t st);
+// partials[4 * b + 1] = block b's share of sum_i beta_i' XtX beta_i over the own spots (blocks 0 .. min(256, rows) - 1; `rows` rows of
+// four exist): beta beta' by MFMA, contracted with XtX at the end.  For objective passes run with skip_quad (K <= 112).
+int launch_beta_quad(const double* beta, long long ld, long long n, int K, const double* XtX, double* partials, int rows,
+                     hipStream_t st);
 
 }  // namespace fdx
 

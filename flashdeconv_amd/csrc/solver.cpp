@@ -66,9 +66,14 @@ int solver_objective_partials(const fdx_graph& g, const double* beta, long long 
         a.lambda = 0.0; a.rho = 0.0; a.tol = 0.0; a.ldh = (int)ldh; a.ld = (int)ld; a.n = (int)g.n;
         a.n_slices = g.n_slices; a.K = K; a.tiled = 1; a.ell_local = g.ell_local.as<unsigned short>();
         a.tile_halo = g.tile_halo.as<int>(); a.tile_hcnt = g.tile_hcnt.as<int>(); a.n_tiles = g.n_tiles; a.halo_max = g.halo_max;
+        // the padded sizes above 64 types: the traversal without the K^2 products, the quadratic term as a Gram matrix by MFMA
+        a.skip_quad = (K > FDX_MAX_K_FAST && sweep_instantiated(K)) ? 1 : 0;
         rc_t = launch_bcd_objective_tiled(a, scratch_partials, st);
         if (rc_t < 0) return rc_t;
-        if (rc_t == 0) nblk = g.n_tiles;
+        if (rc_t == 0) {
+            nblk = g.n_tiles;
+            if (a.skip_quad) FDX_TRY(launch_beta_quad(beta, ld, g.n, K, XtX, scratch_partials, g.n_tiles, st));   // fills the zeros the traversal left in column 1
+        }
     }
     if (rc_t != 0)
         FDX_TRY(launch_objective_partials(beta, ld, H, ldh, XtX, g.ell.as<int>(), g.slice_off.as<int>(), g.deg.as<int>(),
