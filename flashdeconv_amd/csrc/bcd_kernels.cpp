@@ -97,113 +97,105 @@ __global__ __launch_bounds__(256) void bcd_sweep_generic_kernel(BcdSweepArgs a, 
     }
 }
 
-// More than 64 cell types: the abundances of a 64-spot slice live in LDS (KP x 64 doubles, KP = K rounded up to 16; one workgroup =
-// one wave), each lane reading and writing only its own column - LDS as indexed per-lane storage, no barrier anywhere - and the
-// coordinate loop is ROLLED.  The register-resident kernels need every loop over the types unrolled (static register indices): K^2
-// FMAs of straight-line code, which leaves the 64 KB instruction cache at 72 types (0.41 ms per sweep and 500k spots at 64 types, 0.74
-// at 72), runs one wave per SIMD from 112 on (2 K registers for the abundances alone) and spills.  Here a sweep costs K^2
-// ds_read_b64 per spot and the code is the same few hundred bytes for every K.  Per 16 types: one row piece of XtX by scalar loads
-// (its rows are padded with zeros to KP, so nothing is clamped or predicated: a first version with per-element index clamps spent ten
-// scalar instructions per product), 16 LDS reads with immediate offsets, 16 FMAs in the two chains.  The neighbour values and H of type
-// k + 1 are requested before the products of type k.  Arithmetic and summation order are those of bcd_sweep_tiled_kernel (even / odd
-// residual association; four chains over the types mod 4 where that kernel has two); the pad types' products are fma(0, 0, r) = r.
-// (The arrays are separate __restrict__ parameters: only then does the compiler fetch the wave-uniform row of XtX with scalar loads.)
-__global__ __launch_bounds__(64) void bcd_sweep_lds_kernel(
+// More than 112 cell types (and every K without a register-resident instantiation): abundances in LDS, coordinate loop ROLLED.
+// The register-resident kernels need every loop over the types unrolled (static register indices): K^2 FMAs of straight-line code,
+// which leaves the 64 KB instruction cache at 72 types, the register file at 112 (2 K registers for the abundances alone) and spills.
+// Mapping: a wave = 16 SPOTS x 4 lane groups.  Lane (s = lane & 15, q = lane >> 4) owns spot s and the types j = q mod 4: per
+// coordinate it sums K / 4 products G[k][j] b[j][s] - b from the wave's LDS slice (KP x 16 doubles, row stride 17: the four groups of a
+// read hit disjoint banks), G[k][j] from the row of XtX the wave stages in LDS for this coordinate (the 16 lanes of a group read one
+// address) - and the four partial sums meet through two cross-row shuffles.  A first form with one spot per lane (K x 64 doubles of LDS
+// per wave) left room for two waves per CU and ran at a tenth of its LDS bound (4.3 ms per sweep at 100 types and 500k spots, behind
+// the padded 112-type register kernel's 3.9); a quarter of the LDS per wave is four times the waves.  The neighbour sum is split the same
+// way (neighbour m by group m mod 4).  Every lane of a spot evaluates the update itself (same operands, same bits); group 0 stores.
+// Summation order differs from the register kernels' (four chains over the types mod 4, neighbours in four partial sums).
+constexpr int LDS_SW_SPOTS = 16;
+constexpr int LDS_SW_STRIDE = 17;
+__global__ __launch_bounds__(256) void bcd_sweep_lds_kernel(
     const double* __restrict__ H, const double* __restrict__ Gp /* (K, KP) */, const double* __restrict__ beta_in,
     double* __restrict__ beta_out, const int* __restrict__ ell_base, const int* __restrict__ slice_off, const int* __restrict__ deg,
     unsigned long long* __restrict__ stats, double* __restrict__ rel_change, const double lambda, const double rho, const double tol,
     const int ldh_, const int ld_, const int n, const int K, const int KP, const int it) {
-    extern __shared__ __attribute__((aligned(16))) double bl[];            // [KP][64]
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double lds_sw[];        // per wave: b [KP][17], then the current row of G [KP]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (it > 0) {
         const double rc = fold_rel_change(stats + (size_t)(it - 1) * 128, lane);
-        if (blockIdx.x == 0 && lane == 0) rel_change[it - 1] = rc;
+        if (blockIdx.x == 0 && threadIdx.x == 0) rel_change[it - 1] = rc;
         if (rc < tol) return;
     }
-    const int slice = xcd_remap(blockIdx.x, gridDim.x);
-    const int i = min(slice * 64 + lane, n - 1);                            // lanes past the last spot mirror spot n-1
-    const bool active = slice * 64 + lane < n;
+    const int s = lane & 15, q = lane >> 4;
+    double* bl = lds_sw + (size_t)wave * ((size_t)KP * LDS_SW_STRIDE + KP);
+    double* gl = bl + (size_t)KP * LDS_SW_STRIDE;
+    const long long g16 = ((long long)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);   // group of 16 spots
+    const long long first = g16 * LDS_SW_SPOTS;
+    if (first >= n) return;                                                 // whole wave (no barrier in this kernel)
+    const int i = (int)min(first + s, (long long)n - 1);                    // lanes past the last spot mirror spot n-1
+    const bool active = first + s < n;
     const size_t ld = (size_t)ld_, ldh = (size_t)ldh_;
+    const int slice = i >> 6;
     const int w0 = slice_off[slice];
-    const int w = slice_off[slice + 1] - w0;                                // wave-uniform ELL width of this slice
+    const int w = slice_off[slice + 1] - w0;                                // ELL width of the spot's slice (uniform: 16 | 64)
     const int* ell = ell_base + (size_t)w0 * 64 + (i & 63);
     const int dg = deg[i];
     const double lam_deg = lambda * (double)dg;
     const double lam_eff = (dg > 0) ? lambda : 0.0;
-    int nbi[16];
+    int nbi[4];                                                             // neighbours m = q, q + 4, q + 8, q + 12 of the spot
 #pragma unroll
-    for (int m = 0; m < 16; ++m) nbi[m] = (m < w) ? ell[(size_t)m * 64] : 0;
-    double* bcol = bl + lane;
-    for (int k = 0; k < K; ++k) bcol[k * 64] = beta_in[k * ld + i];
-    for (int k = K; k < KP; ++k) bcol[k * 64] = 0.0;
-    double nv[16], hn = H[i];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) nv[m] = (m < w) ? beta_in[nbi[m]] : 0.0;
+    for (int t = 0; t < 4; ++t) nbi[t] = (4 * t + q < w) ? ell[(size_t)(4 * t + q) * 64] : -1;
+    for (int k = q; k < KP; k += 4) bl[k * LDS_SW_STRIDE + s] = (k < K) ? beta_in[k * ld + i] : 0.0;
+    __builtin_amdgcn_wave_barrier();
     double dmax = 0.0, amax = 0.0;
     for (int k = 0; k < K; ++k) {
-        double c = 0.0;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) if (m < w) c += nv[m];
-        for (int m = 16; m < w; ++m) c += beta_in[k * ld + ell[(size_t)m * 64]];
-        const double h = hn;
-        if (k + 1 < K) {                                                    // type k + 1: requested now, used in the next trip
-            const double* bn = beta_in + (size_t)(k + 1) * ld;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) nv[m] = (m < w) ? bn[nbi[m]] : 0.0;
-            hn = H[(size_t)(k + 1) * ldh + i];
-        }
+        // this coordinate's row of G into LDS (padded to KP with zeros by sweep_lds_prepare), neighbour values and H requested
         const double* g = Gp + (size_t)k * KP;
-        // four chains (types mod 4) and the next 16 types' loads issued ahead of the current 16 products: one wave per SIMD is all
-        // the LDS leaves room for, so nothing else hides the LDS / scalar-load latency and the FMA chain's own
-        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-        double gs[16], bv[16];
+        for (int j = lane; j < KP; j += 64) gl[j] = g[j];
+        __builtin_amdgcn_wave_barrier();                                    // the row is read by other lanes of this wave (LDS operations of a wave are in order)
+        double c = 0.0;
+        const double* bk = beta_in + (size_t)k * ld;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { gs[u] = g[u]; bv[u] = bcol[u * 64]; }
-        for (int j0 = 16; j0 < KP; j0 += 16) {
-            const double* gp = g + j0;
-            const double* bp = bcol + j0 * 64;
-            double gn[16], bn2[16];
+        for (int t = 0; t < 4; ++t) if (nbi[t] >= 0) c += bk[nbi[t]];
+        for (int m = 16 + q; m < w; m += 4) c += bk[ell[(size_t)m * 64]];
+        const double h = H[(size_t)k * ldh + i];
+        // KP is a multiple of 16: every lane group has KP / 4 terms, taken four at a time with all eight LDS reads issued before the
+        // products (one read pair per product waited ~250 cycles each time)
+        double r = 0.0, r2 = 0.0;
+        const double* glq = gl + q;
+        const double* blq = bl + q * LDS_SW_STRIDE + s;
+        for (int j = 0; j < KP; j += 16) {
+            double gv[4], bv[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) gn[u] = gp[u];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) bn2[u] = bp[u * 64];
-#pragma unroll
-            for (int u = 0; u < 16; u += 4) {
-                q0 = fma(gs[u], bv[u], q0);
-                q1 = fma(gs[u + 1], bv[u + 1], q1);
-                q2 = fma(gs[u + 2], bv[u + 2], q2);
-                q3 = fma(gs[u + 3], bv[u + 3], q3);
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { gs[u] = gn[u]; bv[u] = bn2[u]; }
+            for (int u = 0; u < 4; ++u) { gv[u] = glq[j + 4 * u]; bv[u] = blq[(j + 4 * u) * LDS_SW_STRIDE]; }
+            r = fma(gv[0], bv[0], r);
+            r2 = fma(gv[1], bv[1], r2);
+            r = fma(gv[2], bv[2], r);
+            r2 = fma(gv[3], bv[3], r2);
         }
-#pragma unroll
-        for (int u = 0; u < 16; u += 4) {
-            q0 = fma(gs[u], bv[u], q0);
-            q1 = fma(gs[u + 1], bv[u + 1], q1);
-            q2 = fma(gs[u + 2], bv[u + 2], q2);
-            q3 = fma(gs[u + 3], bv[u + 3], q3);
-        }
-        const double r0 = q0 + q2, r1 = q1 + q3;
-        const double gkk = g[k];
-        const double old = bcol[k * 64];
-        const double res = (h - (r0 + r1) + gkk * old) + lam_eff * c;
+        r += r2;
+        r += __shfl_xor(r, 16, 64);
+        r += __shfl_xor(r, 32, 64);
+        c += __shfl_xor(c, 16, 64);
+        c += __shfl_xor(c, 32, 64);
+        const double gkk = gl[k];
+        const double old = bl[k * LDS_SW_STRIDE + s];
+        const double res = (h - r + gkk * old) + lam_eff * c;
         const double den = gkk + lam_deg;
         const double st = res > rho ? res - rho : (res < -rho ? res + rho : 0.0);
         const double qv = fmax(0.0, st / den);
         const double nw = (den > 1e-10) ? qv : 0.0;
         dmax = fmax(dmax, fabs(nw - old));
         amax = fmax(amax, fabs(old));
-        bcol[k * 64] = nw;
-        if (active) beta_out[k * ld + i] = nw;
+        if (q == 0) {
+            bl[k * LDS_SW_STRIDE + s] = nw;
+            if (active) beta_out[k * ld + i] = nw;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     dmax = wave_max(dmax);
     amax = wave_max(amax);
     if (lane == 0) {
-        unsigned long long* s = stats + (size_t)it * 128;
-        const int slot = slice & 63;
-        atomicMax(s + slot, (unsigned long long)__double_as_longlong(dmax));
-        atomicMax(s + 64 + slot, (unsigned long long)__double_as_longlong(amax));
+        unsigned long long* sp = stats + (size_t)it * 128;
+        const int slot = (int)(g16 & 63);
+        atomicMax(sp + slot, (unsigned long long)__double_as_longlong(dmax));
+        atomicMax(sp + 64 + slot, (unsigned long long)__double_as_longlong(amax));
     }
 }
 
@@ -214,8 +206,12 @@ __global__ void pad_rows_kernel(const double* __restrict__ A, int K, int KP, dou
     B[e] = j < K ? A[i * K + j] : 0.0;
 }
 
+static size_t sweep_lds_bytes(int K) {       // per workgroup of four waves
+    const size_t KP = (size_t)round_up(K, 16);
+    return 4 * (KP * LDS_SW_STRIDE + KP) * sizeof(double);
+}
 bool sweep_uses_lds(int K) {
-    return !sweep_instantiated(K) && (size_t)round_up(K, 16) * 512 <= 150 * 1024 && !getenv("FDX_SWEEP_GENERIC");
+    return !sweep_instantiated(K) && sweep_lds_bytes(K) <= 160 * 1024 && !getenv("FDX_SWEEP_GENERIC");
 }
 size_t sweep_lds_pad_doubles(int K) { return (size_t)K * round_up(K, 16); }
 int sweep_lds_prepare(const double* XtX, int K, double* padded, hipStream_t st) {
@@ -251,9 +247,10 @@ int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scra
     } else if (sweep_uses_lds(a.K)) {
         if (!generic_scratch || scratch_ld != 0) return fail(FDX_ERR_INVALID, "LDS-resident BCD sweep needs the padded copy of XtX (sweep_lds_prepare)");
         const int KP = (int)round_up(a.K, 16);
-        const size_t lds = (size_t)KP * 512;
+        const size_t lds = sweep_lds_bytes(a.K);
         if (lds > 64 * 1024) FDX_HIP(hipFuncSetAttribute((const void*)bcd_sweep_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bcd_sweep_lds_kernel, dim3(a.n_slices), dim3(64), lds, st, a.H, generic_scratch, a.beta_in, a.beta_out, a.ell, a.slice_off,
+        const int grid = ceil_div(a.n, 4 * LDS_SW_SPOTS);
+        hipLaunchKernelGGL(bcd_sweep_lds_kernel, dim3(grid), dim3(256), lds, st, a.H, generic_scratch, a.beta_in, a.beta_out, a.ell, a.slice_off,
                            a.deg, a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, a.K, KP, a.it);
     } else {
         if (!generic_scratch) return fail(FDX_ERR_INVALID, "generic BCD sweep needs a scratch buffer");

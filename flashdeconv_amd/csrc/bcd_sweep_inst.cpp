@@ -47,8 +47,8 @@ constexpr int sweep_chunk(int K) {
     return K < FDX_KC_OVERRIDE ? K : FDX_KC_OVERRIDE;
 #endif
     // above 64 (the padded sizes of solver_padded_K) the kernel is held to 256 registers = two waves per SIMD up to 96 types: chunks
-    // of 6 / 4 / 4 / 2 at 72 / 80 / 88 / 96 (239 / 239 / 255 / 256 registers, no spills: tools/sweep_regs.py); 112 types run one wave per
-    // SIMD (2 K registers for the abundances alone; 150 spills)
+    // of 6 / 4 / 4 / 2 at 72 / 80 / 88 / 96 (239 / 239 / 255 / 256 registers, no spills: tools/sweep_regs.py); 112 types would run one wave
+    // per SIMD with 150 spills - the LDS-resident sweep takes over from 97 (bcd_kernels.cpp)
     return K < 8 ? K : K <= 29 ? 8 : K <= 33 ? 7 : K <= 37 ? 6 : K <= 41 ? 5 : K <= 45 ? 4 : K <= 49 ? 3 : K <= 51 ? 2 : K <= 64 ? 8 : K <= 72 ? 6 : K <= 88 ? 4 : K <= 96 ? 2 : 8;
 }
 

@@ -11,22 +11,20 @@
 namespace fdx {
 
 constexpr int FDX_MAX_K_FAST = 64;  // register-resident sweep kernels are instantiated for every K = 1..64 ...
-// ... and for 72, 80, 88, 96 (256 registers: two waves per SIMD) and 112 (one wave): a solve with 65-112 cell types runs the next of
-// these with all-zero pad types (zero rows / columns of XtX, zero planes of H and beta: a pad type's update is
-// max(0, soft(0) / den) = 0, it adds nothing to any sum) - solver_padded_K.  Above 112 types the LDS-resident sweep takes over
-// (bcd_kernels.cpp: abundances of a 64-spot slice in LDS, rolled coordinate loop; K up to ~290), beyond that the generic kernel
-// (abundances in a per-lane slice of global memory).  Per sweep at 500k spots: 64 types 0.41 ms, 72: 0.74, 96: 1.30, 100 (-> 112): 3.9
-// (LDS form 4.3, generic ~10), 120: LDS 5.8 (a 128-type register instantiation: 6.2 with 300 spills).
-constexpr int FDX_MAX_K_PAD = 112;
+// ... and for 72, 80, 88, 96 (held to 256 registers: two waves per SIMD): a solve with 65-96 cell types runs the next of these with
+// all-zero pad types (zero rows / columns of XtX, zero planes of H and beta: a pad type's update is max(0, soft(0) / den) = 0, it
+// adds nothing to any sum) - solver_padded_K.  Above 96 types the LDS-resident sweep takes over (bcd_kernels.cpp: 16 spots x 4 lane
+// groups per wave, abundances in LDS, rolled coordinate loop; K up to 272), beyond that the generic kernel (abundances in a per-lane
+// slice of global memory).  Per sweep at 500k spots: 64 types 0.41 ms, 72: 0.74, 96: 1.30, 100: 3.3 (a 112-type register instantiation
+// at one wave per SIMD: 3.9; generic ~10), 120: 4.0, 200: 16.
+constexpr int FDX_MAX_K_PAD = 96;
 inline int solver_padded_K(int K) {
     if (K <= FDX_MAX_K_FAST || K > FDX_MAX_K_PAD || getenv("FDX_NO_K_PAD")) return K;
-    for (int kp : {72, 80, 88, 96, 112})
+    for (int kp : {72, 80, 88, 96})
         if (K <= kp) return kp;
     return K;
 }
-inline bool sweep_instantiated(int K) {
-    return K >= 1 && (K <= FDX_MAX_K_FAST || K == 72 || K == 80 || K == 88 || K == 96 || K == 112);
-}
+inline bool sweep_instantiated(int K) { return K >= 1 && (K <= FDX_MAX_K_FAST || K == 72 || K == 80 || K == 88 || K == 96); }
 
 struct BcdSweepArgs {
     const double* H;         // (K, ldh) type-major: H[k*ldh + i] = <X_sketch[k], Y_sketch[i]>
@@ -117,7 +115,7 @@ int launch_sum_partials(const double* in, long long count, double* out, int n_ou
 int objective_partials_count(int n_slices);
 int launch_objective_partials(const double* beta, long long ld, const double* H, long long ldh, const double* XtX,
                               const int* ell, const int* slice_off, const int* deg, int n, int n_slices, int K,
-                              double* partials, hipStream_t st);
+                              double* partials, hipStream_t st, int skip_quad = 0);
 int launch_normalize_export(const double* beta, long long ld, const int* perm, int n, int n_slices, int K,
                             double* beta_out, double* prop_out, hipStream_t st);
 

@@ -14,7 +14,7 @@ namespace fdx {
 __global__ __launch_bounds__(256) void objective_partials_kernel(
     const double* __restrict__ beta, long long ld, const double* __restrict__ H, long long ldh,
     const double* __restrict__ XtX, const int* __restrict__ ell_base, const int* __restrict__ slice_off,
-    const int* __restrict__ deg, int n, int n_slices, int K, int use_lds, double* __restrict__ partials) {
+    const int* __restrict__ deg, int n, int n_slices, int K, int use_lds, int skip_quad, double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4][4];
     const int lane = threadIdx.x & 63;
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void objective_partials_kernel(
             for (int m = 0; m < w; ++m) nb += beta[(size_t)k * ld + ell[(size_t)m * 64]];
             double gb = 0.0;
             const double* g = XtX + (size_t)k * K;
-            for (int l = 0; l < K; ++l) gb = fma(g[l], use_lds ? tile[l * 64 + lane] : beta[(size_t)l * ld + ii], gb);
+            if (!skip_quad)                                   // otherwise launch_beta_quad supplies the quadratic term
+                for (int l = 0; l < K; ++l) gb = fma(g[l], use_lds ? tile[l * 64 + lane] : beta[(size_t)l * ld + ii], gb);
             cross = fma(bk, H[(size_t)k * ldh + ii], cross);
             quad = fma(bk, gb, quad);
             spat = fma(bk, dg * bk - nb, spat);
@@ -119,14 +120,14 @@ int objective_partials_count(int n_slices) { return ceil_div(n_slices, 4); }
 
 int launch_objective_partials(const double* beta, long long ld, const double* H, long long ldh, const double* XtX,
                               const int* ell, const int* slice_off, const int* deg, int n, int n_slices, int K,
-                              double* partials, hipStream_t st) {
+                              double* partials, hipStream_t st, int skip_quad) {
     if (n <= 0) return 0;
     const int use_lds = tile_fits(K) ? 1 : 0;
     const size_t lds = use_lds ? tile_lds_bytes(K) : 0;
     if (lds > 64 * 1024)
         FDX_HIP(hipFuncSetAttribute((const void*)objective_partials_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(objective_partials_kernel, dim3(ceil_div(n_slices, 4)), dim3(256), lds, st, beta, ld, H, ldh, XtX,
-                       ell, slice_off, deg, n, n_slices, K, use_lds, partials);
+                       ell, slice_off, deg, n, n_slices, K, use_lds, skip_quad, partials);
     FDX_CHECK_LAUNCH();
     return 0;
 }

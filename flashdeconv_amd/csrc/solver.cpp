@@ -75,9 +75,14 @@ int solver_objective_partials(const fdx_graph& g, const double* beta, long long 
             if (a.skip_quad) FDX_TRY(launch_beta_quad(beta, ld, g.n, K, XtX, scratch_partials, g.n_tiles, st));   // fills the zeros the traversal left in column 1
         }
     }
-    if (rc_t != 0)
+    if (rc_t != 0) {
+        // no objective traversal for this K (97 types and more): the generic kernel, and up to 112 types without its K^2 reads per
+        // spot - the quadratic term from the Gram matrix of the abundances (9 -> 3 ms at 100 types and 500k spots)
+        const int skip_quad = (K > FDX_MAX_K_FAST && K <= 112) ? 1 : 0;
         FDX_TRY(launch_objective_partials(beta, ld, H, ldh, XtX, g.ell.as<int>(), g.slice_off.as<int>(), g.deg.as<int>(),
-                                          (int)g.n, g.n_slices, K, scratch_partials, st));
+                                          (int)g.n, g.n_slices, K, scratch_partials, st, skip_quad));
+        if (skip_quad) FDX_TRY(launch_beta_quad(beta, ld, g.n, K, XtX, scratch_partials, nblk, st));
+    }
     return launch_sum_partials(scratch_partials, nblk, out4_dev, 4, 4, st);
 }
 
