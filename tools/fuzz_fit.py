@@ -16,7 +16,7 @@ rs = np.random.RandomState(int(os.environ.get("SEED", 0)))
 bad = 0
 for trial in range(int(os.environ.get("TRIALS", 60))):
     n = int(rs.choice([2, 3, 7, 33, 64, 65, 200, 257, 513, 1000]))
-    K = int(rs.choice([1, 2, 5, 8, 17, 31, 33, 48]))
+    K = int(rs.choice([1, 2, 5, 8, 17, 31, 33, 48, 70, 100]))
     G = int(rs.choice([K + 1, 40, 130, 257, 700, 2100]))
     d = int(rs.choice([1, 7, 16, 64, 100, 512]))
     pre = str(rs.choice(["log_cpm", "pearson", "raw"]))
