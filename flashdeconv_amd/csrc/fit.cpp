@@ -389,12 +389,27 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         gram_ms *= scale;
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
-    FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));   // YtY (core/solver.py:348)
+    // YtY (core/solver.py:348) only enters the objective: its two small reductions and the read-back go to the side stream (behind the
+    // sketch, beside the first sweep) instead of standing between the sketch and the sweeps; the verbose trace needs it at once
     double* YtY_h = (double*)pinned_scratch(1, sizeof(double));   // pinned: the host runs ahead and queues the solve behind the sketch
     FDX_REQUIRE(YtY_h != nullptr, "fit: pinned host buffer");
     *YtY_h = 0.0;
-    FDX_HIP(hipMemcpyAsync(YtY_h, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
-    // YtY only enters the objective: the verbose trace evaluates it inside the loop, otherwise it is read after the solve
+    hipEvent_t evSk = nullptr;
+    struct EvGuardSk { hipEvent_t* e; ~EvGuardSk() { if (*e) (void)hipEventDestroy(*e); } } evSk_guard{&evSk};
+    const hipStream_t ys = (side && !prm->verbose) ? side : st;
+    if (ys != st) {
+        FDX_HIP(hipEventCreateWithFlags(&evSk, hipEventDisableTiming));
+        FDX_HIP(hipEventRecord(evSk, st));
+        FDX_HIP(hipStreamWaitEvent(ys, evSk, 0));
+    }
+    FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, ys));
+    FDX_HIP(hipMemcpyAsync(YtY_h, dSum.p, sizeof(double), hipMemcpyDeviceToHost, ys));
+    hipEvent_t evY = nullptr;                                  // YtY has arrived (the export is queued on the same stream later)
+    struct EvGuardY { hipEvent_t* e; ~EvGuardY() { if (*e) (void)hipEventDestroy(*e); } } evY_guard{&evY};
+    if (ys != st) {
+        FDX_HIP(hipEventCreateWithFlags(&evY, hipEventDisableTiming));
+        FDX_HIP(hipEventRecord(evY, ys));
+    }
     if (prm->verbose) FDX_HIP(hipStreamSynchronize(st));
     else FDX_HIP(hipEventSynchronize(evG));
     tm.mark();  // 2
@@ -447,6 +462,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         FDX_TRY(objp.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
         FDX_TRY(objo.alloc(4 * sizeof(double)));
         if (prm->max_iter == 0) FDX_HIP(hipStreamSynchronize(st));
+        if (evY) FDX_HIP(hipEventSynchronize(evY));   // long there
         FDX_TRY(solver_objective(*g, p.beta[r.result_buffer], ld, p.H, ld, p.XtX, KP, *YtY_h, lambda, p.rho_eff, objp.as<double>(),
                                  objo.as<double>(), &r.final_objective, st));
     }

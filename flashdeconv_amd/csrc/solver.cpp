@@ -118,12 +118,13 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
 
     const int max_iter = p.max_iter;
     DevBuf stats, relchg, obj_partials, obj_out, generic_scratch, obj_trace;
-    FDX_TRY(stats.alloc((size_t)std::max(max_iter, 1) * 128 * sizeof(unsigned long long)));
-    FDX_TRY(relchg.alloc((size_t)std::max(max_iter, 1) * sizeof(double)));
+    // the max slots of every iteration and, behind them, the rel_change trace: one block, one fill
+    const size_t stats_bytes = (size_t)std::max(max_iter, 1) * 128 * sizeof(unsigned long long);
+    FDX_TRY(stats.alloc(stats_bytes + (size_t)std::max(max_iter, 1) * sizeof(double)));
     FDX_TRY(obj_partials.alloc((size_t)objective_partials_count(g.n_slices) * 4 * sizeof(double)));
     FDX_TRY(obj_out.alloc(4 * sizeof(double)));
     FDX_HIP(hipMemsetAsync(stats.p, 0, stats.bytes, st));
-    FDX_HIP(hipMemsetAsync(relchg.p, 0, relchg.bytes, st));
+    double* const relchg_p = reinterpret_cast<double*>(static_cast<char*>(stats.p) + stats_bytes);
     size_t scratch_ld = 0;
     if (sweep_uses_lds(K)) {                          // the LDS-resident sweep reads XtX with its rows padded to 16
         FDX_TRY(generic_scratch.alloc(sweep_lds_pad_doubles(K) * sizeof(double)));
@@ -140,7 +141,7 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
 
     BcdSweepArgs a{};
     a.H = p.H; a.XtX = p.XtX; a.ell = g.ell.as<int>(); a.slice_off = g.slice_off.as<int>(); a.deg = g.deg.as<int>();
-    a.stats = stats.as<unsigned long long>(); a.rel_change = relchg.as<double>();
+    a.stats = stats.as<unsigned long long>(); a.rel_change = relchg_p;
     a.lambda = p.lambda; a.rho = p.rho_eff; a.tol = p.tol; a.ldh = (int)p.ldh; a.ld = (int)p.ld; a.n = (int)g.n;
     a.n_slices = g.n_slices; a.K = K;
     if (g.tiled && !getenv("FDX_NO_TILED")) {
@@ -197,7 +198,7 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
         for (int it = done + queued_ahead; it < end; ++it) FDX_TRY(queue_sweep(it));
         FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, end - 1, st));
         FDX_HIP(hipEventRecord(ev1[pair], st));
-        FDX_HIP(hipMemcpyAsync(rc_host + done, relchg.as<double>() + done, (size_t)(end - done) * sizeof(double),
+        FDX_HIP(hipMemcpyAsync(rc_host + done, relchg_p + done, (size_t)(end - done) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
         FDX_HIP(hipEventRecord(evCopy, st));
         int ahead = 0;
