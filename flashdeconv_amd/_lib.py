@@ -126,6 +126,9 @@ SIGNATURES = {
     "fdx_comm_allreduce_sum_dev": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "fdx_sharded_solve_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_double, c_double, c_double, c_i32,
                                       c_void_p, c_void_p, c_i64, ctypes.POINTER(SolveInfo), p_double, p_i32, c_void_p]),
+    "fdx_solver_padded_k": (c_i32, [c_i32]),
+    "fdx_sharded_solve_padded_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_i32, c_double, c_double, c_double,
+                                             c_i32, c_void_p, c_void_p, c_i64, ctypes.POINTER(SolveInfo), p_double, p_i32, c_void_p]),
     "fdx_tile_schedule": (c_int, [p_i32, p_double, c_i32, c_i32, c_i32, c_i32, c_i32, p_i32, p_i32, c_void_p, p_i32, p_double,
                                   c_void_p, c_i64]),
     "fdx_column_sums": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_double]),

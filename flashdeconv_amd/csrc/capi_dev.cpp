@@ -258,7 +258,8 @@ int fdx_bcd_sweep_dev(const fdx_graph* g, const double* H_dev, int64_t ldh, cons
     FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g && H_dev && XtX_dev && beta_in && beta_out && stats_dev && rel_change_dev, "fdx_bcd_sweep_dev: null argument");
     FDX_REQUIRE(ld >= g->n_total + 1, "fdx_bcd_sweep_dev: ld must cover own + halo + zero row");
-    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_FAST, "fdx_bcd_sweep_dev: K must be in 1..64 on the sharded path");
+    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_PAD && sweep_instantiated(K),
+                "fdx_bcd_sweep_dev: K must be in 1..64, or fdx_solver_padded_k of 65..96 cell types, on the sharded path");
     if (g->n == 0) return 0;
     BcdSweepArgs a{};
     a.H = H_dev; a.XtX = XtX_dev; a.beta_in = beta_in; a.beta_out = beta_out;

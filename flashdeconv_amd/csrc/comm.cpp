@@ -351,9 +351,20 @@ int fdx_comm_allreduce_sum_dev(fdx_comm* c, double* buf_dev, int32_t count, void
 int fdx_sharded_solve_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, int32_t K,
                           double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev, double* beta1_dev,
                           int64_t ld, fdx_solve_info* info, double* rel_changes_out, int32_t* result_buffer, void* stream) {
+    return fdx_sharded_solve_padded_dev(c, g, H_dev, ldh, XtX_dev, K, K, lambda, rho_eff, tol, max_iter, beta0_dev, beta1_dev, ld, info,
+                                        rel_changes_out, result_buffer, stream);
+}
+
+int32_t fdx_solver_padded_k(int32_t K) { return fdx::solver_padded_K(K); }
+
+int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, int32_t K,
+                                 int32_t K_real, double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev,
+                                 double* beta1_dev, int64_t ld, fdx_solve_info* info, double* rel_changes_out, int32_t* result_buffer,
+                                 void* stream) {
     FDX_REQUIRE(c && g && H_dev && XtX_dev && beta0_dev && beta1_dev && info && result_buffer, "fdx_sharded_solve_dev: null argument");
     FDX_TRY(fdx::graph_meta_sync(g));
-    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_FAST, "fdx_sharded_solve_dev: K must be in 1..64 on the sharded path");
+    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_PAD && sweep_instantiated(K) && K_real >= 1 && K_real <= K,
+                "fdx_sharded_solve_dev: K must be in 1..64, or fdx_solver_padded_k of 65..96 cell types, on the sharded path");
     FDX_REQUIRE(ld >= g->n_total + 1, "fdx_sharded_solve_dev: ld must cover own + halo + zero row");
     FDX_REQUIRE(max_iter >= 0, "fdx_sharded_solve_dev: max_iter must be >= 0");
     FDX_REQUIRE(g->send_off.size() == (size_t)c->world + 1 && g->recv_off.size() == (size_t)c->world + 1,
@@ -378,7 +389,7 @@ int fdx_sharded_solve_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, 
     FDX_HIP(hipMemsetAsync(relchg.p, 0, relchg.bytes, st));
     FDX_HIP(hipMemcpyAsync(soff.p, g->send_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
     FDX_HIP(hipMemcpyAsync(roff.p, g->recv_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
-    FDX_TRY(solver_init_beta(beta0_dev, ld, g->n_total, K, st));             // beta0 = 1/K on own + halo (solver.py:372)
+    FDX_TRY(solver_init_beta(beta0_dev, ld, g->n_total, K_real, st, K));     // beta0 = 1/K on own + halo (solver.py:372); pad types 0
     FDX_HIP(hipMemsetAsync(beta1_dev, 0, (size_t)K * ld * 8, st));
     FDX_HIP(hipStreamSynchronize(st));                                        // the offset vectors are host objects of g
 

@@ -201,9 +201,10 @@ class ShardedSolver:
 class HipBackend:
     """Per-rank compute through the device-pointer C ABI (include/fdx.h, 'device-pointer building blocks')."""
 
-    def __init__(self, graph, H, ldh, XtX, K, stream=None):
+    def __init__(self, graph, H, ldh, XtX, K, stream=None, K_real=None):
         self.lib = _lib.load()
         self.g, self.H, self.ldh, self.XtX, self.K = graph, H, int(ldh), XtX, int(K)
+        self.K_real = int(K_real) if K_real else int(K)        # K > K_real: all-zero pad types (fdx_solver_padded_k)
         self.stream = stream
 
     def _st(self):
@@ -211,7 +212,8 @@ class HipBackend:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def init_beta(self, beta, n_fill):
-        _lib.check(self.lib.fdx_init_beta_dev(ctypes.c_void_p(beta.data_ptr()), beta.shape[1], int(n_fill), self.K, self._st()))
+        # the buffer arrives zeroed: the pad types' planes stay zero
+        _lib.check(self.lib.fdx_init_beta_dev(ctypes.c_void_p(beta.data_ptr()), beta.shape[1], int(n_fill), self.K_real, self._st()))
 
     def sweep(self, it, b_in, b_out, lam, rho_eff, tol, stats, rel):
         _lib.check(self.lib.fdx_bcd_sweep_dev(self.g.handle, ctypes.c_void_p(self.H.data_ptr()), self.ldh,
@@ -573,7 +575,19 @@ class ShardedFlashDeconv:
             lam = float(self.lambda_spatial)
         rho_eff = float(self.rho_sparsity) * dmean                            # core/solver.py:359-360
         t0 = self._tick("scalars", t0)
-        backend = HipBackend(self._local, H, ld, XtX, K)
+        K_real = K
+        if K > 64:
+            # 65-96 cell types: the next instantiated sweep size with all-zero pad types (include/fdx.h: fdx_solver_padded_k)
+            K = int(lib.fdx_solver_padded_k(K_real))
+            if K == K_real and K not in (72, 80, 88, 96):
+                raise ValueError(f"ShardedFlashDeconv supports up to 96 cell types (got {K_real}); FlashDeconv on one GPU takes more")
+            if K != K_real:
+                Hp = torch.zeros((K, ld), dtype=torch.float64, device=dev)
+                Hp[:K_real] = H
+                Gp = torch.zeros((K, K), dtype=torch.float64, device=dev)
+                Gp[:K_real, :K_real] = XtX
+                H, XtX = Hp, Gp
+        backend = HipBackend(self._local, H, ld, XtX, K, K_real=K_real)
         native = self.native_comm()
         if native is not None and not getattr(self, "time_sweeps", False):
             # the whole iteration loop in C++ on RCCL: boundary tiles first, halo traffic beside the interior sweep
@@ -581,8 +595,8 @@ class ShardedFlashDeconv:
             sinfo = _lib.SolveInfo()
             rel = np.zeros(max(int(self.max_iter), 1))
             which = ctypes.c_int32(0)
-            _lib.check(lib.fdx_sharded_solve_dev(native, self._local.handle, ctypes.c_void_p(H.data_ptr()), ld,
-                                                 ctypes.c_void_p(XtX.data_ptr()), K, float(lam), float(rho_eff), float(self.tol),
+            _lib.check(lib.fdx_sharded_solve_padded_dev(native, self._local.handle, ctypes.c_void_p(H.data_ptr()), ld,
+                                                 ctypes.c_void_p(XtX.data_ptr()), K, K_real, float(lam), float(rho_eff), float(self.tol),
                                                  int(self.max_iter), ctypes.c_void_p(bufs[0].data_ptr()),
                                                  ctypes.c_void_p(bufs[1].data_ptr()), ld, ctypes.byref(sinfo), _lib.ptr_f64(rel),
                                                  ctypes.byref(which), st))
@@ -602,14 +616,14 @@ class ShardedFlashDeconv:
         t0 = self._tick("solve", t0)
         # the export (reads the final abundances, writes two (n_own, K) matrices) runs on a side stream BESIDE the objective pass
         # (reads the same abundances), as in the single-GPU fit; the objective's read-back then waits for both
-        self.beta_ = torch.empty((n_own, K), dtype=torch.float64, device=dev)
-        self.proportions_ = torch.empty((n_own, K), dtype=torch.float64, device=dev)
+        self.beta_ = torch.empty((n_own, K_real), dtype=torch.float64, device=dev)
+        self.proportions_ = torch.empty((n_own, K_real), dtype=torch.float64, device=dev)
         cur = torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=dev)
         side = self._side
         side.wait_stream(cur)
-        _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(beta.data_ptr()), ld, n_own, K, ctypes.c_void_p(self.beta_.data_ptr()),
+        _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(beta.data_ptr()), ld, n_own, K_real, ctypes.c_void_p(self.beta_.data_ptr()),
                                          ctypes.c_void_p(self.proportions_.data_ptr()), ctypes.c_void_p(side.cuda_stream)))
         part_h = np.concatenate([backend.objective_partials(beta), [yty_part]])
         cur.wait_stream(side)

@@ -362,6 +362,15 @@ int fdx_sharded_solve_dev(fdx_comm* comm, const fdx_graph* local, const double* 
                           int32_t K, double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev,
                           double* beta1_dev, int64_t ld, fdx_solve_info* info, double* rel_changes_out,
                           int32_t* result_buffer, void* stream);
+/* More than 64 cell types on the sharded path (65..96): the solve runs the next instantiated sweep size fdx_solver_padded_k(K)
+ * (72 / 80 / 88 / 96; = K up to 64) with all-zero pad types.  The caller provides H (zero planes K_real..K-1), XtX (K x K, zero
+ * rows / columns for the pad types) and the two beta buffers with K = fdx_solver_padded_k(K_real) planes; the first K_real planes of
+ * the result are the abundances.  fdx_sharded_solve_dev is this with K_real = K. */
+int32_t fdx_solver_padded_k(int32_t K);
+int fdx_sharded_solve_padded_dev(fdx_comm* comm, const fdx_graph* local, const double* H_dev, int64_t ldh, const double* XtX_dev,
+                                 int32_t K, int32_t K_real, double lambda, double rho_eff, double tol, int32_t max_iter,
+                                 double* beta0_dev, double* beta1_dev, int64_t ld, fdx_solve_info* info, double* rel_changes_out,
+                                 int32_t* result_buffer, void* stream);
 
 #ifdef __cplusplus
 }

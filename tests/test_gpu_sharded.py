@@ -174,6 +174,24 @@ def test_sharded_class_world1_equals_flashdeconv():
         assert np.array_equal(got, ref.proportions_)
         np.testing.assert_allclose(m.info_["final_objective"], ref.info_["final_objective"], rtol=1e-12)
         np.testing.assert_allclose(m.lambda_used_, ref.lambda_used_, rtol=1e-14)
+        # 65-96 cell types: the next instantiated sweep size with all-zero pad types, on both paths (fdx_solver_padded_k)
+        for K7 in (70, 96):
+            Y7, X7, c7, _ = datagen.gaussian_raw(3000, 500, K7, seed=K7)
+            ref7 = FlashDeconv(sketch_dim=128, preprocess="raw", n_hvg=500, max_iter=12).fit(Y7, X7, c7)
+            m7 = ShardedFlashDeconv(sketch_dim=128, preprocess="raw", n_hvg=500, max_iter=12)
+            own7 = m7.plan(torch.from_numpy(c7).to(dev))
+            P7 = m7.fit_transform(torch.from_numpy(Y7).to(dev)[own7], X7)
+            assert P7.shape == (3000, K7) and m7.beta_.shape == (3000, K7)
+            got7 = np.zeros((3000, K7))
+            got7[own7.cpu().numpy()] = P7.cpu().numpy()
+            assert m7.info_["n_iterations"] == ref7.info_["n_iterations"]
+            np.testing.assert_allclose(got7, ref7.proportions_, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(m7.info_["final_objective"], ref7.info_["final_objective"], rtol=1e-10)
+        with pytest.raises(ValueError, match="up to 96 cell types"):
+            Y9, X9, c9, _ = datagen.gaussian_raw(600, 300, 100, seed=1)
+            m9 = ShardedFlashDeconv(sketch_dim=64, preprocess="raw", n_hvg=300)
+            own9 = m9.plan(torch.from_numpy(c9).to(dev))
+            m9.fit_transform(torch.from_numpy(Y9).to(dev)[own9], X9)
         # gene selection active (G > n_hvg): statistics reduced over the shards, same genes, same fit
         Yc, Xc, cc, _ = datagen.count_like(3000, 900, 6, 0.1, 8)
         kw = dict(sketch_dim=64, preprocess="log_cpm", n_hvg=250, n_markers_per_type=10, max_iter=20)
