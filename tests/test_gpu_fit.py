@@ -267,6 +267,11 @@ def test_fit_with_more_than_64_cell_types(K, pre):
     assert rel_fro(m.beta_, want["beta"]) < 1e-8
     np.testing.assert_allclose(m.info_["final_objective"], want["info"]["final_objective"], rtol=1e-9)
     np.testing.assert_allclose(m.proportions_.sum(1), 1.0, atol=1e-12)
+    if K == 70:                                    # the same through the CSR path (no fused contraction above 64 types) and float32 rows
+        mc = FlashDeconv(**kw).fit(sparse.csr_matrix(Y), X, coords)
+        assert rel_fro(mc.beta_, want["beta"]) < 1e-8
+        m32 = FlashDeconv(**kw).fit(Y.astype(np.float32), X, coords)
+        assert rel_fro(m32.beta_, want["beta"]) < 1e-5
 
 
 def test_leverage_scores_vs_reference():
