@@ -331,12 +331,72 @@ __global__ __launch_bounds__(256) void beta_quad_kernel(const double* __restrict
     if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 4 + 1] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
+// The same for more than 112 types, block by block: the tile pairs (a0 .. a0 + 3) x (b0 .. b0 + 3) of S in one launch (16 accumulator
+// tiles), their contraction with G ADDED to column 1 (weight 2 for a block above the diagonal, which stands for its mirror image too;
+// a diagonal block is computed as a full square).  Launches follow each other on one stream.
+__global__ __launch_bounds__(256) void beta_quad_block_kernel(const double* __restrict__ beta, long long ld, long long n, int K,
+                                                              const double* __restrict__ G, int a0, int b0, double weight,
+                                                              double* __restrict__ partials) {
+    __shared__ double s_part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = lane & 15, kq = lane >> 4;
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    double4_t acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const long long n_slices = (n + 63) / 64;
+    for (long long sl = (long long)blockIdx.x * 4 + wave; sl < n_slices; sl += (long long)gridDim.x * 4) {
+        const long long s0 = sl * 64;
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const long long sp = s0 + ks * 4 + kq;
+            double va[4], vb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ta = (a0 + t) * 16 + tr, tb = (b0 + t) * 16 + tr;
+                va[t] = (ta < K && sp < n) ? beta[(size_t)ta * ld + sp] : 0.0;
+                vb[t] = (tb < K && sp < n) ? beta[(size_t)tb * ld + sp] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a * 4 + b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[a], vb[b], acc[a * 4 + b], 0, 0, 0);
+        }
+    }
+    double q = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = (a0 + a) * 16 + kq + 4 * rr, col = (b0 + b) * 16 + tr;
+                if (row < K && col < K) q = fma(G[(size_t)row * K + col], acc[a * 4 + b][rr], q);
+            }
+        }
+    q *= weight;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    if (lane == 0) s_part[wave] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 4 + 1] += (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
 int launch_beta_quad(const double* beta, long long ld, long long n, int K, const double* XtX, double* partials, int rows,
                      hipStream_t st) {
-    FDX_REQUIRE(K >= 1 && K <= 112 && rows >= 1, "beta quad: 1 <= K <= 112");
+    FDX_REQUIRE(K >= 1 && rows >= 1, "beta quad: bad arguments");
     if (n <= 0) return 0;
     const int grid = (int)std::min<long long>(std::min(256, rows), (n + 255) / 256);
     const int TT = (K + 15) / 16;
+    if (TT > 7) {                                   // more than 112 types: blocks of 4 x 4 type tiles, upper triangle of blocks
+        const int nblk = (TT + 3) / 4;
+        for (int A = 0; A < nblk; ++A)
+            for (int B = A; B < nblk; ++B)
+                hipLaunchKernelGGL(beta_quad_block_kernel, dim3(grid), dim3(256), 0, st, beta, ld, n, K, XtX, A * 4, B * 4, A == B ? 1.0 : 2.0,
+                                   partials);
+        FDX_CHECK_LAUNCH();
+        return 0;
+    }
 #define FDX_BQ(T) case T: hipLaunchKernelGGL(beta_quad_kernel<T>, dim3(grid), dim3(256), 0, st, beta, ld, n, K, XtX, partials); break;
     switch (TT) { FDX_BQ(1) FDX_BQ(2) FDX_BQ(3) FDX_BQ(4) FDX_BQ(5) FDX_BQ(6) FDX_BQ(7) default: return fail(FDX_ERR_INVALID, "beta quad: K"); }
 #undef FDX_BQ

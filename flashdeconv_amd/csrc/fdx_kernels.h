@@ -132,7 +132,8 @@ bool bcd_sweep_uses_tiles(const BcdSweepArgs& a);   // tile lists are honoured o
 int launch_bcd_objective_tiled(const BcdSweepArgs& a, double* partials /* (n_tiles, 4) */, hipStream_t st);
 int launch_bcd_fold_last(const unsigned long long* stats, double* rel_change, int it, hipStream_t st);
 // partials[4 * b + 1] = block b's share of sum_i beta_i' XtX beta_i over the own spots (blocks 0 .. min(256, rows) - 1; `rows` rows of
-// four exist): beta beta' by MFMA, contracted with XtX at the end.  For objective passes run with skip_quad (K <= 112).
+// four exist): beta beta' by MFMA, contracted with XtX at the end (above 112 types block by block, ADDING to the column).  For
+// objective passes run with skip_quad, which leave zeros there.
 int launch_beta_quad(const double* beta, long long ld, long long n, int K, const double* XtX, double* partials, int rows,
                      hipStream_t st);
 

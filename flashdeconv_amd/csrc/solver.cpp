@@ -76,9 +76,9 @@ int solver_objective_partials(const fdx_graph& g, const double* beta, long long 
         }
     }
     if (rc_t != 0) {
-        // no objective traversal for this K (97 types and more): the generic kernel, and up to 112 types without its K^2 reads per
-        // spot - the quadratic term from the Gram matrix of the abundances (9 -> 3 ms at 100 types and 500k spots)
-        const int skip_quad = (K > FDX_MAX_K_FAST && K <= 112) ? 1 : 0;
+        // no objective traversal for this K (97 types and more): the generic kernel without its K^2 reads per spot - the quadratic
+        // term from the Gram matrix of the abundances (9 -> 3 ms at 100 types and 500k spots)
+        const int skip_quad = K > FDX_MAX_K_FAST ? 1 : 0;
         FDX_TRY(launch_objective_partials(beta, ld, H, ldh, XtX, g.ell.as<int>(), g.slice_off.as<int>(), g.deg.as<int>(),
                                           (int)g.n, g.n_slices, K, scratch_partials, st, skip_quad));
         if (skip_quad) FDX_TRY(launch_beta_quad(beta, ld, g.n, K, XtX, scratch_partials, nblk, st));
