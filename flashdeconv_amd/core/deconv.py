@@ -25,6 +25,28 @@ def _is_torch_cuda(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
 
 
+def device_counts_as_float(Y):
+    """A dense CUDA tensor as the float32 / float64 matrix the kernels stream, plus whether its transform must keep float64
+    accuracy (``PRE_F64_MATH``).  Integer counts: numpy promotes them to float64 in the reference (core/deconv.py:190-191),
+    so the log-CPM chain stays float64; float32 STORAGE is used when it holds every value exactly (below 2**24 - checked
+    unless the dtype cannot exceed it), float64 otherwise.  Shared by FlashDeconv.fit and ShardedFlashDeconv.fit_transform."""
+    import torch
+    f64_math = False
+    if Y.dtype not in (torch.float32, torch.float64):
+        f64_math = not Y.dtype.is_floating_point
+        small = Y.dtype in (torch.uint8, torch.int8, torch.int16, torch.bool, torch.float16, torch.bfloat16)
+        exact = small or Y.numel() == 0
+        if not exact:
+            try:                                          # torch lacks min / max for some unsigned dtypes: float64 then
+                hi = int(Y.max().item())
+                lo = int(Y.min().item()) if Y.dtype.is_signed else 0
+                exact = max(hi, -lo) < (1 << 24)
+            except (RuntimeError, TypeError, NotImplementedError):
+                exact = False
+        Y = Y.to(torch.float32 if exact else torch.float64)
+    return Y.contiguous(), f64_math
+
+
 class _DeviceBuffer:
     """Plain device allocation through the C ABI (fdx_malloc / fdx_free)."""
 
@@ -187,14 +209,7 @@ class FlashDeconv:
                 y_ptr, y_code, y_sparse_rule = None, csr.view.dtype, True
             elif _is_torch_cuda(Y):
                 import torch
-                if Y.dtype not in (torch.float32, torch.float64):
-                    # integer counts: float32 holds them exactly below 2**24 (checked, as on the host path); numpy would
-                    # promote them to float64 in the reference, so the transform keeps float64 accuracy (PRE_F64_MATH)
-                    y_f64_math = not Y.dtype.is_floating_point
-                    small = Y.dtype in (torch.uint8, torch.int8, torch.int16, torch.bool, torch.float16, torch.bfloat16)
-                    exact = small or Y.numel() == 0 or bool((Y.abs().max() < (1 << 24)).item())
-                    Y = Y.to(torch.float32 if exact else torch.float64)
-                Y = Y.contiguous()
+                Y, y_f64_math = device_counts_as_float(Y)
                 y_ptr, y_code = ctypes.c_void_p(Y.data_ptr()), (_lib.FDX_F32 if Y.dtype == torch.float32 else _lib.FDX_F64)
                 y_sparse_rule = False
             else:

@@ -198,7 +198,7 @@ int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, 
             w.ptr[(size_t)c->rank] = send;
             w.off[(size_t)c->rank].assign(send_off.begin(), send_off.end());
         }
-        FDX_REQUIRE(w.barrier(), "sharded solve: another rank failed");
+        FDX_REQUIRE(w.barrier(), "sharded solve: another rank of this in-process world failed; the world stays aborted - create a new fdx_local_world");
         for (int q = 0; q < W; ++q) {
             const int nr = recv_off[(size_t)q + 1] - recv_off[(size_t)q];
             if (q == c->rank || nr == 0) continue;
@@ -208,7 +208,7 @@ int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, 
             FDX_HIP(hipMemcpyAsync(recv + (size_t)K * recv_off[(size_t)q], src, (size_t)K * nr * 8, hipMemcpyDeviceToDevice, st));
         }
         FDX_HIP(hipStreamSynchronize(st));
-        FDX_REQUIRE(w.barrier(), "sharded solve: another rank failed");   // nobody overwrites its staging before all have copied
+        FDX_REQUIRE(w.barrier(), "sharded solve: another rank of this in-process world failed; the world stays aborted - create a new fdx_local_world");   // nobody overwrites its staging before all have copied
         return 0;
     }
     return 0;
@@ -232,7 +232,7 @@ int allreduce(fdx_comm* c, void* buf, int count, bool is_max, hipStream_t st) {
             std::lock_guard<std::mutex> lk(w.mu);
             w.host[(size_t)c->rank] = mine;
         }
-        FDX_REQUIRE(w.barrier(), "sharded solve: another rank failed");
+        FDX_REQUIRE(w.barrier(), "sharded solve: another rank of this in-process world failed; the world stays aborted - create a new fdx_local_world");
         std::vector<unsigned long long> out((size_t)count, 0ULL);
         if (is_max) {
             for (int q = 0; q < w.W; ++q)
@@ -247,7 +247,7 @@ int allreduce(fdx_comm* c, void* buf, int count, bool is_max, hipStream_t st) {
                 }
             std::memcpy(out.data(), acc.data(), (size_t)count * 8);
         }
-        FDX_REQUIRE(w.barrier(), "sharded solve: another rank failed");   // everybody has read the mailbox
+        FDX_REQUIRE(w.barrier(), "sharded solve: another rank of this in-process world failed; the world stays aborted - create a new fdx_local_world");   // everybody has read the mailbox
         FDX_HIP(hipMemcpyAsync(buf, out.data(), (size_t)count * 8, hipMemcpyHostToDevice, st));
         FDX_HIP(hipStreamSynchronize(st));
         return 0;

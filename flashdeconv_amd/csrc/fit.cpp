@@ -248,6 +248,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     const long long ld = round_up(n + 1, 64);
     const int KP = solver_padded_K(K);             // 65 - 128 cell types: planes of the next instantiated sweep, pad types all zero
     DevBuf dB0, dB1, dX, dXs, dG, dGp, dSlots, dBits;   // dSlots, dBits (CSR source): per-column {weight, bucket} table over all G_all columns + "selected" bitmap
+    DevBuf dH, dYs, dRowSq, dSum;   // declared ABOVE the drains: on an early return both streams are drained before any of these goes back to the pool (dRowSq / dSum are read on the side stream)
     struct SideDrain { hipStream_t s = nullptr; ~SideDrain() { if (s) (void)hipStreamSynchronize(s); } } side_drain;   // before buffers are released
     // an early return leaves work on the caller's stream that uses the side-stream buffers above: wait for it before they go
     struct AbortDrain { hipStream_t s; bool armed = true; ~AbortDrain() { if (armed) (void)hipStreamSynchronize(s); } } abort_drain{st};
@@ -320,7 +321,6 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     SketchPlan plan_none;
     const SketchPlan& plan_y = plan_y_p ? *plan_y_p : plan_none;
 
-    DevBuf dH, dYs, dRowSq, dSum;
     // ---- Y_sketch in solver order, chunked, contracted into H (K, ld) as it is produced
     FDX_TRY(dH.alloc((size_t)KP * ld * sizeof(double)));
     if (KP != K) FDX_HIP(hipMemsetAsync(dH.as<double>() + (size_t)K * ld, 0, (size_t)(KP - K) * ld * sizeof(double), st));   // pad types

@@ -424,9 +424,9 @@ class ShardedFlashDeconv:
         K, G = X.shape
         if _lib.is_torch_sparse_csr(Y_own):
             return self._fit_transform_csr(Y_own, X)
-        if Y_own.dtype not in (torch.float32, torch.float64):
-            Y_own = Y_own.to(torch.float32)
-        Y_own = Y_own.contiguous()
+        # integer counts keep the float64 transform chain, as in FlashDeconv.fit (numpy promotes them: core/deconv.py:190-191)
+        from .core.deconv import device_counts_as_float
+        Y_own, y_f64_math = device_counts_as_float(Y_own)
         assert Y_own.shape == (self.n_own, G)
         y_code = _lib.FDX_F32 if Y_own.dtype == torch.float32 else _lib.FDX_F64
         self.gene_idx_ = np.arange(G, dtype=np.intp)
@@ -465,6 +465,8 @@ class ShardedFlashDeconv:
         mode_y = mode_x = _lib.PRE_RAW
         if self.preprocess == "log_cpm":
             mode_y = mode_x = _lib.PRE_LOG_CPM
+            if y_f64_math and Y_own.dtype == torch.float32:
+                mode_y |= _lib.PRE_F64_MATH
         elif self.preprocess == "pearson":
             sums = np.zeros(G)
             if self.n_own:

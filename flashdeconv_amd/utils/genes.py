@@ -1,7 +1,7 @@
 """Gene selection and leverage scores: the reference's ``flashdeconv/utils/genes.py`` interface.
 
     compute_leverage_scores   <- utils/genes.py:238-290  (GPU: one-sided Jacobi SVD, csrc/leverage_kernels.cpp)
-    select_markers            <- utils/genes.py:148-235  (host: K x G table logic, method="diff")
+    select_markers            <- utils/genes.py:148-235  (host: K x G table logic; "diff", "ratio", "specificity")
     select_hvg                <- utils/genes.py:18-145   (per-gene moments on the GPU, binning of the G-vector on the host)
     select_informative_genes  <- utils/genes.py:293-341
 """
@@ -59,14 +59,21 @@ def select_markers(X, n_markers=50, method="diff"):
         raise ValueError(f"n_markers must be non-negative, got {n_markers}")
     if n_markers == 0 or K == 0:
         return np.array([], dtype=np.intp), np.array([], dtype=np.intp)
-    if method != "diff":
-        raise NotImplementedError("only method='diff' (the one FlashDeconv.fit uses) is provided")
     frac = X / (X.sum(axis=1, keepdims=True) + 1e-10)
     if K == 1:
         idx = np.arange(min(n_markers, G))
         return idx, np.zeros(len(idx), dtype=np.intp)
-    top = np.partition(frac, K - 2, axis=0)           # only the two largest fractions per gene are needed (no full sort)
-    specificity = top[K - 1] - top[K - 2]
+    if method == "diff":                              # utils/genes.py:197-200
+        top = np.partition(frac, K - 2, axis=0)       # only the two largest fractions per gene are needed (no full sort)
+        specificity = top[K - 1] - top[K - 2]
+    elif method == "ratio":                           # utils/genes.py:202-206: largest fraction over the mean of the others
+        largest = frac.max(axis=0)
+        specificity = largest / ((frac.sum(axis=0) - largest) / (K - 1) + 1e-10)
+    elif method == "specificity":                     # utils/genes.py:208-211: tau score
+        largest = frac.max(axis=0)
+        specificity = np.sum(1 - frac / (largest + 1e-10), axis=0) / (K - 1)
+    else:
+        raise ValueError(f"Unknown method: {method}")
     owner = np.argmax(frac, axis=0)
     chosen, assign = [], []
     for k in range(K):

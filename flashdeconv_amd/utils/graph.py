@@ -39,9 +39,36 @@ def knn_graph_handle(coords, k=6):
     return _lib.Graph.from_coords_knn(coords, k)
 
 
+_ckdtree_probe = None
+
+
+def _ckdtree_restatement_matches_scipy():
+    """The restated traversal order was written against scipy 1.15's cKDTree (build: leafsize 16, sliding midpoint replaced by
+    the median via introselect; query: near child first).  Another scipy / libstdc++ could order ties differently, so the
+    first use replays a small all-ties case (a 19 x 17 lattice in shuffled order) against the installed scipy and warns on a
+    mismatch instead of silently returning a different 'reference' order.  Cached per process."""
+    global _ckdtree_probe
+    if _ckdtree_probe is None:
+        from scipy.spatial import cKDTree
+        rs = np.random.RandomState(5)
+        gx, gy = np.meshgrid(np.arange(19.0), np.arange(17.0))
+        pts = np.ascontiguousarray(np.stack([gx.ravel(), gy.ravel()], axis=1)[rs.permutation(19 * 17)])
+        idx = np.empty((len(pts), 7), dtype=np.int64)
+        _lib.check(_lib.load().fdx_ckdtree_knn(_lib.ptr_f64(pts), len(pts), 2, 7, idx.ctypes.data, None))
+        _ckdtree_probe = bool(np.array_equal(idx, cKDTree(pts).query(pts, k=7)[1]))
+        if not _ckdtree_probe:
+            import warnings
+            warnings.warn("knn ties='ckdtree': libfdx's restatement of scipy.spatial.cKDTree's tie order does not reproduce the "
+                          "installed scipy on a lattice probe (written against scipy 1.15); tied neighbours may be chosen "
+                          "differently from what the reference would choose on this installation.", UserWarning, stacklevel=3)
+    return _ckdtree_probe
+
+
 def ckdtree_knn_lists(coords, k):
     """(n, k + 1) neighbour indices exactly as ``cKDTree(coords).query(coords, k=k+1)`` returns them (utils/graph.py:60-63),
-    ties included: libfdx's host restatement of scipy's tree build and traversal order (csrc/kdtree_order.cpp)."""
+    ties included: libfdx's host restatement of scipy's tree build and traversal order (csrc/kdtree_order.cpp), checked once
+    per process against the installed scipy (``_ckdtree_restatement_matches_scipy``)."""
+    _ckdtree_restatement_matches_scipy()
     coords = np.ascontiguousarray(coords, dtype=np.float64)
     n, dim = coords.shape
     kk = min(int(k), n - 1) + 1

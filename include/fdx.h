@@ -343,7 +343,9 @@ int fdx_normalize_dev(const double* beta_dev, int64_t ld, int64_t n, int32_t K, 
  * ncclSend / ncclRecv on a communication stream while the interior tiles are swept, halo unpacked (one kernel),
  * ncclAllReduce(max) of the iteration's 128 convergence slots.  Same bits and iteration count as fdx_bcd_solve on the
  * unsharded problem.  fdx_local_world_* / fdx_comm_init_local: the same loop with host threads of ONE process as ranks
- * on one GPU (device copies through a shared mailbox) - for tests, no RCCL involved. */
+ * on one GPU (device copies through a shared mailbox) - for tests, no RCCL involved.  When one thread rank leaves a solve with
+ * an error the world is marked aborted (the others return "another rank failed" instead of waiting for ever) and STAYS so:
+ * destroy it and create a new one. */
 typedef struct fdx_comm fdx_comm;
 typedef struct fdx_local_world fdx_local_world;
 int fdx_comm_unique_id(void* id_out_128);

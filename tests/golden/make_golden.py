@@ -411,6 +411,22 @@ def golden_lattice():
     save("lattice.npz", **out)
 
 
+def golden_markers():
+    """select_markers with its three specificity scores (utils/genes.py:148-235) on log-normal signatures of three shapes
+    (case d has more cell types than genes, so some type is nowhere the largest one: the fallback branch :226-229)."""
+    print("markers: diff / ratio / specificity")
+    rs = np.random.RandomState(7)
+    out = {}
+    for tag, (K, G, nm) in dict(a=(6, 400, 12), b=(2, 90, 50), c=(9, 150, 7), d=(9, 6, 3)).items():   # d: more types than genes
+        X = np.exp(rs.randn(K, G) * 0.8)
+        out[f"{tag}_X"], out[f"{tag}_n_markers"] = X, np.array(nm)
+        for method in ("diff", "ratio", "specificity"):
+            mi, ma = select_markers(X, n_markers=nm, method=method)
+            out[f"{tag}_{method}_idx"] = np.asarray(mi, dtype=np.int64)
+            out[f"{tag}_{method}_assign"] = np.asarray(ma, dtype=np.int64)
+    save("markers.npz", **out)
+
+
 def golden_anndata():
     """The AnnData surface: the reference's io.load_reference (mean and sum), io.prepare_data /
     align_genes and tl.deconvolve run on a duck-typed AnnData (anndata is not installed; the loader only touches the
@@ -467,7 +483,7 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(omega=golden_omega, leverage=golden_leverage, graphs=golden_graphs, solver=golden_solver,
                 objective=golden_objective, fits=golden_fits,
-                fits_sparse=golden_fits_sparse, lattice=golden_lattice, anndata=golden_anndata)
+                fits_sparse=golden_fits_sparse, lattice=golden_lattice, anndata=golden_anndata, markers=golden_markers)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -204,6 +204,31 @@ def test_sharded_class_world1_equals_flashdeconv():
         got2[own2.cpu().numpy()] = P2.cpu().numpy()
         assert m2.info_["n_iterations"] == ref2.info_["n_iterations"]
         np.testing.assert_allclose(got2, ref2.proportions_, rtol=1e-9, atol=1e-12)
+        # integer counts: both drivers store them as float32 and keep the float64 transform chain (numpy promotes integer
+        # input, core/deconv.py:190-191) - same bits, and the oracle's float64 fit within 1e-8
+        kw_i = dict(sketch_dim=64, preprocess="log_cpm", n_hvg=900, max_iter=15)
+        Yi = torch.from_numpy(Yc.astype(np.int32)).to(dev)
+        ref_i = FlashDeconv(**kw_i).fit(Yi, Xc, cc)
+        ref_f = FlashDeconv(**kw_i).fit(Yc.astype(np.float64), Xc, cc)
+        m_i = ShardedFlashDeconv(**kw_i)
+        own_i = m_i.plan(torch.from_numpy(cc).to(dev))
+        P_i = m_i.fit_transform(Yi[own_i], Xc)
+        got_i = np.zeros((3000, 6))
+        got_i[own_i.cpu().numpy()] = P_i.cpu().numpy()
+        assert np.array_equal(got_i, ref_i.proportions_)
+        assert np.linalg.norm(got_i - ref_f.proportions_) / np.linalg.norm(ref_f.proportions_) < 1e-8
+        for dt, cap in ((torch.uint16, 60000), (torch.int64, 1 << 40)):    # uint16: torch has no max() for it -> float64 storage
+            Yu = np.minimum(Yc, cap)
+            want_u = FlashDeconv(**kw_i).fit(Yu.astype(np.float64), Xc, cc).proportions_
+            Yt_u = torch.from_numpy(Yu.astype(np.int64)).to(dev)
+            mu = ShardedFlashDeconv(**kw_i)
+            own_u = mu.plan(torch.from_numpy(cc).to(dev))
+            Pu = mu.fit_transform(Yt_u[own_u].to(dt), Xc)
+            got_u = np.zeros((3000, 6))
+            got_u[own_u.cpu().numpy()] = Pu.cpu().numpy()
+            assert np.linalg.norm(got_u - want_u) / np.linalg.norm(want_u) < 1e-8, dt
+            ref_u = FlashDeconv(**kw_i).fit(Yt_u.to(dt), Xc, cc)
+            assert np.linalg.norm(ref_u.proportions_ - want_u) / np.linalg.norm(want_u) < 1e-8, dt
         # the same shard handed over as CSR rows: statistics, selection and the sketch all read the sparse rows
         import scipy.sparse as sp
         for pre in ("log_cpm", "pearson", "raw"):

@@ -133,6 +133,28 @@ def test_markers_and_hvg_binning_vs_reference_golden():
         genes.select_markers(g["X"], -1)
 
 
+def test_select_markers_three_methods_vs_reference_golden():
+    """utils/genes.py:197-211: "diff", "ratio" and "specificity" scores, incl. the fallback for a type that tops no gene."""
+    from flashdeconv_amd.utils import genes
+    g = load_golden("markers.npz")
+    for tag in "abcd":
+        X, nm = g[f"{tag}_X"], int(g[f"{tag}_n_markers"])
+        for method in ("diff", "ratio", "specificity"):
+            idx, assign = genes.select_markers(X, n_markers=nm, method=method)
+            assert np.array_equal(idx, g[f"{tag}_{method}_idx"]), (tag, method)
+            assert np.array_equal(assign, g[f"{tag}_{method}_assign"]), (tag, method)
+    with pytest.raises(ValueError, match="Unknown method"):
+        genes.select_markers(g["a_X"], 5, method="nope")
+
+
+def test_utils_package_exports_the_reference_names():
+    """flashdeconv/utils/__init__.py:3-31 minus the evaluation metrics (out of scope)."""
+    import flashdeconv_amd.utils as u
+    for name in ("select_hvg", "select_markers", "compute_leverage_scores", "build_knn_graph", "build_radius_graph",
+                 "coords_to_adjacency", "check_random_state"):
+        assert callable(getattr(u, name)) and name in u.__all__
+
+
 def test_spatial_helpers():
     from flashdeconv_amd.core.spatial import auto_tune_lambda, compute_laplacian, compute_laplacian_quadratic, get_neighbor_indices
     A = sparse.csr_matrix(np.array([[0, 1, 1, 0], [1, 0, 0, 0], [1, 0, 0, 1], [0, 0, 1, 0]], dtype=float))
