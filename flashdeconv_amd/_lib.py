@@ -58,7 +58,7 @@ class FitInfo(ctypes.Structure):
     _fields_ = [
         ("solve", SolveInfo), ("lambda_used", c_double), ("rho_effective", c_double), ("YtY", c_double), ("nnz", c_i64),
         ("graph_ms", c_double), ("sketch_ms", c_double), ("gram_ms", c_double), ("solve_ms", c_double),
-        ("finish_ms", c_double), ("total_ms", c_double),
+        ("finish_ms", c_double), ("total_ms", c_double), ("prologue_ms", c_double), ("span_ms", c_double),
     ]
 
 
@@ -78,6 +78,8 @@ SIGNATURES = {
     "fdx_graph_build_radius_rows_dev": (c_int, [c_void_p, c_i64, c_i32, c_double, c_i64, c_i64, c_void_p, ctypes.POINTER(c_void_p)]),
     "fdx_graph_knn_lists_dev": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i64, c_i64, c_void_p, c_void_p, c_void_p,
                                         ctypes.POINTER(c_void_p)]),
+    "fdx_graph_knn_lists_band_dev": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i64, c_i64, c_void_p, c_void_p, c_void_p,
+                                             ctypes.POINTER(c_void_p)]),
     "fdx_graph_from_knn_lists_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, ctypes.POINTER(c_void_p)]),
     "fdx_leverage_begin": (c_int, [p_double, c_i32, c_i32, c_double, ctypes.POINTER(c_void_p)]),
     "fdx_leverage_end": (c_int, [c_void_p, p_double]),
@@ -121,6 +123,7 @@ SIGNATURES = {
     "fdx_local_world_create": (c_int, [c_i32, ctypes.POINTER(c_void_p)]),
     "fdx_local_world_destroy": (c_int, [c_void_p]),
     "fdx_comm_init_local": (c_int, [c_void_p, c_i32, ctypes.POINTER(c_void_p)]),
+    "fdx_comm_init_loopback": (c_int, [c_i32, c_i32, ctypes.POINTER(c_void_p)]),
     "fdx_comm_destroy": (c_int, [c_void_p]),
     "fdx_comm_info": (c_int, [c_void_p, p_i32, p_i32]),
     "fdx_comm_allreduce_sum_dev": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
@@ -141,6 +144,7 @@ SIGNATURES = {
     "fdx_graph_destroy": (c_int, [c_void_p]),
     "fdx_graph_info": (c_int, [c_void_p, p_i64, p_i64, p_i32]),
     "fdx_graph_knn_ties": (c_int, [c_void_p, p_i64]),
+    "fdx_graph_knn_far": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "fdx_ckdtree_knn": (c_int, [p_double, c_i64, c_i32, c_i32, c_void_p, c_void_p]),
     "fdx_bcd_solve": (c_int, [c_void_p, p_double, p_double, c_i64, c_i32, c_i32, c_double, c_double, c_i32, c_double,
                               c_i32, p_double, p_double, p_double, ctypes.POINTER(SolveInfo)]),
@@ -295,6 +299,12 @@ class Graph:
         """Spots whose k-th and (k+1)-th nearest neighbours are exactly equidistant (0 unless built by k-NN)."""
         t = c_i64(0)
         check(load().fdx_graph_knn_ties(self._h, ctypes.byref(t)))
+        return int(t.value)
+
+    def knn_far(self):
+        """1 when a k-NN walk of the rows this graph was built for left the 3 x 3 block of grid cells (spot shards: fdx.h)."""
+        t = c_i32(0)
+        check(load().fdx_graph_knn_far(self._h, ctypes.byref(t)))
         return int(t.value)
 
     def close(self):

@@ -156,6 +156,7 @@ class FlashDeconv:
     # ------------------------------------------------------------------ fit
     def fit(self, Y, X, coords, cell_type_names=None, output="numpy"):
         """Fit the model (core/deconv.py:237-405).  ``output="torch"`` keeps ``beta_``/``proportions_`` in HBM."""
+        t_entry = time.perf_counter()
         if Y.shape[1] != X.shape[1]:
             raise ValueError(
                 f"Gene dimension mismatch: Y has {Y.shape[1]} genes but X has {X.shape[1]} genes. They must share "
@@ -366,6 +367,7 @@ class FlashDeconv:
                                            _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim, ctypes.byref(prm),
                                            ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs), _lib.ptr_f64(rels),
                                            ctypes.byref(info), None))
+            t_ret = time.perf_counter()
             if output == "torch":
                 self.beta_, self.proportions_ = beta_t, prop_t
             else:
@@ -409,7 +411,8 @@ class FlashDeconv:
                 "reference's choice (host-side, seconds at a million spots), spatial_method='grid' builds a tie-free graph "
                 "on lattices.", UserWarning, stacklevel=2)
         # additive diagnostics (not in the reference): per-stage GPU milliseconds
-        self.timings_ = {k: float(getattr(info, k)) for k in ("graph_ms", "sketch_ms", "gram_ms", "solve_ms", "finish_ms", "total_ms")}
+        self.timings_ = {k: float(getattr(info, k)) for k in ("graph_ms", "sketch_ms", "gram_ms", "solve_ms", "finish_ms", "total_ms",
+                                                             "prologue_ms", "span_ms")}
         self.timings_["sweep_ms"] = float(info.solve.sweep_ms)
         # host wall of the graph build call, and of the wait for the leverage SVD that ran beside it
         self.timings_["graph_ms"] = (t_lev - t_graph) * 1e3
@@ -417,8 +420,13 @@ class FlashDeconv:
         self.timings_["leverage_wait_ms"] = (t_done - t_lev) * 1e3
         # the graph is built by its own call ahead of fdx_fit_dev, whose total_ms starts after it: one figure for the fit
         self.timings_["device_ms"] = self.timings_["total_ms"]
-        self.timings_["total_ms"] = self.timings_["graph_ms"] + self.timings_["select_ms"] + self.timings_["leverage_wait_ms"] + \
-            self.timings_["device_ms"]
+        # Accounting that tiles the wall time of this call: host_pre_ms (entry -> the graph build call: conversions, gene selection,
+        # leverage job set-up) + span_ms (device, hipEvents: first kernel of the graph build -> end of the export =
+        # prologue_ms + sketch_ms + gram_ms + solve_ms + finish_ms) + host_post_ms (fit_dev's return -> here);
+        # total_ms is their sum, and what the wall has beyond it is the host's last synchronisation
+        self.timings_["host_pre_ms"] = (t_graph - t_entry) * 1e3
+        self.timings_["host_post_ms"] = (time.perf_counter() - t_ret) * 1e3
+        self.timings_["total_ms"] = self.timings_["host_pre_ms"] + self.timings_["span_ms"] + self.timings_["host_post_ms"]
         self._fitted = True
         log(f"  Converged: {self.info_['converged']}")
         log(f"  Iterations: {self.info_['n_iterations']}")

@@ -22,6 +22,8 @@ int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_
     *out = nullptr;
     FDX_REQUIRE(n == 0 || coords_dev != nullptr, "fdx_graph_build_dev: null coords");
     fdx_graph* g = new fdx_graph();
+    if (hipEventCreate(&g->begin_event) == hipSuccess && hipEventRecord(g->begin_event, (hipStream_t)stream) == hipSuccess)
+        g->begin_stream = (hipStream_t)stream;                  // the fit's prologue timer (fdx_fit_info.prologue_ms) starts here
     int rc;
     if (method == FDX_GRAPH_KNN) rc = graph_build_knn(coords_dev, n, dim, k, g, (hipStream_t)stream);
     else if (method == FDX_GRAPH_RADIUS) rc = graph_build_radius(coords_dev, n, dim, radius, 0, n, g, (hipStream_t)stream);
@@ -51,6 +53,22 @@ int fdx_graph_knn_lists_dev(const double* coords_dev, int64_t n, int32_t dim, in
     *plan = nullptr;
     FDX_REQUIRE(coords_dev && nbr_dev && cnt_dev, "fdx_graph_knn_lists_dev: null argument");
     return graph_knn_lists(coords_dev, n, dim, k, lo, hi, nbr_dev, cnt_dev, plan, (hipStream_t)stream);
+}
+
+int fdx_graph_knn_lists_band_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t k, int64_t lo, int64_t hi,
+                                 int32_t* nbr_dev, int32_t* cnt_dev, void* stream, fdx_graph_plan** plan) {
+    PoolStream pool_stream((hipStream_t)stream);
+    FDX_REQUIRE(plan != nullptr, "fdx_graph_knn_lists_band_dev: null output");
+    *plan = nullptr;
+    FDX_REQUIRE(coords_dev && nbr_dev && cnt_dev, "fdx_graph_knn_lists_band_dev: null argument");
+    return graph_knn_lists(coords_dev, n, dim, k, lo, hi, nbr_dev, cnt_dev, plan, (hipStream_t)stream, true);
+}
+
+int fdx_graph_knn_far(const fdx_graph* g, int32_t* far) {
+    FDX_REQUIRE(g != nullptr && far != nullptr, "fdx_graph_knn_far: null argument");
+    FDX_TRY(fdx::graph_meta_sync(g));
+    *far = g->knn_far;
+    return 0;
 }
 
 int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, const int32_t* cnt_dev, int64_t lo, int64_t hi,

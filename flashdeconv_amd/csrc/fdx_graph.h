@@ -58,7 +58,13 @@ struct fdx_graph {
     // such a spot is a choice (utils/graph.py:60-63 leaves it to cKDTree's traversal order)
     fdx::DevBuf ties_dev;
     mutable long long knn_ties = 0;
+    // k-NN builds of a row range: some walk of the range left the 3 x 3 (x 3) block of cells around its point (or the band list
+    // overflowed) - a band-recompute shard build is then not guaranteed to hold every reverse edge
+    mutable int knn_far = 0;
     mutable struct fdx_graph_plan* keep_plan = nullptr;
+    // recorded by fdx_graph_build_dev ahead of the first kernel of the build, on begin_stream: the fit's prologue timer starts here
+    hipEvent_t begin_event = nullptr;
+    hipStream_t begin_stream = nullptr;
     ~fdx_graph();
 };
 

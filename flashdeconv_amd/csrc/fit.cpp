@@ -337,12 +337,12 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     FDX_TRY(solver_zero_pad(dH.as<double>(), ld, n, K, st));   // columns of real spots are all written by the sketch -> H stage
     const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();
     double sketch_ms = 0.0, gram_ms = 0.0;
-    hipEvent_t eS0 = nullptr, eS1 = nullptr;     // around the fused kernel; read at the end of the fit, no wait here
+    hipEvent_t eS0 = nullptr, eS1 = nullptr;     // around the sketch -> H stage; read at the end of the fit, no wait here
     struct EvGuard2 { hipEvent_t* a; hipEvent_t* b; ~EvGuard2() { if (*a) (void)hipEventDestroy(*a); if (*b) (void)hipEventDestroy(*b); } } eS_guard{&eS0, &eS1};
+    FDX_HIP(hipEventCreate(&eS0));
+    FDX_HIP(hipEventCreate(&eS1));
+    FDX_HIP(hipEventRecord(eS0, st));            // the prologue (graph chain, X-side preamble) ends here
     if (fused) {   // one kernel, no Y_sketch: rows -> LDS tile -> bucket sums -> MFMA contraction -> H  (tile_kernels.cpp)
-        FDX_HIP(hipEventCreate(&eS0));
-        FDX_HIP(hipEventCreate(&eS1));
-        FDX_HIP(hipEventRecord(eS0, st));
         if (csr_fused)     // CSR rows -> LDS accumulators -> MFMA contraction -> H  (csr_kernels.cpp)
             FDX_TRY(launch_sketch_csr_contract((const long long*)ysrc.csr->indptr, ysrc.csr->indices, ysrc.csr->data, y_dtype,
                                                row_map, n, d, prm->mode_y, dSlots.p, dBits.as<unsigned>(), sel_words,
@@ -388,6 +388,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         sketch_ms *= scale;
         gram_ms *= scale;
         for (auto& e : ev) (void)hipEventDestroy(e);
+        FDX_HIP(hipEventRecord(eS1, st));
     }
     // YtY (core/solver.py:348) only enters the objective: its two small reductions and the read-back go to the side stream (behind the
     // sketch, beside the first sweep) instead of standing between the sketch and the sweeps; the verbose trace needs it at once
@@ -486,14 +487,21 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     info->YtY = *YtY_h;
     info->nnz = g->nnz;
     info->graph_ms = tm.ms(0, 1);
-    if (eS0) {
-        float t = 0.f;
-        (void)hipEventElapsedTime(&t, eS0, eS1);
-        sketch_ms = t;
-    }
+    float t_stage = 0.f;
+    (void)hipEventElapsedTime(&t_stage, eS0, eS1);
+    if (fused) sketch_ms = t_stage;              // the chunked path keeps its per-chunk split of the same interval
     info->sketch_ms = sketch_ms;
     info->gram_ms = gram_ms;
-    info->solve_ms = tm.ms(2, 3);
+    // contiguous intervals on the caller's stream: [begin, eS0) prologue, [eS0, eS1) sketch -> H, [eS1, mark 3) solve + objective,
+    // [mark 3, mark 4) what is left of the export
+    float t_pro = 0.f, t_solve = 0.f, t_span = 0.f;
+    const bool from_build = g->begin_event && g->begin_stream == st && prm->graph_method == FDX_GRAPH_GIVEN;
+    (void)hipEventElapsedTime(&t_pro, from_build ? g->begin_event : tm.ev[0], eS0);
+    (void)hipEventElapsedTime(&t_solve, eS1, tm.ev[3]);
+    (void)hipEventElapsedTime(&t_span, from_build ? g->begin_event : tm.ev[0], tm.ev[4]);
+    info->prologue_ms = t_pro;
+    info->span_ms = t_span;
+    info->solve_ms = t_solve;
     info->finish_ms = tm.ms(3, 4);
     info->total_ms = tm.ms(0, 4);
     info->solve.total_ms = info->total_ms;

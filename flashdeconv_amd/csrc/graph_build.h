@@ -9,8 +9,9 @@ namespace fdx {
 // coords: device (n, dim) row-major float64, dim in {1,2,3}
 int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_graph* g, hipStream_t st);
 // two-phase k-NN build for spot shards (see graph_kernels.cpp): lists of rows [lo, hi) -> caller all-gathers -> own rows
+// band: also the lists of the rows outside [lo, hi) in cells next to a cell with an own row; every other row of cnt reads 0
 int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long long lo, long long hi, int* nbr, int* cnt,
-                    fdx_graph_plan** out, hipStream_t st);
+                    fdx_graph_plan** out, hipStream_t st, bool band = false);
 int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, long long lo, long long hi, fdx_graph* g,
                          hipStream_t st);
 void graph_plan_destroy(fdx_graph_plan* plan);

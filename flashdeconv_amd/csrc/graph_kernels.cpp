@@ -286,9 +286,15 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
                                                   long long n, GridParams gp, int kk, int* __restrict__ nbr_out,
                                                   int* __restrict__ nbr_cnt, double* __restrict__ nn_dist,
                                                   long long lo, long long hi, int* __restrict__ indeg,
-                                                  int* __restrict__ arrival, int* __restrict__ tie_count, int gp_no_batch) {
-    const long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;      // rows [lo, hi) of the sorted order
-    if (p >= hi) return;
+                                                  int* __restrict__ arrival, int* __restrict__ tie_count, int gp_no_batch,
+                                                  const int* __restrict__ row_list, const int* __restrict__ row_count,
+                                                  int* __restrict__ far_flag, int far_R) {
+    // rows [lo, hi) of the sorted order, or (row_list != NULL: the band of a spot shard) the first min(*row_count, hi) listed rows
+    long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (row_list) {
+        if (p >= hi || p >= (long long)*row_count) return;
+        p = row_list[p];
+    } else if (p >= hi) return;
     const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
     const double pc[3] = {px, py, pz};
     int c[3];
@@ -414,6 +420,9 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
         nn_dist[perm[p]] = sqrt(bd[0]);
         return;
     }
+    // a walk that went past shell far_R of its cell: a spot shard's band (the rows of the cells within far_R cells of an own one)
+    // then does not hold every row that can point at an own row - the sharded build falls back to exchanging the lists
+    if (far_flag && __ballot(R_end > far_R + 1) != 0ULL && (threadIdx.x & 63) == 0) atomicOr(far_flag, 1);
 
     // ---- the threshold: the kk-th smallest distance, how many list entries lie below it, and whether the (kk+1)-th equals it
     double thr = INFINITY, next = INFINITY;
@@ -482,6 +491,75 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
         }
     for (int s = cnt; s < kk; ++s) nbr_out[(size_t)p * kk + s] = -1;
     nbr_cnt[p] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------ band of a spot shard
+// A shard owns rows [lo, hi) of the sorted order.  Row p of the symmetrised k-NN graph is out(p) U in(p): in(p) needs the list of
+// every row q that points at p.  When q's walk stayed within BAND_R shells of its own cell (knn_kernel reports the rows for which
+// it did not), q can only point at rows of cells at most BAND_R cells away - so the rows that can point at an OWN row all live in
+// cells within BAND_R cells of a cell that holds an own row: the BAND.  The shard finds the lists of its band itself ("recompute,
+// don't communicate") instead of receiving the lists of all n rows.  BAND_R = 2: at ~4 points per cell the 3 x 3 block serves the
+// k <= 8 nearest of MOST points (the flat walk of knn_kernel), but on uniform random points 1-3 % of the walks need shell 2 (the
+// 7-th nearest lies beyond the distance to the block's edge); shell 3 would need fewer than 7 points in a disc of 12 cells.
+// counters: [0] cells listed, [1] band rows listed, [2] a walk left the block (knn_kernel), [3] the band list overflowed
+constexpr int BAND_R = 2;
+__global__ __launch_bounds__(256) void band_cells_kernel(const double* __restrict__ sc, long long n, GridParams gp, long long lo,
+                                                         long long hi, int* __restrict__ cell_flag, int* __restrict__ cell_list,
+                                                         int* __restrict__ counters) {
+    const long long p = lo + blockIdx.x * 256LL + threadIdx.x;
+    if (p >= hi) return;
+    int c[3];
+    for (int a = 0; a < 3; ++a) c[a] = (a < gp.dim) ? cell_coord(sc[(size_t)a * n + p], gp.mn[a], gp.inv_h[a], gp.nc[a]) : 0;
+    const int r1 = gp.dim > 1 ? BAND_R : 0, r2 = gp.dim > 2 ? BAND_R : 0;
+    for (int dz = -r2; dz <= r2; ++dz)
+        for (int dy = -r1; dy <= r1; ++dy)
+            for (int dx = -BAND_R; dx <= BAND_R; ++dx) {
+                const int x = c[0] + dx, y = c[1] + dy, z = c[2] + dz;
+                if (x < 0 || x >= gp.nc[0] || y < 0 || y >= gp.nc[1] || z < 0 || z >= gp.nc[2]) continue;
+                const int cell = x * gp.stride[0] + y * gp.stride[1] + z * gp.stride[2];
+                if (cell_flag[cell] == 0 && atomicExch(&cell_flag[cell], 1) == 0) cell_list[atomicAdd(&counters[0], 1)] = cell;
+            }
+}
+
+__global__ __launch_bounds__(256) void band_rows_kernel(const int* __restrict__ cell_list, const int* __restrict__ cstart,
+                                                        const int* __restrict__ cend, long long lo, long long hi, int cap,
+                                                        int* __restrict__ band, int* __restrict__ counters) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= counters[0]) return;
+    const int cell = cell_list[i];
+    for (int q = cstart[cell]; q < cend[cell]; ++q) {
+        if (q >= lo && q < hi) continue;
+        const int at = atomicAdd(&counters[1], 1);
+        if (at < cap) band[at] = q;
+        else counters[3] = 1;
+    }
+}
+
+// indegree / reverse lists of a shard over the rows that HAVE lists: [lo, hi) and the band (every other row is skipped without a
+// look at its count)
+__global__ __launch_bounds__(256) void indegree_rows_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt, int kk,
+                                                            int* __restrict__ indeg, int lo, int hi, const int* __restrict__ rows,
+                                                            const int* __restrict__ n_rows, int cap) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    long long p;
+    if (rows) { if (i >= cap || i >= *n_rows) return; p = rows[i]; } else { p = lo + i; if (p >= hi) return; }
+    for (int m = 0; m < nbr_cnt[p]; ++m) {
+        const int q = nbr[(size_t)p * kk + m];
+        if (q >= lo && q < hi) atomicAdd(&indeg[q], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_reverse_rows_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt, int kk,
+                                                                const int* __restrict__ rev_off, int* __restrict__ cursor,
+                                                                int* __restrict__ rev, int lo, int hi, const int* __restrict__ rows,
+                                                                const int* __restrict__ n_rows, int cap) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    long long p;
+    if (rows) { if (i >= cap || i >= *n_rows) return; p = rows[i]; } else { p = lo + i; if (p >= hi) return; }
+    for (int m = 0; m < nbr_cnt[p]; ++m) {
+        const int q = nbr[(size_t)p * kk + m];
+        if (q >= lo && q < hi) rev[rev_off[q] + atomicAdd(&cursor[q], 1)] = (int)p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ radius graph
@@ -1033,7 +1111,10 @@ static int build_tiles(fdx_graph* g, hipStream_t st) {
 // deg + row segments -> sliced ELL inside g (pad index = n_total)
 // defer: nothing is read back here - the ELL gets room for `W_CAP` entries per row on average (the kernels stop at that bound),
 // the tile tables are built behind it and the counts travel to pinned memory behind g->meta_event (graph_meta_sync).
-static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* seg_extra, hipStream_t st, bool defer = false) {
+// no_tiles (the full-size graph of a spot shard: only rows [lo, hi) are filled): no tile tables - graph_localize builds the local
+// graph's own, and a pass over all n / 256 tiles here would be the shard's only work proportional to the whole graph
+static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* seg_extra, hipStream_t st, bool defer = false,
+                      bool no_tiles = false) {
     const long long n = g->n;
     g->n_slices = (int)((n + 63) / 64);
     DevBuf width, tmp;
@@ -1094,11 +1175,12 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     int total = 0;
     FDX_HIP(hipMemcpyAsync(&total, g->slice_off.as<int>() + g->n_slices, 4, hipMemcpyDeviceToHost, st));
     long long h_red[2] = {0, 0};
-    int h_ties = 0;
+    int h_ties[2] = {0, 0};
     FDX_HIP(hipMemcpyAsync(h_red, red, 16, hipMemcpyDeviceToHost, st));
-    if (g->ties_dev.p) FDX_HIP(hipMemcpyAsync(&h_ties, g->ties_dev.p, 4, hipMemcpyDeviceToHost, st));
+    if (g->ties_dev.p) FDX_HIP(hipMemcpyAsync(h_ties, g->ties_dev.p, std::min<size_t>(8, g->ties_dev.bytes), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
-    g->knn_ties = h_ties;
+    g->knn_ties = h_ties[0];
+    g->knn_far = h_ties[1];
     trace_host("ell: read-back + sync");
     g->ell_rows = total;
     g->nnz = h_red[0];
@@ -1109,6 +1191,7 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
                        (long long)g->ell_rows);
     FDX_CHECK_LAUNCH();
     trace_host("ell: alloc + fill_ell");
+    if (no_tiles) { g->n_tiles = (int)((n + 255) / 256); g->tiled = false; g->halo_max = 0; return 0; }
     FDX_TRY(build_tiles(g, st));
     return 0;
 }
@@ -1128,7 +1211,9 @@ static int empty_graph(long long n, fdx_graph* g, hipStream_t st) {
 
 template <int KMAX>
 static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, long long lo,
-                             long long hi, hipStream_t st, int* indeg = nullptr, int* arrival = nullptr, int* ties = nullptr) {
+                             long long hi, hipStream_t st, int* indeg = nullptr, int* arrival = nullptr, int* ties = nullptr,
+                             const int* row_list = nullptr, const int* row_count = nullptr, int* far_flag = nullptr) {
+    const int far_R = BAND_R;
     if (hi <= lo) return;
     // candidates per round trip: 4 leaves the kernel 77 registers (6 waves per SIMD), 6: 87 (5 waves), 8: 97 (4 waves);
     // 1M spots, wall per fit: 4.69 / 4.84 / 4.88 ms
@@ -1137,7 +1222,7 @@ static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), b.sc2.as<double2>(), perm,
                            b.rank.as<int>(), b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
-                           KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0);
+                           KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0, row_list, row_count, far_flag, far_R);
     };
     if constexpr (KMAX <= 16) {
         if (batch == 4) go(knn_kernel<KMAX, 4>);
@@ -1178,7 +1263,11 @@ struct fdx_graph_plan {
     int kk = 0;
     hipStream_t st = nullptr;      // stream the binning / k-NN kernels were queued on
     fdx::DevBuf indeg, arrival;    // whole graph in one piece: in-degrees and reverse-list places from the k-NN kernel
-    fdx::DevBuf ties;              // one int: rows of [lo, hi) with a tie at the k-th neighbour (knn_kernel)
+    fdx::DevBuf ties;              // [0] rows of [lo, hi) with a tie at the k-th neighbour, [1] some walk of [lo, hi) left the 3 x 3 block (knn_kernel)
+    // spot shard with band recompute (graph_knn_lists, band = true): the rows outside [lo, hi) whose lists were found here,
+    // counters = {cells listed, band rows, -, band list overflowed}
+    fdx::DevBuf band_rows, band_counters;
+    int band_cap = 0;
     bool kernels_done = false;     // set by graph_meta_sync: the graph's meta event (recorded behind every kernel that reads
                                    // the plan) has completed - no stream sync needed, which would also wait for whatever the
                                    // caller queued behind the build (the sketch kernel of the fit)
@@ -1188,12 +1277,13 @@ fdx_graph::~fdx_graph() {
     if (meta_pending && meta_event) (void)hipEventSynchronize(meta_event);   // queued kernels still write into the buffers below
     if (keep_plan) { delete keep_plan; keep_plan = nullptr; }
     if (meta_event) (void)hipEventDestroy(meta_event);
+    if (begin_event) (void)hipEventDestroy(begin_event);
     if (meta_host) fdx::pinned_block_put(meta_host);
 }
 namespace fdx {
 
 int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long long lo, long long hi, int* nbr, int* cnt,
-                    fdx_graph_plan** out, hipStream_t st) {
+                    fdx_graph_plan** out, hipStream_t st, bool band) {
     FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
     FDX_REQUIRE(n >= 2 && n < 0x7fffff00LL, "graph: n out of range");
     FDX_REQUIRE(k >= 1, "graph: k must be positive");
@@ -1223,10 +1313,16 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
         indeg = plan->indeg.as<int>();
         arrival = plan->arrival.as<int>();
     }
-    rc = plan->ties.alloc(4);
+    rc = plan->ties.alloc(8);
     if (rc) { delete plan; return rc; }
-    if (hipMemsetAsync(plan->ties.p, 0, 4, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
+    if (hipMemsetAsync(plan->ties.p, 0, 8, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
     int* ties = plan->ties.as<int>();
+    band = band && (lo > 0 || hi < n);
+    if (band) {
+        // every row without a list must read as empty: one fill of 4 bytes per row (the only pass over all n rows left in a shard's
+        // symmetrisation; the lists themselves are written for the own rows and the band only)
+        if (hipMemsetAsync(cnt, 0, (size_t)n * 4, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
+    }
     // one slot more than the list length, for the tie test (kk = 64 has none: no tie count there).
     // One launch (FDX_KNN_PIECES splits it: while the leverage scores still came from the Jacobi SVD passes on the library's
     // side stream, 2-4 pieces let their small workgroups in between; the Cholesky-QR route is over before this kernel starts).
@@ -1238,12 +1334,46 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     const long long step = ((rows + pieces - 1) / pieces + 127) / 128 * 128;
     for (long long a = lo; a < hi; a += step) {
         const long long e = std::min(hi, a + step);
-        if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties);
-        else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties);
-        else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties);
-        else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties);
+        if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1);
+        else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1);
+        else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1);
+        else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1);
     }
     trace_host("knn: kernel launched");
+    if (band && rows > 0) {
+        // the band: cells next to a cell with an own row -> their rows outside [lo, hi) -> the lists of those rows.  Room for as
+        // many band rows as own rows (a band is a surface: thousands of rows beside a million); an overflow is reported and the
+        // caller falls back to exchanging the lists.
+        const int n_cells = b.n_cells;
+        DevBuf cell_flag, cell_list;
+        plan->band_cap = (int)std::min<long long>(n - rows, std::max<long long>(rows, 4096));
+        rc = cell_flag.alloc((size_t)std::max(n_cells, 1) * 4);
+        if (!rc) rc = cell_list.alloc((size_t)std::max(n_cells, 1) * 4);
+        if (!rc) rc = plan->band_rows.alloc((size_t)std::max(plan->band_cap, 1) * 4);
+        if (!rc) rc = plan->band_counters.alloc(16);
+        if (rc) { delete plan; return rc; }
+        if (hipMemsetAsync(cell_flag.p, 0, cell_flag.bytes, st) != hipSuccess || hipMemsetAsync(plan->band_counters.p, 0, 16, st) != hipSuccess) {
+            delete plan;
+            return fail(FDX_ERR_HIP, "graph: memset failed");
+        }
+        int* ctr = plan->band_counters.as<int>();
+        hipLaunchKernelGGL(band_cells_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, b.sc.as<double>(), n, b.gp, lo, hi,
+                           cell_flag.as<int>(), cell_list.as<int>(), ctr);
+        // at most (2 BAND_R + 1)^dim cells per own row, and never more than there are cells
+        const long long side = 2 * BAND_R + 1;
+        const long long max_cells = std::min<long long>(n_cells, rows * (dim == 1 ? side : dim == 2 ? side * side : side * side * side));
+        hipLaunchKernelGGL(band_rows_kernel, dim3(ceil_div(max_cells, 256)), dim3(256), 0, st, cell_list.as<int>(), b.cstart.as<int>(),
+                           b.cend.as<int>(), lo, hi, plan->band_cap, plan->band_rows.as<int>(), ctr);
+        const int* bl = plan->band_rows.as<int>();
+        const long long cap = plan->band_cap;
+        if (cap > 0) {
+            if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr);
+            else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr);
+            else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr);
+            else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr);
+        }
+        // cell_flag / cell_list go back to the pool here: the pool orders their next use on this stream behind these kernels
+    }
     if (hipGetLastError() != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: k-NN kernel launch failed"); }
     *out = plan;
     return 0;
@@ -1275,7 +1405,16 @@ static int graph_from_knn_lists_impl(fdx_graph_plan* plan, const int* nbr, const
         FDX_HIP(hipMemsetAsync(indeg.p, 0, indeg.bytes, st));
         FDX_HIP(hipMemsetAsync(cursor.p, 0, cursor.bytes, st));
         trace_host("sym: allocs + 2 memsets");
-        hipLaunchKernelGGL(indegree_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, indeg.as<int>(), (int)lo, (int)hi);
+        if (plan->band_rows.p) {      // band recompute: only the own rows and the band have lists
+            if (hi > lo)
+                hipLaunchKernelGGL(indegree_rows_kernel, dim3(ceil_div(hi - lo, 256)), dim3(256), 0, st, nbr, cnt, kk, indeg.as<int>(), (int)lo,
+                                   (int)hi, (const int*)nullptr, (const int*)nullptr, 0);
+            if (plan->band_cap > 0)
+                hipLaunchKernelGGL(indegree_rows_kernel, dim3(ceil_div(plan->band_cap, 256)), dim3(256), 0, st, nbr, cnt, kk, indeg.as<int>(),
+                                   (int)lo, (int)hi, plan->band_rows.as<int>(), plan->band_counters.as<int>() + 1, plan->band_cap);
+        } else {
+            hipLaunchKernelGGL(indegree_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, indeg.as<int>(), (int)lo, (int)hi);
+        }
         FDX_CHECK_LAUNCH();
     }
     FDX_TRY(exclusive_scan_int(indeg.as<int>(), rev_off.as<int>(), n + 1, st, tmp));
@@ -1292,7 +1431,15 @@ static int graph_from_knn_lists_impl(fdx_graph_plan* plan, const int* nbr, const
     if (placed)
         hipLaunchKernelGGL(fill_reverse_placed_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, plan->arrival.as<int>(), n, kk,
                            rev_off.as<int>(), rev.as<int>());
-    else
+    else if (plan->band_rows.p) {
+        if (hi > lo)
+            hipLaunchKernelGGL(fill_reverse_rows_kernel, dim3(ceil_div(hi - lo, 256)), dim3(256), 0, st, nbr, cnt, kk, rev_off.as<int>(),
+                               cursor.as<int>(), rev.as<int>(), (int)lo, (int)hi, (const int*)nullptr, (const int*)nullptr, 0);
+        if (plan->band_cap > 0)
+            hipLaunchKernelGGL(fill_reverse_rows_kernel, dim3(ceil_div(plan->band_cap, 256)), dim3(256), 0, st, nbr, cnt, kk, rev_off.as<int>(),
+                               cursor.as<int>(), rev.as<int>(), (int)lo, (int)hi, plan->band_rows.as<int>(),
+                               plan->band_counters.as<int>() + 1, plan->band_cap);
+    } else
         hipLaunchKernelGGL(fill_reverse_kernel, dim3(nb), dim3(256), 0, st, nbr, cnt, n, kk, rev_off.as<int>(), cursor.as<int>(),
                            rev.as<int>(), (int)lo, (int)hi);
     FDX_CHECK_LAUNCH();
@@ -1307,8 +1454,12 @@ static int graph_from_knn_lists_impl(fdx_graph_plan* plan, const int* nbr, const
     trace_host("sym: fill_reverse, merge_rows launched");
     g->row_stride = kk;
     g->row_extra.take(rev_off);   // keep: segment offsets
-    FDX_TRY(finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), st, defer));
+    const bool shard = lo > 0 || hi < n;
+    int band_over = 0;
+    if (shard && plan->band_counters.p) FDX_HIP(hipMemcpyAsync(&band_over, plan->band_counters.as<int>() + 3, 4, hipMemcpyDeviceToHost, st));
+    FDX_TRY(finish_ell(g, g->rows.as<int>(), g->row_stride, g->row_extra.as<int>(), st, defer, shard));
     if (!defer) FDX_HIP(hipStreamSynchronize(st));
+    if (band_over) g->knn_far = 1;          // the band list overflowed: same remedy as a far walk (exchange the lists)
     return 0;
 }
 
@@ -1407,7 +1558,7 @@ int graph_build_radius(const double* d_coords, long long n, int dim, double radi
     FDX_CHECK_LAUNCH();
     g->deg.take(cnt);
     g->row_stride = 0;
-    FDX_TRY(finish_ell(g, g->rows.as<int>(), 0, g->row_extra.as<int>(), st));
+    FDX_TRY(finish_ell(g, g->rows.as<int>(), 0, g->row_extra.as<int>(), st, false, lo > 0 || hi < n));
     FDX_HIP(hipStreamSynchronize(st));
     return 0;
 }

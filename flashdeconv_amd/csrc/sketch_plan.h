@@ -23,7 +23,7 @@ struct SketchPlan {
     // one per (input type, raw / log, type tiles, wave split) (tile_kernels.cpp)
     std::vector<int> host_bucket;
     std::vector<double> host_w;
-    static constexpr int kTileKeys = 56;     // (input type, raw / log, type tiles, wave split) + the wide form (input type, raw / log)
+    static constexpr int kTileKeys = 224;    // (input type, raw / log, type tiles, wave split) + the wide form (input type, raw / log), x ring of three, x wide raw without WG, x flat schedule
     mutable std::shared_ptr<TilePlanDevice> tile[kTileKeys];
     mutable bool tile_tried[kTileKeys] = {};
     mutable std::mutex tile_mu;              // plans are shared through the cache: schedules are built under this lock

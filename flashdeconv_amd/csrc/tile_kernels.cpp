@@ -46,6 +46,8 @@ struct TileArgs {
     int G, d, K;
     int NE, GB, NBLK, RS, jw_used;
     int NST;   // stage buffers: 2, or 3 (raw mode with loader waves: two blocks in flight while one is consumed)
+    int WB;    // WG form: bytes of a block's weight table at the head of every stage buffer ((GB + 1) doubles, 16-byte rounded)
+    int NSP, GROW;   // flat form (FF, tile_plan.h: TileFlatHost): off_tab rows of NSP offsets per (wave, block, lane class), len_tab rows of GROW bytes
 };
 
 template <typename T> struct TileVec;
@@ -83,7 +85,29 @@ __host__ __device__ constexpr int JW_PAD(int jw) { return (jw + 7) & ~7; }
 // sums) - each group's TT operands are fetched from a copy of X_sketch laid out in operand order (tile_xa_kernel; it
 // stays in L2) when the group's gather starts, and have landed when its sums are final.
 // LOGV (float32 input, log modes): 0 = the float64 table chain, 2 = the float32-class log1p (tile_device.h: tile_log1p_f32).
-template <typename T, int MODE, int NWC, int NWL, int JW, int TT, bool AVL2, int LOGV = 0>
+// WG (round 4, the wide raw form): the per-entry weight table (8 bytes per scheduled step and lane class: 55-65 KB at 5000 genes)
+// is replaced by the weights BY GENE of the column block in flight - (GB + 1) doubles at the head of every stage buffer, copied
+// by the loaders with the block's rows (w_tab then holds NBLK such tables back to back, WB bytes each; entry GB is 0.0 and is
+// what the lockstep padding steps point at, together with the zeroed pad behind every staged row).  The 40 KB this frees make
+// the column blocks larger: 5 of 1024 genes instead of 7 of 736 at 5000 genes - fewer barriers, fewer (group, block) loop
+// entries (they average ~1.1 steps), 12 % less lockstep padding.
+// FF (with WG): the FLAT schedule.  The dynamic form walks a (wave, block)'s steps group by group - a loop per group whose
+// trip count is the group's length in that block, ~1.1 at 5000 genes x 1024 buckets: every step two dependent LDS round trips
+// (offset -> weight, value) with nothing else in flight, which three waves per SIMD cannot hide (the ISA shows a
+// `s_waitcnt lgkmcnt(0)` per step).  Here the same steps, in the same order, are one flat stream served eight at a time - one
+// 16-byte read brings a lane's eight offsets, sixteen reads (weights, values) go out together, eight fused multiply-adds follow -
+// and the group a step belongs to is DATA (a byte per step, scalar loads), not control flow: the bucket sums live in two register
+// vectors that the steps index with a wave-uniform number (s_set_gpr_idx_on + v_mov: what the compiler emits for a dynamically
+// indexed ext_vector_type in registers).  Same sums, bit for bit, as the dynamic form of the same schedule.
+// MEASURED SLOWER (one 1.25M x 5000 x 50 shard, d = 1024: 9.85 ms against 8.69 ms for the group loops) and therefore behind
+// FDX_TILE_FLAT=1 only: the round trips were not the limit - a wave64 vector instruction occupies its SIMD for four cycles, the
+// group loops spend ~5 of them per step (two address forms, convert, multiply-add, pointer bump), the flat form ~10 (offset
+// unpacking, two address forms, convert, multiply-add, four moves through the indexed register) - the gather of the wide form
+// is bound by vector-instruction issue, with the 1056 MFMAs of a tile (7 us per SIMD) behind it.  Kept as a tested variant.
+typedef double tile_acc16_t __attribute__((ext_vector_type(16)));
+typedef double tile_acc8_t __attribute__((ext_vector_type(8)));
+
+template <typename T, int MODE, int NWC, int NWL, int JW, int TT, bool AVL2, int LOGV = 0, bool WG = false, bool FF = false>
 __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch_kernel(
     const TileArgs a, const T* __restrict__ Yp, const int* __restrict__ row_map, const double* __restrict__ Xs,
     double* __restrict__ H, double* __restrict__ row_sumsq, const double* __restrict__ w_tab,
@@ -106,17 +130,22 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int stage_bytes = TILE_ROWS * a.RS;
+    const int WB = WG ? a.WB : 0;
+    const int stage_bytes = WB + TILE_ROWS * a.RS;
     const int NEp = (a.NE + 7) & ~7;
     const int NST = (NWL > 0 && MODE == FDX_PRE_RAW) ? a.NST : 2;
     double* w_l = reinterpret_cast<double*>(smem + (size_t)NST * stage_bytes);
-    unsigned short* off_l = reinterpret_cast<unsigned short*>(w_l + NEp);
+    unsigned short* off_l = reinterpret_cast<unsigned short*>(w_l + (WG ? 0 : NEp));
     double* scales = reinterpret_cast<double*>(off_l + NEp);               // [2][16] scale of a row (log modes)
     int* rowok = reinterpret_cast<int*>(scales + 2 * TILE_ROWS);           // [2][16] every log argument of the row in the fast range
     double* logt = reinterpret_cast<double*>(smem + LOG_TAB_LDS);          // [LOG_TAB_N] (log modes), fixed place: see LOG_TAB_LDS
-    for (int i = tid; i < a.NE; i += NT) {
-        w_l[i] = w_tab[i];
+    for (int i = tid; i < a.NE; i += NT) {          // FF: NE counts the flat form's offsets (NWC x NBLK x 4 x NSP)
+        if (!WG) w_l[i] = w_tab[i];
         off_l[i] = off_tab[i];
+    }
+    if (WG) {       // the pad behind every staged row is what a padding step reads (times weight 0.0): finite, i.e. zero
+        for (int i = tid; i < NST * TILE_ROWS * 4; i += NT)
+            *reinterpret_cast<unsigned*>(smem + (size_t)(i / (TILE_ROWS * 4)) * stage_bytes + WB + ((i >> 2) % TILE_ROWS) * a.RS + a.RS - TILE_ROW_PAD + (i & 3) * 4) = 0u;
     }
     constexpr bool F32LOG = LOGV != 0 && sizeof(T) == 4 && MODE != FDX_PRE_RAW;   // float32-class log1p: no table, no float64 chain
     if (MODE != FDX_PRE_RAW && !F32LOG)
@@ -143,8 +172,15 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
     auto issue_stage = [&](const T* const (&rp)[RPL], int c, int buf) -> int {   // returns the instructions issued (wave-uniform)
         const int gene0 = c * a.GB;
         const int bytes = (min(a.GB, a.G - gene0)) * (int)sizeof(T);
-        unsigned char* base = smem + (size_t)buf * stage_bytes;
+        unsigned char* base = smem + (size_t)buf * stage_bytes + WB;
         int issued = 0;
+        if (WG) {                                                           // the block's weights by gene: pieces lw, lw + NWS, ...
+            const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(w_tab) + (size_t)c * WB + lane * 16;
+            for (int o = lw * 1024; o < WB; o += NWS * 1024) {
+                if (o + lane * 16 < WB) dma16(wsrc + o, base - WB + o);
+                ++issued;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < RPL; ++k) {
             if (!rp[k]) continue;                                           // row past the end: stale LDS, never stored
@@ -285,6 +321,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 if (PAIR) lds_barrier();
                 lds_barrier();
             }
+            if (WG) lds_barrier();
         }
         return;
     }
@@ -318,9 +355,11 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             has_next = tile + gridDim.x < n_tiles;
             load_rows(tile + gridDim.x, rown);
         }
-        double acc[JW];
+        double acc[FF ? 1 : JW];
 #pragma unroll
-        for (int j = 0; j < JW; ++j) acc[j] = 0.0;
+        for (int j = 0; j < (FF ? 1 : JW); ++j) acc[j] = 0.0;
+        tile_acc16_t accA = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // FF: groups 0..15
+        tile_acc8_t accB = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};                                              //     groups 16..23
         double4_t accm[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) accm[t] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -339,11 +378,54 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         auto consume = [&](int c, auto last_tag, auto fast_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             constexpr bool FAST = decltype(fast_tag)::value;
-            const unsigned char* rowb = smem + (size_t)buf * stage_bytes + r * a.RS;
+            const unsigned char* rowb = smem + (size_t)buf * stage_bytes + WB + r * a.RS;
+            const double* wgl = reinterpret_cast<const double*>(smem + (size_t)buf * stage_bytes);   // WG: this block's weights by gene
+            if constexpr (FF) {
+                static_assert(!FF || (WG && MODE == FDX_PRE_RAW && JW <= 24), "flat form: raw mode, weights by gene, at most 24 groups per wave");
+                typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+                const unsigned short* so = off_l + ((size_t)(wave * a.NBLK + c) * 4 + q) * a.NSP;
+                const unsigned long long* gw = reinterpret_cast<const unsigned long long*>(len_tab + (size_t)(wave * a.NBLK + c) * a.GROW);   // scalar loads
+                const int ns_a = (int)(gw[0] & 0xffffULL), ns = (int)((gw[0] >> 16) & 0xffffULL);   // steps of groups 0..15, all steps
+                auto batch = [&](int k0, auto first_tag) {
+                    const uint4_t o = *reinterpret_cast<const uint4_t*>(so + k0);
+                    const unsigned long long g8 = gw[1 + (k0 >> 3)];        // the eight steps' groups
+                    double wv[8];
+                    T yv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned wd = o[u >> 1];
+                        const unsigned of = (u & 1) ? (wd >> 16) : (wd & 0xffffu);   // a padding step reads the padding offset: weight 0.0
+                        wv[u] = wgl[of];
+                        yv[u] = *reinterpret_cast<const T*>(rowb + (size_t)of * sizeof(T));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = (int)((g8 >> (8 * u)) & 0xffULL);
+                        if (decltype(first_tag)::value) accA[j] = fma(wv[u], (double)yv[u], accA[j]);
+                        else accB[j - 16] = fma(wv[u], (double)yv[u], accB[j - 16]);
+                    }
+                };
+                for (int k0 = 0; k0 < ns_a; k0 += 8) batch(k0, std::true_type{});
+                for (int k0 = ns_a; k0 < ns; k0 += 8) batch(k0, std::false_type{});
+                if (LAST) {
+#pragma unroll
+                    for (int j = 0; j < JW; ++j) {
+                        double an[TT];
+                        if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);    // at most four groups' operands in flight
+#pragma unroll
+                        for (int t = 0; t < TT; ++t) an[t] = AVL2 ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xu + (size_t)(j * TT + t) * 64) + lane8) : av[AVL2 ? 0 : j][t];
+                        const double sum = j < 16 ? accA[j < 16 ? j : 0] : accB[j < 16 ? 0 : j - 16];
+#pragma unroll
+                        for (int t = 0; t < TT; ++t) accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t], sum, accm[t], 0, 0, 0);
+                        sq = fma(sum, sum, sq);
+                    }
+                }
+            } else {
             int p = ent_base[wave * (a.NBLK + 1) + c] + q;
             const unsigned long long* lens = reinterpret_cast<const unsigned long long*>(len_tab + ((size_t)wave * a.NBLK + c) * JW_PAD(JW));
-            double wv = w_l[p];
-            T yv = *reinterpret_cast<const T*>(rowb + (size_t)off_l[p] * sizeof(T));
+            const unsigned off0 = off_l[p];
+            double wv = WG ? wgl[off0] : w_l[p];
+            T yv = *reinterpret_cast<const T*>(rowb + (size_t)off0 * sizeof(T));
             unsigned offn = off_l[p + 4];
             auto f = [&](T yy) -> double {
                 if (MODE == FDX_PRE_RAW) return (double)yy;
@@ -366,19 +448,19 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 }
                 int t = 0;
                 for (; t + 2 <= len; t += 2) {                            // two steps per trip: the register sets swap roles
-                    const double wb = w_l[p + 4];
+                    const double wb = WG ? wgl[offn] : w_l[p + 4];
                     const T yb = *reinterpret_cast<const T*>(rowb + (size_t)offn * sizeof(T));
                     const unsigned offb = off_l[p + 8];
                     acc[j] = fma(wv, f(yv), acc[j]);
                     p += 8;
-                    wv = w_l[p];
+                    wv = WG ? wgl[offb] : w_l[p];
                     yv = *reinterpret_cast<const T*>(rowb + (size_t)offb * sizeof(T));
                     offn = off_l[p + 4];
                     acc[j] = fma(wb, f(yb), acc[j]);
                 }
                 if (t < len) {
                     p += 4;
-                    const double wn = w_l[p];
+                    const double wn = WG ? wgl[offn] : w_l[p];
                     const T yn = *reinterpret_cast<const T*>(rowb + (size_t)offn * sizeof(T));
                     offn = off_l[p + 4];
                     acc[j] = fma(wv, f(yv), acc[j]);
@@ -392,6 +474,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                     sq = fma(acc[j], acc[j], sq);
                 }
             }
+        }
         };
         auto block = [&](int c, auto last_tag) {
             if (NWL == 0) __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): this wave's pieces of block c have landed
@@ -417,7 +500,7 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         constexpr bool INTERLEAVE = MODE == FDX_PRE_RAW;
         for (int c = 0; c + 1 < a.NBLK; ++c) block(c, std::false_type{});
         block(a.NBLK - 1, std::integral_constant<bool, INTERLEAVE>{});
-        if (!INTERLEAVE) {
+        if constexpr (!INTERLEAVE) {
 #pragma unroll
             for (int j = 0; j < JW; ++j) {
                 double an[TT];
@@ -486,6 +569,11 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                 row_sumsq[s0 + tid] = sum;
             }
         }
+        if (WG) {   // the sums were written over this buffer's row pads: zero them again before the next block lands here
+            lds_barrier();
+            if (tid < TILE_ROWS * 4)
+                *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(red) + WB + (tid >> 2) * a.RS + a.RS - TILE_ROW_PAD + (tid & 3) * 4) = 0u;
+        }
         // the first barrier of the next tile orders these reads before the next DMA into this buffer
     }
 }
@@ -496,6 +584,8 @@ struct TilePlanDevice {
     TilePlanHost h;
     DevBuf w, off, len, ent_base, slot_bucket;
     int NWC = 0, NWL = 0, JW = 0, RS = 0, TT = 0, NST = 2;
+    int WB = 0;          // WG form: bytes of a block's weights-by-gene table (w holds NBLK of them); 0 = per-entry weights
+    TileFlatHost fh;     // flat form (fh.NSP > 0): `off` holds fh.off, `len` holds fh.gid
     bool wide = false;
     size_t lds = 0;
 };
@@ -545,9 +635,10 @@ static TileCfg tile_cfg(int mode, int K, int d) {
     return c;
 }
 
-static size_t tile_lds_bytes(int RS, int NE, int mode, int NST = 2) {
+static size_t tile_lds_bytes(int RS, int NE, int mode, int NST = 2, int WB = 0) {
     const size_t NEp = ((size_t)NE + 7) & ~(size_t)7;
-    const size_t below = (size_t)NST * TILE_ROWS * RS + NEp * 10 + 2 * TILE_ROWS * (8 + 4);
+    // WB > 0 (WG form): weights by gene inside every stage buffer, the entry table holds the 2-byte offsets only
+    const size_t below = (size_t)NST * ((size_t)WB + (size_t)TILE_ROWS * RS) + NEp * (WB ? 2 : 10) + 2 * TILE_ROWS * (8 + 4);
     if (mode == FDX_PRE_RAW) return below;
     // log modes: the table has a fixed place at the top of the 160 KB (LOG_TAB_LDS); everything else must end below it
     return below <= (size_t)LOG_TAB_LDS ? (size_t)160 * 1024 : (size_t)161 * 1024;
@@ -565,13 +656,20 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     // Stage buffers: two.  FDX_TILE_NST=3 (raw mode with loader waves) makes it a ring of three - two column blocks in flight
     // while one is consumed, smaller blocks (2000 float32 genes: 3 x 704 instead of 2 x 1024).  Measured at 1M x 2000: 1.88-1.95
     // against 1.89-1.90 ms - the consumers' gather, not the bytes in flight, sets the block period; kept as a switch.
+    // The wide raw form keeps its weights by gene in the stage buffers (WG, see the kernel): 5 column blocks of 1024 genes instead
+    // of 7 of 736 at 5000 genes (one 1.25M x 5000 x 50 shard: 8.40 -> 8.05 ms).  FDX_TILE_NO_WG=1: the per-entry weight table.
+    // Measured on the same shard and NOT the default: the ring of three stage buffers on top of it (FDX_TILE_NST=3: 8 blocks of
+    // 672, 8.94 ms - more blocks, more lockstep padding, and the consumers, not the bytes in flight, set the block period) and the
+    // flat schedule (FDX_TILE_FLAT=1, see the kernel: 9.85 ms against 8.69 in the same process).
+    const bool wg = cfg.wide && mode == FDX_PRE_RAW && cfg.NWL > 0 && !getenv("FDX_TILE_NO_WG");
     int NST = 2;
     if (mode == FDX_PRE_RAW && cfg.NWL > 0) {
         const char* e = getenv("FDX_TILE_NST");
         NST = (e && atoi(e) == 3) ? 3 : 2;
     }
-    const int key = key0 + (NST == 3 ? 28 : 0);
-    static_assert(SketchPlan::kTileKeys == 56, "key space of the schedules");
+    const bool flat = wg && getenv("FDX_TILE_FLAT") && cfg.JW <= 24;
+    const int key = key0 + (NST == 3 ? 28 : 0) + (cfg.wide && mode == FDX_PRE_RAW && cfg.NWL > 0 && !wg ? 56 : 0) + (flat ? 112 : 0);
+    static_assert(SketchPlan::kTileKeys == 224, "key space of the schedules");
     std::lock_guard<std::mutex> lock(sp.tile_mu);
     if (sp.tile_tried[key]) return sp.tile[key].get();
     sp.tile_tried[key] = true;
@@ -585,17 +683,24 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     std::unique_ptr<TilePlanDevice> best;
     for (int GB = (int)round_up(sp.G, unit); GB >= unit; GB -= unit) {
         const int RS = GB * sz + TILE_ROW_PAD;
-        if ((size_t)TILE_ROWS * RS < red_bytes) break;
+        const int WB = wg ? (int)round_up((GB + 1) * 8, 16) : 0;
+        if ((size_t)WB + (size_t)TILE_ROWS * RS < red_bytes) break;
         // cheap bound before building: the tables hold at least G entries
         const int nst = (NST == 3 && GB < sp.G) ? 3 : 2;                     // one block per tile: the ring's look-ahead needs two
-        if (tile_lds_bytes(RS, sp.G, mode, nst) > 160 * 1024) continue;
+        if (tile_lds_bytes(RS, sp.G, mode, nst, WB) > 160 * 1024) continue;
         auto cand = std::make_unique<TilePlanDevice>();
         if (!build_tile_plan(sp.host_bucket.data(), sp.host_w.data(), sp.G, sp.d, cfg.NWC, cfg.JW, GB, &cand->h)) return nullptr;
         cand->NWC = cfg.NWC; cand->NWL = cfg.NWL; cand->JW = cfg.JW; cand->RS = RS; cand->TT = TT; cand->wide = cfg.wide;
+        cand->WB = WB;
         cand->NST = (nst == 3 && cand->h.NBLK >= 2) ? 3 : 2;
-        cand->lds = tile_lds_bytes(RS, cand->h.NE, mode, nst);
-        if (dbg) std::fprintf(stderr, "[fdx] tile plan: G=%d d=%d waves=%d+%d stages=%d GB=%d blocks=%d NE=%d steps=%d lds=%zu\n", sp.G, sp.d, cfg.NWC,
-                              cfg.NWL, cand->NST, GB, cand->h.NBLK, cand->h.NE, cand->h.steps, cand->lds);
+        int n_ent = cand->h.NE;
+        if (flat) {
+            if (!build_tile_flat(cand->h, GB, &cand->fh)) return nullptr;
+            n_ent = (int)cand->fh.off.size();
+        }
+        cand->lds = tile_lds_bytes(RS, n_ent, mode, nst, WB);
+        if (dbg) std::fprintf(stderr, "[fdx] tile plan: G=%d d=%d waves=%d+%d stages=%d GB=%d blocks=%d NE=%d steps=%d lds=%zu flat rows of %d\n", sp.G, sp.d, cfg.NWC,
+                              cfg.NWL, cand->NST, GB, cand->h.NBLK, cand->h.NE, cand->h.steps, cand->lds, cand->fh.NSP);
         if (cand->lds > 160 * 1024) continue;
         best = std::move(cand);
         break;
@@ -614,8 +719,20 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
         for (int c = 0; c < t.h.NBLK; ++c)
             for (int j = 0; j < t.JW; ++j)
                 len_pad[((size_t)wv * t.h.NBLK + c) * jp + j] = t.h.len[((size_t)wv * t.h.NBLK + c) * t.JW + j];
-    if (up(t.w, t.h.w.data(), t.h.w.size() * 8) || up(t.off, t.h.off.data(), t.h.off.size() * 2) ||
-        up(t.len, len_pad.data(), len_pad.size()) || up(t.ent_base, t.h.ent_base.data(), t.h.ent_base.size() * 4) ||
+    std::vector<double> wg_tab;
+    if (t.WB) {
+        // weights by gene, one table of WB bytes per column block ((GB + 1) doubles: entry GB stays 0.0); the padding steps of the
+        // schedule (no gene) point at entry GB - weight 0.0 times the zeroed pad behind the staged row
+        const int per = t.WB / 8;
+        wg_tab.assign((size_t)t.h.NBLK * per, 0.0);
+        for (int g = 0; g < sp.G; ++g)
+            if (sp.host_bucket[(size_t)g] >= 0) wg_tab[(size_t)(g / t.h.GB) * per + g % t.h.GB] = sp.host_w[(size_t)g];
+        for (size_t i = 0; i < t.h.off.size(); ++i)
+            if (t.h.gene[i] < 0) t.h.off[i] = (unsigned short)t.h.GB;
+    }
+    if ((t.WB ? up(t.w, wg_tab.data(), wg_tab.size() * 8) : up(t.w, t.h.w.data(), t.h.w.size() * 8)) ||
+        (t.fh.NSP > 0 ? up(t.off, t.fh.off.data(), t.fh.off.size() * 2) : up(t.off, t.h.off.data(), t.h.off.size() * 2)) ||
+        (t.fh.NSP > 0 ? up(t.len, t.fh.gid.data(), t.fh.gid.size()) : up(t.len, len_pad.data(), len_pad.size())) || up(t.ent_base, t.h.ent_base.data(), t.h.ent_base.size() * 4) ||
         up(t.slot_bucket, t.h.slot_bucket.data(), t.h.slot_bucket.size() * 4))
         return nullptr;
     if (hipStreamSynchronize(st) != hipSuccess) return nullptr;            // the host vectors may die with the plan
@@ -662,6 +779,7 @@ struct TileLaunch {
     const int* slot_bucket;
     const double* log_tab;
     const double* XA;
+    bool flat = false;   // the flat schedule (FF)
 };
 
 static thread_local bool t_f64_math = false;
@@ -703,6 +821,10 @@ static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hip
 template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_wide(const TileLaunch& L, size_t lds, int grid, hipStream_t st) {
     const void* kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true>;
+    if constexpr (MODE == FDX_PRE_RAW && NWL > 0) {
+        if (L.a.WB) kern = L.flat ? (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true, 0, true, true>
+                                  : (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true, 0, true>;
+    }
     if constexpr (MODE != FDX_PRE_RAW && std::is_same<T, float>::value) {
         if (tile_logv() != 0) kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true, 2>;
     }
@@ -746,7 +868,12 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     TileLaunch L{};
     TileArgs& a = L.a;
     a.ldy = ldy; a.n = n; a.ldh = ldh; a.G = G; a.d = d; a.K = K;
-    a.NE = t->h.NE; a.GB = t->h.GB; a.NBLK = t->h.NBLK; a.RS = t->RS; a.jw_used = t->h.jw_used; a.NST = t->NST;
+    a.NE = t->h.NE; a.GB = t->h.GB; a.NBLK = t->h.NBLK; a.RS = t->RS; a.jw_used = t->h.jw_used; a.NST = t->NST; a.WB = t->WB;
+    if (t->fh.NSP > 0) {
+        a.NE = (int)t->fh.off.size();
+        a.NSP = t->fh.NSP; a.GROW = t->fh.GROW;
+        L.flat = true;
+    }
     L.Y = Y; L.row_map = row_map; L.Xs = Xs; L.H = H; L.row_sumsq = row_sumsq;
     L.w_tab = t->w.as<double>(); L.off_tab = t->off.as<unsigned short>(); L.len_tab = t->len.as<unsigned char>();
     L.ent_base = t->ent_base.as<int>(); L.slot_bucket = t->slot_bucket.as<int>();

@@ -140,4 +140,53 @@ bool build_tile_plan(const int* gene_bucket, const double* gene_w, int G, int d,
     return true;
 }
 
+bool build_tile_flat(const TilePlanHost& p, int pad_off, TileFlatHost* out) {
+    if (p.NW <= 0 || p.JW <= 0 || p.JW > 24 || p.NBLK <= 0 || pad_off < 0 || pad_off > 65535) return false;
+    TileFlatHost& t = *out;
+    t = TileFlatHost();
+    const int NW = p.NW, JW = p.JW, NBLK = p.NBLK;
+    // steps of a (wave, block): the groups below 16 first, padded to a multiple of 8 (the kernel serves 8 steps at a time and keeps
+    // the sums of groups 0..15 and 16..23 in two register vectors, one of them indexed per phase), then the others, padded likewise
+    auto phase_steps = [&](int w, int c, int j0, int j1) {
+        int ns = 0;
+        for (int j = j0; j < std::min(j1, JW); ++j) ns += p.len[((size_t)w * NBLK + c) * JW + j];
+        return ns;
+    };
+    int ns_max = 0;
+    for (int w = 0; w < NW; ++w)
+        for (int c = 0; c < NBLK; ++c)
+            ns_max = std::max(ns_max, ((phase_steps(w, c, 0, 16) + 7) & ~7) + ((phase_steps(w, c, 16, 24) + 7) & ~7));
+    if (ns_max > 65535) return false;
+    t.NSP = std::max(8, ns_max);
+    t.GROW = 8 + t.NSP;
+    t.off.assign((size_t)NW * NBLK * 4 * t.NSP, (unsigned short)pad_off);
+    t.gid.assign((size_t)NW * NBLK * t.GROW, 0);
+    for (int w = 0; w < NW; ++w)
+        for (int c = 0; c < NBLK; ++c) {
+            unsigned char* g = &t.gid[((size_t)w * NBLK + c) * t.GROW];
+            const int e0 = p.ent_base[(size_t)w * (NBLK + 1) + c];
+            int k = 0, e = 0, n_a = 0;
+            for (int ph = 0; ph < 2; ++ph) {
+                int last = ph * 16;
+                for (int j = ph * 16; j < std::min(ph * 16 + (ph ? 8 : 16), JW); ++j) {
+                    const int L = p.len[((size_t)w * NBLK + c) * JW + j];
+                    for (int s = 0; s < L; ++s, ++k, ++e) {
+                        for (int q = 0; q < 4; ++q) {
+                            const size_t en = (size_t)e0 + (size_t)e * 4 + q;
+                            t.off[(((size_t)w * NBLK + c) * 4 + q) * t.NSP + k] = p.gene[en] < 0 ? (unsigned short)pad_off : p.off[en];
+                        }
+                        g[8 + k] = (unsigned char)j;
+                        last = j;
+                    }
+                }
+                for (; k & 7; ++k) g[8 + k] = (unsigned char)last;      // padding steps: weight 0.0 into a group of this phase
+                if (ph == 0) n_a = k;
+            }
+            if (e0 + e * 4 != p.ent_base[(size_t)w * (NBLK + 1) + c + 1]) return false;   // the entry stream is exactly these steps
+            g[0] = (unsigned char)(n_a & 0xff); g[1] = (unsigned char)(n_a >> 8);          // steps of phase A (groups 0..15)
+            g[2] = (unsigned char)(k & 0xff);   g[3] = (unsigned char)(k >> 8);            // all steps
+        }
+    return true;
+}
+
 }  // namespace fdx

@@ -25,6 +25,18 @@ struct TilePlanHost {
     std::vector<int> gene;                   // (NE): the gene of the entry, -1 for padding entries
 };
 
+// Flat form of the same schedule (tile_kernels.cpp, FF): the steps of a (wave, block) in the dynamic form's order - group by
+// group, genes ascending - as one stream: off[(w, c, q)][k] the offset lane class q reads in step k (pad_off past the last step
+// and for a lockstep padding slot), gid[(w, c)][k] the group step k adds to.
+struct TileFlatHost {
+    int NSP = 0;                                 // steps per (wave, block), rounded up to 8 (rows of `off`)
+    int GROW = 0;                                // bytes per (wave, block) row of `gid`: 8 (the step count, little endian) + NSP
+    std::vector<unsigned short> off;             // (NW, NBLK, 4, NSP)
+    std::vector<unsigned char> gid;              // (NW, NBLK, GROW): [0..1] steps of the groups below 16 (a multiple of 8: they come first), [2..3] all steps (likewise), [8 + k] group of step k
+};
+// `plan` from build_tile_plan; pad_off: the offset a padding slot reads (the kernel keeps weight 0.0 there).
+bool build_tile_flat(const TilePlanHost& plan, int pad_off, TileFlatHost* out);
+
 // gene_bucket[g] in [0, d) or -1 (gene not in Omega), gene_w[g] its weight.  GB = genes per column block (the last block
 // may be shorter).  Returns false when the shape cannot be scheduled (more than 4*NW*JW buckets, a group longer than 255).
 bool build_tile_plan(const int* gene_bucket, const double* gene_w, int G, int d, int NW, int JW, int GB, TilePlanHost* out);

@@ -329,13 +329,39 @@ class ShardedFlashDeconv:
         h = ctypes.c_void_p()
         self.bounds = shard_bounds(n, self.comm.world)
         k = int(self.k_neighbors)
-        if self.spatial_method == "knn" and self.comm.world > 1 and n >= 2 and k >= 1:
-            # sharded build: own k-NN lists -> all-gather of the list rows -> own rows of the symmetrised graph
+        sharded_knn = self.spatial_method == "knn" and self.comm.world > 1 and n >= 2 and k >= 1
+        self.plan_route_ = None
+        if sharded_knn:
             lo, hi = int(self.bounds[self.comm.rank]), int(self.bounds[self.comm.rank + 1])
             kk = min(k, n - 1) + 1
             nbr = torch.empty((n, kk), dtype=torch.int32, device=coords.device)
             cnt = torch.empty((n,), dtype=torch.int32, device=coords.device)
             plan = ctypes.c_void_p()
+            if not os.environ.get("FDX_PLAN_ALLGATHER"):
+                # Band recompute ("recompute, don't communicate"): the lists of the own rows AND of the rows in the grid
+                # cells next to an own cell, which are all the rows that can point at an own row while every k-NN walk stays inside
+                # its 3 x 3 block of cells - own rows of the symmetrised graph without moving a list (include/fdx.h).  Each rank
+                # checks the condition for its own rows; the flag rides in the all-reduce of the edge counts.
+                self.plan_route_ = "band"
+                _lib.check(lib.fdx_graph_knn_lists_band_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, lo, hi,
+                                                            ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), st,
+                                                            ctypes.byref(plan)))
+                t0 = self._tick("plan_knn", t0)
+                _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi,
+                                                            st, ctypes.byref(h)))
+                self._full = _lib.Graph(h.value)
+                own = torch.tensor([float(self._full.info()[1]), float(self._full.knn_ties()), float(self._full.knn_far())],
+                                   dtype=torch.float64, device=coords.device)
+                self.comm.all_reduce_sum(own)
+                tot = own.cpu().numpy()
+                if tot[2] == 0:
+                    self.nnz_total, self.knn_ties_ = int(round(float(tot[0]))), int(round(float(tot[1])))
+                else:       # some rank's walk left its block (very uneven density) or a band list overflowed: exchange the lists
+                    self._full.close()
+                    self._full, h, plan = None, ctypes.c_void_p(), ctypes.c_void_p()
+        if sharded_knn and self._full is None:
+            # sharded build by exchange: own k-NN lists -> all-gather of the list rows -> own rows of the symmetrised graph
+            self.plan_route_ = "allgather"
             _lib.check(lib.fdx_graph_knn_lists_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, lo, hi,
                                                    ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), st,
                                                    ctypes.byref(plan)))
@@ -362,7 +388,7 @@ class ShardedFlashDeconv:
             self.comm.all_reduce_sum(own_nnz)
             tot = own_nnz.cpu().numpy()
             self.nnz_total, self.knn_ties_ = int(round(float(tot[0]))), int(round(float(tot[1])))
-        else:
+        elif not sharded_knn:
             # "radius" / "grid" resolve their radius exactly as FlashDeconv does (utils/graph.py:163-212)
             method, gk, gradius = self._proto._graph_request(coords, None)
             if method == _lib.GRAPH_RADIUS and self.comm.world > 1 and n >= 2:

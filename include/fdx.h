@@ -208,6 +208,11 @@ typedef struct fdx_fit_info {
     double YtY;
     int64_t nnz;             /* structural non-zeros of the adjacency */
     double graph_ms, sketch_ms, gram_ms, solve_ms, finish_ms, total_ms;   /* hipEvent stage timings */
+    /* contiguous device intervals: prologue_ms runs from the first kernel of the graph build (the event fdx_graph_build_dev
+     * records at its top, when the graph was built on this stream; otherwise from the top of this call) to the start of the
+     * sketch stage; span_ms from that same point to the end of the export, so that
+     * prologue_ms + (sketch stage) + solve_ms + finish_ms = span_ms up to event granularity */
+    double prologue_ms, span_ms;
 } fdx_fit_info;
 
 /* Device-resident fit.  Y_dev: (n, G) matrix of `y_dtype` on the device, row stride ldy elements.  X: HOST (K, G)
@@ -292,6 +297,17 @@ int fdx_graph_knn_lists_dev(const double* coords_dev, int64_t n, int32_t dim, in
                             int32_t* nbr_dev, int32_t* cnt_dev, void* stream, fdx_graph_plan** plan);
 int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, const int32_t* cnt_dev, int64_t lo, int64_t hi,
                                  void* stream, fdx_graph** out);
+/* Phase 1 WITHOUT the exchange ("recompute, don't communicate"): besides the lists of rows [lo, hi) the rank finds the lists of
+ * its BAND - the rows outside [lo, hi) that live in grid cells within two cells of a cell holding an own row - and marks every
+ * other row of cnt_dev empty.  A row whose k-NN walk stayed within two shells of its own cell (at ~4 points per cell: all but
+ * freak rows) can only point at rows at most two cells away, so the band holds every row that can point at an own row, and
+ * fdx_graph_from_knn_lists_dev (called directly, step 2 skipped) yields the same rows [lo, hi) bit for bit.  The condition is
+ * checked where it can be: every rank reports through fdx_graph_knn_far() of the graph it built whether a walk of one of its
+ * OWN rows went further (or its band list overflowed); if any rank reports it (one integer more in the all-reduce of the edge
+ * counts), the ranks rebuild by the three steps above.  Cost: own rows + band, plus one 4-byte fill per spot. */
+int fdx_graph_knn_lists_band_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t k, int64_t lo, int64_t hi,
+                                 int32_t* nbr_dev, int32_t* cnt_dev, void* stream, fdx_graph_plan** plan);
+int fdx_graph_knn_far(const fdx_graph* g, int32_t* far);
 /* perm_out_dev[p] = caller's spot id at solver position p (int32, n entries, device). */
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
 /* Shard of a full graph for rank `my_rank`: own spots are solver positions [bounds[my_rank], bounds[my_rank+1])
@@ -351,6 +367,12 @@ typedef struct fdx_local_world fdx_local_world;
 int fdx_comm_unique_id(void* id_out_128);
 int fdx_comm_init(const void* id_128, int32_t rank, int32_t world, fdx_comm** out);
 int fdx_local_world_create(int32_t world, fdx_local_world** out);
+/* One rank of a `world`-rank job ALONE: fdx_sharded_solve_dev runs its complete loop (boundary tiles, pack, interior tiles
+ * beside the copy, unpack, stopping rule, chunked read-backs) with the exchange replaced by a device copy of the rank's own
+ * staging and no all-reduce - the time of a rank's critical path without wire time (bench.py --virtual-ranks: the projected
+ * speed-up of a job this build could not run on N GPUs).  The halo values are NOT those of the job: results are meaningless,
+ * run it with tol = 0 and max_iter = the iteration count of the real solve. */
+int fdx_comm_init_loopback(int32_t rank, int32_t world, fdx_comm** out);
 int fdx_local_world_destroy(fdx_local_world* w);
 int fdx_comm_init_local(fdx_local_world* w, int32_t rank, fdx_comm** out);
 int fdx_comm_destroy(fdx_comm* comm);

@@ -21,7 +21,7 @@ def _st(torch):
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("build", ["replicated", "sharded"])
+@pytest.mark.parametrize("build", ["replicated", "sharded", "band"])
 @pytest.mark.parametrize("W", [2, 3, 5])
 def test_virtual_ranks_equal_single_gpu(W, build):
     import torch
@@ -52,27 +52,34 @@ def test_virtual_ranks_equal_single_gpu(W, build):
         nbrs = [torch.full((n, kk), -7, dtype=torch.int32, device=dev) for _ in range(W)]
         cnts = [torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(W)]
         plans = []
+        lists = lib.fdx_graph_knn_lists_band_dev if build == "band" else lib.fdx_graph_knn_lists_dev
         for r in range(W):
             pl = ctypes.c_void_p()
-            _lib.check(lib.fdx_graph_knn_lists_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, 6, int(bounds[r]), int(bounds[r + 1]),
-                                                   ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()),
-                                                   _st(torch), ctypes.byref(pl)))
+            _lib.check(lists(ctypes.c_void_p(cd.data_ptr()), n, 2, 6, int(bounds[r]), int(bounds[r + 1]),
+                             ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()), _st(torch), ctypes.byref(pl)))
             plans.append(pl)
+        if build == "band":
+            # band recompute: nothing is exchanged - every rank found the lists of the rows that can point at its own rows itself
+            for r in range(W):
+                a, b = int(bounds[r]), int(bounds[r + 1])
+                n_lists = int((cnts[r] > 0).sum())
+                assert b - a <= n_lists < (b - a) + 0.35 * n, (r, n_lists)          # own rows + a band, not the whole graph
         for r in range(W):
             for q in range(W):
-                if q != r:
+                if q != r and build != "band":
                     a, b = int(bounds[q]), int(bounds[q + 1])
                     nbrs[r][a:b] = nbrs[q][a:b]
                     cnts[r][a:b] = cnts[q][a:b]
         fulls, nnz_sum = [], 0
         for r in range(W):
-            assert int(cnts[r].min()) >= 0 and int(nbrs[r].min()) >= -1
+            assert int(cnts[r].min()) >= 0 and (build == "band" or int(nbrs[r].min()) >= -1)    # band: rows without a list are never read
             h = ctypes.c_void_p()
             _lib.check(lib.fdx_graph_from_knn_lists_dev(plans[r], ctypes.c_void_p(nbrs[r].data_ptr()),
                                                         ctypes.c_void_p(cnts[r].data_ptr()), int(bounds[r]), int(bounds[r + 1]),
                                                         _st(torch), ctypes.byref(h)))
             fulls.append(_lib.Graph(h.value))
             nnz_sum += fulls[-1].info()[1]
+            assert fulls[-1].knn_far() == 0                  # uniform density: no walk left its 3 x 3 block of cells
         assert nnz_sum == ref.adjacency_.nnz
     lev = compute_leverage_scores(X)
     bucket, weight = countsketch_tables(G, d, lev, 0)
@@ -149,6 +156,61 @@ def test_virtual_ranks_equal_single_gpu(W, build):
         beta[R["own"]] = out
     torch.cuda.synchronize()
     assert np.array_equal(beta.cpu().numpy(), ref.beta_)
+
+
+def test_band_recompute_reports_walks_that_leave_their_block():
+    """Very uneven density (two tight clusters and a few stragglers far away): the stragglers' k-NN walks leave the 3 x 3 block of
+    grid cells, the rank that owns them says so (fdx_graph_knn_far), and the driver then builds by exchanging the lists - whose
+    result is the reference's graph."""
+    import torch
+    import fdx_oracle as orc
+    from flashdeconv_amd import _lib
+    from flashdeconv_amd.distributed import shard_bounds
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(3)
+    pts = np.concatenate([rs.rand(1500, 2) * 0.05, rs.rand(1500, 2) * 0.05 + 10.0, rs.rand(12, 2) * 10.0])
+    n = len(pts)
+    cd = torch.from_numpy(np.ascontiguousarray(pts)).to(dev)
+    W, kk = 3, 7
+    bounds = shard_bounds(n, W)
+    far, graphs = 0, []
+    nbrs = [torch.full((n, kk), -7, dtype=torch.int32, device=dev) for _ in range(W)]
+    cnts = [torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(W)]
+    for r in range(W):
+        pl, h = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_knn_lists_band_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, 6, int(bounds[r]), int(bounds[r + 1]),
+                                                    ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()), _st(torch),
+                                                    ctypes.byref(pl)))
+        _lib.check(lib.fdx_graph_from_knn_lists_dev(pl, ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()),
+                                                    int(bounds[r]), int(bounds[r + 1]), _st(torch), ctypes.byref(h)))
+        g = _lib.Graph(h.value)
+        far += g.knn_far()
+        g.close()
+    assert far > 0
+    # the exchange route on the same points
+    plans = []
+    for r in range(W):
+        pl = ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_knn_lists_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, 6, int(bounds[r]), int(bounds[r + 1]),
+                                               ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()), _st(torch),
+                                               ctypes.byref(pl)))
+        plans.append(pl)
+    for r in range(W):
+        for q in range(W):
+            if q != r:
+                a, b = int(bounds[q]), int(bounds[q + 1])
+                nbrs[r][a:b] = nbrs[q][a:b]
+                cnts[r][a:b] = cnts[q][a:b]
+    nnz = 0
+    for r in range(W):
+        h = ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_from_knn_lists_dev(plans[r], ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()),
+                                                    int(bounds[r]), int(bounds[r + 1]), _st(torch), ctypes.byref(h)))
+        g = _lib.Graph(h.value)
+        nnz += g.info()[1]
+        g.close()
+    assert nnz == orc.knn_graph_kdtree(pts, 6).nnz
 
 
 def test_sharded_class_world1_equals_flashdeconv():

@@ -462,3 +462,28 @@ def test_wide_tile_kernel_matches_the_two_kernel_path_and_the_oracle(n, G, K, d,
     tol_paths = 1e-11 if dtype == np.float64 or mode != "log_cpm" else 1e-5
     assert rel_fro(a.beta_, b.beta_) < tol_paths
     assert rel_fro(a.proportions_, b.proportions_) < tol_paths
+    if mode == "raw":
+        # the layouts of the wide raw form: weights by gene (default) - also in a ring of three stage buffers and with the flat
+        # schedule (dynamically indexed accumulator vectors) - and the per-entry weight table of round 2: other block boundaries,
+        # the same sums per bucket.  The plan cache is keyed by content, not by these switches: bypass it.
+        monkeypatch.setenv("FDX_NO_PLAN_CACHE", "1")
+        monkeypatch.delenv("FDX_NO_TILE_WIDE")
+        for env in (dict(FDX_TILE_NST="3"), dict(FDX_TILE_FLAT="1"), dict(FDX_TILE_FLAT="1", FDX_TILE_NST="3"), dict(FDX_TILE_NO_WG="1"),
+                    dict(FDX_TILE_NO_WG="1", FDX_TILE_NST="3")):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            c = FlashDeconv(**kw).fit(Y, X, coords)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert c.info_["n_iterations"] == a.info_["n_iterations"], env
+            assert rel_fro(a.beta_, c.beta_) < 1e-12, env
+        # a NaN and a negative entry: only the buckets of those genes may differ from the two-kernel path
+        Yb = Y.copy()
+        Yb[5, 17] = np.nan
+        Yb[n - 1, G - 1] = -3.0
+        a2 = FlashDeconv(**kw).fit(Yb, X, coords)
+        monkeypatch.setenv("FDX_NO_TILE_WIDE", "1")
+        b2 = FlashDeconv(**kw).fit(Yb, X, coords)
+        fin = np.isfinite(b2.beta_)
+        assert np.array_equal(np.isfinite(a2.beta_), fin)
+        assert rel_fro(a2.beta_[fin], b2.beta_[fin]) < 1e-9

@@ -75,9 +75,12 @@ def morton_sorted_coords(torch, coords, k=6):
     return coords[perm.long()].contiguous()
 
 
-def virtual_plan(torch, coords, W, k=6, times=None):
+def virtual_plan(torch, coords, W, k=6, times=None, route=None):
     """The sharded k-NN plan of flashdeconv_amd/distributed.py with W ranks in one process.  Returns the W local graphs
-    (with their bookkeeping) and the global structural nnz."""
+    (with their bookkeeping) and the global structural nnz.  route "band" (default; FDX_PLAN_ALLGATHER=1 selects "allgather"):
+    every rank finds the lists of its own rows and of its band and symmetrises - nothing is exchanged; "allgather": the lists
+    of the own rows, all-gathered (here W^2 device copies)."""
+    route = route or ("allgather" if os.environ.get("FDX_PLAN_ALLGATHER") else "band")
     from flashdeconv_amd import _lib
     from flashdeconv_amd.distributed import shard_bounds
     lib = _lib.load()
@@ -94,21 +97,23 @@ def virtual_plan(torch, coords, W, k=6, times=None):
     for r in range(W):                          # every rank: bin ALL points, lists of its own rows
         t0 = t()
         pl = ctypes.c_void_p()
-        _lib.check(lib.fdx_graph_knn_lists_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, int(bounds[r]), int(bounds[r + 1]),
-                                               ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()),
-                                               _st(torch), ctypes.byref(pl)))
+        lists = lib.fdx_graph_knn_lists_band_dev if route == "band" else lib.fdx_graph_knn_lists_dev
+        _lib.check(lists(ctypes.c_void_p(coords.data_ptr()), n, dim, k, int(bounds[r]), int(bounds[r + 1]),
+                         ctypes.c_void_p(nbrs[r].data_ptr()), ctypes.c_void_p(cnts[r].data_ptr()), _st(torch), ctypes.byref(pl)))
         plans.append(pl)
         times["knn_lists_ms"].append((t() - t0) * 1e3)
-    t0 = t()
-    for r in range(W):                          # the one exchange step of the build: all-gather of the list rows
-        for q in range(W):
-            if q != r:
-                a, b = int(bounds[q]), int(bounds[q + 1])
-                nbrs[r][a:b] = nbrs[q][a:b]
-                cnts[r][a:b] = cnts[q][a:b]
-    times["allgather_ms"] = (t() - t0) * 1e3
-    times["allgather_bytes_per_rank"] = int(n * (kk + 1) * 4)
-    ranks, nnz, ties = [], 0, 0
+    times["plan_route"] = route
+    if route != "band":
+        t0 = t()
+        for r in range(W):                      # the one exchange step of the build: all-gather of the list rows
+            for q in range(W):
+                if q != r:
+                    a, b = int(bounds[q]), int(bounds[q + 1])
+                    nbrs[r][a:b] = nbrs[q][a:b]
+                    cnts[r][a:b] = cnts[q][a:b]
+        times["allgather_ms"] = (t() - t0) * 1e3
+        times["allgather_bytes_per_rank"] = int(n * (kk + 1) * 4)
+    ranks, nnz, ties, far = [], 0, 0, 0
     times["from_lists_ms"], times["localize_ms"] = [], []
     for r in range(W):
         t0 = t()
@@ -118,6 +123,7 @@ def virtual_plan(torch, coords, W, k=6, times=None):
         full = _lib.Graph(h.value)
         nnz += full.info()[1]
         ties += full.knn_ties()
+        far += full.knn_far()
         t1 = t()
         nbrs[r] = cnts[r] = None
         hl = ctypes.c_void_p()
@@ -135,6 +141,10 @@ def virtual_plan(torch, coords, W, k=6, times=None):
         times["localize_ms"].append((t2 - t1) * 1e3)
         ranks.append(dict(g=g, own=perm[:n_own].long(), n_own=n_own, n_halo=int(nh.value), lo=int(bounds[r]), hi=int(bounds[r + 1]),
                           send=sc, recv=rc))
+    if route == "band" and far:                 # a walk left its block / a band overflowed: the drivers rebuild by exchange
+        for R in ranks:
+            R["g"].close()
+        return virtual_plan(torch, coords, W, k, times, route="allgather")
     for r in range(W):                          # what r sends to q is what q expects from r
         for q in range(W):
             assert ranks[r]["send"][q] == ranks[q]["recv"][r]
@@ -237,6 +247,46 @@ def virtual_solve(torch, ranks, K, lam, rho_eff, tol, max_iter, times=None):
     return results
 
 
+def alone_solve_and_finish(torch, ranks, K, lam, rho_eff, n_iter, times):
+    """Every rank's iteration loop and finish ALONE on the GPU (fdx_comm_init_loopback: the exchange is a copy of the rank's own
+    staging, no all-reduce), n_iter iterations as in the real solve, on scratch abundance buffers: the kernel / launch / read-back
+    time of a rank's critical path - no wire time, no waiting for peers.  Then the finish: objective partials + export."""
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    W = len(ranks)
+    t = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
+    times["solve_alone_ms"], times["finish_alone_ms"] = [], []
+    for r, S in enumerate(ranks):
+        dev = S["H"].device
+        bufs = [torch.empty((K, S["ld"]), dtype=torch.float64, device=dev) for _ in range(2)]
+        comm = ctypes.c_void_p()
+        _lib.check(lib.fdx_comm_init_loopback(r, W, ctypes.byref(comm)))
+        info, which, rel = _lib.SolveInfo(), ctypes.c_int32(0), np.zeros(max(n_iter, 1))
+        best = None
+        for rep in range(2):                                                  # second run: warm (tile lists built, pool filled)
+            t0 = t()
+            _lib.check(lib.fdx_sharded_solve_dev(comm, S["g"].handle, ctypes.c_void_p(S["H"].data_ptr()), S["ld"],
+                                                 ctypes.c_void_p(S["XtX"].data_ptr()), K, lam, rho_eff, 0.0, n_iter,
+                                                 ctypes.c_void_p(bufs[0].data_ptr()), ctypes.c_void_p(bufs[1].data_ptr()), S["ld"],
+                                                 ctypes.byref(info), _lib.ptr_f64(rel), ctypes.byref(which), _st(torch)))
+            best = (t() - t0) * 1e3
+        lib.fdx_comm_destroy(comm)
+        times["solve_alone_ms"].append(best)
+        b = torch.empty((S["n_own"], K), dtype=torch.float64, device=dev)
+        p = torch.empty((S["n_own"], K), dtype=torch.float64, device=dev)
+        part = np.zeros(4)
+        for rep in range(2):
+            t0 = t()
+            _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(S["beta"][0].data_ptr()), S["ld"], S["n_own"], K, ctypes.c_void_p(b.data_ptr()),
+                                             ctypes.c_void_p(p.data_ptr()), _st(torch)))
+            _lib.check(lib.fdx_objective_partials_dev(S["g"].handle, ctypes.c_void_p(S["beta"][0].data_ptr()), S["ld"],
+                                                      ctypes.c_void_p(S["H"].data_ptr()), S["ld"], ctypes.c_void_p(S["XtX"].data_ptr()), K,
+                                                      _lib.ptr_f64(part), _st(torch)))
+            best = (t() - t0) * 1e3
+        times["finish_alone_ms"].append(best)
+        del bufs, b, p
+
+
 def assemble(torch, ranks, results, n, K, want_props=True):
     """(beta, proportions) of all spots, (n, K) row-major in the caller's order, through fdx_normalize_dev per rank."""
     from flashdeconv_amd import _lib
@@ -257,8 +307,10 @@ def assemble(torch, ranks, results, n, K, want_props=True):
     return beta, prop
 
 
-def run_config5(torch, W, n=10_000_000, G=5000, K=50, d=1024, seed=11, max_iter=100, tol=1e-4, coords=None, keep=None):
-    """The whole configs[4] job with W virtual ranks; returns (beta, proportions, info dict with per-rank stage times)."""
+def run_config5(torch, W, n=10_000_000, G=5000, K=50, d=1024, seed=11, max_iter=100, tol=1e-4, coords=None, keep=None, alone=False):
+    """The whole configs[4] job (or, with other n / G / K / d, configs[3]) with W virtual ranks; returns (beta, proportions, info
+    dict with per-rank stage times).  alone=True: also every rank's iteration loop and finish timed alone (loopback transport) and
+    `per_rank_critical_path_ms` = plan (lists + band + symmetrise) + localize + prepare + solve + finish of each rank."""
     from flashdeconv_amd import _lib
     from flashdeconv_amd.distributed import diag_mean
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -281,6 +333,11 @@ def run_config5(torch, W, n=10_000_000, G=5000, K=50, d=1024, seed=11, max_iter=
     rho_eff = 0.01 * gmean                                       # core/solver.py:359-360
     results = virtual_solve(torch, ranks, K, lam, rho_eff, tol, max_iter, times)
     beta, prop = assemble(torch, ranks, results, n, K)
+    if alone:
+        alone_solve_and_finish(torch, ranks, K, lam, rho_eff, results[0]["n_iterations"], times)
+        times["per_rank_critical_path_ms"] = [times["knn_lists_ms"][r] + times["from_lists_ms"][r] + times["localize_ms"][r] +
+                                              times["prepare_ms"][r] + times["solve_alone_ms"][r] + times["finish_alone_ms"][r]
+                                              for r in range(W)]
     info = dict(n=n, G=G, K=K, d=d, world=W, nnz=nnz, knn_ties=ties, lambda_used=lam, rho_eff=rho_eff, YtY=yty,
                 n_iterations=[r["n_iterations"] for r in results], converged=[r["converged"] for r in results],
                 final_change=[r["final_change"] for r in results], n_own=[R["n_own"] for R in ranks],
