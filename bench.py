@@ -313,7 +313,7 @@ def main():
             for R in keep["ranks"]:
                 R["g"].close()
             del keep
-            torch.cuda.empty_cache()
+        torch.cuda.empty_cache()                     # only now: between the passes the freed blocks stay with torch's allocator, as in a job that fits twice
         t = info["times"]
         crit = t["per_rank_critical_path_ms"]
         # T1: the SAME job (same coordinates, same rows: generated chunk by chunk from the same seeds) unsharded on this GPU

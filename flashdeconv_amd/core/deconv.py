@@ -179,8 +179,8 @@ class FlashDeconv:
             raise ValueError(f"Unknown method: {self.spatial_method}")
         if len(coords.shape) != 2 or coords.shape[1] == 0:
             raise ValueError(f"coords must be 2D with at least 1 coordinate dimension, got shape {tuple(coords.shape)}")
-        if coords.shape[1] > 3:
-            raise NotImplementedError("flashdeconv_amd builds spatial graphs for 1-, 2- or 3-dimensional coordinates")
+        from ..utils.graph import check_coord_dims
+        check_coord_dims(int(coords.shape[0]), int(coords.shape[1]), self.spatial_method == "knn")
         _lib.require_gpu()
         lib = _lib.load()
         log = print if self.verbose else (lambda *a, **k: None)

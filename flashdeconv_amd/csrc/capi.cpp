@@ -167,7 +167,7 @@ int fdx_graph_from_csr(const int64_t* indptr, const int64_t* indices, int64_t n,
 }
 
 static int upload_coords(const double* coords, int64_t n, int32_t dim, DevBuf* d) {
-    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
+    FDX_REQUIRE(dim >= 1 && dim <= 8, "graph: coordinate dimension must be 1 to 8 (radius / grid graphs: 1 to 3)");
     FDX_REQUIRE(n >= 0, "graph: negative n");
     FDX_REQUIRE(n == 0 || coords != nullptr, "graph: null coords");
     FDX_TRY(d->alloc((size_t)n * dim * sizeof(double)));

@@ -381,8 +381,11 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
                                  void* stream) {
     FDX_REQUIRE(c && g && H_dev && XtX_dev && beta0_dev && beta1_dev && info && result_buffer, "fdx_sharded_solve_dev: null argument");
     FDX_TRY(fdx::graph_meta_sync(g));
-    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_PAD && sweep_instantiated(K) && K_real >= 1 && K_real <= K,
-                "fdx_sharded_solve_dev: K must be in 1..64, or fdx_solver_padded_k of 65..96 cell types, on the sharded path");
+    // 1..64 types and the padded sizes 72 / 80 / 88 / 96 run the tiled register sweeps (boundary tiles first, halo traffic beside the
+    // interior tiles); above that the LDS-resident sweep (to ~270 types) or the generic one takes the whole shard in one launch per
+    // iteration, the exchange behind it - no tile lists there, nothing to overlap with
+    FDX_REQUIRE(K >= 1 && K_real >= 1 && K_real <= K && (sweep_instantiated(K) || K > FDX_MAX_K_FAST),
+                "fdx_sharded_solve_dev: K must be 1..64, fdx_solver_padded_k of 65..96 cell types, or above 96");
     FDX_REQUIRE(ld >= g->n_total + 1, "fdx_sharded_solve_dev: ld must cover own + halo + zero row");
     FDX_REQUIRE(max_iter >= 0, "fdx_sharded_solve_dev: max_iter must be >= 0");
     FDX_REQUIRE(g->send_off.size() == (size_t)c->world + 1 && g->recv_off.size() == (size_t)c->world + 1,
@@ -395,7 +398,15 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
     const int total_send = g->send_off.back(), total_recv = g->recv_off.back();
     FDX_TRY(comm_streams(c));
 
-    DevBuf stats, relchg, send_buf, recv_buf, soff, roff;
+    DevBuf stats, relchg, send_buf, recv_buf, soff, roff, sweep_scratch;
+    size_t scratch_ld = 0;
+    if (sweep_uses_lds(K)) {                          // as in solver_run: XtX with its rows padded to 16 for the LDS-resident sweep
+        FDX_TRY(sweep_scratch.alloc(sweep_lds_pad_doubles(K) * sizeof(double)));
+        FDX_TRY(sweep_lds_prepare(XtX_dev, K, sweep_scratch.as<double>(), (hipStream_t)stream));
+    } else if (!sweep_instantiated(K)) {
+        scratch_ld = (size_t)g->n_slices * 64;
+        FDX_TRY(sweep_scratch.alloc(scratch_ld * 2 * K * sizeof(double)));
+    }
     const int iters = std::max<int>(max_iter, 1);
     FDX_TRY(stats.alloc((size_t)iters * 128 * 8));
     FDX_TRY(relchg.alloc((size_t)iters * 8));
@@ -452,7 +463,7 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
                         FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));
                     } else {
                         a.tile_list = nullptr; a.n_list = 0;
-                        FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));
+                        FDX_TRY(launch_bcd_sweep(a, sweep_scratch.as<double>(), scratch_ld, st));
                     }
                 }
                 if (total_send > 0) {

@@ -493,6 +493,73 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     nbr_cnt[p] = cnt;
 }
 
+// ------------------------------------------------------------------------------------------------ more than three dimensions
+// utils/graph.py:16-22 takes coordinates of any dimension (cKDTree does).  The grid of this file bins three axes; points with 4 to
+// FDX_KNN_MAX_DIM coordinates are put in solver order by their FIRST THREE coordinates (locality of the sweep's tiles only - any
+// order gives the same graph) and searched exhaustively: lane = row, candidates in ascending CALLER index staged through LDS 256 at
+// a time, squared distances summed coordinate by coordinate without contraction, a candidate enters the list on strictly smaller
+// distance - i.e. the (distance, index) rule of knn_kernel.  O(n^2 dim): for the tens of thousands of spots such data has.
+constexpr int FDX_KNN_MAX_DIM = 8;
+__global__ __launch_bounds__(256) void take3_kernel(const double* __restrict__ coords, long long n, int dim, double* __restrict__ out) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    for (int a = 0; a < 3; ++a) out[(size_t)i * 3 + a] = coords[(size_t)i * dim + a];
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_brute_kernel(const double* __restrict__ coords, const int* __restrict__ perm,
+                                                        const int* __restrict__ rank, long long n, int dim, int kk,
+                                                        int* __restrict__ nbr_out, int* __restrict__ nbr_cnt, long long lo, long long hi,
+                                                        int* __restrict__ tie_count) {
+#pragma clang fp contract(off)
+    __shared__ double tile[256 * FDX_KNN_MAX_DIM];
+    const long long p = lo + blockIdx.x * 256LL + threadIdx.x;
+    const bool live = p < hi;
+    const int op = live ? perm[p] : 0;
+    double x[FDX_KNN_MAX_DIM];
+    for (int a = 0; a < FDX_KNN_MAX_DIM; ++a) x[a] = (a < dim) ? coords[(size_t)op * dim + a] : 0.0;
+    double bd[KMAX];
+    int bq[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bq[s] = -1; }
+    for (long long o0 = 0; o0 < n; o0 += 256) {
+        const int cnt = (int)min(256LL, n - o0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * dim; t += 256) tile[t] = coords[(size_t)o0 * dim + t];
+        __syncthreads();
+        if (!live) continue;
+        for (int c = 0; c < cnt; ++c) {
+            double d2 = 0.0;
+            for (int a = 0; a < dim; ++a) { const double dx = tile[c * dim + a] - x[a]; d2 = d2 + dx * dx; }
+            int q = (int)(o0 + c);                       // caller index; turned into a position when the list is written
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const bool ahead = d2 < bd[s];            // equal: the occupant (lower caller index) stays
+                const double td = ahead ? bd[s] : d2;
+                const int tq = ahead ? bq[s] : q;
+                bd[s] = ahead ? d2 : bd[s];
+                bq[s] = ahead ? q : bq[s];
+                d2 = td;
+                q = tq;
+            }
+        }
+    }
+    if (!live) return;
+    double thr = INFINITY, next = INFINITY;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        if (s == kk - 1) thr = bd[s];
+        if (s == kk) next = bd[s];
+    }
+    if (tie_count && KMAX > kk && next == thr && thr < INFINITY) atomicAdd(tie_count, 1);
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+        if (s < kk && bq[s] >= 0 && bq[s] != op) nbr_out[(size_t)p * kk + cnt++] = rank[bq[s]];
+    for (int s = cnt; s < kk; ++s) nbr_out[(size_t)p * kk + s] = -1;
+    nbr_cnt[p] = cnt;
+}
+
 // ------------------------------------------------------------------------------------------------ band of a spot shard
 // A shard owns rows [lo, hi) of the sorted order.  Row p of the symmetrised k-NN graph is out(p) U in(p): in(p) needs the list of
 // every row q that points at p.  When q's walk stayed within BAND_R shells of its own cell (knn_kernel reports the rows for which
@@ -1284,7 +1351,8 @@ namespace fdx {
 
 int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long long lo, long long hi, int* nbr, int* cnt,
                     fdx_graph_plan** out, hipStream_t st, bool band) {
-    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
+    FDX_REQUIRE(dim >= 1 && dim <= FDX_KNN_MAX_DIM, "graph: k-NN graphs take coordinates of 1 to 8 dimensions");
+    FDX_REQUIRE(dim <= 3 || n <= (1 << 18), "graph: coordinates of more than 3 dimensions are searched exhaustively: at most 262144 spots");
     FDX_REQUIRE(n >= 2 && n < 0x7fffff00LL, "graph: n out of range");
     FDX_REQUIRE(k >= 1, "graph: k must be positive");
     FDX_REQUIRE(0 <= lo && lo <= hi && hi <= n, "graph: bad row range");
@@ -1300,7 +1368,38 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     // and the 256-spot Morton tiles come out more compact (1M jittered-lattice spots: graph 1.11 -> 0.95 ms, sweep 0.192 -> 0.186 ms;
     // uniform random spots: unchanged); FDX_GRAPH_TPC overrides (experiments)
     const double tpc = getenv("FDX_GRAPH_TPC") ? atof(getenv("FDX_GRAPH_TPC")) : 4.0;
-    int rc = bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st);
+    int rc = 0;
+    if (dim > 3) {
+        // solver order from the first three coordinates, exhaustive search in all of them
+        DevBuf c3;
+        rc = c3.alloc((size_t)n * 3 * sizeof(double));
+        if (!rc) {
+            hipLaunchKernelGGL(take3_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_coords, n, dim, c3.as<double>());
+            rc = bin_points(c3.as<double>(), n, 3, tpc, 0.0, &plan->b, st);
+        }
+        if (!rc) rc = plan->ties.alloc(8);
+        if (!rc && hipMemsetAsync(plan->ties.p, 0, 8, st) != hipSuccess) rc = fail(FDX_ERR_HIP, "graph: memset failed");
+        if (rc) { delete plan; return rc; }
+        const BinnedPoints& bb = plan->b;
+        int* ties_hd = plan->ties.as<int>();
+        if (band && (lo > 0 || hi < n)) {               // no band in this search: report it, the caller exchanges the lists
+            const int one = 1;
+            if (hipMemcpyAsync(ties_hd + 1, &one, 4, hipMemcpyHostToDevice, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: copy failed"); }
+            if (hipMemsetAsync(cnt, 0, (size_t)n * 4, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
+        }
+        if (hi > lo) {
+            const dim3 grid(ceil_div(hi - lo, 256)), blk(256);
+            if (kk < 8) hipLaunchKernelGGL(knn_brute_kernel<8>, grid, blk, 0, st, d_coords, bb.perm.as<int>(), bb.rank.as<int>(), n, dim, kk, nbr, cnt, lo, hi, ties_hd);
+            else if (kk < 16) hipLaunchKernelGGL(knn_brute_kernel<16>, grid, blk, 0, st, d_coords, bb.perm.as<int>(), bb.rank.as<int>(), n, dim, kk, nbr, cnt, lo, hi, ties_hd);
+            else if (kk < 32) hipLaunchKernelGGL(knn_brute_kernel<32>, grid, blk, 0, st, d_coords, bb.perm.as<int>(), bb.rank.as<int>(), n, dim, kk, nbr, cnt, lo, hi, ties_hd);
+            else hipLaunchKernelGGL(knn_brute_kernel<64>, grid, blk, 0, st, d_coords, bb.perm.as<int>(), bb.rank.as<int>(), n, dim, kk, nbr, cnt, lo, hi, ties_hd);
+        }
+        if (hipGetLastError() != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: k-NN kernel launch failed"); }
+        if (hipStreamSynchronize(st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: sync failed"); }   // c3 and `one` die here
+        *out = plan;
+        return 0;
+    }
+    rc = bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st);
     if (rc) { delete plan; return rc; }
     const BinnedPoints& b = plan->b;
     const int* perm = b.perm.as<int>();
@@ -1494,7 +1593,7 @@ int graph_meta_sync(const fdx_graph* gc) {
 }
 
 int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_graph* g, hipStream_t st) {
-    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph: coordinate dimension must be 1, 2 or 3");
+    FDX_REQUIRE(dim >= 1 && dim <= FDX_KNN_MAX_DIM, "graph: k-NN graphs take coordinates of 1 to 8 dimensions");
     FDX_REQUIRE(n >= 0 && n < 0x7fffff00LL, "graph: n out of range");
     FDX_REQUIRE(k >= 0, "graph: k must be non-negative");
     const int k_act = (int)std::min<long long>(k, n - 1);           // graph.py:51

@@ -606,9 +606,7 @@ class ShardedFlashDeconv:
         K_real = K
         if K > 64:
             # 65-96 cell types: the next instantiated sweep size with all-zero pad types (include/fdx.h: fdx_solver_padded_k)
-            K = int(lib.fdx_solver_padded_k(K_real))
-            if K == K_real and K not in (72, 80, 88, 96):
-                raise ValueError(f"ShardedFlashDeconv supports up to 96 cell types (got {K_real}); FlashDeconv on one GPU takes more")
+            K = int(lib.fdx_solver_padded_k(K_real))           # above 96: K itself (LDS-resident / generic sweep, one launch per iteration)
             if K != K_real:
                 Hp = torch.zeros((K, ld), dtype=torch.float64, device=dev)
                 Hp[:K_real] = H
@@ -648,7 +646,7 @@ class ShardedFlashDeconv:
         self.proportions_ = torch.empty((n_own, K_real), dtype=torch.float64, device=dev)
         cur = torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=dev)
+            self._side = torch.cuda.Stream(device=dev, priority=-1)   # a distinct priority: same-priority streams share hardware queues and can serialise
         side = self._side
         side.wait_stream(cur)
         _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(beta.data_ptr()), ld, n_own, K_real, ctypes.c_void_p(self.beta_.data_ptr()),

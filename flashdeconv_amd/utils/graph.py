@@ -7,7 +7,8 @@
     build_grid_graph     <- utils/graph.py:136-172
     coords_to_adjacency  <- utils/graph.py:175-212
 
-Coordinates with 1, 2 or 3 columns are supported on the device.  On exactly tied distances (regular lattices) the
+Coordinates with 1, 2 or 3 columns are binned on a grid; k-NN graphs also take 4 to 8 columns (exhaustive search, up to
+262144 spots).  On exactly tied distances (regular lattices) the
 k-th neighbour is chosen by the lower spot index, whereas the reference inherits cKDTree's traversal order;
 ``ties="ckdtree"`` reproduces that order (``ckdtree_knn_adjacency``: a host restatement of scipy's tree, used only when
 the device build reports ties).
@@ -18,11 +19,23 @@ from scipy import sparse
 from .. import _lib
 
 
-def _validate_coords(coords):
+def _validate_coords(coords, knn=False):
     if coords.ndim != 2 or coords.shape[1] == 0:                        # utils/graph.py:16-22
         raise ValueError(f"coords must be 2D with at least 1 coordinate dimension, got shape {coords.shape}")
-    if coords.shape[1] > 3:
-        raise NotImplementedError("flashdeconv_amd builds spatial graphs for 1-, 2- or 3-dimensional coordinates")
+    check_coord_dims(coords.shape[0], coords.shape[1], knn)
+
+
+def check_coord_dims(n, dim, knn):
+    """What the device builders take (csrc/graph_kernels.cpp): a grid over up to three axes; k-NN graphs of points with 4 to 8
+    coordinates by exhaustive search (up to 262144 spots).  The reference's cKDTree takes any dimension (utils/graph.py:16-22)."""
+    if dim > 3 and not knn:
+        raise ValueError(f"coords has {dim} dimensions: radius / grid graphs are built for 1 to 3 coordinate dimensions "
+                         "(k-NN graphs for up to 8)")
+    if dim > 8:
+        raise ValueError(f"coords has {dim} dimensions: k-NN graphs are built for 1 to 8 coordinate dimensions")
+    if dim > 3 and n > (1 << 18):
+        raise ValueError(f"coords has {dim} dimensions and {n} spots: above 3 dimensions the k-NN search is exhaustive, "
+                         "at most 262144 spots")
 
 
 def _to_csr(graph, n):
@@ -34,7 +47,7 @@ def _to_csr(graph, n):
 def knn_graph_handle(coords, k=6):
     """Device graph handle for the k-NN graph (used by FlashDeconv.fit to avoid a host round trip)."""
     coords = np.asarray(coords, dtype=np.float64)
-    _validate_coords(coords)
+    _validate_coords(coords, knn=True)
     _lib.require_gpu()
     return _lib.Graph.from_coords_knn(coords, k)
 
@@ -97,7 +110,7 @@ def build_knn_graph(coords, k=6, include_self=False, ties="index"):
     if ties not in ("index", "ckdtree"):
         raise ValueError(f"Unknown ties rule: {ties}. Choose from 'index', 'ckdtree'.")
     coords = np.asarray(coords, dtype=np.float64)
-    _validate_coords(coords)
+    _validate_coords(coords, knn=True)
     n = coords.shape[0]
     if min(k, n - 1) <= 0:                                               # utils/graph.py:51-57
         if include_self and n > 0:
@@ -176,7 +189,7 @@ def coords_to_adjacency(coords, method="knn", k=6, radius=None):
 def coords_to_graph_handle(coords, method="knn", k=6, radius=None):
     """Same dispatch as coords_to_adjacency but returns the device handle (no CSR materialised on the host)."""
     coords = np.asarray(coords, dtype=np.float64)
-    _validate_coords(coords)
+    _validate_coords(coords, knn=method == "knn")
     n = coords.shape[0]
     if method == "knn":
         return knn_graph_handle(coords, k)

@@ -249,11 +249,18 @@ def test_sharded_class_world1_equals_flashdeconv():
             assert m7.info_["n_iterations"] == ref7.info_["n_iterations"]
             np.testing.assert_allclose(got7, ref7.proportions_, rtol=1e-9, atol=1e-13)
             np.testing.assert_allclose(m7.info_["final_objective"], ref7.info_["final_objective"], rtol=1e-10)
-        with pytest.raises(ValueError, match="up to 96 cell types"):
-            Y9, X9, c9, _ = datagen.gaussian_raw(600, 300, 100, seed=1)
-            m9 = ShardedFlashDeconv(sketch_dim=64, preprocess="raw", n_hvg=300)
+        # above 96 types: the LDS-resident sweep over the whole shard per iteration (no boundary / interior split), as on one GPU
+        for K9 in (100, 120):
+            Y9, X9, c9, _ = datagen.gaussian_raw(1500, 400, K9, seed=K9)
+            ref9 = FlashDeconv(sketch_dim=128, preprocess="raw", n_hvg=400, max_iter=8).fit(Y9, X9, c9)
+            m9 = ShardedFlashDeconv(sketch_dim=128, preprocess="raw", n_hvg=400, max_iter=8)
             own9 = m9.plan(torch.from_numpy(c9).to(dev))
-            m9.fit_transform(torch.from_numpy(Y9).to(dev)[own9], X9)
+            P9 = m9.fit_transform(torch.from_numpy(Y9).to(dev)[own9], X9)
+            got9 = np.zeros((1500, K9))
+            got9[own9.cpu().numpy()] = P9.cpu().numpy()
+            assert m9.info_["n_iterations"] == ref9.info_["n_iterations"]
+            assert np.array_equal(got9, ref9.proportions_), K9
+            np.testing.assert_allclose(m9.info_["final_objective"], ref9.info_["final_objective"], rtol=1e-10)
         # gene selection active (G > n_hvg): statistics reduced over the shards, same genes, same fit
         Yc, Xc, cc, _ = datagen.count_like(3000, 900, 6, 0.1, 8)
         kw = dict(sketch_dim=64, preprocess="log_cpm", n_hvg=250, n_markers_per_type=10, max_iter=20)

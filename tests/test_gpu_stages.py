@@ -487,3 +487,34 @@ def test_wide_tile_kernel_matches_the_two_kernel_path_and_the_oracle(n, G, K, d,
         fin = np.isfinite(b2.beta_)
         assert np.array_equal(np.isfinite(a2.beta_), fin)
         assert rel_fro(a2.beta_[fin], b2.beta_[fin]) < 1e-9
+
+
+@pytest.mark.parametrize("n,dim,k", [(1500, 4, 6), (700, 6, 9), (300, 8, 3), (40, 5, 60)])
+def test_knn_graph_in_more_than_three_dimensions(n, dim, k):
+    """utils/graph.py:16-22, 60-81 with 4 to 8 coordinate columns (cKDTree takes any): exhaustive search on the device, solver
+    order from the first three coordinates - the reference's adjacency index for index, and a fit on 4-D coordinates."""
+    import fdx_oracle as orc
+    from flashdeconv_amd.utils.graph import build_knn_graph
+    rs = np.random.RandomState(n + dim)
+    coords = rs.rand(n, dim) * 10.0
+    want = orc.knn_graph_kdtree(coords, k)
+    got = build_knn_graph(coords, k=k)
+    assert got.nnz == want.nnz
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+
+
+def test_fit_with_four_dimensional_coordinates():
+    import datagen
+    import fdx_oracle as orc
+    from flashdeconv_amd import FlashDeconv
+    n, G, K = 900, 400, 6
+    Y, X, coords, _ = datagen.gaussian_raw(n, G, K, seed=21)
+    c4 = np.concatenate([coords, np.random.RandomState(1).rand(n, 2) * coords.max()], axis=1)
+    kw = dict(sketch_dim=64, preprocess="raw", n_hvg=G, max_iter=15)
+    want = orc.fit(Y, X, c4, sketch_dim=64, preprocess_method="raw", n_hvg=G, max_iter=15)
+    m = FlashDeconv(**kw).fit(Y, X, c4)
+    assert m.info_["n_iterations"] == want["info"]["n_iterations"]
+    assert rel_fro(m.beta_, want["beta"]) < 1e-8
+    with pytest.raises(ValueError, match="radius / grid graphs are built for 1 to 3"):
+        FlashDeconv(spatial_method="grid", **kw).fit(Y, X, c4)
+

@@ -155,6 +155,19 @@ def test_utils_package_exports_the_reference_names():
         assert callable(getattr(u, name)) and name in u.__all__
 
 
+def test_coordinate_dimension_limits_are_value_errors_naming_the_limit():
+    """utils/graph.py:16-22 takes any dimension; here k-NN takes 1-8 (4-8 by exhaustive search, up to 262144 spots), radius / grid 1-3."""
+    from flashdeconv_amd.utils.graph import check_coord_dims
+    check_coord_dims(1000, 3, False)
+    check_coord_dims(1000, 8, True)
+    with pytest.raises(ValueError, match="radius / grid graphs are built for 1 to 3"):
+        check_coord_dims(1000, 4, False)
+    with pytest.raises(ValueError, match="1 to 8 coordinate dimensions"):
+        check_coord_dims(1000, 9, True)
+    with pytest.raises(ValueError, match="at most 262144 spots"):
+        check_coord_dims(300000, 4, True)
+
+
 def test_spatial_helpers():
     from flashdeconv_amd.core.spatial import auto_tune_lambda, compute_laplacian, compute_laplacian_quadratic, get_neighbor_indices
     A = sparse.csr_matrix(np.array([[0, 1, 1, 0], [1, 0, 0, 0], [1, 0, 0, 1], [0, 0, 1, 0]], dtype=float))

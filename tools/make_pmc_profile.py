@@ -64,5 +64,7 @@ with open(out, "w") as f:
             f.write(f"| LDS array busy: SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8) | {v['SQ_LDS_IDX_ACTIVE'] / (256 * v['GRBM_GUI_ACTIVE'] / 8):.3f} |\n")
         if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and v.get("GRBM_GUI_ACTIVE"):
             f.write(f"| MFMA pipe busy: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) | {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * v['GRBM_GUI_ACTIVE'] / 8):.3f} |\n")
+        if v.get("TCC_HIT_sum") is not None and (v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)) > 0:
+            f.write(f"| L2 hit rate: TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) | {v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum']):.3f} |\n")
         f.write("\n")
 print("wrote", out)

@@ -3,7 +3,7 @@
 # (extra arguments select another workload for all three passes, e.g. `r02_config5 --config 5`).
 # Counters are collected in their own passes (kernel-trace only alongside), as the pool requires.
 tag=${1:-r01}; shift
-if [ $# -gt 0 ]; then pmc_args="$*"; else pmc_args="--family both"; fi
+if [ $# -gt 0 ]; then pmc_args="$*"; else pmc_args="--family all"; fi   # all: the CSR family's kernels too (FETCH / WRITE of the sparse path)
 out=/root/repo/gpurun_out/${tag}_prof
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
@@ -13,4 +13,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" --
 # keep what the summaries need: stats + counter csvs (the full kernel traces are large)
 find "$out" -name "*kernel_trace.csv" -delete
 find "$out" -name "*agent_info.csv" -delete
+# counter csvs: the library's kernels only (the torch data generators dispatch thousands of kernels; gpurun copies at most 64 MB back)
+for f in $(find "$out" -name "*counter_collection.csv"); do
+  head -1 "$f" > "$f.tmp"; grep "fdx::" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"
+done
 du -sh "$out"; find "$out" -type f | head -20
