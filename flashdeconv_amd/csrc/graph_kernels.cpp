@@ -216,7 +216,10 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const unsigned* __restr
 __global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict__ coords, const unsigned* __restrict__ key32,
                                                         const int* __restrict__ start, const int* __restrict__ members,
                                                         long long n, int dim, int* __restrict__ perm, int* __restrict__ rank,
-                                                        double* __restrict__ sc, double2* __restrict__ sc2) {
+                                                        double* __restrict__ sc, double2* __restrict__ sc2,
+                                                        const unsigned char* __restrict__ need) {
+    // need != NULL (a spot shard's binning): only the cells the shard will look at are laid out - perm / rank / coordinates of
+    // the others are never written, and never read (cell_need_kernel)
     // thread t takes the point that ARRIVED at slot t: its sorted position lies in the same cell's range as t, so the writes of
     // a wave (perm, the coordinate planes, the pairs) fall into one contiguous stretch - five scattered stores per point became
     // two gathers (key, coordinates) and one scattered store (rank)
@@ -224,6 +227,7 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const double* __restrict
     if (t >= n) return;
     const int i = members[t];
     const unsigned k = key32[i];
+    if (need && !need[k]) return;
     const int s = start[k], e = start[k + 1];
     int below = 0;
     for (int q = s; q < e; ++q) below += (members[q] < i) ? 1 : 0;
@@ -249,6 +253,39 @@ __global__ __launch_bounds__(256) void cell_table_kernel(const int* __restrict__
     const int id = c[0] * gp.stride[0] + c[1] * gp.stride[1] + c[2] * gp.stride[2];
     cstart[id] = s0;
     cend[id] = s1;
+}
+
+// A spot shard owns positions [lo, hi) of the sorted order.  Its build looks at: the own rows, the rows of cells within BAND_R cells
+// of an own cell (the band, whose lists it finds itself), and - walking those lists - cells within BAND_R shells of a band cell.
+// Only those cells need their points laid out (perm, rank, sorted coordinates): the ranking pass, the one pass of the binning
+// that gathers coordinates and scatters, then costs the shard's share instead of all n points.  Two dilations by BAND_R of the
+// set of own cells (keys whose range meets [lo, hi)); a walk that goes further reports itself (knn_kernel: far) and the build
+// is redone by exchange with a full binning.
+__device__ __forceinline__ void cell_of_key(long long k, int dim, int c[3]) {
+    c[0] = c[1] = c[2] = 0;
+    if (dim == 1) c[0] = (int)k;
+    else if (dim == 2) { c[0] = (int)compact_bits_2((unsigned long long)k); c[1] = (int)compact_bits_2((unsigned long long)k >> 1); }
+    else { c[0] = (int)compact_bits_3((unsigned long long)k); c[1] = (int)compact_bits_3((unsigned long long)k >> 1); c[2] = (int)compact_bits_3((unsigned long long)k >> 2); }
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void cell_need_kernel(const int* __restrict__ start, long long bins, GridParams gp, long long lo,
+                                                        long long hi, int R, const unsigned char* __restrict__ in,
+                                                        unsigned char* __restrict__ out) {
+    const long long k = blockIdx.x * 256LL + threadIdx.x;
+    if (k >= bins) return;
+    const bool seed = PASS == 0 ? (start[k + 1] > start[k] && (long long)start[k] < hi && (long long)start[k + 1] > lo) : (in[k] != 0);
+    if (!seed) return;
+    int c[3];
+    cell_of_key(k, gp.dim, c);
+    const int r1 = gp.dim > 1 ? R : 0, r2 = gp.dim > 2 ? R : 0;
+    for (int dz = -r2; dz <= r2; ++dz)
+        for (int dy = -r1; dy <= r1; ++dy)
+            for (int dx = -R; dx <= R; ++dx) {
+                int cc[3] = {c[0] + dx, c[1] + dy, c[2] + dz};
+                if (cc[0] < 0 || cc[0] >= gp.nc[0] || cc[1] < 0 || cc[1] >= gp.nc[1] || cc[2] < 0 || cc[2] >= gp.nc[2]) continue;
+                const unsigned long long kk = morton_key(cc, gp.dim);
+                if ((long long)kk < bins) out[kk] = 1;
+            }
 }
 
 // ------------------------------------------------------------------------------------------------ k-NN
@@ -288,7 +325,7 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
                                                   long long lo, long long hi, int* __restrict__ indeg,
                                                   int* __restrict__ arrival, int* __restrict__ tie_count, int gp_no_batch,
                                                   const int* __restrict__ row_list, const int* __restrict__ row_count,
-                                                  int* __restrict__ far_flag, int far_R) {
+                                                  int* __restrict__ far_flag, int far_R, int far_drop) {
     // rows [lo, hi) of the sorted order, or (row_list != NULL: the band of a spot shard) the first min(*row_count, hi) listed rows
     long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (row_list) {
@@ -422,7 +459,16 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     }
     // a walk that went past shell far_R of its cell: a spot shard's band (the rows of the cells within far_R cells of an own one)
     // then does not hold every row that can point at an own row - the sharded build falls back to exchanging the lists
-    if (far_flag && __ballot(R_end > far_R + 1) != 0ULL && (threadIdx.x & 63) == 0) atomicOr(far_flag, 1);
+    const bool went_far = R_end > far_R + 1;
+    if (far_flag && __ballot(went_far) != 0ULL && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(went_far)) - 1)) atomicOr(far_flag, 1);
+    // a spot shard with band recompute lays out only the cells within reach of such walks (bin_points): what a longer walk
+    // met there is not data.  Its row gets an empty list - the build is redone by exchange anyway (far_flag; for a band row
+    // the rank that owns it raises it).
+    if (far_drop && went_far) {
+        for (int s = 0; s < kk; ++s) nbr_out[(size_t)p * kk + s] = -1;
+        nbr_cnt[p] = 0;
+        return;
+    }
 
     // ---- the threshold: the kk-th smallest distance, how many list entries lie below it, and whether the (kk+1)-th equals it
     double thr = INFINITY, next = INFINITY;
@@ -1065,13 +1111,15 @@ static int make_grid(const double* d_coords, long long n, int dim, double target
 struct BinnedPoints {
     GridParams gp;
     DevBuf perm, rank, sc, sc2, cstart, cend;      // sc2: (x, y) pairs of the sorted points, dim <= 2 only
-    DevBuf keys, vals, skeys, sort_tmp, count, start, scan_tmp;   // sort temporaries: kept until the struct dies so that binning needs no final sync
+    DevBuf keys, vals, skeys, sort_tmp, count, start, scan_tmp, need;   // sort temporaries: kept until the struct dies so that binning needs no final sync
     long long n = 0;
     int n_cells = 0;
 };
 
+// shard_lo < shard_hi: a spot shard's binning - the ranking pass lays out only the cells the shard's build looks at
+// (cell_need_kernel; counting path only: the sorting path lays out everything)
 static int bin_points(const double* d_coords, long long n, int dim, double target_per_cell, double min_h,
-                      BinnedPoints* b, hipStream_t st) {
+                      BinnedPoints* b, hipStream_t st, long long shard_lo = 0, long long shard_hi = 0, int shard_R = 0) {
     b->n = n;
     FDX_TRY(make_grid(d_coords, n, dim, target_per_cell, min_h, &b->gp, st));
     trace_host("bin: make_grid (bbox kernel + read-back)");
@@ -1119,8 +1167,21 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
                            tmp.as<int>());
         FDX_CHECK_LAUNCH();
         if (dim < 3) FDX_HIP(hipMemsetAsync(b->sc.as<double>() + (size_t)dim * n, 0, (size_t)(3 - dim) * n * sizeof(double), st));
+        const unsigned char* need = nullptr;
+        if (shard_hi > shard_lo && (shard_lo > 0 || shard_hi < n) && shard_R > 0 && !getenv("FDX_BAND_FULL_BINNING")) {
+            FDX_TRY(b->need.alloc((size_t)bins * 2));
+            FDX_HIP(hipMemsetAsync(b->need.p, 0, (size_t)bins * 2, st));
+            unsigned char* n1 = b->need.as<unsigned char>();
+            unsigned char* n2 = n1 + bins;
+            hipLaunchKernelGGL(cell_need_kernel<0>, dim3(ceil_div(bins, 256)), dim3(256), 0, st, b->start.as<int>(), bins, b->gp, shard_lo,
+                               shard_hi, shard_R, (const unsigned char*)nullptr, n1);
+            hipLaunchKernelGGL(cell_need_kernel<1>, dim3(ceil_div(bins, 256)), dim3(256), 0, st, b->start.as<int>(), bins, b->gp, shard_lo,
+                               shard_hi, shard_R, (const unsigned char*)n1, n2);
+            FDX_CHECK_LAUNCH();
+            need = n2;
+        }
         hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(256), 0, st, d_coords, keys.as<unsigned>(), b->start.as<int>(),
-                           tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), b->sc.as<double>(), b->sc2.as<double2>());
+                           tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), b->sc.as<double>(), b->sc2.as<double2>(), need);
         FDX_CHECK_LAUNCH();
         hipLaunchKernelGGL(cell_table_kernel, dim3(ceil_div(bins, 256)), dim3(256), 0, st, b->start.as<int>(), bins, b->gp,
                            b->cstart.as<int>(), b->cend.as<int>());
@@ -1279,7 +1340,7 @@ static int empty_graph(long long n, fdx_graph* g, hipStream_t st) {
 template <int KMAX>
 static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, long long lo,
                              long long hi, hipStream_t st, int* indeg = nullptr, int* arrival = nullptr, int* ties = nullptr,
-                             const int* row_list = nullptr, const int* row_count = nullptr, int* far_flag = nullptr) {
+                             const int* row_list = nullptr, const int* row_count = nullptr, int* far_flag = nullptr, int far_drop = 0) {
     const int far_R = BAND_R;
     if (hi <= lo) return;
     // candidates per round trip: 4 leaves the kernel 77 registers (6 waves per SIMD), 6: 87 (5 waves), 8: 97 (4 waves);
@@ -1289,7 +1350,7 @@ static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), b.sc2.as<double2>(), perm,
                            b.rank.as<int>(), b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
-                           KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0, row_list, row_count, far_flag, far_R);
+                           KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0, row_list, row_count, far_flag, far_R, far_drop);
     };
     if constexpr (KMAX <= 16) {
         if (batch == 4) go(knn_kernel<KMAX, 4>);
@@ -1399,7 +1460,9 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
         *out = plan;
         return 0;
     }
-    rc = bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st);
+    const bool shard_band = band && (lo > 0 || hi < n) && hi > lo;
+    rc = shard_band ? bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st, lo, hi, BAND_R)
+                    : bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st);
     if (rc) { delete plan; return rc; }
     const BinnedPoints& b = plan->b;
     const int* perm = b.perm.as<int>();
@@ -1433,10 +1496,11 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     const long long step = ((rows + pieces - 1) / pieces + 127) / 128 * 128;
     for (long long a = lo; a < hi; a += step) {
         const long long e = std::min(hi, a + step);
-        if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1);
-        else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1);
-        else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1);
-        else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1);
+        const int fd = shard_band ? 1 : 0;
+        if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1, fd);
+        else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1, fd);
+        else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1, fd);
+        else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1, fd);
     }
     trace_host("knn: kernel launched");
     if (band && rows > 0) {
@@ -1466,10 +1530,10 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
         const int* bl = plan->band_rows.as<int>();
         const long long cap = plan->band_cap;
         if (cap > 0) {
-            if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr);
-            else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr);
-            else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr);
-            else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr);
+            if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr, 1);
+            else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr, 1);
+            else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr, 1);
+            else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr, 1);
         }
         // cell_flag / cell_list go back to the pool here: the pool orders their next use on this stream behind these kernels
     }
