@@ -29,7 +29,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "fdx_internal.h"
@@ -252,10 +254,30 @@ extern "C" int fdx_ckdtree_knn(const double* coords, int64_t n, int32_t dim, int
     std::vector<double> mx(t.maxes), mn(t.mins);
     kd_build(t, 0, n, mx.data(), mn.data());
     if (tree_indices_out) std::memcpy(tree_indices_out, t.indices.data(), (size_t)n * sizeof(int64_t));
-    std::vector<NodeInfo> pool;
-    Heap q, nb;
-    q.h.resize(12);
-    nb.h.resize((size_t)kk);
-    for (long long i = 0; i < n; ++i) kd_query_one(t, coords + i * dim, kk, idx_out + i * kk, pool, q, nb);
+    // the queries are independent (the tree is read-only; every thread has its own node pool and heaps): contiguous ranges of a
+    // few thousand points and more per host thread.  1000 x 1000 lattice points on 8 cores: 2.2 -> 0.8-1.0 s, of which 0.29 s the
+    // serial build (its top levels are full passes over the points - bounds, introselect, partition; building the subtrees below
+    // the second level on four threads was tried and returned nothing measurable).
+    auto run = [&](long long i0, long long i1) {
+        std::vector<NodeInfo> pool;
+        Heap q, nb;
+        q.h.resize(12);
+        nb.h.resize((size_t)kk);
+        for (long long i = i0; i < i1; ++i) kd_query_one(t, coords + i * dim, kk, idx_out + i * kk, pool, q, nb);
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char* e = getenv("FDX_KDTREE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    nt = (unsigned)std::min<long long>(std::max(1u, std::min(nt, 32u)), std::max<long long>(1, n / 4096));
+    if (nt <= 1) {
+        run(0, n);
+        return 0;
+    }
+    std::vector<std::thread> th;
+    const long long per = (n + nt - 1) / nt;
+    for (unsigned k = 0; k < nt; ++k) {
+        const long long i0 = (long long)k * per, i1 = std::min<long long>(n, i0 + per);
+        if (i0 < i1) th.emplace_back(run, i0, i1);
+    }
+    for (auto& x : th) x.join();
     return 0;
 }
