@@ -148,16 +148,18 @@ def alg_bytes(n, G, K, s_y, nnz, n_slices_width_rows, T):
 
 
 TRAFFIC_PROFILE = "profiles/r04_traffic.json"
+TRAFFIC_PROFILE_C5 = "profiles/r04_config5_traffic.json"     # the configs[4] shard (bench.py --config 5)
 
 
 def pmc_traffic(kernel, shape):
     """HBM bytes per launch of `kernel` from the committed PMC pass (TRAFFIC_PROFILE: rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE of this same command on an earlier run of the same build, gfx950 correction applied) - measured then, not
     in this run; None for other workloads or a kernel the profile does not hold."""
-    if shape != (1_000_000, 2000, 30, 512):
+    prof = {(1_000_000, 2000, 30, 512): TRAFFIC_PROFILE, (1_250_000, 5000, 50, 1024): TRAFFIC_PROFILE_C5}.get(tuple(shape))
+    if prof is None:
         return None
     try:
-        with open(os.path.join(ROOT, TRAFFIC_PROFILE)) as f:
+        with open(os.path.join(ROOT, prof)) as f:
             kernels = json.load(f)["kernels"]
         k = kernels.get(kernel) or next((v for name, v in kernels.items() if name.startswith(kernel)), None)
         return int(k["hbm_bytes_corrected"]) if k else None
@@ -177,13 +179,13 @@ def sweep_chunk(K):
 
 
 def sweep_kernel_name(K):
-    return "fdx::bcd_sweep_tiled_kernel<%d, %d, false>" % (K, sweep_chunk(K))
+    return "fdx::bcd_sweep_tiled_kernel<%d, %d, false, true>" % (K, sweep_chunk(K))    # <K, chunk, objective variant, quadratic term inside>
 
 
 def sketch_kernel_name(mode, K, d=512):
     """Kernel that serves the sketch -> H stage of the bench shapes (csrc/tile_kernels.cpp: tile_cfg): template arguments
     <input type, preprocess, consumer waves, loader waves, groups per wave, type tiles, A operands from L2, log1p class
-    (2 = float32-class for float32 rows)>."""
+    (2 = float32-class for float32 rows), weights by gene in the stage buffers (wide raw), flat schedule>."""
     cfg = os.environ.get("FDX_TILE_CFG")
     nwc, nwl, jw = {"12": (12, 4, 11), "16": (16, 0, 8), "8": (8, 2, 16)}.get(cfg, (12, 4, 11) if mode == 0 else (16, 0, 8))
     logv = 0 if (mode == 0 or os.environ.get("FDX_TILE_LOGV") == "0") else 2
@@ -195,8 +197,9 @@ def sketch_kernel_name(mode, K, d=512):
     if K > 32 or d > 4 * nwc * jw:                 # wide form (raw: weights by gene in a ring of three stage buffers)
         (nwc, nwl, jw), tt, avl2 = ((12, 4, 22) if mode == 0 else (8, 0, 32)), 4, True
         wg = mode == 0 and not os.environ.get("FDX_TILE_NO_WG")
-    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d, %s, %d, %s>" % (mode, nwc, nwl, jw, tt, "true" if avl2 else "false", logv,
-                                                                              "true" if wg else "false")
+    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d, %s, %d, %s, %s>" % (
+        mode, nwc, nwl, jw, tt, "true" if avl2 else "false", logv, "true" if wg else "false",
+        "true" if (wg and os.environ.get("FDX_TILE_FLAT")) else "false")
 
 
 def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
@@ -444,7 +447,8 @@ def main():
             "converged": model.info_["converged"], "stage_ms": stage_record(stage, dt / steps * 1e3),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, (n, G, K, d)),
-                         "traffic_source": TRAFFIC_PROFILE + " (PMC pass of an earlier run of this build, not this run)",
+                         "traffic_source": (TRAFFIC_PROFILE_C5 if a.config == 5 else TRAFFIC_PROFILE) +
+                                           " (PMC pass of an earlier run of this build, not this run)",
                          "alg_bytes_per_launch": int(bytes_launch), "ms_per_launch": round(ms_launch, 4)},
             "steps": steps,
         }
