@@ -897,7 +897,9 @@ __global__ __launch_bounds__(256) void fill_ell_kernel(const int* __restrict__ w
 __global__ __launch_bounds__(256) void deg_to_orig_kernel(const int* __restrict__ deg, const int* __restrict__ perm,
                                                           long long n, int* __restrict__ deg_orig) {
     const long long p = blockIdx.x * 256LL + threadIdx.x;
-    if (p < n) deg_orig[perm[p]] = deg[p];
+    // rows without entries are skipped, not copied (deg_orig arrives zeroed): the full-size graph of a spot shard has its
+    // permutation laid out only where the shard looks (bin_points, shard mode) - an empty row's perm[p] is not data there
+    if (p < n && deg[p] > 0) deg_orig[perm[p]] = deg[p];
 }
 
 __global__ __launch_bounds__(256) void export_rows_kernel(const int* __restrict__ ws, int seg_stride,
@@ -905,7 +907,7 @@ __global__ __launch_bounds__(256) void export_rows_kernel(const int* __restrict_
                                                           const int* __restrict__ perm, const long long* __restrict__ indptr,
                                                           long long n, int* __restrict__ indices) {
     const long long p = blockIdx.x * 256LL + threadIdx.x;
-    if (p >= n) return;
+    if (p >= n || deg[p] <= 0) return;              // empty rows: nothing to write, and (spot shards) no valid perm[p] to look up
     const int* seg = ws + (size_t)p * seg_stride + seg_extra[p];
     const long long base = indptr[perm[p]];
     for (int m = 0; m < deg[p]; ++m) indices[base + m] = perm[seg[m]];

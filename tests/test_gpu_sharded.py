@@ -158,6 +158,46 @@ def test_virtual_ranks_equal_single_gpu(W, build):
     assert np.array_equal(beta.cpu().numpy(), ref.beta_)
 
 
+@pytest.mark.parametrize("dim,n,k,W", [(1, 3000, 4, 3), (2, 20000, 6, 4), (3, 9000, 6, 3), (2, 5000, 12, 5)])
+def test_band_recompute_rows_are_the_references_rows(dim, n, k, W):
+    """Every rank's own rows from the band recompute (no exchange; the shard's binning lays out its own neighbourhood only),
+    exported in the caller's labels and put together, are the reference's adjacency (utils/graph.py:25-83) index for index -
+    1-, 2- and 3-dimensional coordinates, k up to 12."""
+    import torch
+    import fdx_oracle as orc
+    from scipy import sparse
+    from flashdeconv_amd import _lib
+    from flashdeconv_amd.distributed import shard_bounds
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(dim * 100 + k)
+    pts = rs.rand(n, dim) * (n ** (1.0 / dim))
+    want = orc.knn_graph_kdtree(pts, k)
+    cd = torch.from_numpy(np.ascontiguousarray(pts)).to(dev)
+    bounds = shard_bounds(n, W)
+    kk = min(k, n - 1) + 1
+    rows, cols = [], []
+    for r in range(W):
+        nbr = torch.full((n, kk), -7, dtype=torch.int32, device=dev)
+        cnt = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        pl, h = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_knn_lists_band_dev(ctypes.c_void_p(cd.data_ptr()), n, dim, k, int(bounds[r]), int(bounds[r + 1]),
+                                                    ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), _st(torch), ctypes.byref(pl)))
+        _lib.check(lib.fdx_graph_from_knn_lists_dev(pl, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()),
+                                                    int(bounds[r]), int(bounds[r + 1]), _st(torch), ctypes.byref(h)))
+        g = _lib.Graph(h.value)
+        assert g.knn_far() == 0
+        indptr, indices = g.to_csr_arrays()                    # all n rows in the caller's labels; rows of other ranks are empty
+        deg = np.diff(indptr)
+        rows.append(np.repeat(np.arange(n), deg))
+        cols.append(indices)
+        g.close()
+    got = sparse.csr_matrix((np.ones(sum(len(c) for c in cols)), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    got.sort_indices()
+    assert got.nnz == want.nnz
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+
+
 def test_band_recompute_reports_walks_that_leave_their_block():
     """Very uneven density (two tight clusters and a few stragglers far away): the stragglers' k-NN walks leave the 3 x 3 block of
     grid cells, the rank that owns them says so (fdx_graph_knn_far), and the driver then builds by exchanging the lists - whose
