@@ -9,6 +9,7 @@ Inputs may be NumPy arrays, SciPy sparse matrices, or CUDA (HIP) ``torch`` tenso
 """
 import ctypes
 import os
+import sys
 import time
 
 import numpy as np
@@ -356,6 +357,7 @@ class FlashDeconv:
             gh = ctypes.c_void_p(self._graph.handle.value)
             bucket32 = np.ascontiguousarray(bucket, dtype=np.int32)
             wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
+            t_call = time.perf_counter()
             if csr is not None:
                 gi32 = np.ascontiguousarray(gene_idx, dtype=np.int32)
                 _lib.check(lib.fdx_fit_csr_dev(ctypes.byref(csr.view), _lib.ptr_i32(gi32), G, _lib.ptr_f64(Xsel), K,
@@ -368,6 +370,9 @@ class FlashDeconv:
                                            ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs), _lib.ptr_f64(rels),
                                            ctypes.byref(info), None))
             t_ret = time.perf_counter()
+            if os.environ.get("FDX_TRACE_HOST"):
+                print(f"[fdx-host] python: entry->build {1e6 * (t_graph - t_entry):.0f} us, build call {1e6 * (t_lev - t_graph):.0f}, leverage wait "
+                      f"{1e6 * (t_done - t_lev):.0f}, tables + setup {1e6 * (t_call - t_done):.0f}, fit call {1e6 * (t_ret - t_call):.0f}", file=sys.stderr)
             if output == "torch":
                 self.beta_, self.proportions_ = beta_t, prop_t
             else:

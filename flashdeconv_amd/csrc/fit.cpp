@@ -4,6 +4,8 @@
 // Everything between "Y, coords resident in HBM" and "beta_, proportions_ resident in HBM" stays on the device; the
 // host only sees a handful of scalars (bounding box, XtX, rel_change trace).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -18,6 +20,16 @@
 using namespace fdx;
 
 namespace {
+
+// FDX_TRACE_HOST=1: host time between the marked points of a fit (stderr), to see whether the host keeps ahead of the device
+void fit_trace_host(const char* what) {
+    static const bool on = getenv("FDX_TRACE_HOST") != nullptr;
+    if (!on) return;
+    static auto t_prev = std::chrono::steady_clock::now();
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[fdx-host] +%7.1f us  fit: %s\n", std::chrono::duration<double, std::micro>(t - t_prev).count(), what);
+    t_prev = t;
+}
 
 struct StageTimer {
     hipStream_t st;
@@ -218,6 +230,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     PoolStream pool_stream(st);
     StageTimer tm(st);
     tm.mark();  // 0
+    fit_trace_host("entry");
 
     // ---- spatial graph (core/deconv.py:358)
     fdx_graph* g = nullptr;
@@ -341,6 +354,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     struct EvGuard2 { hipEvent_t* a; hipEvent_t* b; ~EvGuard2() { if (*a) (void)hipEventDestroy(*a); if (*b) (void)hipEventDestroy(*b); } } eS_guard{&eS0, &eS1};
     FDX_HIP(hipEventCreate(&eS0));
     FDX_HIP(hipEventCreate(&eS1));
+    fit_trace_host("side-stream preamble queued, buffers allocated");
     FDX_HIP(hipEventRecord(eS0, st));            // the prologue (graph chain, X-side preamble) ends here
     if (fused) {   // one kernel, no Y_sketch: rows -> LDS tile -> bucket sums -> MFMA contraction -> H  (tile_kernels.cpp)
         if (csr_fused)     // CSR rows -> LDS accumulators -> MFMA contraction -> H  (csr_kernels.cpp)
@@ -413,6 +427,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     }
     if (prm->verbose) FDX_HIP(hipStreamSynchronize(st));
     else FDX_HIP(hipEventSynchronize(evG));
+    fit_trace_host("sketch queued, XtX on the host");
     tm.mark();  // 2
     double diag_mean = 0.0;
     for (int k = 0; k < K; ++k) diag_mean += Gh[(size_t)k * K + k];
