@@ -63,9 +63,16 @@ def select_markers(X, n_markers=50, method="diff"):
     if K == 1:
         idx = np.arange(min(n_markers, G))
         return idx, np.zeros(len(idx), dtype=np.intp)
-    if method == "diff":                              # utils/genes.py:197-200
-        top = np.partition(frac, K - 2, axis=0)       # only the two largest fractions per gene are needed (no full sort)
-        specificity = top[K - 1] - top[K - 2]
+    owner = np.argmax(frac, axis=0)
+    if method == "diff":                              # utils/genes.py:197-200: largest minus second largest fraction per gene
+        # two column maxima instead of a sort (or a partition along the strided axis: 16 ms at 30 x 20000 against 1.5): the
+        # second largest is the maximum with the first occurrence of the largest taken out - a tie gives the same value twice,
+        # as the sorted column does
+        cols = np.arange(G)
+        largest = frac[owner, cols]
+        rest = frac.copy()
+        rest[owner, cols] = -np.inf
+        specificity = largest - rest.max(axis=0)
     elif method == "ratio":                           # utils/genes.py:202-206: largest fraction over the mean of the others
         largest = frac.max(axis=0)
         specificity = largest / ((frac.sum(axis=0) - largest) / (K - 1) + 1e-10)
@@ -74,7 +81,6 @@ def select_markers(X, n_markers=50, method="diff"):
         specificity = np.sum(1 - frac / (largest + 1e-10), axis=0) / (K - 1)
     else:
         raise ValueError(f"Unknown method: {method}")
-    owner = np.argmax(frac, axis=0)
     chosen, assign = [], []
     for k in range(K):
         mine = np.flatnonzero(owner == k)
