@@ -210,7 +210,7 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
     const long long* __restrict__ indptr, const int* __restrict__ indices, const T* __restrict__ data,
     const int* __restrict__ row_map, long long n, int d, const GeneSlot* __restrict__ table,
     const unsigned* __restrict__ sel_bits, int sel_words, const double* __restrict__ Xs, int K, double* __restrict__ Hout,
-    long long ldh, double* __restrict__ row_sumsq, int no_table) {
+    long long ldh, double* __restrict__ row_sumsq, int no_table, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = 16;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -220,6 +220,12 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
     const int region = max(R * rs, R * TT * 4 * 64);
     double* tabs = rows + region;                                         // [16][64] per-wave log1p tables
     unsigned* bits = reinterpret_cast<unsigned*>(tabs + R * 64);          // [sel_words]
+    // log modes: the SELECTED entries of the wave's row (column, value; `cap` of them) - written by the library-size pass, so
+    // that the sketch pass reads them from LDS and the row is fetched from HBM once (the second read of an 11.5 KB row did not
+    // hit L2 with 16 rows per CU in flight: PMC 24.3 GB for 11.75 GB of rows)
+    unsigned char* keep = reinterpret_cast<unsigned char*>(bits + ((sel_words + 3) & ~3)) + (size_t)wave * cap * (4 + sizeof(T));
+    int* keep_c = reinterpret_cast<int*>(keep);
+    T* keep_v = reinterpret_cast<T*>(keep_c + cap);
     double* red = rows;
     for (int j = tid; j < sel_words; j += R * 64) bits[j] = sel_bits[j];
     const int r = lane & 15, q = lane >> 4;
@@ -263,6 +269,8 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
         if (p < n) {                                                      // wave-uniform: spots past the end stay zero
             double scale = 1.0;
             bool use_tab = false;
+            int kept = 0;                                                 // selected entries of the row (wave-uniform)
+            bool fits = true;                                             // ... all of them are in keep_c / keep_v
             CsrGroup<T> cur, nxt;
             if (MODE != FDX_PRE_RAW) {  // library size over the SELECTED genes (the subset is taken first, deconv.py:321)
                 double s = 0.0, mx = 0.0;
@@ -270,11 +278,27 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
                 for (long long q0 = beg; q0 < end; q0 += 256) {
                     csr_load_group(nxt, indices, data, q0 + 256, end, lane);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u)) {
+                    for (int u = 0; u < 4; ++u) {
+                        const bool sel = cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u);
+                        if (sel) {
                             s += (double)cur.y[u];
                             mx = fmax(mx, (double)cur.y[u]);
                         }
+                        if (cap > 0) {                                     // stream compaction in CSR order: ballot + prefix count
+                            const unsigned long long m = __ballot(sel);
+                            const int here = __popcll(m);
+                            if (kept + here <= cap) {
+                                if (sel) {
+                                    const int pos = kept + __popcll(m & ((1ULL << lane) - 1ULL));
+                                    keep_c[pos] = cur.c[u];
+                                    keep_v[pos] = cur.y[u];
+                                }
+                            } else {
+                                fits = false;
+                            }
+                            kept += here;
+                        }
+                    }
                     cur = nxt;
                 }
                 s = wave_sum(s);
@@ -282,6 +306,31 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
                 use_tab = !no_table && wave_max(mx) < 64.0;
                 if (use_tab) log1p_table_fill(tab, scale, lane);
             }
+            if (MODE != FDX_PRE_RAW && cap > 0 && fits) {
+                // the row's selected entries from LDS: same entries, same order as the pass over the row below
+                __builtin_amdgcn_s_waitcnt(0xc07f);                        // zeroing, table and kept entries are in LDS
+                for (int i0 = 0; i0 < kept; i0 += 256) {
+                    GeneSlot e[4];
+                    T yv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * 64 + lane;
+                        e[u].bucket = -1;
+                        yv[u] = (T)0;
+                        if (i < kept) {
+                            e[u] = table[keep_c[i]];
+                            yv[u] = keep_v[i];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (e[u].bucket >= 0) {
+                            const double v = log1p_scaled((double)yv[u], scale, tab, use_tab);
+                            lds_add(acc + e[u].bucket, e[u].w * v);
+                        }
+                    }
+                }
+            } else {
             csr_load_group(cur, indices, data, beg, end, lane);
             __builtin_amdgcn_s_waitcnt(0xc07f);                            // zeroing done before the adds
             for (long long q0 = beg; q0 < end; q0 += 256) {
@@ -301,6 +350,7 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
                     }
                 }
                 cur = nxt;
+            }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             if (row_sumsq) {
@@ -351,7 +401,17 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
 
 static size_t csr_contract_lds(int d, int TT, int sel_words) {
     const size_t region = std::max<size_t>(16 * ((size_t)d + CSRF_PAD), (size_t)16 * TT * 4 * 64);
-    return region * 8 + 16 * 64 * 8 + (size_t)sel_words * 4;
+    return region * 8 + 16 * 64 * 8 + (((size_t)sel_words + 3) & ~(size_t)3) * 4;
+}
+
+// log modes: entries per wave of the "selected entries of the row" buffer behind the bitmap - what is left of the 160 KB, in
+// whole wave steps, at most 2048 (FDX_CSR_NO_KEEP=1: none, the row is read twice)
+static int csr_contract_keep(int d, int TT, int sel_words, int value_bytes) {
+    if (getenv("FDX_CSR_NO_KEEP")) return 0;
+    const size_t base = csr_contract_lds(d, TT, sel_words);
+    if (base >= 160 * 1024) return 0;
+    const size_t per_wave = (160 * 1024 - base) / 16 / (size_t)(4 + value_bytes);
+    return (int)std::min<size_t>(per_wave & ~(size_t)63, 2048);
 }
 
 // shapes the fused kernel takes: the A operands of a wave (NB x TT x 4 doubles) must fit beside the gather's registers
@@ -368,14 +428,15 @@ static int launch_csr_contract_m(const long long* indptr, const int* indices, co
                                  const void* table, const unsigned* sel_bits, int sel_words, const double* Xs, int K, double* H,
                                  long long ldh, double* row_sumsq, hipStream_t st) {
     const int NB = (d + 255) / 256, TT = (K + 15) / 16;
-    const size_t lds = csr_contract_lds(d, TT, sel_words);
+    const int cap = MODE == FDX_PRE_RAW ? 0 : csr_contract_keep(d, TT, sel_words, (int)sizeof(T));
+    const size_t lds = csr_contract_lds(d, TT, sel_words) + (size_t)16 * cap * (4 + sizeof(T));
     const int grid = (int)std::min<long long>((n + 15) / 16, 256);
     const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             FDX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, indptr, indices, data, row_map, n, d, (const GeneSlot*)table,
-                           sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, no_table);
+                           sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, no_table, cap);
         FDX_CHECK_LAUNCH();
         return 0;
     };
