@@ -47,6 +47,7 @@ struct TileArgs {
     int NE, GB, NBLK, RS, jw_used;
     int NST;   // stage buffers: 2, or 3 (raw mode with loader waves: two blocks in flight while one is consumed)
     int WB;    // WG form: bytes of a block's weight table at the head of every stage buffer ((GB + 1) doubles, 16-byte rounded)
+    int dbg;   // experiment builds (-DFDX_TILE_EXPERIMENT): phases to skip, timing only
     int NSP, GROW;   // flat form (FF, tile_plan.h: TileFlatHost): off_tab rows of NSP offsets per (wave, block, lane class), len_tab rows of GROW bytes
 };
 
@@ -170,6 +171,9 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         }
     };
     auto issue_stage = [&](const T* const (&rp)[RPL], int c, int buf) -> int {   // returns the instructions issued (wave-uniform)
+#ifdef FDX_TILE_EXPERIMENT
+        if (a.dbg & 1) return 0;
+#endif
         const int gene0 = c * a.GB;
         const int bytes = (min(a.GB, a.G - gene0)) * (int)sizeof(T);
         unsigned char* base = smem + (size_t)buf * stage_bytes + WB;
@@ -316,6 +320,9 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             par ^= 1;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) rowp[k] = rown[k];
+#ifdef FDX_TILE_EXPERIMENT
+            if (!(a.dbg & 8))
+#endif
             for (int rd = 0; rd < ROUNDS; ++rd) {                            // the consumers' reduction
                 lds_barrier();
                 if (PAIR) lds_barrier();
@@ -439,7 +446,11 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
             };
 #pragma unroll
             for (int j = 0; j < JW; ++j) {
+#ifdef FDX_TILE_EXPERIMENT
+                const int len = (a.dbg & 2) ? 0 : (int)((lens[j >> 3] >> ((j & 7) * 8)) & 0xffULL);
+#else
                 const int len = (int)((lens[j >> 3] >> ((j & 7) * 8)) & 0xffULL);
+#endif
                 double an[TT];
                 if (LAST && AVL2) {
                     __builtin_amdgcn_sched_barrier(0);                       // the operand loads of later groups stay with their groups
@@ -467,7 +478,11 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
                     wv = wn;
                     yv = yn;
                 }
+#ifdef FDX_TILE_EXPERIMENT
+                if (LAST && !(a.dbg & 4)) {
+#else
                 if (LAST) {
+#endif
 #pragma unroll
                     for (int t = 0; t < TT; ++t)
                         accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(AVL2 ? an[t] : av[AVL2 ? 0 : j][t], acc[j], accm[t], 0, 0, 0);
@@ -525,6 +540,9 @@ __global__ __launch_bounds__((NWC + NWL) * 64, (NWC + NWL) / 4) void tile_sketch
         double* red = reinterpret_cast<double*>(smem + (size_t)(buf == 0 ? NST - 1 : buf - 1) * stage_bytes);   // the block just consumed: [NR][TS] + [NR][64]
         double* red_sq = red + (size_t)NR * TS;
         const long long s0 = tile * TILE_ROWS;
+#ifdef FDX_TILE_EXPERIMENT
+        if (!(a.dbg & 8))
+#endif
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             lds_barrier();                                                  // the last block's buffer / the previous round's sums are free
@@ -869,6 +887,9 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     TileArgs& a = L.a;
     a.ldy = ldy; a.n = n; a.ldh = ldh; a.G = G; a.d = d; a.K = K;
     a.NE = t->h.NE; a.GB = t->h.GB; a.NBLK = t->h.NBLK; a.RS = t->RS; a.jw_used = t->h.jw_used; a.NST = t->NST; a.WB = t->WB;
+#ifdef FDX_TILE_EXPERIMENT
+    if (const char* e = getenv("FDX_TILE_DBG")) a.dbg = atoi(e);
+#endif
     if (t->fh.NSP > 0) {
         a.NE = (int)t->fh.off.size();
         a.NSP = t->fh.NSP; a.GROW = t->fh.GROW;
