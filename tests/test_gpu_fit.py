@@ -107,6 +107,35 @@ def test_sparse_fit_vs_oracle_odd_shapes(n, G, K, d, n_hvg, pre):
     assert np.array_equal(md.gene_idx_, m.gene_idx_) and rel_fro(md.beta_, m.beta_) < 1e-9
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sparse_rows_longer_than_the_keep_buffer(dtype, monkeypatch):
+    """Fused CSR sketch -> H, log-CPM (csr_kernels.cpp): the library-size pass keeps a row's selected entries in LDS for the sketch
+    pass.  At sketch_dim 1024 the buffer holds 128 (float32) / 64 (float64) entries per row: rows with ~600 selected entries take
+    the two-reads path, rows with ~60 the kept one, in the same launch - both against the oracle (core/deconv.py:181-188,
+    core/sketching.py:194-199) and against the build that always reads twice."""
+    from flashdeconv_amd import FlashDeconv
+    n, G, K, d = 300, 1200, 8, 1024
+    rs = np.random.RandomState(5)
+    X = np.exp(rs.randn(K, G) * 0.7)
+    B = rs.dirichlet(np.ones(K), size=n)
+    dens = np.where(np.arange(n) % 2 == 0, 0.5, 0.05)[:, None]
+    Y = rs.poisson(B @ X * 3.0) * (rs.rand(n, G) < dens)
+    Y[:, 0] += 1
+    coords = rs.rand(n, 2) * 20
+    Ys = sparse.csr_matrix(Y.astype(dtype))
+    assert (np.diff(Ys.indptr) > 400).sum() > 100 and (np.diff(Ys.indptr) < 100).sum() > 100
+    kw = dict(sketch_dim=d, preprocess="log_cpm", n_hvg=2000, max_iter=10, tol=1e-9)
+    m = FlashDeconv(**kw).fit(Ys, X, coords)
+    want = orc.fit(sparse.csr_matrix(Y.astype(np.float64)), X, coords, sketch_dim=d, preprocess_method="log_cpm", n_hvg=2000, max_iter=10,
+                   tol=1e-9, graph="kdtree")
+    tol = 1e-8 if dtype == np.float64 else 1e-5
+    assert m.info_["n_iterations"] == want["info"]["n_iterations"]
+    assert rel_fro(m.beta_, want["beta"]) < tol and rel_fro(m.proportions_, want["proportions"]) < tol
+    monkeypatch.setenv("FDX_CSR_NO_KEEP", "1")
+    m2 = FlashDeconv(**kw).fit(Ys, X, coords)
+    assert rel_fro(m2.beta_, m.beta_) < 1e-10
+
+
 def test_csr_gene_moments_and_validation():
     from flashdeconv_amd import _lib
     from flashdeconv_amd.utils import genes
