@@ -91,7 +91,7 @@ class FlashDeconv:
 
     def __init__(self, sketch_dim=512, lambda_spatial="auto", rho_sparsity=0.01, n_hvg=2000, n_markers_per_type=50,
                  spatial_method="knn", k_neighbors=6, radius=None, max_iter=100, tol=1e-4, preprocess="log_cpm",
-                 random_state=0, verbose=False, knn_ties="index"):
+                 random_state=0, verbose=False, knn_ties="auto"):
         if sketch_dim <= 0:
             raise ValueError(f"sketch_dim must be positive, got {sketch_dim}")
         if k_neighbors < 0:
@@ -125,10 +125,14 @@ class FlashDeconv:
         self.preprocess = preprocess
         self.random_state = random_state
         self.verbose = verbose
-        # additive (not in the reference): how exactly equidistant candidates for the k-th neighbour are taken - "index":
-        # ascending spot index (device rule; a warning reports them), "ckdtree": as the reference's cKDTree query does
-        if knn_ties not in ("index", "ckdtree"):
-            raise ValueError(f"knn_ties must be 'index' or 'ckdtree', got {knn_ties}")
+        # additive (not in the reference): how exactly equidistant candidates for the k-th neighbour are taken (regular lattices
+        # tie on every spot).  "auto" (default): the device build's graph when it met no tie - every tie-free input, at no cost -
+        # and otherwise the fit is repeated on the reference's own choice (cKDTree's traversal order, restated on the host:
+        # csrc/kdtree_order.cpp), so the result is the reference's on lattices too; "ckdtree": the same, decided before the
+        # first solve (one fit, but the graph build is waited for); "index": ascending spot index, the device rule, always
+        # (fastest on lattices; a warning reports the ties, proportions a few 1e-4 from the reference's)
+        if knn_ties not in ("auto", "index", "ckdtree"):
+            raise ValueError(f"knn_ties must be 'auto', 'index' or 'ckdtree', got {knn_ties}")
         self.knn_ties = knn_ties
 
         self.beta_ = None
@@ -406,15 +410,24 @@ class FlashDeconv:
         # with the order the spots are listed in; here the lower spot index wins.  Regular lattices tie on every spot.
         resolved = self.spatial_method == "knn" and self.knn_ties == "ckdtree"
         self.info_["knn_ties"] = (n_ties if resolved else self._graph.knn_ties()) if self.spatial_method == "knn" else 0
+        if self.info_["knn_ties"] and self.knn_ties == "auto":
+            # the device rule chose among equidistant neighbours: repeat the fit on the reference's choice (same inputs; the
+            # graph then comes from the cKDTree restatement).  Tie-free inputs never get here.
+            log(f"k-NN ties on {self.info_['knn_ties']} of {n} spots: fitting again on the reference's (cKDTree) neighbour choice")
+            self.knn_ties = "ckdtree"
+            try:
+                return self.fit(Y, X, coords, cell_type_names=cell_type_names, output=output)
+            finally:
+                self.knn_ties = "auto"
         if self.info_["knn_ties"] and not resolved:
             import warnings
             warnings.warn(
                 f"k-NN ties: {self.info_['knn_ties']} of {n} spots have their k-th and (k+1)-th nearest neighbours at exactly "
                 "the same distance (regular lattice?), so the neighbour graph depends on how ties are broken - here by "
                 "spot index, in the reference by cKDTree's traversal, i.e. by the order the spots are listed in.  "
-                "Proportions can differ from the reference's by a few 1e-4 (relative); knn_ties='ckdtree' reproduces the "
-                "reference's choice (host-side, seconds at a million spots), spatial_method='grid' builds a tie-free graph "
-                "on lattices.", UserWarning, stacklevel=2)
+                "Proportions can differ from the reference's by a few 1e-4 (relative); knn_ties='auto' (the default) or "
+                "'ckdtree' reproduce the reference's choice (host-side, about a second per million spots), "
+                "spatial_method='grid' builds a tie-free graph on lattices.", UserWarning, stacklevel=2)
         # additive diagnostics (not in the reference): per-stage GPU milliseconds
         self.timings_ = {k: float(getattr(info, k)) for k in ("graph_ms", "sketch_ms", "gram_ms", "solve_ms", "finish_ms", "total_ms",
                                                              "prologue_ms", "span_ms")}

@@ -424,12 +424,14 @@ def test_tl_deconvolve_anndata_surface():
         fd.tl.deconvolve(st, ref, cell_type_key="nope")
 
 
+@pytest.mark.parametrize("ties", ["auto", "ckdtree"])
 @pytest.mark.parametrize("name", ["square_k6", "hex_k6", "square100_k6"])
-def test_lattice_k6_with_the_reference_tie_order_is_exact(name):
-    """knn_ties="ckdtree": on lattices where the k-th neighbour is tied (square: every spot) the neighbour lists come from
-    the host restatement of scipy's cKDTree order (csrc/kdtree_order.cpp) - the adjacency is then the reference's index
-    for index and the fit agrees at the usual 1e-8 (the device's own tie rule leaves 4.5e-4 / 3.1e-4, see below).  No
-    warning in this mode; the tie count stays in info_."""
+def test_lattice_k6_with_the_reference_tie_order_is_exact(name, ties):
+    """On lattices where the k-th neighbour is tied (square: every spot) the neighbour lists come from the host restatement of
+    scipy's cKDTree order (csrc/kdtree_order.cpp) - the adjacency is then the reference's index for index and the fit agrees
+    at the usual 1e-8 (the device's own tie rule, knn_ties="index", leaves 4.5e-4 / 3.1e-4, see below).  knn_ties="auto" is
+    the DEFAULT (the fit is repeated on the reference's choice once the device build has reported ties), "ckdtree" decides
+    before the first solve.  No warning in either mode; the tie count stays in info_."""
     import warnings
     from flashdeconv_amd import FlashDeconv
     g = load_golden("lattice.npz")
@@ -437,8 +439,10 @@ def test_lattice_k6_with_the_reference_tie_order_is_exact(name):
     Y, X, _, _ = datagen.count_like(coords.shape[0], 400, 5, 0.1, int(g[f"{name}_seed"]))
     with warnings.catch_warnings():
         warnings.simplefilter("error")
+        kw = {} if ties == "auto" else dict(knn_ties=ties)            # "auto" through the constructor's default
         m = FlashDeconv(sketch_dim=64, preprocess="log_cpm", n_hvg=2000, spatial_method="knn", k_neighbors=6, max_iter=30,
-                        knn_ties="ckdtree").fit(Y, X, coords)
+                        **kw).fit(Y, X, coords)
+        assert m.knn_ties == ties
     A = m.adjacency_
     assert np.array_equal(A.indptr, g[f"{name}_indptr"]) and np.array_equal(A.indices, g[f"{name}_indices"])
     assert m.info_["knn_ties"] > 0 and m.info_["n_iterations"] == int(g[f"{name}_n_iter"])
@@ -455,13 +459,13 @@ def test_lattice_k6_with_the_reference_tie_order_is_exact(name):
         FlashDeconv(knn_ties="lapack")
 
 
-def _lattice_case(name):
+def _lattice_case(name, **kw):
     from flashdeconv_amd import FlashDeconv
     g = load_golden("lattice.npz")
     coords = g[f"{name}_coords"]
     Y, X, _, _ = datagen.count_like(coords.shape[0], 400, 5, 0.1, int(g[f"{name}_seed"]))
     m = FlashDeconv(sketch_dim=64, preprocess="log_cpm", n_hvg=2000, spatial_method=str(g[f"{name}_method"]), k_neighbors=6,
-                    max_iter=30).fit(Y, X, coords)
+                    max_iter=30, **kw).fit(Y, X, coords)
     A = m.adjacency_
     same_graph = np.array_equal(A.indptr, g[f"{name}_indptr"]) and np.array_equal(A.indices, g[f"{name}_indices"])
     return m, g, same_graph
@@ -487,14 +491,14 @@ def test_lattice_without_ties_matches_reference(name):
 def test_square_lattice_k6_tie_deviation_is_bounded(name):
     """k = 6 on a square lattice: every spot has four neighbours at distance 1 and must pick two of the four at sqrt(2).
     The reference inherits cKDTree's traversal order there (an effectively arbitrary pair per spot, degrees 6-10 after the
-    union symmetrisation); this implementation takes the two lowest spot indices (degree 8 in the interior).  Both are
+    union symmetrisation); the device rule (knn_ties="index") takes the two lowest spot indices (degree 8 in the interior).  Both are
     k-NN graphs of the same points; they differ, and so do lambda (through the mean degree) and the abundances: measured
     4.5e-4 (square), 3.1e-4 (hexagonal: ties only along the border) relative Frobenius in the proportions.  That is the size
     of the reference's own dependence on the ORDER in which the same spots are listed (4.9e-4 - 5.2e-4 / 2.1e-4 - 2.6e-4:
     tests/test_oracle.py::test_lattice_ties_make_the_reference_depend_on_spot_order), which bounds what any tie rule other
     than a bit-for-bit cKDTree emulation can achieve.  DESIGN.md §4."""
     with pytest.warns(UserWarning, match="k-NN ties"):               # the deviation is announced, not silent
-        m, g, same_graph = _lattice_case(name)
+        m, g, same_graph = _lattice_case(name, knn_ties="index")
     assert m.info_["knn_ties"] > 0.5 * m.n_spots_ * (name != "hex_k6")  # square: nearly every spot; hexagonal: the border
     assert not same_graph                                            # if this ever holds, tighten the test above instead
     A = m.adjacency_
