@@ -118,6 +118,19 @@ int fdx_graph_localize(const fdx_graph* full, int32_t n_ranks, const int64_t* bo
     return 0;
 }
 
+// test hook: the stored neighbour indices of one row (positions of this graph's own order; for a local graph own rows are
+// 0..n-1 and halo slots n..n_total-1), as the sweeps read them
+int fdx_graph_row_indices(const fdx_graph* g, int64_t row, int32_t* idx_out, int32_t cap, int32_t* deg_out) {
+    FDX_REQUIRE(g && idx_out && deg_out && row >= 0 && row < g->n, "fdx_graph_row_indices: bad arguments");
+    int so = 0, dg = 0;
+    FDX_HIP(hipMemcpy(&so, g->slice_off.as<int>() + (row >> 6), 4, hipMemcpyDeviceToHost));
+    FDX_HIP(hipMemcpy(&dg, g->deg.as<int>() + row, 4, hipMemcpyDeviceToHost));
+    *deg_out = dg;
+    for (int m = 0; m < dg && m < cap; ++m)
+        FDX_HIP(hipMemcpy(idx_out + m, g->ell.as<int>() + ((size_t)so + m) * 64 + (row & 63), 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int fdx_graph_halo_info(const fdx_graph* local, int64_t* n_halo, int32_t* send_counts, int32_t* recv_counts) {
     FDX_REQUIRE(local != nullptr, "fdx_graph_halo_info: null graph");
     if (n_halo) *n_halo = local->n_total - local->n;

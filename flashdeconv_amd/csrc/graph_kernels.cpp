@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ 
     const int* seg = (p < n) ? ell + (size_t)slice_off[p >> 6] * 64 + (p & 63) : ell;
     for (int m = 0; m < dg; ++m) {
         const int q = seg[(size_t)m * 64];
-        if ((q >> 8) == tile) continue;
+        if ((q >> 8) == tile && q < n) continue;          // a LOCAL graph's halo slots n..n_total-1 can carry the last tile's number: they are halo
         unsigned h = ((unsigned)q * 2654435761u) >> 21;   // 11 bits
         int probes = 0;
         while (true) {
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ 
             int slot = 256 + H;   // pad -> zero slot
             if (m < dg) {
                 const int q = seg[(size_t)m * 64];
-                if ((q >> 8) == tile) slot = q & 255;
+                if ((q >> 8) == tile && q < n) slot = q & 255;
                 else {
                     int lo = 0, hi = H;   // lower_bound in the sorted halo list
                     while (lo < hi) { const int mid = (lo + hi) >> 1; if (list[mid] < q) lo = mid + 1; else hi = mid; }

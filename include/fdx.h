@@ -315,6 +315,9 @@ int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
 int fdx_graph_localize(const fdx_graph* full, int32_t n_ranks, const int64_t* bounds, int32_t my_rank, void* stream,
                        fdx_graph** local);
 /* Halo bookkeeping of a local graph: n_halo; send_counts[r] own rows rank r needs; recv_counts[r] halo rows owned by r. */
+/* test hook: the stored neighbour indices of one row as the sweeps read them (positions in this graph's own order; local graph:
+ * own rows 0..n-1, halo slots n..n_total-1); at most cap are written, *deg_out is the row's degree */
+int fdx_graph_row_indices(const fdx_graph* g, int64_t row, int32_t* idx_out, int32_t cap, int32_t* deg_out);
 int fdx_graph_halo_info(const fdx_graph* local, int64_t* n_halo, int32_t* send_counts, int32_t* recv_counts);
 /* Own local indices to send, grouped by destination rank ascending (sum(send_counts) int32 entries, device). */
 int fdx_graph_send_indices_dev(const fdx_graph* local, int32_t* idx_out_dev, void* stream);

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 import datagen
+from conftest import rel_fro
 
 pytestmark = pytest.mark.gpu
 
@@ -488,6 +489,32 @@ def test_native_loop_thread_ranks_equal_single_gpu(W, overlap, monkeypatch):
         assert res[2] == results[0][2]                          # every rank saw the same global statistics
     np.testing.assert_allclose(results[0][2], ref.info_["final_change"], rtol=1e-12)
     assert np.array_equal(_assemble(torch, shards, results, n, K).cpu().numpy(), ref.beta_)
+
+
+def test_native_loop_thread_ranks_against_the_oracle():
+    """A sharded fit compared with the ORACLE directly (not with the single-GPU result): four thread ranks over the native halo
+    exchange, float64 rows, log-CPM - abundances at the usual 1e-8, the reference's iteration count (core/solver.py:104-184 on
+    the whole problem is what every rank's sweeps add up to)."""
+    import torch
+    import fdx_oracle as orc
+    from flashdeconv_amd import _lib
+    from flashdeconv_amd.distributed import diag_mean
+    dev = torch.device("cuda", 0)
+    n, G, K, d, W = 3000, 260, 7, 48, 4
+    Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 23)
+    coords = coords + np.random.RandomState(1).rand(n, 2) * 1e-3
+    want = orc.fit(Y, X, coords, sketch_dim=d, preprocess_method="log_cpm", n_hvg=2000, max_iter=40, tol=1e-6, graph="kdtree")
+    cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
+    Yt = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float64)).to(dev)
+    full, shards = _native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM)
+    lam = float(want["lambda_used"]) if "lambda_used" in want else None
+    if lam is None:
+        lam = 0.005 * diag_mean(shards[0]["XtX_h"]) / max(full.info()[1] / n, 1.0)          # core/spatial.py:181-190
+    rho_eff = 0.01 * diag_mean(shards[0]["XtX_h"])
+    results = _run_native_threads(torch, shards, K, lam, rho_eff, 1e-6, 40)
+    assert results[0][0] == want["info"]["n_iterations"]
+    beta = _assemble(torch, shards, results, n, K).cpu().numpy()
+    assert rel_fro(beta, want["beta"]) < 1e-8
 
 
 def test_native_loop_8_ranks_at_1m_spots_config3():
