@@ -490,6 +490,9 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
                     FDX_HIP(hipStreamWaitEvent(st, c->ev_halo, 0));
                 }
                 FDX_TRY(allreduce(c, a.stats + (size_t)it * 128, 128, true, st));
+                // a rank without rows launches no sweep, and it is sweep it + 1 that folds the slots of sweep it into rel_change[it]:
+                // fold here, or this rank reads 0.0, calls the solve converged after its first chunk and leaves the others waiting
+                if (g->n == 0 && it + 1 < end) FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, it, st));
             }
             FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, end - 1, st));
             FDX_HIP(hipEventRecord(ev1, st));

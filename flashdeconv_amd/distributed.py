@@ -181,6 +181,8 @@ class ShardedSolver:
                     self.sweep_events.append((e0, e1))
                 self.halo(beta[(it + 1) & 1])
                 self.comm.all_reduce_max(stats[it])
+                if self.n_own == 0 and it + 1 < end:
+                    be.fold(stats, rel, it)            # no rows, no sweep: nobody else folds sweep `it` into rel[it] (csrc/comm.cpp)
             be.fold(stats, rel, end - 1)
             rc = rel[done:end].cpu().numpy()
             for j, v in enumerate(rc):

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Randomised sharded fits (thread ranks over the native in-process transport) against the single-GPU fit, bit for bit: odd spot
+counts, 2-7 ranks, clustered coordinates (uneven halos), shards shorter than a tile.  Not a test: a bug net.
+usage: SEED=1 TRIALS=40 python tools/fuzz_sharded.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import datagen  # noqa: E402
+import test_gpu_sharded as T  # noqa: E402
+from flashdeconv_amd import FlashDeconv, _lib  # noqa: E402
+from flashdeconv_amd.distributed import diag_mean  # noqa: E402
+
+rs = np.random.RandomState(int(os.environ.get("SEED", 0)))
+dev = torch.device("cuda", 0)
+bad = 0
+for trial in range(int(os.environ.get("TRIALS", 30))):
+    n = int(rs.choice([600, 1000, 1537, 3000, 4099, 8193, 20000]))
+    W = int(rs.choice([2, 3, 4, 5, 6, 7]))
+    K = int(rs.choice([3, 7, 12, 20]))
+    d = int(rs.choice([16, 48, 64]))
+    G = int(rs.choice([64, 260, 300]))
+    shape = str(rs.choice(["uniform", "clusters", "strip"]))
+    Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, int(rs.randint(1 << 30)))
+    if shape == "clusters":
+        c = rs.rand(12, 2) * 100
+        coords = c[rs.randint(12, size=n)] + rs.randn(n, 2) * rs.choice([0.5, 2.0, 6.0], size=(n, 1))
+    elif shape == "strip":
+        coords = np.stack([rs.rand(n) * n * 0.5, rs.rand(n) * 3.0], axis=1)
+    coords = coords + rs.rand(n, 2) * 1e-3
+    it = int(rs.choice([3, 12, 30]))
+    tag = dict(trial=trial, n=n, W=W, K=K, d=d, G=G, shape=shape, iters=it)
+    print("trial", tag, flush=True)
+    try:
+        ref = FlashDeconv(sketch_dim=d, max_iter=it, tol=1e-9).fit(Y.astype(np.float32), X, coords)
+        cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
+        Yt = torch.from_numpy(Y.astype(np.float32)).to(dev)
+        full, shards = T._native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM)
+        lam, rho_eff = ref.lambda_used_, 0.01 * diag_mean(shards[0]["XtX_h"])
+        results = T._run_native_threads(torch, shards, K, lam, rho_eff, 1e-9, it)
+        beta = T._assemble(torch, shards, results, n, K).cpu().numpy()
+    except Exception as e:
+        bad += 1
+        print("ERROR", type(e).__name__, str(e)[:160], tag)
+        continue
+    same = np.array_equal(beta, ref.beta_)
+    if not same or results[0][0] != ref.info_["n_iterations"]:
+        bad += 1
+        d_ = np.abs(beta - ref.beta_).max(axis=1)
+        print("MISMATCH", tag, "iterations", results[0][0], ref.info_["n_iterations"], "spots differing", int((d_ > 0).sum()))
+print("done; problems:", bad)
