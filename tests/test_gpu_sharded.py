@@ -360,8 +360,9 @@ def test_sharded_class_world1_equals_flashdeconv():
         dist.destroy_process_group()
 
 
-def _native_shards(torch, coords_dev, Y_dev, X, W, d, K, mode, random_state=0):
-    """Cut the problem into W shards (replicated graph build + fdx_graph_localize), prepare H / XtX per shard."""
+def _native_shards(torch, coords_dev, Y_dev, X, W, d, K, mode, random_state=0, fulls=None):
+    """Cut the problem into W shards (replicated graph build - or the ranks' own full-size graphs `fulls`, e.g. from the band
+    recompute - + fdx_graph_localize), prepare H / XtX per shard."""
     from flashdeconv_amd import _lib
     from flashdeconv_amd.core.sketching import countsketch_tables
     from flashdeconv_amd.distributed import shard_bounds
@@ -380,7 +381,7 @@ def _native_shards(torch, coords_dev, Y_dev, X, W, d, K, mode, random_state=0):
     shards = []
     for r in range(W):
         hl = ctypes.c_void_p()
-        _lib.check(lib.fdx_graph_localize(full.handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
+        _lib.check(lib.fdx_graph_localize((fulls[r] if fulls else full).handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
         g = _lib.Graph(hl.value)
         n_own = int(bounds[r + 1] - bounds[r])
         perm = torch.empty(max(n_own, 1), dtype=torch.int32, device=dev)

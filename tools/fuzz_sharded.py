@@ -16,6 +16,30 @@ import test_gpu_sharded as T  # noqa: E402
 from flashdeconv_amd import FlashDeconv, _lib  # noqa: E402
 from flashdeconv_amd.distributed import diag_mean  # noqa: E402
 
+import ctypes  # noqa: E402
+
+
+def band_fulls(cd, n, W, k=6):
+    """Every rank's full-size graph by band recompute (distributed.py: plan, route "band"); None when a walk left its block."""
+    from flashdeconv_amd.distributed import shard_bounds
+    lib = _lib.load()
+    bounds = shard_bounds(n, W)
+    kk = min(k, n - 1) + 1
+    fulls = []
+    for r in range(W):
+        nbr = torch.full((n, kk), -7, dtype=torch.int32, device=cd.device)
+        cnt = torch.full((n,), -7, dtype=torch.int32, device=cd.device)
+        pl, h = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_knn_lists_band_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, k, int(bounds[r]), int(bounds[r + 1]),
+                                                    ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), None, ctypes.byref(pl)))
+        _lib.check(lib.fdx_graph_from_knn_lists_dev(pl, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), int(bounds[r]),
+                                                    int(bounds[r + 1]), None, ctypes.byref(h)))
+        fulls.append(_lib.Graph(h.value))
+    if any(g.knn_far() for g in fulls):
+        return None
+    return fulls
+
+
 rs = np.random.RandomState(int(os.environ.get("SEED", 0)))
 dev = torch.device("cuda", 0)
 bad = 0
@@ -35,12 +59,15 @@ for trial in range(int(os.environ.get("TRIALS", 30))):
     coords = coords + rs.rand(n, 2) * 1e-3
     it = int(rs.choice([3, 12, 30]))
     tag = dict(trial=trial, n=n, W=W, K=K, d=d, G=G, shape=shape, iters=it)
-    print("trial", tag, flush=True)
     try:
         ref = FlashDeconv(sketch_dim=d, max_iter=it, tol=1e-9).fit(Y.astype(np.float32), X, coords)
         cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
         Yt = torch.from_numpy(Y.astype(np.float32)).to(dev)
-        full, shards = T._native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM)
+        build = str(rs.choice(["replicated", "band"]))
+        fulls = band_fulls(cd, n, W) if build == "band" else None
+        tag["build"] = build if fulls is not None or build == "replicated" else "band->far walk, replicated"
+        print("trial", tag, flush=True)
+        full, shards = T._native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM, fulls=fulls)
         lam, rho_eff = ref.lambda_used_, 0.01 * diag_mean(shards[0]["XtX_h"])
         results = T._run_native_threads(torch, shards, K, lam, rho_eff, 1e-9, it)
         beta = T._assemble(torch, shards, results, n, K).cpu().numpy()
