@@ -46,7 +46,7 @@ bad = 0
 for trial in range(int(os.environ.get("TRIALS", 30))):
     n = int(rs.choice([600, 1000, 1537, 3000, 4099, 8193, 20000]))
     W = int(rs.choice([2, 3, 4, 5, 6, 7]))
-    K = int(rs.choice([3, 7, 12, 20]))
+    K = int(rs.choice([3, 7, 12, 20, 33, 50, 64, 70, 100] if os.environ.get("BIGK") else [3, 7, 12, 20]))
     d = int(rs.choice([16, 48, 64]))
     G = int(rs.choice([64, 260, 300]))
     shape = str(rs.choice(["uniform", "clusters", "strip"]))
@@ -77,7 +77,13 @@ for trial in range(int(os.environ.get("TRIALS", 30))):
         continue
     same = np.array_equal(beta, ref.beta_)
     if not same or results[0][0] != ref.info_["n_iterations"]:
-        bad += 1
         d_ = np.abs(beta - ref.beta_).max(axis=1)
-        print("MISMATCH", tag, "iterations", results[0][0], ref.info_["n_iterations"], "spots differing", int((d_ > 0).sum()))
+        rel = float(np.linalg.norm(beta - ref.beta_) / max(np.linalg.norm(ref.beta_), 1e-300))
+        # 65..96 cell types: this driver calls the unpadded entry (LDS-resident sweep), the estimator pads to 72 / 80 / 88 / 96
+        # (register sweep) - other kernels, the same abundances to rounding; bit equality is the contract of equal kernels only
+        if 64 < K <= 96 and rel < 1e-11 and results[0][0] == ref.info_["n_iterations"]:
+            print("rounding-only", tag, "rel", rel)
+            continue
+        bad += 1
+        print("MISMATCH", tag, "iterations", results[0][0], ref.info_["n_iterations"], "spots differing", int((d_ > 0).sum()), "rel", rel)
 print("done; problems:", bad)
