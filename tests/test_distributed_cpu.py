@@ -84,7 +84,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out = {}
-        for case, (n, K, d, max_iter, tol) in {"converges": (1500, 6, 32, 100, 1e-4), "max_iter": (900, 5, 24, 7, 1e-12)}.items():
+        for case, (n, K, d, max_iter, tol) in {"converges": (1500, 6, 32, 100, 1e-4), "max_iter": (900, 5, 24, 7, 1e-12), "empty_rank": (200, 4, 16, 9, 1e-12)}.items():
             Ys, Xs, coords, _ = datagen.sketched_problem(n, K, d, seed=3)
             A = orc.knn_graph_kdtree(coords * 40, 6).tocsr()
             order = np.lexsort((coords[:, 1], np.floor(coords[:, 0] * 8)))          # any locality-preserving order works
@@ -148,7 +148,7 @@ def test_two_gloo_ranks_reproduce_single_process_solve():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[0]["gather_ok"] and got[1]["gather_ok"]
-    for case, (n, K, d, max_iter, tol) in {"converges": (1500, 6, 32, 100, 1e-4), "max_iter": (900, 5, 24, 7, 1e-12)}.items():
+    for case, (n, K, d, max_iter, tol) in {"converges": (1500, 6, 32, 100, 1e-4), "max_iter": (900, 5, 24, 7, 1e-12), "empty_rank": (200, 4, 16, 9, 1e-12)}.items():
         Ys, Xs, coords, _ = datagen.sketched_problem(n, K, d, seed=3)
         A = orc.knn_graph_kdtree(coords * 40, 6)
         want, winfo = orc.bcd_solve(Ys, Xs, A, 0.1, 0.01, max_iter=max_iter, tol=tol)
