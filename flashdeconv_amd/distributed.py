@@ -107,6 +107,18 @@ class TorchComm:
 
     def exchange(self, send_bufs, recv_bufs):
         """send_bufs / recv_bufs: {peer: contiguous tensor}.  Grouped point-to-point."""
+        if self.world > 1 and not getattr(self, "_stream_ordered", None):
+            # nccl / RCCL operations are ordered on the device streams.  Any other backend (gloo in the tests, with W processes on one
+            # GPU) reads device buffers from the HOST as soon as it is called - the kernels that pack them have to be finished
+            # (measured without this: abundances 1e-9 .. 3e-5 off and different from run to run, tools/class_ranks_gloo.py)
+            if getattr(self, "_stream_ordered", None) is None:
+                self._stream_ordered = self.dist.get_backend(self.group) == "nccl"
+            if not self._stream_ordered:
+                for t in list(send_bufs.values()) + list(recv_bufs.values()):
+                    if t.is_cuda:
+                        import torch
+                        torch.cuda.current_stream(t.device).synchronize()
+                        break
         ops = []
         for peer, t in sorted(recv_bufs.items()):
             ops.append(self.dist.P2POp(self.dist.irecv, t, peer, self.group))
