@@ -289,9 +289,23 @@ int fdx_bcd_sweep_dev(const fdx_graph* g, const double* H_dev, int64_t ldh, cons
     FDX_TRY(fdx::graph_meta_sync(g));
     FDX_REQUIRE(g && H_dev && XtX_dev && beta_in && beta_out && stats_dev && rel_change_dev, "fdx_bcd_sweep_dev: null argument");
     FDX_REQUIRE(ld >= g->n_total + 1, "fdx_bcd_sweep_dev: ld must cover own + halo + zero row");
-    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_PAD && sweep_instantiated(K),
-                "fdx_bcd_sweep_dev: K must be in 1..64, or fdx_solver_padded_k of 65..96 cell types, on the sharded path");
+    FDX_REQUIRE(K >= 1 && (sweep_instantiated(K) || K > FDX_MAX_K_PAD),
+                "fdx_bcd_sweep_dev: K must be in 1..64, fdx_solver_padded_k of 65..96 cell types, or above 96");
     if (g->n == 0) return 0;
+    // above 96 types: the LDS-resident sweep (XtX with its rows padded to 16, prepared per call) or the generic one (per-call
+    // scratch) takes the whole shard in one launch, as in fdx_sharded_solve_padded_dev
+    DevBuf scratch;
+    size_t scratch_ld = 0;
+    if (!sweep_instantiated(K)) {
+        PoolStream pool_stream((hipStream_t)stream);
+        if (sweep_uses_lds(K)) {
+            FDX_TRY(scratch.alloc(sweep_lds_pad_doubles(K) * sizeof(double)));
+            FDX_TRY(sweep_lds_prepare(XtX_dev, K, scratch.as<double>(), (hipStream_t)stream));
+        } else {
+            scratch_ld = (size_t)g->n_slices * 64;
+            FDX_TRY(scratch.alloc(scratch_ld * 2 * K * sizeof(double)));
+        }
+    }
     BcdSweepArgs a{};
     a.H = H_dev; a.XtX = XtX_dev; a.beta_in = beta_in; a.beta_out = beta_out;
     a.ell = g->ell.as<int>(); a.slice_off = g->slice_off.as<int>(); a.deg = g->deg.as<int>();
@@ -302,7 +316,7 @@ int fdx_bcd_sweep_dev(const fdx_graph* g, const double* H_dev, int64_t ldh, cons
         a.tiled = 1; a.ell_local = g->ell_local.as<unsigned short>(); a.tile_halo = g->tile_halo.as<int>();
         a.tile_hcnt = g->tile_hcnt.as<int>(); a.n_tiles = g->n_tiles; a.halo_max = g->halo_max;
     }
-    return launch_bcd_sweep(a, nullptr, 0, (hipStream_t)stream);
+    return launch_bcd_sweep(a, scratch.as<double>(), scratch_ld, (hipStream_t)stream);
 }
 
 int fdx_bcd_fold_dev(void* stats_dev, double* rel_change_dev, int32_t it, void* stream) {

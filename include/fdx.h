@@ -339,7 +339,9 @@ int fdx_prepare_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t 
 int fdx_init_beta_dev(double* beta_dev, int64_t ld, int64_t n_fill, int32_t K, void* stream);
 /* One BCD sweep of the own spots of `g` (core/solver.py:104-184).  stats_dev: (max_iter, 128) uint64 slots zeroed by
  * the caller; rel_change_dev: (max_iter) doubles.  Sweep `it` tests sweep it-1's statistics on the device and
- * becomes a no-op once they are below tol, so the caller all-reduces (MAX) slot row it-1 across ranks first. */
+ * becomes a no-op once they are below tol, so the caller all-reduces (MAX) slot row it-1 across ranks first.  K: 1..64, the
+ * fdx_solver_padded_k size of 65..96 cell types (pad planes all zero), or any number above 96.  A graph without own spots: no-op
+ * (the caller folds such a rank's statistics itself: fdx_bcd_fold_dev after every all-reduce). */
 int fdx_bcd_sweep_dev(const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, const double* beta_in,
                       double* beta_out, int64_t ld, int32_t K, double lambda, double rho_eff, double tol, int32_t it,
                       void* stats_dev, double* rel_change_dev, void* stream);

@@ -10,6 +10,42 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 
 
+def cases(n):
+    """name -> dict(G, K, d, pre, n_hvg, family, + options); every rank and the checker build the same problem from it"""
+    import numpy as np
+    c = {"raw": dict(G=300, K=9, d=64, pre="raw", n_hvg=2000, family="gaussian"),
+         "log_cpm_selected": dict(G=900, K=6, d=64, pre="log_cpm", n_hvg=250, family="counts"),
+         "pearson": dict(G=300, K=5, d=48, pre="pearson", n_hvg=2000, family="counts"),
+         "csr_log_cpm_selected": dict(G=900, K=6, d=64, pre="log_cpm", n_hvg=250, family="counts", csr=True, tol=1e-9),
+         "radius": dict(G=300, K=9, d=64, pre="raw", n_hvg=2000, family="gaussian", method="radius"),
+         "grid": dict(G=300, K=9, d=64, pre="raw", n_hvg=2000, family="gaussian", method="grid"),
+         "seventy_types": dict(G=400, K=70, d=128, pre="raw", n_hvg=2000, family="gaussian", tol=1e-9),
+         "hundred_types": dict(G=400, K=100, d=128, pre="raw", n_hvg=2000, family="gaussian"),
+         "int_counts": dict(G=300, K=6, d=64, pre="log_cpm", n_hvg=2000, family="counts", dtype=np.int32),
+         "clusters_far_walks": dict(G=300, K=9, d=64, pre="raw", n_hvg=2000, family="gaussian", clusters=True)}
+    only = os.environ.get("CASES")
+    return {k: v for k, v in c.items() if not only or k in only.split(",")}
+
+
+def make(case, kw, n):
+    import numpy as np
+    import datagen
+    if kw["family"] == "gaussian":
+        Y, X, coords, _ = datagen.gaussian_raw(n, kw["G"], kw["K"], seed=2)
+    else:
+        Y, X, coords, _ = datagen.count_like(n, kw["G"], kw["K"], 0.1, 8)
+    if kw.get("clusters"):
+        rs = np.random.RandomState(3)
+        c = rs.rand(10, 2) * 100
+        coords = c[rs.randint(10, size=n)] + rs.randn(n, 2) * rs.choice([0.3, 2.0, 8.0], size=(n, 1))
+    est = dict(sketch_dim=kw["d"], preprocess=kw["pre"], n_hvg=kw["n_hvg"], n_markers_per_type=10, max_iter=15)
+    if kw.get("method") == "radius":
+        est.update(spatial_method="radius", radius=float(np.sqrt(coords.var(axis=0).sum()) * 0.03))
+    elif kw.get("method") == "grid":
+        est.update(spatial_method="grid")
+    return Y, X, coords, est
+
+
 def worker(rank, W, n, port, q):
     import numpy as np
     import torch
@@ -22,14 +58,19 @@ def worker(rank, W, n, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=W)
     out = {}
     try:
-        for case, (G, K, d, pre, n_hvg) in {"raw": (300, 9, 64, "raw", 2000), "log_cpm_selected": (900, 6, 64, "log_cpm", 250)}.items():
-            if pre == "raw":
-                Y, X, coords, _ = datagen.gaussian_raw(n, G, K, seed=2)
-            else:
-                Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 8)
-            m = ShardedFlashDeconv(sketch_dim=d, preprocess=pre, n_hvg=n_hvg, n_markers_per_type=10, max_iter=25)
+        for case, kw in cases(n).items():
+            Y, X, coords, est = make(case, kw, n)
+            m = ShardedFlashDeconv(**est)
             own = m.plan(torch.from_numpy(coords).to(dev), X)
-            P = m.fit_transform(torch.from_numpy(Y.astype(np.float32)).to(dev)[own], X)
+            Yo = Y[own.cpu().numpy()]
+            if kw.get("csr"):
+                import scipy.sparse as sp
+                S = sp.csr_matrix(Yo.astype(np.float32))
+                Yt = torch.sparse_csr_tensor(torch.from_numpy(S.indptr.astype(np.int64)), torch.from_numpy(S.indices.astype(np.int64)),
+                                             torch.from_numpy(S.data), size=S.shape).to(dev)
+            else:
+                Yt = torch.from_numpy(Yo.astype(kw.get("dtype", np.float32))).to(dev)
+            P = m.fit_transform(Yt, X)
             out[case] = (own.cpu().numpy(), P.cpu().numpy(), m.info_, m.plan_route_, float(m.lambda_used_), np.asarray(m.gene_idx_), m.beta_.cpu().numpy())
         q.put((rank, out))
     finally:
@@ -53,19 +94,22 @@ def main():
     import datagen
     from flashdeconv_amd import FlashDeconv
     bad = 0
-    for case, (G, K, d, pre, n_hvg) in {"raw": (300, 9, 64, "raw", 2000), "log_cpm_selected": (900, 6, 64, "log_cpm", 250)}.items():
-        if pre == "raw":
-            Y, X, coords, _ = datagen.gaussian_raw(n, G, K, seed=2)
+    for case, kw in cases(n).items():
+        Y, X, coords, est = make(case, kw, n)
+        K = X.shape[0]
+        if kw.get("csr"):
+            import scipy.sparse as sp
+            Yin = sp.csr_matrix(Y.astype(np.float32))
         else:
-            Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 8)
-        ref = FlashDeconv(sketch_dim=d, preprocess=pre, n_hvg=n_hvg, n_markers_per_type=10, max_iter=25).fit(Y.astype(np.float32), X, coords)
+            Yin = Y.astype(kw.get("dtype", np.float32))
+        ref = FlashDeconv(**est).fit(Yin, X, coords)
         P = np.zeros((n, K))
         for r in range(W):
             own, Pr, info, route, lam, gidx, Br = got[r][case]
             P[own] = Pr
         rel = float(np.linalg.norm(P - ref.proportions_) / np.linalg.norm(ref.proportions_))
         info0 = got[0][case][2]
-        ok = info0["n_iterations"] == ref.info_["n_iterations"] and rel < 1e-9
+        ok = info0["n_iterations"] == ref.info_["n_iterations"] and rel < kw.get("tol", 1e-12)
         bad += 0 if ok else 1
         print(case, "lambda", got[0][case][4], ref.lambda_used_, "genes equal", bool(np.array_equal(got[0][case][5], ref.gene_idx_)), len(got[0][case][5]), len(ref.gene_idx_))
         print(case, "W", W, "route", got[0][case][3], "iterations", info0["n_iterations"], ref.info_["n_iterations"], "rel", rel, "bits equal",
