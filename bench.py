@@ -368,10 +368,17 @@ def main():
     force_dist = bool(os.environ.get("FDX_BENCH_FORCE_DIST"))       # exercise the sharded driver with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("FDX_BENCH_BACKEND", "nccl") == "gloo":
+            # REHEARSAL of the N > 1 driver on a box with one GPU: every rank on cuda:0, collectives over gloo, the Python exchange
+            # loop instead of the native RCCL one.  Checks the code path and the result line; its numbers mean nothing.
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         barrier = dist.barrier
     else:
         barrier = lambda: None

@@ -508,6 +508,26 @@ def test_sharded_class_three_processes_over_gloo_equal_single_gpu():
     assert "route band" in res.stdout and "route allgather" in res.stdout, res.stdout[-3000:]
 
 
+def test_bench_driver_with_two_ranks_rehearsed_over_gloo():
+    """bench.py --gpus 2 as the driver starts it (it spawns its ranks), REHEARSED on this one GPU: FDX_BENCH_BACKEND=gloo puts both
+    ranks on cuda:0 and the collectives on gloo.  The sharded driver's own code - plan + fit per step, barrier / max-over-ranks
+    timing, the extra timed-sweeps fit, the result line - runs as it will on N GPUs; the numbers mean nothing here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FDX_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spots", "60000"],
+                         capture_output=True, text=True, timeout=400, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["spots_total"] == 60000 and line["scaling"] == "strong"
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["config"]["n_iterations"] >= 1
+    assert line["roofline"] and line["roofline"]["ms_per_launch"] > 0 and "bcd_sweep" in line["roofline"]["kernel"]
+
+
 def test_native_loop_with_ranks_that_own_no_spot():
     """1000 spots over 6 ranks: shard boundaries sit on multiples of 256, so two ranks own nothing.  They launch no sweep, must still
     take part in every exchange and all-reduce and must see the same convergence trace (a sweep folds its predecessor's statistics -
