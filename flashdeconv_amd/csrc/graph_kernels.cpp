@@ -1586,6 +1586,10 @@ static int graph_from_knn_lists_impl(fdx_graph_plan* plan, const int* nbr, const
     trace_host("sym: indegree + scan");
     if (lo == 0 && hi == n) {
         FDX_TRY(rev.alloc((size_t)n * kk * 4));          // whole graph: every list entry is a reverse edge - no read-back
+    } else if (plan->band_rows.p) {
+        // band recompute: only the own rows and the band rows have lists, so at most (own + band) * kk entries point into [lo, hi) -
+        // a bound known on the host: no read-back of the count (a synchronisation per plan)
+        FDX_TRY(rev.alloc(((size_t)(hi - lo) + (size_t)plan->band_cap) * kk * 4 + 4));
     } else {
         int total_in = 0;                                // edges into [lo, hi): known only now
         FDX_HIP(hipMemcpyAsync(&total_in, rev_off.as<int>() + n, 4, hipMemcpyDeviceToHost, st));
