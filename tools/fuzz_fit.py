@@ -23,8 +23,10 @@ for trial in range(int(os.environ.get("TRIALS", 60))):
     kind = str(rs.choice(["dense64", "dense32", "int", "csr"]))
     k_nb = int(rs.choice([1, 3, 6, 12]))
     n_hvg = int(rs.choice([2000, max(5, G // 3)]))
-    dim = int(rs.choice([1, 2, 3]))
+    dim = int(rs.choice([1, 2, 3, 4, 6] if os.environ.get("HIGHDIM") else [1, 2, 3]))
     method = str(rs.choice(["knn", "knn", "radius", "grid"]))
+    if dim > 3:
+        method = "knn"                       # radius / grid graphs take 1-3 coordinate columns
     X = np.exp(rs.randn(K, G) * 0.6)
     B = rs.dirichlet(np.ones(K), size=n)
     Y = rs.poisson(B @ X * 2.0).astype(np.float64)
