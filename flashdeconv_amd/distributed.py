@@ -260,13 +260,19 @@ class ShardedFlashDeconv:
 
     def __init__(self, sketch_dim=512, lambda_spatial="auto", rho_sparsity=0.01, n_hvg=2000, k_neighbors=6,
                  spatial_method="knn", radius=None, max_iter=100, tol=1e-4, preprocess="log_cpm", random_state=0,
-                 group=None, comm=None, n_markers_per_type=50):
+                 group=None, comm=None, n_markers_per_type=50, knn_ties="auto"):
         # the reference's constructor checks and messages (core/deconv.py:105-124), through the single-GPU estimator
         from .core.deconv import FlashDeconv
         self._proto = FlashDeconv(sketch_dim=sketch_dim, lambda_spatial=lambda_spatial, rho_sparsity=rho_sparsity, n_hvg=n_hvg,
                                   n_markers_per_type=n_markers_per_type, spatial_method=spatial_method, k_neighbors=k_neighbors,
                                   radius=radius, max_iter=max_iter, tol=tol, preprocess=preprocess, random_state=random_state)
         self.n_markers_per_type = n_markers_per_type
+        # exactly tied k-th neighbour distances (regular lattices): "auto" / "ckdtree" - the graph is then the reference's own
+        # (cKDTree's choice, restated on the host, csrc/kdtree_order.cpp; every rank builds it from the replicated coordinates and
+        # cuts its own rows out, shards in the CALLER's spot order) as in FlashDeconv; "index" - the device rule, with a warning
+        if knn_ties not in ("auto", "index", "ckdtree"):
+            raise ValueError(f"knn_ties must be 'auto', 'index' or 'ckdtree', got {knn_ties}")
+        self.knn_ties = knn_ties
         self.sketch_dim, self.lambda_spatial, self.rho_sparsity = sketch_dim, lambda_spatial, rho_sparsity
         self.n_hvg, self.k_neighbors, self.spatial_method, self.radius = n_hvg, k_neighbors, spatial_method, radius
         self.max_iter, self.tol, self.preprocess, self.random_state = max_iter, tol, preprocess, random_state
@@ -421,7 +427,19 @@ class ShardedFlashDeconv:
                 self.nnz_total = self._full.info()[1]
                 self.knn_ties_ = self._full.knn_ties() if method == _lib.GRAPH_KNN else 0
         t0 = self._tick("plan_build", t0)
-        if getattr(self, "knn_ties_", 0) and self.comm.rank == 0:
+        self.knn_ties_resolved_ = False
+        if getattr(self, "knn_ties_", 0) and self.spatial_method == "knn" and self.knn_ties != "index":
+            # The device builds chose among equidistant neighbours by spot index; the reference's graph comes from cKDTree's
+            # traversal order.  Every rank has the coordinates: each builds that graph (host, ~1 s per million spots) and takes
+            # its rows.  The graph is in the CALLER's order (no Morton sort), so a shard is a range of the caller's spot numbers.
+            from .utils.graph import ckdtree_knn_adjacency
+            A = ckdtree_knn_adjacency(coords.detach().cpu().numpy().astype(np.float64), int(self.k_neighbors))
+            self._full.close()
+            self._full = _lib.Graph.from_csr(A.indptr, A.indices, n)
+            self.nnz_total = int(A.nnz)
+            self.plan_route_ = "ckdtree"
+            self.knn_ties_resolved_ = True
+        if getattr(self, "knn_ties_", 0) and not self.knn_ties_resolved_ and self.comm.rank == 0:
             import warnings
             warnings.warn(f"k-NN ties: {self.knn_ties_} of {n} spots have their k-th and (k+1)-th nearest neighbours at exactly the "
                           "same distance (regular lattice?): the neighbour graph depends on how ties are broken - here by spot "

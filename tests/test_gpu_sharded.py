@@ -495,7 +495,7 @@ def test_native_loop_thread_ranks_equal_single_gpu(W, overlap, monkeypatch):
 def test_sharded_class_three_processes_over_gloo_equal_single_gpu():
     """ShardedFlashDeconv itself with world = 3: three PROCESSES share this GPU and talk over gloo (tools/class_ranks_gloo.py) - plan
     by band recompute with its real all-reduce, gene statistics reduced over the shards, prepare, the Python exchange loop, the
-    objective's all-reduce.  Rank 0's assembly must equal the single-GPU fit bit for bit in all ten cases of the tool.  The only end-to-end run of the estimator's world > 1 code that one GPU allows."""
+    objective's all-reduce.  Rank 0's assembly must equal the single-GPU fit bit for bit in all eleven cases of the tool.  The only end-to-end run of the estimator's world > 1 code that one GPU allows."""
     import subprocess
     import sys
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "class_ranks_gloo.py")
@@ -504,8 +504,9 @@ def test_sharded_class_three_processes_over_gloo_equal_single_gpu():
     assert "done; problems: 0" in res.stdout, res.stdout[-2000:]
     # raw, log-CPM with gene selection, pearson, CSR shards, radius / grid graphs, 70 and 100 cell types, integer counts, clustered
     # coordinates whose k-NN walks leave their block (band recompute falls back to the list exchange)
-    assert res.stdout.count("bits equal True") == 10, res.stdout[-3000:]
-    assert "route band" in res.stdout and "route allgather" in res.stdout, res.stdout[-3000:]
+    # ... and a square lattice with k = 6: ties on every spot, both estimators then take the reference's (cKDTree) graph
+    assert res.stdout.count("bits equal True") == 11, res.stdout[-3000:]
+    assert "route band" in res.stdout and "route allgather" in res.stdout and "route ckdtree" in res.stdout, res.stdout[-3000:]
 
 
 def test_bench_driver_with_two_ranks_rehearsed_over_gloo():

@@ -22,7 +22,8 @@ def cases(n):
          "seventy_types": dict(G=400, K=70, d=128, pre="raw", n_hvg=2000, family="gaussian", tol=1e-9),
          "hundred_types": dict(G=400, K=100, d=128, pre="raw", n_hvg=2000, family="gaussian"),
          "int_counts": dict(G=300, K=6, d=64, pre="log_cpm", n_hvg=2000, family="counts", dtype=np.int32),
-         "clusters_far_walks": dict(G=300, K=9, d=64, pre="raw", n_hvg=2000, family="gaussian", clusters=True)}
+         "clusters_far_walks": dict(G=300, K=9, d=64, pre="raw", n_hvg=2000, family="gaussian", clusters=True),
+         "lattice_ties": dict(G=300, K=9, d=64, pre="raw", n_hvg=2000, family="gaussian", lattice=True)}
     only = os.environ.get("CASES")
     return {k: v for k, v in c.items() if not only or k in only.split(",")}
 
@@ -38,6 +39,8 @@ def make(case, kw, n):
         rs = np.random.RandomState(3)
         c = rs.rand(10, 2) * 100
         coords = c[rs.randint(10, size=n)] + rs.randn(n, 2) * rs.choice([0.3, 2.0, 8.0], size=(n, 1))
+    if kw.get("lattice"):                  # square lattice, k = 6: every spot ties at its k-th neighbour (two of four at sqrt 2)
+        coords = np.stack([np.arange(n) % 50, np.arange(n) // 50], axis=1).astype(np.float64)
     est = dict(sketch_dim=kw["d"], preprocess=kw["pre"], n_hvg=kw["n_hvg"], n_markers_per_type=10, max_iter=15)
     if kw.get("method") == "radius":
         est.update(spatial_method="radius", radius=float(np.sqrt(coords.var(axis=0).sum()) * 0.03))
