@@ -60,14 +60,17 @@ for trial in range(int(os.environ.get("TRIALS", 30))):
     it = int(rs.choice([3, 12, 30]))
     tag = dict(trial=trial, n=n, W=W, K=K, d=d, G=G, shape=shape, iters=it)
     try:
-        ref = FlashDeconv(sketch_dim=d, max_iter=it, tol=1e-9).fit(Y.astype(np.float32), X, coords)
+        pre = str(rs.choice(["log_cpm", "raw"]))
+        dt = np.float32 if rs.rand() < 0.6 else np.float64
+        tag.update(pre=pre, dtype=dt.__name__)
+        ref = FlashDeconv(sketch_dim=d, max_iter=it, tol=1e-9, preprocess=pre).fit(Y.astype(dt), X, coords)
         cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
-        Yt = torch.from_numpy(Y.astype(np.float32)).to(dev)
+        Yt = torch.from_numpy(Y.astype(dt)).to(dev)
         build = str(rs.choice(["replicated", "band"]))
         fulls = band_fulls(cd, n, W) if build == "band" else None
         tag["build"] = build if fulls is not None or build == "replicated" else "band->far walk, replicated"
         print("trial", tag, flush=True)
-        full, shards = T._native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM, fulls=fulls)
+        full, shards = T._native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM if pre == "log_cpm" else _lib.PRE_RAW, fulls=fulls)
         lam, rho_eff = ref.lambda_used_, 0.01 * diag_mean(shards[0]["XtX_h"])
         results = T._run_native_threads(torch, shards, K, lam, rho_eff, 1e-9, it)
         beta = T._assemble(torch, shards, results, n, K).cpu().numpy()
