@@ -54,6 +54,9 @@ def parse():
                     help="the WHOLE configs[3] job (1M x 2000 x 30) or, with --config 5, configs[4] (10M x 5000 x 50; --spots overrides) "
                          "with this many virtual ranks on one GPU (tools/virtual_ranks.py): per-rank critical path, each rank timed "
                          "alone, the unsharded T1 and the projected speed-up (no RCCL wire time)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=None,
+                    help="--gpus N > 1 started from a bare shell: seconds after which a job whose ranks have produced no result "
+                         "is ended (default 900)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     return ap.parse_args()
@@ -262,27 +265,78 @@ def cpu_baseline(n_cpu, G, K, d, seed=0):
                       f"{dt:.1f} s wall (numpy/scipy stages single-threaded as in the reference, C/OpenMP BCD sweep on {cores} threads)"}
 
 
-def spawn_ranks(n_ranks):
-    """--gpus N > 1 from a bare shell: start the N ranks as fresh child processes (this process never initialises a GPU),
-    relay their output, exit with the worst return code."""
+def spawn_ranks(n_ranks, rendezvous_timeout_s=None):
+    """--gpus N > 1 from a bare shell: start the N ranks as fresh child processes (this process never initialises a GPU), poll
+    them all, relay rank 0's output and exit with the worst return code.  The first rank that exits non-zero ends the job: the
+    others are terminated (they would sit in a collective until the driver's timeout) and the parent returns that code within
+    seconds.  Every rank's stderr goes to a file named by rank (gpurun_out/bench_rank<r>.err, else the temp dir); a rank that
+    produces no result within --rendezvous-timeout seconds of the start (default 900; FDX_BENCH_RDZV_TIMEOUT) ends the job too."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:                       # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    timeout_s = float(rendezvous_timeout_s or os.environ.get("FDX_BENCH_RDZV_TIMEOUT", "900"))
+    logdir = os.path.join(ROOT, "gpurun_out")
+    if not os.path.isdir(logdir) or not os.access(logdir, os.W_OK):
+        logdir = tempfile.gettempdir()
+    procs, errs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        err = open(os.path.join(logdir, f"bench_rank{r}.err"), "wb")
+        errs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    sys.stdout.write(out.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err))
+    t0 = time.monotonic()
+    rc, failed = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed, rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - t0 > timeout_s:
+            failed, rc = next(r for r, c in enumerate(codes) if c is None), 124
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        for p in procs:                               # fresh children of this process only: their exact PIDs
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    for e in errs:
+        e.close()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode(errors="replace"))
     sys.stdout.flush()
+    if failed is not None:
+        why = "produced no result in time" if rc == 124 else f"exited with code {rc}"
+        tail = b""
+        try:
+            with open(os.path.join(logdir, f"bench_rank{failed}.err"), "rb") as f:
+                tail = f.read()[-2000:]
+        except OSError:
+            pass
+        print(f"bench.py: rank {failed} of {n_ranks} {why}; the other ranks were terminated.  Per-rank stderr: "
+              f"{os.path.join(logdir, 'bench_rank<r>.err')}\n--- rank {failed} stderr (tail) ---\n{tail.decode(errors='replace')}",
+              file=sys.stderr)
+    else:                                             # relay rank 0's stderr (RCCL banners, warnings) as before
+        try:
+            with open(os.path.join(logdir, "bench_rank0.err"), "rb") as f:
+                sys.stderr.write(f.read().decode(errors="replace"))
+        except OSError:
+            pass
     sys.exit(rc)
 
 
@@ -343,21 +397,27 @@ def main():
                 "n_gpus": 1, "virtual_ranks": W, "spots": n, "n_iterations": info["n_iterations"][0], "t1_n_iterations": t1_iters,
                 "knn_ties": info["knn_ties"], "nnz": info["nnz"], "n_halo": info["n_halo"], "plan_route": t.get("plan_route"),
                 "per_rank_critical_path_ms": [round(x, 3) for x in crit],
-                "per_rank_stage_ms": {k: t[k] for k in ("knn_lists_ms", "from_lists_ms", "localize_ms", "prepare_ms", "solve_alone_ms",
-                                                         "finish_alone_ms")},
+                "per_rank_stage_sum_ms": [round(x, 3) for x in t.get("per_rank_stage_sum_ms", crit)],
+                "per_rank_stage_ms": {k: t[k] for k in ("plan_ms", "prepare_ms", "solve_alone_ms", "finish_alone_ms") if k in t},
                 "t1_ms": None if t1_ms is None else round(t1_ms, 3),
                 "projected_speedup": None if t1_ms is None else round(t1_ms / max(crit), 2),
-                "projection_note": "projection, no RCCL wire time: every rank's plan + localize + prepare + iteration loop (loopback "
-                                   "transport, same iteration count) + finish, timed alone on one GPU with warm caches; T1 = the same job "
-                                   "unsharded on the same GPU",
+                "projection_note": "projection, no RCCL wire time: every rank's whole share - plan (one queued pipeline), sketch -> H, the "
+                                   "iteration loop (loopback transport, same iteration count), export + objective - timed ALONE on one GPU "
+                                   "as ONE interval with warm caches (per_rank_stage_sum_ms: the same stages synchronised one by one); "
+                                   "T1 = the same job unsharded on the same GPU",
                 "stage_ms": t, "wall_s_incl_generation": round(wall, 2), "data": "synthetic"}
         print(json.dumps(line))
         return
     if a.config == 5:      # the shape of one of the eight shards of BASELINE configs[4] (10M x 5000 x 50, d 1024)
         a.spots, a.genes, a.types, a.sketch_dim, a.family, a.no_cpu_baseline = 1_250_000, 5000, 50, 1024, "gaussian", True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(a.gpus)
+        spawn_ranks(a.gpus, a.rendezvous_timeout)
     if os.environ.get("FDX_BENCH_SPAWN_ECHO"):      # launcher self-test (tests/test_host.py): report the rank environment
+        if os.environ.get("FDX_BENCH_SPAWN_FAIL_RANK") == os.environ.get("RANK"):
+            print("rank asked to fail", file=sys.stderr)
+            sys.exit(3)
+        if os.environ.get("FDX_BENCH_SPAWN_HANG"):    # the others of a failing job: sit as in a collective
+            time.sleep(float(os.environ["FDX_BENCH_SPAWN_HANG"]))
         print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
                          | {"gpus": a.gpus, "scaling": a.scaling}))
         return

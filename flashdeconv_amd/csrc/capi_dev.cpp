@@ -92,7 +92,7 @@ int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, c
 
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream) {
     PoolStream pool_stream((hipStream_t)stream);
-    FDX_TRY(fdx::graph_meta_sync(g));
+    if (!(g && g->shard_pending)) FDX_TRY(fdx::graph_meta_sync(g));   // a queued shard build: the copy below is ordered behind it on the stream
     FDX_REQUIRE(g && (g->n == 0 || perm_out_dev), "fdx_graph_perm_dev: null argument");
     return graph_copy_perm(g, perm_out_dev, (hipStream_t)stream);
 }
@@ -118,6 +118,30 @@ int fdx_graph_localize(const fdx_graph* full, int32_t n_ranks, const int64_t* bo
     return 0;
 }
 
+int fdx_graph_shard_knn_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t k, int32_t n_ranks, const int64_t* bounds,
+                            int32_t my_rank, void* stream, fdx_graph** local) {
+    PoolStream pool_stream((hipStream_t)stream);
+    FDX_REQUIRE(coords_dev && bounds && local, "fdx_graph_shard_knn_dev: null argument");
+    FDX_REQUIRE(n_ranks >= 1 && my_rank >= 0 && my_rank < n_ranks, "fdx_graph_shard_knn_dev: bad rank");
+    *local = nullptr;
+    fdx_graph* g = new fdx_graph();
+    std::vector<long long> b(bounds, bounds + n_ranks + 1);
+    const int rc = graph_shard_knn(coords_dev, n, dim, k, n_ranks, b.data(), my_rank, g, (hipStream_t)stream);
+    if (rc) { delete g; return rc; }
+    *local = g;
+    return 0;
+}
+
+int fdx_graph_shard_status(const fdx_graph* local, int64_t* own_nnz, int64_t* knn_ties, int32_t* far, int32_t* overflow) {
+    FDX_REQUIRE(local != nullptr, "fdx_graph_shard_status: null graph");
+    FDX_TRY(fdx::graph_meta_sync(local));
+    if (own_nnz) *own_nnz = local->nnz;
+    if (knn_ties) *knn_ties = local->knn_ties;
+    if (far) *far = local->knn_far;
+    if (overflow) *overflow = local->shard_overflow;
+    return 0;
+}
+
 // test hook: the stored neighbour indices of one row (positions of this graph's own order; for a local graph own rows are
 // 0..n-1 and halo slots n..n_total-1), as the sweeps read them
 int fdx_graph_row_indices(const fdx_graph* g, int64_t row, int32_t* idx_out, int32_t cap, int32_t* deg_out) {
@@ -133,6 +157,7 @@ int fdx_graph_row_indices(const fdx_graph* g, int64_t row, int32_t* idx_out, int
 
 int fdx_graph_halo_info(const fdx_graph* local, int64_t* n_halo, int32_t* send_counts, int32_t* recv_counts) {
     FDX_REQUIRE(local != nullptr, "fdx_graph_halo_info: null graph");
+    FDX_TRY(fdx::graph_meta_sync(local));
     if (n_halo) *n_halo = local->n_total - local->n;
     const size_t R = local->send_off.empty() ? 0 : local->send_off.size() - 1;
     for (size_t r = 0; r < R; ++r) {
@@ -144,6 +169,7 @@ int fdx_graph_halo_info(const fdx_graph* local, int64_t* n_halo, int32_t* send_c
 
 int fdx_graph_send_indices_dev(const fdx_graph* local, int32_t* idx_out_dev, void* stream) {
     FDX_REQUIRE(local != nullptr, "fdx_graph_send_indices_dev: null graph");
+    FDX_TRY(fdx::graph_meta_sync(local));
     const int total = local->send_off.empty() ? 0 : local->send_off.back();
     if (total == 0) return 0;
     FDX_REQUIRE(idx_out_dev != nullptr, "fdx_graph_send_indices_dev: null output");
@@ -166,17 +192,39 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
     // the schedules of an Omega are built once per content and device (sketch_plan.cpp: the cache the single-GPU fit uses) -
     // at 5000 genes x 1024 buckets building them was 10 of the 23 ms of this call
     std::shared_ptr<SketchPlan> plan_y_p, plan_x_p;
-    FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, st, &plan_y_p));
-    if (weight_x == weight_y) plan_x_p = plan_y_p;
-    else FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, st, &plan_x_p));
+    // The X side (upload of the signatures - a pageable copy: the host waits for it -, X_sketch, XtX and its copy to the host) runs
+    // on the library's side stream: queued on the caller's stream behind a shard plan that is still executing, the upload made
+    // the host wait for the whole plan and the launches behind it arrived on an idle device (70 us of a 125k-spot rank's 1.6 ms).
+    DevBuf dX, dXs, dG, dYs, dRowSq, dSum;     // declared above the drain: on any return both streams are idle before these go back to the pool
+    hipStream_t side = getenv("FDX_NO_SIDE_STREAM") ? nullptr : library_side_stream();
+    if (side == st) side = nullptr;
+    const hipStream_t xs = side ? side : st;
+    struct Drain { hipStream_t a, b; ~Drain() { if (a) (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); } } drain{side, st};
+    hipEvent_t evX = nullptr;
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { if (*e) (void)hipEventDestroy(*e); } } evX_guard{&evX};
+    {
+        PoolStream pool_xs(xs);
+        // a new Omega's tables are uploaded on xs as well (the caller's stream waits for the event below before the sketch)
+        FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, xs, &plan_y_p));
+        if (weight_x == weight_y) plan_x_p = plan_y_p;
+        else FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, xs, &plan_x_p));
+        FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
+        FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
+        FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
+        FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, xs));
+        FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, plan_x_p->dev(), dXs.as<double>(), d, nullptr, xs));
+        FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, xs));
+        if (XtX_out_host)
+            FDX_HIP(hipMemcpyAsync(XtX_out_host, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, xs));
+        if (side) {
+            FDX_HIP(hipEventCreateWithFlags(&evX, hipEventDisableTiming));
+            FDX_HIP(hipEventRecord(evX, side));
+            FDX_HIP(hipStreamWaitEvent(st, evX, 0));
+        }
+    }
+    // the caller's XtX buffer belongs to the caller's stream: filled there, behind the event
+    FDX_HIP(hipMemcpyAsync(XtX_out_dev, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, st));
     SketchPlan& plan_y = *plan_y_p;
-    SketchPlan& plan_x = *plan_x_p;
-    DevBuf dX, dXs, dYs, dRowSq, dSum;
-    FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
-    FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
-    FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, plan_x.dev(), dXs.as<double>(), d, nullptr, st));
-    FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, XtX_out_dev, K, nullptr, st));
     double yty = 0.0;
     if (n > 0) {
         FDX_REQUIRE(Y_dev != nullptr, "fdx_prepare_dev: null Y");
@@ -202,9 +250,8 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
         FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));
         FDX_HIP(hipMemcpyAsync(&yty, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    if (XtX_out_host)
-        FDX_HIP(hipMemcpyAsync(XtX_out_host, XtX_out_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
+    if (side) FDX_HIP(hipStreamSynchronize(side));
     if (YtY_partial_out) *YtY_partial_out = yty;
     return 0;
 }

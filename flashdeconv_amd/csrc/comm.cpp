@@ -124,27 +124,28 @@ namespace {
 
 // ---- halo pack / unpack ---------------------------------------------------------------------------------------------------
 // Send staging: for peer r the (K, cnt_r) block starts at K * send_off[r]; recv staging likewise with recv_off.
+// One thread per (row, type): a rank sends a few thousand rows - a thread per row walking its K planes (K dependent scattered
+// loads) was 18 us of a 36 us sweep at 125k spots; this form is a handful of microseconds.
 __global__ void halo_pack_kernel(const double* __restrict__ beta, long long ld, int K, const int* __restrict__ send_idx,
                                  const int* __restrict__ send_off, int world, int total, double* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (t >= (long long)total * K) return;
+    const int k = (int)(t / total), j = (int)(t - (long long)k * total);
     int r = 0;
     while (r + 1 < world && j >= send_off[r + 1]) ++r;
     const int base = send_off[r], cnt = send_off[r + 1] - base;
-    const int i = send_idx[j];
-    double* o = out + (size_t)K * base + (j - base);
-    for (int k = 0; k < K; ++k) o[(size_t)k * cnt] = beta[(size_t)k * ld + i];
+    out[(size_t)K * base + (size_t)k * cnt + (j - base)] = beta[(size_t)k * ld + send_idx[j]];
 }
 
 __global__ void halo_unpack_kernel(double* __restrict__ beta, long long ld, int K, long long n_own, const int* __restrict__ recv_off,
                                    int world, int total, const double* __restrict__ in) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (t >= (long long)total * K) return;
+    const int k = (int)(t / total), j = (int)(t - (long long)k * total);
     int r = 0;
     while (r + 1 < world && j >= recv_off[r + 1]) ++r;
     const int base = recv_off[r], cnt = recv_off[r + 1] - base;
-    const double* s = in + (size_t)K * base + (j - base);
-    for (int k = 0; k < K; ++k) beta[(size_t)k * ld + n_own + j] = s[(size_t)k * cnt];
+    beta[(size_t)k * ld + n_own + j] = in[(size_t)K * base + (size_t)k * cnt + (j - base)];
 }
 
 // tiles (256 rows) that hold a row some peer needs, and the others
@@ -398,7 +399,7 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
     const int total_send = g->send_off.back(), total_recv = g->recv_off.back();
     FDX_TRY(comm_streams(c));
 
-    DevBuf stats, relchg, send_buf, recv_buf, soff, roff, sweep_scratch;
+    DevBuf stats, send_buf, recv_buf, soff, roff, sweep_scratch;
     size_t scratch_ld = 0;
     if (sweep_uses_lds(K)) {                          // as in solver_run: XtX with its rows padded to 16 for the LDS-resident sweep
         FDX_TRY(sweep_scratch.alloc(sweep_lds_pad_doubles(K) * sizeof(double)));
@@ -408,24 +409,35 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
         FDX_TRY(sweep_scratch.alloc(scratch_ld * 2 * K * sizeof(double)));
     }
     const int iters = std::max<int>(max_iter, 1);
-    FDX_TRY(stats.alloc((size_t)iters * 128 * 8));
-    FDX_TRY(relchg.alloc((size_t)iters * 8));
+    // the max slots of every iteration and, behind them, the rel_change trace: one block, one fill
+    const size_t stats_bytes = (size_t)iters * 128 * 8;
+    FDX_TRY(stats.alloc(stats_bytes + (size_t)iters * 8));
+    double* const relchg_p = reinterpret_cast<double*>(static_cast<char*>(stats.p) + stats_bytes);
     FDX_TRY(send_buf.alloc((size_t)std::max(total_send, 1) * K * 8));
     FDX_TRY(recv_buf.alloc((size_t)std::max(total_recv, 1) * K * 8));
-    FDX_TRY(soff.alloc((size_t)(W + 1) * 4));
-    FDX_TRY(roff.alloc((size_t)(W + 1) * 4));
     FDX_HIP(hipMemsetAsync(stats.p, 0, stats.bytes, st));
-    FDX_HIP(hipMemsetAsync(relchg.p, 0, relchg.bytes, st));
     if (c->loopback) FDX_HIP(hipMemsetAsync(recv_buf.p, 0, recv_buf.bytes, st));   // part of it is never written by the self-copy
-    FDX_HIP(hipMemcpyAsync(soff.p, g->send_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(roff.p, g->recv_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
+    // per-peer offsets of the staging blocks: a graph from the queued shard build (fdx_graph_shard_knn_dev) has them on the device
+    const int* soff_p = g->send_off_dev.as<int>();
+    const int* roff_p = g->recv_off_dev.as<int>();
+    const bool upload_offsets = !soff_p || !roff_p;
+    if (upload_offsets) {
+        FDX_TRY(soff.alloc((size_t)(W + 1) * 4));
+        FDX_TRY(roff.alloc((size_t)(W + 1) * 4));
+        FDX_HIP(hipMemcpyAsync(soff.p, g->send_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
+        FDX_HIP(hipMemcpyAsync(roff.p, g->recv_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
+        soff_p = soff.as<int>();
+        roff_p = roff.as<int>();
+    }
     FDX_TRY(solver_init_beta(beta0_dev, ld, g->n_total, K_real, st, K));     // beta0 = 1/K on own + halo (solver.py:372); pad types 0
+    // the second buffer: only its pad rows and halo columns must read as defined before the first sweep has written the own rows
+    // and the first exchange the halo - a fill of the whole buffer is the simple form of that
     FDX_HIP(hipMemsetAsync(beta1_dev, 0, (size_t)K * ld * 8, st));
-    FDX_HIP(hipStreamSynchronize(st));                                        // the offset vectors are host objects of g
+    if (upload_offsets) FDX_HIP(hipStreamSynchronize(st));                    // the offset vectors are host objects of g
 
     BcdSweepArgs a{};
     a.H = H_dev; a.XtX = XtX_dev; a.ell = g->ell.as<int>(); a.slice_off = g->slice_off.as<int>(); a.deg = g->deg.as<int>();
-    a.stats = stats.as<unsigned long long>(); a.rel_change = relchg.as<double>();
+    a.stats = stats.as<unsigned long long>(); a.rel_change = relchg_p;
     a.lambda = lambda; a.rho = rho_eff; a.tol = tol; a.ldh = (int)ldh; a.ld = (int)ld; a.n = (int)g->n;
     a.n_slices = g->n_slices; a.K = K;
     const bool tiled = g->tiled && !getenv("FDX_NO_TILED");
@@ -435,78 +447,107 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
     }
     // boundary-first ordering needs the tiled sweep (tile lists) and somebody to talk to
     bool split = tiled && bcd_sweep_uses_tiles(a) && total_send > 0 && g->n > 0 && !getenv("FDX_NO_OVERLAP");
+    // ... and a shard large enough for the split to pay: a sweep launch lasts at least one workgroup's life (~25-35 us) however few
+    // tiles it has, so below ~2 rounds of resident workgroups (256 CUs x 3) boundary + interior cost two such lives for the work of
+    // one - 125k-spot shards: 36 + 34 us against 36 - and the interior sweep is too short to hide anything behind
+    const int split_min_tiles = getenv("FDX_SPLIT_MIN_TILES") ? atoi(getenv("FDX_SPLIT_MIN_TILES")) : 1536;
+    if (split && g->n_tiles < split_min_tiles) split = false;
     if (split) {
-        FDX_TRY(build_tile_lists(*g, st));
+        FDX_TRY(build_tile_lists(*g, st));          // no-op for a graph of the queued shard build: its lists were made on the device
         split = g->n_tiles_boundary > 0 && g->n_tiles_interior > 0;
     }
 
-    std::vector<double> rc_host((size_t)iters, 0.0);
+    // the trace lands in pinned host memory behind an event; while the host waits for it the first iterations of the NEXT chunk
+    // are already queued (no-ops if this chunk converged: device-side stopping rule), as in solver_run
+    double* rc_host = (double*)pinned_scratch(2, (size_t)iters * sizeof(double));
+    FDX_REQUIRE(rc_host != nullptr, "sharded solve: pinned host buffer");
+    for (int j = 0; j < iters; ++j) rc_host[j] = 0.0;
     int done = 0, n_iter = 0, chunk = 4;
     bool converged = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    FDX_HIP(hipEventCreate(&ev0));
-    FDX_HIP(hipEventCreate(&ev1));
+    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evCopy = nullptr;
+    struct EvGuard { hipEvent_t* e[5]; ~EvGuard() { for (auto* q : e) if (*q) (void)hipEventDestroy(*q); } } ev_guard{{&ev0[0], &ev0[1], &ev1[0], &ev1[1], &evCopy}};
+    for (int j = 0; j < 2; ++j) {
+        FDX_HIP(hipEventCreate(&ev0[j]));
+        FDX_HIP(hipEventCreate(&ev1[j]));
+    }
+    FDX_HIP(hipEventCreateWithFlags(&evCopy, hipEventDisableTiming));
     double sweep_ms = 0.0;
     double* beta[2] = {beta0_dev, beta1_dev};
+    // the in-process transport meets at host barriers: nothing is gained by queueing ahead there
+    const int n_ahead = (c->local || getenv("FDX_NO_SWEEP_AHEAD")) ? 0 : 2;
+    auto iterate = [&](int it, bool last_of_chunk) -> int {
+        a.it = it;
+        a.beta_in = beta[it & 1];
+        a.beta_out = beta[(it + 1) & 1];
+        hipStream_t sx = st;                                          // stream of the halo traffic
+        if (g->n > 0) {
+            if (split) {
+                a.tile_list = g->tiles_boundary.as<int>(); a.n_list = g->n_tiles_boundary;
+                FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));
+            } else {
+                a.tile_list = nullptr; a.n_list = 0;
+                FDX_TRY(launch_bcd_sweep(a, sweep_scratch.as<double>(), scratch_ld, st));
+            }
+        }
+        if (total_send > 0) {
+            hipLaunchKernelGGL(halo_pack_kernel, dim3(ceil_div((long long)total_send * K, 256)), dim3(256), 0, st, a.beta_out, (long long)ld, K,
+                               g->send_idx.as<int>(), soff_p, W, total_send, send_buf.as<double>());
+            FDX_CHECK_LAUNCH();
+        }
+        if (split) {
+            FDX_HIP(hipEventRecord(c->ev_packed, st));
+            a.tile_list = g->tiles_interior.as<int>(); a.n_list = g->n_tiles_interior;
+            FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));             // beside the halo traffic
+            sx = c->side;
+            FDX_HIP(hipStreamWaitEvent(sx, c->ev_packed, 0));
+        }
+        if (c->local || total_send > 0 || total_recv > 0)      // the in-process transport meets at barriers
+            FDX_TRY(exchange(c, send_buf.as<double>(), g->send_off, recv_buf.as<double>(), g->recv_off, K, sx));
+        if (total_recv > 0) {
+            hipLaunchKernelGGL(halo_unpack_kernel, dim3(ceil_div((long long)total_recv * K, 256)), dim3(256), 0, sx, a.beta_out, (long long)ld, K,
+                               (long long)g->n, roff_p, W, total_recv, recv_buf.as<double>());
+            FDX_CHECK_LAUNCH();
+        }
+        if (split) {
+            FDX_HIP(hipEventRecord(c->ev_halo, sx));
+            FDX_HIP(hipStreamWaitEvent(st, c->ev_halo, 0));
+        }
+        FDX_TRY(allreduce(c, a.stats + (size_t)it * 128, 128, true, st));
+        // a rank without rows launches no sweep, and it is sweep it + 1 that folds the slots of sweep it into rel_change[it]:
+        // fold here, or this rank reads 0.0, calls the solve converged after its first chunk and leaves the others waiting
+        if (g->n == 0 && !last_of_chunk) FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, it, st));
+        return 0;
+    };
     auto run = [&]() -> int {
+        int queued_ahead = 0, ci = 0;
         while (done < max_iter && !converged) {
             const int end = std::min<int>(max_iter, done + chunk);
-            FDX_HIP(hipEventRecord(ev0, st));
-            for (int it = done; it < end; ++it) {
-                a.it = it;
-                a.beta_in = beta[it & 1];
-                a.beta_out = beta[(it + 1) & 1];
-                hipStream_t sx = st;                                          // stream of the halo traffic
-                if (g->n > 0) {
-                    if (split) {
-                        a.tile_list = g->tiles_boundary.as<int>(); a.n_list = g->n_tiles_boundary;
-                        FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));
-                    } else {
-                        a.tile_list = nullptr; a.n_list = 0;
-                        FDX_TRY(launch_bcd_sweep(a, sweep_scratch.as<double>(), scratch_ld, st));
-                    }
-                }
-                if (total_send > 0) {
-                    hipLaunchKernelGGL(halo_pack_kernel, dim3(ceil_div(total_send, 256)), dim3(256), 0, st, a.beta_out, (long long)ld, K,
-                                       g->send_idx.as<int>(), soff.as<int>(), W, total_send, send_buf.as<double>());
-                    FDX_CHECK_LAUNCH();
-                }
-                if (split) {
-                    FDX_HIP(hipEventRecord(c->ev_packed, st));
-                    a.tile_list = g->tiles_interior.as<int>(); a.n_list = g->n_tiles_interior;
-                    FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));             // beside the halo traffic
-                    sx = c->side;
-                    FDX_HIP(hipStreamWaitEvent(sx, c->ev_packed, 0));
-                }
-                if (c->local || total_send > 0 || total_recv > 0)      // the in-process transport meets at barriers
-                    FDX_TRY(exchange(c, send_buf.as<double>(), g->send_off, recv_buf.as<double>(), g->recv_off, K, sx));
-                if (total_recv > 0) {
-                    hipLaunchKernelGGL(halo_unpack_kernel, dim3(ceil_div(total_recv, 256)), dim3(256), 0, sx, a.beta_out, (long long)ld, K,
-                                       (long long)g->n, roff.as<int>(), W, total_recv, recv_buf.as<double>());
-                    FDX_CHECK_LAUNCH();
-                }
-                if (split) {
-                    FDX_HIP(hipEventRecord(c->ev_halo, sx));
-                    FDX_HIP(hipStreamWaitEvent(st, c->ev_halo, 0));
-                }
-                FDX_TRY(allreduce(c, a.stats + (size_t)it * 128, 128, true, st));
-                // a rank without rows launches no sweep, and it is sweep it + 1 that folds the slots of sweep it into rel_change[it]:
-                // fold here, or this rank reads 0.0, calls the solve converged after its first chunk and leaves the others waiting
-                if (g->n == 0 && it + 1 < end) FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, it, st));
-            }
+            const int pair = ci & 1;
+            if (queued_ahead == 0) FDX_HIP(hipEventRecord(ev0[pair], st));
+            for (int it = done + queued_ahead; it < end; ++it) FDX_TRY(iterate(it, it + 1 == end));
             FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, end - 1, st));
-            FDX_HIP(hipEventRecord(ev1, st));
-            FDX_HIP(hipMemcpyAsync(rc_host.data() + done, relchg.as<double>() + done, (size_t)(end - done) * 8, hipMemcpyDeviceToHost, st));
-            FDX_HIP(hipStreamSynchronize(st));
+            FDX_HIP(hipEventRecord(ev1[pair], st));
+            FDX_HIP(hipMemcpyAsync(rc_host + done, relchg_p + done, (size_t)(end - done) * 8, hipMemcpyDeviceToHost, st));
+            FDX_HIP(hipEventRecord(evCopy, st));
+            int ahead = 0;
+            if (end < max_iter && n_ahead > 0) {
+                ahead = std::min(n_ahead, max_iter - end);
+                FDX_HIP(hipEventRecord(ev0[pair ^ 1], st));
+                // a rank without rows folds sweep it in iteration it itself unless it is the last of its chunk: these are not
+                for (int it = end; it < end + ahead; ++it) FDX_TRY(iterate(it, false));
+            }
+            FDX_HIP(hipEventSynchronize(evCopy));
             float ms = 0.f;
-            FDX_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+            FDX_HIP(hipEventElapsedTime(&ms, ev0[pair], ev1[pair]));
             sweep_ms += ms;
             for (int it = done; it < end; ++it) {
                 n_iter = it + 1;
                 if (rc_host[(size_t)it] < tol) { converged = true; break; }   // solver.py:409-413
             }
             done = end;
-            chunk = std::min(chunk * 2, 32);
+            queued_ahead = ahead;
+            chunk = std::max(std::min(ci == 0 ? chunk : chunk * 2, 32), ahead);
+            ++ci;
         }
         return 0;
     };
@@ -514,8 +555,6 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
     if (rc && c->local) c->local->abort();     // the other thread ranks leave their barriers with an error instead of hanging
     (void)hipStreamSynchronize(st);
     if (c->side) (void)hipStreamSynchronize(c->side);
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     if (rc) return rc;
     info->n_iterations = n_iter;
     info->converged = converged ? 1 : 0;

@@ -62,6 +62,17 @@ struct fdx_graph {
     // overflowed) - a band-recompute shard build is then not guaranteed to hold every reverse edge
     mutable int knn_far = 0;
     mutable struct fdx_graph_plan* keep_plan = nullptr;
+    // Deferred SHARD build (graph_shard_knn, graph_kernels.cpp): the local graph of one rank - lists of own rows + band,
+    // symmetrise, halo, local ELL, tile tables, send lists, boundary / interior tile lists - queued without a host round trip
+    // after the bounding box.  What only the device knows (n_total, send_off / recv_off, nnz, ties, far, overflow flags)
+    // arrives in the pinned block behind meta_event; graph_meta_sync() takes it over.  send_off_dev / recv_off_dev are the
+    // per-peer offsets (n_ranks + 1 ints) the pack / unpack kernels of the native loop read.
+    mutable bool shard_pending = false;
+    mutable struct fdx_shard_build* keep_shard = nullptr;   // every buffer the queued kernels read
+    mutable int shard_overflow = 0;                          // a bound of the deferred build was too small: rebuild by the stepwise path
+    int shard_world = 0;
+    long long shard_ell_cap = 0, shard_send_cap = 0, shard_halo_cap = 0;
+    fdx::DevBuf send_off_dev, recv_off_dev;
     // recorded by fdx_graph_build_dev ahead of the first kernel of the build, on begin_stream: the fit's prologue timer starts here
     hipEvent_t begin_event = nullptr;
     hipStream_t begin_stream = nullptr;

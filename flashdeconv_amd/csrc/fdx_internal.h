@@ -64,8 +64,12 @@ void pool_trim();   // return every cached block to the driver
 // Thread-local pinned host scratch, a few grow-only slots: the target of asynchronous device-to-host copies (into pageable
 // memory hipMemcpyAsync returns only when the copy has been done, i.e. the host waits for everything queued before it).
 void* pinned_scratch(int slot, size_t bytes);   // nullptr on failure; slot 0..7
-void* pinned_block_get();                        // a recycled 64-byte pinned block (nullptr on failure) ...
+constexpr size_t FDX_PINNED_BLOCK_BYTES = 1024;
+void* pinned_block_get();                        // a recycled pinned block of FDX_PINNED_BLOCK_BYTES (nullptr on failure) ...
 void pinned_block_put(void* p);                  // ... and back
+
+// the library's per-device non-blocking side stream (its own priority: fit.cpp); nullptr if it cannot be made
+hipStream_t library_side_stream();
 
 struct DevBuf {
     void* p = nullptr;

@@ -81,8 +81,15 @@ struct fdx_leverage_job {
     hipStream_t st = nullptr;
 };
 
+namespace fdx {
+hipStream_t library_side_stream();
+}
 namespace {
-hipStream_t leverage_side_stream() {
+hipStream_t leverage_side_stream() { return fdx::library_side_stream(); }
+}
+namespace fdx {
+// the library's per-device side stream (leverage job, the X-side preamble of a fit / a shard's prepare, the export)
+hipStream_t library_side_stream() {
     static hipStream_t streams[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -98,7 +105,7 @@ hipStream_t leverage_side_stream() {
     }
     return streams[dev];
 }
-}  // namespace
+}  // namespace fdx
 
 extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double regularization, fdx_leverage_job** out) {
     FDX_REQUIRE(X && out && K > 0 && G > 0, "fdx_leverage_begin: bad arguments");

@@ -27,6 +27,11 @@ int graph_export_csr(const fdx_graph* g, long long* d_indptr, int* d_indices, hi
 // Shard [lo, hi) of a full coordinate-built graph for rank `my_rank` of `n_ranks` (bounds: n_ranks+1 range starts).
 int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_ranks, const long long* bounds, int my_rank,
                    fdx_graph* loc, hipStream_t st);
+// The local graph of rank `my_rank` of a k-NN job in ONE queued pipeline (lists of own rows + band, symmetrise, halo, local ELL,
+// tile tables, send lists, boundary / interior tile lists): nothing returns to the host after the bounding box; graph_meta_sync(loc)
+// takes over the counts (loc->shard_overflow: a bound was too small - rebuild by knn_lists / from_knn_lists / localize).
+int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_ranks, const long long* bounds, int my_rank,
+                    fdx_graph* loc, hipStream_t st);
 // solver position -> caller's spot id, device int32 (n)
 int graph_copy_perm(const fdx_graph* g, int* d_out, hipStream_t st);
 

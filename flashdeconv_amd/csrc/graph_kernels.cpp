@@ -325,10 +325,22 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
                                                   long long lo, long long hi, int* __restrict__ indeg,
                                                   int* __restrict__ arrival, int* __restrict__ tie_count, int gp_no_batch,
                                                   const int* __restrict__ row_list, const int* __restrict__ row_count,
-                                                  int* __restrict__ far_flag, int far_R, int far_drop) {
-    // rows [lo, hi) of the sorted order, or (row_list != NULL: the band of a spot shard) the first min(*row_count, hi) listed rows
+                                                  int* __restrict__ far_flag, int far_R, int far_drop, int n_direct, int list_cap) {
+    // rows [lo, hi) of the sorted order, or (row_list != NULL: the band of a spot shard) the first min(*row_count, hi) listed rows,
+    // or (n_direct >= 0: a spot shard's own rows AND its band in one launch - each of the two launches lasted one walk's latency,
+    // ~50 us, whatever its size) rows lo .. lo + n_direct - 1 followed by the first min(*row_count, list_cap) listed rows; ties and
+    // far walks are counted for the own rows only
     long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (row_list) {
+    bool listed = false;
+    if (n_direct >= 0) {
+        const long long i = p - lo;
+        if (i >= n_direct) {
+            const long long j = i - n_direct;
+            if (j >= list_cap || j >= (long long)*row_count) return;
+            p = row_list[j];
+            listed = true;
+        }
+    } else if (row_list) {
         if (p >= hi || p >= (long long)*row_count) return;
         p = row_list[p];
     } else if (p >= hi) return;
@@ -460,7 +472,10 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     // a walk that went past shell far_R of its cell: a spot shard's band (the rows of the cells within far_R cells of an own one)
     // then does not hold every row that can point at an own row - the sharded build falls back to exchanging the lists
     const bool went_far = R_end > far_R + 1;
-    if (far_flag && __ballot(went_far) != 0ULL && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(went_far)) - 1)) atomicOr(far_flag, 1);
+    {
+        const unsigned long long mf = __ballot(went_far && !listed);
+        if (far_flag && mf != 0ULL && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)mf) - 1)) atomicOr(far_flag, 1);
+    }
     // a spot shard with band recompute lays out only the cells within reach of such walks (bin_points): what a longer walk
     // met there is not data.  Its row gets an empty list - the build is redone by exchange anyway (far_flag; for a band row
     // the rank that owns it raises it).
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     // the index-ordered route.
     const bool tie = (KMAX > kk) ? (next == thr && thr < INFINITY) : true;
     if (tie_count) {
-        const unsigned long long m = __ballot(tie);
+        const unsigned long long m = __ballot(tie && !listed);
         if (m != 0ULL && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(tie_count, (int)__popcll(m));
     }
     if (__ballot(tie) != 0ULL) {
@@ -648,14 +663,51 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const int* __restrict__ 
     }
 }
 
+// The same band from the need flags of the shard's binning (cell_need_kernel<0>: the keys within BAND_R cells of a key that holds
+// an own row - exactly the band's cells): one thread per key, the rows of a flagged key outside [lo, hi) appended with one atomic
+// per wave.  (band_cells_kernel + band_rows_kernel: 25 flag reads per OWN ROW and an atomic per band row - 55 + 17 us for a
+// 125k-row shard whose whole k-NN search is 60.)
+__global__ __launch_bounds__(256) void band_rows_need_kernel(const int* __restrict__ start, long long bins,
+                                                             const unsigned char* __restrict__ need1, long long lo, long long hi,
+                                                             int cap, int* __restrict__ band, int* __restrict__ counters) {
+    const long long k = blockIdx.x * 256LL + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int s0 = 0, s1 = 0;
+    if (k < bins && need1[k]) { s0 = start[k]; s1 = start[k + 1]; }
+    // rows of the key are positions [s0, s1); those inside [lo, hi) are own rows
+    const int a0 = (int)min((long long)s1, max((long long)s0, lo)), a1 = (int)max((long long)a0, min((long long)s1, hi));   // own part [a0, a1)
+    const int cnt = (s1 - s0) - (a1 - a0);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 63) base = atomicAdd(&counters[1], total);
+    base = __shfl(base, 63, 64);
+    int at = base + incl - cnt;
+    for (int q = s0; q < s1; ++q) {
+        if (q >= a0 && q < a1) continue;
+        if (at < cap) band[at] = q;
+        else counters[3] = 1;
+        ++at;
+    }
+}
+
 // indegree / reverse lists of a shard over the rows that HAVE lists: [lo, hi) and the band (every other row is skipped without a
 // look at its count)
+// n_direct >= 0: threads 0 .. n_direct - 1 take the own rows lo + i, the following ones the listed rows (one launch for both)
 __global__ __launch_bounds__(256) void indegree_rows_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt, int kk,
                                                             int* __restrict__ indeg, int lo, int hi, const int* __restrict__ rows,
-                                                            const int* __restrict__ n_rows, int cap) {
-    const long long i = blockIdx.x * 256LL + threadIdx.x;
+                                                            const int* __restrict__ n_rows, int cap, int n_direct = -1) {
+    long long i = blockIdx.x * 256LL + threadIdx.x;
     long long p;
-    if (rows) { if (i >= cap || i >= *n_rows) return; p = rows[i]; } else { p = lo + i; if (p >= hi) return; }
+    if (n_direct >= 0 && i < n_direct) p = lo + i;
+    else if (rows) { if (n_direct >= 0) i -= n_direct; if (i >= cap || i >= *n_rows) return; p = rows[i]; }
+    else { p = lo + i; if (p >= hi) return; }
     for (int m = 0; m < nbr_cnt[p]; ++m) {
         const int q = nbr[(size_t)p * kk + m];
         if (q >= lo && q < hi) atomicAdd(&indeg[q], 1);
@@ -665,10 +717,12 @@ __global__ __launch_bounds__(256) void indegree_rows_kernel(const int* __restric
 __global__ __launch_bounds__(256) void fill_reverse_rows_kernel(const int* __restrict__ nbr, const int* __restrict__ nbr_cnt, int kk,
                                                                 const int* __restrict__ rev_off, int* __restrict__ cursor,
                                                                 int* __restrict__ rev, int lo, int hi, const int* __restrict__ rows,
-                                                                const int* __restrict__ n_rows, int cap) {
-    const long long i = blockIdx.x * 256LL + threadIdx.x;
+                                                                const int* __restrict__ n_rows, int cap, int n_direct = -1) {
+    long long i = blockIdx.x * 256LL + threadIdx.x;
     long long p;
-    if (rows) { if (i >= cap || i >= *n_rows) return; p = rows[i]; } else { p = lo + i; if (p >= hi) return; }
+    if (n_direct >= 0 && i < n_direct) p = lo + i;
+    else if (rows) { if (n_direct >= 0) i -= n_direct; if (i >= cap || i >= *n_rows) return; p = rows[i]; }
+    else { p = lo + i; if (p >= hi) return; }
     for (int m = 0; m < nbr_cnt[p]; ++m) {
         const int q = nbr[(size_t)p * kk + m];
         if (q >= lo && q < hi) rev[rev_off[q] + atomicAdd(&cursor[q], 1)] = (int)p;
@@ -1112,10 +1166,14 @@ static int make_grid(const double* d_coords, long long n, int dim, double target
 
 struct BinnedPoints {
     GridParams gp;
-    DevBuf perm, rank, sc, sc2, cstart, cend;      // sc2: (x, y) pairs of the sorted points, dim <= 2 only
-    DevBuf keys, vals, skeys, sort_tmp, count, start, scan_tmp, need;   // sort temporaries: kept until the struct dies so that binning needs no final sync
+    DevBuf perm, rank, sc, sc2, cstart;            // sc2: (x, y) pairs of the sorted points, dim <= 2 only; cstart also holds cend, the key counters and the need flags
+    int* cend_p = nullptr;                         // cell -> end of its range (inside cstart's block)
+    int* count_p = nullptr;                        // counting path: members per key
+    unsigned char* need_p = nullptr;               // spot shards: [bins] keys within BAND_R cells of an own key, [bins] within 2 BAND_R
+    DevBuf keys, vals, skeys, sort_tmp, start, scan_tmp;   // sort temporaries: kept until the struct dies so that binning needs no final sync
     long long n = 0;
     int n_cells = 0;
+    long long bins = 0;            // counting path: size of the Morton key space (start has bins + 1 entries); 0 on the sorting path
 };
 
 // shard_lo < shard_hi: a spot shard's binning - the ranking pass lays out only the cells the shard's build looks at
@@ -1137,8 +1195,6 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     FDX_TRY(b->rank.alloc((size_t)n * 4));
     FDX_TRY(b->sc.alloc((size_t)n * 3 * sizeof(double)));
     if (dim <= 2) FDX_TRY(b->sc2.alloc((size_t)n * 2 * sizeof(double)));
-    FDX_TRY(b->cstart.alloc((size_t)b->n_cells * 4));
-    FDX_TRY(b->cend.alloc((size_t)b->n_cells * 4));
     trace_host("bin: allocations");
     const int nb = ceil_div(n, 256);
     typedef unsigned long long u64;
@@ -1146,34 +1202,42 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     int axis_bits = 1;
     while ((1LL << axis_bits) < (long long)max_axis) ++axis_bits;
     const int bits = std::min(64, axis_bits * dim);      // significant bits of the Morton key
-    FDX_HIP(hipMemsetAsync(b->cstart.p, 0, b->cstart.bytes, st));
-    FDX_HIP(hipMemsetAsync(b->cend.p, 0, b->cend.bytes, st));
-    trace_host("bin: 2 memsets");
+    const bool counting = bits <= 22 && (1LL << bits) <= 8 * n + 1024 && !getenv("FDX_GRAPH_SORT");
+    const bool shard_need = counting && shard_hi > shard_lo && (shard_lo > 0 || shard_hi < n) && shard_R > 0 && !getenv("FDX_BAND_FULL_BINNING");
+    {
+        // the cell table, the key counters and (spot shards) the need flags start as zero: one block, one fill
+        auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
+        const size_t cells_b = up16((size_t)b->n_cells * 4);
+        const size_t count_b = counting ? up16((size_t)((1LL << bits) + 1) * 4) : 0;
+        const size_t need_b = shard_need ? up16((size_t)(1LL << bits) * 2) : 0;
+        FDX_TRY(b->cstart.alloc(2 * cells_b + count_b + need_b));
+        FDX_HIP(hipMemsetAsync(b->cstart.p, 0, 2 * cells_b + count_b + need_b, st));
+        b->cend_p = reinterpret_cast<int*>(static_cast<char*>(b->cstart.p) + cells_b);
+        b->count_p = counting ? reinterpret_cast<int*>(static_cast<char*>(b->cstart.p) + 2 * cells_b) : nullptr;
+        b->need_p = shard_need ? reinterpret_cast<unsigned char*>(static_cast<char*>(b->cstart.p) + 2 * cells_b + count_b) : nullptr;
+    }
+    trace_host("bin: 1 memset");
     // Up to 4M keys (and no more than 8 per point) the order comes from counting instead of sorting: 6 launches instead of
     // the ~30 of rocprim's sort at this size (1M points: 0.42 -> 0.1 ms); FDX_GRAPH_SORT=1 forces the sort.
-    if (bits <= 22 && (1LL << bits) <= 8 * n + 1024 && !getenv("FDX_GRAPH_SORT")) {
+    if (counting) {
         const long long bins = 1LL << bits;
+        b->bins = bins;
         FDX_TRY(tmp.alloc((size_t)n * 4));                        // members in arrival order (keys: 32-bit keys, vals: arrival numbers)
-        FDX_TRY(b->count.alloc((size_t)(bins + 1) * 4));
         FDX_TRY(b->start.alloc((size_t)(bins + 1) * 4));
-        trace_host("bin: count/start alloc");
-        FDX_HIP(hipMemsetAsync(b->count.p, 0, b->count.bytes, st));
-        trace_host("bin: memset count");
+        trace_host("bin: start alloc");
         hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(256), 0, st, d_coords, n, b->gp, keys.as<unsigned>(), vals.as<int>(),
-                           b->count.as<int>());
+                           b->count_p);
         FDX_CHECK_LAUNCH();
         trace_host("bin: count kernel");
-        FDX_TRY(exclusive_scan_int(b->count.as<int>(), b->start.as<int>(), bins + 1, st, b->scan_tmp));
+        FDX_TRY(exclusive_scan_int(b->count_p, b->start.as<int>(), bins + 1, st, b->scan_tmp));
         trace_host("bin: scan");
         hipLaunchKernelGGL(cell_place_kernel, dim3(nb), dim3(256), 0, st, keys.as<unsigned>(), vals.as<int>(), b->start.as<int>(), n,
                            tmp.as<int>());
         FDX_CHECK_LAUNCH();
         if (dim < 3) FDX_HIP(hipMemsetAsync(b->sc.as<double>() + (size_t)dim * n, 0, (size_t)(3 - dim) * n * sizeof(double), st));
         const unsigned char* need = nullptr;
-        if (shard_hi > shard_lo && (shard_lo > 0 || shard_hi < n) && shard_R > 0 && !getenv("FDX_BAND_FULL_BINNING")) {
-            FDX_TRY(b->need.alloc((size_t)bins * 2));
-            FDX_HIP(hipMemsetAsync(b->need.p, 0, (size_t)bins * 2, st));
-            unsigned char* n1 = b->need.as<unsigned char>();
+        if (shard_need) {
+            unsigned char* n1 = b->need_p;
             unsigned char* n2 = n1 + bins;
             hipLaunchKernelGGL(cell_need_kernel<0>, dim3(ceil_div(bins, 256)), dim3(256), 0, st, b->start.as<int>(), bins, b->gp, shard_lo,
                                shard_hi, shard_R, (const unsigned char*)nullptr, n1);
@@ -1186,7 +1250,7 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
                            tmp.as<int>(), n, dim, b->perm.as<int>(), b->rank.as<int>(), b->sc.as<double>(), b->sc2.as<double2>(), need);
         FDX_CHECK_LAUNCH();
         hipLaunchKernelGGL(cell_table_kernel, dim3(ceil_div(bins, 256)), dim3(256), 0, st, b->start.as<int>(), bins, b->gp,
-                           b->cstart.as<int>(), b->cend.as<int>());
+                           b->cstart.as<int>(), b->cend_p);
         FDX_CHECK_LAUNCH();
         trace_host("bin: place/rank/table kernels");
         return 0;                        // no sync: the temporaries live in *b, whose owners synchronise before dropping it
@@ -1203,7 +1267,7 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
         FDX_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(cell_range_kernel, dim3(nb), dim3(256), 0, st, skeys.as<u64>(), b->sc.as<double>(), n, b->gp,
-                       b->cstart.as<int>(), b->cend.as<int>());
+                       b->cstart.as<int>(), b->cend_p);
     FDX_CHECK_LAUNCH();
     trace_host("bin: place/rank/range kernels");
     return 0;                            // no sync: the temporaries live in *b, whose owners synchronise before dropping it
@@ -1342,17 +1406,20 @@ static int empty_graph(long long n, fdx_graph* g, hipStream_t st) {
 template <int KMAX>
 static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int* nbr, int* cnt, double* nn_dist, long long lo,
                              long long hi, hipStream_t st, int* indeg = nullptr, int* arrival = nullptr, int* ties = nullptr,
-                             const int* row_list = nullptr, const int* row_count = nullptr, int* far_flag = nullptr, int far_drop = 0) {
+                             const int* row_list = nullptr, const int* row_count = nullptr, int* far_flag = nullptr, int far_drop = 0,
+                             int n_direct = -1, int list_cap = 0) {
     const int far_R = BAND_R;
     if (hi <= lo) return;
+    const long long n_threads = n_direct >= 0 ? (long long)n_direct + list_cap : hi - lo;
     // candidates per round trip: 4 leaves the kernel 77 registers (6 waves per SIMD), 6: 87 (5 waves), 8: 97 (4 waves);
     // 1M spots, wall per fit: 4.69 / 4.84 / 4.88 ms
     const int batch_env = getenv("FDX_KNN_BATCH") ? atoi(getenv("FDX_KNN_BATCH")) : 0;
     const int batch = (KMAX <= 16 && (batch_env == 4 || batch_env == 6 || batch_env == 8)) ? batch_env : (KMAX <= 16 ? 4 : 8);
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(ceil_div(hi - lo, 128)), dim3(128), 0, st, b.sc.as<double>(), b.sc2.as<double2>(), perm,
-                           b.rank.as<int>(), b.cstart.as<int>(), b.cend.as<int>(), b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
-                           KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0, row_list, row_count, far_flag, far_R, far_drop);
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(n_threads, 128)), dim3(128), 0, st, b.sc.as<double>(), b.sc2.as<double2>(), perm,
+                           b.rank.as<int>(), b.cstart.as<int>(), b.cend_p, b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
+                           KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0, row_list, row_count, far_flag, far_R, far_drop,
+                           n_direct, list_cap);
     };
     if constexpr (KMAX <= 16) {
         if (batch == 4) go(knn_kernel<KMAX, 4>);
@@ -1403,8 +1470,11 @@ struct fdx_graph_plan {
                                    // caller queued behind the build (the sketch kernel of the fit)
     ~fdx_graph_plan() { if (!kernels_done) (void)hipStreamSynchronize(st); }   // nothing may still read the buffers when they go back to the pool
 };
+struct fdx_shard_build;
+static void shard_build_drop(fdx_shard_build* sb);
 fdx_graph::~fdx_graph() {
-    if (meta_pending && meta_event) (void)hipEventSynchronize(meta_event);   // queued kernels still write into the buffers below
+    if ((meta_pending || shard_pending) && meta_event) (void)hipEventSynchronize(meta_event);   // queued kernels still write into the buffers below
+    if (keep_shard) { shard_build_drop(keep_shard); keep_shard = nullptr; }
     if (keep_plan) { delete keep_plan; keep_plan = nullptr; }
     if (meta_event) (void)hipEventDestroy(meta_event);
     if (begin_event) (void)hipEventDestroy(begin_event);
@@ -1496,19 +1566,12 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     const int pieces_env = getenv("FDX_KNN_PIECES") ? atoi(getenv("FDX_KNN_PIECES")) : 0;
     const int pieces = pieces_env > 0 ? pieces_env : 1;
     const long long step = ((rows + pieces - 1) / pieces + 127) / 128 * 128;
-    for (long long a = lo; a < hi; a += step) {
-        const long long e = std::min(hi, a + step);
-        const int fd = shard_band ? 1 : 0;
-        if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1, fd);
-        else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1, fd);
-        else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1, fd);
-        else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, nullptr, nullptr, ties + 1, fd);
-    }
-    trace_host("knn: kernel launched");
+    const bool merged = band && rows > 0 && pieces == 1 && rows < 0x3fffffffLL && !getenv("FDX_KNN_TWO_LAUNCHES");
     if (band && rows > 0) {
         // the band: cells next to a cell with an own row -> their rows outside [lo, hi) -> the lists of those rows.  Room for as
         // many band rows as own rows (a band is a surface: thousands of rows beside a million); an overflow is reported and the
-        // caller falls back to exchanging the lists.
+        // caller falls back to exchanging the lists.  The band is listed FIRST (it needs the binning only): own rows and band then
+        // share one k-NN launch.
         const int n_cells = b.n_cells;
         DevBuf cell_flag, cell_list;
         plan->band_cap = (int)std::min<long long>(n - rows, std::max<long long>(rows, 4096));
@@ -1517,27 +1580,50 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
         if (!rc) rc = plan->band_rows.alloc((size_t)std::max(plan->band_cap, 1) * 4);
         if (!rc) rc = plan->band_counters.alloc(16);
         if (rc) { delete plan; return rc; }
-        if (hipMemsetAsync(cell_flag.p, 0, cell_flag.bytes, st) != hipSuccess || hipMemsetAsync(plan->band_counters.p, 0, 16, st) != hipSuccess) {
+        const bool from_need = b.need_p && b.bins > 0 && !getenv("FDX_BAND_CELLS");
+        if ((!from_need && hipMemsetAsync(cell_flag.p, 0, cell_flag.bytes, st) != hipSuccess) ||
+            hipMemsetAsync(plan->band_counters.p, 0, 16, st) != hipSuccess) {
             delete plan;
             return fail(FDX_ERR_HIP, "graph: memset failed");
         }
         int* ctr = plan->band_counters.as<int>();
-        hipLaunchKernelGGL(band_cells_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, b.sc.as<double>(), n, b.gp, lo, hi,
-                           cell_flag.as<int>(), cell_list.as<int>(), ctr);
-        // at most (2 BAND_R + 1)^dim cells per own row, and never more than there are cells
-        const long long side = 2 * BAND_R + 1;
-        const long long max_cells = std::min<long long>(n_cells, rows * (dim == 1 ? side : dim == 2 ? side * side : side * side * side));
-        hipLaunchKernelGGL(band_rows_kernel, dim3(ceil_div(max_cells, 256)), dim3(256), 0, st, cell_list.as<int>(), b.cstart.as<int>(),
-                           b.cend.as<int>(), lo, hi, plan->band_cap, plan->band_rows.as<int>(), ctr);
-        const int* bl = plan->band_rows.as<int>();
-        const long long cap = plan->band_cap;
-        if (cap > 0) {
-            if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr, 1);
-            else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr, 1);
-            else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr, 1);
-            else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, ctr + 1, nullptr, 1);
+        if (from_need) {
+            // the shard's binning has flagged the band's keys already (first dilation of cell_need_kernel)
+            hipLaunchKernelGGL(band_rows_need_kernel, dim3(ceil_div(b.bins, 256)), dim3(256), 0, st, b.start.as<int>(), b.bins,
+                               b.need_p, lo, hi, plan->band_cap, plan->band_rows.as<int>(), ctr);
+        } else {
+            hipLaunchKernelGGL(band_cells_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, b.sc.as<double>(), n, b.gp, lo, hi,
+                               cell_flag.as<int>(), cell_list.as<int>(), ctr);
+            // at most (2 BAND_R + 1)^dim cells per own row, and never more than there are cells
+            const long long side = 2 * BAND_R + 1;
+            const long long max_cells = std::min<long long>(n_cells, rows * (dim == 1 ? side : dim == 2 ? side * side : side * side * side));
+            hipLaunchKernelGGL(band_rows_kernel, dim3(ceil_div(max_cells, 256)), dim3(256), 0, st, cell_list.as<int>(), b.cstart.as<int>(),
+                               b.cend_p, lo, hi, plan->band_cap, plan->band_rows.as<int>(), ctr);
         }
         // cell_flag / cell_list go back to the pool here: the pool orders their next use on this stream behind these kernels
+    }
+    const int* bl = plan->band_rows.as<int>();
+    const int* bctr = plan->band_counters.p ? plan->band_counters.as<int>() + 1 : nullptr;
+    const int nd = merged ? (int)rows : -1, lc = merged ? plan->band_cap : 0;
+    for (long long a = lo; a < hi; a += step) {
+        const long long e = std::min(hi, a + step);
+        const int fd = shard_band ? 1 : 0;
+        const int* rl = merged ? bl : nullptr;
+        const int* rcnt = merged ? bctr : nullptr;
+        if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, rl, rcnt, ties + 1, fd, nd, lc);
+        else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, rl, rcnt, ties + 1, fd, nd, lc);
+        else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, rl, rcnt, ties + 1, fd, nd, lc);
+        else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, a, e, st, indeg, arrival, ties, rl, rcnt, ties + 1, fd, nd, lc);
+    }
+    trace_host("knn: kernel launched");
+    if (band && rows > 0 && !merged) {
+        const long long cap = plan->band_cap;
+        if (cap > 0) {
+            if (kk < 8) launch_knn_range<8>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, bctr, nullptr, 1);
+            else if (kk < 16) launch_knn_range<16>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, bctr, nullptr, 1);
+            else if (kk < 32) launch_knn_range<32>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, bctr, nullptr, 1);
+            else launch_knn_range<64>(b, perm, kk, nbr, cnt, nullptr, 0, cap, st, nullptr, nullptr, nullptr, bl, bctr, nullptr, 1);
+        }
     }
     if (hipGetLastError() != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: k-NN kernel launch failed"); }
     *out = plan;
@@ -1638,7 +1724,9 @@ int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, l
 }
 
 // Waits for a deferred build (finish_ell) and takes over what only the device knew.  Cheap no-op otherwise.
+static int shard_meta_sync(fdx_graph* g);
 int graph_meta_sync(const fdx_graph* gc) {
+    if (gc && gc->shard_pending) return shard_meta_sync(const_cast<fdx_graph*>(gc));
     if (!gc || !gc->meta_pending) return 0;
     fdx_graph* g = const_cast<fdx_graph*>(gc);
     FDX_HIP(hipEventSynchronize(g->meta_event));
@@ -1711,7 +1799,7 @@ int graph_build_radius(const double* d_coords, long long n, int dim, double radi
     FDX_TRY(g->row_extra.alloc((size_t)(n + 1) * 4));
     FDX_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes, st));
     const int nb = ceil_div(n, 128);
-    hipLaunchKernelGGL(radius_kernel<0>, dim3(nb), dim3(128), 0, st, b.sc.as<double>(), b.cstart.as<int>(), b.cend.as<int>(), n,
+    hipLaunchKernelGGL(radius_kernel<0>, dim3(nb), dim3(128), 0, st, b.sc.as<double>(), b.cstart.as<int>(), b.cend_p, n,
                        b.gp, radius, R, cnt.as<int>(), (const int*)nullptr, (int*)nullptr, lo, hi);
     FDX_CHECK_LAUNCH();
     FDX_TRY(exclusive_scan_int(cnt.as<int>(), g->row_extra.as<int>(), n + 1, st, tmp));
@@ -1720,7 +1808,7 @@ int graph_build_radius(const double* d_coords, long long n, int dim, double radi
     FDX_HIP(hipStreamSynchronize(st));
     FDX_REQUIRE(total >= 0, "graph: radius graph has too many edges");
     FDX_TRY(g->rows.alloc((size_t)std::max(total, 1) * 4));
-    hipLaunchKernelGGL(radius_kernel<1>, dim3(nb), dim3(128), 0, st, b.sc.as<double>(), b.cstart.as<int>(), b.cend.as<int>(), n,
+    hipLaunchKernelGGL(radius_kernel<1>, dim3(nb), dim3(128), 0, st, b.sc.as<double>(), b.cstart.as<int>(), b.cend_p, n,
                        b.gp, radius, R, (int*)nullptr, g->row_extra.as<int>(), g->rows.as<int>(), lo, hi);
     FDX_CHECK_LAUNCH();
     hipLaunchKernelGGL(sort_rows_kernel, dim3(nb), dim3(128), 0, st, g->rows.as<int>(), g->row_extra.as<int>(), g->perm.as<int>(), n);
@@ -1991,6 +2079,397 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
     if (!all_send.empty())
         FDX_HIP(hipMemcpyAsync(loc->send_idx.p, all_send.data(), all_send.size() * 4, hipMemcpyHostToDevice, st));
     FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ deferred shard build
+// One rank's LOCAL graph of a k-NN job in one queued pipeline (graph_shard_knn): after the bounding box nothing returns to the
+// host.  Replaces, for the common case, the sequence knn_lists(band) -> from_knn_lists -> localize with its seven round trips
+// (a strong-scaled rank of 125k spots spent 0.9 ms there for ~0.1 ms of kernels).  Every quantity the stepwise path read back
+// to size an allocation is replaced by a bound the host knows (ELL rows: w_cap per slice as in the deferred whole-graph build;
+// halo: the band capacity; send lists: 3 x own rows); a bound that turns out too small is reported (shard_overflow) and the
+// caller rebuilds by the stepwise path.  Rows, order of the entries and tile tables are those of the stepwise path bit for bit.
+
+// own row p: every neighbour position outside [lo, hi) is flagged (the halo is the set of flagged positions) and the owner
+// ranks of those neighbours are collected in a bit mask (by symmetry the owner of q needs row p in ITS halo: the masks are the
+// send lists); per 256-row tile and peer the number of rows to send, and whether the tile holds any such row
+constexpr int SHARD_MAX_RANKS = 32;
+struct ShardBounds { long long b[SHARD_MAX_RANKS + 1]; };      // range starts of the ranks, by value (no upload to wait for)
+__global__ __launch_bounds__(256) void shard_mark_kernel(const int* __restrict__ ws, int kk, const int* __restrict__ seg_extra,
+                                                         const int* __restrict__ deg, long long lo, long long hi,
+                                                         const ShardBounds bounds_v, int n_ranks,
+                                                         int* __restrict__ flag, unsigned* __restrict__ mask,
+                                                         int* __restrict__ cnt_rb, int nblk, int* __restrict__ tileflag) {
+    __shared__ int s_cnt[32];
+    const int tid = threadIdx.x;
+    if (tid < 32) s_cnt[tid] = 0;
+    __syncthreads();
+    const long long t = blockIdx.x * 256LL + tid;
+    const long long p = lo + t;
+    unsigned m = 0;
+    if (p < hi) {
+        const int* seg = ws + (size_t)t * kk + seg_extra[t];
+        const int dg = deg[t];
+        for (int e = 0; e < dg; ++e) {
+            const int q = seg[e];
+            if (q < lo || q >= hi) {
+                flag[q] = 1;
+                int r = 0;
+#pragma unroll
+                for (int j = 1; j < SHARD_MAX_RANKS; ++j) r += (j < n_ranks && (long long)q >= bounds_v.b[j]) ? 1 : 0;   // no dynamic index into the by-value array
+                m |= 1u << r;
+            }
+        }
+        mask[t] = m;
+    }
+    unsigned any = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off, 64);
+    if (any) {
+        for (int r = 0; r < n_ranks; ++r)
+            if ((any >> r) & 1u) {
+                const int c = __popcll(__ballot((m >> r) & 1u));
+                if ((tid & 63) == 0) atomicAdd(&s_cnt[r], c);
+            }
+    }
+    __syncthreads();
+    if (tid < n_ranks) cnt_rb[(size_t)tid * nblk + blockIdx.x] = s_cnt[tid];
+    if (tid == 0) {
+        int a = 0;
+        for (int r = 0; r < n_ranks; ++r) a |= s_cnt[r];
+        tileflag[blockIdx.x] = a ? 1 : 0;
+    }
+}
+
+// halo_global[slot] = q for every flagged position (ascending: slot = number of flagged positions before q)
+__global__ __launch_bounds__(256) void shard_halo_scatter_kernel(const int* __restrict__ flag, const int* __restrict__ hscan,
+                                                                 long long n, int* __restrict__ halo_global, long long cap) {
+    const long long q = blockIdx.x * 256LL + threadIdx.x;
+    if (q >= n || !flag[q]) return;
+    const int s = hscan[q];
+    if (s < cap) halo_global[s] = (int)q;
+}
+
+// local sliced ELL straight from the row segments: own neighbour -> q - lo, outside -> n_own + its halo slot, pad -> n_total
+__global__ __launch_bounds__(256) void fill_ell_local_kernel(const int* __restrict__ ws, int kk, const int* __restrict__ seg_extra,
+                                                             const int* __restrict__ deg, const int* __restrict__ slice_off,
+                                                             long long lo, long long hi, int n_slices,
+                                                             const int* __restrict__ hscan, long long n_all,
+                                                             int* __restrict__ ell, long long cap_rows,
+                                                             const int* __restrict__ perm_g, int* __restrict__ perm_l) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const long long n_own = hi - lo;
+    const long long t = (long long)s * 64 + lane;
+    if (t < n_own) perm_l[t] = perm_g[lo + t];                   // caller's id of the own row
+    if ((long long)slice_off[n_slices] > cap_rows) return;      // bound too small: reported, rebuilt by the stepwise path
+    const int w0 = slice_off[s], w = slice_off[s + 1] - w0;
+    const int dg = (t < n_own) ? deg[t] : 0;
+    const int* seg = (t < n_own) ? ws + (size_t)t * kk + seg_extra[t] : ws;
+    const int pad = (int)n_own + hscan[n_all];
+    for (int m = 0; m < w; ++m) {
+        int v = pad;
+        if (m < dg) {
+            const int q = seg[m];
+            v = (q >= lo && q < hi) ? (int)(q - lo) : (int)n_own + hscan[q];
+        }
+        ell[((size_t)w0 + m) * 64 + lane] = v;
+    }
+}
+
+// send_idx, grouped by peer, ascending row inside a peer: off_rb (exclusive scan of cnt_rb, peer-major) places every tile's rows
+__global__ __launch_bounds__(256) void shard_send_fill_kernel(const unsigned* __restrict__ mask, const int* __restrict__ off_rb,
+                                                              const int* __restrict__ tileflag, int nblk, long long n_own,
+                                                              int n_ranks, int* __restrict__ send_idx, long long cap) {
+    if (!tileflag[blockIdx.x]) return;
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long t = blockIdx.x * 256LL + tid;
+    const unsigned m = (t < n_own) ? mask[t] : 0u;
+    for (int r = 0; r < n_ranks; ++r) {
+        const int base = off_rb[(size_t)r * nblk + blockIdx.x];
+        const int cnt = off_rb[(size_t)r * nblk + blockIdx.x + 1] - base;       // peer-major: the next entry is the next tile (or the next peer's first)
+        if (cnt == 0) continue;                                                // block-uniform
+        const unsigned long long b = __ballot((m >> r) & 1u);
+        if (lane == 0) s_w[wv] = __popcll(b);
+        __syncthreads();
+        int before = 0;
+        for (int w2 = 0; w2 < wv; ++w2) before += s_w[w2];
+        if ((m >> r) & 1u) {
+            const long long at = (long long)base + before + __popcll(b & ((1ULL << lane) - 1ULL));
+            if (at < cap) send_idx[at] = (int)t;
+        }
+        __syncthreads();
+    }
+}
+
+// boundary tiles (hold a row some peer needs) and interior tiles, each ascending; one workgroup
+__global__ __launch_bounds__(256) void shard_tile_lists_kernel(const int* __restrict__ tileflag, int n_tiles,
+                                                               int* __restrict__ tiles_b, int* __restrict__ tiles_i,
+                                                               int* __restrict__ counts) {
+    __shared__ int s_w[4];
+    __shared__ int s_base_b, s_base_i;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { s_base_b = 0; s_base_i = 0; }
+    __syncthreads();
+    for (int t0 = 0; t0 < n_tiles; t0 += 256) {
+        const int t = t0 + tid;
+        const bool in = t < n_tiles;
+        const bool isb = in && tileflag[t] != 0;
+        const unsigned long long b = __ballot(isb);
+        if (lane == 0) s_w[wv] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w2 = 0; w2 < 4; ++w2) { if (w2 < wv) before += s_w[w2]; total += s_w[w2]; }
+        const int rb = before + __popcll(b & ((1ULL << lane) - 1ULL));      // boundary tiles before t in this round
+        const int bb = s_base_b, bi = s_base_i;
+        if (in) {
+            if (isb) tiles_b[bb + rb] = t;
+            else tiles_i[bi + (tid - rb)] = t;
+        }
+        __syncthreads();
+        if (tid == 0) { s_base_b = bb + total; s_base_i = bi + (min(256, n_tiles - t0) - total); }
+        __syncthreads();
+    }
+    if (tid == 0) { counts[0] = s_base_b; counts[1] = s_base_i; }
+}
+
+// everything the host will ask for, in one pinned block (FDX_PINNED_BLOCK_BYTES): [0] ELL rows, [1] nnz of the own rows,
+// [2] widest slice, [3] largest tile halo | failed-tile flag << 32, [4] tied rows, [5] far | band overflow << 1, [6] halo spots,
+// [7] rows to send (all peers), [8] boundary tiles, [9] interior tiles; [16 + r] send_off[r], [56 + r] recv_off[r] (r = 0..n_ranks)
+constexpr int SHARD_META_SEND = 16, SHARD_META_RECV = 56;
+__global__ __launch_bounds__(256) void shard_meta_kernel(const long long* __restrict__ part, int n_part, const int* __restrict__ slice_off,
+                                                         int n_slices, const int* __restrict__ summary, const int* __restrict__ ties,
+                                                         const int* __restrict__ band_ctr, const int* __restrict__ hscan, long long n_all,
+                                                         const int* __restrict__ off_rb, int nblk, const ShardBounds bounds_v, int n_ranks,
+                                                         const int* __restrict__ tile_counts, int* __restrict__ send_off_dev,
+                                                         int* __restrict__ recv_off_dev, long long* __restrict__ meta) {
+    __shared__ long long s_sum[256];
+    __shared__ int s_max[256];
+    __shared__ long long s_b[SHARD_MAX_RANKS + 1];
+    const int r = threadIdx.x;
+    if (r <= SHARD_MAX_RANKS) s_b[r] = bounds_v.b[r];
+    long long tot = 0;                                            // nnz and widest slice from the blocks' partials (slice_width_kernel)
+    int wmax = 0;
+    for (int b = r; b < n_part; b += 256) { tot += part[2 * b]; wmax = max(wmax, (int)part[2 * b + 1]); }
+    s_sum[r] = tot;
+    s_max[r] = wmax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (r < s) { s_sum[r] += s_sum[r + s]; s_max[r] = max(s_max[r], s_max[r + s]); }
+        __syncthreads();
+    }
+    if (r <= n_ranks) {
+        const int so = off_rb[(size_t)r * nblk];                      // r == n_ranks: the total (last entry of the scan)
+        const int ro = hscan[s_b[r]];
+        send_off_dev[r] = so;
+        recv_off_dev[r] = ro;
+        meta[SHARD_META_SEND + r] = so;
+        meta[SHARD_META_RECV + r] = ro;
+    }
+    if (r != 0) return;
+    meta[0] = (long long)slice_off[n_slices];
+    meta[1] = s_sum[0];
+    meta[2] = (long long)s_max[0];
+    meta[3] = (long long)(unsigned)summary[0] | ((long long)summary[1] << 32);
+    meta[4] = (long long)ties[0];
+    meta[5] = (long long)(ties[1] != 0) | ((long long)(band_ctr[3] != 0) << 1);
+    meta[6] = (long long)hscan[n_all];
+    meta[7] = (long long)off_rb[(size_t)n_ranks * nblk];
+    meta[8] = (long long)tile_counts[0];
+    meta[9] = (long long)tile_counts[1];
+}
+
+}  // namespace fdx
+struct fdx_shard_build {
+    fdx_graph_plan* plan = nullptr;
+    fdx::DevBuf nbr, cnt, zeros, rev_off, rev, rows, hscan, mask, off_rb, tileflag, tile_counts, scan_tmp;
+    ~fdx_shard_build() { if (plan) fdx::graph_plan_destroy(plan); }
+};
+static void shard_build_drop(fdx_shard_build* sb) {      // the graph's meta event has completed: nothing reads the buffers any more
+    if (sb->plan) sb->plan->kernels_done = true;
+    delete sb;
+}
+namespace fdx {
+
+int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_ranks, const long long* bounds, int my_rank,
+                    fdx_graph* loc, hipStream_t st) {
+    FDX_REQUIRE(dim >= 1 && dim <= 3, "graph_shard_knn: the deferred shard build takes 1 to 3 coordinates");
+    FDX_REQUIRE(n_ranks >= 2 && n_ranks <= SHARD_MAX_RANKS && my_rank >= 0 && my_rank < n_ranks, "graph_shard_knn: 2 to 32 ranks");
+    static_assert(SHARD_META_RECV + SHARD_MAX_RANKS + 1 <= (int)(FDX_PINNED_BLOCK_BYTES / 8), "shard meta block");
+    FDX_REQUIRE(n >= 2 && k >= 1, "graph_shard_knn: needs at least two spots and k >= 1");
+    const long long lo = bounds[my_rank], hi = bounds[my_rank + 1];
+    FDX_REQUIRE(bounds[0] == 0 && bounds[n_ranks] == n, "graph_shard_knn: bounds must cover [0, n]");
+    for (int r = 0; r < n_ranks; ++r)
+        FDX_REQUIRE(bounds[r + 1] >= bounds[r] && bounds[r] % 256 == 0, "graph_shard_knn: range starts must be non-decreasing multiples of 256");
+    FDX_REQUIRE(hi > lo, "graph_shard_knn: this rank owns no row (use the stepwise path)");
+    const long long n_own = hi - lo;
+    auto sb = std::make_unique<fdx_shard_build>();
+    const int kk = (int)std::min<long long>(k, n - 1) + 1;
+    FDX_REQUIRE(kk <= 64, "graph: k_neighbors above 63 is not supported");
+    FDX_REQUIRE((long long)n * kk < 0x7fffff00LL, "graph: n*k too large");
+    FDX_TRY(sb->nbr.alloc((size_t)n * kk * 4));
+    FDX_TRY(sb->cnt.alloc((size_t)n * 4));
+    // lists of the own rows and of the band (bin_points reads the bounding box back: the one round trip of the build)
+    FDX_TRY(graph_knn_lists(d_coords, n, dim, k, lo, hi, sb->nbr.as<int>(), sb->cnt.as<int>(), &sb->plan, st, true));
+    fdx_graph_plan* plan = sb->plan;
+    FDX_REQUIRE(plan->band_rows.p != nullptr, "graph_shard_knn: no band (one rank owns everything)");
+    const int* nbr = sb->nbr.as<int>();
+    const int* cnt = sb->cnt.as<int>();
+
+    // ---- everything that must start as zero, in one block with one fill: in-degrees and cursors of the own rows, the halo flags
+    // (one per position of the whole order), per-tile / per-peer send counts (+ the closing entry of their scan), slice widths and
+    // the reduction cells behind them
+    const int nblk = ceil_div(n_own, 256);
+    loc->n_slices = (int)((n_own + 63) / 64);
+    const int wblocks = std::min(SLICE_WIDTH_BLOCKS, std::max(1, ceil_div(loc->n_slices, 4)));
+    auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
+    const size_t z_indeg = 0, z_cursor = up16(z_indeg + (size_t)(n_own + 1) * 4), z_flag = up16(z_cursor + (size_t)n_own * 4),
+                 z_cntrb = up16(z_flag + (size_t)(n + 1) * 4), z_width = up16(z_cntrb + ((size_t)n_ranks * nblk + 1) * 4),
+                 z_red = up16(z_width + (size_t)(loc->n_slices + 1) * 4), z_end = z_red + 32 + (size_t)wblocks * 16;
+    FDX_TRY(sb->zeros.alloc(z_end));
+    FDX_HIP(hipMemsetAsync(sb->zeros.p, 0, z_red + 32, st));
+    char* zb = static_cast<char*>(sb->zeros.p);
+    int* indeg_l = reinterpret_cast<int*>(zb + z_indeg);
+    int* cursor_l = reinterpret_cast<int*>(zb + z_cursor);
+    int* flag = reinterpret_cast<int*>(zb + z_flag);
+    int* cnt_rb = reinterpret_cast<int*>(zb + z_cntrb);
+    int* width = reinterpret_cast<int*>(zb + z_width);
+    long long* red = reinterpret_cast<long long*>(zb + z_red);
+    int* summary = reinterpret_cast<int*>(red + 2);
+    long long* part = red + 4;
+    ShardBounds bv;
+    for (int r = 0; r <= SHARD_MAX_RANKS; ++r) bv.b[r] = r <= n_ranks ? bounds[r] : n;
+
+    // ---- symmetrise the own rows (graph.py:80-81): everything indexed by the LOCAL row t = p - lo (pointers shifted by lo);
+    // own rows and band rows in one launch each
+    FDX_TRY(sb->rev_off.alloc((size_t)(n_own + 1) * 4));
+    int* indeg_s = indeg_l - lo;
+    int* cursor_s = cursor_l - lo;
+    int* rev_off_s = sb->rev_off.as<int>() - lo;
+    const int bcap = plan->band_cap;
+    hipLaunchKernelGGL(indegree_rows_kernel, dim3(ceil_div(n_own + bcap, 256)), dim3(256), 0, st, nbr, cnt, kk, indeg_s, (int)lo, (int)hi,
+                       plan->band_rows.as<int>(), plan->band_counters.as<int>() + 1, bcap, (int)n_own);
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(exclusive_scan_int(indeg_l, sb->rev_off.as<int>(), n_own + 1, st, sb->scan_tmp));
+    FDX_TRY(sb->rev.alloc(((size_t)n_own + (size_t)bcap) * kk * 4 + 4));
+    hipLaunchKernelGGL(fill_reverse_rows_kernel, dim3(ceil_div(n_own + bcap, 256)), dim3(256), 0, st, nbr, cnt, kk, rev_off_s, cursor_s,
+                       sb->rev.as<int>(), (int)lo, (int)hi, plan->band_rows.as<int>(), plan->band_counters.as<int>() + 1, bcap,
+                       (int)n_own);
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(sb->rows.alloc((size_t)n_own * kk * 2 * 4));
+    FDX_TRY(loc->deg.alloc((size_t)n_own * 4));
+    int* rows_s = sb->rows.as<int>() - (size_t)lo * kk;
+    int* deg_s = loc->deg.as<int>() - lo;
+    hipLaunchKernelGGL(merge_rows_kernel, dim3(ceil_div(n_own, 128)), dim3(128), 0, st, nbr, cnt, sb->rev.as<int>(), rev_off_s,
+                       plan->b.perm.as<int>(), plan->b.rank.as<int>(), lo, hi, kk, rows_s, deg_s);
+    FDX_CHECK_LAUNCH();
+
+    // ---- halo and send masks
+    FDX_TRY(sb->hscan.alloc((size_t)(n + 1) * 4));
+    FDX_TRY(sb->mask.alloc((size_t)n_own * 4));
+    FDX_TRY(sb->off_rb.alloc(((size_t)n_ranks * nblk + 1) * 4));
+    FDX_TRY(sb->tileflag.alloc((size_t)nblk * 4));
+    FDX_TRY(sb->tile_counts.alloc(8));
+    hipLaunchKernelGGL(shard_mark_kernel, dim3(nblk), dim3(256), 0, st, sb->rows.as<int>(), kk, sb->rev_off.as<int>(),
+                       loc->deg.as<int>(), lo, hi, bv, n_ranks, flag, sb->mask.as<unsigned>(), cnt_rb, nblk, sb->tileflag.as<int>());
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(exclusive_scan_int(flag, sb->hscan.as<int>(), n + 1, st, sb->scan_tmp));
+    loc->shard_halo_cap = std::max<long long>(plan->band_cap, 1);          // halo rows are band rows
+    FDX_TRY(loc->halo_global.alloc((size_t)loc->shard_halo_cap * 4));
+    hipLaunchKernelGGL(shard_halo_scatter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, flag, sb->hscan.as<int>(), n,
+                       loc->halo_global.as<int>(), loc->shard_halo_cap);
+    FDX_CHECK_LAUNCH();
+
+    // ---- local sliced ELL, tile tables
+    loc->n = n_own;
+    loc->identity_order = false;
+    loc->global_lo = lo;
+    loc->n_tiles = nblk;
+    loc->shard_world = n_ranks;
+    FDX_TRY(loc->slice_off.alloc((size_t)(loc->n_slices + 1) * 4));
+    hipLaunchKernelGGL(slice_width_kernel, dim3(wblocks), dim3(256), 0, st, loc->deg.as<int>(), n_own, loc->n_slices, width, part);
+    FDX_CHECK_LAUNCH();
+    FDX_TRY(exclusive_scan_int(width, loc->slice_off.as<int>(), loc->n_slices + 1, st, sb->scan_tmp));
+    const int w_cap = getenv("FDX_GRAPH_WCAP") ? std::max(1, atoi(getenv("FDX_GRAPH_WCAP"))) : std::min(96, std::max(24, 3 * kk + 3));
+    const long long cap = (long long)loc->n_slices * w_cap;
+    loc->shard_ell_cap = cap;
+    FDX_TRY(loc->ell.alloc((size_t)std::max<long long>(cap, 1) * 64 * 4));
+    FDX_TRY(loc->tile_halo.alloc((size_t)nblk * FDX_TILE_HALO_CAP * 4));
+    FDX_TRY(loc->tile_hcnt.alloc((size_t)nblk * 4));
+    FDX_TRY(loc->ell_local.alloc(((size_t)cap + 16) * 64 * 2));
+    FDX_TRY(loc->perm.alloc((size_t)n_own * 4));
+    hipLaunchKernelGGL(fill_ell_local_kernel, dim3(ceil_div(loc->n_slices, 4)), dim3(256), 0, st, sb->rows.as<int>(), kk,
+                       sb->rev_off.as<int>(), loc->deg.as<int>(), loc->slice_off.as<int>(), lo, hi, loc->n_slices, sb->hscan.as<int>(), n,
+                       loc->ell.as<int>(), cap, plan->b.perm.as<int>(), loc->perm.as<int>());
+    FDX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tile_halo_kernel, dim3(nblk), dim3(256), 0, st, loc->ell.as<int>(), loc->deg.as<int>(), loc->slice_off.as<int>(),
+                       n_own, loc->tile_halo.as<int>(), loc->tile_hcnt.as<int>(), loc->ell_local.as<unsigned short>(), cap, summary);
+    FDX_CHECK_LAUNCH();
+
+    // ---- send lists, boundary / interior tiles
+    FDX_TRY(exclusive_scan_int(cnt_rb, sb->off_rb.as<int>(), (long long)n_ranks * nblk + 1, st, sb->scan_tmp));
+    loc->shard_send_cap = n_own * std::min(n_ranks - 1, 3) + 1024;
+    FDX_TRY(loc->send_idx.alloc((size_t)loc->shard_send_cap * 4));
+    hipLaunchKernelGGL(shard_send_fill_kernel, dim3(nblk), dim3(256), 0, st, sb->mask.as<unsigned>(), sb->off_rb.as<int>(),
+                       sb->tileflag.as<int>(), nblk, n_own, n_ranks, loc->send_idx.as<int>(), loc->shard_send_cap);
+    FDX_TRY(loc->tiles_boundary.alloc((size_t)nblk * 4));
+    FDX_TRY(loc->tiles_interior.alloc((size_t)nblk * 4));
+    hipLaunchKernelGGL(shard_tile_lists_kernel, dim3(1), dim3(256), 0, st, sb->tileflag.as<int>(), nblk, loc->tiles_boundary.as<int>(),
+                       loc->tiles_interior.as<int>(), sb->tile_counts.as<int>());
+    FDX_CHECK_LAUNCH();
+
+    // ---- the numbers the host will ask for
+    FDX_TRY(loc->send_off_dev.alloc((size_t)(n_ranks + 1) * 4));
+    FDX_TRY(loc->recv_off_dev.alloc((size_t)(n_ranks + 1) * 4));
+    if (!loc->meta_host) loc->meta_host = (long long*)pinned_block_get();
+    FDX_REQUIRE(loc->meta_host != nullptr, "graph: pinned host block");
+    if (!loc->meta_event) FDX_HIP(hipEventCreateWithFlags(&loc->meta_event, hipEventDisableTiming));
+    std::memset(loc->meta_host, 0, FDX_PINNED_BLOCK_BYTES);
+    void* meta_dev = nullptr;
+    FDX_HIP(hipHostGetDevicePointer(&meta_dev, loc->meta_host, 0));
+    hipLaunchKernelGGL(shard_meta_kernel, dim3(1), dim3(256), 0, st, part, wblocks, loc->slice_off.as<int>(), loc->n_slices, summary,
+                       plan->ties.as<int>(), plan->band_counters.as<int>(), sb->hscan.as<int>(), n, sb->off_rb.as<int>(), nblk, bv, n_ranks,
+                       sb->tile_counts.as<int>(), loc->send_off_dev.as<int>(), loc->recv_off_dev.as<int>(), (long long*)meta_dev);
+    FDX_CHECK_LAUNCH();
+    FDX_HIP(hipEventRecord(loc->meta_event, st));
+    loc->meta_stream = st;
+    loc->shard_pending = true;
+    loc->n_total = n_own;                        // until graph_meta_sync
+    loc->keep_shard = sb.release();
+    return 0;
+}
+
+// takes over what the queued shard build left in the pinned block
+static int shard_meta_sync(fdx_graph* g) {
+    FDX_HIP(hipEventSynchronize(g->meta_event));
+    g->shard_pending = false;
+    if (g->keep_shard) {
+        if (g->keep_shard->plan) g->keep_shard->plan->kernels_done = true;
+        delete g->keep_shard;
+        g->keep_shard = nullptr;
+    }
+    const long long* m = g->meta_host;
+    const int W = g->shard_world;
+    const long long rows = m[0], n_halo = m[6], n_send = m[7];
+    g->nnz = m[1];
+    g->max_deg = (int)(m[2] & 0xffffffffLL);
+    g->knn_ties = m[4];
+    g->knn_far = (int)(m[5] & 3) ? 1 : 0;
+    g->shard_overflow = (rows > g->shard_ell_cap || n_halo > g->shard_halo_cap || n_send > g->shard_send_cap) ? 1 : 0;
+    g->ell_rows = rows;
+    g->n_total = g->n + n_halo;
+    g->halo_max = (int)(m[3] & 0xffffffffLL);
+    g->tiled = g->n_tiles > 0 && rows > 0 && (m[3] >> 32) == 0 && !g->shard_overflow;
+    g->send_off.assign((size_t)W + 1, 0);
+    g->recv_off.assign((size_t)W + 1, 0);
+    for (int r = 0; r <= W; ++r) {
+        g->send_off[(size_t)r] = (int)m[SHARD_META_SEND + r];
+        g->recv_off[(size_t)r] = (int)m[SHARD_META_RECV + r];
+    }
+    g->n_tiles_boundary = (int)m[8];
+    g->n_tiles_interior = (int)m[9];
     return 0;
 }
 

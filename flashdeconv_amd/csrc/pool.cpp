@@ -118,7 +118,7 @@ void* pinned_block_get() {
         if (!g_pin_free.empty()) { void* p = g_pin_free.back(); g_pin_free.pop_back(); return p; }
     }
     void* p = nullptr;
-    if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc(&p, FDX_PINNED_BLOCK_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 void pinned_block_put(void* p) {

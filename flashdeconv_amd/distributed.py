@@ -351,13 +351,40 @@ class ShardedFlashDeconv:
         k = int(self.k_neighbors)
         sharded_knn = self.spatial_method == "knn" and self.comm.world > 1 and n >= 2 and k >= 1
         self.plan_route_ = None
+        self._pending_plan = None
+        self._coords = coords
+        self.n_total_spots = n
+        self.n_own = int(self.bounds[self.comm.rank + 1] - self.bounds[self.comm.rank])
+        if (sharded_knn and dim <= 3 and 2 <= self.comm.world <= 32 and min(k, n - 1) + 1 <= 64
+                and not os.environ.get("FDX_PLAN_ALLGATHER") and not os.environ.get("FDX_PLAN_STEPWISE")):
+            # ONE queued pipeline per rank (fdx_graph_shard_knn_dev): band lists, own rows of the symmetrised graph, halo, local
+            # ELL, tile tables, send lists - nothing returns to the host after the bounding box.  The counts (and the one
+            # all-reduce of the plan: edges, ties, "a walk left its block") are taken over by _finish_plan(): at once when the
+            # tie rule may still change the graph, otherwise behind the sketch that fit_transform queues next.
+            self.plan_route_ = "band"
+            lo, hi = int(self.bounds[self.comm.rank]), int(self.bounds[self.comm.rank + 1])
+            if hi > lo:
+                hl = ctypes.c_void_p()
+                _lib.check(lib.fdx_graph_shard_knn_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, self.comm.world,
+                                                       _lib.ptr_i64(self.bounds), self.comm.rank, st, ctypes.byref(hl)))
+                self._local = _lib.Graph(hl.value)
+            else:
+                self._plan_stepwise_local(coords, lo, hi)          # a rank without rows: nothing to queue, no collective inside
+            self._pending_plan = "shard"
+            perm = torch.empty(max(self.n_own, 1), dtype=torch.int32, device=coords.device)
+            _lib.check(lib.fdx_graph_perm_dev(self._local.handle, ctypes.c_void_p(perm.data_ptr()), st))
+            self.own_ids = perm[:self.n_own].long()
+            t0 = self._tick("plan_build", t0)
+            if self.knn_ties != "index" or self._profile:
+                self._finish_plan()
+            return self.own_ids
         if sharded_knn:
             lo, hi = int(self.bounds[self.comm.rank]), int(self.bounds[self.comm.rank + 1])
             kk = min(k, n - 1) + 1
             nbr = torch.empty((n, kk), dtype=torch.int32, device=coords.device)
             cnt = torch.empty((n,), dtype=torch.int32, device=coords.device)
             plan = ctypes.c_void_p()
-            if not os.environ.get("FDX_PLAN_ALLGATHER"):
+            if not os.environ.get("FDX_PLAN_ALLGATHER") and dim <= 3:      # more than 3 coordinates: exhaustive search, no band
                 # Band recompute ("recompute, don't communicate"): the lists of the own rows AND of the rows in the grid
                 # cells next to an own cell, which are all the rows that can point at an own row while every k-NN walk stays inside
                 # its 3 x 3 block of cells - own rows of the symmetrised graph without moving a list (include/fdx.h).  Each rank
@@ -427,6 +454,87 @@ class ShardedFlashDeconv:
                 self.nnz_total = self._full.info()[1]
                 self.knn_ties_ = self._full.knn_ties() if method == _lib.GRAPH_KNN else 0
         t0 = self._tick("plan_build", t0)
+        self._resolve_ties_and_localize(coords, st, t0)
+        return self.own_ids
+
+    def _plan_stepwise_local(self, coords, lo, hi):
+        """This rank's local graph by the three stepwise calls of the band route (lists of own rows + band, own rows of the
+        symmetrised graph, localize) - no collective inside: the remedy when a bound of the queued pipeline was too small, and
+        the path of a rank that owns no row."""
+        import torch
+        lib = _lib.load()
+        n, dim = coords.shape
+        k = int(self.k_neighbors)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        kk = min(k, n - 1) + 1
+        nbr = torch.empty((n, kk), dtype=torch.int32, device=coords.device)
+        cnt = torch.empty((n,), dtype=torch.int32, device=coords.device)
+        plan, h, hl = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_knn_lists_band_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, lo, hi,
+                                                    ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), st, ctypes.byref(plan)))
+        _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi,
+                                                    st, ctypes.byref(h)))
+        full = _lib.Graph(h.value)
+        self._step_counts = (float(full.info()[1]), float(full.knn_ties()), float(full.knn_far()))
+        _lib.check(lib.fdx_graph_localize(full.handle, self.comm.world, _lib.ptr_i64(self.bounds), self.comm.rank, st, ctypes.byref(hl)))
+        full.close()
+        if self._local is not None:
+            self._local.close()
+        self._local = _lib.Graph(hl.value)
+
+    def _finish_plan(self):
+        """Second half of a queued plan (fdx_graph_shard_knn_dev): wait for the counts, all-reduce (edges, tied rows, far flag),
+        apply the remedies (a bound too small: this rank rebuilds stepwise; a far walk anywhere: every rank rebuilds by the list
+        exchange; ties under "auto" / "ckdtree": the reference's graph), halo bookkeeping."""
+        if getattr(self, "_pending_plan", None) is None:
+            return
+        import torch
+        lib = _lib.load()
+        self._pending_plan = None
+        coords = self._coords
+        n = coords.shape[0]
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        t0 = time.perf_counter()
+        lo, hi = int(self.bounds[self.comm.rank]), int(self.bounds[self.comm.rank + 1])
+        if hi > lo:
+            nnz, ties, far, over = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+            _lib.check(lib.fdx_graph_shard_status(self._local.handle, ctypes.byref(nnz), ctypes.byref(ties), ctypes.byref(far),
+                                                  ctypes.byref(over)))
+            counts = (float(nnz.value), float(ties.value), float(far.value))
+            if over.value and not far.value:
+                self._plan_stepwise_local(coords, lo, hi)          # same rows, same order, exact sizes
+                counts = self._step_counts
+        else:
+            counts = self._step_counts
+        own = torch.tensor(counts, dtype=torch.float64, device=coords.device)
+        self.comm.all_reduce_sum(own)
+        tot = own.cpu().numpy()
+        t0 = self._tick("plan_counts", t0)
+        if tot[2] != 0:
+            # some rank's walk left its block (very uneven density) or a band list overflowed: every rank rebuilds by the exchange
+            self._local.close()
+            self._local = None
+            prev = os.environ.get("FDX_PLAN_ALLGATHER")
+            os.environ["FDX_PLAN_ALLGATHER"] = "1"
+            try:
+                lev = getattr(self, "_lev_job", None)
+                self.plan(coords)
+                self._lev_job = lev
+            finally:
+                if prev is None:
+                    del os.environ["FDX_PLAN_ALLGATHER"]
+                else:
+                    os.environ["FDX_PLAN_ALLGATHER"] = prev
+            return
+        self.nnz_total, self.knn_ties_ = int(round(float(tot[0]))), int(round(float(tot[1])))
+        self._full = None
+        self._resolve_ties_and_localize(coords, st, t0, localized=True)
+
+    def _resolve_ties_and_localize(self, coords, st, t0, localized=False):
+        """Tail of plan(): the reference's tie order when asked for, the local graph of this rank, its halo bookkeeping."""
+        import torch
+        lib = _lib.load()
+        n = coords.shape[0]
         self.knn_ties_resolved_ = False
         if getattr(self, "knn_ties_", 0) and self.spatial_method == "knn" and self.knn_ties != "index":
             # The device builds chose among equidistant neighbours by spot index; the reference's graph comes from cKDTree's
@@ -434,11 +542,13 @@ class ShardedFlashDeconv:
             # its rows.  The graph is in the CALLER's order (no Morton sort), so a shard is a range of the caller's spot numbers.
             from .utils.graph import ckdtree_knn_adjacency
             A = ckdtree_knn_adjacency(coords.detach().cpu().numpy().astype(np.float64), int(self.k_neighbors))
-            self._full.close()
+            if self._full is not None:
+                self._full.close()
             self._full = _lib.Graph.from_csr(A.indptr, A.indices, n)
             self.nnz_total = int(A.nnz)
             self.plan_route_ = "ckdtree"
             self.knn_ties_resolved_ = True
+            localized = False
         if getattr(self, "knn_ties_", 0) and not self.knn_ties_resolved_ and self.comm.rank == 0:
             import warnings
             warnings.warn(f"k-NN ties: {self.knn_ties_} of {n} spots have their k-th and (k+1)-th nearest neighbours at exactly the "
@@ -446,15 +556,19 @@ class ShardedFlashDeconv:
                           "index, in the reference by cKDTree's traversal order.  spatial_method='grid' builds a tie-free graph "
                           "on lattices.", UserWarning, stacklevel=2)
         self.n_total_spots = n
-        hl = ctypes.c_void_p()
-        _lib.check(lib.fdx_graph_localize(self._full.handle, self.comm.world, _lib.ptr_i64(self.bounds), self.comm.rank, st,
-                                          ctypes.byref(hl)))
-        self._local = _lib.Graph(hl.value)
-        t0 = self._tick("plan_localize", t0)
-        self.n_own = int(self.bounds[self.comm.rank + 1] - self.bounds[self.comm.rank])
-        perm = torch.empty(max(self.n_own, 1), dtype=torch.int32, device=coords.device)
-        _lib.check(lib.fdx_graph_perm_dev(self._local.handle, ctypes.c_void_p(perm.data_ptr()), st))
-        self.own_ids = perm[:self.n_own].long()
+        if not localized:
+            hl = ctypes.c_void_p()
+            _lib.check(lib.fdx_graph_localize(self._full.handle, self.comm.world, _lib.ptr_i64(self.bounds), self.comm.rank, st,
+                                              ctypes.byref(hl)))
+            if self._local is not None:
+                self._local.close()
+            self._local = _lib.Graph(hl.value)
+            t0 = self._tick("plan_localize", t0)
+            self.n_own = int(self.bounds[self.comm.rank + 1] - self.bounds[self.comm.rank])
+            perm = torch.empty(max(self.n_own, 1), dtype=torch.int32, device=coords.device)
+            _lib.check(lib.fdx_graph_perm_dev(self._local.handle, ctypes.c_void_p(perm.data_ptr()), st))
+            self.own_ids = perm[:self.n_own].long()
+        self.own_nnz_ = int(self._local.info()[1])
         n_halo = ctypes.c_int64(0)
         sc = np.zeros(self.comm.world, dtype=np.int32)
         rc = np.zeros(self.comm.world, dtype=np.int32)
@@ -464,7 +578,6 @@ class ShardedFlashDeconv:
         _lib.check(lib.fdx_graph_send_indices_dev(self._local.handle, ctypes.c_void_p(sidx.data_ptr()), st))
         self._halo = HaloExchange(self.comm, self.n_own, sidx[:int(sc.sum())].long(), sc, rc)
         self._tick("plan_lists", t0)
-        return self.own_ids
 
     def fit_transform(self, Y_own, X):
         import torch
@@ -539,8 +652,8 @@ class ShardedFlashDeconv:
         elif self.preprocess != "raw":
             raise ValueError(f"Unknown preprocess method: {self.preprocess}. Choose from 'log_cpm', 'pearson', or 'raw'.")
         t0 = self._tick("tables", t0)
-        n_own, n_total = self.n_own, self.n_own + self.n_halo
-        ld = ((n_total + 1 + 63) // 64) * 64
+        n_own = self.n_own
+        ld = ((n_own + 1 + 63) // 64) * 64          # H is read for the own rows only: its stride does not wait for the halo count
         H = torch.zeros((K, ld), dtype=torch.float64, device=dev)
         XtX = torch.empty((K, K), dtype=torch.float64, device=dev)
         XtX_h = np.empty((K, K))
@@ -601,8 +714,8 @@ class ShardedFlashDeconv:
                 mu_x = Xs.mean(axis=0) + 1e-6
                 weight_y = weight / np.sqrt(mu_y + mu_y ** 2 / 100.0)
                 weight_x = weight / np.sqrt(mu_x + mu_x ** 2 / 100.0)
-            n_own, n_total = self.n_own, self.n_own + self.n_halo
-            ld = ((n_total + 1 + 63) // 64) * 64
+            n_own = self.n_own
+            ld = ((n_own + 1 + 63) // 64) * 64
             H = torch.zeros((K, ld), dtype=torch.float64, device=dev)
             XtX = torch.empty((K, K), dtype=torch.float64, device=dev)
             XtX_h = np.empty((K, K))
@@ -618,14 +731,16 @@ class ShardedFlashDeconv:
             csr.free()
         return self._solve_shard(H, XtX, XtX_h, yty.value, K, ld)
 
-    def _solve_shard(self, H, XtX, XtX_h, yty_part, K, ld):
+    def _solve_shard(self, H, XtX, XtX_h, yty_part, K, ldh):
         """Everything after H / XtX exist for the own rows: global YtY, lambda, the sharded BCD solve, the objective,
         normalisation (core/deconv.py:358-398)."""
         import torch
         lib = _lib.load()
         dev = H.device
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._finish_plan()                      # a queued plan: its counts have long arrived behind the sketch
         n_own, n_total = self.n_own, self.n_own + self.n_halo
+        ld = ((n_total + 1 + 63) // 64) * 64     # abundance planes: own rows, halo, the all-zero pad row
         t0 = time.perf_counter()
         # YtY only enters the final objective: its sum over the ranks rides in the objective's all-reduce at the end
         dmean = diag_mean(XtX_h)
@@ -640,12 +755,12 @@ class ShardedFlashDeconv:
             # 65-96 cell types: the next instantiated sweep size with all-zero pad types (include/fdx.h: fdx_solver_padded_k)
             K = int(lib.fdx_solver_padded_k(K_real))           # above 96: K itself (LDS-resident / generic sweep, one launch per iteration)
             if K != K_real:
-                Hp = torch.zeros((K, ld), dtype=torch.float64, device=dev)
+                Hp = torch.zeros((K, ldh), dtype=torch.float64, device=dev)
                 Hp[:K_real] = H
                 Gp = torch.zeros((K, K), dtype=torch.float64, device=dev)
                 Gp[:K_real, :K_real] = XtX
                 H, XtX = Hp, Gp
-        backend = HipBackend(self._local, H, ld, XtX, K, K_real=K_real)
+        backend = HipBackend(self._local, H, ldh, XtX, K, K_real=K_real)
         native = self.native_comm()
         if native is not None and not getattr(self, "time_sweeps", False):
             # the whole iteration loop in C++ on RCCL: boundary tiles first, halo traffic beside the interior sweep
@@ -653,7 +768,7 @@ class ShardedFlashDeconv:
             sinfo = _lib.SolveInfo()
             rel = np.zeros(max(int(self.max_iter), 1))
             which = ctypes.c_int32(0)
-            _lib.check(lib.fdx_sharded_solve_padded_dev(native, self._local.handle, ctypes.c_void_p(H.data_ptr()), ld,
+            _lib.check(lib.fdx_sharded_solve_padded_dev(native, self._local.handle, ctypes.c_void_p(H.data_ptr()), ldh,
                                                  ctypes.c_void_p(XtX.data_ptr()), K, K_real, float(lam), float(rho_eff), float(self.tol),
                                                  int(self.max_iter), ctypes.c_void_p(bufs[0].data_ptr()),
                                                  ctypes.c_void_p(bufs[1].data_ptr()), ld, ctypes.byref(sinfo), _lib.ptr_f64(rel),
@@ -752,7 +867,7 @@ def bench_main(a, rank, world, local_rank):
     sweep_ms = float(np.mean(model.sweep_ms_)) if getattr(model, "sweep_ms_", None) else None
     roof = None
     if sweep_ms:
-        own_nnz = int(model._full.info()[1])
+        own_nnz = int(model.own_nnz_)
         alg = 3 * model.n_own * K * 8 + (own_nnz + model.n_own + 1) * 4
         ach = alg / (sweep_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": bench.sweep_kernel_name(K), "achieved": round(ach, 1),

@@ -314,6 +314,20 @@ int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
  * (range starts must be multiples of 256).  The local graph indexes own spots first, then the halo. */
 int fdx_graph_localize(const fdx_graph* full, int32_t n_ranks, const int64_t* bounds, int32_t my_rank, void* stream,
                        fdx_graph** local);
+/* The three steps above (band lists -> own rows of the symmetrised graph -> local graph of rank `my_rank`) as ONE queued
+ * pipeline: after the bounding box of the coordinates nothing returns to the host - the halo, the local sliced ELL, the tile
+ * tables of the sweep, the send lists of every peer and the boundary / interior tile lists are produced on the device, with
+ * allocations sized by bounds the host knows.  The call returns with the kernels queued on `stream`; fdx_graph_perm_dev may be
+ * queued behind it at once, every other consumer of the graph (and fdx_graph_shard_status) waits for its counts first.
+ * 2 <= n_ranks <= 32, 1 to 3 coordinates, this rank must own at least one row; bounds as for fdx_graph_localize.
+ * fdx_graph_shard_status: structural non-zeros of the own rows, own rows with a tied k-th neighbour, `far` (a k-NN walk of an own
+ * row left its block or the band list overflowed: all-reduce it, and if any rank reports it every rank rebuilds by
+ * fdx_graph_knn_lists_dev + exchange), `overflow` (a bound of this pipeline was too small, e.g. hub rows: rebuild this rank's graph
+ * by the three stepwise calls - same rows, same order).  Reference: utils/graph.py:25-83 (the rows), core/solver.py:157-166
+ * (what makes a shard's halo sufficient). */
+int fdx_graph_shard_knn_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t k, int32_t n_ranks, const int64_t* bounds,
+                            int32_t my_rank, void* stream, fdx_graph** local);
+int fdx_graph_shard_status(const fdx_graph* local, int64_t* own_nnz, int64_t* knn_ties, int32_t* far, int32_t* overflow);
 /* Halo bookkeeping of a local graph: n_halo; send_counts[r] own rows rank r needs; recv_counts[r] halo rows owned by r. */
 /* test hook: the stored neighbour indices of one row as the sweeps read them (positions in this graph's own order; local graph:
  * own rows 0..n-1, halo slots n..n_total-1); at most cap are written, *deg_out is the row's degree */

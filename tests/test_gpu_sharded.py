@@ -22,7 +22,7 @@ def _st(torch):
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("build", ["replicated", "sharded", "band"])
+@pytest.mark.parametrize("build", ["replicated", "sharded", "band", "pipeline"])
 @pytest.mark.parametrize("W", [2, 3, 5])
 def test_virtual_ranks_equal_single_gpu(W, build):
     import torch
@@ -42,10 +42,25 @@ def test_virtual_ranks_equal_single_gpu(W, build):
 
     cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
     bounds = shard_bounds(n, W)
+    locals_ = None
     if build == "replicated":
         h = ctypes.c_void_p()
         _lib.check(lib.fdx_graph_build_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, _lib.GRAPH_KNN, 6, 0.0, _st(torch), ctypes.byref(h)))
         fulls = [_lib.Graph(h.value)] * W
+    elif build == "pipeline":
+        # the queued pipeline (fdx_graph_shard_knn_dev): every rank's LOCAL graph in one go, nothing read back before the counts
+        locals_, nnz_sum = [], 0
+        for r in range(W):
+            hl = ctypes.c_void_p()
+            _lib.check(lib.fdx_graph_shard_knn_dev(ctypes.c_void_p(cd.data_ptr()), n, 2, 6, W, _lib.ptr_i64(bounds), r, _st(torch),
+                                                   ctypes.byref(hl)))
+            locals_.append(_lib.Graph(hl.value))
+        for g in locals_:
+            nnz, ties, far, over = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+            _lib.check(lib.fdx_graph_shard_status(g.handle, ctypes.byref(nnz), ctypes.byref(ties), ctypes.byref(far), ctypes.byref(over)))
+            assert far.value == 0 and over.value == 0 and ties.value == 0
+            nnz_sum += nnz.value
+        assert nnz_sum == ref.adjacency_.nnz
     else:
         # sharded build: every rank finds the k-NN lists of its own rows, the rows are all-gathered (here: copied between
         # the virtual ranks' buffers), every rank symmetrises its own rows only
@@ -89,9 +104,12 @@ def test_virtual_ranks_equal_single_gpu(W, build):
     ranks = []
     yty = 0.0
     for r in range(W):
-        hl = ctypes.c_void_p()
-        _lib.check(lib.fdx_graph_localize(fulls[r].handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
-        g = _lib.Graph(hl.value)
+        if locals_ is not None:
+            g = locals_[r]
+        else:
+            hl = ctypes.c_void_p()
+            _lib.check(lib.fdx_graph_localize(fulls[r].handle, W, _lib.ptr_i64(bounds), r, _st(torch), ctypes.byref(hl)))
+            g = _lib.Graph(hl.value)
         n_own = int(bounds[r + 1] - bounds[r])
         perm = torch.empty(max(n_own, 1), dtype=torch.int32, device=dev)
         _lib.check(lib.fdx_graph_perm_dev(g.handle, ctypes.c_void_p(perm.data_ptr()), _st(torch)))
@@ -473,6 +491,8 @@ def test_native_loop_thread_ranks_equal_single_gpu(W, overlap, monkeypatch):
     from flashdeconv_amd.distributed import diag_mean
     if not overlap:
         monkeypatch.setenv("FDX_NO_OVERLAP", "1")               # one sweep launch per iteration, halo on the compute stream
+    else:
+        monkeypatch.setenv("FDX_SPLIT_MIN_TILES", "0")          # shards this small would not be split by themselves (comm.cpp)
     dev = torch.device("cuda", 0)
     n, G, K, d = 6000, 300, 12, 64
     Y, X, coords, _ = datagen.count_like(n, G, K, 0.1, 11)

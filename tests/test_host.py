@@ -278,6 +278,21 @@ def test_bench_spawns_its_own_ranks():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["RANK"] == "0" and line["LOCAL_RANK"] == "0" and line["WORLD_SIZE"] == "3" and line["MASTER_ADDR"] == "127.0.0.1"
     assert line["gpus"] == 3 and line["scaling"] == "weak" and int(line["MASTER_PORT"]) > 0
+    # one rank dies at start-up (exit code 3), the others sit as in a collective: the parent ends them and returns non-zero
+    # within seconds, naming the rank and where its stderr went
+    import time
+    env3 = dict(env, FDX_BENCH_SPAWN_FAIL_RANK="1", FDX_BENCH_SPAWN_HANG="120")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env3, capture_output=True, text=True,
+                         timeout=100)
+    assert out.returncode == 3 and time.monotonic() - t0 < 30, (out.returncode, out.stderr)
+    assert "rank 1 of 3 exited with code 3" in out.stderr and "rank asked to fail" in out.stderr
+    # ... and a job whose ranks never produce a result ends at the rendezvous timeout
+    env4 = dict(env, FDX_BENCH_SPAWN_HANG="120")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-timeout", "2"], env=env4,
+                         capture_output=True, text=True, timeout=100)
+    assert out.returncode == 124 and time.monotonic() - t0 < 30 and "produced no result in time" in out.stderr
     # under torch.distributed.run the environment is already there: no second level of processes
     env2 = dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True,

@@ -80,7 +80,9 @@ def virtual_plan(torch, coords, W, k=6, times=None, route=None):
     (with their bookkeeping) and the global structural nnz.  route "band" (default; FDX_PLAN_ALLGATHER=1 selects "allgather"):
     every rank finds the lists of its own rows and of its band and symmetrises - nothing is exchanged; "allgather": the lists
     of the own rows, all-gathered (here W^2 device copies)."""
-    route = route or ("allgather" if os.environ.get("FDX_PLAN_ALLGATHER") else "band")
+    route = route or ("allgather" if os.environ.get("FDX_PLAN_ALLGATHER") else "band" if os.environ.get("FDX_PLAN_STEPWISE") else "pipeline")
+    if route == "pipeline":
+        return virtual_plan_pipeline(torch, coords, W, k, times)
     from flashdeconv_amd import _lib
     from flashdeconv_amd.distributed import shard_bounds
     lib = _lib.load()
@@ -146,6 +148,65 @@ def virtual_plan(torch, coords, W, k=6, times=None, route=None):
             R["g"].close()
         return virtual_plan(torch, coords, W, k, times, route="allgather")
     for r in range(W):                          # what r sends to q is what q expects from r
+        for q in range(W):
+            assert ranks[r]["send"][q] == ranks[q]["recv"][r]
+    return ranks, int(nnz), int(ties), bounds
+
+
+def shard_graph(torch, coords, W, r, bounds, k=6):
+    """Rank r's local graph by the queued pipeline (fdx_graph_shard_knn_dev), as ShardedFlashDeconv.plan queues it; returns
+    (graph, own ids tensor) WITHOUT waiting for the counts."""
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    n, dim = coords.shape
+    hl = ctypes.c_void_p()
+    _lib.check(lib.fdx_graph_shard_knn_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, W, _lib.ptr_i64(bounds), r, _st(torch),
+                                           ctypes.byref(hl)))
+    g = _lib.Graph(hl.value)
+    n_own = int(bounds[r + 1] - bounds[r])
+    perm = torch.empty(max(n_own, 1), dtype=torch.int32, device=coords.device)
+    _lib.check(lib.fdx_graph_perm_dev(g.handle, ctypes.c_void_p(perm.data_ptr()), _st(torch)))
+    return g, perm[:n_own].long()
+
+
+def shard_status(g):
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    nnz, ties, far, over = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    _lib.check(lib.fdx_graph_shard_status(g.handle, ctypes.byref(nnz), ctypes.byref(ties), ctypes.byref(far), ctypes.byref(over)))
+    return int(nnz.value), int(ties.value), int(far.value), int(over.value)
+
+
+def virtual_plan_pipeline(torch, coords, W, k=6, times=None):
+    """The sharded k-NN plan as ShardedFlashDeconv.plan runs it by default: one queued pipeline per rank, the counts read once."""
+    from flashdeconv_amd import _lib
+    from flashdeconv_amd.distributed import shard_bounds
+    lib = _lib.load()
+    n, dim = coords.shape
+    bounds = shard_bounds(n, W)
+    times = times if times is not None else {}
+    t = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
+    times["plan_route"] = "pipeline"
+    times["plan_ms"] = []
+    ranks, nnz, ties, far, over = [], 0, 0, 0, 0
+    for r in range(W):
+        if bounds[r + 1] <= bounds[r]:            # a rank without rows: the stepwise path (nothing to queue)
+            return virtual_plan(torch, coords, W, k, times, route="band")
+        t0 = t()
+        g, own = shard_graph(torch, coords, W, r, bounds, k)
+        a, b, c, d = shard_status(g)
+        nh = ctypes.c_int64(0)
+        sc, rc = np.zeros(W, dtype=np.int32), np.zeros(W, dtype=np.int32)
+        _lib.check(lib.fdx_graph_halo_info(g.handle, ctypes.byref(nh), _lib.ptr_i32(sc), _lib.ptr_i32(rc)))
+        times["plan_ms"].append((t() - t0) * 1e3)
+        nnz, ties, far, over = nnz + a, ties + b, far + c, over + d
+        n_own = int(bounds[r + 1] - bounds[r])
+        ranks.append(dict(g=g, own=own, n_own=n_own, n_halo=int(nh.value), lo=int(bounds[r]), hi=int(bounds[r + 1]), send=sc, recv=rc))
+    if far or over:                               # the drivers rebuild: far -> by exchange, a bound too small -> stepwise
+        for R in ranks:
+            R["g"].close()
+        return virtual_plan(torch, coords, W, k, times, route="allgather" if far else "band")
+    for r in range(W):
         for q in range(W):
             assert ranks[r]["send"][q] == ranks[q]["recv"][r]
     return ranks, int(nnz), int(ties), bounds
@@ -294,6 +355,81 @@ def alone_solve_and_finish(torch, ranks, K, lam, rho_eff, n_iter, times):
         del bufs, b, p
 
 
+def alone_pipelined(torch, coords, ranks, bounds, X, make_rows, d, mode, K, lam, rho_eff, n_iter, times, k=6, random_state=0,
+                    rank_ids=None, world=None):
+    """Every rank's WHOLE share of the sharded fit, ALONE and as the driver queues it - plan (one queued pipeline), the sketch
+    behind it without a host round trip in between, the counts, the iteration loop (loopback transport: no peers, no wire time),
+    export beside the objective pass - timed as ONE interval, host clock, device idle before and after: the rank's critical path
+    as it would run, not the sum of separately synchronised stages."""
+    from flashdeconv_amd import _lib
+    from flashdeconv_amd.core.sketching import countsketch_tables
+    from flashdeconv_amd.utils.genes import compute_leverage_scores
+    lib = _lib.load()
+    W = world or len(ranks)
+    rank_ids = rank_ids if rank_ids is not None else list(range(len(ranks)))
+    trace = bool(os.environ.get("FDX_RANK_TRACE"))
+    Kx, G = X.shape
+    lev = compute_leverage_scores(X)
+    bucket, weight = countsketch_tables(G, d, lev, random_state)
+    b32 = np.ascontiguousarray(bucket, dtype=np.int32)
+    Xc = np.ascontiguousarray(X, dtype=np.float64)
+    t = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
+    times["pipelined_ms"] = []
+    for r, S in zip(rank_ids, ranks):
+        dev = S["H"].device
+        Y = make_rows(S["lo"], S["hi"])
+        n_own = S["n_own"]
+        ldh = ((n_own + 1 + 63) // 64) * 64
+        H = torch.empty((Kx, ldh), dtype=torch.float64, device=dev)
+        XtX = torch.empty((Kx, Kx), dtype=torch.float64, device=dev)
+        XtX_h = np.empty((Kx, Kx))
+        bufs = [torch.empty((Kx, S["ld"]), dtype=torch.float64, device=dev) for _ in range(2)]     # ld from the real plan: same halo
+        b = torch.empty((n_own, Kx), dtype=torch.float64, device=dev)
+        p = torch.empty((n_own, Kx), dtype=torch.float64, device=dev)
+        side = torch.cuda.Stream(device=dev, priority=-1)
+        comm = ctypes.c_void_p()
+        _lib.check(lib.fdx_comm_init_loopback(r, W, ctypes.byref(comm)))
+        best = None
+        for rep in range(int(os.environ.get("FDX_RANK_REPS", "6"))):     # the fastest of a few: a rank's share is ~1 ms, one stray host delay is 20 % of it
+            part, yty = np.zeros(4), ctypes.c_double(0.0)
+            info, which, rel = _lib.SolveInfo(), ctypes.c_int32(0), np.zeros(max(n_iter, 1))
+            t0 = t()
+            g, own = shard_graph(torch, coords, W, r, bounds, k)                                  # queued
+            h1 = time.perf_counter()
+            H.zero_()
+            _lib.check(lib.fdx_prepare_dev(ctypes.c_void_p(Y.data_ptr()), _lib.FDX_F32, n_own, G, G, None, _lib.ptr_f64(Xc), Kx,
+                                           _lib.ptr_i32(b32), _lib.ptr_f64(weight), _lib.ptr_f64(weight), d, mode, mode,
+                                           ctypes.c_void_p(H.data_ptr()), ldh, ctypes.c_void_p(XtX.data_ptr()), _lib.ptr_f64(XtX_h),
+                                           ctypes.byref(yty), _st(torch)))
+            h2 = time.perf_counter()
+            st_ = shard_status(g)                                                                # long there
+            nh = ctypes.c_int64(0)
+            _lib.check(lib.fdx_graph_halo_info(g.handle, ctypes.byref(nh), None, None))
+            assert int(nh.value) == S["n_halo"] and not st_[2] and not st_[3], (nh.value, S["n_halo"], st_)
+            _lib.check(lib.fdx_sharded_solve_dev(comm, g.handle, ctypes.c_void_p(H.data_ptr()), ldh, ctypes.c_void_p(XtX.data_ptr()), Kx,
+                                                 lam, rho_eff, 0.0, n_iter, ctypes.c_void_p(bufs[0].data_ptr()),
+                                                 ctypes.c_void_p(bufs[1].data_ptr()), S["ld"], ctypes.byref(info), _lib.ptr_f64(rel),
+                                                 ctypes.byref(which), _st(torch)))
+            h3 = time.perf_counter()
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            _lib.check(lib.fdx_normalize_dev(ctypes.c_void_p(bufs[which.value].data_ptr()), S["ld"], n_own, Kx, ctypes.c_void_p(b.data_ptr()),
+                                             ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(side.cuda_stream)))
+            _lib.check(lib.fdx_objective_partials_dev(g.handle, ctypes.c_void_p(bufs[which.value].data_ptr()), S["ld"],
+                                                      ctypes.c_void_p(H.data_ptr()), ldh, ctypes.c_void_p(XtX.data_ptr()), Kx,
+                                                      _lib.ptr_f64(part), _st(torch)))
+            cur.wait_stream(side)
+            dt = (t() - t0) * 1e3
+            if trace:
+                print(f"[rank {r}] host: plan call {1e3 * (h1 - t0):.3f}, prepare (to its sync) {1e3 * (h2 - h1):.3f}, counts + loop "
+                      f"{1e3 * (h3 - h2):.3f}, finish {dt - 1e3 * (h3 - t0):.3f}, total {dt:.3f} ms", file=sys.stderr)
+            best = dt if best is None else min(best, dt)
+            g.close()
+        lib.fdx_comm_destroy(comm)
+        times["pipelined_ms"].append(best)
+        del Y, H, bufs, b, p
+
+
 def assemble(torch, ranks, results, n, K, want_props=True):
     """(beta, proportions) of all spots, (n, K) row-major in the caller's order, through fdx_normalize_dev per rank."""
     from flashdeconv_amd import _lib
@@ -342,9 +478,20 @@ def run_config5(torch, W, n=10_000_000, G=5000, K=50, d=1024, seed=11, max_iter=
     beta, prop = assemble(torch, ranks, results, n, K)
     if alone:
         alone_solve_and_finish(torch, ranks, K, lam, rho_eff, results[0]["n_iterations"], times)
-        times["per_rank_critical_path_ms"] = [times["knn_lists_ms"][r] + times["from_lists_ms"][r] + times["localize_ms"][r] +
-                                              times["prepare_ms"][r] + times["solve_alone_ms"][r] + times["finish_alone_ms"][r]
-                                              for r in range(W)]
+        if times.get("plan_route") == "pipeline":
+            plan_ms = times["plan_ms"]
+        else:
+            plan_ms = [times["knn_lists_ms"][r] + times["from_lists_ms"][r] + times["localize_ms"][r] for r in range(W)]
+            times["plan_ms"] = plan_ms
+        # sum of the separately synchronised stages (what rounds 3-4 reported) ...
+        times["per_rank_stage_sum_ms"] = [plan_ms[r] + times["prepare_ms"][r] + times["solve_alone_ms"][r] + times["finish_alone_ms"][r]
+                                          for r in range(W)]
+        times["per_rank_critical_path_ms"] = times["per_rank_stage_sum_ms"]
+        if times.get("plan_route") == "pipeline":
+            # ... and the rank's share timed as ONE interval, queued as the driver queues it
+            alone_pipelined(torch, coords, ranks, bounds, X, lambda lo, hi: gaussian_rows(torch, X32, lo, hi, seed), d, _lib.PRE_RAW, K,
+                            lam, rho_eff, results[0]["n_iterations"], times)
+            times["per_rank_critical_path_ms"] = times["pipelined_ms"]
     info = dict(n=n, G=G, K=K, d=d, world=W, nnz=nnz, knn_ties=ties, lambda_used=lam, rho_eff=rho_eff, YtY=yty,
                 n_iterations=[r["n_iterations"] for r in results], converged=[r["converged"] for r in results],
                 final_change=[r["final_change"] for r in results], n_own=[R["n_own"] for R in ranks],
