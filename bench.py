@@ -398,13 +398,16 @@ def main():
                 "knn_ties": info["knn_ties"], "nnz": info["nnz"], "n_halo": info["n_halo"], "plan_route": t.get("plan_route"),
                 "per_rank_critical_path_ms": [round(x, 3) for x in crit],
                 "per_rank_stage_sum_ms": [round(x, 3) for x in t.get("per_rank_stage_sum_ms", crit)],
+                "per_rank_c_calls_ms": [round(x, 3) for x in t["pipelined_ms"]] if "pipelined_ms" in t else None,
                 "per_rank_stage_ms": {k: t[k] for k in ("plan_ms", "prepare_ms", "solve_alone_ms", "finish_alone_ms") if k in t},
                 "t1_ms": None if t1_ms is None else round(t1_ms, 3),
                 "projected_speedup": None if t1_ms is None else round(t1_ms / max(crit), 2),
-                "projection_note": "projection, no RCCL wire time: every rank's whole share - plan (one queued pipeline), sketch -> H, the "
-                                   "iteration loop (loopback transport, same iteration count), export + objective - timed ALONE on one GPU "
-                                   "as ONE interval with warm caches (per_rank_stage_sum_ms: the same stages synchronised one by one); "
-                                   "T1 = the same job unsharded on the same GPU",
+                "projection_note": "projection, no RCCL wire time: every rank's whole share through the real driver "
+                                   "(ShardedFlashDeconv.plan + fit_transform with a LoopbackComm: leverage, tables, plan, sketch -> H, the "
+                                   "native iteration loop over the loopback transport for the job's iteration count, export + objective), "
+                                   "timed ALONE on one GPU as ONE interval with warm caches (per_rank_c_calls_ms: the same C calls without "
+                                   "the class; per_rank_stage_sum_ms: the stages synchronised one by one); T1 = the same job unsharded "
+                                   "on the same GPU",
                 "stage_ms": t, "wall_s_incl_generation": round(wall, 2), "data": "synthetic"}
         print(json.dumps(line))
         return

@@ -48,6 +48,22 @@ class FitParams(ctypes.Structure):
     ]
 
 
+class ShardFitParams(ctypes.Structure):
+    """fdx_shard_fit_params (include/fdx.h)."""
+    _fields_ = [("sketch_dim", c_i32), ("mode_y", c_i32), ("mode_x", c_i32), ("lambda_auto", c_i32), ("max_iter", c_i32),
+                ("stop_on_ties", c_i32), ("lambda_spatial", c_double), ("rho_sparsity", c_double), ("tol", c_double),
+                ("n_total_spots", c_i64), ("nnz_total", c_i64)]
+
+
+class ShardFitInfo(ctypes.Structure):
+    """fdx_shard_fit_info (include/fdx.h)."""
+    _fields_ = [("status", c_i32), ("reserved", c_i32), ("nnz_total", c_i64), ("knn_ties_total", c_i64), ("own_nnz", c_i64),
+                ("n_halo", c_i64), ("lambda_used", c_double), ("rho_effective", c_double), ("YtY", c_double), ("solve", SolveInfo)]
+
+
+SHARD_FAR, SHARD_OVERFLOW, SHARD_TIES = 1, 2, 3
+
+
 class CsrView(ctypes.Structure):
     """fdx_csr_view: device pointers of a CSR matrix (include/fdx.h)."""
     _fields_ = [("indptr", c_void_p), ("indices", c_void_p), ("data", c_void_p), ("dtype", c_i32), ("n", c_i64),
@@ -133,6 +149,8 @@ SIGNATURES = {
     "fdx_sharded_solve_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_double, c_double, c_double, c_i32,
                                       c_void_p, c_void_p, c_i64, ctypes.POINTER(SolveInfo), p_double, p_i32, c_void_p]),
     "fdx_solver_padded_k": (c_i32, [c_i32]),
+    "fdx_shard_fit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_i32, p_i32, p_double, p_double,
+                                  ctypes.POINTER(ShardFitParams), c_void_p, c_void_p, p_double, ctypes.POINTER(ShardFitInfo), c_void_p]),
     "fdx_sharded_solve_padded_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_i32, c_double, c_double, c_double,
                                              c_i32, c_void_p, c_void_p, c_i64, ctypes.POINTER(SolveInfo), p_double, p_i32, c_void_p]),
     "fdx_tile_schedule": (c_int, [p_i32, p_double, c_i32, c_i32, c_i32, c_i32, c_i32, p_i32, p_i32, c_void_p, p_i32, p_double,
@@ -149,6 +167,8 @@ SIGNATURES = {
     "fdx_graph_knn_ties": (c_int, [c_void_p, p_i64]),
     "fdx_graph_knn_far": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "fdx_ckdtree_knn": (c_int, [p_double, c_i64, c_i32, c_i32, c_void_p, c_void_p]),
+    "fdx_ckdtree_knn_rows": (c_int, [p_double, c_i64, c_i32, c_i32, p_i64, c_i64, c_void_p]),
+    "fdx_graph_plan_order_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdx_bcd_solve": (c_int, [c_void_p, p_double, p_double, c_i64, c_i32, c_i32, c_double, c_double, c_i32, c_double,
                               c_i32, p_double, p_double, p_double, ctypes.POINTER(SolveInfo)]),
 }

@@ -8,6 +8,7 @@
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
 #include "graph_build.h"
+#include "prepare.h"
 #include "sketch_plan.h"
 #include "solver.h"
 
@@ -62,6 +63,11 @@ int fdx_graph_knn_lists_band_dev(const double* coords_dev, int64_t n, int32_t di
     *plan = nullptr;
     FDX_REQUIRE(coords_dev && nbr_dev && cnt_dev, "fdx_graph_knn_lists_band_dev: null argument");
     return graph_knn_lists(coords_dev, n, dim, k, lo, hi, nbr_dev, cnt_dev, plan, (hipStream_t)stream, true);
+}
+
+int fdx_graph_plan_order_dev(const fdx_graph_plan* plan, int32_t* perm_out_dev, int32_t* rank_out_dev, void* stream) {
+    FDX_REQUIRE(plan != nullptr, "fdx_graph_plan_order_dev: null plan");
+    return graph_plan_order(plan, perm_out_dev, rank_out_dev, (hipStream_t)stream);
 }
 
 int fdx_graph_knn_far(const fdx_graph* g, int32_t* far) {
@@ -181,80 +187,91 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
                     const double* X, int32_t K, const int32_t* bucket, const double* weight_y, const double* weight_x,
                     int32_t d, int32_t mode_y_in, int32_t mode_x, double* H_out_dev, int64_t ldh, double* XtX_out_dev,
                     double* XtX_out_host, double* YtY_partial_out, void* stream) {
+    FDX_REQUIRE(XtX_out_dev != nullptr, "fdx_prepare_dev: null array");
+    hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
+    PrepareJob job;
+    // on any return both streams are idle before the job's buffers go back to the pool
+    struct Drain { PrepareJob* j; hipStream_t s; ~Drain() { if (j->side) (void)hipStreamSynchronize(j->side); (void)hipStreamSynchronize(s); } } drain{&job, st};
+    FDX_TRY(prepare_queue(&job, Y_dev, y_dtype, n, G, ldy, row_map_dev, X, K, bucket, weight_y, weight_x, d, mode_y_in, mode_x,
+                          H_out_dev, ldh, XtX_out_host, st));
+    // the caller's XtX buffer belongs to the caller's stream: filled there (the stream already waits for the X side)
+    FDX_HIP(hipMemcpyAsync(XtX_out_dev, job.dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, st));
+    double yty = 0.0;
+    if (n > 0) FDX_HIP(hipMemcpyAsync(&yty, job.dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    if (job.side) FDX_HIP(hipStreamSynchronize(job.side));
+    if (YtY_partial_out) *YtY_partial_out = yty;
+    return 0;
+}
+
+}  // extern "C"
+
+namespace fdx {
+int prepare_queue(PrepareJob* job, const void* Y_dev, int y_dtype, long long n, int G, long long ldy, const int* row_map_dev,
+                  const double* X, int K, const int* bucket, const double* weight_y, const double* weight_x, int d, int mode_y_in,
+                  int mode_x, double* H_out_dev, long long ldh, double* XtX_host, hipStream_t st) {
     const int32_t mode_y = mode_y_in & 0xff;
     TileF64Math f64_math((mode_y_in & FDX_PRE_F64_MATH) != 0);
     FDX_REQUIRE(y_dtype == FDX_F32 || y_dtype == FDX_F64, "fdx_prepare_dev: Y dtype must be FDX_F32 or FDX_F64");
     FDX_REQUIRE(n >= 0 && G > 0 && K > 0 && d > 0, "fdx_prepare_dev: bad shape");
-    FDX_REQUIRE(X && bucket && weight_y && weight_x && H_out_dev && XtX_out_dev, "fdx_prepare_dev: null array");
+    FDX_REQUIRE(X && bucket && weight_y && weight_x && H_out_dev, "fdx_prepare_dev: null array");
     FDX_REQUIRE(ldh >= n && ldy >= G, "fdx_prepare_dev: leading dimension too small");
-    hipStream_t st = (hipStream_t)stream;
-    PoolStream pool_stream(st);
-    // the schedules of an Omega are built once per content and device (sketch_plan.cpp: the cache the single-GPU fit uses) -
-    // at 5000 genes x 1024 buckets building them was 10 of the 23 ms of this call
-    std::shared_ptr<SketchPlan> plan_y_p, plan_x_p;
     // The X side (upload of the signatures - a pageable copy: the host waits for it -, X_sketch, XtX and its copy to the host) runs
     // on the library's side stream: queued on the caller's stream behind a shard plan that is still executing, the upload made
     // the host wait for the whole plan and the launches behind it arrived on an idle device (70 us of a 125k-spot rank's 1.6 ms).
-    DevBuf dX, dXs, dG, dYs, dRowSq, dSum;     // declared above the drain: on any return both streams are idle before these go back to the pool
+    // The schedules of an Omega are built once per content and device (sketch_plan.cpp: the cache the single-GPU fit uses).
     hipStream_t side = getenv("FDX_NO_SIDE_STREAM") ? nullptr : library_side_stream();
     if (side == st) side = nullptr;
+    job->side = side;
     const hipStream_t xs = side ? side : st;
-    struct Drain { hipStream_t a, b; ~Drain() { if (a) (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); } } drain{side, st};
-    hipEvent_t evX = nullptr;
-    struct EvGuard { hipEvent_t* e; ~EvGuard() { if (*e) (void)hipEventDestroy(*e); } } evX_guard{&evX};
     {
         PoolStream pool_xs(xs);
         // a new Omega's tables are uploaded on xs as well (the caller's stream waits for the event below before the sketch)
-        FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, xs, &plan_y_p));
-        if (weight_x == weight_y) plan_x_p = plan_y_p;
-        else FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, xs, &plan_x_p));
-        FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
-        FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
-        FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
-        FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, xs));
-        FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, plan_x_p->dev(), dXs.as<double>(), d, nullptr, xs));
-        FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, xs));
-        if (XtX_out_host)
-            FDX_HIP(hipMemcpyAsync(XtX_out_host, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, xs));
-        if (side) {
-            FDX_HIP(hipEventCreateWithFlags(&evX, hipEventDisableTiming));
-            FDX_HIP(hipEventRecord(evX, side));
-            FDX_HIP(hipStreamWaitEvent(st, evX, 0));
-        }
+        FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, xs, &job->plan_y));
+        if (weight_x == weight_y) job->plan_x = job->plan_y;
+        else FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, xs, &job->plan_x));
+        FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
+        FDX_TRY(job->dXs.alloc((size_t)K * d * sizeof(double)));
+        FDX_TRY(job->dG.alloc((size_t)K * K * sizeof(double)));
+        FDX_HIP(hipMemcpyAsync(job->dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, xs));
+        FDX_TRY(launch_sketch_rows(job->dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, job->plan_x->dev(), job->dXs.as<double>(), d, nullptr, xs));
+        FDX_TRY(launch_xyt(job->dXs.as<double>(), job->dXs.as<double>(), d, K, d, K, job->dG.as<double>(), K, nullptr, xs));
+        if (XtX_host)
+            FDX_HIP(hipMemcpyAsync(XtX_host, job->dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, xs));
+        FDX_HIP(hipEventCreateWithFlags(&job->evX, hipEventDisableTiming));
+        FDX_HIP(hipEventRecord(job->evX, xs));
+        if (side) FDX_HIP(hipStreamWaitEvent(st, job->evX, 0));
     }
-    // the caller's XtX buffer belongs to the caller's stream: filled there, behind the event
-    FDX_HIP(hipMemcpyAsync(XtX_out_dev, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, st));
-    SketchPlan& plan_y = *plan_y_p;
-    double yty = 0.0;
+    SketchPlan& plan_y = *job->plan_y;
     if (n > 0) {
         FDX_REQUIRE(Y_dev != nullptr, "fdx_prepare_dev: null Y");
         const long long chunk = std::min<long long>(n, 1LL << 18);
-        FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
-        FDX_TRY(dSum.alloc(sizeof(double)));
+        FDX_TRY(job->dRowSq.alloc((size_t)n * sizeof(double)));
+        FDX_TRY(job->dSum.alloc(sizeof(double)));
         // same choice as the single-GPU fit (fit.cpp): shards start on multiples of 256, so the fused kernel's groups of 16
         // spots coincide with those of an unsharded run and H keeps the same bits
         const bool fused = fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, mode_y, plan_y.dev());
         if (fused)
-            FDX_TRY(launch_sketch_contract(Y_dev, y_dtype, ldy, row_map_dev, n, G, d, mode_y, plan_y.dev(), dXs.as<double>(), K,
-                                           H_out_dev, ldh, dRowSq.as<double>(), st));
+            FDX_TRY(launch_sketch_contract(Y_dev, y_dtype, ldy, row_map_dev, n, G, d, mode_y, plan_y.dev(), job->dXs.as<double>(), K,
+                                           H_out_dev, ldh, job->dRowSq.as<double>(), st));
         else
-            FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
+            FDX_TRY(job->dYs.alloc((size_t)chunk * d * sizeof(double)));
         for (long long r0 = 0; r0 < n && !fused; r0 += chunk) {
             const long long nr = std::min(chunk, n - r0);
             const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
             if (!row_map_dev) ybase += (size_t)r0 * (size_t)ldy * (y_dtype == FDX_F32 ? 4 : 8);
             FDX_TRY(launch_sketch_rows(ybase, y_dtype, ldy, row_map_dev ? row_map_dev + r0 : nullptr, nr, G, d, mode_y,
-                                       plan_y.dev(), dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
-            FDX_TRY(launch_xyt(dXs.as<double>(), dYs.as<double>(), d, nr, d, K, H_out_dev + r0, ldh, nullptr, st));
+                                       plan_y.dev(), job->dYs.as<double>(), d, job->dRowSq.as<double>() + r0, st));
+            FDX_TRY(launch_xyt(job->dXs.as<double>(), job->dYs.as<double>(), d, nr, d, K, H_out_dev + r0, ldh, nullptr, st));
         }
-        FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));
-        FDX_HIP(hipMemcpyAsync(&yty, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+        FDX_TRY(launch_sum_partials(job->dRowSq.as<double>(), n, job->dSum.as<double>(), 1, 1, st));
     }
-    FDX_HIP(hipStreamSynchronize(st));
-    if (side) FDX_HIP(hipStreamSynchronize(side));
-    if (YtY_partial_out) *YtY_partial_out = yty;
     return 0;
 }
+}  // namespace fdx
+
+extern "C" {
 
 // The same for a CSR shard (core/deconv.py:181-188 sparse log-CPM rule, core/sketching.py:194-199): the own rows stay
 // sparse in HBM; gene_idx selects G of the matrix's columns (NULL = all, in order).

@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,7 @@
 #include "fdx_graph.h"
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
+#include "prepare.h"
 #include "solver.h"
 
 using namespace fdx;
@@ -376,10 +378,137 @@ int fdx_sharded_solve_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, 
 
 int32_t fdx_solver_padded_k(int32_t K) { return fdx::solver_padded_K(K); }
 
+static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, int32_t K,
+                              int32_t K_real, double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev,
+                              double* beta1_dev, int64_t ld, fdx_solve_info* info, double* rel_changes_out, int32_t* result_buffer,
+                              void* stream);
+
 int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, int32_t K,
                                  int32_t K_real, double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev,
                                  double* beta1_dev, int64_t ld, fdx_solve_info* info, double* rel_changes_out, int32_t* result_buffer,
                                  void* stream) {
+    return sharded_solve_impl(c, g, H_dev, ldh, XtX_dev, K, K_real, lambda, rho_eff, tol, max_iter, beta0_dev, beta1_dev, ld, info,
+                              rel_changes_out, result_buffer, stream);
+}
+
+// One rank's whole fit behind a queued plan: sketch -> H of the own rows, the plan's counts all-reduced while the sketch runs,
+// lambda, the iteration loop, objective and export - one call, the device never waiting for the host between its stages
+// (the separate calls cost a 125k-spot rank ~0.35 ms of idle device: 1.25 -> 1.6 ms).  Reference: core/deconv.py:326-398 for the
+// stages, core/solver.py:157-166 for the sharding.
+int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_t y_dtype, int64_t n_own, int32_t G, int64_t ldy,
+                      const double* X, int32_t K, const int32_t* bucket, const double* weight_y, const double* weight_x,
+                      const fdx_shard_fit_params* prm, double* beta_out_dev, double* prop_out_dev, double* rel_changes_out,
+                      fdx_shard_fit_info* info, void* stream) {
+    FDX_REQUIRE(c && g && prm && info && X && bucket && weight_y && weight_x, "fdx_shard_fit_dev: null argument");
+    FDX_REQUIRE(n_own == g->n && n_own > 0, "fdx_shard_fit_dev: the matrix must hold the graph's own rows (at least one)");
+    FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_PAD, "fdx_shard_fit_dev: 1 to 96 cell types (more: the stepwise calls)");
+    FDX_REQUIRE(prm->sketch_dim > 0 && prm->max_iter >= 0 && prm->n_total_spots >= n_own, "fdx_shard_fit_dev: bad parameters");
+    std::memset(info, 0, sizeof(*info));
+    hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
+    FDX_TRY(comm_streams(c));
+    const int W = c->world;
+    const int KP = solver_padded_K(K);
+    const long long ldh = round_up(n_own + 1, 64);
+    PrepareJob job;
+    DevBuf dH, dGp, dB0, dB1, dCnt, objp, objo, dFin;
+    // on any return every stream this call used is idle before the buffers above go back to the pool
+    struct Drain { PrepareJob* j; fdx_comm* c; hipStream_t s; ~Drain() { if (j->side) (void)hipStreamSynchronize(j->side); if (c->side) (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(s); } } drain{&job, c, st};
+    FDX_TRY(dH.alloc((size_t)KP * ldh * sizeof(double)));
+    FDX_TRY(solver_zero_pad(dH.as<double>(), ldh, n_own, K, st));                       // the sketch writes columns [0, n_own) of the real types
+    if (KP != K) FDX_HIP(hipMemsetAsync(dH.as<double>() + (size_t)K * ldh, 0, (size_t)(KP - K) * ldh * sizeof(double), st));
+    double* Gh = (double*)pinned_scratch(4, (size_t)K * K * sizeof(double) + 64);
+    FDX_REQUIRE(Gh != nullptr, "fdx_shard_fit_dev: pinned host buffer");
+    FDX_TRY(prepare_queue(&job, Y_dev, y_dtype, n_own, G, ldy, nullptr, X, K, bucket, weight_y, weight_x, prm->sketch_dim, prm->mode_y,
+                          prm->mode_x, dH.as<double>(), ldh, Gh, st));
+    const double* XtX_dev = job.dG.as<double>();
+    if (KP != K) {
+        PoolStream pool_xs(job.side ? job.side : st);
+        FDX_TRY(dGp.alloc((size_t)KP * KP * sizeof(double)));
+        FDX_TRY(solver_pad_square(job.dG.as<double>(), K, dGp.as<double>(), KP, job.side ? job.side : st));
+        if (job.side) {                                                     // behind the first event: the sweeps wait for this one too
+            FDX_HIP(hipEventRecord(c->ev_packed, job.side));
+            FDX_HIP(hipStreamWaitEvent(st, c->ev_packed, 0));
+        }
+        XtX_dev = dGp.as<double>();
+    }
+
+    // ---- the plan's counts: all-reduced on the communication stream as soon as the plan has produced them, beside the sketch
+    double* cnt_h = (double*)pinned_scratch(5, 8 * sizeof(double));
+    FDX_REQUIRE(cnt_h != nullptr, "fdx_shard_fit_dev: pinned host buffer");
+    double tot[4] = {0, 0, 0, 0};
+    const bool queued_plan = g->shard_pending || g->counts_dev.p != nullptr;
+    if (queued_plan && g->counts_dev.p && W > 1 && !c->loopback) {
+        FDX_TRY(dCnt.alloc(4 * sizeof(double)));
+        if (g->shard_pending) FDX_HIP(hipStreamWaitEvent(c->side, g->meta_event, 0));
+        FDX_HIP(hipMemcpyAsync(dCnt.p, g->counts_dev.p, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->side));
+        FDX_TRY(allreduce(c, dCnt.p, 4, false, c->side));
+        FDX_HIP(hipMemcpyAsync(cnt_h, dCnt.p, 4 * sizeof(double), hipMemcpyDeviceToHost, c->side));
+        FDX_HIP(hipStreamSynchronize(c->side));
+        for (int j = 0; j < 4; ++j) tot[j] = cnt_h[j];
+        FDX_TRY(fdx::graph_meta_sync(g));
+    } else {
+        FDX_TRY(fdx::graph_meta_sync(g));
+        tot[0] = (double)g->nnz; tot[1] = (double)g->knn_ties; tot[2] = (double)g->knn_far; tot[3] = (double)g->shard_overflow;
+    }
+    if (prm->nnz_total >= 0) tot[0] = (double)prm->nnz_total;              // the caller knows the job's total (a graph that was not built here)
+    info->nnz_total = (int64_t)std::llround(tot[0]);
+    info->knn_ties_total = (int64_t)std::llround(tot[1]);
+    info->own_nnz = g->nnz;
+    info->n_halo = g->n_total - g->n;
+    // remedies are the caller's: a far walk anywhere (every rank rebuilds by the list exchange), a bound too small on some rank
+    // (that rank rebuilds stepwise; the others wait for nobody - but lambda needs every rank's exact edge count, which an
+    // overflowing rank cannot give), ties when the reference's order is asked for
+    if (tot[2] != 0.0) info->status = FDX_SHARD_FAR;
+    else if (tot[3] != 0.0) info->status = FDX_SHARD_OVERFLOW;
+    else if (tot[1] != 0.0 && prm->stop_on_ties) info->status = FDX_SHARD_TIES;
+    if (info->status != 0) return 0;                                        // the drain waits for the sketch; nothing was solved
+    FDX_REQUIRE(g->send_off.size() == (size_t)W + 1, "fdx_shard_fit_dev: the graph was built for a different number of ranks");
+
+    // ---- lambda, scaled rho (host scalars of the sweeps): XtX has long arrived
+    FDX_HIP(hipEventSynchronize(job.evX));
+    double diag_mean = 0.0;
+    for (int k = 0; k < K; ++k) diag_mean += Gh[(size_t)k * K + k];
+    diag_mean /= (double)K;
+    double lambda = prm->lambda_spatial;
+    if (prm->lambda_auto) lambda = 0.005 * diag_mean / std::max(tot[0] / (double)prm->n_total_spots, 1.0);   // core/spatial.py:181-190
+    const double rho_eff = prm->rho_sparsity * diag_mean;                                                       // core/solver.py:359-360
+    info->lambda_used = lambda;
+    info->rho_effective = rho_eff;
+
+    // ---- the loop, queued behind the sketch
+    const long long ld = round_up(g->n_total + 1, 64);
+    FDX_TRY(dB0.alloc((size_t)KP * ld * sizeof(double)));
+    FDX_TRY(dB1.alloc((size_t)KP * ld * sizeof(double)));
+    int32_t which = 0;
+    FDX_TRY(sharded_solve_impl(c, g, dH.as<double>(), ldh, XtX_dev, KP, K, lambda, rho_eff, prm->tol, prm->max_iter, dB0.as<double>(),
+                               dB1.as<double>(), ld, &info->solve, rel_changes_out, &which, stream));
+    const double* beta = which ? dB1.as<double>() : dB0.as<double>();
+
+    // ---- export beside the objective pass (both only read the final abundances), YtY and the objective's sums in one all-reduce
+    FDX_TRY(objp.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
+    FDX_TRY(dFin.alloc(8 * sizeof(double)));
+    if (beta_out_dev || prop_out_dev) {
+        FDX_HIP(hipEventRecord(c->ev_packed, st));
+        FDX_HIP(hipStreamWaitEvent(c->side, c->ev_packed, 0));
+        FDX_TRY(launch_normalize_export(beta, ld, nullptr, (int)n_own, g->n_slices, K, beta_out_dev, prop_out_dev, c->side));
+        FDX_HIP(hipEventRecord(c->ev_halo, c->side));
+    }
+    FDX_TRY(solver_objective_partials(*g, beta, ld, dH.as<double>(), ldh, XtX_dev, KP, objp.as<double>(), dFin.as<double>(), st));
+    FDX_HIP(hipMemcpyAsync(dFin.as<double>() + 4, job.dSum.p, sizeof(double), hipMemcpyDeviceToDevice, st));
+    FDX_TRY(allreduce(c, dFin.p, 5, false, st));
+    FDX_HIP(hipMemcpyAsync(cnt_h, dFin.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (beta_out_dev || prop_out_dev) FDX_HIP(hipStreamWaitEvent(st, c->ev_halo, 0));
+    FDX_HIP(hipStreamSynchronize(st));
+    info->YtY = cnt_h[4];
+    info->solve.final_objective = 0.5 * (cnt_h[4] - 2.0 * cnt_h[0] + cnt_h[1]) + 0.5 * lambda * cnt_h[2] + rho_eff * cnt_h[3];   // core/solver.py:272-284
+    return 0;
+}
+
+static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_dev, int64_t ldh, const double* XtX_dev, int32_t K,
+                              int32_t K_real, double lambda, double rho_eff, double tol, int32_t max_iter, double* beta0_dev,
+                              double* beta1_dev, int64_t ld, fdx_solve_info* info, double* rel_changes_out, int32_t* result_buffer,
+                              void* stream) {
     FDX_REQUIRE(c && g && H_dev && XtX_dev && beta0_dev && beta1_dev && info && result_buffer, "fdx_sharded_solve_dev: null argument");
     FDX_TRY(fdx::graph_meta_sync(g));
     // 1..64 types and the padded sizes 72 / 80 / 88 / 96 run the tiled register sweeps (boundary tiles first, halo traffic beside the

@@ -73,6 +73,7 @@ struct fdx_graph {
     int shard_world = 0;
     long long shard_ell_cap = 0, shard_send_cap = 0, shard_halo_cap = 0;
     fdx::DevBuf send_off_dev, recv_off_dev;
+    fdx::DevBuf counts_dev;                                  // 4 doubles behind meta_event: own nnz, tied own rows, far, overflow (all-reduced by fdx_shard_fit_dev)
     // recorded by fdx_graph_build_dev ahead of the first kernel of the build, on begin_stream: the fit's prologue timer starts here
     hipEvent_t begin_event = nullptr;
     hipStream_t begin_stream = nullptr;

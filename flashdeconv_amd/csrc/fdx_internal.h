@@ -67,6 +67,8 @@ void* pinned_scratch(int slot, size_t bytes);   // nullptr on failure; slot 0..7
 constexpr size_t FDX_PINNED_BLOCK_BYTES = 1024;
 void* pinned_block_get();                        // a recycled pinned block of FDX_PINNED_BLOCK_BYTES (nullptr on failure) ...
 void pinned_block_put(void* p);                  // ... and back
+void* pinned_buffer_get(size_t bytes, size_t* cap_out);   // a recycled pinned buffer of at least `bytes` (capacity class in *cap_out)
+void pinned_buffer_put(void* p, size_t cap);
 
 // the library's per-device non-blocking side stream (its own priority: fit.cpp); nullptr if it cannot be made
 hipStream_t library_side_stream();

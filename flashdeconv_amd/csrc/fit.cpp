@@ -74,6 +74,15 @@ int build_csc_from_tables(const int32_t* bucket, const double* weight, int G, in
 // caller put the spatial-graph build (many short, latency-bound kernels on the caller's stream) under it: the job runs
 // on a library-owned non-blocking side stream.
 struct fdx_leverage_job {
+    // the scores and the status words travel to pinned memory right behind the kernels (queued by begin): end only waits for
+    // the event - collecting a finished job cost 70 us of two pageable copies and a stream synchronisation
+    double* pin = nullptr;          // G doubles, then 8 ints
+    size_t pin_cap = 0;
+    hipEvent_t done = nullptr;
+    ~fdx_leverage_job() {
+        if (done) (void)hipEventDestroy(done);
+        if (pin) fdx::pinned_buffer_put(pin, pin_cap);
+    }
     DevBuf dX, dW, dS, dL, dDbg, dScratch;
     std::vector<double> hX;   // the caller may drop X once begin returns
     int K = 0, G = 0, route = LEV_ROUTE_SVD;
@@ -128,6 +137,12 @@ extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double 
         job->route = leverage_qr_applies(K, G) ? LEV_ROUTE_QR : LEV_ROUTE_SVD;
         FDX_TRY(launch_leverage(job->dX.as<double>(), K, G, regularization, job->dW.as<double>(), job->dS.as<double>(),
                                 job->dL.as<double>(), job->dDbg.as<int>(), job->dScratch.as<double>(), job->st, job->route));
+        job->pin = (double*)pinned_buffer_get((size_t)G * sizeof(double) + 64, &job->pin_cap);
+        FDX_REQUIRE(job->pin != nullptr, "fdx_leverage_begin: pinned host buffer");
+        FDX_HIP(hipMemcpyAsync(job->pin, job->dL.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, job->st));
+        FDX_HIP(hipMemcpyAsync(job->pin + G, job->dDbg.p, 8 * sizeof(int), hipMemcpyDeviceToHost, job->st));
+        FDX_HIP(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
+        FDX_HIP(hipEventRecord(job->done, job->st));
         return 0;
     };
     const int rc = run();
@@ -150,8 +165,19 @@ extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) {
         FDX_HIP(hipMemcpyAsync(dbg, job->dDbg.p, sizeof(dbg), hipMemcpyDeviceToHost, job->st));
         return 0;
     };
-    rc = run();
-    hipError_t e = hipStreamSynchronize(job->st);   // always drain before the buffers go back to the pool
+    hipError_t e = hipSuccess;
+    if (lev_out == nullptr) rc = fail(FDX_ERR_INVALID, "fdx_leverage_end: null output");
+    if (job->done && job->pin) {
+        // the job's kernels and its copies are the last work of the job on its stream: behind the event nothing of it is in flight
+        e = hipEventSynchronize(job->done);
+        if (!rc && e == hipSuccess) {
+            std::memcpy(lev_out, job->pin, (size_t)job->G * sizeof(double));
+            std::memcpy(dbg, job->pin + job->G, sizeof(dbg));
+        }
+    } else {
+        if (!rc) rc = run();
+        e = hipStreamSynchronize(job->st);          // always drain before the buffers go back to the pool
+    }
     if (!rc && e == hipSuccess && job->route == LEV_ROUTE_QR && dbg[7] != 1) {
         // the Cholesky-QR route refused the matrix (rank-deficient or cond above ~3e4): the Jacobi SVD passes, as before
         PoolStream pool_stream(job->st);

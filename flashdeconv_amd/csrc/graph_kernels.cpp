@@ -1632,6 +1632,11 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
 
 void graph_plan_destroy(fdx_graph_plan* plan) { delete plan; }
 int graph_plan_kk(const fdx_graph_plan* plan) { return plan->kk; }
+int graph_plan_order(const fdx_graph_plan* plan, int* d_perm_out, int* d_rank_out, hipStream_t st) {
+    if (d_perm_out) FDX_HIP(hipMemcpyAsync(d_perm_out, plan->b.perm.p, (size_t)plan->n * 4, hipMemcpyDeviceToDevice, st));
+    if (d_rank_out) FDX_HIP(hipMemcpyAsync(d_rank_out, plan->b.rank.p, (size_t)plan->n * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
 
 static int graph_from_knn_lists_impl(fdx_graph_plan* plan, const int* nbr, const int* cnt, long long lo, long long hi, fdx_graph* g,
                                      hipStream_t st, bool defer) {
@@ -2244,7 +2249,9 @@ __global__ __launch_bounds__(256) void shard_meta_kernel(const long long* __rest
                                                          const int* __restrict__ band_ctr, const int* __restrict__ hscan, long long n_all,
                                                          const int* __restrict__ off_rb, int nblk, const ShardBounds bounds_v, int n_ranks,
                                                          const int* __restrict__ tile_counts, int* __restrict__ send_off_dev,
-                                                         int* __restrict__ recv_off_dev, long long* __restrict__ meta) {
+                                                         int* __restrict__ recv_off_dev, long long* __restrict__ meta,
+                                                         double* __restrict__ counts_dev, long long ell_cap, long long halo_cap,
+                                                         long long send_cap) {
     __shared__ long long s_sum[256];
     __shared__ int s_max[256];
     __shared__ long long s_b[SHARD_MAX_RANKS + 1];
@@ -2279,6 +2286,13 @@ __global__ __launch_bounds__(256) void shard_meta_kernel(const long long* __rest
     meta[7] = (long long)off_rb[(size_t)n_ranks * nblk];
     meta[8] = (long long)tile_counts[0];
     meta[9] = (long long)tile_counts[1];
+    // the same counts where an all-reduce over the ranks can take them without the host: edges of the own rows, tied own rows,
+    // "a walk left its block / the band list overflowed", "a bound of this pipeline was too small"
+    counts_dev[0] = (double)s_sum[0];
+    counts_dev[1] = (double)ties[0];
+    counts_dev[2] = (ties[1] != 0 || band_ctr[3] != 0) ? 1.0 : 0.0;
+    counts_dev[3] = ((long long)slice_off[n_slices] > ell_cap || (long long)hscan[n_all] > halo_cap ||
+                     (long long)off_rb[(size_t)n_ranks * nblk] > send_cap) ? 1.0 : 0.0;
 }
 
 }  // namespace fdx
@@ -2423,6 +2437,7 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     // ---- the numbers the host will ask for
     FDX_TRY(loc->send_off_dev.alloc((size_t)(n_ranks + 1) * 4));
     FDX_TRY(loc->recv_off_dev.alloc((size_t)(n_ranks + 1) * 4));
+    FDX_TRY(loc->counts_dev.alloc(4 * sizeof(double)));
     if (!loc->meta_host) loc->meta_host = (long long*)pinned_block_get();
     FDX_REQUIRE(loc->meta_host != nullptr, "graph: pinned host block");
     if (!loc->meta_event) FDX_HIP(hipEventCreateWithFlags(&loc->meta_event, hipEventDisableTiming));
@@ -2431,7 +2446,8 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     FDX_HIP(hipHostGetDevicePointer(&meta_dev, loc->meta_host, 0));
     hipLaunchKernelGGL(shard_meta_kernel, dim3(1), dim3(256), 0, st, part, wblocks, loc->slice_off.as<int>(), loc->n_slices, summary,
                        plan->ties.as<int>(), plan->band_counters.as<int>(), sb->hscan.as<int>(), n, sb->off_rb.as<int>(), nblk, bv, n_ranks,
-                       sb->tile_counts.as<int>(), loc->send_off_dev.as<int>(), loc->recv_off_dev.as<int>(), (long long*)meta_dev);
+                       sb->tile_counts.as<int>(), loc->send_off_dev.as<int>(), loc->recv_off_dev.as<int>(), (long long*)meta_dev,
+                       loc->counts_dev.as<double>(), loc->shard_ell_cap, loc->shard_halo_cap, loc->shard_send_cap);
     FDX_CHECK_LAUNCH();
     FDX_HIP(hipEventRecord(loc->meta_event, st));
     loc->meta_stream = st;

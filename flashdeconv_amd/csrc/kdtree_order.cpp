@@ -158,7 +158,7 @@ struct Heap {
 struct NodeInfo {
     long long node;
     double min_distance;
-    double side[3];
+    double side[8];
 };
 
 void kd_query_one(const KdTree& t, const double* x, int kmax, int64_t* out_idx, std::vector<NodeInfo>& pool, Heap& q,
@@ -168,7 +168,7 @@ void kd_query_one(const KdTree& t, const double* x, int kmax, int64_t* out_idx, 
     q.n = 0;
     neighbors.n = 0;
     double upper = HUGE_VAL;
-    pool.push_back(NodeInfo{0, 0.0, {0.0, 0.0, 0.0}});
+    pool.push_back(NodeInfo{0, 0.0, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}});
     {
         NodeInfo& r = pool[0];
         for (int i = 0; i < m; ++i) {
@@ -231,10 +231,11 @@ void kd_query_one(const KdTree& t, const double* x, int kmax, int64_t* out_idx, 
 }  // namespace
 }  // namespace fdx
 
-// include/fdx.h
-extern "C" int fdx_ckdtree_knn(const double* coords, int64_t n, int32_t dim, int32_t kk, int64_t* idx_out, int64_t* tree_indices_out) {
-    using namespace fdx;
-    FDX_REQUIRE(coords && idx_out && n >= 1 && dim >= 1 && dim <= 3 && kk >= 1, "fdx_ckdtree_knn: bad arguments");
+namespace fdx {
+namespace {
+// tree of all n points, then the queries of `rows` (NULL: every point, in order) - idx_out row j holds the answer for rows[j]
+int ckdtree_knn_impl(const double* coords, int64_t n, int32_t dim, int32_t kk, const int64_t* rows, int64_t n_rows, int64_t* idx_out,
+                     int64_t* tree_indices_out) {
     KdTree t;
     t.data = coords;
     t.n = n;
@@ -258,26 +259,78 @@ extern "C" int fdx_ckdtree_knn(const double* coords, int64_t n, int32_t dim, int
     // few thousand points and more per host thread.  1000 x 1000 lattice points on 8 cores: 2.2 -> 0.8-1.0 s, of which 0.29 s the
     // serial build (its top levels are full passes over the points - bounds, introselect, partition; building the subtrees below
     // the second level on four threads was tried and returned nothing measurable).
+    const long long nq = rows ? n_rows : n;
     auto run = [&](long long i0, long long i1) {
         std::vector<NodeInfo> pool;
         Heap q, nb;
         q.h.resize(12);
         nb.h.resize((size_t)kk);
-        for (long long i = i0; i < i1; ++i) kd_query_one(t, coords + i * dim, kk, idx_out + i * kk, pool, q, nb);
+        for (long long i = i0; i < i1; ++i) {
+            const long long p = rows ? rows[i] : i;
+            kd_query_one(t, coords + p * dim, kk, idx_out + i * kk, pool, q, nb);
+        }
     };
     unsigned nt = std::thread::hardware_concurrency();
     if (const char* e = getenv("FDX_KDTREE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
-    nt = (unsigned)std::min<long long>(std::max(1u, std::min(nt, 32u)), std::max<long long>(1, n / 4096));
-    if (nt <= 1) {
-        run(0, n);
-        return 0;
-    }
+    nt = (unsigned)std::min<long long>(std::max(1u, std::min(nt, 32u)), std::max<long long>(1, nq / 4096));
+    // a thread that cannot be started (process limits, W ranks x 32 threads) or a failed allocation inside a worker must not end
+    // the process: what was started is joined, the rest of the range runs here
     std::vector<std::thread> th;
-    const long long per = (n + nt - 1) / nt;
-    for (unsigned k = 0; k < nt; ++k) {
-        const long long i0 = (long long)k * per, i1 = std::min<long long>(n, i0 + per);
-        if (i0 < i1) th.emplace_back(run, i0, i1);
+    std::vector<int> failed(nt, 0);
+    const long long per = (nq + nt - 1) / std::max(1u, nt);
+    long long next = 0;
+    if (nt > 1) {
+        for (unsigned k = 0; k < nt; ++k) {
+            const long long i0 = (long long)k * per, i1 = std::min<long long>(nq, i0 + per);
+            if (i0 >= i1) break;
+            try {
+                th.emplace_back([&, i0, i1, k] {
+                    try { run(i0, i1); } catch (...) { failed[k] = 1; }
+                });
+            } catch (...) {
+                break;                                   // this and the following ranges: serially below
+            }
+            next = i1;
+        }
+    }
+    int rc = 0;
+    try {
+        if (next < nq) run(next, nq);
+    } catch (...) {
+        rc = fail(FDX_ERR_INVALID, "fdx_ckdtree_knn: out of memory in the query loop");
     }
     for (auto& x : th) x.join();
-    return 0;
+    for (unsigned k = 0; k < nt; ++k) {
+        if (!failed[k]) continue;
+        const long long i0 = (long long)k * per, i1 = std::min<long long>(nq, i0 + per);
+        try { run(i0, i1); } catch (...) { rc = fail(FDX_ERR_INVALID, "fdx_ckdtree_knn: out of memory in the query loop"); }
+    }
+    return rc;
+}
+}  // namespace
+}  // namespace fdx
+
+// include/fdx.h
+extern "C" int fdx_ckdtree_knn(const double* coords, int64_t n, int32_t dim, int32_t kk, int64_t* idx_out, int64_t* tree_indices_out) {
+    using namespace fdx;
+    FDX_REQUIRE(coords && idx_out && n >= 1 && dim >= 1 && dim <= 8 && kk >= 1, "fdx_ckdtree_knn: bad arguments (1 to 8 coordinates)");
+    try {
+        return ckdtree_knn_impl(coords, n, dim, kk, nullptr, 0, idx_out, tree_indices_out);
+    } catch (...) {
+        return fail(FDX_ERR_INVALID, "fdx_ckdtree_knn: out of memory");
+    }
+}
+
+extern "C" int fdx_ckdtree_knn_rows(const double* coords, int64_t n, int32_t dim, int32_t kk, const int64_t* rows, int64_t n_rows,
+                                    int64_t* idx_out) {
+    using namespace fdx;
+    FDX_REQUIRE(coords && n >= 1 && dim >= 1 && dim <= 8 && kk >= 1 && n_rows >= 0 && (n_rows == 0 || (rows && idx_out)),
+                "fdx_ckdtree_knn_rows: bad arguments (1 to 8 coordinates)");
+    for (int64_t j = 0; j < n_rows; ++j) FDX_REQUIRE(rows[j] >= 0 && rows[j] < n, "fdx_ckdtree_knn_rows: row index out of range");
+    if (n_rows == 0) return 0;
+    try {
+        return ckdtree_knn_impl(coords, n, dim, kk, rows, n_rows, idx_out, nullptr);
+    } catch (...) {
+        return fail(FDX_ERR_INVALID, "fdx_ckdtree_knn_rows: out of memory");
+    }
 }

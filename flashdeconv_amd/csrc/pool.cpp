@@ -127,6 +127,28 @@ void pinned_block_put(void* p) {
     g_pin_free.push_back(p);
 }
 
+// Recycled pinned buffers of any size (capacity classes: powers of two from 4 KB) for objects that outlive a call and read back
+// more than a block - a leverage job's scores.  Never returned to the driver.
+static std::map<size_t, std::vector<void*>> g_pinbuf_free;
+void* pinned_buffer_get(size_t bytes, size_t* cap_out) {
+    size_t cap = 4096;
+    while (cap < bytes) cap <<= 1;
+    if (cap_out) *cap_out = cap;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto& v = g_pinbuf_free[cap];
+        if (!v.empty()) { void* p = v.back(); v.pop_back(); return p; }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void pinned_buffer_put(void* p, size_t cap) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinbuf_free[cap].push_back(p);
+}
+
 void* pinned_scratch(int slot, size_t bytes) {
     static const bool pageable = getenv("FDX_PAGEABLE_READBACK") != nullptr;   // diagnostic: what the copies cost without pinning
     struct Slot {

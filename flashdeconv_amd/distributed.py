@@ -129,6 +129,40 @@ class TorchComm:
                 req.wait()
 
 
+class LoopbackComm:
+    """MEASUREMENT ONLY: rank `rank` of a `world`-rank job ALONE on its GPU.  The collectives of the sharded driver return at
+    once with what the real job would have produced - sums come from `totals` (tensor shape -> the all-reduced values, recorded
+    from a run of the real job) when given, else the rank's own values - and the native iteration loop runs over the loopback
+    transport (fdx_comm_init_loopback: the exchange is a device copy of the rank's own staging).  `bench.py --virtual-ranks` times
+    every rank's whole share of the sharded fit through ShardedFlashDeconv with this comm: the driver's real code path - Python,
+    launches, read-backs - without peers and without wire time.  Results are NOT those of the job (the halo values are the
+    rank's own)."""
+
+    loopback = True
+
+    def __init__(self, rank, world, totals=None):
+        self.rank, self.world = int(rank), int(world)
+        self.totals = totals or {}
+        self.group = None
+
+    def all_reduce_max(self, t):
+        pass
+
+    def all_reduce_sum(self, t):
+        tot = self.totals.get(tuple(t.shape))
+        if tot is not None:
+            t.copy_(tot.to(t.device))
+
+    def all_gather_rows(self, nbr, cnt, bounds):
+        raise RuntimeError("LoopbackComm has no peers to gather from")
+
+    def exchange(self, send_bufs, recv_bufs):
+        for peer, t in recv_bufs.items():
+            src = send_bufs.get(peer)
+            if src is not None and src.shape == t.shape:
+                t.copy_(src)
+
+
 class HaloExchange:
     """Moves boundary rows of a type-major (K, ld) abundance buffer into the halo columns of the peers."""
 
@@ -282,6 +316,7 @@ class ShardedFlashDeconv:
         self.timings_ = {}
         self.knn_ties_ = 0
         self._profile = bool(os.environ.get("FDX_DIST_TIMING"))
+        self._trace = [] if os.environ.get("FDX_TRACE_DRIVER") else None
 
     def native_comm(self):
         """libfdx's own RCCL communicator for the native iteration loop (fdx_sharded_solve_dev): rank 0 draws the
@@ -290,10 +325,15 @@ class ShardedFlashDeconv:
         import torch
         if self._native is not None or os.environ.get("FDX_PY_LOOP"):
             return self._native
+        lib = _lib.load()
+        if getattr(self.comm, "loopback", False):              # measurement: one rank alone (LoopbackComm)
+            h = ctypes.c_void_p()
+            _lib.check(lib.fdx_comm_init_loopback(self.comm.rank, self.comm.world, ctypes.byref(h)))
+            self._native = h
+            return self._native
         dist = getattr(self.comm, "dist", None)
         if dist is None or dist.get_backend(self.comm.group) != "nccl":
             return None
-        lib = _lib.load()
         ident = np.zeros(128, dtype=np.uint8)
         if self.comm.rank == 0:
             _lib.check(lib.fdx_comm_unique_id(ident.ctypes.data))
@@ -314,6 +354,23 @@ class ShardedFlashDeconv:
                 g.close()
         self._local = self._full = None
 
+    def _mark(self, name):
+        """FDX_TRACE_DRIVER=1: host clock at the steps of plan / fit_transform (no synchronisation), printed after the fit."""
+        if self._trace is not None:
+            self._trace.append((name, time.perf_counter()))
+
+    def _mark_dump(self):
+        if self._trace:
+            import sys
+            t0 = self._trace[0][1]
+            prev = t0
+            out = []
+            for name, t in self._trace:
+                out.append(f"{name} +{1e6 * (t - prev):.0f}")
+                prev = t
+            print(f"[fdx-driver rank {self.comm.rank}] total {1e6 * (prev - t0):.0f} us: " + ", ".join(out), file=sys.stderr)
+            self._trace = []
+
     def _tick(self, name, t0):
         """Stage timing for tools/dist_probe.py (FDX_DIST_TIMING=1: synchronises, so only for diagnosis)."""
         if not self._profile:
@@ -333,10 +390,12 @@ class ShardedFlashDeconv:
         lib = _lib.load()
         self._lev_job = None
         self.knn_ties_ = 0
+        self._mark("plan:entry")
         if X is not None:
             Xj = np.ascontiguousarray(X, dtype=np.float64)
             if Xj.shape[1] <= self.n_hvg:
                 self._lev_job = (Xj, LeverageJob(Xj))
+        self._mark("plan:leverage job")
         assert coords.is_cuda and coords.dtype == torch.float64
         coords = coords.contiguous()
         n, dim = coords.shape
@@ -370,12 +429,14 @@ class ShardedFlashDeconv:
                 self._local = _lib.Graph(hl.value)
             else:
                 self._plan_stepwise_local(coords, lo, hi)          # a rank without rows: nothing to queue, no collective inside
+            self._mark("plan:shard_knn queued")
             self._pending_plan = "shard"
             perm = torch.empty(max(self.n_own, 1), dtype=torch.int32, device=coords.device)
             _lib.check(lib.fdx_graph_perm_dev(self._local.handle, ctypes.c_void_p(perm.data_ptr()), st))
             self.own_ids = perm[:self.n_own].long()
             t0 = self._tick("plan_build", t0)
-            if self.knn_ties != "index" or self._profile:
+            self._mark("plan:perm")
+            if self._profile:
                 self._finish_plan()
             return self.own_ids
         if sharded_knn:
@@ -482,10 +543,60 @@ class ShardedFlashDeconv:
             self._local.close()
         self._local = _lib.Graph(hl.value)
 
-    def _finish_plan(self):
+    def _ties_remedy_lists(self, coords, st):
+        """The reference's neighbour lists (cKDTree's choice among equidistant candidates) for this rank's own rows and band, in
+        place of the device's index-rule lists; then the stepwise symmetrise + localize.  Needs the band to hold every row that
+        can point at an own row - the same condition as the band recompute itself (no far walk: checked before this is called)."""
+        import torch
+        from .utils.graph import ckdtree_knn_lists_rows
+        lib = _lib.load()
+        n, dim = coords.shape
+        k = int(self.k_neighbors)
+        kk = min(k, n - 1) + 1
+        lo, hi = int(self.bounds[self.comm.rank]), int(self.bounds[self.comm.rank + 1])
+        dev = coords.device
+        nbr = torch.empty((n, kk), dtype=torch.int32, device=dev)
+        cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+        plan, h, hl = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_knn_lists_band_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, lo, hi,
+                                                    ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), st, ctypes.byref(plan)))
+        perm_t = torch.empty(n, dtype=torch.int32, device=dev)
+        rank_t = torch.empty(n, dtype=torch.int32, device=dev)
+        _lib.check(lib.fdx_graph_plan_order_dev(plan, ctypes.c_void_p(perm_t.data_ptr()), ctypes.c_void_p(rank_t.data_ptr()), st))
+        rows_pos = torch.nonzero(cnt > 0).flatten()                       # own rows + band: the rows that have lists
+        if rows_pos.numel():
+            ids = perm_t[rows_pos].long().cpu().numpy()
+            lists = ckdtree_knn_lists_rows(coords.detach().cpu().numpy(), k, ids)          # caller ids, self included, -1 padded
+            keep = (lists >= 0) & (lists != ids[:, None])                                     # utils/graph.py:70-74: drop row == col
+            # left-compact the kept entries of every row (their order inside a list does not matter: the symmetrisation sorts)
+            order = np.argsort(~keep, axis=1, kind="stable")
+            lists_c = np.take_along_axis(lists, order, axis=1)
+            n_keep = keep.sum(axis=1)
+            lists_c[np.arange(kk)[None, :] >= n_keep[:, None]] = -1
+            lt = torch.from_numpy(lists_c).to(dev)
+            pos = torch.where(lt >= 0, rank_t[lt.clamp(min=0)].long(), torch.full_like(lt, -1))
+            nbr[rows_pos] = pos.to(torch.int32)
+            cnt[rows_pos] = torch.from_numpy(n_keep.astype(np.int32)).to(dev)
+        _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi,
+                                                    st, ctypes.byref(h)))
+        full = _lib.Graph(h.value)
+        own = torch.tensor([float(full.info()[1])], dtype=torch.float64, device=dev)
+        self.comm.all_reduce_sum(own)                                        # edges of the reference's graph (auto lambda)
+        self.nnz_total = int(round(float(own.item())))
+        _lib.check(lib.fdx_graph_localize(full.handle, self.comm.world, _lib.ptr_i64(self.bounds), self.comm.rank, st, ctypes.byref(hl)))
+        full.close()
+        if self._local is not None:
+            self._local.close()
+        self._local = _lib.Graph(hl.value)
+        perm = torch.empty(max(self.n_own, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.fdx_graph_perm_dev(self._local.handle, ctypes.c_void_p(perm.data_ptr()), st))
+        self.own_ids = perm[:self.n_own].long()                              # the same Morton range as before
+
+    def _finish_plan(self, totals=None):
         """Second half of a queued plan (fdx_graph_shard_knn_dev): wait for the counts, all-reduce (edges, tied rows, far flag),
         apply the remedies (a bound too small: this rank rebuilds stepwise; a far walk anywhere: every rank rebuilds by the list
-        exchange; ties under "auto" / "ckdtree": the reference's graph), halo bookkeeping."""
+        exchange; ties under "auto" / "ckdtree": the reference's neighbour choice), halo bookkeeping.  totals: (edges, tied rows,
+        far) already all-reduced by fdx_shard_fit_dev."""
         if getattr(self, "_pending_plan", None) is None:
             return
         import torch
@@ -501,15 +612,20 @@ class ShardedFlashDeconv:
             _lib.check(lib.fdx_graph_shard_status(self._local.handle, ctypes.byref(nnz), ctypes.byref(ties), ctypes.byref(far),
                                                   ctypes.byref(over)))
             counts = (float(nnz.value), float(ties.value), float(far.value))
-            if over.value and not far.value:
+            if over.value and not far.value and not (totals is not None and totals[2]):
                 self._plan_stepwise_local(coords, lo, hi)          # same rows, same order, exact sizes
                 counts = self._step_counts
         else:
             counts = self._step_counts
-        own = torch.tensor(counts, dtype=torch.float64, device=coords.device)
-        self.comm.all_reduce_sum(own)
-        tot = own.cpu().numpy()
+        self._mark("finish_plan:status")
+        if totals is None:
+            own = torch.tensor(counts, dtype=torch.float64, device=coords.device)
+            self.comm.all_reduce_sum(own)
+            tot = own.cpu().numpy()
+        else:
+            tot = np.asarray(totals, dtype=np.float64)
         t0 = self._tick("plan_counts", t0)
+        self._mark("finish_plan:allreduce+cpu")
         if tot[2] != 0:
             # some rank's walk left its block (very uneven density) or a band list overflowed: every rank rebuilds by the exchange
             self._local.close()
@@ -536,10 +652,20 @@ class ShardedFlashDeconv:
         lib = _lib.load()
         n = coords.shape[0]
         self.knn_ties_resolved_ = False
-        if getattr(self, "knn_ties_", 0) and self.spatial_method == "knn" and self.knn_ties != "index":
-            # The device builds chose among equidistant neighbours by spot index; the reference's graph comes from cKDTree's
-            # traversal order.  Every rank has the coordinates: each builds that graph (host, ~1 s per million spots) and takes
-            # its rows.  The graph is in the CALLER's order (no Morton sort), so a shard is a range of the caller's spot numbers.
+        if (getattr(self, "knn_ties_", 0) and self.spatial_method == "knn" and self.knn_ties != "index" and self.comm.world > 1
+                and coords.shape[1] <= 3 and not os.environ.get("FDX_TIES_FULL_GRAPH")):
+            # The device builds chose among equidistant neighbours by spot index; the reference takes whichever cKDTree's query
+            # meets first.  The shards stay what they are (Morton ranges: own_ids do not change): every rank asks the restated
+            # tree (csrc/kdtree_order.cpp: the tree of all points - O(n log n) on the host - but only the queries of its own rows
+            # and of its band) for the reference's lists, puts them in the place of the device's, and symmetrises / localises as
+            # before - the reference's rows index for index.
+            self._ties_remedy_lists(coords, st)
+            self.plan_route_ = "ckdtree-lists"
+            self.knn_ties_resolved_ = True
+            localized = True
+        elif getattr(self, "knn_ties_", 0) and self.spatial_method == "knn" and self.knn_ties != "index":
+            # (one rank, or more than 3 coordinates) every rank builds the reference's whole graph on the host and takes its rows;
+            # the graph is in the CALLER's order (no Morton sort), so a shard is a range of the caller's spot numbers.
             from .utils.graph import ckdtree_knn_adjacency
             A = ckdtree_knn_adjacency(coords.detach().cpu().numpy().astype(np.float64), int(self.k_neighbors))
             if self._full is not None:
@@ -577,6 +703,7 @@ class ShardedFlashDeconv:
         sidx = torch.empty(max(int(sc.sum()), 1), dtype=torch.int32, device=coords.device)
         _lib.check(lib.fdx_graph_send_indices_dev(self._local.handle, ctypes.c_void_p(sidx.data_ptr()), st))
         self._halo = HaloExchange(self.comm, self.n_own, sidx[:int(sc.sum())].long(), sc, rc)
+        self._mark("plan:halo lists")
         self._tick("plan_lists", t0)
 
     def fit_transform(self, Y_own, X):
@@ -595,6 +722,7 @@ class ShardedFlashDeconv:
         K, G = X.shape
         if _lib.is_torch_sparse_csr(Y_own):
             return self._fit_transform_csr(Y_own, X)
+        self._mark("fit:entry")
         # integer counts keep the float64 transform chain, as in FlashDeconv.fit (numpy promotes them: core/deconv.py:190-191)
         from .core.deconv import device_counts_as_float
         Y_own, y_f64_math = device_counts_as_float(Y_own)
@@ -631,6 +759,7 @@ class ShardedFlashDeconv:
         else:
             lev = compute_leverage_scores(X)
         t0 = self._tick("leverage", t0)
+        self._mark("fit:leverage")
         bucket, weight = countsketch_tables(G, self.sketch_dim, lev, self.random_state)
         weight_y = weight_x = weight
         mode_y = mode_x = _lib.PRE_RAW
@@ -652,20 +781,90 @@ class ShardedFlashDeconv:
         elif self.preprocess != "raw":
             raise ValueError(f"Unknown preprocess method: {self.preprocess}. Choose from 'log_cpm', 'pearson', or 'raw'.")
         t0 = self._tick("tables", t0)
+        self._mark("fit:tables")
         n_own = self.n_own
+        b32 = np.ascontiguousarray(bucket, dtype=np.int32)
+        wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
+        for attempt in range(2):
+            # the whole rest of the fit in ONE native call (csrc/comm.cpp: fdx_shard_fit_dev) when libfdx owns the communicator;
+            # a status (far walk / bound too small / ties) sends the plan through its remedy and, with the final graph, back here
+            done = self._fit_native(Y_own, y_code, X, K, G, b32, wy, wx, mode_y, mode_x)
+            if done is not False:
+                break
+        if done:
+            return self.proportions_
         ld = ((n_own + 1 + 63) // 64) * 64          # H is read for the own rows only: its stride does not wait for the halo count
         H = torch.zeros((K, ld), dtype=torch.float64, device=dev)
         XtX = torch.empty((K, K), dtype=torch.float64, device=dev)
         XtX_h = np.empty((K, K))
         yty = ctypes.c_double(0.0)
-        b32 = np.ascontiguousarray(bucket, dtype=np.int32)
-        wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
         _lib.check(lib.fdx_prepare_dev(ctypes.c_void_p(Y_own.data_ptr()), _lib.FDX_F32 if Y_own.dtype == torch.float32 else _lib.FDX_F64,
                                        n_own, G, G, None, _lib.ptr_f64(X), K, _lib.ptr_i32(b32), _lib.ptr_f64(wy), _lib.ptr_f64(wx),
                                        int(self.sketch_dim), mode_y, mode_x, ctypes.c_void_p(H.data_ptr()), ld,
                                        ctypes.c_void_p(XtX.data_ptr()), _lib.ptr_f64(XtX_h), ctypes.byref(yty), st))
         t0 = self._tick("prepare", t0)
+        self._mark("fit:prepare")
         return self._solve_shard(H, XtX, XtX_h, yty.value, K, ld)
+
+    def _fit_native(self, Y_own, y_code, X, K, G, b32, wy, wx, mode_y, mode_x):
+        """fdx_shard_fit_dev: sketch -> H, the plan's counts all-reduced beside it, lambda, the loop, objective, export - one
+        call.  True: done (results set); False: a remedy was applied to the plan, call again; None: not applicable here (the
+        process group is not libfdx's own communicator, more than 96 cell types, a rank without rows, sweeps being timed)."""
+        import torch
+        if (os.environ.get("FDX_NO_SHARD_FIT") or getattr(self, "time_sweeps", False) or self.n_own <= 0 or K > 96
+                or self._local is None):
+            return None
+        native = self.native_comm()
+        if native is None:
+            return None
+        lib = _lib.load()
+        dev = Y_own.device
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        pending = getattr(self, "_pending_plan", None) is not None
+        prm = _lib.ShardFitParams()
+        prm.sketch_dim, prm.mode_y, prm.mode_x = int(self.sketch_dim), int(mode_y), int(mode_x)
+        prm.lambda_auto = 1 if self.lambda_spatial == "auto" else 0
+        prm.lambda_spatial = 0.0 if prm.lambda_auto else float(self.lambda_spatial)
+        prm.rho_sparsity, prm.tol, prm.max_iter = float(self.rho_sparsity), float(self.tol), int(self.max_iter)
+        prm.stop_on_ties = 1 if (pending and self.spatial_method == "knn" and self.knn_ties != "index") else 0
+        prm.n_total_spots = int(self.n_total_spots)
+        prm.nnz_total = -1 if pending else int(self.nnz_total)
+        if getattr(self.comm, "loopback", False) and pending:               # measurement: the job's total, known to the stand-in
+            tot = getattr(self.comm, "totals", {}).get((3,))
+            if tot is not None:
+                prm.nnz_total = int(round(float(tot[0])))
+        info = _lib.ShardFitInfo()
+        rel = np.zeros(max(int(self.max_iter), 1))
+        beta_t = torch.empty((self.n_own, K), dtype=torch.float64, device=dev)
+        prop_t = torch.empty((self.n_own, K), dtype=torch.float64, device=dev)
+        _lib.check(lib.fdx_shard_fit_dev(native, self._local.handle, ctypes.c_void_p(Y_own.data_ptr()), y_code, self.n_own, G, G,
+                                         _lib.ptr_f64(X), K, _lib.ptr_i32(b32), _lib.ptr_f64(wy), _lib.ptr_f64(wx), ctypes.byref(prm),
+                                         ctypes.c_void_p(beta_t.data_ptr()), ctypes.c_void_p(prop_t.data_ptr()), _lib.ptr_f64(rel),
+                                         ctypes.byref(info), st))
+        self._mark("fit:native call")
+        if info.status != 0:
+            self._finish_plan(totals=(float(info.nnz_total), float(info.knn_ties_total), 1.0 if info.status == _lib.SHARD_FAR else 0.0))
+            return False
+        if pending:
+            self._pending_plan = None
+            self.nnz_total, self.knn_ties_ = int(info.nnz_total), int(info.knn_ties_total)
+            self.knn_ties_resolved_ = False
+            self.n_halo, self.own_nnz_ = int(info.n_halo), int(info.own_nnz)
+            if self.knn_ties_ and self.comm.rank == 0:
+                import warnings
+                warnings.warn(f"k-NN ties: {self.knn_ties_} of {self.n_total_spots} spots have their k-th and (k+1)-th nearest "
+                              "neighbours at exactly the same distance (regular lattice?): the neighbour graph depends on how ties "
+                              "are broken - here by spot index, in the reference by cKDTree's traversal order.  "
+                              "spatial_method='grid' builds a tie-free graph on lattices.", UserWarning, stacklevel=3)
+        self.beta_, self.proportions_ = beta_t, prop_t
+        self.lambda_used_ = float(info.lambda_used)
+        n_it = int(info.solve.n_iterations)
+        self.info_ = {"converged": bool(info.solve.converged), "n_iterations": n_it, "final_change": float(info.solve.final_change),
+                      "rel_changes": [float(v) for v in rel[:n_it]], "final_objective": float(info.solve.final_objective),
+                      "objectives": []}
+        self.sweep_loop_ms_ = float(info.solve.sweep_ms)
+        self._mark_dump()
+        return True
 
     def _fit_transform_csr(self, Y_own, X):
         """CSR shard (the own rows as a CUDA torch.sparse_csr tensor; reference core/deconv.py:181-188, utils/genes.py:52-83):
@@ -750,6 +949,7 @@ class ShardedFlashDeconv:
             lam = float(self.lambda_spatial)
         rho_eff = float(self.rho_sparsity) * dmean                            # core/solver.py:359-360
         t0 = self._tick("scalars", t0)
+        self._mark("solve:finish_plan+scalars")
         K_real = K
         if K > 64:
             # 65-96 cell types: the next instantiated sweep size with all-zero pad types (include/fdx.h: fdx_solver_padded_k)
@@ -787,6 +987,7 @@ class ShardedFlashDeconv:
                 real = solver.sweep_events[:info["n_iterations"]]              # later launches are post-convergence no-ops
                 self.sweep_ms_ = [a.elapsed_time(b) for a, b in real]
         t0 = self._tick("solve", t0)
+        self._mark("solve:loop")
         # the export (reads the final abundances, writes two (n_own, K) matrices) runs on a side stream BESIDE the objective pass
         # (reads the same abundances), as in the single-GPU fit; the objective's read-back then waits for both
         self.beta_ = torch.empty((n_own, K_real), dtype=torch.float64, device=dev)
@@ -811,6 +1012,8 @@ class ShardedFlashDeconv:
         info["objectives"] = []
         self._tick("finish", t0)
         self.lambda_used_, self.info_ = lam, info
+        self._mark("solve:finish")
+        self._mark_dump()
         return self.proportions_
 
 

@@ -90,6 +90,19 @@ def ckdtree_knn_lists(coords, k):
     return idx
 
 
+def ckdtree_knn_lists_rows(coords, k, rows):
+    """Rows `rows` of ``ckdtree_knn_lists``: the tree of ALL points, the queries of the listed ones only (a spot shard asks for
+    its own rows and its band)."""
+    _ckdtree_restatement_matches_scipy()
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    n, dim = coords.shape
+    kk = min(int(k), n - 1) + 1
+    idx = np.empty((len(rows), kk), dtype=np.int64)
+    _lib.check(_lib.load().fdx_ckdtree_knn_rows(_lib.ptr_f64(coords), n, dim, kk, _lib.ptr_i64(rows), len(rows), idx.ctypes.data))
+    return idx
+
+
 def ckdtree_knn_adjacency(coords, k):
     """The reference's k-NN adjacency from those lists: self dropped, ones, A + A^T, binary (utils/graph.py:66-81)."""
     idx = ckdtree_knn_lists(coords, k)

@@ -144,10 +144,14 @@ int fdx_graph_knn_ties(const fdx_graph* g, int64_t* ties);
 /* The neighbour lists the REFERENCE gets on such inputs: a host restatement of scipy.spatial.cKDTree(coords) with the
  * constructor's defaults followed by tree.query(coords, k = kk) with p = 2 (utils/graph.py:60-63), reproducing the order in
  * which the library meets equidistant points - hence which of them it returns.  coords: HOST (n, dim) row-major f64,
- * dim 1..3; idx_out: HOST (n, kk) int64, row i = the kk nearest of point i (itself included), nearest first, -1 padded
+ * dim 1..8; idx_out: HOST (n, kk) int64, row i = the kk nearest of point i (itself included), nearest first, -1 padded
  * when n < kk; tree_indices_out: optional HOST int64[n], the tree's index array (tests compare it with scipy's).  Pure
  * host code, serial, O(n log n): for the opt-in knn_ties="ckdtree" of the Python driver when fdx_graph_knn_ties() > 0. */
 int fdx_ckdtree_knn(const double* coords, int64_t n, int32_t dim, int32_t kk, int64_t* idx_out, int64_t* tree_indices_out);
+/* The same tree, queried for the listed points only (rows: HOST int64[n_rows], idx_out: HOST (n_rows, kk), row j = the answer for
+ * point rows[j]) - a spot shard asks for its own rows and its band instead of all n.  dim 1..8 for both entries. */
+int fdx_ckdtree_knn_rows(const double* coords, int64_t n, int32_t dim, int32_t kk, const int64_t* rows, int64_t n_rows,
+                         int64_t* idx_out);
 
 /* ---- solver (replaces core/solver.py:287-428 bcd_solve and everything it calls) ---------------------- */
 typedef struct fdx_solve_info {
@@ -308,6 +312,10 @@ int fdx_graph_from_knn_lists_dev(fdx_graph_plan* plan, const int32_t* nbr_dev, c
 int fdx_graph_knn_lists_band_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t k, int64_t lo, int64_t hi,
                                  int32_t* nbr_dev, int32_t* cnt_dev, void* stream, fdx_graph_plan** plan);
 int fdx_graph_knn_far(const fdx_graph* g, int32_t* far);
+/* Spot order of a plan of fdx_graph_knn_lists[_band]_dev: perm_out_dev[p] = caller's id at solver position p, rank_out_dev[id] = its
+ * position (int32, n entries each, device; either may be NULL).  A band plan lays out only the neighbourhood of its own rows
+ * (positions / ids elsewhere are not data). */
+int fdx_graph_plan_order_dev(const fdx_graph_plan* plan, int32_t* perm_out_dev, int32_t* rank_out_dev, void* stream);
 /* perm_out_dev[p] = caller's spot id at solver position p (int32, n entries, device). */
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
 /* Shard of a full graph for rank `my_rank`: own spots are solver positions [bounds[my_rank], bounds[my_rank+1])
@@ -398,6 +406,32 @@ int fdx_comm_destroy(fdx_comm* comm);
 int fdx_comm_info(const fdx_comm* comm, int32_t* rank, int32_t* world);
 /* In-place sum over the ranks of `count` device doubles (YtY, objective partials, nnz, per-gene moment sums). */
 int fdx_comm_allreduce_sum_dev(fdx_comm* comm, double* buf_dev, int32_t count, void* stream);
+/* One rank's WHOLE fit behind a plan queued by fdx_graph_shard_knn_dev (or any local graph): X_sketch / XtX, sketch -> H of the
+ * own rows (Y_dev: the own rows in the order of fdx_graph_perm_dev), the plan's counts all-reduced over the ranks while the sketch
+ * runs, lambda (core/spatial.py:181-190), the iteration loop of fdx_sharded_solve_dev, the objective (its sums and YtY in one
+ * all-reduce) and the export - core/deconv.py:326-398 for one shard, one call, no host round trip between the stages.
+ * status != 0: nothing was solved and the caller applies the remedy - FDX_SHARD_FAR (some rank's k-NN walk left its block: every
+ * rank rebuilds its graph by the list exchange), FDX_SHARD_OVERFLOW (a bound of some rank's queued plan was too small: the ranks
+ * rebuild by the stepwise calls), FDX_SHARD_TIES (stop_on_ties set and some k-th neighbour is tied: the reference's order is the
+ * caller's to establish).  nnz_total >= 0: the job's edge count (the graph was not built by the queued plan); 1 to 96 cell types. */
+typedef struct {
+    int32_t sketch_dim, mode_y, mode_x, lambda_auto, max_iter, stop_on_ties;
+    double lambda_spatial, rho_sparsity, tol;
+    int64_t n_total_spots, nnz_total;
+} fdx_shard_fit_params;
+typedef struct {
+    int32_t status, reserved;
+    int64_t nnz_total, knn_ties_total, own_nnz, n_halo;
+    double lambda_used, rho_effective, YtY;
+    fdx_solve_info solve;
+} fdx_shard_fit_info;
+#define FDX_SHARD_FAR 1
+#define FDX_SHARD_OVERFLOW 2
+#define FDX_SHARD_TIES 3
+int fdx_shard_fit_dev(fdx_comm* comm, const fdx_graph* local, const void* Y_dev, int32_t y_dtype, int64_t n_own, int32_t G,
+                      int64_t ldy, const double* X, int32_t K, const int32_t* bucket, const double* weight_y,
+                      const double* weight_x, const fdx_shard_fit_params* prm, double* beta_out_dev, double* prop_out_dev,
+                      double* rel_changes_out, fdx_shard_fit_info* info, void* stream);
 /* The bcd_solve loop (core/solver.py:385-413) over this rank's shard.  beta0_dev / beta1_dev: (K, ld) type-major buffers
  * of the caller (initialised here: 1/K on own + halo, 0 on the pad); *result_buffer says which of the two holds the
  * final abundances.  info: n_iterations, converged, final_change, sweep_ms; rel_changes_out: max_iter doubles or NULL. */

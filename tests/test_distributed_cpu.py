@@ -139,7 +139,10 @@ def test_two_gloo_ranks_reproduce_single_process_solve():
     import fdx_oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -50,6 +50,8 @@ def make(case, kw, n):
 
 
 def worker(rank, W, n, port, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("FDX_WORKER_DEADLINE", "240")), exit=True)   # a hung rank ends with its stack, not silently
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -87,7 +89,10 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 1000
+    import socket
+    with socket.socket() as sk:                       # a free rendezvous port (a fixed one can be taken: the ranks then wait for ever)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=worker, args=(r, W, n, port, q)) for r in range(W)]
     for p in procs:
         p.start()
