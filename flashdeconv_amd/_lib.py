@@ -104,6 +104,8 @@ SIGNATURES = {
                             p_double, ctypes.POINTER(FitInfo), c_void_p]),
     "fdx_graph_build_dev": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i32, c_double, c_void_p, ctypes.POINTER(c_void_p)]),
     "fdx_graph_perm_dev": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fdx_side_stream": (c_int, [ctypes.POINTER(c_void_p)]),
+    "fdx_stream_wait_stream": (c_int, [c_void_p, c_void_p]),
     "fdx_graph_localize": (c_int, [c_void_p, c_i32, p_i64, c_i32, c_void_p, ctypes.POINTER(c_void_p)]),
     "fdx_graph_shard_knn_dev": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i32, p_i64, c_i32, c_void_p, ctypes.POINTER(c_void_p)]),
     "fdx_graph_shard_status": (c_int, [c_void_p, p_i64, p_i64, p_i32, p_i32]),

@@ -227,32 +227,9 @@ class FlashDeconv:
                 owned.append(ybuf)
                 y_ptr = ybuf.ptr
             csr_colsum = None
-            log("Step 1: Selecting informative genes...")
-            t_sel = time.perf_counter()
-            if G_all <= self.n_hvg:
-                # select_hvg returns every gene when the matrix has no more than n_hvg of them and the marker union is a
-                # subset (utils/genes.py:135-145, 330) - no pass over Y needed.
-                gene_idx = np.arange(G_all, dtype=np.intp)
-            else:
-                # the marker table depends on X only: a helper thread ranks it while the device reduces Y to its per-gene
-                # moments (the C call releases the GIL)
-                import concurrent.futures
-                with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
-                    fut = pool.submit(_genes.select_markers, X, self.n_markers_per_type)
-                    if csr is not None:
-                        mean, var, csr_colsum = csr.gene_moments(want_colsum=self.preprocess == "pearson")
-                    else:
-                        mean, var = _genes.gene_moments_device(y_ptr, y_code, n, G_all, G_all)
-                    hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
-                    markers, _ = fut.result()
-                gene_idx = np.union1d(hvg, markers).astype(np.intp)                  # utils/genes.py:330
-                if len(gene_idx) == 0:
-                    raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
-            self.gene_idx_ = gene_idx
-            t_sel = time.perf_counter() - t_sel
-            G = len(gene_idx)
-            log(f"  Selected {G} genes (HVG + markers)")
-            Xsel = np.ascontiguousarray(X[:, gene_idx])
+            # coordinates into HBM; with gene selection active (G > n_hvg) the spatial graph - which does not depend on the genes -
+            # is queued FIRST: its ~0.7 ms of kernels then run under the gene statistics and the host's ranking of the G-vector
+            # instead of after them (the device idled ~1.5 ms there)
             if _is_torch_cuda(coords):
                 import torch
                 cd = coords.to(torch.float64).contiguous()
@@ -265,10 +242,73 @@ class FlashDeconv:
                 c_ptr = cbuf.ptr
             dim = int(coords.shape[1])
             g_method, g_k, g_radius = self._graph_request(coords, coords_host)
+            graph_early = G_all > self.n_hvg
+            t_graph = t_graph_done = None
+            if self._graph is not None:
+                self._graph.close()
+                self._graph = None
+            self._adjacency = None
+            if graph_early:
+                t_graph = time.perf_counter()
+                gh = ctypes.c_void_p()
+                side = ctypes.c_void_p()
+                if os.environ.get("FDX_NO_SIDE_STREAM"):
+                    side = None
+                else:
+                    # on the library's side stream, behind whatever produced the coordinates on the default stream so far
+                    _lib.check(lib.fdx_side_stream(ctypes.byref(side)))
+                    if _is_torch_cuda(coords):
+                        import torch
+                        _lib.check(lib.fdx_stream_wait_stream(side, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                _lib.check(lib.fdx_graph_build_dev(c_ptr, n, dim, g_method, g_k, g_radius, side, ctypes.byref(gh)))
+                self._graph = _lib.Graph(gh.value)
+                t_graph_done = time.perf_counter()
+            log("Step 1: Selecting informative genes...")
+            t_sel = time.perf_counter()
+            if G_all <= self.n_hvg:
+                # select_hvg returns every gene when the matrix has no more than n_hvg of them and the marker union is a
+                # subset (utils/genes.py:135-145, 330) - no pass over Y needed.
+                gene_idx = np.arange(G_all, dtype=np.intp)
+            else:
+                # the marker table depends on X only: a helper thread ranks it while the device reduces Y to its per-gene
+                # moments (the C call releases the GIL)
+                import concurrent.futures
+                tr = [time.perf_counter()] if os.environ.get("FDX_TRACE_HOST") else None
+                with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+                    fut = pool.submit(_genes.select_markers, X, self.n_markers_per_type)
+                    if csr is not None:
+                        mean, var, csr_colsum = csr.gene_moments(want_colsum=self.preprocess == "pearson")
+                    else:
+                        mean, var = _genes.gene_moments_device(y_ptr, y_code, n, G_all, G_all)
+                    if tr is not None:
+                        tr.append(time.perf_counter())
+                    hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
+                    if tr is not None:
+                        tr.append(time.perf_counter())
+                    markers, _ = fut.result()
+                    if tr is not None:
+                        tr.append(time.perf_counter())
+                gene_idx = np.union1d(hvg, markers).astype(np.intp)                  # utils/genes.py:330
+                if tr is not None:
+                    tr.append(time.perf_counter())
+                    print("[fdx-host] python select: moments (device + read-back) %.0f us, hvg ranking %.0f, wait for the marker table %.0f, "
+                          "pool shutdown + union %.0f" % tuple(1e6 * (b - a) for a, b in zip(tr[:-1], tr[1:])), file=sys.stderr)
+                if len(gene_idx) == 0:
+                    raise ValueError("No genes selected. Increase n_hvg or n_markers_per_type.")
+            self.gene_idx_ = gene_idx
+            t_sel_end = time.perf_counter()
+            t_sel = t_sel_end - t_sel
+            G = len(gene_idx)
+            log(f"  Selected {G} genes (HVG + markers)")
+            Xsel = X if G == G_all else np.take(X, gene_idx, axis=1)          # (np.take: half the time of X[:, gene_idx] at 30 x 3300 of 20000)
             # The leverage SVD runs on the library's side stream beside the graph build.  Its job is set up FIRST: set up behind
             # the build call, its pooled buffers (last used on the caller's stream) order the side stream behind everything the
             # build has just queued - the SVD then starts when the graph is done (measured: the wait 0.6 -> 1.3 ms).
+            t_x0 = time.perf_counter()
             lev_job = _genes.LeverageJob(Xsel)
+            if os.environ.get("FDX_TRACE_HOST"):
+                print(f"[fdx-host] python: select end -> Xsel {1e6 * (t_x0 - t_sel_end):.0f} us, leverage job set-up {1e6 * (time.perf_counter() - t_x0):.0f}",
+                      file=sys.stderr)
             if G != G_all and csr is None:          # Y[:, gene_idx] (core/deconv.py:321) as a compact device matrix
                 sub = _DeviceBuffer(n * G * (4 if y_code == _lib.FDX_F32 else 8))
                 owned.append(sub)
@@ -278,14 +318,11 @@ class FlashDeconv:
             ldy = G
 
             # Step 4 runs here, under the leverage SVD (no data dependence between core/deconv.py:318 and :358)
-            t_graph = time.perf_counter()
-            if self._graph is not None:
-                self._graph.close()
-                self._graph = None
-            self._adjacency = None
-            gh = ctypes.c_void_p()
-            _lib.check(lib.fdx_graph_build_dev(c_ptr, n, dim, g_method, g_k, g_radius, None, ctypes.byref(gh)))
-            self._graph = _lib.Graph(gh.value)
+            if not graph_early:
+                t_graph = time.perf_counter()
+                gh = ctypes.c_void_p()
+                _lib.check(lib.fdx_graph_build_dev(c_ptr, n, dim, g_method, g_k, g_radius, None, ctypes.byref(gh)))
+                self._graph = _lib.Graph(gh.value)
             n_ties = 0
             if self.spatial_method == "knn" and self.knn_ties == "ckdtree":
                 # the reference's tie order, on request: only when the device build met ties (this question waits for the
@@ -433,7 +470,7 @@ class FlashDeconv:
                                                              "prologue_ms", "span_ms")}
         self.timings_["sweep_ms"] = float(info.solve.sweep_ms)
         # host wall of the graph build call, and of the wait for the leverage SVD that ran beside it
-        self.timings_["graph_ms"] = (t_lev - t_graph) * 1e3
+        self.timings_["graph_ms"] = ((t_graph_done if graph_early else t_lev) - t_graph) * 1e3
         self.timings_["select_ms"] = t_sel * 1e3      # gene statistics on the device + HVG/marker ranking on the host
         self.timings_["leverage_wait_ms"] = (t_done - t_lev) * 1e3
         # the graph is built by its own call ahead of fdx_fit_dev, whose total_ms starts after it: one figure for the fit

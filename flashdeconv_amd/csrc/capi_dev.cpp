@@ -34,6 +34,23 @@ int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_
     return 0;
 }
 
+int fdx_side_stream(void** stream_out) {
+    FDX_REQUIRE(stream_out != nullptr, "fdx_side_stream: null output");
+    *stream_out = (void*)library_side_stream();
+    FDX_REQUIRE(*stream_out != nullptr, "fdx_side_stream: the side stream could not be created");
+    return 0;
+}
+
+int fdx_stream_wait_stream(void* waiter, void* producer) {
+    hipEvent_t ev = nullptr;
+    FDX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)producer);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    (void)hipEventDestroy(ev);                      // released when the wait has been satisfied
+    if (e != hipSuccess) return fail(FDX_ERR_HIP, hipGetErrorString(e));
+    return 0;
+}
+
 int fdx_graph_build_radius_rows_dev(const double* coords_dev, int64_t n, int32_t dim, double radius, int64_t lo, int64_t hi,
                                     void* stream, fdx_graph** out) {
     PoolStream pool_stream((hipStream_t)stream);

@@ -47,15 +47,23 @@ struct CsrGroup {
     T y[4];
 };
 
-template <typename T>
+// NT: the row is read ONCE (the fused kernel's library-size pass keeps what it needs in LDS): non-temporal loads, so that the
+// 11.5 GB stream does not push the 320 KB {weight, bucket} table out of L2 - its gathers (one 16-byte slot per selected entry,
+// 3.8 GB of requests per fit) then stay L2 hits instead of going out to the fabric
+template <typename T, bool NT = false>
 __device__ __forceinline__ void csr_load_group(CsrGroup<T>& g, const int* __restrict__ indices, const T* __restrict__ data,
                                                long long q0, long long end, int lane) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const long long q = q0 + u * 64 + lane;
         const bool ok = q < end;
-        g.c[u] = ok ? indices[q] : -1;           // no non-temporal hint: log-CPM reads the row a second time from L2/MALL
-        g.y[u] = ok ? data[q] : (T)0;
+        if (NT) {
+            g.c[u] = ok ? __builtin_nontemporal_load(indices + q) : -1;
+            g.y[u] = ok ? __builtin_nontemporal_load(data + q) : (T)0;
+        } else {
+            g.c[u] = ok ? indices[q] : -1;       // no non-temporal hint: log-CPM reads the row a second time from L2/MALL
+            g.y[u] = ok ? data[q] : (T)0;
+        }
     }
 }
 
@@ -274,9 +282,12 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
             CsrGroup<T> cur, nxt;
             if (MODE != FDX_PRE_RAW) {  // library size over the SELECTED genes (the subset is taken first, deconv.py:321)
                 double s = 0.0, mx = 0.0;
-                csr_load_group(cur, indices, data, beg, end, lane);
+                const bool stream = cap > 0 && (end - beg) <= 4LL * cap;     // wave-uniform guess: the row's selected entries will fit the keep buffer - it is read once
+                if (stream) csr_load_group<T, true>(cur, indices, data, beg, end, lane);
+                else csr_load_group(cur, indices, data, beg, end, lane);
                 for (long long q0 = beg; q0 < end; q0 += 256) {
-                    csr_load_group(nxt, indices, data, q0 + 256, end, lane);
+                    if (stream) csr_load_group<T, true>(nxt, indices, data, q0 + 256, end, lane);
+                    else csr_load_group(nxt, indices, data, q0 + 256, end, lane);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const bool sel = cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u);
@@ -582,7 +593,13 @@ __global__ __launch_bounds__(1024, 8) void csr_moments_cursor_kernel(const long 
             const bool use_tab = sc_signed > 0.0;
             if (use_tab) log1p_table_fill(tab, sc, lane);
             __builtin_amdgcn_s_waitcnt(0xc07f);
-            while (q0 < end) {                                            // wave-uniform
+            // Steps of 256 entries while most of what the tile is expected to hold of this row (columns are roughly uniform: row
+            // length x tile width / G) is still ahead, then steps of 64: a step that reaches past the tile's last entry reads the
+            // rest of its 256 for nothing (and again on the next visit) - with ~290 entries per visit the 256-entry steps read
+            // 512, i.e. 1.8 x the bytes (PMC 22.8 GB for 11.5 GB: the kernel ran at the copy ceiling on bytes it did not need)
+            const long long est = ((end - beg) * (long long)(t1 - t0)) / (long long)G;
+            long long consumed = 0;
+            while (q0 < end && consumed + 256 <= est - (est >> 3)) {   // wave-uniform
                 // 256 entries per step, FOUR CONSECUTIVE ones per lane: one 16-byte load for the columns and one for the values
                 // instead of four 4-byte loads each (the kernel waits on its vector-memory instructions - 70 M of them per
                 // pass over 1.44e9 entries, texture addresser half busy, 80 % of the wave time parked; the loads only need
@@ -624,7 +641,24 @@ __global__ __launch_bounds__(1024, 8) void csr_moments_cursor_kernel(const long 
                         }
                 }
                 q0 += taken;
-                if (taken < 256) break;                                   // reached the next tile (or the row's end)
+                consumed += taken;
+                if (taken < 256) { consumed = -1; break; }                // reached the next tile (or the row's end)
+            }
+            while (consumed >= 0 && q0 < end) {                           // one entry per lane
+                const long long q = q0 + lane;
+                const bool ok = q < end;
+                const int c = ok ? indices[q] : 0x7fffffff;
+                const double y = ok ? (double)data[q] : 0.0;
+                const bool in = c < t1;
+                const int taken = __popcll(__ballot(in));
+                if (in) {
+                    const double z = log1p_scaled(y, sc, tab, use_tab);
+                    lds_add(acc + (c - t0), z);
+                    lds_add(acc + tile + (c - t0), z * z);
+                    if (NS == 3) lds_add(acc + 2 * tile + (c - t0), y);
+                }
+                q0 += taken;
+                if (taken < 64) break;
             }
             if (lane == 0) cursor[row] = (int)(q0 - beg);
         }

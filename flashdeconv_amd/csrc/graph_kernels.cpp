@@ -48,29 +48,48 @@ struct GridParams {
 };
 
 // ------------------------------------------------------------------------------------------------ bbox
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// (the tree reduction of six 256-entry LDS arrays this kernel used to end with - eight barrier-separated steps - made a 16 MB
+// read take 37-47 us; the loop itself is a few microseconds: wave shuffles, then four values per quantity through LDS)
 __global__ __launch_bounds__(256) void bbox_partial_kernel(const double* __restrict__ coords, long long n, int dim,
                                                            double* __restrict__ part /* (nblk, 6) */) {
-    __shared__ double smn[3][256], smx[3][256];
+    __shared__ double s_v[6][4];
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        for (int a = 0; a < dim; ++a) {
-            const double v = coords[(size_t)i * dim + a];
-            mn[a] = fmin(mn[a], v);
-            mx[a] = fmax(mx[a], v);
+    if (dim == 2 && ((unsigned long long)coords & 15ULL) == 0ULL) {      // one 16-byte load per point
+        const double2* c2 = reinterpret_cast<const double2*>(coords);
+        for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const double2 v = c2[i];
+            mn[0] = fmin(mn[0], v.x); mx[0] = fmax(mx[0], v.x);
+            mn[1] = fmin(mn[1], v.y); mx[1] = fmax(mx[1], v.y);
         }
-    for (int a = 0; a < 3; ++a) { smn[a][threadIdx.x] = mn[a]; smx[a][threadIdx.x] = mx[a]; }
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s)
-            for (int a = 0; a < 3; ++a) {
-                smn[a][threadIdx.x] = fmin(smn[a][threadIdx.x], smn[a][threadIdx.x + s]);
-                smx[a][threadIdx.x] = fmax(smx[a][threadIdx.x], smx[a][threadIdx.x + s]);
+    } else {
+        for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+            for (int a = 0; a < dim; ++a) {
+                const double v = coords[(size_t)i * dim + a];
+                mn[a] = fmin(mn[a], v);
+                mx[a] = fmax(mx[a], v);
             }
-        __syncthreads();
     }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double lo = wave_min_f64(mn[a]), hi = wave_max_f64(mx[a]);
+        if (lane == 0) { s_v[a][wv] = lo; s_v[3 + a][wv] = hi; }
+    }
+    __syncthreads();
     if (threadIdx.x < 3) {
-        part[(size_t)blockIdx.x * 6 + threadIdx.x] = smn[threadIdx.x][0];
-        part[(size_t)blockIdx.x * 6 + 3 + threadIdx.x] = smx[threadIdx.x][0];
+        const int a = threadIdx.x;
+        part[(size_t)blockIdx.x * 6 + a] = fmin(fmin(s_v[a][0], s_v[a][1]), fmin(s_v[a][2], s_v[a][3]));
+        part[(size_t)blockIdx.x * 6 + 3 + a] = fmax(fmax(s_v[3 + a][0], s_v[3 + a][1]), fmax(s_v[3 + a][2], s_v[3 + a][3]));
     }
 }
 
@@ -1414,7 +1433,10 @@ static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int
     // candidates per round trip: 4 leaves the kernel 77 registers (6 waves per SIMD), 6: 87 (5 waves), 8: 97 (4 waves);
     // 1M spots, wall per fit: 4.69 / 4.84 / 4.88 ms
     const int batch_env = getenv("FDX_KNN_BATCH") ? atoi(getenv("FDX_KNN_BATCH")) : 0;
-    const int batch = (KMAX <= 16 && (batch_env == 4 || batch_env == 6 || batch_env == 8)) ? batch_env : (KMAX <= 16 ? 4 : 8);
+    // a launch of a few hundred thousand rows does not fill the chip anyway (a spot shard's own rows + band): what it takes is one
+    // walk's chain of round trips, and 8 candidates per round trip halve that chain (97 registers, 4 waves per SIMD - no loss here)
+    const int batch_auto = (KMAX <= 16 && n_threads <= 300000) ? 8 : 4;
+    const int batch = (KMAX <= 16 && (batch_env == 4 || batch_env == 6 || batch_env == 8)) ? batch_env : (KMAX <= 16 ? batch_auto : 8);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(ceil_div(n_threads, 128)), dim3(128), 0, st, b.sc.as<double>(), b.sc2.as<double2>(), perm,
                            b.rank.as<int>(), b.cstart.as<int>(), b.cend_p, b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,

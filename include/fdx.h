@@ -281,6 +281,11 @@ int fdx_type_sums_csr_dev(const fdx_csr_view* Y, const int32_t* rows_dev, const 
  * own stream behind the build when it differs). */
 int fdx_graph_build_dev(const double* coords_dev, int64_t n, int32_t dim, int32_t method, int32_t k, double radius,
                         void* stream, fdx_graph** out);
+/* The library's own non-blocking side stream of the current device (hipStream_t): a graph build queued there runs beside whatever
+ * the caller's stream is doing (FlashDeconv.fit with gene selection: beside the gene statistics and the host's ranking). */
+int fdx_side_stream(void** stream_out);
+/* Work queued on `waiter` from now on starts after everything queued on `producer` so far (event record + stream wait). */
+int fdx_stream_wait_stream(void* waiter, void* producer);
 /* Spot shards, radius / grid graphs (utils/graph.py:84-212): rows [lo, hi) (solver positions, lo a multiple of 64) of the
  * radius graph, all other rows left empty - the shard's part of fdx_graph_build_dev(FDX_GRAPH_RADIUS).  A radius graph is
  * symmetric by construction (query_pairs, graph.py:115-121), so a shard's own rows need nothing from the other shards; the
