@@ -45,6 +45,7 @@ class FitParams(ctypes.Structure):
         ("sketch_dim", c_i32), ("mode_y", c_i32), ("mode_x", c_i32), ("graph_method", c_i32), ("k_neighbors", c_i32),
         ("lambda_auto", c_i32), ("max_iter", c_i32), ("verbose", c_i32),
         ("radius", c_double), ("lambda_spatial", c_double), ("rho_sparsity", c_double), ("tol", c_double),
+        ("stop_on_ties", c_i32), ("reserved", c_i32),
     ]
 
 
@@ -75,7 +76,11 @@ class FitInfo(ctypes.Structure):
         ("solve", SolveInfo), ("lambda_used", c_double), ("rho_effective", c_double), ("YtY", c_double), ("nnz", c_i64),
         ("graph_ms", c_double), ("sketch_ms", c_double), ("gram_ms", c_double), ("solve_ms", c_double),
         ("finish_ms", c_double), ("total_ms", c_double), ("prologue_ms", c_double), ("span_ms", c_double),
+        ("knn_ties", c_i64), ("status", c_i32), ("reserved", c_i32),
     ]
+
+
+FIT_TIES = 3
 
 
 GRAPH_KNN, GRAPH_RADIUS, GRAPH_GIVEN = 0, 1, 2
@@ -171,6 +176,7 @@ SIGNATURES = {
     "fdx_ckdtree_knn": (c_int, [p_double, c_i64, c_i32, c_i32, c_void_p, c_void_p]),
     "fdx_ckdtree_knn_rows": (c_int, [p_double, c_i64, c_i32, c_i32, p_i64, c_i64, c_void_p]),
     "fdx_graph_plan_order_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fdx_graph_plan_lists_replaced": (c_int, [c_void_p]),
     "fdx_bcd_solve": (c_int, [c_void_p, p_double, p_double, c_i64, c_i32, c_i32, c_double, c_double, c_i32, c_double,
                               c_i32, p_double, p_double, p_double, ctypes.POINTER(SolveInfo)]),
 }

@@ -80,6 +80,56 @@ class _DeviceBuffer:
             pass
 
 
+def reference_tie_graph(c_ptr, coords_host, n, dim, k):
+    """The k-NN graph on the REFERENCE's choice among exactly equidistant neighbours (regular lattices tie on every spot): the
+    lists come from the restated cKDTree (utils/graph.py: ckdtree_knn_lists - scipy's build and traversal order, on the host),
+    everything else stays on the device - the lists are put, in solver positions, where the device's own lists would be and
+    symmetrised / laid out by fdx_graph_from_knn_lists_dev.  The graph therefore keeps the Morton order and the sweep tiles of
+    any other device-built graph (the round-4 route went through a host adjacency in the caller's order: A + A^T in scipy, an
+    untiled upload).  Reference: utils/graph.py:60-81."""
+    from ..utils.graph import ckdtree_knn_lists
+    lib = _lib.load()
+    kk = min(int(k), n - 1) + 1
+    nbr, cnt = _DeviceBuffer(n * kk * 4), _DeviceBuffer(n * 4)
+    perm_d, rank_d = _DeviceBuffer(n * 4), _DeviceBuffer(n * 4)
+    plan, h = ctypes.c_void_p(), ctypes.c_void_p()
+    try:
+        _lib.check(lib.fdx_graph_knn_lists_dev(c_ptr, n, dim, int(k), 0, n, nbr.ptr, cnt.ptr, None, ctypes.byref(plan)))
+        try:
+            _lib.check(lib.fdx_graph_plan_order_dev(plan, perm_d.ptr, rank_d.ptr, None))
+            rank = rank_d.to_host((n,), dtype=np.int32)
+            lists = ckdtree_knn_lists(coords_host, k)                       # (n, kk) caller ids, nearest first, self included
+            own = np.arange(n, dtype=lists.dtype)
+            if kk >= 2 and bool((lists[:, 0] == own).all()) and bool((lists[:, 1:] >= 0).all()) and bool((lists[:, 1:] != own[:, None]).all()):
+                keep_n = np.full(n, kk - 1, dtype=np.int32)                    # the usual case: self is the first entry, all others real
+                comp = np.concatenate([lists[:, 1:], np.full((n, 1), -1, dtype=lists.dtype)], axis=1)
+            else:                                                              # duplicates of a point can push self out of its own list
+                keep = (lists >= 0) & (lists != own[:, None])                  # utils/graph.py:70-74
+                order = np.argsort(~keep, axis=1, kind="stable")
+                comp = np.take_along_axis(lists, order, axis=1)
+                keep_n = keep.sum(axis=1).astype(np.int32)
+                comp[np.arange(kk)[None, :] >= keep_n[:, None]] = -1
+            pos = np.where(comp >= 0, rank[np.maximum(comp, 0)], -1).astype(np.int32)
+            nbr_h = np.empty((n, kk), dtype=np.int32)
+            cnt_h = np.empty(n, dtype=np.int32)
+            nbr_h[rank] = pos                                                  # row of caller id i sits at solver position rank[i]
+            cnt_h[rank] = keep_n
+            _lib.check(lib.fdx_memcpy_h2d(nbr.ptr, nbr_h.ctypes.data, nbr_h.nbytes, None))
+            _lib.check(lib.fdx_memcpy_h2d(cnt.ptr, cnt_h.ctypes.data, cnt_h.nbytes, None))
+            _lib.check(lib.fdx_graph_plan_lists_replaced(plan))
+        except Exception:
+            dead = ctypes.c_void_p()                                           # the plan owns device buffers: consume it
+            lib.fdx_graph_from_knn_lists_dev(plan, nbr.ptr, cnt.ptr, 0, 0, None, ctypes.byref(dead))
+            if dead.value:
+                _lib.Graph(dead.value).close()
+            raise
+        _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, nbr.ptr, cnt.ptr, 0, n, None, ctypes.byref(h)))
+        return _lib.Graph(h.value)
+    finally:
+        for b in (nbr, cnt, perm_d, rank_d):
+            b.free()
+
+
 class FlashDeconv:
     """Fast spatial transcriptomics deconvolution with spatial regularisation (MI355X implementation).
 
@@ -300,7 +350,7 @@ class FlashDeconv:
             t_sel = t_sel_end - t_sel
             G = len(gene_idx)
             log(f"  Selected {G} genes (HVG + markers)")
-            Xsel = X if G == G_all else np.take(X, gene_idx, axis=1)          # (np.take: half the time of X[:, gene_idx] at 30 x 3300 of 20000)
+            Xsel = np.ascontiguousarray(X) if G == G_all else np.take(X, gene_idx, axis=1)          # (np.take: half the time of X[:, gene_idx] at 30 x 3300 of 20000)
             # The leverage SVD runs on the library's side stream beside the graph build.  Its job is set up FIRST: set up behind
             # the build call, its pooled buffers (last used on the caller's stream) order the side stream behind everything the
             # build has just queued - the SVD then starts when the graph is done (measured: the wait 0.6 -> 1.3 ms).
@@ -330,12 +380,10 @@ class FlashDeconv:
                 # tree (csrc/kdtree_order.cpp) and the graph is rebuilt from the reference's own adjacency
                 n_ties = self._graph.knn_ties()
                 if n_ties:
-                    from ..utils.graph import ckdtree_knn_adjacency
                     ch = coords_host if coords_host is not None else coords.detach().cpu().numpy().astype(np.float64)
-                    A = ckdtree_knn_adjacency(ch, int(self.k_neighbors))
                     self._graph.close()
-                    self._graph = _lib.Graph.from_csr(A.indptr, A.indices, n)
-                    self._adjacency = A
+                    self._graph = None
+                    self._graph = reference_tie_graph(c_ptr, ch, n, dim, int(self.k_neighbors))
             t_lev = time.perf_counter()
             leverage = lev_job.result()
             t_done = time.perf_counter()
@@ -379,6 +427,10 @@ class FlashDeconv:
             prm.lambda_spatial = 0.0 if prm.lambda_auto else float(self.lambda_spatial)
             prm.radius = 0.0
             prm.graph_method = _lib.GRAPH_GIVEN
+            # "auto": the question "is any k-th neighbour tied?" is answered inside the fit, where the graph's counts are taken
+            # over anyway - tie-free inputs pay nothing; on ties the call returns before the solve and the graph is rebuilt on the
+            # reference's choice
+            prm.stop_on_ties = 1 if (self.spatial_method == "knn" and self.knn_ties == "auto") else 0
             log("Step 4: Building spatial graph...")
 
             if output == "torch":
@@ -399,17 +451,38 @@ class FlashDeconv:
             bucket32 = np.ascontiguousarray(bucket, dtype=np.int32)
             wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
             t_call = time.perf_counter()
-            if csr is not None:
-                gi32 = np.ascontiguousarray(gene_idx, dtype=np.int32)
-                _lib.check(lib.fdx_fit_csr_dev(ctypes.byref(csr.view), _lib.ptr_i32(gi32), G, _lib.ptr_f64(Xsel), K,
-                                               _lib.ptr_i32(bucket32), _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim,
-                                               ctypes.byref(prm), ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs),
-                                               _lib.ptr_f64(rels), ctypes.byref(info), None))
+            gi32 = np.ascontiguousarray(gene_idx, dtype=np.int32)
+
+            def run_fit():
+                if csr is not None:
+                    _lib.check(lib.fdx_fit_csr_dev(ctypes.byref(csr.view), _lib.ptr_i32(gi32), G, _lib.ptr_f64(Xsel), K,
+                                                   _lib.ptr_i32(bucket32), _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim,
+                                                   ctypes.byref(prm), ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs),
+                                                   _lib.ptr_f64(rels), ctypes.byref(info), None))
+                else:
+                    _lib.check(lib.fdx_fit_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(Xsel), K, _lib.ptr_i32(bucket32),
+                                               _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim, ctypes.byref(prm),
+                                               ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs), _lib.ptr_f64(rels),
+                                               ctypes.byref(info), None))
+
+            run_fit()
+            ties_remedy_ms = 0.0
+            if info.status == _lib.FIT_TIES:
+                # ties under "auto": the reference's neighbour choice, then the fit proper (one solve; the sketch is queued again)
+                n_ties = int(info.knn_ties)
+                log(f"k-NN ties on {n_ties} of {n} spots: rebuilding the graph on the reference's (cKDTree) neighbour choice")
+                ch = coords_host if coords_host is not None else coords.detach().cpu().numpy().astype(np.float64)
+                self._graph.close()
+                self._graph = None
+                self._graph = reference_tie_graph(c_ptr, ch, n, dim, int(self.k_neighbors))
+                gh = ctypes.c_void_p(self._graph.handle.value)
+                prm.stop_on_ties = 0
+                ties_resolved_here = True
+                ties_remedy_ms = (time.perf_counter() - t_call) * 1e3
+                t_call = time.perf_counter()
+                run_fit()
             else:
-                _lib.check(lib.fdx_fit_dev(y_ptr, y_code, n, G, ldy, _lib.ptr_f64(Xsel), K, _lib.ptr_i32(bucket32),
-                                           _lib.ptr_f64(wy), _lib.ptr_f64(wx), c_ptr, dim, ctypes.byref(prm),
-                                           ctypes.byref(gh), b_ptr, p_ptr, _lib.ptr_f64(objs), _lib.ptr_f64(rels),
-                                           ctypes.byref(info), None))
+                ties_resolved_here = False
             t_ret = time.perf_counter()
             if os.environ.get("FDX_TRACE_HOST"):
                 print(f"[fdx-host] python: entry->build {1e6 * (t_graph - t_entry):.0f} us, build call {1e6 * (t_lev - t_graph):.0f}, leverage wait "
@@ -445,17 +518,8 @@ class FlashDeconv:
         # additive (not in the reference): spots whose k-NN set is a choice - the k-th and (k+1)-th neighbours exactly
         # equidistant.  The reference takes whichever cKDTree.query meets first (utils/graph.py:60-63), which changes
         # with the order the spots are listed in; here the lower spot index wins.  Regular lattices tie on every spot.
-        resolved = self.spatial_method == "knn" and self.knn_ties == "ckdtree"
-        self.info_["knn_ties"] = (n_ties if resolved else self._graph.knn_ties()) if self.spatial_method == "knn" else 0
-        if self.info_["knn_ties"] and self.knn_ties == "auto":
-            # the device rule chose among equidistant neighbours: repeat the fit on the reference's choice (same inputs; the
-            # graph then comes from the cKDTree restatement).  Tie-free inputs never get here.
-            log(f"k-NN ties on {self.info_['knn_ties']} of {n} spots: fitting again on the reference's (cKDTree) neighbour choice")
-            self.knn_ties = "ckdtree"
-            try:
-                return self.fit(Y, X, coords, cell_type_names=cell_type_names, output=output)
-            finally:
-                self.knn_ties = "auto"
+        resolved = self.spatial_method == "knn" and (self.knn_ties == "ckdtree" or ties_resolved_here)
+        self.info_["knn_ties"] = (n_ties if resolved else int(info.knn_ties)) if self.spatial_method == "knn" else 0
         if self.info_["knn_ties"] and not resolved:
             import warnings
             warnings.warn(
@@ -469,6 +533,8 @@ class FlashDeconv:
         self.timings_ = {k: float(getattr(info, k)) for k in ("graph_ms", "sketch_ms", "gram_ms", "solve_ms", "finish_ms", "total_ms",
                                                              "prologue_ms", "span_ms")}
         self.timings_["sweep_ms"] = float(info.solve.sweep_ms)
+        # ties under "auto": the stopped first call + the reference's lists (host tree) + the rebuilt graph; ahead of the fit proper
+        self.timings_["ties_remedy_ms"] = ties_remedy_ms
         # host wall of the graph build call, and of the wait for the leverage SVD that ran beside it
         self.timings_["graph_ms"] = ((t_graph_done if graph_early else t_lev) - t_graph) * 1e3
         self.timings_["select_ms"] = t_sel * 1e3      # gene statistics on the device + HVG/marker ranking on the host
@@ -480,6 +546,10 @@ class FlashDeconv:
         # prologue_ms + sketch_ms + gram_ms + solve_ms + finish_ms) + host_post_ms (fit_dev's return -> here);
         # total_ms is their sum, and what the wall has beyond it is the host's last synchronisation
         self.timings_["host_pre_ms"] = (t_graph - t_entry) * 1e3
+        if ties_resolved_here or (resolved and n_ties):
+            # the graph was rebuilt on the reference's tie order: the device span starts with the fit call that used it, and
+            # everything before that call (first build, the stopped call, the host tree, the rebuild) is host time
+            self.timings_["host_pre_ms"] = (t_call - t_entry) * 1e3
         self.timings_["host_post_ms"] = (time.perf_counter() - t_ret) * 1e3
         self.timings_["total_ms"] = self.timings_["host_pre_ms"] + self.timings_["span_ms"] + self.timings_["host_post_ms"]
         self._fitted = True

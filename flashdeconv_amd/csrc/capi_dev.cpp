@@ -87,6 +87,11 @@ int fdx_graph_plan_order_dev(const fdx_graph_plan* plan, int32_t* perm_out_dev, 
     return graph_plan_order(plan, perm_out_dev, rank_out_dev, (hipStream_t)stream);
 }
 
+int fdx_graph_plan_lists_replaced(fdx_graph_plan* plan) {
+    FDX_REQUIRE(plan != nullptr, "fdx_graph_plan_lists_replaced: null plan");
+    return graph_plan_lists_replaced(plan);
+}
+
 int fdx_graph_knn_far(const fdx_graph* g, int32_t* far) {
     FDX_REQUIRE(g != nullptr && far != nullptr, "fdx_graph_knn_far: null argument");
     FDX_TRY(fdx::graph_meta_sync(g));

@@ -468,6 +468,14 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     // a graph whose build was only queued (graph_kernels.cpp, deferred completion) has long finished behind the sketch: take over
     // its counts before lambda and the sweep launches need them
     FDX_TRY(graph_meta_sync(g));
+    info->knn_ties = g->knn_ties;
+    info->nnz = g->nnz;
+    if (prm->stop_on_ties && g->knn_ties > 0) {
+        // the caller wants the reference's choice among equidistant neighbours: nothing is solved on this graph (the sketch that
+        // is already queued is waited for by the drains below and dropped - tie-free inputs never pay for the question)
+        info->status = FDX_FIT_TIES;
+        return 0;
+    }
     // auto_tune_lambda (core/spatial.py:181-190): alpha * mean(diag XtX) / max(mean degree, 1), alpha = 0.005
     double lambda = prm->lambda_spatial;
     if (prm->lambda_auto) {

@@ -1654,6 +1654,16 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
 
 void graph_plan_destroy(fdx_graph_plan* plan) { delete plan; }
 int graph_plan_kk(const fdx_graph_plan* plan) { return plan->kk; }
+// the caller has written other lists into nbr / cnt than the ones the k-NN kernel produced: the in-degrees and reverse-list places
+// that kernel drew for ITS lists (whole-graph builds) no longer apply - the symmetrisation counts again
+int graph_plan_lists_replaced(fdx_graph_plan* plan) {
+    if (plan->indeg.p || plan->arrival.p) {
+        FDX_HIP(hipStreamSynchronize(plan->st));        // the k-NN kernel may still be writing them
+        plan->indeg.release();
+        plan->arrival.release();
+    }
+    return 0;
+}
 int graph_plan_order(const fdx_graph_plan* plan, int* d_perm_out, int* d_rank_out, hipStream_t st) {
     if (d_perm_out) FDX_HIP(hipMemcpyAsync(d_perm_out, plan->b.perm.p, (size_t)plan->n * 4, hipMemcpyDeviceToDevice, st));
     if (d_rank_out) FDX_HIP(hipMemcpyAsync(d_rank_out, plan->b.rank.p, (size_t)plan->n * 4, hipMemcpyDeviceToDevice, st));

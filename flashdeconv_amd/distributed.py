@@ -577,6 +577,7 @@ class ShardedFlashDeconv:
             pos = torch.where(lt >= 0, rank_t[lt.clamp(min=0)].long(), torch.full_like(lt, -1))
             nbr[rows_pos] = pos.to(torch.int32)
             cnt[rows_pos] = torch.from_numpy(n_keep.astype(np.int32)).to(dev)
+            _lib.check(lib.fdx_graph_plan_lists_replaced(plan))
         _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi,
                                                     st, ctypes.byref(h)))
         full = _lib.Graph(h.value)

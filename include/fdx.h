@@ -203,7 +203,11 @@ typedef struct fdx_fit_params {
     double lambda_spatial;   /* used when lambda_auto == 0 */
     double rho_sparsity;     /* user-facing fraction, scaled by mean(diag XtX) inside */
     double tol;
+    int32_t stop_on_ties;    /* k-NN graphs: 1 = return with info->status = FDX_FIT_TIES before the solve when some spot's k-th neighbour is
+                                tied (the caller then rebuilds the graph on the reference's choice, utils/graph.py:60-63, and calls again) */
+    int32_t reserved;
 } fdx_fit_params;
+#define FDX_FIT_TIES 3
 
 typedef struct fdx_fit_info {
     fdx_solve_info solve;
@@ -217,6 +221,9 @@ typedef struct fdx_fit_info {
      * sketch stage; span_ms from that same point to the end of the export, so that
      * prologue_ms + (sketch stage) + solve_ms + finish_ms = span_ms up to event granularity */
     double prologue_ms, span_ms;
+    int64_t knn_ties;        /* spots whose k-th and (k+1)-th nearest neighbours are exactly equidistant (k-NN graphs built on the device) */
+    int32_t status;          /* 0: fitted; FDX_FIT_TIES: stopped before the solve (stop_on_ties) - nothing but knn_ties / nnz is valid */
+    int32_t reserved;
 } fdx_fit_info;
 
 /* Device-resident fit.  Y_dev: (n, G) matrix of `y_dtype` on the device, row stride ldy elements.  X: HOST (K, G)
@@ -321,6 +328,10 @@ int fdx_graph_knn_far(const fdx_graph* g, int32_t* far);
  * position (int32, n entries each, device; either may be NULL).  A band plan lays out only the neighbourhood of its own rows
  * (positions / ids elsewhere are not data). */
 int fdx_graph_plan_order_dev(const fdx_graph_plan* plan, int32_t* perm_out_dev, int32_t* rank_out_dev, void* stream);
+/* The caller has REPLACED rows of nbr_dev / cnt_dev (e.g. by the reference's choice among equidistant neighbours,
+ * fdx_ckdtree_knn): call this before fdx_graph_from_knn_lists_dev so that the symmetrisation counts the lists it is given
+ * (a whole-graph plan carries counts its k-NN kernel drew for its own lists). */
+int fdx_graph_plan_lists_replaced(fdx_graph_plan* plan);
 /* perm_out_dev[p] = caller's spot id at solver position p (int32, n entries, device). */
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
 /* Shard of a full graph for rank `my_rank`: own spots are solver positions [bounds[my_rank], bounds[my_rank+1])

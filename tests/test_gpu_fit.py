@@ -459,6 +459,34 @@ def test_lattice_k6_with_the_reference_tie_order_is_exact(name, ties):
         FlashDeconv(knn_ties="lapack")
 
 
+@pytest.mark.parametrize("dim,shape", [(4, (6, 5, 6, 5)), (5, (4, 4, 4, 4, 3)), (3, (10, 9, 10))])
+def test_lattice_in_three_to_five_dimensions_takes_the_reference_tie_order_by_default(dim, shape):
+    """Integer lattices with 3, 4 and 5 coordinates (every k-th neighbour tied; above 3 dimensions the device search is exhaustive):
+    the default knn_ties="auto" gives the reference's adjacency - scipy's cKDTree order, utils/graph.py:60-81 - index for index, in
+    ONE solve, and the fit equals the oracle's on that graph.  (Round 4: the tie route stopped at 3 dimensions and raised.)"""
+    import warnings
+    from flashdeconv_amd import FlashDeconv
+    from flashdeconv_amd.utils.graph import build_knn_graph
+    grids = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
+    coords = np.stack([g.ravel() for g in grids], axis=1)
+    rs = np.random.RandomState(dim)
+    coords = np.ascontiguousarray(coords[rs.permutation(len(coords))])
+    n = len(coords)
+    want = orc.knn_graph_kdtree(coords, 6)
+    Y, X, _, _ = datagen.count_like(n, 300, 4, 0.1, 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m = FlashDeconv(sketch_dim=32, max_iter=12).fit(Y, X, coords)
+    A = m.adjacency_
+    assert m.info_["knn_ties"] > 0
+    assert np.array_equal(A.indptr, want.indptr) and np.array_equal(A.indices, want.indices)
+    ref = orc.fit(Y, X, coords, sketch_dim=32, preprocess_method="log_cpm", n_hvg=2000, graph="kdtree", engine="c", max_iter=12)
+    assert m.info_["n_iterations"] == ref["info"]["n_iterations"]
+    assert rel_fro(m.proportions_, ref["proportions"]) < 1e-8
+    B = build_knn_graph(coords, k=6, ties="ckdtree")
+    assert np.array_equal(B.indptr, want.indptr) and np.array_equal(B.indices, want.indices)
+
+
 def _lattice_case(name, **kw):
     from flashdeconv_amd import FlashDeconv
     g = load_golden("lattice.npz")

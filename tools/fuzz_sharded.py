@@ -66,11 +66,13 @@ for trial in range(int(os.environ.get("TRIALS", 30))):
         ref = FlashDeconv(sketch_dim=d, max_iter=it, tol=1e-9, preprocess=pre).fit(Y.astype(dt), X, coords)
         cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
         Yt = torch.from_numpy(Y.astype(dt)).to(dev)
-        build = str(rs.choice(["replicated", "band"]))
+        build = str(rs.choice(["replicated", "band", "pipeline"]))
         fulls = band_fulls(cd, n, W) if build == "band" else None
-        tag["build"] = build if fulls is not None or build == "replicated" else "band->far walk, replicated"
+        locs = T._pipeline_locals(torch, cd, W) if build == "pipeline" else None      # the queued shard pipeline (fdx_graph_shard_knn_dev)
+        tag["build"] = build if (fulls is not None or locs is not None or build == "replicated") else build + "->far walk / empty rank, replicated"
         print("trial", tag, flush=True)
-        full, shards = T._native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM if pre == "log_cpm" else _lib.PRE_RAW, fulls=fulls)
+        full, shards = T._native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_LOG_CPM if pre == "log_cpm" else _lib.PRE_RAW, fulls=fulls,
+                                        locals_=locs)
         lam, rho_eff = ref.lambda_used_, 0.01 * diag_mean(shards[0]["XtX_h"])
         results = T._run_native_threads(torch, shards, K, lam, rho_eff, 1e-9, it)
         beta = T._assemble(torch, shards, results, n, K).cpu().numpy()
