@@ -82,6 +82,7 @@ struct LocalWorld {
     int arrived = 0;
     long long generation = 0;
     std::vector<const void*> ptr;                   // mailbox: one pointer per rank
+    std::vector<const void*> sptr;                  // mailbox: each rank's convergence slots of the iteration (or nullptr)
     std::vector<std::vector<long long>> off;        // mailbox: per rank, element offsets per destination (W + 1)
     std::vector<std::vector<unsigned long long>> host;   // mailbox for the reductions
     bool aborted = false;                           // a rank left its loop on an error: nobody waits for it any more
@@ -140,8 +141,15 @@ __global__ void halo_pack_kernel(const double* __restrict__ beta, long long ld, 
 }
 
 __global__ void halo_unpack_kernel(double* __restrict__ beta, long long ld, int K, long long n_own, const int* __restrict__ recv_off,
-                                   int world, int total, const double* __restrict__ in) {
+                                   int world, int total, const double* __restrict__ in, unsigned long long* __restrict__ stat_local,
+                                   const unsigned long long* __restrict__ stat_recv, int rank) {
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (stat_local && t < 128) {        // the peers' convergence slots of this iteration, folded into ours (bit patterns of doubles >= 0)
+        unsigned long long v = stat_local[t];
+        for (int r = 0; r < world; ++r)
+            if (r != rank) v = max(v, stat_recv[(size_t)r * 128 + t]);
+        stat_local[t] = v;
+    }
     if (t >= (long long)total * K) return;
     const int k = (int)(t / total), j = (int)(t - (long long)k * total);
     int r = 0;
@@ -176,8 +184,11 @@ int build_tile_lists(const fdx_graph& g, hipStream_t st) {
 
 // ---- transports ---------------------------------------------------------------------------------------------------------------
 // send / recv staging blocks per peer, all on stream `st`
+// stat_send != NULL: every rank also hands its 128 convergence slots of the iteration to EVERY peer inside the same group
+// (stat_recv: W blocks of 128 words, block r from rank r) - the halo unpack kernel folds them, and the separate all-reduce(max) of
+// the iteration is gone: one RCCL group per iteration instead of a group and a collective
 int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, double* recv, const std::vector<int>& recv_off, int K,
-             hipStream_t st) {
+             hipStream_t st, const unsigned long long* stat_send = nullptr, unsigned long long* stat_recv = nullptr) {
     const int W = c->world;
     if (c->loopback) {       // what arrives is this rank's own staging (as many values as both sides have): timing only
         const long long ns = send_off.back(), nr = recv_off.back();
@@ -198,6 +209,12 @@ int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, 
             if (r != c->rank && ns > 0)
                 FDX_NCCL(api->Send(send + (size_t)K * send_off[(size_t)r], (size_t)K * ns, ncclDouble, r, c->nccl, st));
         }
+        if (stat_send && stat_recv) {
+            for (int r = 0; r < W; ++r)
+                if (r != c->rank) FDX_NCCL(api->Recv(stat_recv + (size_t)r * 128, 128, ncclUint64, r, c->nccl, st));
+            for (int r = 0; r < W; ++r)
+                if (r != c->rank) FDX_NCCL(api->Send(stat_send, 128, ncclUint64, r, c->nccl, st));
+        }
         FDX_NCCL(api->GroupEnd());
         return 0;
     }
@@ -207,6 +224,7 @@ int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, 
         {
             std::lock_guard<std::mutex> lk(w.mu);
             w.ptr[(size_t)c->rank] = send;
+            w.sptr[(size_t)c->rank] = stat_send;
             w.off[(size_t)c->rank].assign(send_off.begin(), send_off.end());
         }
         FDX_REQUIRE(w.barrier(), "sharded solve: another rank of this in-process world failed; the world stays aborted - create a new fdx_local_world");
@@ -218,6 +236,12 @@ int exchange(fdx_comm* c, const double* send, const std::vector<int>& send_off, 
             FDX_REQUIRE(ns == nr, "sharded solve: send and receive lists of two ranks disagree");
             FDX_HIP(hipMemcpyAsync(recv + (size_t)K * recv_off[(size_t)q], src, (size_t)K * nr * 8, hipMemcpyDeviceToDevice, st));
         }
+        if (stat_send && stat_recv)
+            for (int q = 0; q < W; ++q) {
+                if (q == c->rank) continue;
+                FDX_REQUIRE(w.sptr[(size_t)q] != nullptr, "sharded solve: the ranks disagree on how the convergence slots travel");
+                FDX_HIP(hipMemcpyAsync(stat_recv + (size_t)q * 128, w.sptr[(size_t)q], 128 * 8, hipMemcpyDeviceToDevice, st));
+            }
         FDX_HIP(hipStreamSynchronize(st));
         FDX_REQUIRE(w.barrier(), "sharded solve: another rank of this in-process world failed; the world stays aborted - create a new fdx_local_world");   // nobody overwrites its staging before all have copied
         return 0;
@@ -315,6 +339,7 @@ int fdx_local_world_create(int32_t world, fdx_local_world** out) {
     auto* w = new fdx_local_world();
     w->w.W = world;
     w->w.ptr.assign((size_t)world, nullptr);
+    w->w.sptr.assign((size_t)world, nullptr);
     w->w.off.assign((size_t)world, {});
     w->w.host.assign((size_t)world, {});
     *out = w;
@@ -528,7 +553,7 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     const int total_send = g->send_off.back(), total_recv = g->recv_off.back();
     FDX_TRY(comm_streams(c));
 
-    DevBuf stats, send_buf, recv_buf, soff, roff, sweep_scratch;
+    DevBuf stats, send_buf, recv_buf, soff, roff, sweep_scratch, stat_recv;
     size_t scratch_ld = 0;
     if (sweep_uses_lds(K)) {                          // as in solver_run: XtX with its rows padded to 16 for the LDS-resident sweep
         FDX_TRY(sweep_scratch.alloc(sweep_lds_pad_doubles(K) * sizeof(double)));
@@ -544,6 +569,7 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     double* const relchg_p = reinterpret_cast<double*>(static_cast<char*>(stats.p) + stats_bytes);
     FDX_TRY(send_buf.alloc((size_t)std::max(total_send, 1) * K * 8));
     FDX_TRY(recv_buf.alloc((size_t)std::max(total_recv, 1) * K * 8));
+    FDX_TRY(stat_recv.alloc((size_t)W * 128 * 8));
     FDX_HIP(hipMemsetAsync(stats.p, 0, stats.bytes, st));
     if (c->loopback) FDX_HIP(hipMemsetAsync(recv_buf.p, 0, recv_buf.bytes, st));   // part of it is never written by the self-copy
     // per-peer offsets of the staging blocks: a graph from the queued shard build (fdx_graph_shard_knn_dev) has them on the device
@@ -581,6 +607,11 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     // one - 125k-spot shards: 36 + 34 us against 36 - and the interior sweep is too short to hide anything behind
     const int split_min_tiles = getenv("FDX_SPLIT_MIN_TILES") ? atoi(getenv("FDX_SPLIT_MIN_TILES")) : 1536;
     if (split && g->n_tiles < split_min_tiles) split = false;
+    // every rank must take the same route for the convergence slots: they ride with the halo only when NO rank of the job can
+    // split (shards are equal to within one tile: the largest has at most ceil(tiles / W) + 1 of them)
+    const long long tiles_max = g->world_n > 0 ? ((g->world_n + 255) / 256 + W - 1) / W + 1 : (1LL << 40);
+    const bool piggy_ok = W > 1 && !c->loopback && (c->nccl || c->local) && !getenv("FDX_STATS_ALLREDUCE") &&
+                          (tiles_max < split_min_tiles || getenv("FDX_NO_OVERLAP") != nullptr);
     if (split) {
         FDX_TRY(build_tile_lists(*g, st));          // no-op for a graph of the queued shard build: its lists were made on the device
         split = g->n_tiles_boundary > 0 && g->n_tiles_interior > 0;
@@ -630,18 +661,25 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
             sx = c->side;
             FDX_HIP(hipStreamWaitEvent(sx, c->ev_packed, 0));
         }
-        if (c->local || total_send > 0 || total_recv > 0)      // the in-process transport meets at barriers
-            FDX_TRY(exchange(c, send_buf.as<double>(), g->send_off, recv_buf.as<double>(), g->recv_off, K, sx));
-        if (total_recv > 0) {
-            hipLaunchKernelGGL(halo_unpack_kernel, dim3(ceil_div((long long)total_recv * K, 256)), dim3(256), 0, sx, a.beta_out, (long long)ld, K,
-                               (long long)g->n, roff_p, W, total_recv, recv_buf.as<double>());
+        // Without the boundary / interior split the iteration's convergence slots are complete when the rows are sent: they ride in
+        // the same group to every peer and the unpack kernel folds them - no all-reduce.  (With the split the interior tiles are
+        // still being swept then: large shards keep the all-reduce, whose latency is noise beside their sweeps.)
+        const bool piggy = piggy_ok && !split;
+        unsigned long long* st_it = a.stats + (size_t)it * 128;
+        if (c->local || total_send > 0 || total_recv > 0 || piggy)      // the in-process transport meets at barriers
+            FDX_TRY(exchange(c, send_buf.as<double>(), g->send_off, recv_buf.as<double>(), g->recv_off, K, sx, piggy ? st_it : nullptr,
+                             piggy ? stat_recv.as<unsigned long long>() : nullptr));
+        if (total_recv > 0 || piggy) {
+            hipLaunchKernelGGL(halo_unpack_kernel, dim3(std::max(1, ceil_div((long long)total_recv * K, 256))), dim3(256), 0, sx, a.beta_out,
+                               (long long)ld, K, (long long)g->n, roff_p, W, total_recv, recv_buf.as<double>(), piggy ? st_it : nullptr,
+                               piggy ? stat_recv.as<unsigned long long>() : nullptr, c->rank);
             FDX_CHECK_LAUNCH();
         }
         if (split) {
             FDX_HIP(hipEventRecord(c->ev_halo, sx));
             FDX_HIP(hipStreamWaitEvent(st, c->ev_halo, 0));
         }
-        FDX_TRY(allreduce(c, a.stats + (size_t)it * 128, 128, true, st));
+        if (!piggy) FDX_TRY(allreduce(c, a.stats + (size_t)it * 128, 128, true, st));
         // a rank without rows launches no sweep, and it is sweep it + 1 that folds the slots of sweep it into rel_change[it]:
         // fold here, or this rank reads 0.0, calls the solve converged after its first chunk and leaves the others waiting
         if (g->n == 0 && !last_of_chunk) FDX_TRY(launch_bcd_fold_last(a.stats, a.rel_change, it, st));

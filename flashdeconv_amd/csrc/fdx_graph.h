@@ -38,6 +38,7 @@ struct fdx_graph {
     // rows recv_off[r] .. recv_off[r+1] come from rank r).  send_idx[send_off[r] .. send_off[r+1]) are the own local
     // indices rank r needs from this rank, in the order rank r stores them.
     long long global_lo = 0;
+    long long world_n = 0;          // spots of the whole job (bounds[n_ranks]); 0: unknown
     fdx::DevBuf halo_global, send_idx;
     std::vector<int> send_off, recv_off;
     // tiles of the sweep that hold a row some peer needs (boundary) and the rest (interior), built on first use by the

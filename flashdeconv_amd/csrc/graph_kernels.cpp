@@ -1961,6 +1961,7 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
     loc->n = n_own;
     loc->identity_order = false;
     loc->global_lo = lo;
+    loc->world_n = bounds[n_ranks];
     loc->n_slices = (int)((n_own + 63) / 64);
     // halo = sorted unique set of the neighbour positions outside [lo, hi) that the own rows reference
     DevBuf tmp, counter, ext, ext_sorted, n_uniq, d_bounds, skeys, skeys_sorted, skeys_uniq;
@@ -2432,6 +2433,7 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     loc->n = n_own;
     loc->identity_order = false;
     loc->global_lo = lo;
+    loc->world_n = n;
     loc->n_tiles = nblk;
     loc->shard_world = n_ranks;
     FDX_TRY(loc->slice_off.alloc((size_t)(loc->n_slices + 1) * 4));
