@@ -679,6 +679,9 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     // Measured on the same shard and NOT the default: the ring of three stage buffers on top of it (FDX_TILE_NST=3: 8 blocks of
     // 672, 8.94 ms - more blocks, more lockstep padding, and the consumers, not the bytes in flight, set the block period) and the
     // flat schedule (FDX_TILE_FLAT=1, see the kernel: 9.85 ms against 8.69 in the same process).
+    // (the three alternatives - FDX_TILE_NO_WG, FDX_TILE_NST=3, FDX_TILE_FLAT - were all measured slower and are compiled only
+    // into experiment builds, `make EXTRA=-DFDX_TILE_EXPERIMENT`: the shipped library has one layout per shape)
+#ifdef FDX_TILE_EXPERIMENT
     const bool wg = cfg.wide && mode == FDX_PRE_RAW && cfg.NWL > 0 && !getenv("FDX_TILE_NO_WG");
     int NST = 2;
     if (mode == FDX_PRE_RAW && cfg.NWL > 0) {
@@ -686,6 +689,11 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
         NST = (e && atoi(e) == 3) ? 3 : 2;
     }
     const bool flat = wg && getenv("FDX_TILE_FLAT") && cfg.JW <= 24;
+#else
+    const bool wg = cfg.wide && mode == FDX_PRE_RAW && cfg.NWL > 0;
+    const int NST = 2;
+    const bool flat = false;
+#endif
     const int key = key0 + (NST == 3 ? 28 : 0) + (cfg.wide && mode == FDX_PRE_RAW && cfg.NWL > 0 && !wg ? 56 : 0) + (flat ? 112 : 0);
     static_assert(SketchPlan::kTileKeys == 224, "key space of the schedules");
     std::lock_guard<std::mutex> lock(sp.tile_mu);
@@ -838,10 +846,18 @@ static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hip
 
 template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_wide(const TileLaunch& L, size_t lds, int grid, hipStream_t st) {
-    const void* kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true>;
+    const void* kern = nullptr;
     if constexpr (MODE == FDX_PRE_RAW && NWL > 0) {
+#ifdef FDX_TILE_EXPERIMENT
+        kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true>;
         if (L.a.WB) kern = L.flat ? (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true, 0, true, true>
                                   : (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true, 0, true>;
+#else
+        if (!L.a.WB || L.flat) return fail(FDX_ERR_INVALID, "tile sketch: this layout is compiled into experiment builds only");
+        kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true, 0, true>;
+#endif
+    } else {
+        kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true>;
     }
     if constexpr (MODE != FDX_PRE_RAW && std::is_same<T, float>::value) {
         if (tile_logv() != 0) kern = (const void*)tile_sketch_kernel<T, MODE, NWC, NWL, JW, 4, true, 2>;
@@ -921,6 +937,24 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     }
     if (dtype == FDX_F32) return launch_tile_mode<float>(L, mode, t->NWC, t->TT, t->lds, grid, st);
     return launch_tile_mode<double>(L, mode, t->NWC, t->TT, t->lds, grid, st);
+}
+
+// The one-kernel sketch -> H stage: the tile kernel for every shape it takes (a CountSketch with d <= 1056, K <= 64, rows whole
+// 16-byte vectors); everything else runs the two-kernel path (sketch_rows_* + xyt_split), also selected by FDX_NO_FUSED=1.
+// (The round-1 atomic fused kernel that used to serve odd row lengths behind this pair was slower than the two-kernel path it
+// replaced there and is gone.)
+bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan,
+                              hipStream_t st) {
+    if (getenv("FDX_NO_FUSED")) return false;
+    return tile_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st);
+}
+
+int launch_sketch_contract(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
+                           const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
+                           hipStream_t st) {
+    if (n <= 0) return 0;
+    if (!tile_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st)) return fail(FDX_ERR_INVALID, "sketch -> H: no one-kernel form for this shape");
+    return launch_tile_sketch(Y, dtype, ldy, row_map, n, G, d, mode, plan, Xs, K, H, ldh, row_sumsq, st);
 }
 
 }  // namespace fdx
