@@ -9,13 +9,23 @@
 // HBM traffic is proportional to the stored entries (8 bytes each for f32 data + int32 column), not to N x G, and the
 // log1p work shrinks with it - on ~5-10 % dense count matrices that is the 10x the dense kernel cannot reach.
 //
-// Sketch mapping: one wavefront = one spot row.  The row's entries are read 64 at a time (coalesced), every lane looks
-// its column up in a 16-byte per-gene table {weight, bucket} that covers ALL G_all columns (bucket -1 = gene not
-// selected; the table is L2 resident: 16 B x 30k genes = 480 KB), applies the transform and adds weight * f(y) into
-// the wave's private d-entry accumulator in LDS with ds_add_f64.  Several entries of one row can hit the same bucket,
-// so the order of those additions is the hardware's; the reference's scipy product carries the same freedom, and
-// the 1e-4 parity budget is 12 orders of magnitude above it.  The finished row is written as one coalesced d*8-byte row
-// of Y_sketch exactly like the dense kernel, so the H contraction downstream is shared.
+// Kernels of this file:
+//   sketch_csr_contract_kernel   DEFAULT sketch -> H for CSR rows (d <= 1024, K <= 64): a 16-wave workgroup takes 16 consecutive
+//                                spots; wave w walks the row of spot w ONCE (non-temporal stream; a G_all-bit bitmap in LDS says
+//                                which columns are selected; the library-size pass compacts the selected entries into a per-wave
+//                                LDS buffer, the sketch pass reads them from there), gathers {weight, bucket} for selected entries
+//                                only (16-byte slots of an L2-resident table) and adds weight * f(y) into the spot's accumulator
+//                                row in LDS (ds_add_f64); the 16 x d block is then the B operand of v_mfma_f64_16x16x4_f64 against
+//                                register-resident X_sketch slices - H is stored, Y_sketch never exists.
+//   sketch_csr_kernel            the same walk, one wave = one row, writing Y_sketch (d * 8 bytes per row) for the shapes the fused
+//                                kernel does not take; the contraction is then xyt_split_kernel's.
+//   csr_row_scale_kernel, csr_moments_cursor_kernel, csr_fold_moments_kernel
+//                                gene statistics of utils/genes.py:52-83: per-row 1e4 / library size, then per-gene sums of
+//                                z = log1p(scaled) and z^2 in LDS tiles of 4096 genes (a row stripe per workgroup, a cursor per
+//                                row through its sorted columns, 256-entry steps shrinking to 64 near a tile's end), folded in
+//                                stripe order.  csr_moments_tiled_kernel: rows whose columns are not sorted.
+// Several entries of one row can hit the same bucket, so the order of those additions is the hardware's; the reference's scipy
+// product carries the same freedom, and the 1e-4 parity budget is 12 orders of magnitude above it.
 #include <algorithm>
 #include <cstdlib>
 
