@@ -236,6 +236,10 @@ class FlashDeconv:
             raise ValueError(f"coords must be 2D with at least 1 coordinate dimension, got shape {tuple(coords.shape)}")
         from ..utils.graph import check_coord_dims
         check_coord_dims(int(coords.shape[0]), int(coords.shape[1]), self.spatial_method == "knn")
+        if self.spatial_method == "knn" and min(int(self.k_neighbors), int(coords.shape[0]) - 1) > 63:
+            # the reference takes any k (utils/graph.py:51); the device's k-NN lists hold at most 64 entries per spot (self included)
+            raise ValueError(f"k_neighbors = {self.k_neighbors}: at most 63 neighbours per spot on this backend "
+                             "(spatial_method='radius' builds denser graphs)")
         _lib.require_gpu()
         lib = _lib.load()
         log = print if self.verbose else (lambda *a, **k: None)

@@ -557,6 +557,11 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     (void)hipEventElapsedTime(&t_span, from_build ? g->begin_event : tm.ev[0], tm.ev[4]);
     info->prologue_ms = t_pro;
     info->span_ms = t_span;
+    if (from_build) {       // the build's start event has served its one fit: a later fit on the same handle starts its own clock
+        (void)hipEventDestroy(g->begin_event);
+        g->begin_event = nullptr;
+        g->begin_stream = nullptr;
+    }
     info->solve_ms = t_solve;
     info->finish_ms = tm.ms(3, 4);
     info->total_ms = tm.ms(0, 4);
