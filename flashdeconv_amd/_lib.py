@@ -152,6 +152,7 @@ SIGNATURES = {
     "fdx_comm_init_loopback": (c_int, [c_i32, c_i32, ctypes.POINTER(c_void_p)]),
     "fdx_comm_destroy": (c_int, [c_void_p]),
     "fdx_comm_info": (c_int, [c_void_p, p_i32, p_i32]),
+    "fdx_comm_rccl_count": (c_int, [c_void_p, p_i32]),
     "fdx_comm_allreduce_sum_dev": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "fdx_sharded_solve_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_double, c_double, c_double, c_i32,
                                       c_void_p, c_void_p, c_i64, ctypes.POINTER(SolveInfo), p_double, p_i32, c_void_p]),

@@ -45,6 +45,7 @@ struct RcclApi {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     bool ok = false;
 };
 
@@ -60,7 +61,7 @@ const RcclApi* rccl() {
         if (!h) return;
 #define FDX_SYM(f) api.f = reinterpret_cast<decltype(api.f)>(dlsym(h, "nccl" #f))
         FDX_SYM(GetUniqueId); FDX_SYM(CommInitRank); FDX_SYM(CommDestroy); FDX_SYM(GroupStart); FDX_SYM(GroupEnd);
-        FDX_SYM(Send); FDX_SYM(Recv); FDX_SYM(AllReduce); FDX_SYM(GetErrorString);
+        FDX_SYM(Send); FDX_SYM(Recv); FDX_SYM(AllReduce); FDX_SYM(GetErrorString); FDX_SYM(CommCount);
 #undef FDX_SYM
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv &&
                  api.AllReduce && api.GetErrorString;
@@ -386,6 +387,17 @@ int fdx_comm_info(const fdx_comm* c, int32_t* rank, int32_t* world) {
     FDX_REQUIRE(c != nullptr, "fdx_comm_info: null communicator");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
+    return 0;
+}
+
+int fdx_comm_rccl_count(const fdx_comm* c, int32_t* count) {
+    FDX_REQUIRE(c != nullptr && count != nullptr, "fdx_comm_rccl_count: null argument");
+    *count = 0;                                        // not an RCCL communicator (in-process / loopback transport)
+    if (c->nccl && rccl() && rccl()->CommCount) {
+        int n = 0;
+        FDX_NCCL(rccl()->CommCount(c->nccl, &n));
+        *count = n;
+    }
     return 0;
 }
 

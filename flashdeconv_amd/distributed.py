@@ -341,9 +341,30 @@ class ShardedFlashDeconv:
         dist.broadcast(t, src=dist.get_global_rank(self.comm.group, 0) if self.comm.group is not None else 0, group=self.comm.group)
         ident = t.cpu().numpy()
         h = ctypes.c_void_p()
-        _lib.check(lib.fdx_comm_init(ident.ctypes.data, self.comm.rank, self.comm.world, ctypes.byref(h)))
+        try:
+            _lib.check(lib.fdx_comm_init(ident.ctypes.data, self.comm.rank, self.comm.world, ctypes.byref(h)))
+        except _lib.FdxError as e:
+            # LOUD fallback: the Python exchange loop over torch.distributed (same kernels, same bits, slower per iteration)
+            import warnings
+            self.native_error_ = str(e)
+            os.environ["FDX_PY_LOOP"] = "1"          # do not try again in this process
+            warnings.warn(f"libfdx could not create its own RCCL communicator ({e}); the sharded fit falls back to the Python "
+                          "exchange loop over torch.distributed", RuntimeWarning, stacklevel=2)
+            return None
         self._native = h
         return self._native
+
+    def comm_report(self):
+        """What ran: for bench.py's result line and for debugging a first multi-GPU contact."""
+        import torch
+        rep = {"rank": int(self.comm.rank), "device": int(torch.cuda.current_device()), "plan_route": self.plan_route_,
+               "loop": "native" if self._native is not None else "python", "rccl_ranks": None,
+               "native_comm_error": getattr(self, "native_error_", None)}
+        if self._native is not None:
+            c = ctypes.c_int32(0)
+            _lib.check(_lib.load().fdx_comm_rccl_count(self._native, ctypes.byref(c)))
+            rep["rccl_ranks"] = int(c.value)
+        return rep
 
     def close(self):
         if self._native is not None:
@@ -1077,6 +1098,8 @@ def bench_main(a, rank, world, local_rank):
         roof = {"bound": "hbm", "kernel": bench.sweep_kernel_name(K), "achieved": round(ach, 1),
                 "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / bench.HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": int(alg), "ms_per_launch": round(sweep_ms, 4), "rank": 0}
+    reports = [None] * world
+    dist.all_gather_object(reports, model.comm_report())
     dist.destroy_process_group()
     ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in the C stdio buffer: get it out BEFORE the result line
     if rank == 0:
@@ -1089,4 +1112,9 @@ def bench_main(a, rank, world, local_rank):
             "config": {"workload": f"{n} spots x {G} genes x {K} types, sketch_dim {d}, k_neighbors 6, gaussian/raw family, "
                                    f"Y float32 in HBM, spots sharded over {world} GPUs (Morton ranges, RCCL halo exchange)",
                        "n_iterations": n_it, "converged": conv},
-            "roofline": roof, "cpu_baseline": None}), flush=True)
+            "roofline": roof, "cpu_baseline": None,
+            # what actually ran on every rank: the ranks RCCL itself reports for libfdx's communicator (None: not created), the
+            # device, the route of the plan, native or Python iteration loop
+            "rccl_ranks": reports[0]["rccl_ranks"], "loop": sorted({r["loop"] for r in reports}),
+            "native_comm_error": next((r["native_comm_error"] for r in reports if r["native_comm_error"]), None),
+            "ranks": reports}), flush=True)

@@ -420,6 +420,8 @@ int fdx_local_world_destroy(fdx_local_world* w);
 int fdx_comm_init_local(fdx_local_world* w, int32_t rank, fdx_comm** out);
 int fdx_comm_destroy(fdx_comm* comm);
 int fdx_comm_info(const fdx_comm* comm, int32_t* rank, int32_t* world);
+/* Ranks RCCL itself reports for this communicator (ncclCommCount); 0 for the in-process / loopback transports. */
+int fdx_comm_rccl_count(const fdx_comm* comm, int32_t* count);
 /* In-place sum over the ranks of `count` device doubles (YtY, objective partials, nnz, per-gene moment sums). */
 int fdx_comm_allreduce_sum_dev(fdx_comm* comm, double* buf_dev, int32_t count, void* stream);
 /* One rank's WHOLE fit behind a plan queued by fdx_graph_shard_knn_dev (or any local graph): X_sketch / XtX, sketch -> H of the
