@@ -178,6 +178,7 @@ SIGNATURES = {
     "fdx_ckdtree_knn_rows": (c_int, [p_double, c_i64, c_i32, c_i32, p_i64, c_i64, c_void_p]),
     "fdx_graph_plan_order_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdx_graph_plan_lists_replaced": (c_int, [c_void_p]),
+    "fdx_graph_plan_set_lists_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "fdx_bcd_solve": (c_int, [c_void_p, p_double, p_double, c_i64, c_i32, c_i32, c_double, c_double, c_i32, c_double,
                               c_i32, p_double, p_double, p_double, ctypes.POINTER(SolveInfo)]),
 }

@@ -89,34 +89,23 @@ def reference_tie_graph(c_ptr, coords_host, n, dim, k):
     untiled upload).  Reference: utils/graph.py:60-81."""
     from ..utils.graph import ckdtree_knn_lists
     lib = _lib.load()
+    tr = [("start", time.perf_counter())] if os.environ.get("FDX_TRACE_HOST") else None
+
+    def mark(name):
+        if tr is not None:
+            tr.append((name, time.perf_counter()))
     kk = min(int(k), n - 1) + 1
     nbr, cnt = _DeviceBuffer(n * kk * 4), _DeviceBuffer(n * 4)
-    perm_d, rank_d = _DeviceBuffer(n * 4), _DeviceBuffer(n * 4)
     plan, h = ctypes.c_void_p(), ctypes.c_void_p()
     try:
         _lib.check(lib.fdx_graph_knn_lists_dev(c_ptr, n, dim, int(k), 0, n, nbr.ptr, cnt.ptr, None, ctypes.byref(plan)))
         try:
-            _lib.check(lib.fdx_graph_plan_order_dev(plan, perm_d.ptr, rank_d.ptr, None))
-            rank = rank_d.to_host((n,), dtype=np.int32)
+            mark("device lists + order")
             lists = ckdtree_knn_lists(coords_host, k)                       # (n, kk) caller ids, nearest first, self included
-            own = np.arange(n, dtype=lists.dtype)
-            if kk >= 2 and bool((lists[:, 0] == own).all()) and bool((lists[:, 1:] >= 0).all()) and bool((lists[:, 1:] != own[:, None]).all()):
-                keep_n = np.full(n, kk - 1, dtype=np.int32)                    # the usual case: self is the first entry, all others real
-                comp = np.concatenate([lists[:, 1:], np.full((n, 1), -1, dtype=lists.dtype)], axis=1)
-            else:                                                              # duplicates of a point can push self out of its own list
-                keep = (lists >= 0) & (lists != own[:, None])                  # utils/graph.py:70-74
-                order = np.argsort(~keep, axis=1, kind="stable")
-                comp = np.take_along_axis(lists, order, axis=1)
-                keep_n = keep.sum(axis=1).astype(np.int32)
-                comp[np.arange(kk)[None, :] >= keep_n[:, None]] = -1
-            pos = np.where(comp >= 0, rank[np.maximum(comp, 0)], -1).astype(np.int32)
-            nbr_h = np.empty((n, kk), dtype=np.int32)
-            cnt_h = np.empty(n, dtype=np.int32)
-            nbr_h[rank] = pos                                                  # row of caller id i sits at solver position rank[i]
-            cnt_h[rank] = keep_n
-            _lib.check(lib.fdx_memcpy_h2d(nbr.ptr, nbr_h.ctypes.data, nbr_h.nbytes, None))
-            _lib.check(lib.fdx_memcpy_h2d(cnt.ptr, cnt_h.ctypes.data, cnt_h.nbytes, None))
-            _lib.check(lib.fdx_graph_plan_lists_replaced(plan))
+            mark("host tree: build + queries")
+            # to solver positions, self dropped, at the rows' positions: on the device (numpy took 55 ms per million spots for this)
+            _lib.check(lib.fdx_graph_plan_set_lists_dev(plan, lists.ctypes.data, None, n, nbr.ptr, cnt.ptr, None))
+            mark("lists to positions + upload")
         except Exception:
             dead = ctypes.c_void_p()                                           # the plan owns device buffers: consume it
             lib.fdx_graph_from_knn_lists_dev(plan, nbr.ptr, cnt.ptr, 0, 0, None, ctypes.byref(dead))
@@ -124,9 +113,13 @@ def reference_tie_graph(c_ptr, coords_host, n, dim, k):
                 _lib.Graph(dead.value).close()
             raise
         _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, nbr.ptr, cnt.ptr, 0, n, None, ctypes.byref(h)))
+        mark("symmetrise + ELL + tiles (device)")
+        if tr is not None:
+            print("[fdx-host] reference_tie_graph: " + ", ".join(f"{b[0]} {1e3 * (b[1] - a[1]):.1f} ms" for a, b in zip(tr[:-1], tr[1:])),
+                  file=sys.stderr)
         return _lib.Graph(h.value)
     finally:
-        for b in (nbr, cnt, perm_d, rank_d):
+        for b in (nbr, cnt):
             b.free()
 
 

@@ -87,6 +87,13 @@ int fdx_graph_plan_order_dev(const fdx_graph_plan* plan, int32_t* perm_out_dev, 
     return graph_plan_order(plan, perm_out_dev, rank_out_dev, (hipStream_t)stream);
 }
 
+int fdx_graph_plan_set_lists_dev(fdx_graph_plan* plan, const int64_t* ids_host, const int64_t* rows_host, int64_t n_rows,
+                                 int32_t* nbr_dev, int32_t* cnt_dev, void* stream) {
+    PoolStream pool_stream((hipStream_t)stream);
+    FDX_REQUIRE(plan && nbr_dev && cnt_dev && (n_rows == 0 || ids_host), "fdx_graph_plan_set_lists_dev: null argument");
+    return graph_plan_set_lists(plan, (const long long*)ids_host, (const long long*)rows_host, n_rows, nbr_dev, cnt_dev, (hipStream_t)stream);
+}
+
 int fdx_graph_plan_lists_replaced(fdx_graph_plan* plan) {
     FDX_REQUIRE(plan != nullptr, "fdx_graph_plan_lists_replaced: null plan");
     return graph_plan_lists_replaced(plan);

@@ -17,6 +17,9 @@ int graph_from_knn_lists(fdx_graph_plan* plan, const int* nbr, const int* cnt, l
 void graph_plan_destroy(fdx_graph_plan* plan);
 int graph_plan_kk(const fdx_graph_plan* plan);
 int graph_plan_lists_replaced(fdx_graph_plan* plan);   // nbr / cnt were overwritten by the caller: forget the counts drawn for the kernel's own lists
+// replace list rows by the answers of a k-nearest query in caller ids (host arrays): mapped to solver positions on the device
+int graph_plan_set_lists(fdx_graph_plan* plan, const long long* ids_host, const long long* rows_host, long long n_rows, int* nbr,
+                         int* cnt, hipStream_t st);
 int graph_plan_order(const fdx_graph_plan* plan, int* d_perm_out, int* d_rank_out, hipStream_t st);   // device copies of perm / rank (either may be NULL)
 // rows [lo, hi) (solver positions) of the radius graph, the others left empty; [0, n) = the whole graph
 int graph_build_radius(const double* d_coords, long long n, int dim, double radius, long long lo, long long hi, fdx_graph* g,

@@ -66,7 +66,14 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const double* __restr
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (dim == 2 && ((unsigned long long)coords & 15ULL) == 0ULL) {      // one 16-byte load per point
         const double2* c2 = reinterpret_cast<const double2*>(coords);
-        for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long stride = (long long)gridDim.x * 256;
+        long long i = blockIdx.x * 256LL + threadIdx.x;
+        for (; i + 3 * stride < n; i += 4 * stride) {          // four loads in flight per thread
+            const double2 a = c2[i], b = c2[i + stride], c = c2[i + 2 * stride], d = c2[i + 3 * stride];
+            mn[0] = fmin(fmin(mn[0], a.x), fmin(fmin(b.x, c.x), d.x)); mx[0] = fmax(fmax(mx[0], a.x), fmax(fmax(b.x, c.x), d.x));
+            mn[1] = fmin(fmin(mn[1], a.y), fmin(fmin(b.y, c.y), d.y)); mx[1] = fmax(fmax(mx[1], a.y), fmax(fmax(b.y, c.y), d.y));
+        }
+        for (; i < n; i += stride) {
             const double2 v = c2[i];
             mn[0] = fmin(mn[0], v.x); mx[0] = fmax(mx[0], v.x);
             mn[1] = fmin(mn[1], v.y); mx[1] = fmax(mx[1], v.y);
@@ -1123,9 +1130,9 @@ struct BboxJob {
 static int bbox_begin(const double* d_coords, long long n, int dim, hipStream_t st, BboxJob* job) {
     job->coords = d_coords; job->n = n; job->dim = dim;
     FDX_HIP(hipGetDevice(&job->dev));
-    // one point per thread up to 4M points (a thread that loops issues its loads one after the other: 1024 blocks took 37 us for
-    // the 16 MB of a million 2-D points)
-    const int nblk = (int)std::min<long long>(16384, (n + 255) / 256);
+    // (256 to 16384 blocks, one to sixteen points per thread, four loads in flight or one: 33-60 us for the 16 MB of a million 2-D
+    // points whatever the shape - the kernel's time is not its loop; 512 blocks measured best)
+    const int nblk = (int)std::min<long long>(getenv("FDX_BBOX_BLOCKS") ? atoi(getenv("FDX_BBOX_BLOCKS")) : 512, (n + 255) / 256);
     FDX_TRY(job->part.alloc((size_t)nblk * 6 * sizeof(double)));
     job->host = (double*)pinned_block_get();
     FDX_REQUIRE(job->host != nullptr, "graph: pinned host block");
@@ -1666,6 +1673,44 @@ int graph_plan_lists_replaced(fdx_graph_plan* plan) {
     }
     return 0;
 }
+// ids (n_rows, kk): caller ids as a k-nearest query returns them (the point itself usually among them, -1 padded); row r answers for
+// caller id rows[r] (rows NULL: r itself).  Written where the symmetrisation expects a row's list: at the row's solver position,
+// as solver positions, the point itself dropped (utils/graph.py:70-74), compacted, -1 padded.
+__global__ __launch_bounds__(256) void lists_from_ids_kernel(const long long* __restrict__ ids, const long long* __restrict__ rows,
+                                                            long long n_rows, int kk, const int* __restrict__ rank,
+                                                            int* __restrict__ nbr, int* __restrict__ cnt) {
+    const long long r = blockIdx.x * 256LL + threadIdx.x;
+    if (r >= n_rows) return;
+    const long long self = rows ? rows[r] : r;
+    const int p = rank[self];
+    int c = 0;
+    for (int j = 0; j < kk; ++j) {
+        const long long id = ids[(size_t)r * kk + j];
+        if (id >= 0 && id != self) nbr[(size_t)p * kk + c++] = rank[id];
+    }
+    cnt[p] = c;
+    for (; c < kk; ++c) nbr[(size_t)p * kk + c] = -1;
+}
+
+int graph_plan_set_lists(fdx_graph_plan* plan, const long long* ids_host, const long long* rows_host, long long n_rows, int* nbr,
+                         int* cnt, hipStream_t st) {
+    FDX_REQUIRE(n_rows >= 0 && n_rows <= plan->n, "graph: more list rows than spots");
+    if (n_rows == 0) return graph_plan_lists_replaced(plan);
+    DevBuf d_ids, d_rows;
+    FDX_TRY(d_ids.alloc((size_t)n_rows * plan->kk * 8));
+    FDX_HIP(hipMemcpyAsync(d_ids.p, ids_host, (size_t)n_rows * plan->kk * 8, hipMemcpyHostToDevice, st));
+    if (rows_host) {
+        for (long long r = 0; r < n_rows; ++r) FDX_REQUIRE(rows_host[r] >= 0 && rows_host[r] < plan->n, "graph: list row out of range");
+        FDX_TRY(d_rows.alloc((size_t)n_rows * 8));
+        FDX_HIP(hipMemcpyAsync(d_rows.p, rows_host, (size_t)n_rows * 8, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(lists_from_ids_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, st, d_ids.as<long long>(),
+                       rows_host ? d_rows.as<long long>() : (const long long*)nullptr, n_rows, plan->kk, plan->b.rank.as<int>(), nbr, cnt);
+    FDX_CHECK_LAUNCH();
+    FDX_HIP(hipStreamSynchronize(st));            // the host arrays are the caller's
+    return graph_plan_lists_replaced(plan);
+}
+
 int graph_plan_order(const fdx_graph_plan* plan, int* d_perm_out, int* d_rank_out, hipStream_t st) {
     if (d_perm_out) FDX_HIP(hipMemcpyAsync(d_perm_out, plan->b.perm.p, (size_t)plan->n * 4, hipMemcpyDeviceToDevice, st));
     if (d_rank_out) FDX_HIP(hipMemcpyAsync(d_rank_out, plan->b.rank.p, (size_t)plan->n * 4, hipMemcpyDeviceToDevice, st));

@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -56,14 +57,18 @@ struct KdTree {
     std::vector<double> maxes, mins;   // of the whole data set
 };
 
-long long kd_build(KdTree& t, long long start, long long end, double* maxes, double* mins) {
+// par_depth > 0: the `less` subtree of a large node is built by another thread into a node vector of its own and appended
+// afterwards (the index array is partitioned in place - disjoint ranges; the NUMBERING of the nodes differs from a serial build,
+// which nothing reads: queries follow the less / greater links).  The serial build was 130 of the 145 ms the tie remedy spent on
+// the host for a million lattice points: its top levels are cache-missing passes over all points.
+long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long long end, double* maxes, double* mins, int par_depth) {
     const int m = t.m;
     const double* data = t.data;
     long long* indices = t.indices.data();
-    t.nodes.emplace_back();
-    const long long node_index = (long long)t.nodes.size() - 1;
-    t.nodes[(size_t)node_index].start = start;
-    t.nodes[(size_t)node_index].end = end;
+    nodes.emplace_back();
+    const long long node_index = (long long)nodes.size() - 1;
+    nodes[(size_t)node_index].start = start;
+    nodes[(size_t)node_index].end = end;
     if (end - start <= t.leafsize) return node_index;                 // leaf
     // compact nodes: bounds from the node's own points
     for (int i = 0; i < m; ++i) maxes[i] = mins[i] = data[indices[start] * m + i];
@@ -106,9 +111,44 @@ long long kd_build(KdTree& t, long long start, long long end, double* maxes, dou
         std::swap(indices[end - 1], indices[j]);
         p = end - 1;
     }
-    const long long less = kd_build(t, start, p, maxes, mins);
-    const long long greater = kd_build(t, p, end, maxes, mins);
-    KdNode& nd = t.nodes[(size_t)node_index];                         // (the vector may have moved)
+    long long less = -1, greater = -1;
+    bool forked = false;
+    if (par_depth > 0 && end - start > 32768) {
+        std::vector<KdNode> sub;
+        long long sub_root = -1;
+        bool sub_ok = true;
+        try {
+            std::thread th([&] {
+                try {
+                    std::vector<double> mx((size_t)m), mn((size_t)m);
+                    sub_root = kd_build(t, sub, start, p, mx.data(), mn.data(), par_depth - 1);
+                } catch (...) { sub_ok = false; }
+            });
+            forked = true;
+            try {
+                greater = kd_build(t, nodes, p, end, maxes, mins, par_depth - 1);
+            } catch (...) { th.join(); throw; }
+            th.join();
+        } catch (const std::system_error&) {
+            if (forked) throw;                                        // came out of the join path
+        }
+        if (forked) {
+            if (!sub_ok) throw std::bad_alloc();
+            const long long off = (long long)nodes.size();
+            nodes.reserve(nodes.size() + sub.size());
+            for (KdNode nd2 : sub) {
+                if (nd2.less >= 0) nd2.less += off;
+                if (nd2.greater >= 0) nd2.greater += off;
+                nodes.push_back(nd2);
+            }
+            less = sub_root + off;
+        }
+    }
+    if (!forked) {
+        less = kd_build(t, nodes, start, p, maxes, mins, par_depth - 1);
+        greater = kd_build(t, nodes, p, end, maxes, mins, par_depth - 1);
+    }
+    KdNode& nd = nodes[(size_t)node_index];                           // (the vector may have moved)
     nd.split_dim = d;
     nd.split = split;
     nd.less = less;
@@ -234,9 +274,17 @@ void kd_query_one(const KdTree& t, const double* x, int kmax, int64_t* out_idx, 
 namespace fdx {
 namespace {
 // tree of all n points, then the queries of `rows` (NULL: every point, in order) - idx_out row j holds the answer for rows[j]
+void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim);
+int ckdtree_query_host(const KdTree& t, int32_t kk, const int64_t* rows, int64_t n_rows, int64_t* idx_out, int64_t* tree_indices_out);
+
 int ckdtree_knn_impl(const double* coords, int64_t n, int32_t dim, int32_t kk, const int64_t* rows, int64_t n_rows, int64_t* idx_out,
                      int64_t* tree_indices_out) {
     KdTree t;
+    kd_build_tree(t, coords, n, dim);
+    return ckdtree_query_host(t, kk, rows, n_rows, idx_out, tree_indices_out);
+}
+
+void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
     t.data = coords;
     t.n = n;
     t.m = dim;
@@ -253,7 +301,14 @@ int ckdtree_knn_impl(const double* coords, int64_t n, int32_t dim, int32_t kk, c
         }
     t.nodes.reserve((size_t)(2 * (n / 8) + 16));
     std::vector<double> mx(t.maxes), mn(t.mins);
-    kd_build(t, 0, n, mx.data(), mn.data());
+    const int par = getenv("FDX_KDTREE_SERIAL_BUILD") ? 0 : 5;       // up to 32 subtrees in flight
+    kd_build(t, t.nodes, 0, n, mx.data(), mn.data(), par);
+}
+
+int ckdtree_query_host(const KdTree& t, int32_t kk, const int64_t* rows, int64_t n_rows, int64_t* idx_out, int64_t* tree_indices_out) {
+    const double* coords = t.data;
+    const long long n = t.n;
+    const int dim = t.m;
     if (tree_indices_out) std::memcpy(tree_indices_out, t.indices.data(), (size_t)n * sizeof(int64_t));
     // the queries are independent (the tree is read-only; every thread has its own node pool and heaps): contiguous ranges of a
     // few thousand points and more per host thread.  1000 x 1000 lattice points on 8 cores: 2.2 -> 0.8-1.0 s, of which 0.29 s the
@@ -272,7 +327,7 @@ int ckdtree_knn_impl(const double* coords, int64_t n, int32_t dim, int32_t kk, c
     };
     unsigned nt = std::thread::hardware_concurrency();
     if (const char* e = getenv("FDX_KDTREE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
-    nt = (unsigned)std::min<long long>(std::max(1u, std::min(nt, 32u)), std::max<long long>(1, nq / 4096));
+    nt = (unsigned)std::min<long long>(std::max(1u, std::min(nt, 128u)), std::max<long long>(1, nq / 4096));
     // a thread that cannot be started (process limits, W ranks x 32 threads) or a failed allocation inside a worker must not end
     // the process: what was started is joined, the rest of the range runs here
     std::vector<std::thread> th;

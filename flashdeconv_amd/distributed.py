@@ -582,23 +582,14 @@ class ShardedFlashDeconv:
         _lib.check(lib.fdx_graph_knn_lists_band_dev(ctypes.c_void_p(coords.data_ptr()), n, dim, k, lo, hi,
                                                     ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), st, ctypes.byref(plan)))
         perm_t = torch.empty(n, dtype=torch.int32, device=dev)
-        rank_t = torch.empty(n, dtype=torch.int32, device=dev)
-        _lib.check(lib.fdx_graph_plan_order_dev(plan, ctypes.c_void_p(perm_t.data_ptr()), ctypes.c_void_p(rank_t.data_ptr()), st))
+        _lib.check(lib.fdx_graph_plan_order_dev(plan, ctypes.c_void_p(perm_t.data_ptr()), None, st))
         rows_pos = torch.nonzero(cnt > 0).flatten()                       # own rows + band: the rows that have lists
         if rows_pos.numel():
-            ids = perm_t[rows_pos].long().cpu().numpy()
+            ids = np.ascontiguousarray(perm_t[rows_pos].long().cpu().numpy())
             lists = ckdtree_knn_lists_rows(coords.detach().cpu().numpy(), k, ids)          # caller ids, self included, -1 padded
-            keep = (lists >= 0) & (lists != ids[:, None])                                     # utils/graph.py:70-74: drop row == col
-            # left-compact the kept entries of every row (their order inside a list does not matter: the symmetrisation sorts)
-            order = np.argsort(~keep, axis=1, kind="stable")
-            lists_c = np.take_along_axis(lists, order, axis=1)
-            n_keep = keep.sum(axis=1)
-            lists_c[np.arange(kk)[None, :] >= n_keep[:, None]] = -1
-            lt = torch.from_numpy(lists_c).to(dev)
-            pos = torch.where(lt >= 0, rank_t[lt.clamp(min=0)].long(), torch.full_like(lt, -1))
-            nbr[rows_pos] = pos.to(torch.int32)
-            cnt[rows_pos] = torch.from_numpy(n_keep.astype(np.int32)).to(dev)
-            _lib.check(lib.fdx_graph_plan_lists_replaced(plan))
+            # to solver positions, self dropped (utils/graph.py:70-74), at the rows' positions: on the device
+            _lib.check(lib.fdx_graph_plan_set_lists_dev(plan, lists.ctypes.data, ids.ctypes.data, len(ids), ctypes.c_void_p(nbr.data_ptr()),
+                                                        ctypes.c_void_p(cnt.data_ptr()), st))
         _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi,
                                                     st, ctypes.byref(h)))
         full = _lib.Graph(h.value)

@@ -332,6 +332,12 @@ int fdx_graph_plan_order_dev(const fdx_graph_plan* plan, int32_t* perm_out_dev, 
  * fdx_ckdtree_knn): call this before fdx_graph_from_knn_lists_dev so that the symmetrisation counts the lists it is given
  * (a whole-graph plan carries counts its k-NN kernel drew for its own lists). */
 int fdx_graph_plan_lists_replaced(fdx_graph_plan* plan);
+/* The usual replacement in one call: ids_host (n_rows, kk) int64 = the answers of a k-nearest query in CALLER ids (the point itself
+ * usually among them, -1 padded: fdx_ckdtree_knn / fdx_ckdtree_knn_rows), row r for caller id rows_host[r] (NULL: r).  Uploaded and
+ * written on the device where the symmetrisation expects them - the row's solver position, neighbours as solver positions, the
+ * point itself dropped (utils/graph.py:70-74), -1 padded; includes fdx_graph_plan_lists_replaced.  Rows not listed keep their lists. */
+int fdx_graph_plan_set_lists_dev(fdx_graph_plan* plan, const int64_t* ids_host, const int64_t* rows_host, int64_t n_rows,
+                                 int32_t* nbr_dev, int32_t* cnt_dev, void* stream);
 /* perm_out_dev[p] = caller's spot id at solver position p (int32, n entries, device). */
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
 /* Shard of a full graph for rank `my_rank`: own spots are solver positions [bounds[my_rank], bounds[my_rank+1])
