@@ -101,15 +101,23 @@ __global__ __launch_bounds__(256) void normalize_export_kernel(const double* __r
     row_s[wib][lane] = active ? orow : -1;
     // same-wave LDS hand-off: the wave's own ds_writes are ordered before its later ds_reads
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    // element f = lane + 64 j of the wave's 64 x K block: (spot, type) advance by (64 / K, 64 % K) with a carry - one integer
+    // division per lane instead of one per element; the results are written once and never read here: non-temporal stores
     const int total = 64 * K;
+    const int ds = 64 / K, dk = 64 - ds * K;
+    int sp = lane / K, k = lane - sp * K;
+    const double inv_K = 1.0 / (double)K;
     for (int f = lane; f < total; f += 64) {
-        const int sp = f / K, k = f - sp * K;
         const int row = row_s[wib][sp];
-        if (row < 0) continue;
-        const double v = tile[sp * Ks + k];
-        const double dd = inv_s[wib][sp];
-        if (beta_out) beta_out[(size_t)row * K + k] = v;
-        if (prop_out) prop_out[(size_t)row * K + k] = (dd < 0.0) ? 1.0 / (double)K : v / dd;
+        if (row >= 0) {
+            const double v = tile[sp * Ks + k];
+            const double dd = inv_s[wib][sp];
+            if (beta_out) __builtin_nontemporal_store(v, beta_out + (size_t)row * K + k);
+            if (prop_out) __builtin_nontemporal_store((dd < 0.0) ? inv_K : v / dd, prop_out + (size_t)row * K + k);
+        }
+        sp += ds;
+        k += dk;
+        if (k >= K) { k -= K; ++sp; }
     }
 }
 
