@@ -824,8 +824,10 @@ class ShardedFlashDeconv:
         call.  True: done (results set); False: a remedy was applied to the plan, call again; None: not applicable here (the
         process group is not libfdx's own communicator, more than 96 cell types, a rank without rows, sweeps being timed)."""
         import torch
-        if (os.environ.get("FDX_NO_SHARD_FIT") or getattr(self, "time_sweeps", False) or self.n_own <= 0 or K > 96
-                or self._local is None):
+        # every rank must take the same route (the native call all-reduces on libfdx's communicator, the stepwise flow on
+        # torch's): the conditions are properties of the JOB - a rank without rows anywhere sends all ranks the stepwise way
+        if (os.environ.get("FDX_NO_SHARD_FIT") or getattr(self, "time_sweeps", False) or K > 96 or self._local is None
+                or bool(np.any(np.diff(self.bounds) <= 0))):
             return None
         native = self.native_comm()
         if native is None:
