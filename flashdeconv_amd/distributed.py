@@ -1060,9 +1060,16 @@ def bench_main(a, rank, world, local_rank):
         Y[r0:r1] = (B @ X + 0.1 * torch.randn(r1 - r0, G, generator=g2, device=dev, dtype=torch.float64)).to(torch.float32)
     Xh = X.cpu().numpy()
 
+    # A step that does not come back (a collective some rank never joined) must not sit until the launcher's own timeout: every
+    # step re-arms a deadline after which this rank dumps its stack and exits non-zero (FDX_BENCH_STEP_DEADLINE seconds, default 240)
+    import faulthandler
+    deadline = float(os.environ.get("FDX_BENCH_STEP_DEADLINE", "240"))
+
     def step():
+        faulthandler.dump_traceback_later(deadline, exit=True)
         model.plan(coords, Xh)
         model.fit_transform(Y, Xh)
+        faulthandler.cancel_dump_traceback_later()
 
     for _ in range(a.warmup):
         step()
