@@ -1099,7 +1099,12 @@ def bench_main(a, rank, world, local_rank):
                 "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / bench.HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": int(alg), "ms_per_launch": round(sweep_ms, 4), "rank": 0}
     reports = [None] * world
-    dist.all_gather_object(reports, model.comm_report())
+    rep = model.comm_report()
+    # sanity of the run itself, per rank: the iteration count every rank stopped at (must agree), finite proportions whose rows sum to 1
+    P = model.proportions_
+    rep["n_iterations"] = int(n_it)
+    rep["rows_sum_to_one"] = bool(P.numel() == 0 or (torch.isfinite(P).all() and ((P.sum(dim=1) - 1.0).abs().max() < 1e-9)))
+    dist.all_gather_object(reports, rep)
     dist.destroy_process_group()
     ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in the C stdio buffer: get it out BEFORE the result line
     if rank == 0:
@@ -1117,4 +1122,5 @@ def bench_main(a, rank, world, local_rank):
             # device, the route of the plan, native or Python iteration loop
             "rccl_ranks": reports[0]["rccl_ranks"], "loop": sorted({r["loop"] for r in reports}),
             "native_comm_error": next((r["native_comm_error"] for r in reports if r["native_comm_error"]), None),
+            "ranks_agree": len({r["n_iterations"] for r in reports}) == 1 and all(r["rows_sum_to_one"] for r in reports),
             "ranks": reports}), flush=True)

@@ -579,7 +579,7 @@ def test_bench_driver_with_two_ranks_rehearsed_over_gloo():
     assert line["value"] > 0 and line["ms_per_step"] > 0 and line["config"]["n_iterations"] >= 1
     assert line["roofline"] and line["roofline"]["ms_per_launch"] > 0 and "bcd_sweep" in line["roofline"]["kernel"]
     # what ran, per rank: over gloo there is no RCCL communicator of libfdx's own - the Python exchange loop, and the line says so
-    assert line["loop"] == ["python"] and line["rccl_ranks"] is None and line["native_comm_error"] is None
+    assert line["loop"] == ["python"] and line["rccl_ranks"] is None and line["native_comm_error"] is None and line["ranks_agree"] is True
     assert [r["rank"] for r in line["ranks"]] == [0, 1] and all(r["plan_route"] == "band" and r["device"] == 0 for r in line["ranks"])
 
 
