@@ -615,9 +615,11 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     // boundary-first ordering needs the tiled sweep (tile lists) and somebody to talk to
     bool split = tiled && bcd_sweep_uses_tiles(a) && total_send > 0 && g->n > 0 && !getenv("FDX_NO_OVERLAP");
     // ... and a shard large enough for the split to pay: a sweep launch lasts at least one workgroup's life (~25-35 us) however few
-    // tiles it has, so below ~2 rounds of resident workgroups (256 CUs x 3) boundary + interior cost two such lives for the work of
+    // tiles it has, so for shards of a few rounds of resident workgroups (256 CUs x 3) boundary + interior cost two such lives for the work of
     // one - 125k-spot shards: 36 + 34 us against 36 - and the interior sweep is too short to hide anything behind
-    const int split_min_tiles = getenv("FDX_SPLIT_MIN_TILES") ? atoi(getenv("FDX_SPLIT_MIN_TILES")) : 1536;
+    // (4096 tiles = 1M spots per rank: below that a rank's halo is a few hundred KB per peer - ~20 us of transfer and latency to
+    // hide, against the ~36 us the extra launch costs; the 1.25M-spot ranks of configs[4], 1-2.6 MB per peer, are about even)
+    const int split_min_tiles = getenv("FDX_SPLIT_MIN_TILES") ? atoi(getenv("FDX_SPLIT_MIN_TILES")) : 4096;
     if (split && g->n_tiles < split_min_tiles) split = false;
     // every rank must take the same route for the convergence slots: they ride with the halo only when NO rank of the job can
     // split (shards are equal to within one tile: the largest has at most ceil(tiles / W) + 1 of them)
