@@ -371,6 +371,8 @@ def main():
                 R["g"].close()
             del keep
         torch.cuda.empty_cache()                     # only now: between the passes the freed blocks stay with torch's allocator, as in a job that fits twice
+        from flashdeconv_amd import _lib as _fdx_lib
+        _fdx_lib.load().fdx_trim()                   # ... and libfdx's pooled scratch (a 5M-spot rank's H and abundances): T1 needs the room at 10M spots
         t = info["times"]
         crit = t["per_rank_critical_path_ms"]
         # T1: the SAME job (same coordinates, same rows: generated chunk by chunk from the same seeds) unsharded on this GPU

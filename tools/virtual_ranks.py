@@ -375,6 +375,7 @@ def alone_pipelined(torch, coords, ranks, bounds, X, make_rows, d, mode, K, lam,
     Xc = np.ascontiguousarray(X, dtype=np.float64)
     t = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
     times["pipelined_ms"] = []
+    torch.cuda.empty_cache()
     for r, S in zip(rank_ids, ranks):
         dev = S["H"].device
         Y = make_rows(S["lo"], S["hi"])
@@ -428,6 +429,7 @@ def alone_pipelined(torch, coords, ranks, bounds, X, make_rows, d, mode, K, lam,
         lib.fdx_comm_destroy(comm)
         times["pipelined_ms"].append(best)
         del Y, H, bufs, b, p
+        torch.cuda.empty_cache()          # a 10M-spot job's shard is 25-100 GB: hand it back before the next rank's is made
 
 
 def driver_alone(torch, coords, ranks, X, make_rows, d, K, nnz_total, n_iter, times, reps=None, knn_ties="auto"):
@@ -458,6 +460,7 @@ def driver_alone(torch, coords, ranks, X, make_rows, d, K, nnz_total, n_iter, ti
         times["driver_ms"].append(best)
         model.close()
         del Y, model
+        torch.cuda.empty_cache()
 
 
 def assemble(torch, ranks, results, n, K, want_props=True):
