@@ -16,6 +16,7 @@
 namespace fdx {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
+std::string get_error() { return g_last_error; }
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
     // An error return unwinds through DevBuf destructors, which hand their blocks back to the pool while kernels queued

@@ -17,8 +17,10 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -27,6 +29,7 @@
 #include "fdx_graph.h"
 #include "fdx_internal.h"
 #include "fdx_kernels.h"
+#include "graph_build.h"
 #include "prepare.h"
 #include "solver.h"
 
@@ -432,6 +435,16 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
 // lambda, the iteration loop, objective and export - one call, the device never waiting for the host between its stages
 // (the separate calls cost a 125k-spot rank ~0.35 ms of idle device: 1.25 -> 1.6 ms).  Reference: core/deconv.py:326-398 for the
 // stages, core/solver.py:157-166 for the sharding.
+// FDX_TRACE_HOST=1: host clock at the steps of a shard's fit (stderr)
+static void shard_trace(const char* what) {
+    static const bool on = getenv("FDX_TRACE_HOST") != nullptr;
+    if (!on) return;
+    static auto t_prev = std::chrono::steady_clock::now();
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[fdx-host] +%7.1f us  shard fit: %s\n", std::chrono::duration<double, std::micro>(t - t_prev).count(), what);
+    t_prev = t;
+}
+
 int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_t y_dtype, int64_t n_own, int32_t G, int64_t ldy,
                       const double* X, int32_t K, const int32_t* bucket, const double* weight_y, const double* weight_x,
                       const fdx_shard_fit_params* prm, double* beta_out_dev, double* prop_out_dev, double* rel_changes_out,
@@ -441,6 +454,7 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
     FDX_REQUIRE(K >= 1 && K <= FDX_MAX_K_PAD, "fdx_shard_fit_dev: 1 to 96 cell types (more: the stepwise calls)");
     FDX_REQUIRE(prm->sketch_dim > 0 && prm->max_iter >= 0 && prm->n_total_spots >= n_own, "fdx_shard_fit_dev: bad parameters");
     std::memset(info, 0, sizeof(*info));
+    shard_trace("entry");
     hipStream_t st = (hipStream_t)stream;
     PoolStream pool_stream(st);
     FDX_TRY(comm_streams(c));
@@ -456,8 +470,20 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
     if (KP != K) FDX_HIP(hipMemsetAsync(dH.as<double>() + (size_t)K * ldh, 0, (size_t)(KP - K) * ldh * sizeof(double), st));
     double* Gh = (double*)pinned_scratch(4, (size_t)K * K * sizeof(double) + 64);
     FDX_REQUIRE(Gh != nullptr, "fdx_shard_fit_dev: pinned host buffer");
-    FDX_TRY(prepare_queue(&job, Y_dev, y_dtype, n_own, G, ldy, nullptr, X, K, bucket, weight_y, weight_x, prm->sketch_dim, prm->mode_y,
-                          prm->mode_x, dH.as<double>(), ldh, Gh, st));
+    // A shard build may still be on its way (graph_shard_knn: second phase queued by the helper thread on the plan stream): the
+    // sketch of the own rows does not need the graph and runs beside it.
+    // (FDX_SKETCH_RESERVE: compute units the sketch's persistent workgroups leave to that build; measured at 16 / 32 / 64 on a
+    // 125k-spot shard it only slowed both down - the build is a chain of dependent launches, not a matter of free units.)
+    int reserve = 0;
+    if (g->shard_pending) if (const char* e = getenv("FDX_SKETCH_RESERVE")) reserve = atoi(e);
+    const int reserve_prev = tile_sketch_reserve_cus(reserve);
+    const int prc = prepare_queue(&job, Y_dev, y_dtype, n_own, G, ldy, nullptr, X, K, bucket, weight_y, weight_x, prm->sketch_dim,
+                                  prm->mode_y, prm->mode_x, dH.as<double>(), ldh, Gh, st);
+    tile_sketch_reserve_cus(reserve_prev);
+    FDX_TRY(prc);
+    shard_trace("X side + sketch queued");
+    FDX_TRY(graph_shard_join(g));
+    shard_trace("rest of the plan queued");
     const double* XtX_dev = job.dG.as<double>();
     if (KP != K) {
         PoolStream pool_xs(job.side ? job.side : st);
@@ -488,6 +514,7 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
         FDX_TRY(fdx::graph_meta_sync(g));
         tot[0] = (double)g->nnz; tot[1] = (double)g->knn_ties; tot[2] = (double)g->knn_far; tot[3] = (double)g->shard_overflow;
     }
+    shard_trace("plan's counts on the host");
     if (prm->nnz_total >= 0) tot[0] = (double)prm->nnz_total;              // the caller knows the job's total (a graph that was not built here)
     info->nnz_total = (int64_t)std::llround(tot[0]);
     info->knn_ties_total = (int64_t)std::llround(tot[1]);
@@ -504,6 +531,7 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
 
     // ---- lambda, scaled rho (host scalars of the sweeps): XtX has long arrived
     FDX_HIP(hipEventSynchronize(job.evX));
+    shard_trace("XtX on the host");
     double diag_mean = 0.0;
     for (int k = 0; k < K; ++k) diag_mean += Gh[(size_t)k * K + k];
     diag_mean /= (double)K;
@@ -521,6 +549,7 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
     FDX_TRY(sharded_solve_impl(c, g, dH.as<double>(), ldh, XtX_dev, KP, K, lambda, rho_eff, prm->tol, prm->max_iter, dB0.as<double>(),
                                dB1.as<double>(), ld, &info->solve, rel_changes_out, &which, stream));
     const double* beta = which ? dB1.as<double>() : dB0.as<double>();
+    shard_trace("loop returned");
 
     // ---- export beside the objective pass (both only read the final abundances), YtY and the objective's sums in one all-reduce
     FDX_TRY(objp.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
@@ -537,6 +566,7 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
     FDX_HIP(hipMemcpyAsync(cnt_h, dFin.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (beta_out_dev || prop_out_dev) FDX_HIP(hipStreamWaitEvent(st, c->ev_halo, 0));
     FDX_HIP(hipStreamSynchronize(st));
+    shard_trace("objective on the host");
     info->YtY = cnt_h[4];
     info->solve.final_objective = 0.5 * (cnt_h[4] - 2.0 * cnt_h[0] + cnt_h[1]) + 0.5 * lambda * cnt_h[2] + rho_eff * cnt_h[3];   // core/solver.py:272-284
     return 0;

@@ -6,7 +6,11 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 
 namespace fdx {
@@ -17,6 +21,7 @@ namespace fdx {
 // (codes: FDX_OK / FDX_ERR_* from include/fdx.h)
 
 void set_error(const std::string& msg);
+std::string get_error();
 int fail(int code, const std::string& msg);
 
 #define FDX_HIP(expr)                                                                             \
@@ -69,6 +74,12 @@ void* pinned_block_get();                        // a recycled pinned block of F
 void pinned_block_put(void* p);                  // ... and back
 void* pinned_buffer_get(size_t bytes, size_t* cap_out);   // a recycled pinned buffer of at least `bytes` (capacity class in *cap_out)
 void pinned_buffer_put(void* p, size_t cap);
+
+// Helper thread (helper_thread.cpp): fn runs there with the caller's device current; helper_wait returns fn's code (and makes its
+// message this thread's last error).  fn must only queue device work, never wait for the device.
+struct HelperTicket { std::mutex mu; std::condition_variable cv; bool done = false; int rc = 0; std::string err; };
+std::shared_ptr<HelperTicket> helper_submit(std::function<int()> fn);
+int helper_wait(const std::shared_ptr<HelperTicket>& ticket);
 
 // the library's per-device non-blocking side stream (its own priority: fit.cpp); nullptr if it cannot be made
 hipStream_t library_side_stream();

@@ -101,6 +101,8 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
 int launch_sketch_contract(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                            const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
                            hipStream_t st);
+// units the next tile-kernel launches of this thread leave to other streams (0 = none); returns the previous setting
+int tile_sketch_reserve_cus(int cus);
 int column_sums_parts(long long n);
 int launch_column_sums(const void* Y, int dtype, long long ldy, long long n, int G, double* partials, double* out,
                        hipStream_t st);

@@ -79,15 +79,18 @@ struct fdx_leverage_job {
     double* pin = nullptr;          // G doubles, then 8 ints
     size_t pin_cap = 0;
     hipEvent_t done = nullptr;
+    double* hX = nullptr;           // pinned copy of the signatures (the caller may drop X once begin returns; the upload does not stage)
+    size_t hX_cap = 0;
     ~fdx_leverage_job() {
         if (done) (void)hipEventDestroy(done);
         if (pin) fdx::pinned_buffer_put(pin, pin_cap);
+        if (hX) fdx::pinned_buffer_put(hX, hX_cap);
     }
     DevBuf dX, dW, dS, dL, dDbg, dScratch;
-    std::vector<double> hX;   // the caller may drop X once begin returns
     int K = 0, G = 0, route = LEV_ROUTE_SVD;
     double reg = 0.0;
     hipStream_t st = nullptr;
+    std::shared_ptr<fdx::HelperTicket> ticket;   // begin's launches were handed to the helper thread: end waits for them first
 };
 
 namespace fdx {
@@ -123,15 +126,20 @@ extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double 
     job->K = K;
     job->G = G;
     job->st = leverage_side_stream();
-    PoolStream pool_stream(job->st);
-    auto run = [&]() -> int {
+    job->hX = (double*)pinned_buffer_get((size_t)K * G * sizeof(double), &job->hX_cap);
+    if (!job->hX) { delete job; return fail(FDX_ERR_HIP, "fdx_leverage_begin: pinned host buffer"); }
+    std::memcpy(job->hX, X, (size_t)K * G * sizeof(double));
+    // the upload (a pageable copy: the host waits for it) and the launches cost ~75 us of host time that the caller - on its way to
+    // a graph build, with the scores not needed before the sketch tables - has better uses for: the helper thread queues them
+    const bool async = !getenv("FDX_NO_HELPER_THREAD");
+    auto run = [job, K, G, regularization]() -> int {
+        PoolStream pool_stream(job->st);
         FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
         FDX_TRY(job->dW.alloc((size_t)K * G * sizeof(double)));
         FDX_TRY(job->dS.alloc((size_t)K * sizeof(double)));
         FDX_TRY(job->dL.alloc((size_t)G * sizeof(double)));
         FDX_TRY(job->dDbg.alloc(8 * sizeof(int)));
-        job->hX.assign(X, X + (size_t)K * G);
-        FDX_HIP(hipMemcpyAsync(job->dX.p, job->hX.data(), (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, job->st));
+        FDX_HIP(hipMemcpyAsync(job->dX.p, job->hX, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, job->st));
         FDX_TRY(job->dScratch.alloc(leverage_scratch_doubles(K, G) * sizeof(double)));
         job->reg = regularization;
         job->route = leverage_qr_applies(K, G) ? LEV_ROUTE_QR : LEV_ROUTE_SVD;
@@ -145,6 +153,11 @@ extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double 
         FDX_HIP(hipEventRecord(job->done, job->st));
         return 0;
     };
+    if (async) {
+        job->ticket = helper_submit(run);
+        *out = job;
+        return 0;
+    }
     const int rc = run();
     if (rc) {
         (void)hipStreamSynchronize(job->st);
@@ -157,6 +170,15 @@ extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double 
 
 extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) {
     FDX_REQUIRE(job != nullptr, "fdx_leverage_end: null job");
+    if (job->ticket) {
+        const int qrc = helper_wait(job->ticket);
+        job->ticket.reset();
+        if (qrc) {
+            (void)hipStreamSynchronize(job->st);
+            delete job;
+            return qrc;
+        }
+    }
     int rc = 0;
     int dbg[8] = {0};
     auto run = [&]() -> int {

@@ -37,6 +37,10 @@ int graph_localize(const fdx_graph* full, long long lo, long long hi, int n_rank
 // takes over the counts (loc->shard_overflow: a bound was too small - rebuild by knn_lists / from_knn_lists / localize).
 int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_ranks, const long long* bounds, int my_rank,
                     fdx_graph* loc, hipStream_t st);
+// queue the second phase of a deferred shard build now (no-op when it has been queued); st NULL: the library's plan stream
+int shard_queue_rest(fdx_graph* loc, hipStream_t st);
+// a pending shard build's second phase is queued when this returns (waits for the helper thread, or queues it here)
+int graph_shard_join(const fdx_graph* g);
 // solver position -> caller's spot id, device int32 (n)
 int graph_copy_perm(const fdx_graph* g, int* d_out, hipStream_t st);
 

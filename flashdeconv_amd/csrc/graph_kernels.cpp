@@ -1503,7 +1503,9 @@ struct fdx_graph_plan {
 };
 struct fdx_shard_build;
 static void shard_build_drop(fdx_shard_build* sb);
+static void shard_build_join(fdx_shard_build* sb);
 fdx_graph::~fdx_graph() {
+    if (keep_shard) shard_build_join(keep_shard);             // the helper thread may still be queueing the build's second phase
     if ((meta_pending || shard_pending) && meta_event) (void)hipEventSynchronize(meta_event);   // queued kernels still write into the buffers below
     if (keep_shard) { shard_build_drop(keep_shard); keep_shard = nullptr; }
     if (keep_plan) { delete keep_plan; keep_plan = nullptr; }
@@ -2247,7 +2249,7 @@ __global__ __launch_bounds__(256) void fill_ell_local_kernel(const int* __restri
     if (s >= n_slices) return;
     const long long n_own = hi - lo;
     const long long t = (long long)s * 64 + lane;
-    if (t < n_own) perm_l[t] = perm_g[lo + t];                   // caller's id of the own row
+    if (perm_l && t < n_own) perm_l[t] = perm_g[lo + t];         // caller's id of the own row
     if ((long long)slice_off[n_slices] > cap_rows) return;      // bound too small: reported, rebuilt by the stepwise path
     const int w0 = slice_off[s], w = slice_off[s + 1] - w0;
     const int dg = (t < n_own) ? deg[t] : 0;
@@ -2379,13 +2381,50 @@ __global__ __launch_bounds__(256) void shard_meta_kernel(const long long* __rest
 struct fdx_shard_build {
     fdx_graph_plan* plan = nullptr;
     fdx::DevBuf nbr, cnt, zeros, rev_off, rev, rows, hscan, mask, off_rb, tileflag, tile_counts, scan_tmp;
-    ~fdx_shard_build() { if (plan) fdx::graph_plan_destroy(plan); }
+    // what the second phase (shard_queue_rest) needs; `queued` = it has run
+    long long n = 0, lo = 0, hi = 0;
+    int kk = 0, n_ranks = 0;
+    long long bounds[fdx::SHARD_MAX_RANKS + 1] = {};
+    hipStream_t st_first = nullptr;          // stream of the first phase (the caller's)
+    hipEvent_t ev_first = nullptr;           // recorded there behind the k-NN lists and the copy of the own rows' ids
+    bool queued = false;
+    std::shared_ptr<fdx::HelperTicket> ticket;   // the second phase was handed to the helper thread: wait before touching anything it writes
+    ~fdx_shard_build() {
+        if (plan) fdx::graph_plan_destroy(plan);
+        if (ev_first) (void)hipEventDestroy(ev_first);
+    }
 };
-static void shard_build_drop(fdx_shard_build* sb) {      // the graph's meta event has completed: nothing reads the buffers any more
-    if (sb->plan) sb->plan->kernels_done = true;
+static void shard_build_join(fdx_shard_build* sb) {
+    if (sb->ticket) { (void)fdx::helper_wait(sb->ticket); sb->ticket.reset(); }
+}
+static void shard_build_drop(fdx_shard_build* sb) {
+    if (sb->ticket) { (void)fdx::helper_wait(sb->ticket); sb->ticket.reset(); }
+    // second phase queued: the graph's meta event has completed, nothing reads the buffers any more; never queued: the plan's
+    // destructor waits for the first phase's stream
+    if (sb->plan && sb->queued) sb->plan->kernels_done = true;
     delete sb;
 }
 namespace fdx {
+
+// the library's per-device stream for the second phase of a shard build (beside the sketch of the own rows on the caller's stream)
+hipStream_t library_plan_stream() {
+    static hipStream_t streams[64] = {};
+    static std::mutex mu;
+    if (getenv("FDX_NO_PLAN_STREAM")) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!streams[dev]) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, hi) != hipSuccess &&
+            hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess)
+            streams[dev] = nullptr;
+    }
+    return streams[dev];
+}
+
+int shard_queue_rest(fdx_graph* loc, hipStream_t st);
 
 int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_ranks, const long long* bounds, int my_rank,
                     fdx_graph* loc, hipStream_t st) {
@@ -2409,6 +2448,62 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     FDX_TRY(graph_knn_lists(d_coords, n, dim, k, lo, hi, sb->nbr.as<int>(), sb->cnt.as<int>(), &sb->plan, st, true));
     fdx_graph_plan* plan = sb->plan;
     FDX_REQUIRE(plan->band_rows.p != nullptr, "graph_shard_knn: no band (one rank owns everything)");
+    // the caller's ids of the own rows are final with the binning: copied now, so that the caller can lay its rows out while the
+    // rest of the build is still to be queued
+    FDX_TRY(loc->perm.alloc((size_t)n_own * 4));
+    FDX_HIP(hipMemcpyAsync(loc->perm.p, plan->b.perm.as<int>() + lo, (size_t)n_own * 4, hipMemcpyDeviceToDevice, st));
+    loc->n = n_own;
+    loc->n_total = n_own;                        // until graph_meta_sync
+    loc->identity_order = false;
+    loc->global_lo = lo;
+    loc->world_n = n;
+    loc->n_tiles = ceil_div(n_own, 256);
+    loc->n_slices = (int)((n_own + 63) / 64);
+    loc->shard_world = n_ranks;
+    sb->n = n; sb->lo = lo; sb->hi = hi; sb->kk = kk; sb->n_ranks = n_ranks;
+    for (int r = 0; r <= SHARD_MAX_RANKS; ++r) sb->bounds[r] = r <= n_ranks ? bounds[r] : n;
+    sb->st_first = st;
+    FDX_HIP(hipEventCreateWithFlags(&sb->ev_first, hipEventDisableTiming));
+    FDX_HIP(hipEventRecord(sb->ev_first, st));
+    if (!loc->meta_event) FDX_HIP(hipEventCreateWithFlags(&loc->meta_event, hipEventDisableTiming));
+    loc->shard_pending = true;
+    loc->keep_shard = sb.release();
+    // The second phase (~35 dependent launches, 0.12 ms of host time) is queued by the library's helper thread on the plan stream
+    // while this thread returns to the caller: a rank's critical path is the host's way to the sketch of its own rows, which does
+    // not need the graph.  Consumers join (graph_shard_join).  FDX_SHARD_EAGER=1: here and now, on the caller's stream (=2: on the
+    // plan stream); FDX_NO_HELPER_THREAD: by the first consumer.
+    if (const char* e = getenv("FDX_SHARD_EAGER")) return shard_queue_rest(loc, atoi(e) == 2 ? nullptr : st);   // 2: on the plan stream
+    if (!getenv("FDX_NO_HELPER_THREAD")) loc->keep_shard->ticket = helper_submit([loc] { return shard_queue_rest(loc, nullptr); });
+    return 0;
+}
+
+// the second phase of a pending shard build is queued when this returns (by the helper thread, or here)
+int graph_shard_join(const fdx_graph* gc) {
+    fdx_graph* g = const_cast<fdx_graph*>(gc);
+    if (!g || !g->shard_pending || !g->keep_shard) return 0;
+    fdx_shard_build* sb = g->keep_shard;
+    if (sb->ticket) {
+        const std::shared_ptr<HelperTicket> t = sb->ticket;
+        sb->ticket.reset();
+        FDX_TRY(helper_wait(t));
+    }
+    return shard_queue_rest(g, nullptr);         // no-op when queued
+}
+
+// Second phase of graph_shard_knn: symmetrisation of the own rows, halo, local ELL, tile tables, send lists, meta block - on `st`
+// (the library's plan stream when NULL), behind the first phase.
+int shard_queue_rest(fdx_graph* loc, hipStream_t st) {
+    fdx_shard_build* sb = loc->keep_shard;
+    if (!sb || sb->queued) return 0;
+    if (!st) st = library_plan_stream();
+    if (!st) st = sb->st_first;
+    PoolStream pool_stream(st);
+    if (st != sb->st_first) FDX_HIP(hipStreamWaitEvent(st, sb->ev_first, 0));
+    sb->queued = true;                           // whatever happens below, kernels of this phase may be in flight on `st`
+    fdx_graph_plan* plan = sb->plan;
+    plan->st = st;
+    const long long n = sb->n, lo = sb->lo, hi = sb->hi, n_own = hi - lo;
+    const int kk = sb->kk, n_ranks = sb->n_ranks;
     const int* nbr = sb->nbr.as<int>();
     const int* cnt = sb->cnt.as<int>();
 
@@ -2416,7 +2511,6 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     // (one per position of the whole order), per-tile / per-peer send counts (+ the closing entry of their scan), slice widths and
     // the reduction cells behind them
     const int nblk = ceil_div(n_own, 256);
-    loc->n_slices = (int)((n_own + 63) / 64);
     const int wblocks = std::min(SLICE_WIDTH_BLOCKS, std::max(1, ceil_div(loc->n_slices, 4)));
     auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
     const size_t z_indeg = 0, z_cursor = up16(z_indeg + (size_t)(n_own + 1) * 4), z_flag = up16(z_cursor + (size_t)n_own * 4),
@@ -2434,7 +2528,7 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     int* summary = reinterpret_cast<int*>(red + 2);
     long long* part = red + 4;
     ShardBounds bv;
-    for (int r = 0; r <= SHARD_MAX_RANKS; ++r) bv.b[r] = r <= n_ranks ? bounds[r] : n;
+    for (int r = 0; r <= SHARD_MAX_RANKS; ++r) bv.b[r] = sb->bounds[r];
 
     // ---- symmetrise the own rows (graph.py:80-81): everything indexed by the LOCAL row t = p - lo (pointers shifted by lo);
     // own rows and band rows in one launch each
@@ -2477,12 +2571,6 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     FDX_CHECK_LAUNCH();
 
     // ---- local sliced ELL, tile tables
-    loc->n = n_own;
-    loc->identity_order = false;
-    loc->global_lo = lo;
-    loc->world_n = n;
-    loc->n_tiles = nblk;
-    loc->shard_world = n_ranks;
     FDX_TRY(loc->slice_off.alloc((size_t)(loc->n_slices + 1) * 4));
     hipLaunchKernelGGL(slice_width_kernel, dim3(wblocks), dim3(256), 0, st, loc->deg.as<int>(), n_own, loc->n_slices, width, part);
     FDX_CHECK_LAUNCH();
@@ -2494,10 +2582,9 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     FDX_TRY(loc->tile_halo.alloc((size_t)nblk * FDX_TILE_HALO_CAP * 4));
     FDX_TRY(loc->tile_hcnt.alloc((size_t)nblk * 4));
     FDX_TRY(loc->ell_local.alloc(((size_t)cap + 16) * 64 * 2));
-    FDX_TRY(loc->perm.alloc((size_t)n_own * 4));
     hipLaunchKernelGGL(fill_ell_local_kernel, dim3(ceil_div(loc->n_slices, 4)), dim3(256), 0, st, sb->rows.as<int>(), kk,
                        sb->rev_off.as<int>(), loc->deg.as<int>(), loc->slice_off.as<int>(), lo, hi, loc->n_slices, sb->hscan.as<int>(), n,
-                       loc->ell.as<int>(), cap, plan->b.perm.as<int>(), loc->perm.as<int>());
+                       loc->ell.as<int>(), cap, plan->b.perm.as<int>(), (int*)nullptr);
     FDX_CHECK_LAUNCH();
     hipLaunchKernelGGL(tile_halo_kernel, dim3(nblk), dim3(256), 0, st, loc->ell.as<int>(), loc->deg.as<int>(), loc->slice_off.as<int>(),
                        n_own, loc->tile_halo.as<int>(), loc->tile_hcnt.as<int>(), loc->ell_local.as<unsigned short>(), cap, summary);
@@ -2521,7 +2608,6 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     FDX_TRY(loc->counts_dev.alloc(4 * sizeof(double)));
     if (!loc->meta_host) loc->meta_host = (long long*)pinned_block_get();
     FDX_REQUIRE(loc->meta_host != nullptr, "graph: pinned host block");
-    if (!loc->meta_event) FDX_HIP(hipEventCreateWithFlags(&loc->meta_event, hipEventDisableTiming));
     std::memset(loc->meta_host, 0, FDX_PINNED_BLOCK_BYTES);
     void* meta_dev = nullptr;
     FDX_HIP(hipHostGetDevicePointer(&meta_dev, loc->meta_host, 0));
@@ -2532,21 +2618,15 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     FDX_CHECK_LAUNCH();
     FDX_HIP(hipEventRecord(loc->meta_event, st));
     loc->meta_stream = st;
-    loc->shard_pending = true;
-    loc->n_total = n_own;                        // until graph_meta_sync
-    loc->keep_shard = sb.release();
     return 0;
 }
 
 // takes over what the queued shard build left in the pinned block
 static int shard_meta_sync(fdx_graph* g) {
+    FDX_TRY(graph_shard_join(g));
     FDX_HIP(hipEventSynchronize(g->meta_event));
     g->shard_pending = false;
-    if (g->keep_shard) {
-        if (g->keep_shard->plan) g->keep_shard->plan->kernels_done = true;
-        delete g->keep_shard;
-        g->keep_shard = nullptr;
-    }
+    if (g->keep_shard) { shard_build_drop(g->keep_shard); g->keep_shard = nullptr; }
     const long long* m = g->meta_host;
     const int W = g->shard_world;
     const long long rows = m[0], n_halo = m[6], n_send = m[7];
@@ -2576,6 +2656,9 @@ int graph_copy_perm(const fdx_graph* g, int* d_out, hipStream_t st) {
         hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(g->n, 256)), dim3(256), 0, st, d_out, g->n);
         FDX_CHECK_LAUNCH();
     } else {
+        // a shard build still pending: its first phase wrote the ids on the stream it was given
+        if (g->shard_pending && g->keep_shard && g->keep_shard->ev_first && st != g->keep_shard->st_first)
+            FDX_HIP(hipStreamWaitEvent(st, g->keep_shard->ev_first, 0));
         FDX_HIP(hipMemcpyAsync(d_out, g->perm.p, (size_t)g->n * 4, hipMemcpyDeviceToDevice, st));
     }
     return 0;

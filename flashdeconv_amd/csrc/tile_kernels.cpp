@@ -892,6 +892,16 @@ static int launch_tile_mode(const TileLaunch& L, int mode, int NWC, int TT, size
 }
 
 // H[:, 0..n) (type-major, row stride ldh) and row_sumsq[0..n) for the n spots listed by row_map (NULL = rows 0..n-1).
+// A persistent workgroup fills its compute unit (16 waves x 127 registers): a launch of 256 leaves nothing for kernels of another
+// stream until it ends.  A caller with latency-bound work to run beside the sketch (the second phase of a shard build) asks for
+// some units to be left alone; results do not depend on the grid (tiles are independent).
+static thread_local int t_reserve_cus = 0;
+int tile_sketch_reserve_cus(int cus) {
+    const int prev = t_reserve_cus;
+    t_reserve_cus = std::max(0, std::min(cus, 192));
+    return prev;
+}
+
 // Call only when tile_sketch_ok(...) holds.
 int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_map, long long n, int G, int d, int mode,
                        const SketchPlanDev& plan, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
@@ -920,7 +930,7 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
         if (!L.log_tab) return fail(FDX_ERR_HIP, "tile sketch: log table upload failed");
     }
     const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
-    const int grid = (int)std::min<long long>(n_tiles, 256);
+    const int grid = (int)std::min<long long>(n_tiles, 256 - t_reserve_cus);
     DevBuf xa;                                                              // wide form: X_sketch in operand order
     L.XA = nullptr;
     // narrow log modes: the float64 chain needs the registers the operands would take (operand copy in L2, fetched per
