@@ -16,6 +16,7 @@
 // coalesced loads, reduces the three inner products with wave shuffles and applies the rotation.  Rounds are
 // separated by workgroup barriers.  The reference matrix is tiny (K x G doubles), so this kernel is latency-, not
 // bandwidth-bound; it runs once per fit.
+#include <algorithm>
 #include <cstdlib>
 
 #include "fdx_internal.h"
@@ -733,13 +734,249 @@ static int launch_leverage_qr(const double* X, int K, int G, double reg, double*
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same CholeskyQR2 for 129 - 272 cell types: the (K - 1)^2 matrices no longer fit in LDS beside a stripe, so the K x K part lives
+// in global memory (L2-resident: 0.6 MB at 272 types) and every step is a kernel of its own -
+//   Z (Householder-deflated, centred genes) and the ridge rows sqrt(reg) I as extra columns      lev_big_z_kernel
+//   C = Z Z^T over all columns, 32 x 32 output blocks, columns in order (deterministic)           lev_big_gram_kernel
+//   C = L L^T in place, one workgroup of 1024, left-looking by block columns of 32, pivots watched  lev_big_chol_kernel
+//   Z <- L^-1 Z by stripes of 64 columns (stripe in LDS, L by scalar loads, blocked by 32 rows)   lev_big_forward_kernel<1>
+//   again Gram, Cholesky, then lev_g = |L2^-1 q1_g|^2                                             lev_big_forward_kernel<2>
+// (The Jacobi SVD passes take 0.65 s at 200 types; this takes a few milliseconds.)
+constexpr int LEV_BIG_MAX_K = 272;
+
+__global__ __launch_bounds__(256) void lev_big_z_kernel(const double* __restrict__ X, int K, int G, double reg, double* __restrict__ Z,
+                                                        int ldz, int nb) {
+    __shared__ double s_mean[LEV_STRIPE], s_shift[LEV_STRIPE];
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, m = K - 1;
+    const int b = blockIdx.x, c0 = b * LEV_STRIPE;
+    if (b >= nb) {                                                        // ridge rows 64 (b - nb) ... as columns nb * 64 + r
+        for (int k = q; k < m; k += 4) Z[(size_t)k * ldz + c0 + lane] = (k == (b - nb) * LEV_STRIPE + lane) ? sqrt(reg) : 0.0;
+        return;
+    }
+    const int g = c0 + lane;
+    if (tid < LEV_STRIPE) {
+        double mean = 0.0, shift = 0.0;
+        if (g < G) {
+            for (int k = 0; k < K; ++k) mean += X[(size_t)k * G + g];
+            mean /= (double)K;                                            // genes.py:264
+            double sc = 0.0;
+            for (int k = 0; k < K; ++k) sc += X[(size_t)k * G + g] - mean;
+            const double rk = sqrt((double)K);
+            const double xl = X[(size_t)m * G + g] - mean;
+            shift = (sc / rk + xl) / (rk + 1.0);                          // Householder v = 1/sqrt(K) + e_K applied to xc
+        }
+        s_mean[tid] = mean;
+        s_shift[tid] = shift;
+    }
+    __syncthreads();
+    const double mean = s_mean[lane], shift = s_shift[lane];
+    for (int k = q; k < m; k += 4) Z[(size_t)k * ldz + g] = (g < G) ? (X[(size_t)k * G + g] - mean) - shift : 0.0;
+}
+
+// C (m x m, lower triangle written) = Z Z^T over all ldz columns
+__global__ __launch_bounds__(256) void lev_big_gram_kernel(const double* __restrict__ Z, int ldz, int m, double* __restrict__ C) {
+    __shared__ double P[32][LEV_STRIPE + 1], Q[32][LEV_STRIPE + 1];
+    int bi = 0, rem = blockIdx.x;
+    while (rem > bi) { rem -= bi + 1; ++bi; }
+    const int bj = rem;                                                   // bj <= bi
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+    for (int col0 = 0; col0 < ldz; col0 += LEV_STRIPE) {
+        for (int e = tid; e < 32 * LEV_STRIPE; e += 256) {
+            const int r = e >> 6, j = e & 63;
+            const int pi = bi * 32 + r, qi = bj * 32 + r;
+            P[r][j] = pi < m ? Z[(size_t)pi * ldz + col0 + j] : 0.0;
+            Q[r][j] = qi < m ? Z[(size_t)qi * ldz + col0 + j] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < LEV_STRIPE; ++j) {
+            const double p0 = P[2 * ty][j], p1 = P[2 * ty + 1][j], q0 = Q[2 * tx][j], q1 = Q[2 * tx + 1][j];
+            a00 = fma(p0, q0, a00);
+            a01 = fma(p0, q1, a01);
+            a10 = fma(p1, q0, a10);
+            a11 = fma(p1, q1, a11);
+        }
+        __syncthreads();
+    }
+    const int r0 = bi * 32 + 2 * ty, c0 = bj * 32 + 2 * tx;
+    if (r0 < m && c0 <= r0) C[(size_t)r0 * m + c0] = a00;
+    if (r0 < m && c0 + 1 <= r0) C[(size_t)r0 * m + c0 + 1] = a01;
+    if (r0 + 1 < m && c0 <= r0 + 1 && c0 < m) C[(size_t)(r0 + 1) * m + c0] = a10;
+    if (r0 + 1 < m && c0 + 1 <= r0 + 1 && c0 + 1 < m) C[(size_t)(r0 + 1) * m + c0 + 1] = a11;
+}
+
+// lower Cholesky factor of C in place (global memory), one workgroup; Lout = the factor with zeros above the diagonal
+__global__ __launch_bounds__(1024) void lev_big_chol_kernel(double* C, int m, double* __restrict__ Lout, int* status, int final_stage) {
+    __shared__ double D[32][33];
+    __shared__ double s_thr;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        double mx = 0.0;
+        for (int i = tid; i < m; i += 64) mx = fmax(mx, C[(size_t)i * m + i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+        if (tid == 0) {
+            s_thr = mx * LEV_PIVOT_TOL;
+            s_bad = !(mx > 0.0) || !(mx < 1e300);
+        }
+    }
+    __syncthreads();
+    for (int J0 = 0; J0 < m; J0 += 32) {
+        const int w = min(32, m - J0), rows = m - J0;
+        // (a) the block column minus the contributions of the finished columns (k < J0: read only here)
+        for (int e = tid; e < rows * w; e += 1024) {
+            const int i = J0 + e / w, j = J0 + e % w;
+            if (j > i) continue;
+            const double* ri = C + (size_t)i * m;
+            const double* rj = C + (size_t)j * m;
+            double a0 = 0.0, a1 = 0.0;
+            for (int k = 0; k < J0; k += 2) {                            // J0 is a multiple of 32
+                a0 = fma(ri[k], rj[k], a0);
+                a1 = fma(ri[k + 1], rj[k + 1], a1);
+            }
+            C[(size_t)i * m + j] -= a0 + a1;
+        }
+        __threadfence();
+        __syncthreads();
+        // (b) the diagonal block, in LDS
+        if (tid < w * w) {
+            const int i = tid / w, j = tid % w;
+            D[i][j] = (j <= i) ? C[(size_t)(J0 + i) * m + J0 + j] : 0.0;
+        }
+        __syncthreads();
+        for (int j = 0; j < w; ++j) {
+            double d = D[j][j];
+            const bool small = !(d > s_thr);                              // also NaN
+            if (small) d = s_thr > 0.0 ? s_thr : 1.0;
+            const double sd = sqrt(d);
+            __syncthreads();                                              // everyone has read the pivot
+            if (tid == 0) {
+                D[j][j] = sd;
+                if (small) s_bad = 1;
+            }
+            if (tid > j && tid < w) D[tid][j] /= sd;
+            __syncthreads();
+            const int i = tid >> 5, k = tid & 31;
+            if (i < w && k <= i && k > j) D[i][k] -= D[i][j] * D[k][j];
+            __syncthreads();
+        }
+        if (tid < w * w) {
+            const int i = tid / w, j = tid % w;
+            if (j <= i) C[(size_t)(J0 + i) * m + J0 + j] = D[i][j];
+        }
+        // (c) the rows below the block: x L_JJ^T = c, one thread per row (its own entries only)
+        for (int i = J0 + w + tid; i < m; i += 1024) {
+            double* r = C + (size_t)i * m + J0;
+            for (int j = 0; j < w; ++j) {
+                double sv = r[j];
+                for (int k = 0; k < j; ++k) sv = fma(-r[k], D[j][k], sv);
+                r[j] = sv / D[j][j];
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    for (int e = tid; e < m * m; e += 1024) {
+        const int i = e / m, j = e - i * m;
+        Lout[e] = (j <= i) ? C[e] : 0.0;
+    }
+    if (tid == 0) {
+        if (s_bad) *status = 2;
+        else if (final_stage && *status == 0) *status = 1;
+    }
+}
+
+// STAGE 1: columns [64 b, 64 b + 64) of Z <- L^-1 (those columns).  STAGE 2: lev_g = |L^-1 z_g|^2 and the stripe sums.
+template <int STAGE>
+__global__ __launch_bounds__(256) void lev_big_forward_kernel(double* __restrict__ Z, int ldz, int m, int G, const double* __restrict__ L,
+                                                              double* __restrict__ lev, double* __restrict__ bsum) {
+    extern __shared__ __attribute__((aligned(16))) double lev_big_lds[];
+    double (*tile)[LEV_STRIPE + 1] = reinterpret_cast<double (*)[LEV_STRIPE + 1]>(lev_big_lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c0 = blockIdx.x * LEV_STRIPE;
+    for (int e = tid; e < m * LEV_STRIPE; e += 256) {
+        const int k = e >> 6, j = e & 63;
+        tile[k][j] = Z[(size_t)k * ldz + c0 + j];
+    }
+    __syncthreads();
+    for (int I0 = 0; I0 < m; I0 += 32) {
+        const int w = min(32, m - I0);
+        if (I0 > 0) {                                                     // rows of the block minus the finished rows, 8 rows per wave
+            for (int i = I0 + wave; i < I0 + w; i += 4) {
+                const double* Li = L + (size_t)i * m;
+                double s0 = tile[i][lane], s1 = 0.0;
+                for (int k = 0; k < I0; k += 2) {
+                    s0 = fma(-Li[k], tile[k][lane], s0);
+                    s1 = fma(-Li[k + 1], tile[k + 1][lane], s1);
+                }
+                tile[i][lane] = s0 + s1;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                                  // inside the block: a lane's own column only
+            for (int i = I0; i < I0 + w; ++i) {
+                const double* Li = L + (size_t)i * m;
+                double sv = tile[i][lane];
+                for (int k = I0; k < i; ++k) sv = fma(-Li[k], tile[k][lane], sv);
+                tile[i][lane] = sv / Li[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (STAGE == 1) {
+        for (int e = tid; e < m * LEV_STRIPE; e += 256) {
+            const int k = e >> 6, j = e & 63;
+            Z[(size_t)k * ldz + c0 + j] = tile[k][j];
+        }
+    } else if (wave == 0) {
+        double l = 0.0;
+        if (c0 + lane < G) {
+            for (int k = 0; k < m; ++k) l = fma(tile[k][lane], tile[k][lane], l);
+            lev[c0 + lane] = l;
+        }
+        l = wsum(l);
+        if (lane == 0) bsum[blockIdx.x] = l;
+    }
+}
+
+static int launch_leverage_qr_big(const double* X, int K, int G, double reg, double* lev, int* sweeps, double* scratch, hipStream_t st) {
+    const int m = K - 1, nb = (G + LEV_STRIPE - 1) / LEV_STRIPE, nr = (m + LEV_STRIPE - 1) / LEV_STRIPE, gb = (G + 255) / 256;
+    const int ldz = (nb + nr) * LEV_STRIPE;
+    double* Z = scratch;
+    double* C = Z + (size_t)m * ldz;
+    double* L1 = C + (size_t)m * m;
+    double* L2 = L1 + (size_t)m * m;
+    double* bsum = L2 + (size_t)m * m;
+    const int tb = (m + 31) / 32, gram_blocks = tb * (tb + 1) / 2;
+    const size_t lds = (size_t)m * (LEV_STRIPE + 1) * sizeof(double);
+    FDX_HIP(hipFuncSetAttribute((const void*)lev_big_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FDX_HIP(hipFuncSetAttribute((const void*)lev_big_forward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FDX_HIP(hipMemsetAsync(sweeps, 0, 8 * sizeof(int), st));             // [7]: 1 = done, 2 = refused
+    hipLaunchKernelGGL(lev_big_z_kernel, dim3(nb + nr), dim3(256), 0, st, X, K, G, reg, Z, ldz, nb);
+    hipLaunchKernelGGL(lev_big_gram_kernel, dim3(gram_blocks), dim3(256), 0, st, Z, ldz, m, C);
+    hipLaunchKernelGGL(lev_big_chol_kernel, dim3(1), dim3(1024), 0, st, C, m, L1, sweeps + 7, 0);
+    hipLaunchKernelGGL(lev_big_forward_kernel<1>, dim3(nb + nr), dim3(256), lds, st, Z, ldz, m, G, L1, lev, bsum);
+    hipLaunchKernelGGL(lev_big_gram_kernel, dim3(gram_blocks), dim3(256), 0, st, Z, ldz, m, C);
+    hipLaunchKernelGGL(lev_big_chol_kernel, dim3(1), dim3(1024), 0, st, C, m, L2, sweeps + 7, 1);
+    hipLaunchKernelGGL(lev_big_forward_kernel<2>, dim3(nb), dim3(256), lds, st, Z, ldz, m, G, L2, lev, bsum);
+    hipLaunchKernelGGL(lev_normalise_kernel, dim3(gb), dim3(256), 0, st, lev, G, bsum, nb, reg);
+    FDX_CHECK_LAUNCH();
+    return 0;
+}
+
 bool leverage_qr_applies(int K, int G) {
-    return K >= 2 && K <= 128 && G >= 1 && !getenv("FDX_LEV_NO_QR") && !getenv("FDX_LEV_ONE_WG");
+    return K >= 2 && K <= LEV_BIG_MAX_K && G >= 1 && !getenv("FDX_LEV_NO_QR") && !getenv("FDX_LEV_ONE_WG") &&
+           (K <= 128 || !getenv("FDX_LEV_NO_QR_BIG"));
 }
 
 size_t leverage_scratch_doubles(int K, int G) {
     const size_t nb = (size_t)(G + LEV_STRIPE - 1) / LEV_STRIPE;
-    return (nb + 2) * K * K + 2 * (size_t)K * K + nb + 16;               // the larger of the two routes' layouts
+    const size_t small = (nb + 2) * K * K + 2 * (size_t)K * K + nb + 16;   // the larger of the Jacobi / Cholesky-QR layouts up to 128 types
+    const size_t nr = (size_t)(K + LEV_STRIPE - 1) / LEV_STRIPE;
+    const size_t big = (size_t)K * (nb + nr) * LEV_STRIPE + 3 * (size_t)K * K + nb + 16;
+    return std::max(small, big);
 }
 
 static int launch_leverage_multi(const double* X, int K, int G, double reg, double* work, double* sig2, double* lev,
@@ -772,7 +1009,8 @@ int launch_leverage(const double* X, int K, int G, double reg, double* work, dou
                     double* scratch, hipStream_t st, int route) {
     if (K <= 0 || G <= 0) return fail(FDX_ERR_INVALID, "leverage: empty reference matrix");
     if (route == LEV_ROUTE_QR) {
-        if (!leverage_qr_applies(K, G) || !scratch) return fail(FDX_ERR_INVALID, "leverage: the Cholesky-QR route needs 2 <= K <= 128");
+        if (!leverage_qr_applies(K, G) || !scratch) return fail(FDX_ERR_INVALID, "leverage: the Cholesky-QR route needs 2 <= K <= 272");
+        if (K > 128) return launch_leverage_qr_big(X, K, G, reg, lev, sweeps, scratch, st);
         return launch_leverage_qr(X, K, G, reg, work, lev, sweeps, scratch, st);
     }
     if (K <= 64 && K >= 2 && scratch && !getenv("FDX_LEV_ONE_WG"))

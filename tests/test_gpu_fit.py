@@ -349,6 +349,60 @@ def test_leverage_cholesky_qr_route_refuses_rank_deficient_signatures(capfd, mon
     np.testing.assert_allclose(got, orc.leverage_scores(X), rtol=1e-8, atol=1e-15)
 
 
+@pytest.mark.parametrize("K,G,cond", [(129, 700, 1e2), (200, 3000, 1e3), (150, 2000, 1e4), (272, 1500, 1e2), (140, 64, 5.0)])
+def test_leverage_above_128_types_takes_the_blocked_cholesky_qr(K, G, cond, capfd, monkeypatch):
+    """129 - 272 cell types (utils/genes.py:238-290 takes any K): CholeskyQR2 with the K x K part in global memory
+    (leverage_kernels.cpp, lev_big_*) against LAPACK through the oracle; a few milliseconds where the Jacobi SVD passes took
+    0.15 - 2 s; rank-deficient signatures are refused and fall back to those passes."""
+    import time
+    from flashdeconv_amd.utils.genes import compute_leverage_scores
+    rs = np.random.RandomState(K + G)
+    r = min(K, G)
+    U, _ = np.linalg.qr(rs.randn(G, r))
+    Vt, _ = np.linalg.qr(rs.randn(K, K))
+    X = np.ascontiguousarray(((U * (np.geomspace(1.0, 1.0 / cond, r) * 50.0)) @ Vt[:r] + rs.rand(G, 1) * 3.0).T)
+    want = orc.leverage_scores(X)
+    monkeypatch.setenv("FDX_DEBUG", "1")
+    got = compute_leverage_scores(X)
+    assert "route=cholesky-qr" in capfd.readouterr().err
+    np.testing.assert_allclose(got, want, rtol=2e-8 * max(1.0, cond / 1e4), atol=1e-15)
+    if K == 200:
+        monkeypatch.delenv("FDX_DEBUG")
+        t0 = time.perf_counter()
+        compute_leverage_scores(X)
+        assert time.perf_counter() - t0 < 5e-3                      # round 4: ~650 ms
+        monkeypatch.setenv("FDX_DEBUG", "1")
+    if K == 129:
+        X = rs.gamma(2.0, 3.0, size=(K, G))
+        X[5] = X[2]
+        X[7] = 0.5 * (X[2] + X[3])
+        got = compute_leverage_scores(X)
+        assert "route=jacobi-svd" in capfd.readouterr().err
+        np.testing.assert_allclose(got, orc.leverage_scores(X), rtol=1e-8, atol=1e-15)
+
+
+def test_sketch_dim_2048_dense_and_csr_against_the_oracle():
+    """sketch_dim above the one-kernel forms' 1024 / 1056 (core/sketching.py takes any d): dense and CSR rows take the two-kernel
+    sketch -> H path."""
+    from flashdeconv_amd import FlashDeconv
+    rs = np.random.RandomState(5)
+    n, G, K, d = 700, 2600, 9, 2048
+    X = np.exp(rs.randn(K, G) * 0.7)
+    B = rs.dirichlet(np.ones(K), size=n)
+    Y = rs.poisson(B @ X * 3.0) * (rs.rand(n, G) < 0.35)
+    Y[:, 0] += 1
+    coords = rs.rand(n, 2) * 30
+    Ys = sparse.csr_matrix(Y.astype(np.float64))
+    for pre in ("log_cpm", "raw"):
+        kw = dict(sketch_dim=d, preprocess=pre, n_hvg=3000, n_markers_per_type=5, max_iter=15, tol=1e-9)
+        want = orc.fit(Ys, X, coords, sketch_dim=d, preprocess_method=pre, n_hvg=3000, n_markers_per_type=5, max_iter=15, tol=1e-9,
+                       graph="kdtree")
+        for Yin in (Ys, Y.astype(np.float64)):
+            m = FlashDeconv(**kw).fit(Yin, X, coords)
+            assert m.info_["n_iterations"] == want["info"]["n_iterations"]
+            assert rel_fro(m.beta_, want["beta"]) < 1e-8 and rel_fro(m.proportions_, want["proportions"]) < 1e-8
+
+
 def test_seed_reproducibility_and_errors():
     from flashdeconv_amd import FlashDeconv
     g = load_golden("fit_counts_100x500x5_d64.npz")
