@@ -357,7 +357,7 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     // ~50 us, whatever its size) rows lo .. lo + n_direct - 1 followed by the first min(*row_count, list_cap) listed rows; ties and
     // far walks are counted for the own rows only
     long long p = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    bool listed = false;
+    bool listed = false, ghost = false;
     if (n_direct >= 0) {
         const long long i = p - lo;
         if (i >= n_direct) {
@@ -369,7 +369,11 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     } else if (row_list) {
         if (p >= hi || p >= (long long)*row_count) return;
         p = row_list[p];
-    } else if (p >= hi) return;
+    } else if (p >= hi) {
+        if (!indeg) return;
+        ghost = true;                                     // whole-graph build: the block's in-degree counters meet at barriers below -
+        p = hi - 1;                                       // a lane past the end walks as the last row and writes nothing
+    }
     const double px = sc[p], py = sc[(size_t)n + p], pz = sc[2 * (size_t)n + p];
     const double pc[3] = {px, py, pz};
     int c[3];
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     // the index-ordered route.
     const bool tie = (KMAX > kk) ? (next == thr && thr < INFINITY) : true;
     if (tie_count) {
-        const unsigned long long m = __ballot(tie && !listed);
+        const unsigned long long m = __ballot(tie && !listed && !ghost);
         if (m != 0ULL && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(tie_count, (int)__popcll(m));
     }
     if (__ballot(tie) != 0ULL) {
@@ -564,10 +568,33 @@ __global__ __launch_bounds__(128) void knn_kernel(const double* __restrict__ sc,
     // stay, as in the reference.  indeg != NULL (whole graph in one piece): the symmetrisation's first pass rides along -
     // every list entry counts itself into its target's in-degree, and the number it draws is its place in the target's
     // reverse list (all counters asked at once: one round trip)
+    // Most targets are rows of the same block (128 consecutive rows of the Morton order: an ~11 x 11 patch): those count in LDS
+    // and the block adds each row's sum to the global counter once - 6 returning atomics per row on L2 became ~2.5.
     int arr[KMAX];
     if (indeg) {
+        __shared__ int s_loc[128], s_base[128];
+        const long long blk0 = lo + blockIdx.x * (long long)blockDim.x;
+        s_loc[tid] = 0;
+        __syncthreads();
+        constexpr int LOCAL = 0x40000000;
 #pragma unroll
-        for (int s = 0; s < KMAX; ++s) arr[s] = (s < kk && bq[s] >= 0 && bq[s] != (int)p) ? atomicAdd(&indeg[bq[s]], 1) : 0;
+        for (int s = 0; s < KMAX; ++s) {
+            arr[s] = 0;
+            if (s < kk && bq[s] >= 0 && bq[s] != (int)p && !ghost) {
+                const long long t = (long long)bq[s] - blk0;
+                arr[s] = (t >= 0 && t < 128) ? (atomicAdd(&s_loc[t], 1) | LOCAL) : atomicAdd(&indeg[bq[s]], 1);
+            }
+        }
+        __syncthreads();
+        {
+            const int c = s_loc[tid];
+            s_base[tid] = c > 0 ? atomicAdd(&indeg[blk0 + tid], c) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+            if (arr[s] & LOCAL) arr[s] = s_base[bq[s] - blk0] + (arr[s] & ~LOCAL);
+        if (ghost) return;
     }
     int cnt = 0;
 #pragma unroll

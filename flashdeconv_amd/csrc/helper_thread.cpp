@@ -6,6 +6,7 @@
 // The thread only ever queues device work (pool allocations, launches, event records): it never waits for the device.
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <thread>
 
@@ -35,8 +36,13 @@ struct Helper {
             std::string err = rc ? "helper thread: hipSetDevice failed" : "";
             if (!rc) {
                 set_error("");
-                rc = job.fn();
-                if (rc) err = get_error();
+                try {
+                    rc = job.fn();
+                    if (rc) err = get_error();
+                } catch (const std::exception& e) {       // e.g. bad_alloc: an error code for the waiting thread, not std::terminate
+                    rc = FDX_ERR_INVALID;
+                    err = std::string("helper thread: ") + e.what();
+                }
             }
             {
                 std::lock_guard<std::mutex> lk(job.ticket->mu);
@@ -73,10 +79,20 @@ std::shared_ptr<HelperTicket> helper_submit(std::function<int()> fn) {
         return ticket;
     }
     Helper& h = helper();
-    {
+    bool queued = false;
+    try {
         std::lock_guard<std::mutex> lk(h.mu);
-        if (!h.th.joinable()) h.th = std::thread([&h] { h.run(); });
-        h.q.push_back(Job{std::move(fn), ticket, dev});
+        if (!h.th.joinable()) h.th = std::thread([&h] { h.run(); });   // may throw (thread limit of a container)
+        h.q.push_back(Job{fn, ticket, dev});
+        queued = true;
+    } catch (...) {
+    }
+    if (!queued) {                                        // no helper: the caller does the work itself, now
+        set_error("");
+        ticket->rc = fn();
+        if (ticket->rc) ticket->err = get_error();
+        ticket->done = true;
+        return ticket;
     }
     h.cv.notify_one();
     return ticket;
