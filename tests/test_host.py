@@ -345,7 +345,7 @@ def test_bench_sweep_chunk_mirrors_the_kernel_table():
 
 
 @pytest.mark.parametrize("case", ["square", "square_scaled", "hex", "cube3d", "random2d", "random3d", "line", "duplicates",
-                                  "square_shuffled", "rect_large"])
+                                  "square_shuffled", "rect_large", "square_big", "random_big"])
 def test_ckdtree_order_restatement_matches_scipy(case):
     """fdx_ckdtree_knn (csrc/kdtree_order.cpp) is a host restatement of scipy.spatial.cKDTree's build and k-nearest query
     ORDER - what decides the reference's neighbour graph when distances tie exactly (flashdeconv/utils/graph.py:60-63).
@@ -367,6 +367,9 @@ def test_ckdtree_order_restatement_matches_scipy(case):
         "duplicates": (np.concatenate([rs.rand(300, 2), rs.rand(100, 2).repeat(3, axis=0)]), 5),
         "square_shuffled": (sq[rs.permutation(len(sq))], 7),
         "rect_large": (np.stack(np.meshgrid(np.arange(211.0), np.arange(97.0), indexing="ij"), -1).reshape(-1, 2), 7),
+        # above 32768 points the subtrees are built on threads, above 4096 per node on contiguous (coordinate, index) pairs
+        "square_big": (np.stack(np.meshgrid(np.arange(310.0), np.arange(300.0), indexing="ij"), -1).reshape(-1, 2), 7),
+        "random_big": (np.round(rs.rand(70000, 2) * 40.0, 1), 7),          # many equal coordinates, a few coincident points
     }[case]
     coords = np.ascontiguousarray(coords, dtype=np.float64)
     n, dim = coords.shape
