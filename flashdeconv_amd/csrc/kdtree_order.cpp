@@ -63,6 +63,11 @@ struct KdTree {
 // afterwards (the index array is partitioned in place - disjoint ranges; the NUMBERING of the nodes differs from a serial build,
 // which nothing reads: queries follow the less / greater links).  The serial build was 130 of the 145 ms the tie remedy spent on
 // the host for a million lattice points: its top levels are cache-missing passes over all points.
+static long long kd_fork_min() {
+    static const long long v = getenv("FDX_KDTREE_FORK_MIN") ? std::max(1024, atoi(getenv("FDX_KDTREE_FORK_MIN"))) : 32768;
+    return v;
+}
+
 long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long long end, double* maxes, double* mins, int par_depth) {
     const int m = t.m;
     const double* data = t.data;
@@ -117,7 +122,7 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
     }
     long long less = -1, greater = -1;
     bool forked = false;
-    if (par_depth > 0 && end - start > 32768) {
+    if (par_depth > 0 && end - start > kd_fork_min()) {
         std::vector<KdNode> sub;
         long long sub_root = -1;
         bool sub_ok = true;
@@ -313,7 +318,9 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
         }
     t.nodes.reserve((size_t)(2 * (n / 8) + 16));
     std::vector<double> mx(t.maxes), mn(t.mins);
-    const int par = getenv("FDX_KDTREE_SERIAL_BUILD") ? 0 : 5;       // up to 32 subtrees in flight
+    int par = 5;                                                     // up to 32 subtrees in flight
+    if (const char* e = getenv("FDX_KDTREE_PAR_DEPTH")) par = std::max(0, std::min(10, atoi(e)));
+    if (getenv("FDX_KDTREE_SERIAL_BUILD")) par = 0;
     kd_build(t, t.nodes, 0, n, mx.data(), mn.data(), par);
 }
 
