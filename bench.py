@@ -245,6 +245,28 @@ def stage_record(stage, ms_per_step):
     return out
 
 
+def host_cpu_budget():
+    """CPUs this process may keep busy: its affinity mask, cut to the control group's CPU bandwidth quota (a GPU box of this pool
+    shows 256 CPUs and grants 16: threads beyond the quota only get the process throttled)."""
+    cpus = float(len(os.sched_getaffinity(0)))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+        if q != "max" and float(period) > 0:
+            cpus = min(cpus, float(q) / float(period))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = float(f.read())
+            if q > 0 and period > 0:
+                cpus = min(cpus, q / period)
+        except (OSError, ValueError):
+            pass
+    return max(1, int(round(cpus)))
+
+
 def cpu_baseline(n_cpu, G, K, d, seed=0):
     """Oracle (CPU restatement of the reference path) on a bounded sample, all host cores for the OpenMP BCD sweep."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -256,7 +278,12 @@ def cpu_baseline(n_cpu, G, K, d, seed=0):
     B /= B.sum(axis=1, keepdims=True)
     Y = B @ X + 0.1 * rs.randn(n_cpu, G)
     coords = rs.rand(n_cpu, 2) * np.sqrt(n_cpu)
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cpu_budget()
+    try:                                       # the C sweep's OpenMP team: as many threads as the process may actually run
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(cores))
+    except OSError:
+        pass
     t0 = time.perf_counter()
     out = orc.fit(Y, X, coords, sketch_dim=d, preprocess_method="raw", n_hvg=G, graph="kdtree", engine="c")
     dt = time.perf_counter() - t0

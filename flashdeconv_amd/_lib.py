@@ -176,6 +176,7 @@ SIGNATURES = {
     "fdx_graph_knn_far": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "fdx_ckdtree_knn": (c_int, [p_double, c_i64, c_i32, c_i32, c_void_p, c_void_p]),
     "fdx_ckdtree_knn_rows": (c_int, [p_double, c_i64, c_i32, c_i32, p_i64, c_i64, c_void_p]),
+    "fdx_graph_plan_set_ckdtree_lists_dev": (c_int, [c_void_p, p_double, c_void_p, c_i64, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "fdx_graph_plan_order_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdx_graph_plan_lists_replaced": (c_int, [c_void_p]),
     "fdx_graph_plan_set_lists_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),

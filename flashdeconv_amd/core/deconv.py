@@ -87,7 +87,7 @@ def reference_tie_graph(c_ptr, coords_host, n, dim, k):
     symmetrised / laid out by fdx_graph_from_knn_lists_dev.  The graph therefore keeps the Morton order and the sweep tiles of
     any other device-built graph (the round-4 route went through a host adjacency in the caller's order: A + A^T in scipy, an
     untiled upload).  Reference: utils/graph.py:60-81."""
-    from ..utils.graph import ckdtree_knn_lists
+    from ..utils.graph import _ckdtree_restatement_matches_scipy
     lib = _lib.load()
     tr = [("start", time.perf_counter())] if os.environ.get("FDX_TRACE_HOST") else None
 
@@ -101,11 +101,12 @@ def reference_tie_graph(c_ptr, coords_host, n, dim, k):
         _lib.check(lib.fdx_graph_knn_lists_dev(c_ptr, n, dim, int(k), 0, n, nbr.ptr, cnt.ptr, None, ctypes.byref(plan)))
         try:
             mark("device lists + order")
-            lists = ckdtree_knn_lists(coords_host, k)                       # (n, kk) caller ids, nearest first, self included
-            mark("host tree: build + queries")
-            # to solver positions, self dropped, at the rows' positions: on the device (numpy took 55 ms per million spots for this)
-            _lib.check(lib.fdx_graph_plan_set_lists_dev(plan, lists.ctypes.data, None, n, nbr.ptr, cnt.ptr, None))
-            mark("lists to positions + upload")
+            # the restated tree is built on the host, its queries run on the device (1-3 coordinates), and the answers go - as solver
+            # positions, self dropped - to the rows' positions without leaving the device
+            _ckdtree_restatement_matches_scipy()
+            ch = np.ascontiguousarray(coords_host, dtype=np.float64)
+            _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, _lib.ptr_f64(ch), c_ptr, n, dim, None, 0, nbr.ptr, cnt.ptr, None))
+            mark("host tree + device queries + lists to positions")
         except Exception:
             dead = ctypes.c_void_p()                                           # the plan owns device buffers: consume it
             lib.fdx_graph_from_knn_lists_dev(plan, nbr.ptr, cnt.ptr, 0, 0, None, ctypes.byref(dead))

@@ -94,6 +94,29 @@ int fdx_graph_plan_set_lists_dev(fdx_graph_plan* plan, const int64_t* ids_host, 
     return graph_plan_set_lists(plan, (const long long*)ids_host, (const long long*)rows_host, n_rows, nbr_dev, cnt_dev, (hipStream_t)stream);
 }
 
+int fdx_graph_plan_set_ckdtree_lists_dev(fdx_graph_plan* plan, const double* coords_host, const double* coords_dev, int64_t n,
+                                         int32_t dim, const int64_t* rows_host, int64_t n_rows, int32_t* nbr_dev, int32_t* cnt_dev,
+                                         void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
+    FDX_REQUIRE(plan && coords_host && coords_dev && nbr_dev && cnt_dev, "fdx_graph_plan_set_ckdtree_lists_dev: null argument");
+    FDX_REQUIRE(n >= 1 && dim >= 1 && dim <= 8 && n_rows >= 0 && (n_rows == 0 || rows_host),
+                "fdx_graph_plan_set_ckdtree_lists_dev: bad arguments (1 to 8 coordinates)");
+    const int kk = graph_plan_kk(plan);
+    const long long nq = rows_host ? n_rows : n;
+    if (rows_host)
+        for (int64_t j = 0; j < n_rows; ++j) FDX_REQUIRE(rows_host[j] >= 0 && rows_host[j] < n, "fdx_graph_plan_set_ckdtree_lists_dev: row index out of range");
+    if (nq == 0) return graph_plan_lists_replaced(plan);
+    DevBuf d_ids;
+    FDX_TRY(d_ids.alloc((size_t)nq * kk * 8));
+    try {
+        FDX_TRY(ckdtree_lists_device(coords_host, coords_dev, n, dim, kk, (const long long*)rows_host, nq, d_ids.as<long long>(), st));
+    } catch (...) {
+        return fail(FDX_ERR_INVALID, "fdx_graph_plan_set_ckdtree_lists_dev: out of memory");
+    }
+    return graph_plan_set_lists_device(plan, d_ids.as<long long>(), (const long long*)rows_host, nq, nbr_dev, cnt_dev, st);
+}
+
 int fdx_graph_plan_lists_replaced(fdx_graph_plan* plan) {
     FDX_REQUIRE(plan != nullptr, "fdx_graph_plan_lists_replaced: null plan");
     return graph_plan_lists_replaced(plan);

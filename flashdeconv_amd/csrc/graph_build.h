@@ -20,6 +20,12 @@ int graph_plan_lists_replaced(fdx_graph_plan* plan);   // nbr / cnt were overwri
 // replace list rows by the answers of a k-nearest query in caller ids (host arrays): mapped to solver positions on the device
 int graph_plan_set_lists(fdx_graph_plan* plan, const long long* ids_host, const long long* rows_host, long long n_rows, int* nbr,
                          int* cnt, hipStream_t st);
+int graph_plan_set_lists_device(fdx_graph_plan* plan, const long long* ids_dev, const long long* rows_host, long long n_rows, int* nbr,
+                                int* cnt, hipStream_t st);
+// kdtree_order.cpp: the reference's k-nearest lists (scipy cKDTree's tie order) for rows_host (NULL: all points) into ids_dev
+// (n_rows x kk int64, caller ids, nearest first, self included, -1 padded); tree on the host, queries on the device
+int ckdtree_lists_device(const double* coords_host, const double* coords_dev, long long n, int dim, int kk, const long long* rows_host,
+                         long long n_rows, long long* ids_dev, hipStream_t st);
 int graph_plan_order(const fdx_graph_plan* plan, int* d_perm_out, int* d_rank_out, hipStream_t st);   // device copies of perm / rank (either may be NULL)
 // rows [lo, hi) (solver positions) of the radius graph, the others left empty; [0, n) = the whole graph
 int graph_build_radius(const double* d_coords, long long n, int dim, double radius, long long lo, long long hi, fdx_graph* g,

@@ -1740,6 +1740,24 @@ int graph_plan_set_lists(fdx_graph_plan* plan, const long long* ids_host, const 
     return graph_plan_lists_replaced(plan);
 }
 
+// the same with the query answers already on the device (ids_dev: n_rows x kk int64; rows_host NULL: row r answers for caller id r)
+int graph_plan_set_lists_device(fdx_graph_plan* plan, const long long* ids_dev, const long long* rows_host, long long n_rows, int* nbr,
+                                int* cnt, hipStream_t st) {
+    FDX_REQUIRE(n_rows >= 0 && n_rows <= plan->n, "graph: more list rows than spots");
+    if (n_rows == 0) return graph_plan_lists_replaced(plan);
+    DevBuf d_rows;
+    if (rows_host) {
+        for (long long r = 0; r < n_rows; ++r) FDX_REQUIRE(rows_host[r] >= 0 && rows_host[r] < plan->n, "graph: list row out of range");
+        FDX_TRY(d_rows.alloc((size_t)n_rows * 8));
+        FDX_HIP(hipMemcpyAsync(d_rows.p, rows_host, (size_t)n_rows * 8, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(lists_from_ids_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, st, ids_dev,
+                       rows_host ? d_rows.as<long long>() : (const long long*)nullptr, n_rows, plan->kk, plan->b.rank.as<int>(), nbr, cnt);
+    FDX_CHECK_LAUNCH();
+    FDX_HIP(hipStreamSynchronize(st));            // rows_host is the caller's
+    return graph_plan_lists_replaced(plan);
+}
+
 int graph_plan_order(const fdx_graph_plan* plan, int* d_perm_out, int* d_rank_out, hipStream_t st) {
     if (d_perm_out) FDX_HIP(hipMemcpyAsync(d_perm_out, plan->b.perm.p, (size_t)plan->n * 4, hipMemcpyDeviceToDevice, st));
     if (d_rank_out) FDX_HIP(hipMemcpyAsync(d_rank_out, plan->b.rank.p, (size_t)plan->n * 4, hipMemcpyDeviceToDevice, st));

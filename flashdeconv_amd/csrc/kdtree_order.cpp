@@ -63,6 +63,31 @@ struct KdTree {
 // afterwards (the index array is partitioned in place - disjoint ranges; the NUMBERING of the nodes differs from a serial build,
 // which nothing reads: queries follow the less / greater links).  The serial build was 130 of the 145 ms the tie remedy spent on
 // the host for a million lattice points: its top levels are cache-missing passes over all points.
+// Host threads this process may keep busy: the hardware's count, cut to the CPU bandwidth quota of the control group the process
+// runs in (containers: /sys/fs/cgroup/cpu.max or the v1 pair).  A burst on more threads than the quota covers gets the whole
+// process - its main thread included - throttled for the rest of the scheduler period: on a 256-thread host with a 16-CPU quota
+// the 128 query threads of one tie remedy cost the NEXT calls 10-30 ms stalls in unrelated places (measured; round 5).
+static unsigned host_cpu_budget() {
+    static const unsigned budget = [] {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw == 0) hw = 1;
+        double cpus = (double)hw;
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            long long period = 0;
+            if (std::fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) cpus = std::min(cpus, atof(q) / (double)period);
+            std::fclose(f);
+        } else {
+            long long quota = -1, period = 0;
+            if (FILE* fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(fq, "%lld", &quota) != 1) quota = -1; std::fclose(fq); }
+            if (FILE* fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(fp, "%lld", &period) != 1) period = 0; std::fclose(fp); }
+            if (quota > 0 && period > 0) cpus = std::min(cpus, (double)quota / (double)period);
+        }
+        return (unsigned)std::max(1.0, std::floor(cpus + 0.5));
+    }();
+    return budget;
+}
+
 static long long kd_fork_min() {
     static const long long v = getenv("FDX_KDTREE_FORK_MIN") ? std::max(1024, atoi(getenv("FDX_KDTREE_FORK_MIN"))) : 32768;
     return v;
@@ -318,7 +343,8 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
         }
     t.nodes.reserve((size_t)(2 * (n / 8) + 16));
     std::vector<double> mx(t.maxes), mn(t.mins);
-    int par = 5;                                                     // up to 32 subtrees in flight
+    int par = 5;                                                     // up to 32 subtrees in flight ...
+    while (par > 0 && (1u << par) > host_cpu_budget()) --par;        // ... but no more than the process may run at once
     if (const char* e = getenv("FDX_KDTREE_PAR_DEPTH")) par = std::max(0, std::min(10, atoi(e)));
     if (getenv("FDX_KDTREE_SERIAL_BUILD")) par = 0;
     kd_build(t, t.nodes, 0, n, mx.data(), mn.data(), par);
@@ -344,7 +370,7 @@ int ckdtree_query_host(const KdTree& t, int32_t kk, const int64_t* rows, int64_t
             kd_query_one(t, coords + p * dim, kk, idx_out + i * kk, pool, q, nb);
         }
     };
-    unsigned nt = std::thread::hardware_concurrency();
+    unsigned nt = host_cpu_budget();
     if (const char* e = getenv("FDX_KDTREE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
     nt = (unsigned)std::min<long long>(std::max(1u, std::min(nt, 128u)), std::max<long long>(1, nq / 4096));
     // a thread that cannot be started (process limits, W ranks x 32 threads) or a failed allocation inside a worker must not end
@@ -382,6 +408,279 @@ int ckdtree_query_host(const KdTree& t, int32_t kk, const int64_t* rows, int64_t
     return rc;
 }
 }  // namespace
+}  // namespace fdx
+
+
+// ================================================================================================================
+// The QUERIES on the device.  The tree is built on the host (above: introselect's permutation has to be replayed step by step)
+// and uploaded - 24 bytes per node, 4 per point; one lane answers one query with exactly the host's sequence of node visits,
+// heap operations and comparisons (kd_query_one): best-first over the nodes with scipy's binary heap, the far node's record
+// (node, distance, per-axis side distances) held IN the heap entry - the host keeps it in a pool and the index in the heap: the
+// same priorities, the same sift sequences -, a leaf's points tested in index-array order against the strict bound.  Sums and
+// products are rounded one by one (no contraction), as the host compiles them.  The two heaps of a lane live in a global work
+// area laid out lane-interleaved (entry j of lane l at [j][l]): a wave's accesses to "its" entry j coalesce.  Entry counts are
+// bounded (far-node heap: KD_QCAP; a deeper heap than that - never seen, the heap holds about one entry per tree level - raises
+// a flag and the caller repeats the queries on the host).  1M lattice points, k = 6: 11-15 ms on the host's threads -> see DESIGN.
+namespace fdx {
+namespace {
+constexpr int KD_QCAP = 48;
+struct KdBounds { double mins[3], maxes[3]; };
+
+template <int M>
+__global__ __launch_bounds__(256) void kd_query_kernel(const double* __restrict__ coords, const int4* __restrict__ meta,
+                                                       const double* __restrict__ split, const int* __restrict__ indices,
+                                                       const KdBounds bnd, int kk, const long long* __restrict__ rows, long long n_rows,
+                                                       long long* __restrict__ ids_out, double* __restrict__ q_pri, int* __restrict__ q_node,
+                                                       double* __restrict__ q_side, double* __restrict__ nb_pri, int* __restrict__ nb_idx,
+                                                       long long L, int* __restrict__ overflow) {
+#pragma clang fp contract(off)
+    const long long gid = blockIdx.x * 256LL + threadIdx.x;
+    auto QP = [&](int j) -> double& { return q_pri[(size_t)j * L + gid]; };
+    auto QN = [&](int j) -> int& { return q_node[(size_t)j * L + gid]; };
+    auto QS = [&](int j, int a) -> double& { return q_side[((size_t)j * M + a) * L + gid]; };
+    auto NP = [&](int j) -> double& { return nb_pri[(size_t)j * L + gid]; };
+    auto NI = [&](int j) -> int& { return nb_idx[(size_t)j * L + gid]; };
+    for (long long r = gid; r < n_rows; r += L) {
+        const long long self = rows ? rows[r] : r;
+        double x[M];
+#pragma unroll
+        for (int a = 0; a < M; ++a) x[a] = coords[(size_t)self * M + a];
+        int qn = 0, nn = 0;
+        double upper = HUGE_VAL;
+        bool over = false;
+        // current node record
+        int c_node = 0;
+        double c_md = 0.0, c_side[M];
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            double sd = fmax(0.0, fmax(bnd.mins[a] - x[a], x[a] - bnd.maxes[a]));
+            sd = sd * sd;
+            c_md += sd - 0.0;
+            c_side[a] = sd;
+        }
+        for (;;) {
+            const int4 nd = meta[c_node];                          // x: split dim (-1 leaf), y / z: start / end or less / greater
+            if (nd.x < 0) {
+                for (int i = nd.y; i < nd.z; ++i) {
+                    const int id = indices[i];
+                    double d = 0.0;
+#pragma unroll
+                    for (int a = 0; a < M; ++a) {
+                        const double diff = coords[(size_t)id * M + a] - x[a];
+                        d += diff * diff;
+                    }
+                    if (d < upper) {
+                        if (nn == kk) {                            // remove the root: the last entry sifts down from the top
+                            const double mp = NP(nn - 1);
+                            const int mi = NI(nn - 1);
+                            --nn;
+                            int h = 0;
+                            for (;;) {
+                                const int j = 2 * h + 1, k2 = 2 * h + 2;
+                                const double pj = j < nn ? NP(j) : 0.0, pk = k2 < nn ? NP(k2) : 0.0;
+                                if (!((j < nn && mp > pj) || (k2 < nn && mp > pk))) break;
+                                const int l = (k2 < nn && pj > pk) ? k2 : j;
+                                NP(h) = l == j ? pj : pk;
+                                NI(h) = NI(l);
+                                h = l;
+                            }
+                            if (nn > 0) { NP(h) = mp; NI(h) = mi; }
+                        }
+                        {                                          // push (-d, id): sift up from the end
+                            const double np = -d;
+                            int h = nn++;
+                            while (h > 0) {
+                                const int par = (h - 1) / 2;
+                                const double pp = NP(par);
+                                if (!(np < pp)) break;
+                                NP(h) = pp;
+                                NI(h) = NI(par);
+                                h = par;
+                            }
+                            NP(h) = np;
+                            NI(h) = id;
+                        }
+                        if (nn == kk) upper = -NP(0);
+                    }
+                }
+                if (qn == 0) break;
+                // pop the nearest pending node
+                c_md = QP(0);
+                c_node = QN(0);
+#pragma unroll
+                for (int a = 0; a < M; ++a) c_side[a] = QS(0, a);
+                {
+                    --qn;
+                    const double mp = QP(qn);
+                    const int mnode = QN(qn);
+                    double ms[M];
+#pragma unroll
+                    for (int a = 0; a < M; ++a) ms[a] = QS(qn, a);
+                    int h = 0;
+                    for (;;) {
+                        const int j = 2 * h + 1, k2 = 2 * h + 2;
+                        const double pj = j < qn ? QP(j) : 0.0, pk = k2 < qn ? QP(k2) : 0.0;
+                        if (!((j < qn && mp > pj) || (k2 < qn && mp > pk))) break;
+                        const int l = (k2 < qn && pj > pk) ? k2 : j;
+                        QP(h) = l == j ? pj : pk;
+                        QN(h) = QN(l);
+#pragma unroll
+                        for (int a = 0; a < M; ++a) QS(h, a) = QS(l, a);
+                        h = l;
+                    }
+                    if (qn > 0) {
+                        QP(h) = mp;
+                        QN(h) = mnode;
+#pragma unroll
+                        for (int a = 0; a < M; ++a) QS(h, a) = ms[a];
+                    }
+                }
+            } else {
+                if (c_md > upper) break;                           // the nearest remaining cell is too far: done
+                const double sp = split[c_node];
+                double xs = x[0];
+#pragma unroll
+                for (int a = 1; a < M; ++a) xs = nd.x == a ? x[a] : xs;
+                int f_node;
+                double side_distance;
+                if (xs < sp) { c_node = nd.y; f_node = nd.z; side_distance = sp - xs; }
+                else { c_node = nd.z; f_node = nd.y; side_distance = xs - sp; }
+                side_distance = side_distance * side_distance;
+                double f_side[M], f_md = c_md;
+                double old = c_side[0];
+#pragma unroll
+                for (int a = 0; a < M; ++a) { f_side[a] = c_side[a]; old = nd.x == a ? c_side[a] : old; }
+                f_md += side_distance - old;
+#pragma unroll
+                for (int a = 0; a < M; ++a) f_side[a] = nd.x == a ? side_distance : f_side[a];
+                if (c_md > f_md) {                                 // the closer one is followed
+                    const double t = c_md; c_md = f_md; f_md = t;
+                    const int tn = c_node; c_node = f_node; f_node = tn;
+#pragma unroll
+                    for (int a = 0; a < M; ++a) { const double ts = c_side[a]; c_side[a] = f_side[a]; f_side[a] = ts; }
+                }
+                if (f_md <= upper) {
+                    if (qn >= KD_QCAP) { over = true; break; }
+                    int h = qn++;
+                    while (h > 0) {
+                        const int par = (h - 1) / 2;
+                        const double pp = QP(par);
+                        if (!(f_md < pp)) break;
+                        QP(h) = pp;
+                        QN(h) = QN(par);
+#pragma unroll
+                        for (int a = 0; a < M; ++a) QS(h, a) = QS(par, a);
+                        h = par;
+                    }
+                    QP(h) = f_md;
+                    QN(h) = f_node;
+#pragma unroll
+                    for (int a = 0; a < M; ++a) QS(h, a) = f_side[a];
+                }
+            }
+        }
+        if (over) {
+            atomicOr(overflow, 1);
+            for (int i = 0; i < kk; ++i) ids_out[(size_t)r * kk + i] = -1;
+            continue;
+        }
+        // nearest first: the heap gives them farthest first
+        const int found = nn;
+        for (int i = found; i < kk; ++i) ids_out[(size_t)r * kk + i] = -1;
+        for (int i = found - 1; i >= 0; --i) {
+            ids_out[(size_t)r * kk + i] = (long long)NI(0);
+            const double mp = NP(nn - 1);
+            const int mi = NI(nn - 1);
+            --nn;
+            int h = 0;
+            for (;;) {
+                const int j = 2 * h + 1, k2 = 2 * h + 2;
+                const double pj = j < nn ? NP(j) : 0.0, pk = k2 < nn ? NP(k2) : 0.0;
+                if (!((j < nn && mp > pj) || (k2 < nn && mp > pk))) break;
+                const int l = (k2 < nn && pj > pk) ? k2 : j;
+                NP(h) = l == j ? pj : pk;
+                NI(h) = NI(l);
+                h = l;
+            }
+            if (nn > 0) { NP(h) = mp; NI(h) = mi; }
+        }
+    }
+}
+}  // namespace
+
+// ids_dev (n_rows, kk) int64, device: the answers for rows_host (NULL: every point in order), nearest first, self included, -1 padded.
+// coords_dev: the same (n, dim) float64 array as coords_host.  Queries on the device for 1-3 coordinates (FDX_KDTREE_HOST_QUERIES=1
+// or a deeper far-node heap than the work area holds: on the host's threads, then uploaded).
+int ckdtree_lists_device(const double* coords_host, const double* coords_dev, long long n, int dim, int kk, const long long* rows_host,
+                         long long n_rows, long long* ids_dev, hipStream_t st) {
+    const long long nq = rows_host ? n_rows : n;
+    if (nq == 0) return 0;
+    const bool trace = getenv("FDX_TRACE_HOST") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    KdTree t;
+    kd_build_tree(t, coords_host, n, dim);
+    const auto t1 = std::chrono::steady_clock::now();
+    bool on_device = dim <= 3 && n < 0x7fffff00LL && (long long)t.nodes.size() < 0x7fffff00LL && !getenv("FDX_KDTREE_HOST_QUERIES");
+    if (on_device) {
+        const size_t nn = t.nodes.size();
+        std::vector<int4> meta(nn);
+        std::vector<double> split(nn);
+        for (size_t i = 0; i < nn; ++i) {
+            const KdNode& nd = t.nodes[i];
+            const bool leaf = nd.split_dim == -1;
+            meta[i] = make_int4(leaf ? -1 : (int)nd.split_dim, (int)(leaf ? nd.start : nd.less), (int)(leaf ? nd.end : nd.greater), 0);
+            split[i] = nd.split;
+        }
+        std::vector<int> idx32((size_t)n);
+        for (long long i = 0; i < n; ++i) idx32[(size_t)i] = (int)t.indices[(size_t)i];
+        const long long L = std::min<long long>((nq + 255) / 256, 1024) * 256;
+        DevBuf d_meta, d_split, d_idx, d_rows, d_over, qp, qnode, qs, np, ni;
+        FDX_TRY(d_meta.alloc(nn * sizeof(int4)));
+        FDX_TRY(d_split.alloc(nn * sizeof(double)));
+        FDX_TRY(d_idx.alloc((size_t)n * 4));
+        FDX_TRY(d_over.alloc(4));
+        FDX_TRY(qp.alloc((size_t)KD_QCAP * L * 8));
+        FDX_TRY(qnode.alloc((size_t)KD_QCAP * L * 4));
+        FDX_TRY(qs.alloc((size_t)KD_QCAP * dim * L * 8));
+        FDX_TRY(np.alloc((size_t)kk * L * 8));
+        FDX_TRY(ni.alloc((size_t)kk * L * 4));
+        FDX_HIP(hipMemcpyAsync(d_meta.p, meta.data(), nn * sizeof(int4), hipMemcpyHostToDevice, st));
+        FDX_HIP(hipMemcpyAsync(d_split.p, split.data(), nn * sizeof(double), hipMemcpyHostToDevice, st));
+        FDX_HIP(hipMemcpyAsync(d_idx.p, idx32.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        FDX_HIP(hipMemsetAsync(d_over.p, 0, 4, st));
+        if (rows_host) {
+            FDX_TRY(d_rows.alloc((size_t)nq * 8));
+            FDX_HIP(hipMemcpyAsync(d_rows.p, rows_host, (size_t)nq * 8, hipMemcpyHostToDevice, st));
+        }
+        KdBounds bnd{};
+        for (int a = 0; a < dim; ++a) { bnd.mins[a] = t.mins[(size_t)a]; bnd.maxes[a] = t.maxes[(size_t)a]; }
+        const dim3 grid((unsigned)(L / 256)), blk(256);
+        const long long* rows_d = rows_host ? d_rows.as<long long>() : nullptr;
+#define FDX_KD_LAUNCH(MM)                                                                                                              \
+        hipLaunchKernelGGL(kd_query_kernel<MM>, grid, blk, 0, st, coords_dev, d_meta.as<int4>(), d_split.as<double>(), d_idx.as<int>(), bnd, \
+                           kk, rows_d, nq, ids_dev, qp.as<double>(), qnode.as<int>(), qs.as<double>(), np.as<double>(), ni.as<int>(), L,  \
+                           d_over.as<int>())
+        if (dim == 1) FDX_KD_LAUNCH(1);
+        else if (dim == 2) FDX_KD_LAUNCH(2);
+        else FDX_KD_LAUNCH(3);
+#undef FDX_KD_LAUNCH
+        FDX_CHECK_LAUNCH();
+        int over = 0;
+        FDX_HIP(hipMemcpyAsync(&over, d_over.p, 4, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));                 // the staging vectors are this function's; the flag decides the route
+        if (trace)
+            std::fprintf(stderr, "[fdx-host] ckdtree: build %.1f ms (%lld nodes), %lld queries on the device %.1f ms%s\n",
+                         std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)nn, nq,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(),
+                         over ? " (far-node heap too deep: repeated on the host)" : "");
+        if (!over) return 0;
+    }
+    std::vector<int64_t> ids((size_t)nq * kk);
+    FDX_TRY(ckdtree_query_host(t, kk, (const int64_t*)rows_host, nq, ids.data(), nullptr));
+    FDX_HIP(hipMemcpyAsync(ids_dev, ids.data(), ids.size() * 8, hipMemcpyHostToDevice, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
 }  // namespace fdx
 
 // include/fdx.h

@@ -1,5 +1,7 @@
 // Caching device allocator behind DevBuf (see fdx_internal.h).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -76,7 +78,12 @@ int pool_alloc(size_t bytes, void** p, size_t* cap) {
             return 0;
         }
     }
+    static const bool trace = getenv("FDX_POOL_TRACE") != nullptr;   // diagnostic: every miss of the cache, with what the driver took for it
+    const auto t_miss = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, c);
+    if (trace)
+        std::fprintf(stderr, "[fdx-pool] hipMalloc(%zu MB) %.2f ms\n", c >> 20,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_miss).count());
     if (e != hipSuccess) {     // out of memory: drop the cache and retry once
         (void)hipGetLastError();
         pool_trim();

@@ -569,7 +569,7 @@ class ShardedFlashDeconv:
         place of the device's index-rule lists; then the stepwise symmetrise + localize.  Needs the band to hold every row that
         can point at an own row - the same condition as the band recompute itself (no far walk: checked before this is called)."""
         import torch
-        from .utils.graph import ckdtree_knn_lists_rows
+        from .utils.graph import _ckdtree_restatement_matches_scipy
         lib = _lib.load()
         n, dim = coords.shape
         k = int(self.k_neighbors)
@@ -586,10 +586,14 @@ class ShardedFlashDeconv:
         rows_pos = torch.nonzero(cnt > 0).flatten()                       # own rows + band: the rows that have lists
         if rows_pos.numel():
             ids = np.ascontiguousarray(perm_t[rows_pos].long().cpu().numpy())
-            lists = ckdtree_knn_lists_rows(coords.detach().cpu().numpy(), k, ids)          # caller ids, self included, -1 padded
-            # to solver positions, self dropped (utils/graph.py:70-74), at the rows' positions: on the device
-            _lib.check(lib.fdx_graph_plan_set_lists_dev(plan, lists.ctypes.data, ids.ctypes.data, len(ids), ctypes.c_void_p(nbr.data_ptr()),
-                                                        ctypes.c_void_p(cnt.data_ptr()), st))
+            ch = np.ascontiguousarray(coords.detach().cpu().numpy(), dtype=np.float64)
+            cd = coords if (coords.dtype == torch.float64 and coords.is_contiguous()) else coords.double().contiguous()
+            _ckdtree_restatement_matches_scipy()
+            # the restated tree on the host, its queries for these rows on the device; the answers (caller ids, self included) go to
+            # solver positions, self dropped (utils/graph.py:70-74), at the rows' positions
+            _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, _lib.ptr_f64(ch), ctypes.c_void_p(cd.data_ptr()), n, dim,
+                                                                ids.ctypes.data, len(ids), ctypes.c_void_p(nbr.data_ptr()),
+                                                                ctypes.c_void_p(cnt.data_ptr()), st))
         _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi,
                                                     st, ctypes.byref(h)))
         full = _lib.Graph(h.value)

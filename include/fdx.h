@@ -338,6 +338,13 @@ int fdx_graph_plan_lists_replaced(fdx_graph_plan* plan);
  * point itself dropped (utils/graph.py:70-74), -1 padded; includes fdx_graph_plan_lists_replaced.  Rows not listed keep their lists. */
 int fdx_graph_plan_set_lists_dev(fdx_graph_plan* plan, const int64_t* ids_host, const int64_t* rows_host, int64_t n_rows,
                                  int32_t* nbr_dev, int32_t* cnt_dev, void* stream);
+/* The reference's choice among equidistant neighbours for rows_host (n_rows caller ids; NULL: every spot) in one call: scipy
+ * cKDTree's build restated on the host (coords_host), its k-nearest queries answered on the device for 1-3 coordinates (coords_dev:
+ * the same (n, dim) float64 array; 4-8 coordinates: on the host's threads), the answers written where the symmetrisation expects
+ * them as by fdx_graph_plan_set_lists_dev.  Replaces utils/graph.py:60-74 for those rows. */
+int fdx_graph_plan_set_ckdtree_lists_dev(fdx_graph_plan* plan, const double* coords_host, const double* coords_dev, int64_t n,
+                                         int32_t dim, const int64_t* rows_host, int64_t n_rows, int32_t* nbr_dev, int32_t* cnt_dev,
+                                         void* stream);
 /* perm_out_dev[p] = caller's spot id at solver position p (int32, n entries, device). */
 int fdx_graph_perm_dev(const fdx_graph* g, int32_t* perm_out_dev, void* stream);
 /* Shard of a full graph for rank `my_rank`: own spots are solver positions [bounds[my_rank], bounds[my_rank+1])

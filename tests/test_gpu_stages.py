@@ -503,3 +503,73 @@ def test_fit_with_four_dimensional_coordinates():
     with pytest.raises(ValueError, match="radius / grid graphs are built for 1 to 3"):
         FlashDeconv(spatial_method="grid", **kw).fit(Y, X, c4)
 
+
+
+@pytest.mark.parametrize("case", ["square", "hex", "cube3d", "random2d_ties", "line", "duplicates", "square_big_rows"])
+def test_device_ckdtree_queries_equal_the_host_restatement(case, monkeypatch):
+    """fdx_graph_plan_set_ckdtree_lists_dev (csrc/kdtree_order.cpp): the k-nearest queries of the restated cKDTree answered by a
+    device kernel (one lane per query: the host's node visits, heap operations and comparisons, in its order) against the same
+    queries on the host's threads (FDX_KDTREE_HOST_QUERIES=1), which tests/test_host.py pins to scipy itself - list for list,
+    on lattices (every k-th neighbour tied), rounded and duplicated points, 1 to 3 coordinates, all rows and a subset."""
+    import ctypes
+    import torch
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(7)
+    sq = np.stack(np.meshgrid(np.arange(40.0), np.arange(33.0), indexing="ij"), -1).reshape(-1, 2)
+    coords, k, rows = {
+        "square": (sq, 6, None),
+        "hex": (np.array([(c + 0.5 * (r & 1), r * np.sqrt(3.0) / 2.0) for r in range(30) for c in range(29)]), 6, None),
+        "cube3d": (np.stack(np.meshgrid(*[np.arange(12.0)] * 3, indexing="ij"), -1).reshape(-1, 3), 8, None),
+        "random2d_ties": (np.round(rs.rand(30000, 2) * 25.0, 1), 6, None),
+        "line": (np.round(rs.rand(900, 1) * 50.0), 3, None),
+        "duplicates": (np.concatenate([rs.rand(300, 2), rs.rand(100, 2).repeat(3, axis=0)]), 5, None),
+        "square_big_rows": (np.stack(np.meshgrid(np.arange(260.0), np.arange(250.0), indexing="ij"), -1).reshape(-1, 2), 6,
+                            np.sort(rs.choice(65000, 9000, replace=False)).astype(np.int64)),
+    }[case]
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    n, dim = coords.shape
+    kk = min(k, n - 1) + 1
+    cd = torch.from_numpy(coords).cuda()
+
+    def lists(host_queries):
+        if host_queries:
+            monkeypatch.setenv("FDX_KDTREE_HOST_QUERIES", "1")
+        else:
+            monkeypatch.delenv("FDX_KDTREE_HOST_QUERIES", raising=False)
+        nbr = torch.full((n, kk), -7, dtype=torch.int32, device="cuda")
+        cnt = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        plan, h = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.fdx_graph_knn_lists_dev(ctypes.c_void_p(cd.data_ptr()), n, dim, k, 0, n, ctypes.c_void_p(nbr.data_ptr()),
+                                               ctypes.c_void_p(cnt.data_ptr()), None, ctypes.byref(plan)))
+        torch.cuda.synchronize()
+        before = (nbr.clone(), cnt.clone())
+        _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, _lib.ptr_f64(coords), ctypes.c_void_p(cd.data_ptr()), n, dim,
+                                                            None if rows is None else rows.ctypes.data, 0 if rows is None else len(rows),
+                                                            ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), None))
+        perm = torch.empty(n, dtype=torch.int32, device="cuda")
+        _lib.check(lib.fdx_graph_plan_order_dev(plan, ctypes.c_void_p(perm.data_ptr()), None, None))
+        _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), 0, n, None,
+                                                    ctypes.byref(h)))
+        _lib.Graph(h.value).close()
+        torch.cuda.synchronize()
+        return nbr.cpu().numpy(), cnt.cpu().numpy(), perm.cpu().numpy(), before
+
+    nb_d, cn_d, perm_d, before = lists(False)
+    nb_h, cn_h, perm_h, _ = lists(True)
+    assert np.array_equal(perm_d, perm_h)
+    assert np.array_equal(cn_d, cn_h) and np.array_equal(nb_d, nb_h)
+    # the lists are the restated tree's: position p holds the answer for caller id perm[p], as positions, self dropped
+    want = np.empty((n, kk), dtype=np.int64)
+    _lib.check(lib.fdx_ckdtree_knn(_lib.ptr_f64(coords), n, dim, kk, want.ctypes.data, None))
+    rank = np.empty(n, dtype=np.int64)
+    rank[perm_d] = np.arange(n)
+    check = np.arange(n) if rows is None else rows
+    for i in check[:: max(1, len(check) // 500)]:
+        exp = [rank[j] for j in want[i] if j >= 0 and j != i]
+        p = rank[i]
+        assert cn_d[p] == len(exp) and list(nb_d[p, :len(exp)]) == exp, (case, i)
+    if rows is not None:                          # rows not asked for keep the device's own lists
+        keep = np.setdiff1d(np.arange(n), rows)
+        pk = rank[keep]
+        assert np.array_equal(cn_d[pk], before[1].cpu().numpy()[pk]) and np.array_equal(nb_d[pk], before[0].cpu().numpy()[pk])
