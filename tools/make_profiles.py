@@ -63,7 +63,7 @@ for k in fetch:
     f_mean = sum(fv[i] for i in keep) / max(len(keep), 1)
     w_keep = [wv[i] for i in keep if i < len(wv)]
     w_mean = sum(w_keep) / max(len(w_keep), 1)
-    name = k.replace("void ", "").split("(")[0]
+    name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     kern[name] = {"launches": len(keep), "fetch_kb": f_mean, "write_kb": w_mean,
                   "hbm_bytes_corrected": (2 * f_mean + w_mean) * 1024}
 json.dump({"note": "per-launch means over non no-op launches; hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: "
@@ -72,7 +72,7 @@ json.dump({"note": "per-launch means over non no-op launches; hbm_bytes_correcte
 with open(os.path.join(dst, f"{tag}_pmc_traffic.md"), "w") as f:
     f.write(f"# {tag} - HBM traffic per launch from PMC counters (FETCH_SIZE, WRITE_SIZE)\n\n")
     f.write("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python3 bench.py --steps 1 --warmup 0 "
-            f"--no-cpu-baseline {extra if extra else '--family both'}` (tools/profile_round.sh); per-launch means over the real (non no-op) launches; "
+            f"--no-cpu-baseline {extra if extra else '--family all'}` (tools/profile_round.sh); per-launch means over the real (non no-op) launches; "
             "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read "
             "(MI355X_MICROARCH.md, HBM section).\n\n")
     f.write("| kernel | launches | 2 x FETCH_SIZE (MB) | WRITE_SIZE (MB) | HBM bytes per launch (MB) |\n|---|---|---|---|---|\n")
