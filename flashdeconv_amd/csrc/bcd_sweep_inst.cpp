@@ -162,14 +162,17 @@ __device__ __forceinline__ unsigned lane_off(unsigned off) {
 // summation order are identical to bcd_sweep_kernel, so both variants produce the same bits.
 // QUAD = false (objective above 64 types): the quadratic term beta' XtX beta is left to launch_beta_quad - with the K products per type
 // the objective variant of the padded sizes spills at 256 registers (88: 7 ... 112: hundreds) and cost 1.7 x a sweep.
-template <int K, int KC, bool OBJ, bool QUAD = true>
+// INIT = true (first sweep of a solve that starts from the uniform 1/K, core/solver.py:372): the old abundances are the constant
+// init_v everywhere - own spots and halo alike - and are not read: the start vector is never written to HBM (240 MB at 1M x 30)
+// and the first sweep moves two thirds of a sweep's bytes.  Same arithmetic on the same values: same bits.
+template <int K, int KC, bool OBJ, bool QUAD = true, bool INIT = false>
 __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <= 96)) ? 2 : 1) void bcd_sweep_tiled_kernel(
     const double* __restrict__ H, const double* __restrict__ XtX, const double* __restrict__ beta_in,
     double* __restrict__ beta_out, const unsigned short* __restrict__ ell_local, const int* __restrict__ slice_off,
     const int* __restrict__ deg, const int* __restrict__ tile_halo, const int* __restrict__ tile_hcnt,
     unsigned long long* __restrict__ stats, double* __restrict__ rel_change, const double lambda, const double rho,
     const double tol, const int ldh, const int ld_, const int n, const int S, const int it,
-    const int* __restrict__ tile_list) {
+    const int* __restrict__ tile_list, const double init_v) {
     // tile_list != NULL: the grid covers the listed tiles only (sharded solve: boundary tiles first, interior tiles while
     // the halo is on the wire); NULL: all tiles, XCD-contiguous remap.
     // OBJ = true turns the same traversal into the objective evaluation (core/solver.py:269-284): no update, no store;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
 #define PLANE_AT(base, off) (*(const double __attribute__((address_space(1)))*)(plane_base(base) + lane_off(off)))
     double b[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) b[k] = PLANE_AT(beta_in + k * ld, ioff);
+    for (int k = 0; k < K; ++k) b[k] = INIT ? init_v : PLANE_AT(beta_in + k * ld, ioff);
     const unsigned short* ell = ell_local + (size_t)w0 * 64 + (i & 63);
     const double lam_deg = lambda * (double)dg;
     const double lam_eff = (dg > 0) ? lambda : 0.0;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
     double hv[KC], hreg[KC];
 #pragma unroll
     for (int q = 0; q < KC; ++q) {
-        hv[q] = PLANE_AT(beta_in + q * ld, hoff);                                  // threads past Ht read spot 0: harmless
+        hv[q] = INIT ? init_v : PLANE_AT(beta_in + q * ld, hoff);                  // threads past Ht read spot 0: harmless
         hreg[q] = __builtin_nontemporal_load(&PLANE_AT(H + q * (size_t)ldh, ioff));             // streamed once per sweep: keep L2 for beta_in (halo re-use)
     }
 
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
             const int j = halo[h];
 #pragma unroll
             for (int q = 0; q < KC; ++q)
-                if (kc + q < K) lds[q * S + 256 + h] = beta_in[(kc + q) * ld + j];
+                if (kc + q < K) lds[q * S + 256 + h] = INIT ? init_v : beta_in[(kc + q) * ld + j];
         }
         if (tid < KC) lds[tid * S + 256 + Ht] = 0.0;
         __syncthreads();
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
                 for (int t = 2 * q; t < 2 * q + 2; ++t) {
                     const int j = t < KC ? t : t - KC;
                     if (kc + KC + j < K) {
-                        if (t < KC) hv[j] = PLANE_AT(beta_in + (kc + KC + j) * ld, hoff);
+                        if (t < KC) { if (!INIT) hv[j] = PLANE_AT(beta_in + (kc + KC + j) * ld, hoff); }
                         else hreg[j] = __builtin_nontemporal_load(&PLANE_AT(H + (kc + KC + j) * (size_t)ldh, ioff));
                     }
                 }
@@ -357,18 +360,24 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
                 if constexpr (K > 64) {                    // always with skip_quad (solver.cpp): only that variant is instantiated
                     hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true, false>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
                                        a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr);
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0);
                 } else {
                     hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
                                        a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr);
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0);
                 }
             }
             else if (a.tile_list) {
                 if (a.n_list > 0)
                     hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false>), dim3(a.n_list), dim3(256), lds, st, a.H, a.XtX,
                                        a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, a.tile_list);
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, a.tile_list, 0.0);
+            } else if (a.init_uniform != 0.0) {
+                if constexpr (K <= 64) {
+                    hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false, true, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
+                                       a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, a.init_uniform);
+                }
             } else {
                 // FDX_SWEEP_LDS_PAD_KB (diagnostic): unused dynamic LDS on top, to time this kernel at the occupancy a fused
                 // two-sweep kernel would have (its intermediate iterate of tile + first ring lives in LDS: DESIGN section 7)
@@ -379,7 +388,7 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
                                               (int)lds_launch);
                 hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false>), dim3(a.n_tiles), dim3(256), lds_launch, st, a.H, a.XtX,
                                    a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr);
+                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0);
             }
             return;
         }

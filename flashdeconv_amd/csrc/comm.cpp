@@ -626,7 +626,6 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
         soff_p = soff.as<int>();
         roff_p = roff.as<int>();
     }
-    FDX_TRY(solver_init_beta(beta0_dev, ld, g->n_total, K_real, st, K));     // beta0 = 1/K on own + halo (solver.py:372); pad types 0
     // the second buffer: only its pad rows and halo columns must read as defined before the first sweep has written the own rows
     // and the first exchange the halo - a fill of the whole buffer is the simple form of that
     FDX_HIP(hipMemsetAsync(beta1_dev, 0, (size_t)K * ld * 8, st));
@@ -642,6 +641,8 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
         a.tiled = 1; a.ell_local = g->ell_local.as<unsigned short>(); a.tile_halo = g->tile_halo.as<int>();
         a.tile_hcnt = g->tile_hcnt.as<int>(); a.n_tiles = g->n_tiles; a.halo_max = g->halo_max;
     }
+    a.beta_in = beta0_dev;
+    a.beta_out = beta1_dev;
     // boundary-first ordering needs the tiled sweep (tile lists) and somebody to talk to
     bool split = tiled && bcd_sweep_uses_tiles(a) && total_send > 0 && g->n > 0 && !getenv("FDX_NO_OVERLAP");
     // ... and a shard large enough for the split to pay: a sweep launch lasts at least one workgroup's life (~25-35 us) however few
@@ -659,6 +660,16 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     if (split) {
         FDX_TRY(build_tile_lists(*g, st));          // no-op for a graph of the queued shard build: its lists were made on the device
         split = g->n_tiles_boundary > 0 && g->n_tiles_interior > 0;
+    }
+
+    // beta0 = 1/K on own + halo (solver.py:372), pad types 0: a constant of the first sweep where the tiled kernel takes one
+    // (bcd_sweep_inst.cpp, INIT: whole-shard launches, no pad types), written to the buffer otherwise
+    double init_uniform = 0.0;
+    if (!split && tiled && K_real == K && K <= FDX_MAX_K_FAST && max_iter > 0 && g->n > 0 && bcd_sweep_uses_tiles(a) && !getenv("FDX_NO_INIT_SWEEP")) {
+        init_uniform = 1.0 / (double)K;
+        FDX_TRY(solver_zero_pad(beta0_dev, ld, g->n_total, K, st));
+    } else {
+        FDX_TRY(solver_init_beta(beta0_dev, ld, g->n_total, K_real, st, K));
     }
 
     // the trace lands in pinned host memory behind an event; while the host waits for it the first iterations of the NEXT chunk
@@ -690,6 +701,7 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
                 FDX_TRY(launch_bcd_sweep(a, nullptr, 0, st));
             } else {
                 a.tile_list = nullptr; a.n_list = 0;
+                a.init_uniform = it == 0 ? init_uniform : 0.0;
                 FDX_TRY(launch_bcd_sweep(a, sweep_scratch.as<double>(), scratch_ld, st));
             }
         }

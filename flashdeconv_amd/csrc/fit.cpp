@@ -334,12 +334,15 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     hipEvent_t evG = nullptr;
     FDX_HIP(hipEventCreateWithFlags(&evG, hipEventDisableTiming));
     struct EvGuard { hipEvent_t e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evG_guard{evG};
+    const bool beta0_virtual = side && KP == K && K <= FDX_MAX_K_FAST && prm->max_iter > 0 && !prm->verbose && !getenv("FDX_NO_INIT_SWEEP");
     {
         PoolStream pool_xs(xs);
         FDX_TRY(dB0.alloc((size_t)KP * ld * sizeof(double)));
         FDX_TRY(dB1.alloc((size_t)KP * ld * sizeof(double)));
         if (side) {
-            FDX_TRY(solver_init_beta(dB0.as<double>(), ld, g->n_total, K, xs, KP));
+            // no pad types: the uniform start vector is a constant of the first sweep and is not written (solver.cpp: beta0_virtual)
+            if (beta0_virtual) FDX_TRY(solver_zero_pad(dB0.as<double>(), ld, g->n_total, KP, xs));
+            else FDX_TRY(solver_init_beta(dB0.as<double>(), ld, g->n_total, K, xs, KP));
             FDX_TRY(solver_zero_pad(dB1.as<double>(), ld, g->n_total, KP, xs));
         }
         if (ysrc.csr) {
@@ -520,6 +523,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     struct EvGuard3 { hipEvent_t* a; hipEvent_t* b; ~EvGuard3() { if (*a) (void)hipEventDestroy(*a); if (*b) (void)hipEventDestroy(*b); } } evX_guard{&evSolved, &evExported};
     if (evInit) {
         p.init_beta = 0;                     // done on the side stream at the top
+        p.beta0_virtual = beta0_virtual ? 1 : 0;
         FDX_HIP(hipStreamWaitEvent(st, evInit, 0));
     }
     FDX_TRY(solver_run(p, &r, st));          // its chunked read-backs synchronise the stream: YtY has arrived after it

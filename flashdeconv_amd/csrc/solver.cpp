@@ -133,7 +133,8 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
         scratch_ld = (size_t)g.n_slices * 64;
         FDX_TRY(generic_scratch.alloc(scratch_ld * 2 * K * sizeof(double)));
     }
-    if (p.init_beta) FDX_TRY(solver_init_beta(p.beta[0], p.ld, g.n_total, p.K_real > 0 ? p.K_real : K, st, K));   // beta0 = 1/K (solver.py:372)
+    const int K_real = p.K_real > 0 ? p.K_real : K;
+    if (p.init_beta) FDX_TRY(solver_init_beta(p.beta[0], p.ld, g.n_total, K_real, st, K));   // beta0 = 1/K (solver.py:372)
     // the second buffer's pad rows must also read as zero
     // (only the pad: every real row is written by the first sweep before anything reads it - a memset of the whole
     // buffer was 30 us of a 6 ms fit)
@@ -147,6 +148,18 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
     if (g.tiled && !getenv("FDX_NO_TILED")) {
         a.tiled = 1; a.ell_local = g.ell_local.as<unsigned short>(); a.tile_halo = g.tile_halo.as<int>();
         a.tile_hcnt = g.tile_hcnt.as<int>(); a.n_tiles = g.n_tiles; a.halo_max = g.halo_max;
+    }
+
+    // the start vector as a constant of the first sweep (bcd_sweep_inst.cpp, INIT) - or written now, where that kernel does not apply
+    double init_uniform = 0.0;
+    if (!p.init_beta && p.beta0_virtual) {
+        BcdSweepArgs probe = a;
+        probe.beta_in = p.beta[0];
+        probe.beta_out = p.beta[1];
+        if (max_iter > 0 && K_real == K && K <= FDX_MAX_K_FAST && g.n_total == g.n && bcd_sweep_uses_tiles(probe) && !getenv("FDX_NO_INIT_SWEEP"))
+            init_uniform = 1.0 / (double)K;
+        else
+            FDX_TRY(solver_init_beta(p.beta[0], p.ld, g.n_total, K_real, st, K));
     }
 
     // per chunk: events around its sweeps (alternating pairs: the next chunk's first sweeps are queued before this chunk's
@@ -182,6 +195,7 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
         a.it = it;
         a.beta_in = p.beta[it & 1];
         a.beta_out = p.beta[(it + 1) & 1];
+        a.init_uniform = it == 0 ? init_uniform : 0.0;
         FDX_TRY(launch_bcd_sweep(a, generic_scratch.as<double>(), scratch_ld, st));
         if (p.verbose && (it % 10 == 0 || it == max_iter - 1)) {
             double obj = 0.0;  // synchronous; verbose mode trades speed for the trace, as the reference does

@@ -24,6 +24,9 @@ struct SolveProblem {
     double tol = 1e-4;
     int verbose = 0;
     int init_beta = 1;             // fill beta[0] with 1/K and clear the pad rows
+    int beta0_virtual = 0;         // init_beta == 0 only: the caller cleared the pad rows of BOTH buffers but did not write 1/K into
+                                   // beta[0] - the first sweep takes the constant instead of reading it (tiled kernel, no pad types);
+                                   // where that kernel does not apply, solver_run writes the start vector itself
     int compute_objective = 1;
     int first_chunk = 4;
 };
