@@ -17,6 +17,7 @@
 //      by original index + unique.
 //   5. sliced ELL (slice = 64 consecutive sorted points = one wavefront of the BCD sweep).
 #include <chrono>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <cstring>
@@ -1173,10 +1174,13 @@ static int bbox_begin(const double* d_coords, long long n, int dim, hipStream_t 
     return 0;
 }
 
+// under_wait: queued behind the bounding-box kernels and ahead of the host's wait for them - fills whose sizes depend on n alone
+// run on the device while the host takes the six numbers over (they used to sit in the chain of dependent launches after it)
 static int make_grid(const double* d_coords, long long n, int dim, double target_per_cell, double min_h,
-                     GridParams* gp, hipStream_t st) {
+                     GridParams* gp, hipStream_t st, const std::function<int()>* under_wait = nullptr) {
     auto job = std::make_unique<BboxJob>();
     FDX_TRY(bbox_begin(d_coords, n, dim, st, job.get()));
+    if (under_wait && *under_wait) FDX_TRY((*under_wait)());
     FDX_HIP(hipEventSynchronize(job->ev));
     double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     for (int a = 0; a < dim; ++a) {
@@ -1234,9 +1238,17 @@ struct BinnedPoints {
 // shard_lo < shard_hi: a spot shard's binning - the ranking pass lays out only the cells the shard's build looks at
 // (cell_need_kernel; counting path only: the sorting path lays out everything)
 static int bin_points(const double* d_coords, long long n, int dim, double target_per_cell, double min_h,
-                      BinnedPoints* b, hipStream_t st, long long shard_lo = 0, long long shard_hi = 0, int shard_R = 0) {
+                      BinnedPoints* b, hipStream_t st, long long shard_lo = 0, long long shard_hi = 0, int shard_R = 0,
+                      const std::function<int()>* extra_under_wait = nullptr) {
     b->n = n;
-    FDX_TRY(make_grid(d_coords, n, dim, target_per_cell, min_h, &b->gp, st));
+    FDX_TRY(b->sc.alloc((size_t)n * 3 * sizeof(double)));
+    const std::function<int()> under_wait = [&]() -> int {
+        // the coordinate planes past `dim` read as zero (8 MB at a million 2-D points: 16 us that used to sit between place and rank)
+        if (dim < 3) FDX_HIP(hipMemsetAsync(b->sc.as<double>() + (size_t)dim * n, 0, (size_t)(3 - dim) * n * sizeof(double), st));
+        if (extra_under_wait && *extra_under_wait) FDX_TRY((*extra_under_wait)());
+        return 0;
+    };
+    FDX_TRY(make_grid(d_coords, n, dim, target_per_cell, min_h, &b->gp, st, &under_wait));
     trace_host("bin: make_grid (bbox kernel + read-back)");
     b->n_cells = b->gp.nc[0] * b->gp.nc[1] * b->gp.nc[2];
     DevBuf& keys = b->keys;
@@ -1248,7 +1260,6 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     FDX_TRY(skeys.alloc((size_t)n * 8));
     FDX_TRY(b->perm.alloc((size_t)n * 4));
     FDX_TRY(b->rank.alloc((size_t)n * 4));
-    FDX_TRY(b->sc.alloc((size_t)n * 3 * sizeof(double)));
     if (dim <= 2) FDX_TRY(b->sc2.alloc((size_t)n * 2 * sizeof(double)));
     trace_host("bin: allocations");
     const int nb = ceil_div(n, 256);
@@ -1289,7 +1300,6 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
         hipLaunchKernelGGL(cell_place_kernel, dim3(nb), dim3(256), 0, st, keys.as<unsigned>(), vals.as<int>(), b->start.as<int>(), n,
                            tmp.as<int>());
         FDX_CHECK_LAUNCH();
-        if (dim < 3) FDX_HIP(hipMemsetAsync(b->sc.as<double>() + (size_t)dim * n, 0, (size_t)(3 - dim) * n * sizeof(double), st));
         const unsigned char* need = nullptr;
         if (shard_need) {
             unsigned char* n1 = b->need_p;
@@ -1593,23 +1603,25 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
         return 0;
     }
     const bool shard_band = band && (lo > 0 || hi < n) && hi > lo;
-    rc = shard_band ? bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st, lo, hi, BAND_R)
-                    : bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st);
+    // the in-degree counters (whole graph) and the tie / far words start as zero: filled while the host waits for the bounding box
+    const bool whole = lo == 0 && hi == n;
+    const std::function<int()> fills = [&]() -> int {
+        if (whole) {
+            FDX_TRY(plan->indeg.alloc((size_t)(n + 1) * 4));
+            FDX_TRY(plan->arrival.alloc((size_t)n * kk * 4));
+            FDX_HIP(hipMemsetAsync(plan->indeg.p, 0, plan->indeg.bytes, st));
+        }
+        FDX_TRY(plan->ties.alloc(8));
+        FDX_HIP(hipMemsetAsync(plan->ties.p, 0, 8, st));
+        return 0;
+    };
+    rc = shard_band ? bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st, lo, hi, BAND_R, &fills)
+                    : bin_points(d_coords, n, dim, tpc, 0.0, &plan->b, st, 0, 0, 0, &fills);
     if (rc) { delete plan; return rc; }
     const BinnedPoints& b = plan->b;
     const int* perm = b.perm.as<int>();
-    int *indeg = nullptr, *arrival = nullptr;
-    if (lo == 0 && hi == n) {
-        rc = plan->indeg.alloc((size_t)(n + 1) * 4);
-        if (!rc) rc = plan->arrival.alloc((size_t)n * kk * 4);
-        if (rc) { delete plan; return rc; }
-        if (hipMemsetAsync(plan->indeg.p, 0, plan->indeg.bytes, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
-        indeg = plan->indeg.as<int>();
-        arrival = plan->arrival.as<int>();
-    }
-    rc = plan->ties.alloc(8);
-    if (rc) { delete plan; return rc; }
-    if (hipMemsetAsync(plan->ties.p, 0, 8, st) != hipSuccess) { delete plan; return fail(FDX_ERR_HIP, "graph: memset failed"); }
+    int* indeg = whole ? plan->indeg.as<int>() : nullptr;
+    int* arrival = whole ? plan->arrival.as<int>() : nullptr;
     int* ties = plan->ties.as<int>();
     band = band && (lo > 0 || hi < n);
     if (band) {
