@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
     const int* __restrict__ deg, const int* __restrict__ tile_halo, const int* __restrict__ tile_hcnt,
     unsigned long long* __restrict__ stats, double* __restrict__ rel_change, const double lambda, const double rho,
     const double tol, const int ldh, const int ld_, const int n, const int S, const int it,
-    const int* __restrict__ tile_list, const double init_v) {
+    const int* __restrict__ tile_list, const double init_v, const int* __restrict__ send_head, const int4* __restrict__ send_ent,
+    double* __restrict__ send_buf) {
     // tile_list != NULL: the grid covers the listed tiles only (sharded solve: boundary tiles first, interior tiles while
     // the halo is on the wire); NULL: all tiles, XCD-contiguous remap.
     // OBJ = true turns the same traversal into the objective evaluation (core/solver.py:269-284): no update, no store;
@@ -339,6 +340,18 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
         if (tid < 4) rel_change[(size_t)tile * 4 + tid] = ((lds[tid] + lds[4 + tid]) + lds[8 + tid]) + lds[12 + tid];
         return;
     }
+    // sharded solve: a row some peer needs is written into the send staging here, where its new abundances are in registers (the
+    // separate pack launch was one of four per iteration on a 125k-spot shard whose sweep lasts 36 us)
+    if (!OBJ && send_head != nullptr) {
+        int hd = real ? send_head[i] : 0;
+        while (hd != 0) {
+            const int4 e = send_ent[hd - 1];
+            double* o = send_buf + (size_t)K * e.x + e.z;
+#pragma unroll
+            for (int k = 0; k < K; ++k) o[(size_t)k * e.y] = b[k];
+            hd = e.w;
+        }
+    }
     dmax = wave_max(dmax);
     amax = wave_max(amax);
     if (lane == 0) {
@@ -360,23 +373,23 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
                 if constexpr (K > 64) {                    // always with skip_quad (solver.cpp): only that variant is instantiated
                     hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true, false>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
                                        a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0);
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0, a.send_head, a.send_ent, a.send_buf);
                 } else {
                     hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
                                        a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0);
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0, a.send_head, a.send_ent, a.send_buf);
                 }
             }
             else if (a.tile_list) {
                 if (a.n_list > 0)
                     hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false>), dim3(a.n_list), dim3(256), lds, st, a.H, a.XtX,
                                        a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, a.tile_list, 0.0);
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, a.tile_list, 0.0, a.send_head, a.send_ent, a.send_buf);
             } else if (a.init_uniform != 0.0) {
                 if constexpr (K <= 64) {
                     hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false, true, true>), dim3(a.n_tiles), dim3(256), lds, st, a.H, a.XtX,
                                        a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, a.init_uniform);
+                                       a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, a.init_uniform, a.send_head, a.send_ent, a.send_buf);
                 }
             } else {
                 // FDX_SWEEP_LDS_PAD_KB (diagnostic): unused dynamic LDS on top, to time this kernel at the occupancy a fused
@@ -388,7 +401,7 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
                                               (int)lds_launch);
                 hipLaunchKernelGGL((bcd_sweep_tiled_kernel<K, KC, false>), dim3(a.n_tiles), dim3(256), lds_launch, st, a.H, a.XtX,
                                    a.beta_in, a.beta_out, a.ell_local, a.slice_off, a.deg, a.tile_halo, a.tile_hcnt,
-                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0);
+                                   a.stats, a.rel_change, a.lambda, a.rho, a.tol, a.ldh, a.ld, a.n, S, a.it, nullptr, 0.0, a.send_head, a.send_ent, a.send_buf);
             }
             return;
         }

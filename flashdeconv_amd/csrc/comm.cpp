@@ -144,6 +144,18 @@ __global__ void halo_pack_kernel(const double* __restrict__ beta, long long ld, 
     out[(size_t)K * base + (size_t)k * cnt + (j - base)] = beta[(size_t)k * ld + send_idx[j]];
 }
 
+// the send lists seen from the rows (fdx_graph::send_head / send_ent): one thread per entry of send_idx
+__global__ void send_entries_kernel(const int* __restrict__ send_idx, const int* __restrict__ send_off, int world, int total,
+                                    int* __restrict__ head, int4* __restrict__ ent) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    int r = 0;
+    while (r + 1 < world && e >= send_off[r + 1]) ++r;
+    const int base = send_off[r];
+    const int prev = atomicExch(&head[send_idx[e]], e + 1);           // a row goes to at most a few peers: a short chain, any order
+    ent[e] = make_int4(base, send_off[r + 1] - base, e - base, prev);
+}
+
 __global__ void halo_unpack_kernel(double* __restrict__ beta, long long ld, int K, long long n_own, const int* __restrict__ recv_off,
                                    int world, int total, const double* __restrict__ in, unsigned long long* __restrict__ stat_local,
                                    const unsigned long long* __restrict__ stat_recv, int rank) {
@@ -672,6 +684,23 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
         FDX_TRY(solver_init_beta(beta0_dev, ld, g->n_total, K_real, st, K));
     }
 
+    // rows a peer needs are written into the send staging by the sweep itself (tiled kernel; bcd_sweep_inst.cpp) - the lists seen
+    // from the rows are made once per graph
+    const bool fused_pack = tiled && total_send > 0 && g->n > 0 && bcd_sweep_uses_tiles(a) && !getenv("FDX_NO_FUSED_PACK");
+    if (fused_pack) {
+        if (!g->send_head.p) {
+            FDX_TRY(g->send_head.alloc((size_t)g->n * 4));
+            FDX_TRY(g->send_ent.alloc((size_t)total_send * sizeof(int4)));
+            FDX_HIP(hipMemsetAsync(g->send_head.p, 0, (size_t)g->n * 4, st));
+            hipLaunchKernelGGL(send_entries_kernel, dim3(ceil_div(total_send, 256)), dim3(256), 0, st, g->send_idx.as<int>(), soff_p, W, total_send,
+                               g->send_head.as<int>(), g->send_ent.as<int4>());
+            FDX_CHECK_LAUNCH();
+        }
+        a.send_head = g->send_head.as<int>();
+        a.send_ent = g->send_ent.as<int4>();
+        a.send_buf = send_buf.as<double>();
+    }
+
     // the trace lands in pinned host memory behind an event; while the host waits for it the first iterations of the NEXT chunk
     // are already queued (no-ops if this chunk converged: device-side stopping rule), as in solver_run
     double* rc_host = (double*)pinned_scratch(2, (size_t)iters * sizeof(double));
@@ -705,7 +734,7 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
                 FDX_TRY(launch_bcd_sweep(a, sweep_scratch.as<double>(), scratch_ld, st));
             }
         }
-        if (total_send > 0) {
+        if (total_send > 0 && !fused_pack) {
             hipLaunchKernelGGL(halo_pack_kernel, dim3(ceil_div((long long)total_send * K, 256)), dim3(256), 0, st, a.beta_out, (long long)ld, K,
                                g->send_idx.as<int>(), soff_p, W, total_send, send_buf.as<double>());
             FDX_CHECK_LAUNCH();

@@ -44,6 +44,10 @@ struct fdx_graph {
     // tiles of the sweep that hold a row some peer needs (boundary) and the rest (interior), built on first use by the
     // native sharded solve (comm.cpp): boundary tiles are swept first, their rows packed and sent while the interior runs
     mutable fdx::DevBuf tiles_boundary, tiles_interior;
+    // the send lists seen from the rows (built on first use by the native sharded solve): send_head[i] = 1 + first entry of own
+    // row i in send_ent (0: no peer needs it), send_ent[e] = {send_off[r], rows to r, e - send_off[r], 1 + next entry of the row}
+    // for entry e of send_idx - the tiled sweep writes a row's new abundances straight into the send staging through them
+    mutable fdx::DevBuf send_head, send_ent;
     mutable int n_tiles_boundary = -1, n_tiles_interior = 0;
     // Deferred completion (whole-graph k-NN build, graph_kernels.cpp): every kernel of the build is queued without a host
     // round trip - the ELL is allocated for ell_cap_rows (an upper bound the kernels respect) - and the numbers only the device

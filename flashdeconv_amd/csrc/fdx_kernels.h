@@ -45,6 +45,10 @@ struct BcdSweepArgs {
     int skip_quad = 0;       // objective above 64 types: the quadratic term is left to launch_beta_quad (Gram matrix of the abundances)
     const int* tile_list = nullptr;   // tiled kernel only: sweep just these n_list tiles (sharded solve: boundary / interior)
     int n_list = 0;
+    // tiled kernel: rows a peer needs also go to the send staging (send_buf[K * e.x + k * e.y + e.z], see fdx_graph::send_ent); NULL: no
+    const int* send_head = nullptr;
+    const int4* send_ent = nullptr;
+    double* send_buf = nullptr;
     double init_uniform = 0.0;        // tiled kernel, K <= 64, whole graph: != 0 - every old abundance IS this value, beta_in is not read (sweep_init_ok)
     unsigned long long* stats;  // (max_iter, 2, 64) per-iteration max slots (bit patterns of doubles >= 0)
     double* rel_change;      // (max_iter) rel_change per iteration, written by the following kernel
