@@ -182,7 +182,7 @@ def sweep_chunk(K):
 
 
 def sweep_kernel_name(K):
-    return "fdx::bcd_sweep_tiled_kernel<%d, %d, false, true>" % (K, sweep_chunk(K))    # <K, chunk, objective variant, quadratic term inside>
+    return "fdx::bcd_sweep_tiled_kernel<%d, %d, false, true, false>" % (K, sweep_chunk(K))    # <K, chunk, objective variant, quadratic term inside, constant start vector>
 
 
 def sketch_kernel_name(mode, K, d=512):
