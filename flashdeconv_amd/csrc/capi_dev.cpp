@@ -250,6 +250,7 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
     // the caller's XtX buffer belongs to the caller's stream: filled there (the stream already waits for the X side)
     FDX_HIP(hipMemcpyAsync(XtX_out_dev, job.dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, st));
     double yty = 0.0;
+    if (n > 0 && job.evSum) FDX_HIP(hipStreamWaitEvent(st, job.evSum, 0));
     if (n > 0) FDX_HIP(hipMemcpyAsync(&yty, job.dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
     if (job.side) FDX_HIP(hipStreamSynchronize(job.side));
@@ -317,7 +318,22 @@ int prepare_queue(PrepareJob* job, const void* Y_dev, int y_dtype, long long n, 
                                        plan_y.dev(), job->dYs.as<double>(), d, job->dRowSq.as<double>() + r0, st));
             FDX_TRY(launch_xyt(job->dXs.as<double>(), job->dYs.as<double>(), d, nr, d, K, H_out_dev + r0, ldh, nullptr, st));
         }
-        FDX_TRY(launch_sum_partials(job->dRowSq.as<double>(), n, job->dSum.as<double>(), 1, 1, st));
+        // the shard's partial YtY only enters the objective: its reduction goes to the side stream (behind the sketch, beside the
+        // first sweep) instead of standing between the sketch and the sweeps
+        hipStream_t ys = side ? side : st;
+        if (ys != st) {
+            hipEvent_t evSk = nullptr;
+            FDX_HIP(hipEventCreateWithFlags(&evSk, hipEventDisableTiming));
+            const hipError_t e1 = hipEventRecord(evSk, st);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(ys, evSk, 0) : e1;
+            (void)hipEventDestroy(evSk);                              // released once the wait has consumed it
+            FDX_HIP(e2);
+        }
+        FDX_TRY(launch_sum_partials(job->dRowSq.as<double>(), n, job->dSum.as<double>(), 1, 1, ys));
+        if (ys != st) {
+            FDX_HIP(hipEventCreateWithFlags(&job->evSum, hipEventDisableTiming));
+            FDX_HIP(hipEventRecord(job->evSum, ys));
+        }
     }
     return 0;
 }

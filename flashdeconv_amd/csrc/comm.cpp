@@ -573,6 +573,7 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
         FDX_HIP(hipEventRecord(c->ev_halo, c->side));
     }
     FDX_TRY(solver_objective_partials(*g, beta, ld, dH.as<double>(), ldh, XtX_dev, KP, objp.as<double>(), dFin.as<double>(), st));
+    if (job.evSum) FDX_HIP(hipStreamWaitEvent(st, job.evSum, 0));
     FDX_HIP(hipMemcpyAsync(dFin.as<double>() + 4, job.dSum.p, sizeof(double), hipMemcpyDeviceToDevice, st));
     FDX_TRY(allreduce(c, dFin.p, 5, false, st));
     FDX_HIP(hipMemcpyAsync(cnt_h, dFin.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -13,7 +13,8 @@ struct PrepareJob {
     std::shared_ptr<SketchPlan> plan_y, plan_x;
     hipStream_t side = nullptr;                    // nullptr: everything on the caller's stream
     hipEvent_t evX = nullptr;                      // X side done (XtX in dG, and on the host when asked for)
-    ~PrepareJob() { if (evX) (void)hipEventDestroy(evX); }
+    hipEvent_t evSum = nullptr;                    // dSum written (on the side stream when there is one: consumers on another stream wait for it)
+    ~PrepareJob() { if (evX) (void)hipEventDestroy(evX); if (evSum) (void)hipEventDestroy(evSum); }
 };
 
 // Y_dev: (n, G) rows of this shard in solver order (row_map_dev: optional gather).  XtX_host: pinned or pageable, K*K doubles or
