@@ -1110,6 +1110,95 @@ __global__ __launch_bounds__(256) void tile_halo_kernel(const int* __restrict__ 
     }
 }
 
+// fill_ell_kernel and tile_halo_kernel in one pass over the rows (deferred whole-graph build): a row is read once, from its
+// segment, and goes to the global-index ELL and - through the tile's halo list - to the tile-local slots
+__global__ __launch_bounds__(256) void tile_ell_kernel(const int* __restrict__ ws, int seg_stride, const int* __restrict__ seg_extra,
+                                                       int pad, int* __restrict__ ell, const int* __restrict__ deg,
+                                                        const int* __restrict__ slice_off, long long n,
+                                                        int* __restrict__ tile_halo, int* __restrict__ tile_hcnt,
+                                                        unsigned short* __restrict__ ell_local, long long cap_rows,
+                                                        int* __restrict__ summary /* [0] largest halo, [1] some tile failed */) {
+    if ((long long)slice_off[(n + 63) >> 6] > cap_rows) return;
+    __shared__ int tab[TILE_HASH];
+    __shared__ int list[FDX_TILE_HALO_CAP];
+    __shared__ int s_cnt, s_over;
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    for (int s = tid; s < TILE_HASH; s += 256) tab[s] = -1;
+    if (tid == 0) { s_cnt = 0; s_over = 0; }
+    __syncthreads();
+    const long long p = (long long)tile * 256 + tid;
+    const int dg = (p < n) ? deg[p] : 0;
+    // row p of the sliced ELL: entry m at ell[(slice_off[p/64] + m)*64 + p%64]
+    const int* seg = (p < n) ? ws + (size_t)p * seg_stride + seg_extra[p] : ws;
+    for (int m = 0; m < dg; ++m) {
+        const int q = seg[m];
+        if ((q >> 8) == tile && q < n) continue;          // a LOCAL graph's halo slots n..n_total-1 can carry the last tile's number: they are halo
+        unsigned h = ((unsigned)q * 2654435761u) >> 21;   // 11 bits
+        int probes = 0;
+        while (true) {
+            const int old = atomicCAS(&tab[h], -1, q);
+            if (old == -1 || old == q) break;
+            h = (h + 1) & (TILE_HASH - 1);
+            if (++probes > TILE_HASH) { s_over = 1; break; }
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < TILE_HASH; s += 256)
+        if (tab[s] != -1) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < FDX_TILE_HALO_CAP) list[pos] = tab[s];
+        }
+    __syncthreads();
+    const int H = s_cnt;
+    if (H > FDX_TILE_HALO_CAP || s_over) {      // irregular graph: this tile cannot use the LDS path - the global-index ELL is still written
+        if (tid == 0) { tile_hcnt[tile] = -1; if (summary) atomicOr(summary + 1, 1); }
+        if ((p >> 6) < ((n + 63) >> 6)) {           // every lane of the last slice: lanes past n carry the pad index
+            const int s = (int)(p >> 6), lane = (int)(p & 63);
+            const int w0 = slice_off[s], w = slice_off[s + 1] - w0;
+            for (int m = 0; m < w; ++m) ell[((size_t)w0 + m) * 64 + lane] = (m < dg) ? seg[m] : pad;
+        }
+        return;
+    }
+    if (tid == 0 && summary && H > __builtin_nontemporal_load(summary)) atomicMax(summary, H);   // a glance first: one address for 4000 tiles
+    int P = 1;
+    while (P < H) P <<= 1;
+    for (int s = H + tid; s < P; s += 256) list[s] = 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = tid; idx < P; idx += 256) {
+                const int ixj = idx ^ j;
+                if (ixj > idx) {
+                    const int a = list[idx], b = list[ixj];
+                    const bool up = ((idx & k) == 0);
+                    if ((a > b) == up) { list[idx] = b; list[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int h = tid; h < H; h += 256) tile_halo[(size_t)tile * FDX_TILE_HALO_CAP + h] = list[h];
+    if (tid == 0) tile_hcnt[tile] = H;
+    if ((p >> 6) < ((n + 63) >> 6)) {               // every lane of the last slice: lanes past n carry the pad index / the zero slot
+        const int s = (int)(p >> 6), lane = (int)(p & 63);
+        const int w0 = slice_off[s], w = slice_off[s + 1] - w0;
+        for (int m = 0; m < w; ++m) {
+            int slot = 256 + H;   // pad -> zero slot
+            if (m >= dg) ell[((size_t)w0 + m) * 64 + lane] = pad;
+            if (m < dg) {
+                const int q = seg[m];
+                ell[((size_t)w0 + m) * 64 + lane] = q;
+                if ((q >> 8) == tile && q < n) slot = q & 255;
+                else {
+                    int lo = 0, hi = H;   // lower_bound in the sorted halo list
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (list[mid] < q) lo = mid + 1; else hi = mid; }
+                    slot = 256 + lo;
+                }
+            }
+            ell_local[((size_t)w0 + m) * 64 + lane] = (unsigned short)slot;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // FDX_TRACE_HOST=1: host clock at the steps of a graph build (stderr), to see which calls the host spends its time in
 static void trace_host(const char* what) {
@@ -1403,14 +1492,21 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
         FDX_TRY(g->tile_halo.alloc((size_t)std::max(g->n_tiles, 1) * FDX_TILE_HALO_CAP * 4));
         FDX_TRY(g->tile_hcnt.alloc((size_t)std::max(g->n_tiles, 1) * 4));
         FDX_TRY(g->ell_local.alloc(((size_t)cap + 16) * 64 * 2));
-        hipLaunchKernelGGL(fill_ell_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, ws, seg_stride, seg_extra,
-                           g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>(), cap);
-        FDX_CHECK_LAUNCH();
-        if (g->n_tiles > 0) {
-            hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, g->ell.as<int>(), g->deg.as<int>(),
-                               g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
+        if (g->n_tiles > 0 && !getenv("FDX_GRAPH_TWO_ELL_KERNELS")) {
+            hipLaunchKernelGGL(tile_ell_kernel, dim3(g->n_tiles), dim3(256), 0, st, ws, seg_stride, seg_extra, (int)g->n_total, g->ell.as<int>(),
+                               g->deg.as<int>(), g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
                                g->ell_local.as<unsigned short>(), cap, summary);
             FDX_CHECK_LAUNCH();
+        } else {
+            hipLaunchKernelGGL(fill_ell_kernel, dim3(ceil_div(g->n_slices, 4)), dim3(256), 0, st, ws, seg_stride, seg_extra,
+                               g->deg.as<int>(), g->slice_off.as<int>(), n, g->n_slices, (int)g->n_total, g->ell.as<int>(), cap);
+            FDX_CHECK_LAUNCH();
+            if (g->n_tiles > 0) {
+                hipLaunchKernelGGL(tile_halo_kernel, dim3(g->n_tiles), dim3(256), 0, st, g->ell.as<int>(), g->deg.as<int>(),
+                                   g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
+                                   g->ell_local.as<unsigned short>(), cap, summary);
+                FDX_CHECK_LAUNCH();
+            }
         }
         if (!g->meta_host) g->meta_host = (long long*)pinned_block_get();
         FDX_REQUIRE(g->meta_host != nullptr, "graph: pinned host block");
