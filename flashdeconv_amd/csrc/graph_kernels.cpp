@@ -925,11 +925,15 @@ __global__ __launch_bounds__(128) void sort_rows_kernel(int* __restrict__ nbr, c
 // width[s] = widest row of slice s; per block the sum of its degrees and its widest slice (part[2b], part[2b + 1]).
 // (One atomic per slice on a single pair of counters was 370 us at 1M spots: 31k same-address atomics, ~12 ns each.)
 constexpr int SLICE_WIDTH_BLOCKS = 1024;
+// zero_tail: the closing entry of the scan's input (width[n_slices]) and the two summary words the tile kernel raises are cleared
+// here instead of by a fill of their own in front of this launch
 __global__ __launch_bounds__(256) void slice_width_kernel(const int* __restrict__ deg, long long n, int n_slices,
-                                                          int* __restrict__ width, long long* __restrict__ part) {
+                                                          int* __restrict__ width, long long* __restrict__ part,
+                                                          int* __restrict__ summary_zero = nullptr) {
     __shared__ long long s_sum[4];
     __shared__ int s_max[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (summary_zero && blockIdx.x == 0 && threadIdx.x == 0) { width[n_slices] = 0; summary_zero[0] = 0; summary_zero[1] = 0; }
     long long tot = 0;
     int wmax = 0;
     for (int s = blockIdx.x * 4 + wv; s < n_slices; s += gridDim.x * 4) {
@@ -1472,11 +1476,10 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     const size_t red_at = ((size_t)(g->n_slices + 1) * 4 + 15) / 16 * 16;
     FDX_TRY(width.alloc(red_at + 32 + (size_t)wblocks * 16));
     FDX_TRY(g->slice_off.alloc((size_t)(g->n_slices + 1) * 4));
-    FDX_HIP(hipMemsetAsync(width.p, 0, red_at + 32, st));
     long long* red = reinterpret_cast<long long*>(static_cast<char*>(width.p) + red_at);
     int* summary = reinterpret_cast<int*>(red + 2);
     long long* part = red + 4;
-    hipLaunchKernelGGL(slice_width_kernel, dim3(wblocks), dim3(256), 0, st, g->deg.as<int>(), n, g->n_slices, width.as<int>(), part);
+    hipLaunchKernelGGL(slice_width_kernel, dim3(wblocks), dim3(256), 0, st, g->deg.as<int>(), n, g->n_slices, width.as<int>(), part, summary);
     FDX_CHECK_LAUNCH();
     FDX_TRY(exclusive_scan_int(width.as<int>(), g->slice_off.as<int>(), g->n_slices + 1, st, tmp));
     trace_host("ell: width + sums + scan");
