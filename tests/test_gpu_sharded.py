@@ -782,3 +782,40 @@ def test_two_models_fitted_from_two_threads_at_once_equal_the_single_thread_bits
         for j in range(2):
             assert out[j] is not None and out[j].info_["n_iterations"] == alone[j].info_["n_iterations"]
             assert np.array_equal(out[j].beta_, alone[j].beta_) and np.array_equal(out[j].proportions_, alone[j].proportions_), (rnd, j)
+
+
+def test_sweep_variants_give_the_same_bits(monkeypatch):
+    """Round 5's forms of the tiled sweep against the ones they replaced, bit for bit: the first sweep that takes the uniform start
+    vector as a constant (INIT) vs the written one, the sweep that writes the send staging itself vs the separate pack kernel, and
+    the one-pass ELL / tile-table kernel vs fill_ell + tile_halo."""
+    import torch
+    from flashdeconv_amd import FlashDeconv, _lib
+    from flashdeconv_amd.distributed import diag_mean
+    dev = torch.device("cuda", 0)
+    n, G, K, d, W = 5000, 260, 7, 48, 4
+    Y, X, coords, _ = datagen.gaussian_raw(n, G, K, seed=31)
+    Yt = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float64)).to(dev)
+    cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
+
+    def single():
+        m = FlashDeconv(sketch_dim=d, preprocess="raw", n_hvg=G, max_iter=25, tol=1e-7).fit(Yt, X, cd, output="torch")
+        return m.beta_.clone(), m.info_["n_iterations"], m.lambda_used_
+
+    def sharded(lam):
+        full, shards = _native_shards(torch, cd, Yt, X, W, d, K, _lib.PRE_RAW)
+        res = _run_native_threads(torch, shards, K, lam, 0.01 * diag_mean(shards[0]["XtX_h"]), 1e-7, 25)
+        return _assemble(torch, shards, res, n, K), res[0][0]
+
+    b0, it0, lam = single()
+    s0, sit0 = sharded(lam)
+    assert sit0 == it0 and torch.equal(s0, b0)
+    for var in ("FDX_NO_INIT_SWEEP", "FDX_GRAPH_TWO_ELL_KERNELS"):
+        monkeypatch.setenv(var, "1")
+        b1, it1, _ = single()
+        monkeypatch.delenv(var)
+        assert it1 == it0 and torch.equal(b1, b0), var
+    for var in ("FDX_NO_INIT_SWEEP", "FDX_NO_FUSED_PACK"):
+        monkeypatch.setenv(var, "1")
+        s1, sit1 = sharded(lam)
+        monkeypatch.delenv(var)
+        assert sit1 == it0 and torch.equal(s1, b0), var
