@@ -103,6 +103,7 @@ SIGNATURES = {
                                              ctypes.POINTER(c_void_p)]),
     "fdx_graph_from_knn_lists_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, ctypes.POINTER(c_void_p)]),
     "fdx_leverage_begin": (c_int, [p_double, c_i32, c_i32, c_double, ctypes.POINTER(c_void_p)]),
+    "fdx_leverage_begin_opt": (c_int, [p_double, c_i32, c_i32, c_double, c_i32, ctypes.POINTER(c_void_p)]),
     "fdx_leverage_end": (c_int, [c_void_p, p_double]),
     "fdx_fit_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
                             c_i32, ctypes.POINTER(FitParams), ctypes.POINTER(c_void_p), c_void_p, c_void_p, p_double,
@@ -243,6 +244,20 @@ def require_gpu():
         raise FdxError("flashdeconv_amd needs an AMD Instinct GPU (gfx950); no HIP device is visible "
                        "and there is no CPU fallback.")
     return n.value
+
+
+def tensor_to_host(t):
+    """A CUDA torch tensor as a numpy array, copied through the library's pinned staging (fdx_memcpy_d2h): ``t.cpu()`` hands the
+    driver pageable memory to pin, and unmapping that memory later stalls the process's GPU queues (csrc/pool.cpp: copy_d2h)."""
+    import torch
+    if not getattr(t, "is_cuda", False):
+        return t.detach().cpu().numpy()
+    t = t.detach().contiguous()
+    out = np.empty(tuple(t.shape), dtype=np.dtype(str(t.dtype).replace("torch.", "")))
+    if out.nbytes:
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(load().fdx_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(t.data_ptr()), out.nbytes, st))
+    return out
 
 
 def as_f64(a):

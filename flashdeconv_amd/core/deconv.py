@@ -104,8 +104,10 @@ def reference_tie_graph(c_ptr, coords_host, n, dim, k):
             # the restated tree is built on the host, its queries run on the device (1-3 coordinates), and the answers go - as solver
             # positions, self dropped - to the rows' positions without leaving the device
             _ckdtree_restatement_matches_scipy()
-            ch = np.ascontiguousarray(coords_host, dtype=np.float64)
-            _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, _lib.ptr_f64(ch), c_ptr, n, dim, None, 0, nbr.ptr, cnt.ptr, None))
+            # coordinates that only exist on the device are fetched by the library into pinned memory (a pageable copy here would be
+            # pinned by the driver, and unmapping it afterwards stalls the process's GPU queues: DESIGN appendix)
+            ch = None if coords_host is None else _lib.ptr_f64(np.ascontiguousarray(coords_host, dtype=np.float64))
+            _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, ch, c_ptr, n, dim, None, 0, nbr.ptr, cnt.ptr, None))
             mark("host tree + device queries + lists to positions")
         except Exception:
             dead = ctypes.c_void_p()                                           # the plan owns device buffers: consume it
@@ -353,7 +355,7 @@ class FlashDeconv:
             # the build call, its pooled buffers (last used on the caller's stream) order the side stream behind everything the
             # build has just queued - the SVD then starts when the graph is done (measured: the wait 0.6 -> 1.3 ms).
             t_x0 = time.perf_counter()
-            lev_job = _genes.LeverageJob(Xsel)
+            lev_job = _genes.LeverageJob(Xsel, queue_async=not graph_early)   # graph already queued: the scores are collected next
             if os.environ.get("FDX_TRACE_HOST"):
                 print(f"[fdx-host] python: select end -> Xsel {1e6 * (t_x0 - t_sel_end):.0f} us, leverage job set-up {1e6 * (time.perf_counter() - t_x0):.0f}",
                       file=sys.stderr)
@@ -378,10 +380,9 @@ class FlashDeconv:
                 # tree (csrc/kdtree_order.cpp) and the graph is rebuilt from the reference's own adjacency
                 n_ties = self._graph.knn_ties()
                 if n_ties:
-                    ch = coords_host if coords_host is not None else coords.detach().cpu().numpy().astype(np.float64)
                     self._graph.close()
                     self._graph = None
-                    self._graph = reference_tie_graph(c_ptr, ch, n, dim, int(self.k_neighbors))
+                    self._graph = reference_tie_graph(c_ptr, coords_host, n, dim, int(self.k_neighbors))
             t_lev = time.perf_counter()
             leverage = lev_job.result()
             t_done = time.perf_counter()
@@ -469,10 +470,9 @@ class FlashDeconv:
                 # ties under "auto": the reference's neighbour choice, then the fit proper (one solve; the sketch is queued again)
                 n_ties = int(info.knn_ties)
                 log(f"k-NN ties on {n_ties} of {n} spots: rebuilding the graph on the reference's (cKDTree) neighbour choice")
-                ch = coords_host if coords_host is not None else coords.detach().cpu().numpy().astype(np.float64)
                 self._graph.close()
                 self._graph = None
-                self._graph = reference_tie_graph(c_ptr, ch, n, dim, int(self.k_neighbors))
+                self._graph = reference_tie_graph(c_ptr, coords_host, n, dim, int(self.k_neighbors))
                 gh = ctypes.c_void_p(self._graph.handle.value)
                 prm.stop_on_ties = 0
                 ties_resolved_here = True
@@ -568,7 +568,7 @@ class FlashDeconv:
             if coords.shape[0] < 2:
                 return _lib.GRAPH_KNN, 0, 0.0
             from ..utils.graph import grid_radius
-            ch = coords_host if coords_host is not None else coords.detach().cpu().numpy()
+            ch = coords_host if coords_host is not None else _lib.tensor_to_host(coords)
             return _lib.GRAPH_RADIUS, 0, grid_radius(ch)
         raise ValueError(f"Unknown method: {self.spatial_method}. Choose from 'knn', 'radius', 'grid'.")
 

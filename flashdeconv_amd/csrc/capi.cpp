@@ -83,16 +83,14 @@ int fdx_trim(void) {
 
 int fdx_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes, void* stream) {
     if (bytes == 0) return 0;
-    FDX_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    FDX_TRY(copy_h2d(dev_dst, host_src, bytes, (hipStream_t)stream));
     FDX_HIP(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 
 int fdx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes, void* stream) {
     if (bytes == 0) return 0;
-    FDX_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    FDX_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return 0;
+    return copy_d2h(host_dst, dev_src, bytes, (hipStream_t)stream);
 }
 
 int fdx_memset(void* dev_dst, int value, size_t bytes, void* stream) {
@@ -155,13 +153,14 @@ int fdx_graph_from_csr(const int64_t* indptr, const int64_t* indices, int64_t n,
         delete g;
         return rc;
     }
-    hipError_t e = hipSuccess;
-    if (!ell.empty()) e = hipMemcpy(g->ell.p, ell.data(), ell.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(g->slice_off.p, slice_off.data(), slice_off.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !deg.empty()) e = hipMemcpy(g->deg.p, deg.data(), deg.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
+    // (through pinned staging: the vectors are unmapped when this returns - pool.cpp, copy_h2d)
+    if (!ell.empty()) rc = copy_h2d(g->ell.p, ell.data(), ell.size() * sizeof(int), nullptr);
+    if (!rc) rc = copy_h2d(g->slice_off.p, slice_off.data(), slice_off.size() * sizeof(int), nullptr);
+    if (!rc && !deg.empty()) rc = copy_h2d(g->deg.p, deg.data(), deg.size() * sizeof(int), nullptr);
+    if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(FDX_ERR_HIP, "fdx_graph_from_csr upload: synchronisation failed");
+    if (rc) {
         delete g;
-        return fail(FDX_ERR_HIP, std::string("fdx_graph_from_csr upload: ") + hipGetErrorString(e));
+        return rc;
     }
     *out = g;
     return 0;
@@ -172,7 +171,7 @@ static int upload_coords(const double* coords, int64_t n, int32_t dim, DevBuf* d
     FDX_REQUIRE(n >= 0, "graph: negative n");
     FDX_REQUIRE(n == 0 || coords != nullptr, "graph: null coords");
     FDX_TRY(d->alloc((size_t)n * dim * sizeof(double)));
-    if (n) FDX_HIP(hipMemcpy(d->p, coords, (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice));
+    if (n) FDX_TRY(copy_h2d(d->p, coords, (size_t)n * dim * sizeof(double), nullptr)); FDX_HIP(hipStreamSynchronize(nullptr));
     return 0;
 }
 
@@ -206,7 +205,7 @@ int fdx_nearest_distance(const double* coords, int64_t n, int32_t dim, double* d
     FDX_TRY(upload_coords(coords, n, dim, &dc));
     FDX_TRY(dd.alloc((size_t)n * sizeof(double)));
     FDX_TRY(graph_nearest_distance(dc.as<double>(), n, dim, dd.as<double>(), nullptr));
-    FDX_HIP(hipMemcpy(dist_out, dd.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    FDX_TRY(copy_d2h(dist_out, dd.p, (size_t)n * sizeof(double), nullptr));
     return 0;
 }
 
@@ -219,8 +218,8 @@ int fdx_graph_export_csr(const fdx_graph* g, int64_t* indptr, int32_t* indices) 
     FDX_TRY(di.alloc((size_t)std::max<long long>(g->nnz, 1) * 4));
     FDX_HIP(hipMemset(dp.p, 0, dp.bytes));
     FDX_TRY(graph_export_csr(g, dp.as<long long>(), di.as<int>(), nullptr));
-    FDX_HIP(hipMemcpy(indptr, dp.p, (size_t)(g->n + 1) * 8, hipMemcpyDeviceToHost));
-    if (g->nnz) FDX_HIP(hipMemcpy(indices, di.p, (size_t)g->nnz * 4, hipMemcpyDeviceToHost));
+    FDX_TRY(copy_d2h(indptr, dp.p, (size_t)(g->n + 1) * 8, nullptr));
+    if (g->nnz) FDX_TRY(copy_d2h(indices, di.p, (size_t)g->nnz * 4, nullptr));
     return 0;
 }
 
@@ -261,9 +260,9 @@ int fdx_sketch(const void* Y, int32_t dtype, int64_t n, int32_t G, const int64_t
     const size_t ybytes = (size_t)n * G * dtype_size(dtype);
     FDX_TRY(dY.alloc(ybytes));
     FDX_TRY(dYs.alloc((size_t)n * d * sizeof(double)));
-    FDX_HIP(hipMemcpyAsync(dY.p, Y, ybytes, hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(dY.p, Y, ybytes, st));
     FDX_TRY(launch_sketch_rows(dY.p, dtype, G, nullptr, n, G, d, mode, plan.dev(), dYs.as<double>(), d, nullptr, st));
-    FDX_HIP(hipMemcpyAsync(Ys_out, dYs.p, (size_t)n * d * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_TRY(copy_d2h(Ys_out, dYs.p, (size_t)n * d * sizeof(double), st));
     FDX_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -277,9 +276,9 @@ int fdx_column_sums(const void* Y, int32_t dtype, int64_t n, int32_t G, double* 
     FDX_TRY(dY.alloc(ybytes));
     FDX_TRY(dPart.alloc((size_t)column_sums_parts(n) * G * sizeof(double)));
     FDX_TRY(dOut.alloc((size_t)G * sizeof(double)));
-    if (n) FDX_HIP(hipMemcpyAsync(dY.p, Y, ybytes, hipMemcpyHostToDevice, st));
+    if (n) FDX_TRY(copy_h2d(dY.p, Y, ybytes, st));
     FDX_TRY(launch_column_sums(dY.p, dtype, G, n, G, dPart.as<double>(), dOut.as<double>(), st));
-    FDX_HIP(hipMemcpyAsync(sums_out, dOut.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_TRY(copy_d2h(sums_out, dOut.p, (size_t)G * sizeof(double), st));
     FDX_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -320,8 +319,8 @@ int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sk
     FDX_TRY(dPart.alloc((size_t)xyt_partials_count(n) * sizeof(double)));
     FDX_TRY(dSum.alloc(sizeof(double)));
     FDX_TRY(dOut.alloc((size_t)n * K * sizeof(double)));
-    FDX_HIP(hipMemcpyAsync(dY.p, Y_sketch, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(dX.p, X_sketch, (size_t)K * d * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(dY.p, Y_sketch, (size_t)n * d * sizeof(double), st));
+    FDX_TRY(copy_h2d(dX.p, X_sketch, (size_t)K * d * sizeof(double), st));
     FDX_HIP(hipMemsetAsync(dH.p, 0, dH.bytes, st));
     // XtX = Xs Xs^T (solver.py:346), H = Xs Ys^T (:347), YtY = ||Ys||^2 (:348)
     FDX_TRY(launch_xyt(dX.as<double>(), dX.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, st));
@@ -329,8 +328,8 @@ int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sk
     FDX_TRY(launch_sum_partials(dPart.as<double>(), xyt_partials_count(n), dSum.as<double>(), 1, 1, st));
     std::vector<double> G((size_t)K * K);
     double YtY = 0.0;
-    FDX_HIP(hipMemcpyAsync(G.data(), dG.p, G.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipMemcpyAsync(&YtY, dSum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_TRY(copy_d2h(G.data(), dG.p, G.size() * sizeof(double), st));
+    FDX_TRY(copy_d2h(&YtY, dSum.p, sizeof(double), st));
     FDX_HIP(hipStreamSynchronize(st));
     double diag_mean = 0.0;  // rho <- rho * mean(diag XtX)   (solver.py:359-360)
     for (int k = 0; k < K; ++k) diag_mean += G[(size_t)k * K + k];
@@ -348,7 +347,7 @@ int fdx_bcd_solve(const fdx_graph* g, const double* Y_sketch, const double* X_sk
     FDX_TRY(solver_run(p, &r, st));
     FDX_TRY(launch_normalize_export(p.beta[r.result_buffer], ld, g->identity_order ? nullptr : g->perm.as<int>(), (int)n,
                                     g->n_slices, K, dOut.as<double>(), nullptr, st));
-    FDX_HIP(hipMemcpyAsync(beta_out, dOut.p, (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_TRY(copy_d2h(beta_out, dOut.p, (size_t)n * K * sizeof(double), st));
     FDX_HIP(hipEventRecord(e1, st));
     FDX_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
@@ -381,17 +380,17 @@ extern "C" int fdx_gram_xty(const double* X_sketch, const double* Y_sketch, int6
     hipStream_t st = nullptr;
     DevBuf dX, dY, dG, dH;
     FDX_TRY(dX.alloc((size_t)K * d * sizeof(double)));
-    FDX_HIP(hipMemcpyAsync(dX.p, X_sketch, (size_t)K * d * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(dX.p, X_sketch, (size_t)K * d * sizeof(double), st));
     if (XtX_out) {
         FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
         FDX_TRY(launch_xyt(dX.as<double>(), dX.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, st));
-        FDX_HIP(hipMemcpyAsync(XtX_out, dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, st));
+        FDX_TRY(copy_d2h(XtX_out, dG.p, (size_t)K * K * sizeof(double), st));
     }
     if (H_out && n > 0) {
         const long long ld = round_up(n, 64);
         FDX_TRY(dY.alloc((size_t)n * d * sizeof(double)));
         FDX_TRY(dH.alloc((size_t)K * ld * sizeof(double)));
-        FDX_HIP(hipMemcpyAsync(dY.p, Y_sketch, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, st));
+        FDX_TRY(copy_h2d(dY.p, Y_sketch, (size_t)n * d * sizeof(double), st));
         FDX_TRY(launch_xyt(dX.as<double>(), dY.as<double>(), d, n, d, K, dH.as<double>(), ld, nullptr, st));
         FDX_HIP(hipMemcpy2DAsync(H_out, (size_t)n * sizeof(double), dH.p, (size_t)ld * sizeof(double), (size_t)n * sizeof(double),
                                  (size_t)K, hipMemcpyDeviceToHost, st));
@@ -421,9 +420,9 @@ extern "C" int fdx_objective(const fdx_graph* g, const double* beta, const doubl
     FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
     FDX_TRY(dPart.alloc((size_t)std::max(objective_partials_count(g->n_slices), g->n_tiles) * 4 * sizeof(double)));
     FDX_TRY(dOut.alloc(4 * sizeof(double)));
-    FDX_HIP(hipMemcpyAsync(dB.p, bt.data(), bt.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(dH.p, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(dG.p, XtX, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(dB.p, bt.data(), bt.size() * sizeof(double), st));
+    FDX_TRY(copy_h2d(dH.p, ht.data(), ht.size() * sizeof(double), st));
+    FDX_TRY(copy_h2d(dG.p, XtX, (size_t)K * K * sizeof(double), st));
     if (K <= FDX_MAX_K_FAST || true)
         FDX_TRY(solver_objective(*g, dB.as<double>(), ld, dH.as<double>(), ld, dG.as<double>(), K, YtY, lambda, rho, dPart.as<double>(),
                                  dOut.as<double>(), obj_out, st));

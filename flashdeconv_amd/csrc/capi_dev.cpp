@@ -99,7 +99,7 @@ int fdx_graph_plan_set_ckdtree_lists_dev(fdx_graph_plan* plan, const double* coo
                                          void* stream) {
     hipStream_t st = (hipStream_t)stream;
     PoolStream pool_stream(st);
-    FDX_REQUIRE(plan && coords_host && coords_dev && nbr_dev && cnt_dev, "fdx_graph_plan_set_ckdtree_lists_dev: null argument");
+    FDX_REQUIRE(plan && coords_dev && nbr_dev && cnt_dev, "fdx_graph_plan_set_ckdtree_lists_dev: null argument");   // coords_host NULL: fetched from coords_dev
     FDX_REQUIRE(n >= 1 && dim >= 1 && dim <= 8 && n_rows >= 0 && (n_rows == 0 || rows_host),
                 "fdx_graph_plan_set_ckdtree_lists_dev: bad arguments (1 to 8 coordinates)");
     const int kk = graph_plan_kk(plan);
@@ -287,7 +287,7 @@ int prepare_queue(PrepareJob* job, const void* Y_dev, int y_dtype, long long n, 
         FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
         FDX_TRY(job->dXs.alloc((size_t)K * d * sizeof(double)));
         FDX_TRY(job->dG.alloc((size_t)K * K * sizeof(double)));
-        FDX_HIP(hipMemcpyAsync(job->dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, xs));
+        FDX_TRY(copy_h2d(job->dX.p, X, (size_t)K * G * sizeof(double), xs));
         FDX_TRY(launch_sketch_rows(job->dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, job->plan_x->dev(), job->dXs.as<double>(), d, nullptr, xs));
         FDX_TRY(launch_xyt(job->dXs.as<double>(), job->dXs.as<double>(), d, K, d, K, job->dG.as<double>(), K, nullptr, xs));
         if (XtX_host)
@@ -374,13 +374,13 @@ int fdx_prepare_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t 
     DevBuf dSlots, dBits, dX, dXs, dYs, dRowSq, dSum;
     FDX_TRY(dSlots.alloc(slots.size() * sizeof(Slot)));
     FDX_TRY(dBits.alloc(bits.size() * sizeof(unsigned)));
-    FDX_HIP(hipMemcpyAsync(dSlots.p, slots.data(), slots.size() * sizeof(Slot), hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(dSlots.p, slots.data(), slots.size() * sizeof(Slot), st));
     FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
     std::shared_ptr<SketchPlan> plan_x;
     FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, st, &plan_x));
     FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
     FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
-    FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(dX.p, X, (size_t)K * G * sizeof(double), st));
     FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, plan_x->dev(), dXs.as<double>(), d, nullptr, st));
     FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, XtX_out_dev, K, nullptr, st));
     double yty = 0.0;
@@ -495,9 +495,8 @@ extern "C" int fdx_gene_moments_dev(const void* Y_dev, int32_t dtype, int64_t n,
     FDX_TRY(mean.alloc((size_t)G * 8));
     FDX_TRY(var.alloc((size_t)G * 8));
     FDX_TRY(launch_gene_moments(Y_dev, dtype, ldy, n, G, scale.as<double>(), part.as<double>(), mean.as<double>(), var.as<double>(), st));
-    FDX_HIP(hipMemcpyAsync(mean_out_host, mean.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipMemcpyAsync(var_out_host, var.p, (size_t)G * 8, hipMemcpyDeviceToHost, st));
-    FDX_HIP(hipStreamSynchronize(st));
+    FDX_TRY(copy_d2h(mean_out_host, mean.p, (size_t)G * 8, st));
+    FDX_TRY(copy_d2h(var_out_host, var.p, (size_t)G * 8, st));
     return 0;
 }
 
@@ -509,7 +508,7 @@ extern "C" int fdx_gather_columns_dev(const void* Y_dev, int32_t dtype, int64_t 
     PoolStream pool_stream(st);
     DevBuf di;
     FDX_TRY(di.alloc((size_t)G_sel * 4));
-    FDX_HIP(hipMemcpyAsync(di.p, idx_host, (size_t)G_sel * 4, hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(di.p, idx_host, (size_t)G_sel * 4, st));
     FDX_TRY(launch_gather_columns(Y_dev, dtype, ldy, n, G, di.as<int>(), G_sel, out_dev, st));
     FDX_HIP(hipStreamSynchronize(st));
     return 0;

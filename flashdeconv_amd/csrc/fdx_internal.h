@@ -81,6 +81,12 @@ struct HelperTicket { std::mutex mu; std::condition_variable cv; bool done = fal
 std::shared_ptr<HelperTicket> helper_submit(std::function<int()> fn);
 int helper_wait(const std::shared_ptr<HelperTicket>& ticket);
 
+// Copies between the device and CALLER (possibly pageable) memory, through recycled pinned buffers for 64 KB - 32 MB (pool.cpp: the
+// driver must never pin pages the caller may unmap).  copy_h2d: asynchronous like hipMemcpyAsync (src may be reused at once);
+// copy_d2h: complete on return (it synchronises the stream).
+int copy_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st);
+int copy_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st);
+
 // the library's per-device non-blocking side stream (its own priority: fit.cpp); nullptr if it cannot be made
 hipStream_t library_side_stream();
 

@@ -120,6 +120,13 @@ hipStream_t library_side_stream() {
 }  // namespace fdx
 
 extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double regularization, fdx_leverage_job** out) {
+    return fdx_leverage_begin_opt(X, K, G, regularization, 1, out);
+}
+
+// queue_async = 0: the launches are queued by the calling thread (a caller that collects the scores at once gains nothing from the
+// helper thread - and in the gene-selection flow of FlashDeconv.fit the hand-over measurably cost ~3 ms of wait on some boxes)
+extern "C" int fdx_leverage_begin_opt(const double* X, int32_t K, int32_t G, double regularization, int32_t queue_async,
+                                      fdx_leverage_job** out) {
     FDX_REQUIRE(X && out && K > 0 && G > 0, "fdx_leverage_begin: bad arguments");
     *out = nullptr;
     auto* job = new fdx_leverage_job();
@@ -131,7 +138,7 @@ extern "C" int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double 
     std::memcpy(job->hX, X, (size_t)K * G * sizeof(double));
     // the upload (a pageable copy: the host waits for it) and the launches cost ~75 us of host time that the caller - on its way to
     // a graph build, with the scores not needed before the sketch tables - has better uses for: the helper thread queues them
-    const bool async = !getenv("FDX_NO_HELPER_THREAD");
+    const bool async = queue_async != 0 && !getenv("FDX_NO_HELPER_THREAD");
     auto run = [job, K, G, regularization]() -> int {
         PoolStream pool_stream(job->st);
         FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
@@ -237,7 +244,7 @@ extern "C" int fdx_column_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, 
     FDX_TRY(dPart.alloc((size_t)column_sums_parts(n) * G * sizeof(double)));
     FDX_TRY(dOut.alloc((size_t)G * sizeof(double)));
     FDX_TRY(launch_column_sums(Y_dev, dtype, ldy, n, G, dPart.as<double>(), dOut.as<double>(), st));
-    FDX_HIP(hipMemcpyAsync(sums_out_host, dOut.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
+    FDX_TRY(copy_d2h(sums_out_host, dOut.p, (size_t)G * sizeof(double), st));
     FDX_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -361,7 +368,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
                 if (slots[(size_t)c].bucket >= 0) bits[(size_t)c >> 5] |= 1u << (c & 31);
             FDX_TRY(dSlots.alloc(slots.size() * sizeof(GeneSlotHost)));
             FDX_TRY(dBits.alloc(bits.size() * sizeof(unsigned)));
-            FDX_HIP(hipMemcpyAsync(dSlots.p, slots.data(), slots.size() * sizeof(GeneSlotHost), hipMemcpyHostToDevice, xs));
+            FDX_TRY(copy_h2d(dSlots.p, slots.data(), slots.size() * sizeof(GeneSlotHost), xs));
             FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, xs));
             FDX_HIP(hipStreamSynchronize(xs));   // `slots` is a stack-scoped host buffer
         } else {
@@ -372,7 +379,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
         FDX_TRY(dXs.alloc((size_t)K * d * sizeof(double)));
         FDX_TRY(dG.alloc((size_t)K * K * sizeof(double)));
-        FDX_HIP(hipMemcpyAsync(dX.p, X, (size_t)K * G * sizeof(double), hipMemcpyHostToDevice, xs));
+        FDX_TRY(copy_h2d(dX.p, X, (size_t)K * G * sizeof(double), xs));
         FDX_TRY(launch_sketch_rows(dX.p, FDX_F64, G, nullptr, K, G, d, prm->mode_x, plan_x_p->dev(), dXs.as<double>(), d, nullptr, xs));
         FDX_TRY(launch_xyt(dXs.as<double>(), dXs.as<double>(), d, K, d, K, dG.as<double>(), K, nullptr, xs));
         if (KP != K) {
@@ -655,9 +662,9 @@ extern "C" int fdx_csr_gene_moments_dev(const fdx_csr_view* Y, double* mean_out_
     FDX_TRY(launch_csr_moments((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, Y->n, Y->G, scale.as<double>(),
                                part.as<double>(), o, o + G, colsum_out_host ? o + 2 * G : nullptr,
                                Y->sorted_rows ? cursor.as<int>() : nullptr, st));
-    if (mean_out_host) FDX_HIP(hipMemcpyAsync(mean_out_host, o, G * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (var_out_host) FDX_HIP(hipMemcpyAsync(var_out_host, o + G, G * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (colsum_out_host) FDX_HIP(hipMemcpyAsync(colsum_out_host, o + 2 * G, G * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (mean_out_host) FDX_TRY(copy_d2h(mean_out_host, o, G * sizeof(double), st));
+    if (var_out_host) FDX_TRY(copy_d2h(var_out_host, o + G, G * sizeof(double), st));
+    if (colsum_out_host) FDX_TRY(copy_d2h(colsum_out_host, o + 2 * G, G * sizeof(double), st));
     FDX_HIP(hipStreamSynchronize(st));
     return 0;
 }

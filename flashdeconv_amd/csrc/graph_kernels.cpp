@@ -1838,11 +1838,11 @@ int graph_plan_set_lists(fdx_graph_plan* plan, const long long* ids_host, const 
     if (n_rows == 0) return graph_plan_lists_replaced(plan);
     DevBuf d_ids, d_rows;
     FDX_TRY(d_ids.alloc((size_t)n_rows * plan->kk * 8));
-    FDX_HIP(hipMemcpyAsync(d_ids.p, ids_host, (size_t)n_rows * plan->kk * 8, hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(d_ids.p, ids_host, (size_t)n_rows * plan->kk * 8, st));
     if (rows_host) {
         for (long long r = 0; r < n_rows; ++r) FDX_REQUIRE(rows_host[r] >= 0 && rows_host[r] < plan->n, "graph: list row out of range");
         FDX_TRY(d_rows.alloc((size_t)n_rows * 8));
-        FDX_HIP(hipMemcpyAsync(d_rows.p, rows_host, (size_t)n_rows * 8, hipMemcpyHostToDevice, st));
+        FDX_TRY(copy_h2d(d_rows.p, rows_host, (size_t)n_rows * 8, st));
     }
     hipLaunchKernelGGL(lists_from_ids_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, st, d_ids.as<long long>(),
                        rows_host ? d_rows.as<long long>() : (const long long*)nullptr, n_rows, plan->kk, plan->b.rank.as<int>(), nbr, cnt);
@@ -1860,7 +1860,7 @@ int graph_plan_set_lists_device(fdx_graph_plan* plan, const long long* ids_dev, 
     if (rows_host) {
         for (long long r = 0; r < n_rows; ++r) FDX_REQUIRE(rows_host[r] >= 0 && rows_host[r] < plan->n, "graph: list row out of range");
         FDX_TRY(d_rows.alloc((size_t)n_rows * 8));
-        FDX_HIP(hipMemcpyAsync(d_rows.p, rows_host, (size_t)n_rows * 8, hipMemcpyHostToDevice, st));
+        FDX_TRY(copy_h2d(d_rows.p, rows_host, (size_t)n_rows * 8, st));
     }
     hipLaunchKernelGGL(lists_from_ids_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, st, ids_dev,
                        rows_host ? d_rows.as<long long>() : (const long long*)nullptr, n_rows, plan->kk, plan->b.rank.as<int>(), nbr, cnt);

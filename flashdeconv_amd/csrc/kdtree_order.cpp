@@ -611,10 +611,28 @@ __global__ __launch_bounds__(256) void kd_query_kernel(const double* __restrict_
 // ids_dev (n_rows, kk) int64, device: the answers for rows_host (NULL: every point in order), nearest first, self included, -1 padded.
 // coords_dev: the same (n, dim) float64 array as coords_host.  Queries on the device for 1-3 coordinates (FDX_KDTREE_HOST_QUERIES=1
 // or a deeper far-node heap than the work area holds: on the host's threads, then uploaded).
-int ckdtree_lists_device(const double* coords_host, const double* coords_dev, long long n, int dim, int kk, const long long* rows_host,
+// a recycled pinned buffer for the lifetime of one call (uploads / downloads from pageable memory make the driver pin the caller's
+// pages, and unmapping such pages later - a freed vector, a collected numpy array - evicts the process's GPU queues for 10-25 ms)
+struct PinnedScope {
+    void* p = nullptr;
+    size_t cap = 0;
+    int get(size_t bytes) { p = pinned_buffer_get(bytes, &cap); return p ? 0 : fail(FDX_ERR_HIP, "ckdtree: pinned host buffer"); }
+    ~PinnedScope() { if (p) pinned_buffer_put(p, cap); }
+};
+
+int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev, long long n, int dim, int kk, const long long* rows_host,
                          long long n_rows, long long* ids_dev, hipStream_t st) {
     const long long nq = rows_host ? n_rows : n;
     if (nq == 0) return 0;
+    // coords_host NULL: the coordinates are fetched here, into pinned memory
+    PinnedScope pin_coords;
+    const double* coords_host = coords_host_in;
+    if (!coords_host) {
+        FDX_TRY(pin_coords.get((size_t)n * dim * sizeof(double)));
+        FDX_HIP(hipMemcpyAsync(pin_coords.p, coords_dev, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        coords_host = static_cast<const double*>(pin_coords.p);
+    }
     const bool trace = getenv("FDX_TRACE_HOST") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     KdTree t;
@@ -623,16 +641,22 @@ int ckdtree_lists_device(const double* coords_host, const double* coords_dev, lo
     bool on_device = dim <= 3 && n < 0x7fffff00LL && (long long)t.nodes.size() < 0x7fffff00LL && !getenv("FDX_KDTREE_HOST_QUERIES");
     if (on_device) {
         const size_t nn = t.nodes.size();
-        std::vector<int4> meta(nn);
-        std::vector<double> split(nn);
+        // staging in pinned memory: [meta | split | indices | rows]
+        const size_t o_split = nn * sizeof(int4), o_idx = o_split + nn * sizeof(double), o_rows = o_idx + (((size_t)n * 4 + 15) & ~(size_t)15);
+        PinnedScope stage;
+        FDX_TRY(stage.get(o_rows + (rows_host ? (size_t)nq * 8 : 0) + 64));
+        char* sp = static_cast<char*>(stage.p);
+        int4* meta = reinterpret_cast<int4*>(sp);
+        double* split = reinterpret_cast<double*>(sp + o_split);
+        int* idx32 = reinterpret_cast<int*>(sp + o_idx);
         for (size_t i = 0; i < nn; ++i) {
             const KdNode& nd = t.nodes[i];
             const bool leaf = nd.split_dim == -1;
             meta[i] = make_int4(leaf ? -1 : (int)nd.split_dim, (int)(leaf ? nd.start : nd.less), (int)(leaf ? nd.end : nd.greater), 0);
             split[i] = nd.split;
         }
-        std::vector<int> idx32((size_t)n);
         for (long long i = 0; i < n; ++i) idx32[(size_t)i] = (int)t.indices[(size_t)i];
+        if (rows_host) std::memcpy(sp + o_rows, rows_host, (size_t)nq * 8);
         const long long L = std::min<long long>((nq + 255) / 256, 1024) * 256;
         DevBuf d_meta, d_split, d_idx, d_rows, d_over, qp, qnode, qs, np, ni;
         FDX_TRY(d_meta.alloc(nn * sizeof(int4)));
@@ -644,13 +668,13 @@ int ckdtree_lists_device(const double* coords_host, const double* coords_dev, lo
         FDX_TRY(qs.alloc((size_t)KD_QCAP * dim * L * 8));
         FDX_TRY(np.alloc((size_t)kk * L * 8));
         FDX_TRY(ni.alloc((size_t)kk * L * 4));
-        FDX_HIP(hipMemcpyAsync(d_meta.p, meta.data(), nn * sizeof(int4), hipMemcpyHostToDevice, st));
-        FDX_HIP(hipMemcpyAsync(d_split.p, split.data(), nn * sizeof(double), hipMemcpyHostToDevice, st));
-        FDX_HIP(hipMemcpyAsync(d_idx.p, idx32.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        FDX_HIP(hipMemcpyAsync(d_meta.p, meta, nn * sizeof(int4), hipMemcpyHostToDevice, st));
+        FDX_HIP(hipMemcpyAsync(d_split.p, split, nn * sizeof(double), hipMemcpyHostToDevice, st));
+        FDX_HIP(hipMemcpyAsync(d_idx.p, idx32, (size_t)n * 4, hipMemcpyHostToDevice, st));
         FDX_HIP(hipMemsetAsync(d_over.p, 0, 4, st));
         if (rows_host) {
             FDX_TRY(d_rows.alloc((size_t)nq * 8));
-            FDX_HIP(hipMemcpyAsync(d_rows.p, rows_host, (size_t)nq * 8, hipMemcpyHostToDevice, st));
+            FDX_HIP(hipMemcpyAsync(d_rows.p, sp + o_rows, (size_t)nq * 8, hipMemcpyHostToDevice, st));
         }
         KdBounds bnd{};
         for (int a = 0; a < dim; ++a) { bnd.mins[a] = t.mins[(size_t)a]; bnd.maxes[a] = t.maxes[(size_t)a]; }

@@ -3,6 +3,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -154,6 +156,83 @@ void pinned_buffer_put(void* p, size_t cap) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pin_mu);
     g_pinbuf_free[cap].push_back(p);
+}
+
+// ---- transfers between the device and CALLER (pageable) memory --------------------------------------------------------------------
+// hipMemcpy on pageable memory lets the driver pin the caller's pages for the DMA; when such pages are unmapped later (a collected
+// numpy array, a freed std::vector above malloc's mmap threshold) the kernel's MMU notifier evicts the process's GPU queues and the
+// next launch waits 10-25 ms for their restore (measured, round 5: the lattice and CSR families' "stalls after a host phase").
+// Copies of 64 KB to 32 MB therefore go through recycled pinned buffers: the caller's memory is only ever touched by memcpy.
+// (Smaller ones live on the heap, which is not unmapped; larger ones - a result matrix - keep the direct path: a staging copy of
+// hundreds of megabytes costs more than the stall it avoids.)
+namespace {
+constexpr size_t kStageMin = 64 * 1024, kStageMax = 32u << 20;
+struct PendingPin { void* p; size_t cap; hipEvent_t ev; };
+std::vector<PendingPin> g_pin_pending;        // uploads still in flight: released when their event has completed (g_pin_mu)
+void reap_pending_pins() {
+    std::vector<PendingPin> done;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pin_pending.size();) {
+            if (hipEventQuery(g_pin_pending[i].ev) != hipErrorNotReady) {
+                done.push_back(g_pin_pending[i]);
+                g_pin_pending[i] = g_pin_pending.back();
+                g_pin_pending.pop_back();
+            } else {
+                ++i;
+            }
+        }
+    }
+    for (const PendingPin& d : done) {
+        (void)hipEventDestroy(d.ev);
+        pinned_buffer_put(d.p, d.cap);
+    }
+}
+}  // namespace
+
+int copy_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if (bytes < kStageMin || bytes > kStageMax || getenv("FDX_NO_STAGED_COPIES")) {
+        FDX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+        return 0;
+    }
+    reap_pending_pins();
+    size_t cap = 0;
+    void* pin = pinned_buffer_get(bytes, &cap);
+    if (!pin) return fail(FDX_ERR_HIP, "copy_h2d: pinned host buffer");
+    std::memcpy(pin, src_host, bytes);
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipMemcpyAsync(dst_dev, pin, bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, st);
+    if (e != hipSuccess) {                                   // nothing may still read the buffer when it goes back
+        (void)hipStreamSynchronize(st);
+        if (ev) (void)hipEventDestroy(ev);
+        pinned_buffer_put(pin, cap);
+        return fail(FDX_ERR_HIP, std::string("copy_h2d: ") + hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_pending.push_back(PendingPin{pin, cap, ev});
+    return 0;
+}
+
+int copy_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if (bytes < kStageMin || bytes > kStageMax || getenv("FDX_NO_STAGED_COPIES")) {
+        FDX_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        FDX_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    size_t cap = 0;
+    void* pin = pinned_buffer_get(bytes, &cap);
+    if (!pin) return fail(FDX_ERR_HIP, "copy_d2h: pinned host buffer");
+    hipError_t e = hipMemcpyAsync(pin, src_dev, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) std::memcpy(dst_host, pin, bytes);
+    else (void)hipStreamSynchronize(st);
+    pinned_buffer_put(pin, cap);
+    if (e != hipSuccess) return fail(FDX_ERR_HIP, std::string("copy_d2h: ") + hipGetErrorString(e));
+    return 0;
 }
 
 void* pinned_scratch(int slot, size_t bytes) {

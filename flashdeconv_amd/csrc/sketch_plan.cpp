@@ -45,8 +45,8 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
     }
     FDX_TRY(gene_w.alloc(gw.size() * sizeof(double)));
     FDX_TRY(gene_bucket.alloc(gb.size() * sizeof(int)));
-    FDX_HIP(hipMemcpyAsync(gene_w.p, gw.data(), gw.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(gene_bucket.p, gb.data(), gb.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(gene_w.p, gw.data(), gw.size() * sizeof(double), st));
+    FDX_TRY(copy_h2d(gene_bucket.p, gb.data(), gb.size() * sizeof(int), st));
     if (scatter_ok && sketch_scatter_fits(G, d) && !getenv("FDX_SKETCH_GATHER") && !getenv("FDX_SKETCH_NO_SCATTER")) {
         // the scatter kernel will serve this plan: the gather schedule below is never read
         n_groups = 0;
@@ -112,15 +112,15 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
         }
     }
     FDX_TRY(sched_pack.alloc(sp.size() * sizeof(unsigned int)));
-    FDX_HIP(hipMemcpyAsync(sched_pack.p, sp.data(), sp.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(sched_pack.p, sp.data(), sp.size() * sizeof(unsigned int), st));
     FDX_TRY(sched_gene.alloc(sg.size() * sizeof(int)));
     FDX_TRY(sched_w.alloc(sw.size() * sizeof(double)));
     FDX_TRY(group_off.alloc(goff.size() * sizeof(int)));
     FDX_TRY(slot_bucket.alloc(slot_b.size() * sizeof(int)));
-    FDX_HIP(hipMemcpyAsync(sched_gene.p, sg.data(), sg.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(sched_w.p, sw.data(), sw.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(group_off.p, goff.data(), goff.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    FDX_HIP(hipMemcpyAsync(slot_bucket.p, slot_b.data(), slot_b.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    FDX_TRY(copy_h2d(sched_gene.p, sg.data(), sg.size() * sizeof(int), st));
+    FDX_TRY(copy_h2d(sched_w.p, sw.data(), sw.size() * sizeof(double), st));
+    FDX_TRY(copy_h2d(group_off.p, goff.data(), goff.size() * sizeof(int), st));
+    FDX_TRY(copy_h2d(slot_bucket.p, slot_b.data(), slot_b.size() * sizeof(int), st));
     FDX_HIP(hipStreamSynchronize(st));   // the host vectors die at scope exit
     return 0;
 }

@@ -735,7 +735,7 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     TilePlanDevice& t = *best;
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         FDX_TRY(b.alloc(bytes));
-        FDX_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+        FDX_TRY(copy_h2d(b.p, src, bytes, st));
         return 0;
     };
     // group lengths, 8 to a 64-bit word: rows of JW_PAD(JW) bytes

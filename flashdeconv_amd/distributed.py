@@ -585,13 +585,12 @@ class ShardedFlashDeconv:
         _lib.check(lib.fdx_graph_plan_order_dev(plan, ctypes.c_void_p(perm_t.data_ptr()), None, st))
         rows_pos = torch.nonzero(cnt > 0).flatten()                       # own rows + band: the rows that have lists
         if rows_pos.numel():
-            ids = np.ascontiguousarray(perm_t[rows_pos].long().cpu().numpy())
-            ch = np.ascontiguousarray(coords.detach().cpu().numpy(), dtype=np.float64)
+            ids = np.ascontiguousarray(_lib.tensor_to_host(perm_t[rows_pos].long()))
             cd = coords if (coords.dtype == torch.float64 and coords.is_contiguous()) else coords.double().contiguous()
             _ckdtree_restatement_matches_scipy()
             # the restated tree on the host, its queries for these rows on the device; the answers (caller ids, self included) go to
             # solver positions, self dropped (utils/graph.py:70-74), at the rows' positions
-            _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, _lib.ptr_f64(ch), ctypes.c_void_p(cd.data_ptr()), n, dim,
+            _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, None, ctypes.c_void_p(cd.data_ptr()), n, dim,
                                                                 ids.ctypes.data, len(ids), ctypes.c_void_p(nbr.data_ptr()),
                                                                 ctypes.c_void_p(cnt.data_ptr()), st))
         _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi,
@@ -684,7 +683,7 @@ class ShardedFlashDeconv:
             # (one rank, or more than 3 coordinates) every rank builds the reference's whole graph on the host and takes its rows;
             # the graph is in the CALLER's order (no Morton sort), so a shard is a range of the caller's spot numbers.
             from .utils.graph import ckdtree_knn_adjacency
-            A = ckdtree_knn_adjacency(coords.detach().cpu().numpy().astype(np.float64), int(self.k_neighbors))
+            A = ckdtree_knn_adjacency(_lib.tensor_to_host(coords).astype(np.float64), int(self.k_neighbors))
             if self._full is not None:
                 self._full.close()
             self._full = _lib.Graph.from_csr(A.indptr, A.indices, n)
@@ -756,7 +755,7 @@ class ShardedFlashDeconv:
                 mean_r, var_r = _genes.gene_moments_device(ctypes.c_void_p(Y_own.data_ptr()), y_code, self.n_own, G, G)
                 sums[0], sums[1] = combine_moment_sums(mean_r, var_r, self.n_own, dev)
             self.comm.all_reduce_sum(sums)
-            mean, var = moments_from_sums(sums[0].cpu().numpy(), sums[1].cpu().numpy(), self.n_total_spots)
+            mean, var = moments_from_sums(_lib.tensor_to_host(sums[0]), _lib.tensor_to_host(sums[1]), self.n_total_spots)
             hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
             markers, _ = _genes.select_markers(X, n_markers=self.n_markers_per_type)
             self.gene_idx_ = np.union1d(hvg, markers).astype(np.intp)
@@ -791,7 +790,7 @@ class ShardedFlashDeconv:
                                                    self.n_own, G, G, _lib.ptr_f64(sums), st))
             tsum = torch.from_numpy(sums).to(dev)
             self.comm.all_reduce_sum(tsum)
-            mu_y = tsum.cpu().numpy() / self.n_total_spots + 1e-6
+            mu_y = _lib.tensor_to_host(tsum) / self.n_total_spots + 1e-6
             mu_x = X.mean(axis=0) + 1e-6
             weight_y = weight / np.sqrt(mu_y + mu_y ** 2 / 100.0)
             weight_x = weight / np.sqrt(mu_x + mu_x ** 2 / 100.0)
@@ -910,9 +909,9 @@ class ShardedFlashDeconv:
                     sums[0], sums[1] = combine_moment_sums(mean_r, var_r, self.n_own, dev)
                     sums[2] = torch.from_numpy(col_r).to(dev)
                 self.comm.all_reduce_sum(sums)
-                colsum = sums[2].cpu().numpy()
+                colsum = _lib.tensor_to_host(sums[2])
                 if G_all > self.n_hvg:
-                    mean, var = moments_from_sums(sums[0].cpu().numpy(), sums[1].cpu().numpy(), self.n_total_spots)
+                    mean, var = moments_from_sums(_lib.tensor_to_host(sums[0]), _lib.tensor_to_host(sums[1]), self.n_total_spots)
                     hvg = _genes._hvg_from_moments(mean, var, self.n_hvg, 0.0125, 3.0, 0.5)
                     markers, _ = _genes.select_markers(X, n_markers=self.n_markers_per_type)
                     self.gene_idx_ = np.union1d(hvg, markers).astype(np.intp)

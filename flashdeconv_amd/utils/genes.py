@@ -26,13 +26,15 @@ class LeverageJob:
     """compute_leverage_scores split in two: the constructor enqueues the single-workgroup SVD on a side stream,
     ``result()`` waits for it.  FlashDeconv.fit builds the spatial graph in between."""
 
-    def __init__(self, X, regularization=1e-6):
+    def __init__(self, X, regularization=1e-6, queue_async=True):
         X = _lib.as_f64(X)
         self.G = X.shape[1]
         _lib.require_gpu()
         self._job = ctypes.c_void_p()
-        _lib.check(_lib.load().fdx_leverage_begin(_lib.ptr_f64(X), X.shape[0], X.shape[1], float(regularization),
-                                                  ctypes.byref(self._job)))
+        # queue_async: the library's helper thread queues the upload and the launches while this thread goes on (to a graph build);
+        # False for a caller that collects the result at once
+        _lib.check(_lib.load().fdx_leverage_begin_opt(_lib.ptr_f64(X), X.shape[0], X.shape[1], float(regularization),
+                                                      1 if queue_async else 0, ctypes.byref(self._job)))
 
     def result(self):
         if self._job is None:
@@ -59,20 +61,47 @@ def select_markers(X, n_markers=50, method="diff"):
         raise ValueError(f"n_markers must be non-negative, got {n_markers}")
     if n_markers == 0 or K == 0:
         return np.array([], dtype=np.intp), np.array([], dtype=np.intp)
-    frac = X / (X.sum(axis=1, keepdims=True) + 1e-10)
     if K == 1:
         idx = np.arange(min(n_markers, G))
         return idx, np.zeros(len(idx), dtype=np.intp)
-    owner = np.argmax(frac, axis=0)
-    if method == "diff":                              # utils/genes.py:197-200: largest minus second largest fraction per gene
-        # two column maxima instead of a sort (or a partition along the strided axis: 16 ms at 30 x 20000 against 1.5): the
-        # second largest is the maximum with the first occurrence of the largest taken out - a tie gives the same value twice,
-        # as the sorted column does
-        cols = np.arange(G)
-        largest = frac[owner, cols]
-        rest = frac.copy()
-        rest[owner, cols] = -np.inf
-        specificity = largest - rest.max(axis=0)
+    denom = X.sum(axis=1, keepdims=True) + 1e-10
+    frac = None
+    if method == "diff" and np.isfinite(X).all():     # utils/genes.py:197-200: largest minus second largest fraction per gene
+        # One pass over the cell types with a running (largest, second largest, owner) per gene instead of the (K, G) fraction
+        # matrix, its strided argmax and a masked second maximum (3.2 -> 1 ms at 30 x 20000; this runs beside the device's gene
+        # statistics and must not outlast them).  The same divisions, the same selections: a strictly larger value takes over
+        # (np.argmax keeps the FIRST maximum), a tie leaves the owner and makes the second largest equal the largest, as the
+        # sorted column does.
+        # (selections only - maximum / minimum of non-negative finite values - so the bits are those of the matrix form; masked
+        # copies cost 20 x a plain pass in numpy, hence the arithmetic owner update)
+        m1 = np.divide(X[0], denom[0])
+        m2 = np.full(G, -np.inf)
+        owner = np.zeros(G, dtype=np.int64)
+        v = np.empty(G)
+        lo = np.empty(G)
+        bigger = np.empty(G, dtype=bool)
+        step = np.empty(G, dtype=np.int64)
+        for k in range(1, K):
+            np.divide(X[k], denom[k], out=v)
+            np.greater(v, m1, out=bigger)
+            np.minimum(m1, v, out=lo)                 # what does not become the largest ...
+            np.maximum(m2, lo, out=m2)                # ... competes for second place (a tie: the same value twice)
+            np.maximum(m1, v, out=m1)
+            np.subtract(k, owner, out=step)           # owner = k where v took over
+            np.multiply(step, bigger, out=step)
+            np.add(owner, step, out=owner)
+        specificity = m1 - m2
+    else:
+        frac = X / denom
+        owner = np.argmax(frac, axis=0)
+        if method == "diff":                          # NaN / inf somewhere: the plain form (np.argmax's and max's NaN rules)
+            cols = np.arange(G)
+            largest = frac[owner, cols]
+            rest = frac.copy()
+            rest[owner, cols] = -np.inf
+            specificity = largest - rest.max(axis=0)
+    if method == "diff":
+        pass
     elif method == "ratio":                           # utils/genes.py:202-206: largest fraction over the mean of the others
         largest = frac.max(axis=0)
         specificity = largest / ((frac.sum(axis=0) - largest) / (K - 1) + 1e-10)
@@ -82,12 +111,16 @@ def select_markers(X, n_markers=50, method="diff"):
     else:
         raise ValueError(f"Unknown method: {method}")
     chosen, assign = [], []
+    # the genes of every type in ascending order (= np.flatnonzero(owner == k)) from one stable sort
+    by_owner = np.argsort(owner.astype(np.uint8 if K <= 256 else np.int64), kind="stable")   # (8-bit keys: a counting sort)
+    ends = np.cumsum(np.bincount(owner, minlength=K))
     for k in range(K):
-        mine = np.flatnonzero(owner == k)
+        mine = by_owner[(ends[k - 1] if k else 0):ends[k]]
         if mine.size:
             pick = mine[np.argsort(specificity[mine])[::-1][:n_markers]]
         else:
-            pick = np.argsort(frac[k])[::-1][:n_markers]
+            row = frac[k] if frac is not None else X[k] / denom[k]
+            pick = np.argsort(row)[::-1][:n_markers]
         chosen.extend(pick.tolist())
         assign.extend([k] * len(pick))
     return np.unique(chosen), np.array(assign)

@@ -112,6 +112,10 @@ int fdx_leverage_scores(const double* X, int32_t K, int32_t G, double regulariza
 typedef struct fdx_leverage_job fdx_leverage_job;
 int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double regularization, fdx_leverage_job** job);
 int fdx_leverage_end(fdx_leverage_job* job, double* lev_out);
+/* fdx_leverage_begin with a choice of who queues the job's upload and launches: queue_async != 0 - the library's helper thread (the
+ * caller returns at once and has ~75 us more for its own launches: fdx_leverage_begin does this); 0 - the calling thread (for a caller
+ * that collects the scores right away). */
+int fdx_leverage_begin_opt(const double* X, int32_t K, int32_t G, double regularization, int32_t queue_async, fdx_leverage_job** job);
 
 /* ---- spatial graph (replaces utils/graph.py:25-212 and the CSR handling of core/solver.py:363-365) ---- */
 typedef struct fdx_graph fdx_graph;
