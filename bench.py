@@ -499,7 +499,7 @@ def main():
             import warnings
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                model, dt, stage = run_family(torch, kw, Y, X, coords, lsteps, min(a.warmup, 1), barrier)
+                model, dt, stage = run_family(torch, kw, Y, X, coords, lsteps, min(a.warmup, 2), barrier)
             ms_step = dt / lsteps * 1e3
             results[fam] = {
                 "value": n * lsteps / dt, "unit": "spots/s", "ms_per_step": ms_step, "cold_ms": round(stage["cold_ms"], 3),
@@ -515,7 +515,7 @@ def main():
         if fam == "sparse":
             Y, X, coords = gen_sparse(torch, n, a.sparse_genes, K, device, seed=0)
             kw = dict(sketch_dim=d, preprocess="log_cpm", n_hvg=G, max_iter=20)
-            model, dt, stage = run_family(torch, kw, Y, X, coords, max(1, min(a.steps, 2)), min(a.warmup, 1), barrier)
+            model, dt, stage = run_family(torch, kw, Y, X, coords, max(1, min(a.steps, 2)), min(a.warmup, 2), barrier)   # two untimed fits: the second one still pays ~6 ms once (pooled buffers changing hands)
             nnz_y = int(Y.values().numel())
             # fused CSR sketch -> H (gram_ms == 0): reads the stored entries (4 B value + 4 B column each) and the row extents, writes
             # H; the two-kernel path also writes and re-reads Y_sketch (n x d x 8 B)
@@ -548,7 +548,7 @@ def main():
             Y, X, coords = gen_counts(torch, n, G, K, device, seed=0)
             kw = dict(sketch_dim=d, preprocess="log_cpm", n_hvg=G)
         steps = a.steps if fam == "gaussian" else max(1, min(a.steps, 2))
-        model, dt, stage = run_family(torch, kw, Y, X, coords, steps, a.warmup if fam == "gaussian" else min(a.warmup, 1), barrier)
+        model, dt, stage = run_family(torch, kw, Y, X, coords, steps, a.warmup if fam == "gaussian" else min(a.warmup, 2), barrier)
         T = model.info_["n_iterations"]
         nnz = int(model._graph.info()[1])
         sk_bytes, sw_bytes = alg_bytes(n, G, K, 4, nnz, 0, T)
