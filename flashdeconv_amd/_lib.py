@@ -53,7 +53,7 @@ class ShardFitParams(ctypes.Structure):
     """fdx_shard_fit_params (include/fdx.h)."""
     _fields_ = [("sketch_dim", c_i32), ("mode_y", c_i32), ("mode_x", c_i32), ("lambda_auto", c_i32), ("max_iter", c_i32),
                 ("stop_on_ties", c_i32), ("lambda_spatial", c_double), ("rho_sparsity", c_double), ("tol", c_double),
-                ("n_total_spots", c_i64), ("nnz_total", c_i64)]
+                ("n_total_spots", c_i64), ("nnz_total", c_i64), ("X_dev", c_void_p)]
 
 
 class ShardFitInfo(ctypes.Structure):
@@ -105,6 +105,7 @@ SIGNATURES = {
     "fdx_leverage_begin": (c_int, [p_double, c_i32, c_i32, c_double, ctypes.POINTER(c_void_p)]),
     "fdx_leverage_begin_opt": (c_int, [p_double, c_i32, c_i32, c_double, c_i32, ctypes.POINTER(c_void_p)]),
     "fdx_leverage_end": (c_int, [c_void_p, p_double]),
+    "fdx_leverage_end_keep": (c_int, [c_void_p, p_double, ctypes.POINTER(c_void_p)]),
     "fdx_fit_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
                             c_i32, ctypes.POINTER(FitParams), ctypes.POINTER(c_void_p), c_void_p, c_void_p, p_double,
                             p_double, ctypes.POINTER(FitInfo), c_void_p]),

@@ -263,7 +263,7 @@ int fdx_prepare_dev(const void* Y_dev, int32_t y_dtype, int64_t n, int32_t G, in
 namespace fdx {
 int prepare_queue(PrepareJob* job, const void* Y_dev, int y_dtype, long long n, int G, long long ldy, const int* row_map_dev,
                   const double* X, int K, const int* bucket, const double* weight_y, const double* weight_x, int d, int mode_y_in,
-                  int mode_x, double* H_out_dev, long long ldh, double* XtX_host, hipStream_t st) {
+                  int mode_x, double* H_out_dev, long long ldh, double* XtX_host, hipStream_t st, const double* X_dev) {
     const int32_t mode_y = mode_y_in & 0xff;
     TileF64Math f64_math((mode_y_in & FDX_PRE_F64_MATH) != 0);
     FDX_REQUIRE(y_dtype == FDX_F32 || y_dtype == FDX_F64, "fdx_prepare_dev: Y dtype must be FDX_F32 or FDX_F64");
@@ -284,11 +284,15 @@ int prepare_queue(PrepareJob* job, const void* Y_dev, int y_dtype, long long n, 
         FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, xs, &job->plan_y));
         if (weight_x == weight_y) job->plan_x = job->plan_y;
         else FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, xs, &job->plan_x));
-        FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
         FDX_TRY(job->dXs.alloc((size_t)K * d * sizeof(double)));
         FDX_TRY(job->dG.alloc((size_t)K * K * sizeof(double)));
-        FDX_TRY(copy_h2d(job->dX.p, X, (size_t)K * G * sizeof(double), xs));
-        FDX_TRY(launch_sketch_rows(job->dX.p, FDX_F64, G, nullptr, K, G, d, mode_x, job->plan_x->dev(), job->dXs.as<double>(), d, nullptr, xs));
+        const void* Xd = X_dev;                                            // already there (the leverage job's copy, complete)
+        if (!Xd) {
+            FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
+            FDX_TRY(copy_h2d(job->dX.p, X, (size_t)K * G * sizeof(double), xs));
+            Xd = job->dX.p;
+        }
+        FDX_TRY(launch_sketch_rows(Xd, FDX_F64, G, nullptr, K, G, d, mode_x, job->plan_x->dev(), job->dXs.as<double>(), d, nullptr, xs));
         FDX_TRY(launch_xyt(job->dXs.as<double>(), job->dXs.as<double>(), d, K, d, K, job->dG.as<double>(), K, nullptr, xs));
         if (XtX_host)
             FDX_HIP(hipMemcpyAsync(XtX_host, job->dG.p, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, xs));

@@ -490,7 +490,7 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
     if (g->shard_pending) if (const char* e = getenv("FDX_SKETCH_RESERVE")) reserve = atoi(e);
     const int reserve_prev = tile_sketch_reserve_cus(reserve);
     const int prc = prepare_queue(&job, Y_dev, y_dtype, n_own, G, ldy, nullptr, X, K, bucket, weight_y, weight_x, prm->sketch_dim,
-                                  prm->mode_y, prm->mode_x, dH.as<double>(), ldh, Gh, st);
+                                  prm->mode_y, prm->mode_x, dH.as<double>(), ldh, Gh, st, prm->X_dev);
     tile_sketch_reserve_cus(reserve_prev);
     FDX_TRY(prc);
     shard_trace("X side + sketch queued");

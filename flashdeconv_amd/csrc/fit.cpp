@@ -175,7 +175,14 @@ extern "C" int fdx_leverage_begin_opt(const double* X, int32_t K, int32_t G, dou
     return 0;
 }
 
-extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) {
+static int leverage_end_impl(fdx_leverage_job* job, double* lev_out, double** x_dev_out);
+extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) { return leverage_end_impl(job, lev_out, nullptr); }
+extern "C" int fdx_leverage_end_keep(fdx_leverage_job* job, double* lev_out, double** x_dev_out) {
+    FDX_REQUIRE(x_dev_out != nullptr, "fdx_leverage_end_keep: null output");
+    *x_dev_out = nullptr;
+    return leverage_end_impl(job, lev_out, x_dev_out);
+}
+static int leverage_end_impl(fdx_leverage_job* job, double* lev_out, double** x_dev_out) {
     FDX_REQUIRE(job != nullptr, "fdx_leverage_end: null job");
     if (job->ticket) {
         const int qrc = helper_wait(job->ticket);
@@ -220,6 +227,11 @@ extern "C" int fdx_leverage_end(fdx_leverage_job* job, double* lev_out) {
     if (!rc && e != hipSuccess) rc = fail(FDX_ERR_HIP, hipGetErrorString(e));
     if (e == hipSuccess)              // nothing of the job is in flight any more: the blocks may follow any stream
         for (DevBuf* b : {&job->dX, &job->dW, &job->dS, &job->dL, &job->dDbg, &job->dScratch}) b->mark_idle();
+    if (!rc && e == hipSuccess && x_dev_out) {      // the device copy of X changes hands (the caller returns it with fdx_free)
+        *x_dev_out = job->dX.as<double>();
+        job->dX.p = nullptr;
+        job->dX.bytes = job->dX.cap = 0;
+    }
     if (!rc && getenv("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
         std::fprintf(stderr, "[fdx] leverage: K=%d G=%d route=%s passes/sweeps=%d converged=%d\n", job->K, job->G,
                      job->route == LEV_ROUTE_QR ? "cholesky-qr" : "jacobi-svd", dbg[0], dbg[6]);

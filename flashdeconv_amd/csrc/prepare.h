@@ -21,6 +21,6 @@ struct PrepareJob {
 // NULL - filled behind job->evX (pageable: before this returns).  H_out_dev (K, ldh): columns [0, n) written.
 int prepare_queue(PrepareJob* job, const void* Y_dev, int y_dtype, long long n, int G, long long ldy, const int* row_map_dev,
                   const double* X, int K, const int* bucket, const double* weight_y, const double* weight_x, int d, int mode_y_in,
-                  int mode_x, double* H_out_dev, long long ldh, double* XtX_host, hipStream_t st);
+                  int mode_x, double* H_out_dev, long long ldh, double* XtX_host, hipStream_t st, const double* X_dev = nullptr);
 
 }  // namespace fdx

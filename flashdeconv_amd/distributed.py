@@ -770,8 +770,10 @@ class ShardedFlashDeconv:
             G = len(gi32)
         t0 = time.perf_counter()
         job, self._lev_job = getattr(self, "_lev_job", None), None
+        self._x_dev_job = None
         if job is not None and job[0].shape == X.shape and np.array_equal(job[0], X):
-            lev = job[1].result()
+            lev = job[1].result(keep_x=True)       # the job's device copy of X serves the native fit below (no second upload)
+            self._x_dev_job = job[1]
         else:
             lev = compute_leverage_scores(X)
         t0 = self._tick("leverage", t0)
@@ -801,12 +803,17 @@ class ShardedFlashDeconv:
         n_own = self.n_own
         b32 = np.ascontiguousarray(bucket, dtype=np.int32)
         wy, wx = _lib.as_f64(weight_y), _lib.as_f64(weight_x)
-        for attempt in range(2):
-            # the whole rest of the fit in ONE native call (csrc/comm.cpp: fdx_shard_fit_dev) when libfdx owns the communicator;
-            # a status (far walk / bound too small / ties) sends the plan through its remedy and, with the final graph, back here
-            done = self._fit_native(Y_own, y_code, X, K, G, b32, wy, wx, mode_y, mode_x)
-            if done is not False:
-                break
+        try:
+            for attempt in range(2):
+                # the whole rest of the fit in ONE native call (csrc/comm.cpp: fdx_shard_fit_dev) when libfdx owns the communicator;
+                # a status (far walk / bound too small / ties) sends the plan through its remedy and, with the final graph, back here
+                done = self._fit_native(Y_own, y_code, X, K, G, b32, wy, wx, mode_y, mode_x)
+                if done is not False:
+                    break
+        finally:
+            if self._x_dev_job is not None:
+                self._x_dev_job.release_x()
+                self._x_dev_job = None
         if done:
             return self.proportions_
         ld = ((n_own + 1 + 63) // 64) * 64          # H is read for the own rows only: its stride does not wait for the halo count
@@ -847,6 +854,8 @@ class ShardedFlashDeconv:
         prm.stop_on_ties = 1 if (pending and self.spatial_method == "knn" and self.knn_ties != "index") else 0
         prm.n_total_spots = int(self.n_total_spots)
         prm.nnz_total = -1 if pending else int(self.nnz_total)
+        xj = getattr(self, "_x_dev_job", None)
+        prm.X_dev = getattr(xj, "x_dev", None) if xj is not None else None
         if getattr(self.comm, "loopback", False) and pending:               # measurement: the job's total, known to the stand-in
             tot = getattr(self.comm, "totals", {}).get((3,))
             if tot is not None:

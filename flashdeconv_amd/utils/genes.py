@@ -36,13 +36,25 @@ class LeverageJob:
         _lib.check(_lib.load().fdx_leverage_begin_opt(_lib.ptr_f64(X), X.shape[0], X.shape[1], float(regularization),
                                                       1 if queue_async else 0, ctypes.byref(self._job)))
 
-    def result(self):
+    def result(self, keep_x=False):
+        """The scores.  keep_x: the job's device copy of X is kept (``self.x_dev``, until ``release_x()``) for a fit that needs
+        the same matrix on the device."""
         if self._job is None:
             raise RuntimeError("leverage job already collected")
         lev = np.empty(self.G, dtype=np.float64)
         job, self._job = self._job, None
-        _lib.check(_lib.load().fdx_leverage_end(job, _lib.ptr_f64(lev)))
+        if keep_x:
+            xd = ctypes.c_void_p()
+            _lib.check(_lib.load().fdx_leverage_end_keep(job, _lib.ptr_f64(lev), ctypes.byref(xd)))
+            self.x_dev = xd if xd.value else None
+        else:
+            _lib.check(_lib.load().fdx_leverage_end(job, _lib.ptr_f64(lev)))
         return lev
+
+    def release_x(self):
+        xd, self.x_dev = getattr(self, "x_dev", None), None
+        if xd is not None:
+            _lib.load().fdx_free(xd)
 
     def __del__(self):
         if getattr(self, "_job", None) is not None:
@@ -50,6 +62,10 @@ class LeverageJob:
                 self.result()
             except Exception:
                 pass
+        try:
+            self.release_x()
+        except Exception:
+            pass
 
 
 def select_markers(X, n_markers=50, method="diff"):

@@ -112,6 +112,9 @@ int fdx_leverage_scores(const double* X, int32_t K, int32_t G, double regulariza
 typedef struct fdx_leverage_job fdx_leverage_job;
 int fdx_leverage_begin(const double* X, int32_t K, int32_t G, double regularization, fdx_leverage_job** job);
 int fdx_leverage_end(fdx_leverage_job* job, double* lev_out);
+/* fdx_leverage_end that hands the job's device copy of X to the caller instead of releasing it (*x_dev_out: K x G float64, to be
+ * returned with fdx_free): a fit that follows needs the same matrix on the device (fdx_shard_fit_params.X_dev). */
+int fdx_leverage_end_keep(fdx_leverage_job* job, double* lev_out, double** x_dev_out);
 /* fdx_leverage_begin with a choice of who queues the job's upload and launches: queue_async != 0 - the library's helper thread (the
  * caller returns at once and has ~75 us more for its own launches: fdx_leverage_begin does this); 0 - the calling thread (for a caller
  * that collects the scores right away). */
@@ -453,6 +456,7 @@ typedef struct {
     int32_t sketch_dim, mode_y, mode_x, lambda_auto, max_iter, stop_on_ties;
     double lambda_spatial, rho_sparsity, tol;
     int64_t n_total_spots, nnz_total;
+    const double* X_dev;          /* optional: X already on the device (K x G row-major float64, e.g. from fdx_leverage_end_keep): not uploaded again */
 } fdx_shard_fit_params;
 typedef struct {
     int32_t status, reserved;
