@@ -247,6 +247,28 @@ def require_gpu():
     return n.value
 
 
+def host_cpu_budget():
+    """CPUs this process may keep busy: its affinity mask cut to the control group's CPU bandwidth quota (csrc/kdtree_order.cpp has
+    the same rule: threads beyond the quota only get the whole process throttled)."""
+    cpus = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+        if q != "max" and float(period) > 0:
+            cpus = min(cpus, float(q) / float(period))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = float(f.read())
+            if q > 0 and period > 0:
+                cpus = min(cpus, q / period)
+        except (OSError, ValueError):
+            pass
+    return max(1, int(round(cpus)))
+
+
 def tensor_to_host(t):
     """A CUDA torch tensor as a numpy array, copied through the library's pinned staging (fdx_memcpy_d2h): ``t.cpu()`` hands the
     driver pageable memory to pin, and unmapping that memory later stalls the process's GPU queues (csrc/pool.cpp: copy_d2h)."""
