@@ -360,26 +360,11 @@ int fdx_prepare_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t 
     FDX_REQUIRE(ldh >= n, "fdx_prepare_csr_dev: leading dimension too small");
     hipStream_t st = (hipStream_t)stream;
     PoolStream pool_stream(st);
-    struct Slot { double w; int bucket; int pad; };
-    FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(Slot), "fdx_prepare_csr_dev: gene slot layout mismatch");
     const int G_all = Y->G;
-    std::vector<Slot> slots((size_t)G_all, Slot{0.0, -1, 0});
-    for (int j = 0; j < G; ++j) {
-        const int c = gene_idx ? gene_idx[j] : j;
-        FDX_REQUIRE(c >= 0 && c < G_all, "fdx_prepare_csr_dev: gene index out of range");
-        FDX_REQUIRE(slots[(size_t)c].bucket < 0, "fdx_prepare_csr_dev: duplicate gene index");
-        FDX_REQUIRE(bucket[j] >= 0 && bucket[j] < d, "fdx_prepare_csr_dev: bucket index out of range");
-        slots[(size_t)c] = Slot{weight_y[j], bucket[j], 0};
-    }
-    const int sel_words = (G_all + 31) / 32;
-    std::vector<unsigned> bits((size_t)sel_words, 0u);
-    for (int c = 0; c < G_all; ++c)
-        if (slots[(size_t)c].bucket >= 0) bits[(size_t)c >> 5] |= 1u << (c & 31);
-    DevBuf dSlots, dBits, dX, dXs, dYs, dRowSq, dSum;
-    FDX_TRY(dSlots.alloc(slots.size() * sizeof(Slot)));
-    FDX_TRY(dBits.alloc(bits.size() * sizeof(unsigned)));
-    FDX_TRY(copy_h2d(dSlots.p, slots.data(), slots.size() * sizeof(Slot), st));
-    FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    const bool csr_fused = csr_contract_ok(d, K, (G_all + 31) / 32);       // the same choice as fit_impl: sharded = unsharded bits
+    CsrSelection sel;
+    FDX_TRY(sel.build(gene_idx, G, G_all, bucket, weight_y, d, csr_fused, st, "fdx_prepare_csr_dev"));
+    DevBuf dX, dXs, dYs, dRowSq, dSum;
     std::shared_ptr<SketchPlan> plan_x;
     FDX_TRY(sketch_plan_cached(bucket, weight_x, G, d, st, &plan_x));
     FDX_TRY(dX.alloc((size_t)K * G * sizeof(double)));
@@ -390,18 +375,16 @@ int fdx_prepare_csr_dev(const fdx_csr_view* Y, const int32_t* gene_idx, int32_t 
     double yty = 0.0;
     if (n > 0) {
         const long long chunk = std::min<long long>(n, 1LL << 18);
-        const bool csr_fused = csr_contract_ok(d, K, sel_words);       // the same choice as fit_impl: sharded = unsharded bits
         if (!csr_fused) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
         FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
         FDX_TRY(dSum.alloc(sizeof(double)));
         if (csr_fused)
-            FDX_TRY(launch_sketch_csr_contract((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, nullptr, n, d, mode_y,
-                                               dSlots.p, dBits.as<unsigned>(), sel_words, dXs.as<double>(), K, H_out_dev, ldh,
-                                               dRowSq.as<double>(), st));
+            FDX_TRY(launch_sketch_csr_contract((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, nullptr, n, d, mode_y, sel,
+                                               dXs.as<double>(), K, H_out_dev, ldh, dRowSq.as<double>(), st));
         for (long long r0 = 0; r0 < n && !csr_fused; r0 += chunk) {
             const long long nr = std::min(chunk, n - r0);
-            FDX_TRY(launch_sketch_csr((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, nullptr, r0, nr, d, mode_y, dSlots.p,
-                                      dBits.as<unsigned>(), sel_words, dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
+            FDX_TRY(launch_sketch_csr((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, nullptr, r0, nr, d, mode_y, sel.slots.p,
+                                      sel.bits.as<unsigned>(), sel.sel_words, dYs.as<double>(), d, dRowSq.as<double>() + r0, st));
             FDX_TRY(launch_xyt(dXs.as<double>(), dYs.as<double>(), d, nr, d, K, H_out_dev + r0, ldh, nullptr, st));
         }
         FDX_TRY(launch_sum_partials(dRowSq.as<double>(), n, dSum.as<double>(), 1, 1, st));

@@ -11,12 +11,11 @@
 //
 // Kernels of this file:
 //   sketch_csr_contract_kernel   DEFAULT sketch -> H for CSR rows (d <= 1024, K <= 64): a 16-wave workgroup takes 16 consecutive
-//                                spots; wave w walks the row of spot w ONCE (non-temporal stream; a G_all-bit bitmap in LDS says
-//                                which columns are selected; the library-size pass compacts the selected entries into a per-wave
-//                                LDS buffer, the sketch pass reads them from there), gathers {weight, bucket} for selected entries
-//                                only (16-byte slots of an L2-resident table) and adds weight * f(y) into the spot's accumulator
-//                                row in LDS (ds_add_f64); the 16 x d block is then the B operand of v_mfma_f64_16x16x4_f64 against
-//                                register-resident X_sketch slices - H is stored, Y_sketch never exists.
+//                                spots; wave w holds the row of spot w in REGISTERS (fetched once, a group ahead), looks every
+//                                column up in an LDS table {selected?, rank}, takes {weight, bucket} by rank from LDS and adds
+//                                weight * f(y) into the spot's accumulator row in LDS (ds_add_f64); the 16 x d block is then the
+//                                B operand of v_mfma_f64_16x16x4_f64 against register-resident X_sketch slices - H is stored,
+//                                Y_sketch never exists.
 //   sketch_csr_kernel            the same walk, one wave = one row, writing Y_sketch (d * 8 bytes per row) for the shapes the fused
 //                                kernel does not take; the contraction is then xyt_split_kernel's.
 //   csr_row_scale_kernel, csr_moments_cursor_kernel, csr_fold_moments_kernel
@@ -207,45 +206,136 @@ int launch_sketch_csr(const long long* indptr, const int* indices, const void* d
     return fail(FDX_ERR_INVALID, "sketch (CSR): dtype must be FDX_F32 or FDX_F64");
 }
 
-size_t csr_gene_slot_bytes() { return sizeof(GeneSlot); }
+// ------------------------------------------------------------------------------------------------ selection tables
+// Which columns of the matrix are selected genes, and their {weight, bucket}: the device tables of the two sketch kernels.
+//   two-kernel path   slots (per column GeneSlot), bits (u32 bitmap)
+//   fused path        words: per 32 columns {bitmap word, number of selected columns before the word} - one 8-byte LDS read answers
+//                     "selected?" and gives the gene's RANK among the selected ones; w / b: weight and bucket BY RANK (10 bytes per
+//                     selected gene: the whole table sits in LDS beside the accumulators, no gather leaves the CU)
+int CsrSelection::build(const int32_t* gene_idx, int G, int G_all, const int32_t* bucket, const double* weight, int d, bool fused,
+                        hipStream_t st, const char* who) {
+    std::vector<GeneSlot> sl((size_t)G_all, GeneSlot{0.0, -1, 0});
+    for (int j = 0; j < G; ++j) {
+        const int c = gene_idx ? gene_idx[j] : j;
+        FDX_REQUIRE(c >= 0 && c < G_all, std::string(who) + ": gene index out of range");
+        FDX_REQUIRE(sl[(size_t)c].bucket < 0, std::string(who) + ": duplicate gene index");
+        FDX_REQUIRE(bucket[j] >= 0 && bucket[j] < d, std::string(who) + ": bucket index out of range");
+        sl[(size_t)c] = GeneSlot{weight[j], bucket[j], 0};
+    }
+    sel_words = (G_all + 31) / 32;
+    n_sel = G;
+    if (!fused) {
+        std::vector<unsigned> bt((size_t)sel_words, 0u);
+        for (int c = 0; c < G_all; ++c)
+            if (sl[(size_t)c].bucket >= 0) bt[(size_t)c >> 5] |= 1u << (c & 31);
+        FDX_TRY(slots.alloc(sl.size() * sizeof(GeneSlot)));
+        FDX_TRY(bits.alloc(bt.size() * sizeof(unsigned)));
+        FDX_TRY(copy_h2d(slots.p, sl.data(), sl.size() * sizeof(GeneSlot), st));
+        FDX_TRY(copy_h2d(bits.p, bt.data(), bt.size() * sizeof(unsigned), st));
+    } else {
+        std::vector<unsigned long long> wd((size_t)sel_words, 0ull);
+        std::vector<double> wv((size_t)G);
+        std::vector<unsigned short> bv((size_t)G);
+        int r = 0;
+        for (int c = 0; c < G_all; ++c) {
+            if ((c & 31) == 0) wd[(size_t)c >> 5] = (unsigned long long)(unsigned)r << 32;
+            if (sl[(size_t)c].bucket >= 0) {
+                wd[(size_t)c >> 5] |= 1ull << (c & 31);
+                wv[(size_t)r] = sl[(size_t)c].w;
+                bv[(size_t)r] = (unsigned short)sl[(size_t)c].bucket;
+                ++r;
+            }
+        }
+        FDX_TRY(words.alloc(wd.size() * sizeof(unsigned long long)));
+        FDX_TRY(w.alloc(wv.size() * sizeof(double)));
+        FDX_TRY(b.alloc(bv.size() * sizeof(unsigned short)));
+        FDX_TRY(copy_h2d(words.p, wd.data(), wd.size() * sizeof(unsigned long long), st));
+        FDX_TRY(copy_h2d(w.p, wv.data(), wv.size() * sizeof(double), st));
+        FDX_TRY(copy_h2d(b.p, bv.data(), bv.size() * sizeof(unsigned short), st));
+    }
+    FDX_HIP(hipStreamSynchronize(st));       // the host tables are locals (copies below the staging threshold read them directly)
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------------ fused CSR sketch -> H
 // H = X_sketch * (f(Y) Omega)^T for CSR rows without Y_sketch in HBM (core/deconv.py:181-188, core/sketching.py:194-199,
-// core/solver.py:205-223 in one pass).  The two-kernel path writes every sketched row (d doubles = 4 KB at d = 512) and
-// reads it back for the contraction - 8.2 GB beside 11.5 GB of input at 1M spots x 1438 stored entries.  Here a 16-wave
-// workgroup takes GROUPS of 16 consecutive spots (solver order):
-//   gather     wave w walks the CSR row of spot w exactly as sketch_csr_kernel does (bitmap filter, {weight, bucket} gather,
-//              ds_add_f64 into the spot's d-entry accumulator row in LDS); ||row||^2 goes to row_sumsq;
+// core/solver.py:205-223 in one pass).  A 16-wave workgroup per CU takes GROUPS of 16 consecutive spots (solver order):
+//   fetch      wave w holds the WHOLE row of spot w in registers (NE x 64 entries, a coalesced dword load per 64;
+//              the few longer rows continue in a streamed loop): the loads of a row are all issued at once, and those of the
+//              wave's row of the NEXT group before the barrier of this one - the contraction and the wait for the slowest wave
+//              hide their latency (round 5: a chain of 256-entry hops per row, one in flight per wave: 4.9 ms, 0.29 of peak).
+//   select     one 8-byte LDS read per entry: selected? / rank among the selected genes (CsrSelection); the selected entries are
+//              compacted {rank, value} into the wave's keep buffer in LDS, the registers are free for the next fetch.  log modes:
+//              library size over the selected entries (the subset is taken first, deconv.py:321).
+//   scatter    over full waves of kept entries: weight and bucket by rank from LDS, log1p by the row's table, ds_add_f64 into the
+//              spot's d accumulators.
 //   contract   the 16 x d block in LDS is the B operand of v_mfma_f64_16x16x4_f64, the contraction index split over the
 //              16 waves (X_sketch slices as register-resident A operands), partial 16 x 16 type tiles added in wave order
-//              through LDS and stored to H - the contract phase of sketch_contract_kernel (fused_kernels.cpp).
+//              through LDS and stored to H.
 // The rows of a group have different lengths and meet at a barrier: the group costs its longest row.
 typedef double csr_double4_t __attribute__((ext_vector_type(4)));
 constexpr int CSRF_PAD = 16;     // doubles of padding per accumulator row (conflict-free B-operand reads)
 
-template <typename T, int MODE, int NB, int TT>
+template <typename T, int NE>
+struct CsrRowRegs {          // entry u * 64 + lane of the row in slot u
+    int c[NE];
+    T y[NE];
+};
+
+template <typename T, int NE, int U0 = 0, int U1 = NE>
+__device__ __forceinline__ void csr_row_fetch(CsrRowRegs<T, NE>& r, const int* __restrict__ indices, const T* __restrict__ data,
+                                              long long beg, long long end, int lane) {
+    const int len = (int)min<long long>(end - beg, (long long)NE * 64);
+    const int* ci = indices + beg + lane;
+    const T* yi = data + beg + lane;
+#pragma unroll
+    for (int u = U0; u < U1; ++u) {
+        const bool ok = u * 64 + lane < len;
+        r.c[u] = ok ? __builtin_nontemporal_load(ci + u * 64) : -1;
+        r.y[u] = ok ? __builtin_nontemporal_load(yi + u * 64) : (T)0;
+    }
+}
+
+// the general log1p as a CALL: it is met on a rare path only (entries the row's table does not hold); inlined, its temporaries
+// push the in-flight row of the next group out of the registers on the common path
+static __device__ __attribute__((noinline)) double csr_log1p_any(double x) { return fast_log1p(x); }
+
+// rank of column c among the selected genes, -1 when it is not selected (c < 0: no entry)
+__device__ __forceinline__ int csr_sel_rank(const unsigned long long* words, int c) {
+    if (c < 0) return -1;
+    const unsigned long long wd = words[c >> 5];
+    const unsigned lo = (unsigned)wd, bit = 1u << (c & 31);
+    return (lo & bit) ? (int)(wd >> 32) + __popc(lo & (bit - 1u)) : -1;
+}
+
+template <typename T, int MODE, int NB, int TT, int NE, int NE1_>
 __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
     const long long* __restrict__ indptr, const int* __restrict__ indices, const T* __restrict__ data,
-    const int* __restrict__ row_map, long long n, int d, const GeneSlot* __restrict__ table,
-    const unsigned* __restrict__ sel_bits, int sel_words, const double* __restrict__ Xs, int K, double* __restrict__ Hout,
-    long long ldh, double* __restrict__ row_sumsq, int no_table, int cap) {
+    const int* __restrict__ row_map, long long n, int d, const unsigned long long* __restrict__ sel_words_g, int sel_words,
+    const double* __restrict__ sel_w_g, const unsigned short* __restrict__ sel_b_g, int n_sel, int sel_in_lds,
+    const double* __restrict__ Xs, int K, double* __restrict__ Hout, long long ldh, double* __restrict__ row_sumsq, int no_table,
+    int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = 16;
+    constexpr int NE1 = NE1_;                                             // slots of the next row fetched ahead of the contraction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rs = d + CSRF_PAD;
     double* rows = reinterpret_cast<double*>(smem);                       // [16][rs]; re-used as red[16][TT*4*64]
     const int region = max(R * rs, R * TT * 4 * 64);
     double* tabs = rows + region;                                         // [16][64] per-wave log1p tables
-    unsigned* bits = reinterpret_cast<unsigned*>(tabs + R * 64);          // [sel_words]
-    // log modes: the SELECTED entries of the wave's row (column, value; `cap` of them) - written by the library-size pass, so
-    // that the sketch pass reads them from LDS and the row is fetched from HBM once (the second read of an 11.5 KB row did not
-    // hit L2 with 16 rows per CU in flight: PMC 24.3 GB for 11.75 GB of rows)
-    unsigned char* keep = reinterpret_cast<unsigned char*>(bits + ((sel_words + 3) & ~3)) + (size_t)wave * cap * (4 + sizeof(T));
-    int* keep_c = reinterpret_cast<int*>(keep);
-    T* keep_v = reinterpret_cast<T*>(keep_c + cap);
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(tabs + R * 64);   // [sel_words]
+    double* sel_w_l = reinterpret_cast<double*>(words + sel_words);       // [n_sel] weight by rank (sel_in_lds)
+    T* keep_y = reinterpret_cast<T*>(sel_w_l + (sel_in_lds ? n_sel : 0)) + (size_t)wave * cap;   // [16][cap] the wave's selected entries: value,
+    unsigned short* keep_r = reinterpret_cast<unsigned short*>(reinterpret_cast<T*>(sel_w_l + (sel_in_lds ? n_sel : 0)) + (size_t)R * cap) + (size_t)wave * cap;   // rank
+    unsigned short* sel_b_l = reinterpret_cast<unsigned short*>(reinterpret_cast<T*>(sel_w_l + (sel_in_lds ? n_sel : 0)) + (size_t)R * cap) + (size_t)R * cap;   // [n_sel] bucket by rank
     double* red = rows;
-    for (int j = tid; j < sel_words; j += R * 64) bits[j] = sel_bits[j];
+    for (int j = tid; j < sel_words; j += R * 64) words[j] = sel_words_g[j];
+    if (sel_in_lds)
+        for (int j = tid; j < n_sel; j += R * 64) {
+            sel_w_l[j] = sel_w_g[j];
+            sel_b_l[j] = sel_b_g[j];
+        }
     const int r = lane & 15, q = lane >> 4;
     double a[NB][TT][4];
 #pragma unroll
@@ -263,115 +353,97 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
     double* acc = rows + (size_t)wave * rs;
     double* tab = tabs + (size_t)wave * 64;
     const long long n_groups = (n + R - 1) / R;
+    auto extents = [&](long long g, long long& b0, long long& e0) {
+        b0 = e0 = 0;
+        const long long p0 = g * R + wave;
+        if (g < n_groups && p0 < n) {
+            const long long row = row_map ? (long long)row_map[p0] : p0;
+            b0 = indptr[row];
+            e0 = indptr[row + 1];
+        }
+    };
     long long grp = blockIdx.x;
-    long long beg = 0, end = 0;
-    if (grp < n_groups && grp * R + wave < n) {
-        const long long p0 = grp * R + wave;
-        const long long row = row_map ? (long long)row_map[p0] : p0;
-        beg = indptr[row];
-        end = indptr[row + 1];
-    }
+    long long beg, end, nbeg, nend;
+    extents(grp, beg, end);
+    extents(grp + gridDim.x, nbeg, nend);
+    CsrRowRegs<T, NE> row;
+    csr_row_fetch(row, indices, data, beg, end, lane);
     for (; grp < n_groups; grp += gridDim.x) {
         const long long s0 = grp * R;
         const long long p = s0 + wave;
-        long long nbeg = 0, nend = 0;                                     // extents of this wave's row of the next group, early
-        {
-            const long long pn = (grp + gridDim.x) * R + wave;
-            if (grp + gridDim.x < n_groups && pn < n) {
-                const long long nrow = row_map ? (long long)row_map[pn] : pn;
-                nbeg = indptr[nrow];
-                nend = indptr[nrow + 1];
-            }
-        }
+        long long nnbeg, nnend;                                           // extents two groups ahead: there when the next fetch is issued
+        extents(grp + 2 * (long long)gridDim.x, nnbeg, nnend);
         for (int c = lane; c < d; c += 64) acc[c] = 0.0;
+        // select: one LDS read per entry says whether its column is a selected gene and which (its rank); the selected entries go,
+        // compacted in CSR order, to the wave's keep buffer {rank, value} (ballot + prefix count).  Typically one entry in four
+        // to six is selected: everything after this loop - library size, log1p, weights, the adds - runs over full waves of
+        // selected entries.  A row longer than the registers hold is continued from memory.
+        int kept = 0;                                                     // wave-uniform
+        auto keep_entry = [&](int c, T yv) {                               // c < 0: no entry
+            const unsigned long long wd = words[max(c, 0) >> 5];
+            const unsigned lo = (unsigned)wd, bit = 1u << (c & 31);
+            const bool sel = c >= 0 && (lo & bit) != 0u;
+            const unsigned long long m = __ballot(sel);
+            const int pos = kept + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (sel && pos < cap) {
+                keep_r[pos] = (unsigned short)((unsigned)(wd >> 32) + __popc(lo & (bit - 1u)));
+                keep_y[pos] = yv;
+            }
+            kept += __popcll(m);
+        };
+#pragma unroll
+        for (int u = 0; u < NE; ++u) keep_entry(row.c[u], row.y[u]);
+        for (long long q0 = beg + (long long)NE * 64; q0 < end; q0 += 64) {       // (rows of more than NE x 64 entries)
+            const long long qq = q0 + lane;
+            const bool ok = qq < end;
+            keep_entry(ok ? indices[qq] : -1, ok ? data[qq] : (T)0);
+        }
         if (p < n) {                                                      // wave-uniform: spots past the end stay zero
             double scale = 1.0;
-            bool use_tab = false;
-            int kept = 0;                                                 // selected entries of the row (wave-uniform)
-            bool fits = true;                                             // ... all of them are in keep_c / keep_v
-            CsrGroup<T> cur, nxt;
-            if (MODE != FDX_PRE_RAW) {  // library size over the SELECTED genes (the subset is taken first, deconv.py:321)
-                double s = 0.0, mx = 0.0;
-                const bool stream = cap > 0 && (end - beg) <= 4LL * cap;     // wave-uniform guess: the row's selected entries will fit the keep buffer - it is read once
-                if (stream) csr_load_group<T, true>(cur, indices, data, beg, end, lane);
-                else csr_load_group(cur, indices, data, beg, end, lane);
-                for (long long q0 = beg; q0 < end; q0 += 256) {
-                    if (stream) csr_load_group<T, true>(nxt, indices, data, q0 + 256, end, lane);
-                    else csr_load_group(nxt, indices, data, q0 + 256, end, lane);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool sel = cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u);
-                        if (sel) {
-                            s += (double)cur.y[u];
-                            mx = fmax(mx, (double)cur.y[u]);
-                        }
-                        if (cap > 0) {                                     // stream compaction in CSR order: ballot + prefix count
-                            const unsigned long long m = __ballot(sel);
-                            const int here = __popcll(m);
-                            if (kept + here <= cap) {
-                                if (sel) {
-                                    const int pos = kept + __popcll(m & ((1ULL << lane) - 1ULL));
-                                    keep_c[pos] = cur.c[u];
-                                    keep_v[pos] = cur.y[u];
-                                }
-                            } else {
-                                fits = false;
-                            }
-                            kept += here;
-                        }
-                    }
-                    cur = nxt;
+            bool table_ok = false;                                         // wave-uniform
+            if (MODE != FDX_PRE_RAW) {
+                // library size over the selected entries (the subset is taken first, deconv.py:321)
+                double s = 0.0;
+                __builtin_amdgcn_s_waitcnt(0xc07f);                        // the kept entries are in LDS
+                if (kept <= cap) {
+                    for (int i = lane; i < kept; i += 64) s += (double)keep_y[i];
+                } else {
+                    for (long long qq = beg + lane; qq < end; qq += 64)
+                        if (csr_sel_rank(words, indices[qq]) >= 0) s += (double)data[qq];
                 }
                 s = wave_sum(s);
                 scale = 10000.0 / (s == 0.0 ? 1.0 : s);                    // deconv.py:183-185
-                use_tab = !no_table && wave_max(mx) < 64.0;
-                if (use_tab) log1p_table_fill(tab, scale, lane);
+                // counts below 64 take log1p from the row's table ENTRY BY ENTRY (a row with a few large counts keeps the table for
+                // the others); its arguments are 0 .. 63 * scale: the lean log1p; a row of negative sum goes without
+                table_ok = !no_table && scale > 0.0 && scale <= 10000.0;
+                if (table_ok) tab[lane] = fast_log1p_core((double)lane * scale);
             }
-            if (MODE != FDX_PRE_RAW && cap > 0 && fits) {
-                // the row's selected entries from LDS: same entries, same order as the pass over the row below
-                __builtin_amdgcn_s_waitcnt(0xc07f);                        // zeroing, table and kept entries are in LDS
-                for (int i0 = 0; i0 < kept; i0 += 256) {
-                    GeneSlot e[4];
-                    T yv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + u * 64 + lane;
-                        e[u].bucket = -1;
-                        yv[u] = (T)0;
-                        if (i < kept) {
-                            e[u] = table[keep_c[i]];
-                            yv[u] = keep_v[i];
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (e[u].bucket >= 0) {
-                            const double v = log1p_scaled((double)yv[u], scale, tab, use_tab);
-                            lds_add(acc + e[u].bucket, e[u].w * v);
-                        }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                            // zeroing, table and kept entries are in LDS
+            auto add_entry = [&](int rk, double yv) {
+                double val = yv;
+                if (MODE != FDX_PRE_RAW) {
+                    const int ci = (int)yv;
+                    const bool hit = table_ok && (double)ci == yv && (unsigned)ci < 64u;
+                    val = hit ? tab[ci] : 0.0;
+                    if (__ballot(!hit) != 0ULL) {                           // (rare for counts: a call, its temporaries stay out of the loop)
+                        if (!hit) val = csr_log1p_any(yv * scale);
                     }
                 }
-            } else {
-            csr_load_group(cur, indices, data, beg, end, lane);
-            __builtin_amdgcn_s_waitcnt(0xc07f);                            // zeroing done before the adds
-            for (long long q0 = beg; q0 < end; q0 += 256) {
-                GeneSlot e[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    e[u].bucket = -1;
-                    if (cur.c[u] >= 0 && ((bits[cur.c[u] >> 5] >> (cur.c[u] & 31)) & 1u)) e[u] = table[cur.c[u]];
+                const double wgt = sel_in_lds ? sel_w_l[rk] : sel_w_g[rk];
+                const int bk = sel_in_lds ? (int)sel_b_l[rk] : (int)sel_b_g[rk];
+                lds_add(acc + bk, wgt * val);
+            };
+            if (kept <= cap) {
+                for (int i0 = 0; i0 < kept; i0 += 64) {
+                    const int i = i0 + lane;
+                    if (i < kept) add_entry((int)keep_r[i], (double)keep_y[i]);
                 }
-                csr_load_group(nxt, indices, data, q0 + 256, end, lane);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (e[u].bucket >= 0) {
-                        double v = (double)cur.y[u];
-                        if (MODE != FDX_PRE_RAW) v = log1p_scaled(v, scale, tab, use_tab);
-                        lds_add(acc + e[u].bucket, e[u].w * v);
-                    }
+            } else {          // more selected entries than the keep buffer holds: the row is walked again from memory
+                for (long long q0 = beg; q0 < end; q0 += 64) {
+                    const long long qq = q0 + lane;
+                    const int rk = qq < end ? csr_sel_rank(words, indices[qq]) : -1;
+                    if (rk >= 0) add_entry(rk, (double)data[qq]);
                 }
-                cur = nxt;
-            }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             if (row_sumsq) {
@@ -384,6 +456,13 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
                 if (lane == 0) row_sumsq[p] = sq;
             }
         }
+        // The registers of the row are free since the select: the wave's row of the NEXT group is fetched into them - the first NE1
+        // slots here (in flight under the barriers and the contraction), the others behind the MFMAs.  Not earlier, and not all at
+        // once: vector memory returns in order, so ANY later vector-memory wait - a spill reload above all - waits for the whole
+        // fetch.  Issued ahead of the scatter, the log1p table's spilled constants were reloaded behind it (the fetch was waited for
+        // on the spot, as if not prefetched: 4.7 ms whatever else changed); whole, beside the A operands and the MFMA accumulators,
+        // the allocator spilled the A operands.
+        csr_row_fetch<T, NE, 0, NE1>(row, indices, data, nbeg, nend, lane);
         __syncthreads();                                                  // the 16 x d block is complete
         csr_double4_t accm[TT];
 #pragma unroll
@@ -404,6 +483,7 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) red[(size_t)wave * (TT * 4 * 64) + (t * 4 + rr) * 64 + lane] = accm[t][rr];
+        csr_row_fetch<T, NE, NE1, NE>(row, indices, data, nbeg, nend, lane);   // the rest of the next row
         __syncthreads();
         for (int o = tid; o < TT * 4 * 64; o += R * 64) {
             double sum = 0.0;
@@ -415,81 +495,85 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
             if (type < K && sp < n) Hout[(size_t)type * ldh + sp] = sum;
         }
         __syncthreads();                                                  // red is rows again for the next group
-        beg = nbeg;
-        end = nend;
+        beg = nbeg; end = nend;
+        nbeg = nnbeg; nend = nnend;
     }
 }
 
 static size_t csr_contract_lds(int d, int TT, int sel_words) {
     const size_t region = std::max<size_t>(16 * ((size_t)d + CSRF_PAD), (size_t)16 * TT * 4 * 64);
-    return region * 8 + 16 * 64 * 8 + (((size_t)sel_words + 3) & ~(size_t)3) * 4;
+    return region * 8 + 16 * 64 * 8 + (size_t)sel_words * 8;
 }
 
-// log modes: entries per wave of the "selected entries of the row" buffer behind the bitmap - what is left of the 160 KB, in
-// whole wave steps, at most 2048 (FDX_CSR_NO_KEEP=1: none, the row is read twice)
-static int csr_contract_keep(int d, int TT, int sel_words, int value_bytes) {
-    if (getenv("FDX_CSR_NO_KEEP")) return 0;
-    const size_t base = csr_contract_lds(d, TT, sel_words);
-    if (base >= 160 * 1024) return 0;
-    const size_t per_wave = (160 * 1024 - base) / 16 / (size_t)(4 + value_bytes);
-    return (int)std::min<size_t>(per_wave & ~(size_t)63, 2048);
-}
-
-// shapes the fused kernel takes: the A operands of a wave (NB x TT x 4 doubles) must fit beside the gather's registers
+// shapes the fused kernel takes: the A operands of a wave (NB x TT x 4 doubles) must fit beside the row's registers, and the keep
+// buffers need room for a wave's worth of entries at least
 bool csr_contract_ok(int d, int K, int sel_words) {
     if (getenv("FDX_CSR_NO_FUSED")) return false;
     if (d <= 0 || K <= 0 || K > 64 || d % 4 != 0) return false;
     const int NB = (d + 255) / 256, TT = (K + 15) / 16;
     if (NB * TT > 4) return false;
-    return csr_contract_lds(d, TT, sel_words) <= 160 * 1024;
+    return csr_contract_lds(d, TT, sel_words) + 16 * 64 * 10 <= 160 * 1024;
 }
 
 template <typename T, int MODE>
 static int launch_csr_contract_m(const long long* indptr, const int* indices, const T* data, const int* row_map, long long n, int d,
-                                 const void* table, const unsigned* sel_bits, int sel_words, const double* Xs, int K, double* H,
-                                 long long ldh, double* row_sumsq, hipStream_t st) {
+                                 const CsrSelection& sel, const double* Xs, int K, double* H, long long ldh, double* row_sumsq,
+                                 hipStream_t st) {
     const int NB = (d + 255) / 256, TT = (K + 15) / 16;
-    const int cap = MODE == FDX_PRE_RAW ? 0 : csr_contract_keep(d, TT, sel_words, (int)sizeof(T));
-    const size_t lds = csr_contract_lds(d, TT, sel_words) + (size_t)16 * cap * (4 + sizeof(T));
+    const size_t base = csr_contract_lds(d, TT, sel.sel_words);
+    const size_t tables = (size_t)sel.n_sel * (sizeof(double) + sizeof(unsigned short)) + 16;
+    const size_t per_entry = 16 * (sizeof(T) + sizeof(unsigned short));          // one keep-buffer entry of every wave
+    // weight / bucket by rank in LDS when that leaves the keep buffers 256 entries per wave; else read by rank from global memory
+    // (a few KB: cache-resident)
+    const int sel_in_lds = (sel.n_sel < 65536 && base + tables + 256 * per_entry <= 160 * 1024) ? 1 : 0;
+    FDX_REQUIRE(sel.n_sel < 65536, "sketch (CSR, fused): more than 65535 selected genes");
+    const size_t used = base + (sel_in_lds ? tables : 16);
+    const int cap = (int)std::min<size_t>(((160 * 1024 - used) / per_entry) & ~(size_t)63, 4096);
+    const size_t lds = used + (size_t)cap * per_entry;
     const int grid = (int)std::min<long long>((n + 15) / 16, 256);
     const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             FDX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, indptr, indices, data, row_map, n, d, (const GeneSlot*)table,
-                           sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, no_table, cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, indptr, indices, data, row_map, n, d,
+                           sel.words.as<unsigned long long>(), sel.sel_words, sel.w.as<double>(), sel.b.as<unsigned short>(), sel.n_sel,
+                           sel_in_lds, Xs, K, H, ldh, row_sumsq, no_table, cap);
         FDX_CHECK_LAUNCH();
         return 0;
     };
-    if (NB == 1 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 1, 1>);
-    if (NB == 1 && TT == 2) return launch(sketch_csr_contract_kernel<T, MODE, 1, 2>);
-    if (NB == 1 && TT == 3) return launch(sketch_csr_contract_kernel<T, MODE, 1, 3>);
-    if (NB == 1 && TT == 4) return launch(sketch_csr_contract_kernel<T, MODE, 1, 4>);
-    if (NB == 2 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 2, 1>);
-    if (NB == 2 && TT == 2) return launch(sketch_csr_contract_kernel<T, MODE, 2, 2>);
-    if (NB == 3 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 3, 1>);
-    if (NB == 4 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 4, 1>);
+    // rows in registers: 24 x 64 float32 entries (48 registers) beside two type tiles, 16 x 64 otherwise
+    constexpr int NV2 = sizeof(T) == 4 ? 24 : 16;
+    constexpr int NV1 = sizeof(T) == 4 ? 12 : 6;
+    if (NB == 1 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 1, 1, NV2, NV1>);
+    if (NB == 1 && TT == 2) return launch(sketch_csr_contract_kernel<T, MODE, 1, 2, NV2, NV1>);
+    if (NB == 1 && TT == 3) return launch(sketch_csr_contract_kernel<T, MODE, 1, 3, 16, 8>);
+    if (NB == 1 && TT == 4) return launch(sketch_csr_contract_kernel<T, MODE, 1, 4, 16, 8>);
+    if (NB == 2 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 2, 1, NV2, NV1>);
+    if (NB == 2 && TT == 2) return launch(sketch_csr_contract_kernel<T, MODE, 2, 2, NV2, NV1>);
+    if (NB == 3 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 3, 1, NV2, NV1>);
+    if (NB == 4 && TT == 1) return launch(sketch_csr_contract_kernel<T, MODE, 4, 1, NV2, NV1>);
     return fail(FDX_ERR_UNSUPPORTED, "sketch (CSR, fused): shape not instantiated");
 }
 
 // H[:, 0..n) (type-major, row stride ldh) and row_sumsq[0..n) for the n spots listed by row_map (NULL = rows 0..n-1).
-// Call only when csr_contract_ok(...) holds; Xs must be 32-byte aligned.
+// Call only when csr_contract_ok(...) holds and `sel` was built for the fused path; Xs must be 32-byte aligned.
 int launch_sketch_csr_contract(const long long* indptr, const int* indices, const void* data, int dtype, const int* row_map,
-                               long long n, int d, int mode, const void* table, const unsigned* sel_bits, int sel_words,
-                               const double* Xs, int K, double* H, long long ldh, double* row_sumsq, hipStream_t st) {
+                               long long n, int d, int mode, const CsrSelection& sel, const double* Xs, int K, double* H,
+                               long long ldh, double* row_sumsq, hipStream_t st) {
     if (n <= 0) return 0;
     if ((reinterpret_cast<uintptr_t>(Xs) & 31) != 0) return fail(FDX_ERR_INVALID, "sketch (CSR, fused): X_sketch must be 32-byte aligned");
+    FDX_REQUIRE(sel.words.p && sel.w.p && sel.b.p, "sketch (CSR, fused): selection tables were not built for the fused path");
     const bool raw = mode == FDX_PRE_RAW;
     if (!raw && mode != FDX_PRE_LOG_CPM_SPARSE && mode != FDX_PRE_LOG_CPM) return fail(FDX_ERR_INVALID, "sketch (CSR, fused): unknown preprocess mode");
     if (dtype == FDX_F32) {
         const float* y = (const float*)data;
-        return raw ? launch_csr_contract_m<float, FDX_PRE_RAW>(indptr, indices, y, row_map, n, d, table, sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, st)
-                   : launch_csr_contract_m<float, FDX_PRE_LOG_CPM_SPARSE>(indptr, indices, y, row_map, n, d, table, sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, st);
+        return raw ? launch_csr_contract_m<float, FDX_PRE_RAW>(indptr, indices, y, row_map, n, d, sel, Xs, K, H, ldh, row_sumsq, st)
+                   : launch_csr_contract_m<float, FDX_PRE_LOG_CPM_SPARSE>(indptr, indices, y, row_map, n, d, sel, Xs, K, H, ldh, row_sumsq, st);
     }
     if (dtype == FDX_F64) {
         const double* y = (const double*)data;
-        return raw ? launch_csr_contract_m<double, FDX_PRE_RAW>(indptr, indices, y, row_map, n, d, table, sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, st)
-                   : launch_csr_contract_m<double, FDX_PRE_LOG_CPM_SPARSE>(indptr, indices, y, row_map, n, d, table, sel_bits, sel_words, Xs, K, H, ldh, row_sumsq, st);
+        return raw ? launch_csr_contract_m<double, FDX_PRE_RAW>(indptr, indices, y, row_map, n, d, sel, Xs, K, H, ldh, row_sumsq, st)
+                   : launch_csr_contract_m<double, FDX_PRE_LOG_CPM_SPARSE>(indptr, indices, y, row_map, n, d, sel, Xs, K, H, ldh, row_sumsq, st);
     }
     return fail(FDX_ERR_INVALID, "sketch (CSR, fused): dtype must be FDX_F32 or FDX_F64");
 }
@@ -578,106 +662,136 @@ __global__ __launch_bounds__(1024, 8) void csr_moments_tiled_kernel(const long l
 // Sorted rows (canonical CSR): the entries of a row that fall into gene tile t+1 start where those of tile t ended, so a
 // workgroup keeps its stripe of rows and walks the tiles itself, resuming every row at a saved cursor - the column
 // indices are then read once instead of once per tile (5x at 20000 genes: 29 GB -> 6 GB of the kernel's traffic).
-template <typename T, int NS>
-__global__ __launch_bounds__(1024, 8) void csr_moments_cursor_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+//
+// A visit (row, tile) is a chain of dependent round trips - extents + cursor + scale, then the entries - and a wave that
+// walks it in order spends its life waiting (round 5: 3 round trips per visit, 3.74 ms at 1M x 20000 whatever the bytes).
+// Here the chain is a software pipeline over the wave's rows: while visit i is being added into the tile, the entries of
+// visit i + 1 (a WINDOW of up to NW x 64 entries from that row's cursor, sized by what the wave's last finished visit took)
+// are in flight.  What makes that real (vector memory returns IN ORDER, and the compiler can only wait for "all but the N
+// youngest" when it can count them): the window is the ONLY vector-memory traffic of the loop and its loads are unconditional
+// (clamped addresses, masked afterwards) - extents and scales come by scalar loads, the cursors live in LDS (a separate
+// counter).  With a cursor in global memory, or loads under a branch, every wait was for everything outstanding and the
+// "prefetched" window was waited for on the spot.  A window that ends before the tile does is continued by dependent windows.
+template <typename T, int NW>
+struct CsrWindow {
+    int c[NW];
+    T y[NW];
+};
+
+struct CsrVisit {          // wave-uniform
+    long long beg, end, q0;
+    double sc;
+};
+
+// nw steps of 64 entries from q0; entries past `end` read the matrix's last entry instead (nnz > 0) and are masked by the caller
+template <typename T, int NW>
+__device__ __forceinline__ void csr_window_load(CsrWindow<T, NW>& w, const int* __restrict__ indices, const T* __restrict__ data,
+                                                long long q0, long long last, int nw, int lane) {
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        const long long q = min(q0 + (min(u, nw - 1) * 64 + lane), last);   // (steps past nw repeat step nw - 1: same lines, no new traffic)
+        w.c[u] = indices[q];
+        w.y[u] = data[q];
+    }
+}
+
+constexpr int CSR_MOM_SUB = 4096;     // rows of a stripe walked at a time: their cursors (16 KB) live in LDS
+
+template <typename T, int NS, int NW, int WPE>
+__global__ __launch_bounds__(1024, WPE) void csr_moments_cursor_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
                                                                      const T* __restrict__ data, const double* __restrict__ scale,
-                                                                     long long n, int G, int tile, int rows_per_stripe,
-                                                                     int* __restrict__ cursor /* (n) */,
+                                                                     long long n, long long nnz, int G, int tile, int rows_per_stripe,
                                                                      double* __restrict__ part /* (stripes, NS, G) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* acc = reinterpret_cast<double*>(smem);                       // [NS][tile]
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* tab = acc + (size_t)NS * tile + (size_t)wib * 64;
-    const long long r0 = (long long)blockIdx.x * rows_per_stripe;
-    const long long r1 = min(n, r0 + rows_per_stripe);
-    for (int t0 = 0; t0 < G; t0 += tile) {
-        const int t1 = min(G, t0 + tile);
-        for (int j = threadIdx.x; j < NS * tile; j += 1024) acc[j] = 0.0;
-        __syncthreads();
-        for (long long row = r0 + wib; row < r1; row += 16) {
-            const long long beg = indptr[row], end = indptr[row + 1];
-            long long q0 = beg + (t0 == 0 ? 0 : (long long)cursor[row]);
-            const double sc_signed = scale[row];
-            const double sc = fabs(sc_signed);
-            const bool use_tab = sc_signed > 0.0;
-            if (use_tab) log1p_table_fill(tab, sc, lane);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            // Steps of 256 entries while most of what the tile is expected to hold of this row (columns are roughly uniform: row
-            // length x tile width / G) is still ahead, then steps of 64: a step that reaches past the tile's last entry reads the
-            // rest of its 256 for nothing (and again on the next visit) - with ~290 entries per visit the 256-entry steps read
-            // 512, i.e. 1.8 x the bytes (PMC 22.8 GB for 11.5 GB: the kernel ran at the copy ceiling on bytes it did not need)
-            const long long est = ((end - beg) * (long long)(t1 - t0)) / (long long)G;
-            long long consumed = 0;
-            while (q0 < end && consumed + 256 <= est - (est >> 3)) {   // wave-uniform
-                // 256 entries per step, FOUR CONSECUTIVE ones per lane: one 16-byte load for the columns and one for the values
-                // instead of four 4-byte loads each (the kernel waits on its vector-memory instructions - 70 M of them per
-                // pass over 1.44e9 entries, texture addresser half busy, 80 % of the wave time parked; the loads only need
-                // 4-byte alignment)
-                typedef int int4_u __attribute__((ext_vector_type(4), aligned(4)));
-                typedef T val4_u __attribute__((ext_vector_type(4), aligned(4)));
-                const long long q = q0 + 4 * lane;
-                int c[4];
-                double y[4];
-                if (q + 3 < end) {
-                    // the values travel with the columns (not after them): one round trip per step; what lies past the tile is
-                    // read again on the next visit (~a fifth more value bytes)
-                    const int4_u v = *reinterpret_cast<const int4_u*>(indices + q);
-                    const val4_u w = *reinterpret_cast<const val4_u*>(data + q);
-                    c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
-                    y[0] = (double)w.x; y[1] = (double)w.y; y[2] = (double)w.z; y[3] = (double)w.w;
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        c[u] = (q + u < end) ? indices[q + u] : 0x7fffffff;
-                        y[u] = (q + u < end) ? (double)data[q + u] : 0.0;
-                    }
+    int* cursor = reinterpret_cast<int*>(acc + (size_t)NS * tile + 16 * 64);   // [CSR_MOM_SUB]
+    const long long s0 = (long long)blockIdx.x * rows_per_stripe;
+    const long long s1 = min(n, s0 + rows_per_stripe);
+    const long long last = nnz - 1;
+    for (long long r0 = s0; r0 < s1; r0 += CSR_MOM_SUB) {
+        const long long r1 = min(s1, r0 + CSR_MOM_SUB);
+        for (int t0 = 0; t0 < G; t0 += tile) {
+            const int t1 = min(G, t0 + tile);
+            for (int j = threadIdx.x; j < NS * tile; j += 1024) acc[j] = 0.0;
+            __syncthreads();
+            auto visit = [&](long long row) -> CsrVisit {
+                CsrVisit v{0, 0, 0, 1.0};
+                if (row < r1) {
+                    v.beg = indptr[row];
+                    v.end = indptr[row + 1];
+                    v.q0 = v.beg + (t0 == 0 ? 0 : (long long)cursor[row - r0]);
+                    v.sc = scale[row];
                 }
-                bool in[4];
-                int taken = 0;
+                return v;
+            };
+            // entries a visit is expected to take: what this wave's last finished visit took, before that the share of the tile's
+            // width in the row (columns roughly uniform); half a step of margin, whole steps of 64
+            auto steps_for = [&](const CsrVisit& v, int pred) -> int {
+                const long long left = v.end - v.q0;
+                const long long want = min<long long>(left, (long long)pred + 32);
+                return (int)max<long long>(1, min<long long>(NW, (want + 63) >> 6));
+            };
+            long long row = r0 + wib;
+            CsrVisit v_cur = visit(row), v_nxt = visit(row + 16);
+            int pred = (int)(((v_cur.end - v_cur.beg) * (long long)(t1 - t0)) / (long long)G);
+            CsrWindow<T, NW> w_cur, w_nxt;
+            int nw_cur = steps_for(v_cur, pred);
+            csr_window_load(w_cur, indices, data, v_cur.q0, last, nw_cur, lane);
+            for (; row < r1; row += 16) {
+                const CsrVisit v_nn = visit(row + 32);
+                const int nw_nxt = steps_for(v_nxt, pred);
+                csr_window_load(w_nxt, indices, data, v_nxt.q0, last, nw_nxt, lane);
+                const double sc = fabs(v_cur.sc);
+                const bool use_tab = v_cur.sc > 0.0;
+                if (use_tab) log1p_table_fill(tab, sc, lane);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                long long q0 = v_cur.q0;
+                int nw = nw_cur;
+                for (;;) {
+                    bool more = true;                                     // wave-uniform: every entry so far belonged to the tile
+                    int taken = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    in[u] = c[u] < t1;                                    // sorted: the taken entries are a prefix
-                    taken += __popcll(__ballot(in[u]));
-                }
-                if (in[0]) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (in[u]) {
-                            const double z = log1p_scaled(y[u], sc, tab, use_tab);
-                            lds_add(acc + (c[u] - t0), z);
-                            lds_add(acc + tile + (c[u] - t0), z * z);
-                            if (NS == 3) lds_add(acc + 2 * tile + (c[u] - t0), y[u]);
+                    for (int u = 0; u < NW; ++u) {
+                        if (u < nw && more) {
+                            const int c = w_cur.c[u];
+                            const bool in = c < t1 && q0 + u * 64 + lane < v_cur.end;   // sorted: the taken entries are a prefix
+                            const int cnt = __popcll(__ballot(in));
+                            if (in) {
+                                const double y = (double)w_cur.y[u];
+                                const double z = log1p_scaled(y, sc, tab, use_tab);
+                                lds_add(acc + (c - t0), z);
+                                lds_add(acc + tile + (c - t0), z * z);
+                                if (NS == 3) lds_add(acc + 2 * tile + (c - t0), y);
+                            }
+                            taken += cnt;
+                            more = cnt == 64;
                         }
+                    }
+                    q0 += taken;
+                    if (!more || q0 >= v_cur.end) break;
+                    nw = (int)min<long long>(NW, (v_cur.end - q0 + 63) >> 6);   // the window ended inside the tile: a dependent one
+                    csr_window_load(w_cur, indices, data, q0, last, nw, lane);
                 }
-                q0 += taken;
-                consumed += taken;
-                if (taken < 256) { consumed = -1; break; }                // reached the next tile (or the row's end)
+                if (lane == 0) cursor[row - r0] = (int)(q0 - v_cur.beg);
+                pred = (int)(q0 - v_cur.q0);
+                v_cur = v_nxt;
+                v_nxt = v_nn;
+                w_cur = w_nxt;
+                nw_cur = nw_nxt;
             }
-            while (consumed >= 0 && q0 < end) {                           // one entry per lane
-                const long long q = q0 + lane;
-                const bool ok = q < end;
-                const int c = ok ? indices[q] : 0x7fffffff;
-                const double y = ok ? (double)data[q] : 0.0;
-                const bool in = c < t1;
-                const int taken = __popcll(__ballot(in));
-                if (in) {
-                    const double z = log1p_scaled(y, sc, tab, use_tab);
-                    lds_add(acc + (c - t0), z);
-                    lds_add(acc + tile + (c - t0), z * z);
-                    if (NS == 3) lds_add(acc + 2 * tile + (c - t0), y);
+            __syncthreads();
+            for (int j = threadIdx.x; j < NS * tile; j += 1024) {
+                const int s = j / tile, g = j - s * tile;
+                if (t0 + g < t1) {
+                    double* dst = part + ((size_t)blockIdx.x * NS + s) * G + t0 + g;
+                    *dst = (r0 == s0) ? acc[j] : *dst + acc[j];           // (a stripe of more than CSR_MOM_SUB rows: its parts add up)
                 }
-                q0 += taken;
-                if (taken < 64) break;
             }
-            if (lane == 0) cursor[row] = (int)(q0 - beg);
+            __syncthreads();
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < NS * tile; j += 1024) {
-            const int s = j / tile, g = j - s * tile;
-            if (t0 + g < t1) part[((size_t)blockIdx.x * NS + s) * G + t0 + g] = acc[j];
-        }
-        __syncthreads();
     }
 }
 
@@ -703,22 +817,35 @@ __global__ __launch_bounds__(256) void csr_fold_moments_kernel(const double* __r
 int csr_moment_stripes(long long n) { return (int)std::min<long long>(512, std::max<long long>(1, (n + 255) / 256)); }
 
 template <typename T, int NS>
-static int launch_csr_moments_t(const long long* indptr, const int* indices, const T* data, long long n, int G, double* scale,
-                                double* part, double* mean, double* var, double* colsum, int* cursor, hipStream_t st) {
-    const int tile = std::min(G, (int)(64 * 1024 / (NS * sizeof(double))));   // + 16 waves x 512 B of log1p tables
-    const int tiles = ceil_div(G, tile);
-    const int stripes = csr_moment_stripes(n);
+static int launch_csr_moments_t(const long long* indptr, const int* indices, const T* data, long long n, long long nnz, int G,
+                                double* scale, double* part, double* mean, double* var, double* colsum, bool sorted_rows,
+                                hipStream_t st) {
+    // sorted rows: ONE 16-wave workgroup per CU at 128 registers with as much of the gene axis as 152 KB of LDS hold (fewer
+    // visits per row, fewer windows that end beside a tile edge); FDX_CSR_MOM_CFG=2: two workgroups per CU, 64 KB tiles
+    const bool cursor_path = sorted_rows && nnz > 0 && !getenv("FDX_CSR_NO_CURSOR");
+    const bool one_wg = cursor_path && !(getenv("FDX_CSR_MOM_CFG") && atoi(getenv("FDX_CSR_MOM_CFG")) == 2);
+    // (+ 16 waves x 512 B of log1p tables, + 16 KB of row cursors on the sorted path)
+    const int tile_max = (int)((one_wg ? 136 : (cursor_path ? 56 : 64)) * 1024 / (NS * sizeof(double)));
+    const int tiles = ceil_div(G, tile_max);
+    const int tile = one_wg ? std::min(G, (ceil_div(G, tiles) + 63) & ~63) : std::min(G, tile_max);
+    const int stripes = one_wg ? (int)std::min<long long>(csr_moment_stripes(n), 256) : csr_moment_stripes(n);
     const int rows_per_stripe = (int)((n + stripes - 1) / stripes);
     const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
     hipLaunchKernelGGL(csr_row_scale_kernel<T>, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, indptr, data, n, scale, no_table);
     FDX_CHECK_LAUNCH();
     const size_t lds_m = (size_t)NS * tile * sizeof(double) + 16 * 64 * sizeof(double);
-    FDX_HIP(hipFuncSetAttribute((const void*)csr_moments_tiled_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-    if (cursor && !getenv("FDX_CSR_NO_CURSOR")) {     // rows sorted by column: one pass over the indices
-        FDX_HIP(hipFuncSetAttribute((const void*)csr_moments_cursor_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        hipLaunchKernelGGL((csr_moments_cursor_kernel<T, NS>), dim3(stripes), dim3(1024), lds_m, st, indptr, indices, data, scale,
-                           n, G, tile, rows_per_stripe, cursor, part);
+    if (cursor_path) {     // rows sorted by column: one pass over the indices
+        auto launch = [&](auto kern) -> int {
+            const size_t lds_c = lds_m + (size_t)CSR_MOM_SUB * sizeof(int);
+            FDX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+            hipLaunchKernelGGL(kern, dim3(stripes), dim3(1024), lds_c, st, indptr, indices, data, scale, n, nnz, G, tile,
+                               rows_per_stripe, part);
+            return 0;
+        };
+        if (one_wg) FDX_TRY(launch(csr_moments_cursor_kernel<T, NS, 8, 4>));
+        else FDX_TRY(launch(csr_moments_cursor_kernel<T, NS, 6, 8>));
     } else {
+        FDX_HIP(hipFuncSetAttribute((const void*)csr_moments_tiled_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
         hipLaunchKernelGGL((csr_moments_tiled_kernel<T, NS>), dim3(stripes, tiles), dim3(1024), lds_m, st,
                            indptr, indices, data, scale, n, G, tile, rows_per_stripe, part);
     }
@@ -729,15 +856,15 @@ static int launch_csr_moments_t(const long long* indptr, const int* indices, con
 }
 
 // scale: n doubles; part: csr_moment_stripes(n) * (colsum ? 3 : 2) * G doubles; colsum may be NULL
-int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, int G,
-                       double* scale, double* part, double* mean, double* var, double* colsum, int* cursor, hipStream_t st) {
+int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, long long nnz, int G,
+                       double* scale, double* part, double* mean, double* var, double* colsum, bool sorted_rows, hipStream_t st) {
     if (G <= 0 || n <= 0) return fail(FDX_ERR_INVALID, "gene moments (CSR): empty matrix");
     if (dtype == FDX_F32)
-        return colsum ? launch_csr_moments_t<float, 3>(indptr, indices, (const float*)data, n, G, scale, part, mean, var, colsum, cursor, st)
-                      : launch_csr_moments_t<float, 2>(indptr, indices, (const float*)data, n, G, scale, part, mean, var, colsum, cursor, st);
+        return colsum ? launch_csr_moments_t<float, 3>(indptr, indices, (const float*)data, n, nnz, G, scale, part, mean, var, colsum, sorted_rows, st)
+                      : launch_csr_moments_t<float, 2>(indptr, indices, (const float*)data, n, nnz, G, scale, part, mean, var, colsum, sorted_rows, st);
     if (dtype == FDX_F64)
-        return colsum ? launch_csr_moments_t<double, 3>(indptr, indices, (const double*)data, n, G, scale, part, mean, var, colsum, cursor, st)
-                      : launch_csr_moments_t<double, 2>(indptr, indices, (const double*)data, n, G, scale, part, mean, var, colsum, cursor, st);
+        return colsum ? launch_csr_moments_t<double, 3>(indptr, indices, (const double*)data, n, nnz, G, scale, part, mean, var, colsum, sorted_rows, st)
+                      : launch_csr_moments_t<double, 2>(indptr, indices, (const double*)data, n, nnz, G, scale, part, mean, var, colsum, sorted_rows, st);
     return fail(FDX_ERR_INVALID, "gene moments (CSR): dtype must be FDX_F32 or FDX_F64");
 }
 

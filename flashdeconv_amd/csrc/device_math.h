@@ -16,8 +16,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 //   log(m): f = m - 1, s = f/(2+f), log(m) = f - (f^2/2 - s*(f^2/2 + R(s^2))),  R = degree-7 minimax (fdlibm Lg1..Lg7)
 // Error < 1 ulp (checked against numpy.log1p in tests/test_gpu_stages.py).  Negative / non-finite inputs take the
 // library path (the reference yields NaN for x < -1 as well).
-__device__ __forceinline__ double fast_log1p(double x) {
-    if (!(x >= 0.0) || x > 1e300) return log1p(x);
+__device__ __forceinline__ double fast_log1p_core(double x) {        // 0 <= x <= 1e300 only
     const double u = 1.0 + x;
     const double c = (x >= 1.0) ? 1.0 - (u - x) : x - (u - 1.0);
     const double c_over_u = c * (double)__frcp_rn((float)u);          // |c| <= ulp(u)/2: 24-bit reciprocal is plenty
@@ -42,6 +41,11 @@ __device__ __forceinline__ double fast_log1p(double x) {
     const double dk = (double)k;
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + (dk * ln2_lo + c_over_u))) - f);
+}
+
+__device__ __forceinline__ double fast_log1p(double x) {
+    if (!(x >= 0.0) || x > 1e300) return log1p(x);
+    return fast_log1p_core(x);
 }
 
 // log1p(y * scale) for one row of count data.  Counts are small non-negative integers, and all entries of a row share

@@ -124,6 +124,17 @@ struct DevBuf {
     }
 };
 
+// Which columns of a CSR spot matrix are selected genes, and their CountSketch {weight, bucket}: device tables of the CSR sketch
+// kernels (csr_kernels.cpp), built from the host-side gene list of a fit / a shard's prepare.
+struct CsrSelection {
+    DevBuf slots, bits;        // two-kernel path: per column {weight, bucket}, u32 bitmap
+    DevBuf words, w, b;        // fused path: per 32 columns {bitmap word, rank of its first column}; weight / bucket by rank
+    int sel_words = 0, n_sel = 0;
+    // gene_idx: G selected columns of G_all (NULL = all, in order); fused: the tables of the fused kernel, else of the two-kernel path
+    int build(const int32_t* gene_idx, int G, int G_all, const int32_t* bucket, const double* weight, int d, bool fused,
+              hipStream_t st, const char* who);
+};
+
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline long long round_up(long long a, long long b) { return (a + b - 1) / b * b; }
 

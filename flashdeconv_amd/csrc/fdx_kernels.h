@@ -162,15 +162,15 @@ namespace fdx {
 int launch_sketch_csr(const long long* indptr, const int* indices, const void* data, int dtype, const int* row_map,
                       long long row0, long long n, int d, int mode, const void* table, const unsigned* sel_bits,
                       int sel_words, double* Ys, long long ldys, double* row_sumsq, hipStream_t st);
-size_t csr_gene_slot_bytes();
 // fused form (csr_kernels.cpp): CSR rows -> LDS accumulators -> MFMA contraction -> H, no Y_sketch
 bool csr_contract_ok(int d, int K, int sel_words);
+struct CsrSelection;
 int launch_sketch_csr_contract(const long long* indptr, const int* indices, const void* data, int dtype, const int* row_map,
-                               long long n, int d, int mode, const void* table, const unsigned* sel_bits, int sel_words,
-                               const double* Xs, int K, double* H, long long ldh, double* row_sumsq, hipStream_t st);
+                               long long n, int d, int mode, const CsrSelection& sel, const double* Xs, int K, double* H,
+                               long long ldh, double* row_sumsq, hipStream_t st);
 int csr_moment_stripes(long long n);
-int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, int G,
-                       double* scale, double* part, double* mean, double* var, double* colsum, int* cursor, hipStream_t st);
+int launch_csr_moments(const long long* indptr, const int* indices, const void* data, int dtype, long long n, long long nnz, int G,
+                       double* scale, double* part, double* mean, double* var, double* colsum, bool sorted_rows, hipStream_t st);
 int launch_csr_check(const long long* indptr, const int* indices, long long n, long long nnz, int G, int check_sorted, int* flag,
                      hipStream_t st);
 }  // namespace fdx

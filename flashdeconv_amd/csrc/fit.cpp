@@ -273,12 +273,6 @@ struct YSource {
     const int32_t* gene_idx = nullptr;
 };
 
-struct GeneSlotHost {   // layout of csr_kernels.cpp's GeneSlot
-    double w;
-    int bucket;
-    int pad;
-};
-
 int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t K, const int32_t* bucket,
              const double* weight_y, const double* weight_x, const double* coords_dev, int32_t dim,
              const fdx_fit_params* prm_in, fdx_graph** graph_inout, double* beta_out_dev, double* prop_out_dev,
@@ -334,7 +328,9 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     // plan's table upload made the host wait for the whole graph build.)
     const long long ld = round_up(n + 1, 64);
     const int KP = solver_padded_K(K);             // 65 - 128 cell types: planes of the next instantiated sweep, pad types all zero
-    DevBuf dB0, dB1, dX, dXs, dG, dGp, dSlots, dBits;   // dSlots, dBits (CSR source): per-column {weight, bucket} table over all G_all columns + "selected" bitmap
+    DevBuf dB0, dB1, dX, dXs, dG, dGp;
+    CsrSelection csr_sel;           // CSR source: which columns are selected genes, their {weight, bucket}
+    bool csr_fused = false;
     DevBuf dH, dYs, dRowSq, dSum;   // declared ABOVE the drains: on an early return both streams are drained before any of these goes back to the pool (dRowSq / dSum are read on the side stream)
     struct SideDrain { hipStream_t s = nullptr; ~SideDrain() { if (s) (void)hipStreamSynchronize(s); } } side_drain;   // before buffers are released
     // an early return leaves work on the caller's stream that uses the side-stream buffers above: wait for it before they go
@@ -346,7 +342,6 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     const hipStream_t xs = side ? side : st;
     if (side) side_drain.s = side;
     std::shared_ptr<SketchPlan> plan_y_p, plan_x_p;
-    int sel_words = 0;
     for (int g_ = 0; g_ < G; ++g_) FDX_REQUIRE(bucket[g_] >= 0 && bucket[g_] < d, "fit: bucket index out of range");
     double* Gh = (double*)pinned_scratch(0, (size_t)K * K * sizeof(double));   // pinned: the copy below must not hold the host back
     FDX_REQUIRE(Gh != nullptr, "fit: pinned host buffer");
@@ -365,24 +360,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
             FDX_TRY(solver_zero_pad(dB1.as<double>(), ld, g->n_total, KP, xs));
         }
         if (ysrc.csr) {
-            const int G_all = ysrc.csr->G;
-            FDX_REQUIRE(csr_gene_slot_bytes() == sizeof(GeneSlotHost), "fit: gene slot layout mismatch");
-            std::vector<GeneSlotHost> slots((size_t)G_all, GeneSlotHost{0.0, -1, 0});
-            for (int j = 0; j < G; ++j) {
-                const int c = ysrc.gene_idx ? ysrc.gene_idx[j] : j;
-                FDX_REQUIRE(c >= 0 && c < G_all, "fdx_fit_csr_dev: gene index out of range");
-                FDX_REQUIRE(slots[(size_t)c].bucket < 0, "fdx_fit_csr_dev: duplicate gene index");
-                slots[(size_t)c] = GeneSlotHost{weight_y[j], bucket[j], 0};
-            }
-            sel_words = (G_all + 31) / 32;
-            std::vector<unsigned> bits((size_t)sel_words, 0u);
-            for (int c = 0; c < G_all; ++c)
-                if (slots[(size_t)c].bucket >= 0) bits[(size_t)c >> 5] |= 1u << (c & 31);
-            FDX_TRY(dSlots.alloc(slots.size() * sizeof(GeneSlotHost)));
-            FDX_TRY(dBits.alloc(bits.size() * sizeof(unsigned)));
-            FDX_TRY(copy_h2d(dSlots.p, slots.data(), slots.size() * sizeof(GeneSlotHost), xs));
-            FDX_HIP(hipMemcpyAsync(dBits.p, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, xs));
-            FDX_HIP(hipStreamSynchronize(xs));   // `slots` is a stack-scoped host buffer
+            csr_fused = csr_contract_ok(d, K, (ysrc.csr->G + 31) / 32);
+            FDX_TRY(csr_sel.build(ysrc.gene_idx, G, ysrc.csr->G, bucket, weight_y, d, csr_fused, xs, "fdx_fit_csr_dev"));
         } else {
             FDX_TRY(sketch_plan_cached(bucket, weight_y, G, d, xs, &plan_y_p));
         }
@@ -421,7 +400,6 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     long long chunk_rows = 1LL << 18;
     if (const char* e = getenv("FDX_FIT_CHUNK")) chunk_rows = std::max<long long>(64, atoll(e));
     const long long chunk = std::min<long long>(n, chunk_rows);
-    const bool csr_fused = ysrc.csr && csr_contract_ok(d, K, sel_words);
     const bool fused = csr_fused || (!ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, prm->mode_y, plan_y.dev()));
     if (!fused) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
     FDX_TRY(solver_zero_pad(dH.as<double>(), ld, n, K, st));   // columns of real spots are all written by the sketch -> H stage
@@ -436,8 +414,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     if (fused) {   // one kernel, no Y_sketch: rows -> LDS tile -> bucket sums -> MFMA contraction -> H  (tile_kernels.cpp)
         if (csr_fused)     // CSR rows -> LDS accumulators -> MFMA contraction -> H  (csr_kernels.cpp)
             FDX_TRY(launch_sketch_csr_contract((const long long*)ysrc.csr->indptr, ysrc.csr->indices, ysrc.csr->data, y_dtype,
-                                               row_map, n, d, prm->mode_y, dSlots.p, dBits.as<unsigned>(), sel_words,
-                                               dXs.as<double>(), K, dH.as<double>(), ld, dRowSq.as<double>(), st));
+                                               row_map, n, d, prm->mode_y, csr_sel, dXs.as<double>(), K, dH.as<double>(), ld,
+                                               dRowSq.as<double>(), st));
         else
         FDX_TRY(launch_sketch_contract(Y_dev, y_dtype, ldy, row_map, n, G, d, prm->mode_y, plan_y.dev(), dXs.as<double>(), K,
                                        dH.as<double>(), ld, dRowSq.as<double>(), st));
@@ -454,8 +432,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
             // with a row map the chunk gathers rows perm[r0..]; without one it reads rows r0.. of Y directly
             if (ysrc.csr) {
                 FDX_TRY(launch_sketch_csr((const long long*)ysrc.csr->indptr, ysrc.csr->indices, ysrc.csr->data, y_dtype,
-                                          row_map ? row_map + r0 : nullptr, r0, nr, d, prm->mode_y, dSlots.p,
-                                          dBits.as<unsigned>(), sel_words, dYs.as<double>(), d,
+                                          row_map ? row_map + r0 : nullptr, r0, nr, d, prm->mode_y, csr_sel.slots.p,
+                                          csr_sel.bits.as<unsigned>(), csr_sel.sel_words, dYs.as<double>(), d,
                                           dRowSq.as<double>() + r0, st));
             } else {
                 const unsigned char* ybase = static_cast<const unsigned char*>(Y_dev);
@@ -664,16 +642,14 @@ extern "C" int fdx_csr_gene_moments_dev(const fdx_csr_view* Y, double* mean_out_
     hipStream_t st = (hipStream_t)stream;
     PoolStream pool_stream(st);
     const size_t G = (size_t)Y->G;
-    DevBuf scale, part, out, cursor;
+    DevBuf scale, part, out;
     const int ns = colsum_out_host ? 3 : 2;
-    if (Y->sorted_rows) FDX_TRY(cursor.alloc((size_t)Y->n * sizeof(int)));
     FDX_TRY(scale.alloc((size_t)Y->n * sizeof(double)));
     FDX_TRY(part.alloc((size_t)csr_moment_stripes(Y->n) * ns * G * sizeof(double)));
     FDX_TRY(out.alloc(3 * G * sizeof(double)));
     double* o = out.as<double>();
-    FDX_TRY(launch_csr_moments((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, Y->n, Y->G, scale.as<double>(),
-                               part.as<double>(), o, o + G, colsum_out_host ? o + 2 * G : nullptr,
-                               Y->sorted_rows ? cursor.as<int>() : nullptr, st));
+    FDX_TRY(launch_csr_moments((const long long*)Y->indptr, Y->indices, Y->data, Y->dtype, Y->n, Y->nnz, Y->G, scale.as<double>(),
+                               part.as<double>(), o, o + G, colsum_out_host ? o + 2 * G : nullptr, Y->sorted_rows != 0, st));
     if (mean_out_host) FDX_TRY(copy_d2h(mean_out_host, o, G * sizeof(double), st));
     if (var_out_host) FDX_TRY(copy_d2h(var_out_host, o + G, G * sizeof(double), st));
     if (colsum_out_host) FDX_TRY(copy_d2h(colsum_out_host, o + 2 * G, G * sizeof(double), st));
