@@ -205,6 +205,13 @@ def sketch_kernel_name(mode, K, d=512):
         "true" if (wg and os.environ.get("FDX_TILE_FLAT")) else "false")
 
 
+def aux_steps(a):
+    """Timed steps of the families beside the headline (count-like, CSR, lattice): the driver's --steps, at most 10; they get
+    the same --warmup as the headline (a family's first two or three fits in a process still pay for pooled buffers changing
+    hands: with two warm-up fits and two timed ones the driver's figure was the tail of the warm-up)."""
+    return max(1, min(a.steps, 10))
+
+
 def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
     from flashdeconv_amd import FlashDeconv
     model = FlashDeconv(**model_kw)
@@ -214,15 +221,20 @@ def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     stage = {}
+    t_prev, walls = t0, []
     for _ in range(steps):
         model.fit(Y, X, coords, output="torch")
         for k, v in model.timings_.items():
             stage[k] = stage.get(k, 0.0) + v
+        t_now = time.perf_counter()             # (no synchronisation: fit returns with its results complete)
+        walls.append((t_now - t_prev) * 1e3)
+        t_prev = t_now
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     for k in stage:
         stage[k] /= steps
+    stage["step_ms_min_max"] = [round(min(walls), 3), round(max(walls), 3)]
     # cold fit: the same call with the library's content-keyed caches (sketch plans, tile schedules) bypassed - what a user who
     # calls fit_transform ONCE pays (the GPU context itself is warm); outside the timed region
     os.environ["FDX_NO_PLAN_CACHE"] = "1"
@@ -240,7 +252,7 @@ def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
 def stage_record(stage, ms_per_step):
     """Stage times of one step as they tile its wall time: host_pre (Python before the first kernel) + span (device, hipEvents:
     prologue + sketch + gram + solve + finish) + host_post; `unaccounted_ms` = wall - that sum."""
-    out = {k: round(v, 3) for k, v in stage.items() if k != "cold_ms"}
+    out = {k: round(v, 3) for k, v in stage.items() if k not in ("cold_ms", "step_ms_min_max")}
     out["unaccounted_ms"] = round(ms_per_step - (stage["host_pre_ms"] + stage["span_ms"] + stage["host_post_ms"]), 3)
     return out
 
@@ -495,14 +507,15 @@ def main():
             ii = torch.arange(n, device=device)
             coords = torch.stack([(ii % side).double(), (ii // side).double()], dim=1)
             kw = dict(sketch_dim=d, preprocess="log_cpm", n_hvg=G)
-            lsteps = max(1, min(a.steps, 2))
+            lsteps = aux_steps(a)
             import warnings
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                model, dt, stage = run_family(torch, kw, Y, X, coords, lsteps, min(a.warmup, 2), barrier)
+                model, dt, stage = run_family(torch, kw, Y, X, coords, lsteps, a.warmup, barrier)
             ms_step = dt / lsteps * 1e3
             results[fam] = {
-                "value": n * lsteps / dt, "unit": "spots/s", "ms_per_step": ms_step, "cold_ms": round(stage["cold_ms"], 3),
+                "value": n * lsteps / dt, "unit": "spots/s", "ms_per_step": ms_step, "steps": lsteps, "warmup": a.warmup,
+                "step_ms_min_max": stage.pop("step_ms_min_max"), "cold_ms": round(stage["cold_ms"], 3),
                 "workload": f"{n} spots on a {side} x {side} square lattice (every k-th neighbour tied), {G} genes x {K} types, count-like / "
                             f"log_cpm, knn_ties='auto' (default): the reference's cKDTree tie order",
                 "n_iterations": model.info_["n_iterations"], "converged": model.info_["converged"],
@@ -515,16 +528,18 @@ def main():
         if fam == "sparse":
             Y, X, coords = gen_sparse(torch, n, a.sparse_genes, K, device, seed=0)
             kw = dict(sketch_dim=d, preprocess="log_cpm", n_hvg=G, max_iter=20)
-            model, dt, stage = run_family(torch, kw, Y, X, coords, max(1, min(a.steps, 2)), min(a.warmup, 2), barrier)   # two untimed fits: the second one still pays ~6 ms once (pooled buffers changing hands)
+            ssteps = aux_steps(a)
+            model, dt, stage = run_family(torch, kw, Y, X, coords, ssteps, a.warmup, barrier)
             nnz_y = int(Y.values().numel())
             # fused CSR sketch -> H (gram_ms == 0): reads the stored entries (4 B value + 4 B column each) and the row extents, writes
             # H; the two-kernel path also writes and re-reads Y_sketch (n x d x 8 B)
             csr_bytes = nnz_y * 8 + n * 8 + n * K * 8 + (2 * n * d * 8 if stage["gram_ms"] > 0.0 else 0)
             csr_ms = stage["sketch_ms"] + stage["gram_ms"]
             csr_gbs = csr_bytes / (csr_ms * 1e-3) / 1e9
-            ms_step = dt / max(1, min(a.steps, 2)) * 1e3
+            ms_step = dt / ssteps * 1e3
             results[fam] = {
-                "value": n * max(1, min(a.steps, 2)) / dt, "unit": "spots/s", "ms_per_step": ms_step, "cold_ms": round(stage["cold_ms"], 3),
+                "value": n * ssteps / dt, "unit": "spots/s", "ms_per_step": ms_step, "steps": ssteps, "warmup": a.warmup,
+                "step_ms_min_max": stage.pop("step_ms_min_max"), "cold_ms": round(stage["cold_ms"], 3),
                 "workload": f"CSR input: {n} spots x {a.sparse_genes} genes, {nnz_y} stored entries ({nnz_y / n / a.sparse_genes:.3f} dense, "
                             f"{nnz_y / n:.0f} per spot), float32 values + int32 columns in HBM; HVG+markers select "
                             f"{len(model.gene_idx_)} genes, log_cpm, max_iter 20 (the solve is not the subject here)",
@@ -547,8 +562,8 @@ def main():
         else:
             Y, X, coords = gen_counts(torch, n, G, K, device, seed=0)
             kw = dict(sketch_dim=d, preprocess="log_cpm", n_hvg=G)
-        steps = a.steps if fam == "gaussian" else max(1, min(a.steps, 2))
-        model, dt, stage = run_family(torch, kw, Y, X, coords, steps, a.warmup if fam == "gaussian" else min(a.warmup, 2), barrier)
+        steps = a.steps if fam == "gaussian" else aux_steps(a)
+        model, dt, stage = run_family(torch, kw, Y, X, coords, steps, a.warmup, barrier)
         T = model.info_["n_iterations"]
         nnz = int(model._graph.info()[1])
         sk_bytes, sw_bytes = alg_bytes(n, G, K, 4, nnz, 0, T)
@@ -568,7 +583,8 @@ def main():
                 kname = "fdx::sketch_rows_scatter_kernel<float, %d, true>" % (0 if fam == "gaussian" else 1)
         ach = bytes_launch / (ms_launch * 1e-3) / 1e9
         results[fam] = {
-            "value": n * steps / dt, "ms_per_step": dt / steps * 1e3, "cold_ms": round(stage["cold_ms"], 3), "n_iterations": T,
+            "value": n * steps / dt, "ms_per_step": dt / steps * 1e3, "step_ms_min_max": stage.pop("step_ms_min_max"),
+            "cold_ms": round(stage["cold_ms"], 3), "n_iterations": T,
             "converged": model.info_["converged"], "stage_ms": stage_record(stage, dt / steps * 1e3),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, (n, G, K, d)),
@@ -593,11 +609,12 @@ def main():
         "config": {"workload": f"{n} spots x {G} genes x {K} types, sketch_dim {d}, k_neighbors 6, "
                                f"{'gaussian/raw' if main_fam == 'gaussian' else 'count-like/log_cpm'} family, Y float32 in HBM, "
                                f"tol 1e-4, max_iter 100", "n_iterations": r["n_iterations"], "converged": r["converged"]},
-        "roofline": r["roofline"], "stage_ms": r["stage_ms"], "cold_ms": r["cold_ms"],
+        "roofline": r["roofline"], "stage_ms": r["stage_ms"], "cold_ms": r["cold_ms"], "step_ms_min_max": r["step_ms_min_max"],
     }
     if "counts" in results and main_fam != "counts":
         c = results["counts"]
-        line["count_like"] = {"value": c["value"], "unit": "spots/s", "ms_per_step": c["ms_per_step"], "cold_ms": c["cold_ms"],
+        line["count_like"] = {"value": c["value"], "unit": "spots/s", "ms_per_step": c["ms_per_step"], "steps": c["steps"],
+                              "step_ms_min_max": c["step_ms_min_max"], "cold_ms": c["cold_ms"],
                               "n_iterations": c["n_iterations"], "converged": c["converged"], "roofline": c["roofline"],
                               "stage_ms": c["stage_ms"], "workload": "same shape, count-like / log_cpm family (runs max_iter)"}
     if "sparse" in results:

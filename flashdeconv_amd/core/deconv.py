@@ -544,6 +544,11 @@ class FlashDeconv:
         # prologue_ms + sketch_ms + gram_ms + solve_ms + finish_ms) + host_post_ms (fit_dev's return -> here);
         # total_ms is their sum, and what the wall has beyond it is the host's last synchronisation
         self.timings_["host_pre_ms"] = (t_graph - t_entry) * 1e3
+        if graph_early:
+            # gene selection active: the graph was queued on the side stream FIRST and the device span starts with the fit call -
+            # gene statistics (device) + ranking (host) + leverage + tables all lie before it (select_ms is the part of it that
+            # selects)
+            self.timings_["host_pre_ms"] = (t_call - t_entry) * 1e3
         if ties_resolved_here or (resolved and n_ties):
             # the graph was rebuilt on the reference's tie order: the device span starts with the fit call that used it, and
             # everything before that call (first build, the stopped call, the host tree, the rebuild) is host time

@@ -414,9 +414,10 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
                 s = wave_sum(s);
                 scale = 10000.0 / (s == 0.0 ? 1.0 : s);                    // deconv.py:183-185
                 // counts below 64 take log1p from the row's table ENTRY BY ENTRY (a row with a few large counts keeps the table for
-                // the others); its arguments are 0 .. 63 * scale: the lean log1p; a row of negative sum goes without
-                table_ok = !no_table && scale > 0.0 && scale <= 10000.0;
-                if (table_ok) tab[lane] = fast_log1p_core((double)lane * scale);
+                // the others).  The table is filled by the very function (and the very code: a call, not a second inlined copy
+                // that the compiler may contract differently) that evaluates what the table does not hold - same bits either way
+                table_ok = !no_table;
+                if (table_ok) tab[lane] = csr_log1p_any(__dmul_rn((double)lane, scale));
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);                            // zeroing, table and kept entries are in LDS
             auto add_entry = [&](int rk, double yv) {
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(1024, 4) void sketch_csr_contract_kernel(
                     const bool hit = table_ok && (double)ci == yv && (unsigned)ci < 64u;
                     val = hit ? tab[ci] : 0.0;
                     if (__ballot(!hit) != 0ULL) {                           // (rare for counts: a call, its temporaries stay out of the loop)
-                        if (!hit) val = csr_log1p_any(yv * scale);
+                        if (!hit) val = csr_log1p_any(__dmul_rn(yv, scale));
                     }
                 }
                 const double wgt = sel_in_lds ? sel_w_l[rk] : sel_w_g[rk];
@@ -753,11 +754,12 @@ __global__ __launch_bounds__(1024, WPE) void csr_moments_cursor_kernel(const lon
                 for (;;) {
                     bool more = true;                                     // wave-uniform: every entry so far belonged to the tile
                     int taken = 0;
+                    const int left = (int)min<long long>(v_cur.end - q0, 0x7fffffffLL);   // entries of the row from q0 on
 #pragma unroll
                     for (int u = 0; u < NW; ++u) {
                         if (u < nw && more) {
                             const int c = w_cur.c[u];
-                            const bool in = c < t1 && q0 + u * 64 + lane < v_cur.end;   // sorted: the taken entries are a prefix
+                            const bool in = c < t1 && u * 64 + lane < left;   // sorted: the taken entries are a prefix
                             const int cnt = __popcll(__ballot(in));
                             if (in) {
                                 const double y = (double)w_cur.y[u];
@@ -795,19 +797,33 @@ __global__ __launch_bounds__(1024, WPE) void csr_moments_cursor_kernel(const lon
     }
 }
 
+// mean / variance (/ column sums) from the stripes' partial sums, in stripe order: 64 genes per workgroup, the stripes dealt to
+// four quarter-workgroups whose sums meet through LDS (256 stripes x 2 x 20000 doubles = 82 MB: one block per 256 genes read it
+// at a tenth of the memory's rate)
 template <int NS>
 __global__ __launch_bounds__(256) void csr_fold_moments_kernel(const double* __restrict__ part, int stripes, int G, long long n,
                                                                double* __restrict__ mean, double* __restrict__ var,
                                                                double* __restrict__ colsum) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= G) return;
+    __shared__ double red[3][4][64];
+    const int gl = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + gl;
     double s1 = 0.0, s2 = 0.0, s0 = 0.0;
-    for (int b = 0; b < stripes; ++b) {
-        const double* p = part + (size_t)b * NS * G;
-        s1 += p[g];
-        s2 += p[(size_t)G + g];
-        if (NS == 3) s0 += p[2 * (size_t)G + g];
-    }
+    const int per = (stripes + 3) / 4;
+    if (g < G)
+        for (int b = qtr * per; b < min(stripes, (qtr + 1) * per); ++b) {
+            const double* p = part + (size_t)b * NS * G;
+            s1 += p[g];
+            s2 += p[(size_t)G + g];
+            if (NS == 3) s0 += p[2 * (size_t)G + g];
+        }
+    red[0][qtr][gl] = s1;
+    red[1][qtr][gl] = s2;
+    red[2][qtr][gl] = s0;
+    __syncthreads();
+    if (qtr != 0 || g >= G) return;
+    s1 = ((red[0][0][gl] + red[0][1][gl]) + red[0][2][gl]) + red[0][3][gl];
+    s2 = ((red[1][0][gl] + red[1][1][gl]) + red[1][2][gl]) + red[1][3][gl];
+    s0 = ((red[2][0][gl] + red[2][1][gl]) + red[2][2][gl]) + red[2][3][gl];
     const double m = s1 / (double)n;
     mean[g] = m;
     var[g] = (n >= 2) ? fmax(((s2 / (double)n) - m * m) * ((double)n / (double)(n - 1)), 0.0) : 0.0;   // genes.py:74-83
@@ -850,7 +866,7 @@ static int launch_csr_moments_t(const long long* indptr, const int* indices, con
                            indptr, indices, data, scale, n, G, tile, rows_per_stripe, part);
     }
     FDX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(csr_fold_moments_kernel<NS>, dim3(ceil_div(G, 256)), dim3(256), 0, st, part, stripes, G, n, mean, var, colsum);
+    hipLaunchKernelGGL(csr_fold_moments_kernel<NS>, dim3(ceil_div(G, 64)), dim3(256), 0, st, part, stripes, G, n, mean, var, colsum);
     FDX_CHECK_LAUNCH();
     return 0;
 }

@@ -54,7 +54,7 @@ __device__ __forceinline__ double fast_log1p(double x) {
 // counts, normalised or non-integer input, NaN - is computed directly.  tab[c] is the same function of the same argument,
 // so results are bit-identical with and without the table.
 __device__ __forceinline__ void log1p_table_fill(double* tab, double scale, int lane) {
-    tab[lane] = fast_log1p((double)lane * scale);
+    tab[lane] = fast_log1p(__dmul_rn((double)lane, scale));      // (rounded product: never fused into the 1 + x of the log1p)
 }
 
 // use_tab is wave-uniform (row maximum below 64): rows of large counts or normalised values skip the table and its
@@ -64,7 +64,7 @@ __device__ __forceinline__ double log1p_scaled(double y, double scale, const dou
         const int c = (int)y;
         if ((double)c == y && (unsigned)c < 64u) return tab[c];
     }
-    return fast_log1p(y * scale);
+    return fast_log1p(__dmul_rn(y, scale));
 }
 
 __device__ __forceinline__ double wave_max(double v) {
