@@ -16,7 +16,7 @@ the N ranks.  --scaling weak: N x 1M spots, 1M per rank.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      - dominant kernel of the step vs the HBM roofline (algorithmic bytes / hipEvent-measured duration)
   cpu_baseline  - the oracle (CPU restatement of the reference, numpy/scipy + C/OpenMP BCD) timed on this box's host
-                  cores on a bounded sample of the same workload (N=1 only)
+                  cores on the headline's own rows (--cpu-sample, default all 1M: ~30 s of CPU; N=1 only)
   count_like    - the same measurement on the count-like / log_cpm family, which runs all 100 iterations
 """
 import argparse
@@ -58,7 +58,8 @@ def parse():
                     help="--gpus N > 1 started from a bare shell: seconds after which a job whose ranks have produced no result "
                          "is ended (default 900)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000,
+                    help="rows of the headline matrix the CPU baseline is timed on (default: all of configs[2]: ~30 s of CPU)")
     return ap.parse_args()
 
 
@@ -279,17 +280,16 @@ def host_cpu_budget():
     return max(1, int(round(cpus)))
 
 
-def cpu_baseline(n_cpu, G, K, d, seed=0):
-    """Oracle (CPU restatement of the reference path) on a bounded sample, all host cores for the OpenMP BCD sweep."""
+def cpu_baseline(Yh32, X, coords_h, d):
+    """Oracle (CPU restatement of the reference path, every stage as the reference computes it: dense HVG statistics, the
+    fancy-index copy of Y, scipy's dense @ CSR sketch, cKDTree, BLAS Gram, then the C/OpenMP BCD sweep in place of numba's
+    prange) on the HEADLINE's own rows: the float32 matrix the GPU steps read, as float64 (core/deconv.py:229)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fdx_oracle as orc
-    rs = np.random.RandomState(seed)
-    X = rs.randn(K, G)
-    B = rs.rand(n_cpu, K)
-    B /= B.sum(axis=1, keepdims=True)
-    Y = B @ X + 0.1 * rs.randn(n_cpu, G)
-    coords = rs.rand(n_cpu, 2) * np.sqrt(n_cpu)
+    n_cpu, G = Yh32.shape
+    K = X.shape[0]
+    Y = Yh32.astype(np.float64)
     cores = host_cpu_budget()
     try:                                       # the C sweep's OpenMP team: as many threads as the process may actually run
         import ctypes
@@ -297,10 +297,10 @@ def cpu_baseline(n_cpu, G, K, d, seed=0):
     except OSError:
         pass
     t0 = time.perf_counter()
-    out = orc.fit(Y, X, coords, sketch_dim=d, preprocess_method="raw", n_hvg=G, graph="kdtree", engine="c")
+    out = orc.fit(Y, X, coords_h, sketch_dim=d, preprocess_method="raw", n_hvg=G, graph="kdtree", engine="c")
     dt = time.perf_counter() - t0
     return {"value": n_cpu / dt, "unit": "spots/s", "cores": cores, "kind": "port",
-            "sample": f"{n_cpu} spots x {G} genes x {K} types, gaussian/raw float64, {out['info']['n_iterations']} iterations, "
+            "sample": f"{n_cpu} spots x {G} genes x {K} types (the headline's rows), gaussian/raw float64, {out['info']['n_iterations']} iterations, "
                       f"{dt:.1f} s wall (numpy/scipy stages single-threaded as in the reference, C/OpenMP BCD sweep on {cores} threads)"}
 
 
@@ -496,6 +496,7 @@ def main():
     torch.cuda.set_device(device)
     n, G, K, d = a.spots, a.genes, a.types, a.sketch_dim
     results = {}
+    cpu_inputs = None
     fams = {"both": ["gaussian", "counts"], "all": ["gaussian", "counts", "sparse", "lattice"]}.get(a.family, [a.family])
     for fam in fams:
         if fam == "lattice":
@@ -593,6 +594,11 @@ def main():
                          "alg_bytes_per_launch": int(bytes_launch), "ms_per_launch": round(ms_launch, 4)},
             "steps": steps,
         }
+        if fam == "gaussian" and not a.no_cpu_baseline and a.config == 3:
+            # the CPU baseline runs on these very rows, at the end (outside every timed region): a host copy through pinned staging
+            from flashdeconv_amd import _lib as _fdx_lib
+            n_cpu = min(a.cpu_sample, n)
+            cpu_inputs = (_fdx_lib.tensor_to_host(Y[:n_cpu]), X, _fdx_lib.tensor_to_host(coords[:n_cpu]))
         del Y, coords, model
         torch.cuda.empty_cache()
 
@@ -621,8 +627,8 @@ def main():
         line["sparse_csr"] = results["sparse"]
     if "lattice" in results:
         line["lattice"] = results["lattice"]
-    if not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, n), G, K, d)
+    if cpu_inputs is not None:
+        line["cpu_baseline"] = cpu_baseline(*cpu_inputs, d)
     print(json.dumps(line))
 
 

@@ -1,5 +1,6 @@
-"""-m gpu: BASELINE.json's full single-GPU size (1M spots x 2000 genes x 30 types, d=512) through size-independent
-properties - the oracle cannot run at this size.  Synthetic inputs are generated on the device (bench.py generators)."""
+"""-m gpu: BASELINE.json's full single-GPU size (1M spots x 2000 genes x 30 types, d=512): against the CPU oracle at that
+very size (test_config3_at_one_million_spots_against_the_oracle: 16 GB of host float64, ~30-45 s of CPU per family) and through
+size-independent properties.  Synthetic inputs are generated on the device (bench.py generators)."""
 import hashlib
 import os
 import sys
@@ -93,6 +94,51 @@ def test_baseline_configs_at_full_size_against_the_oracle(n, K, family):
     assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
     assert m.info_["n_iterations"] == want["info"]["n_iterations"] and m.info_["converged"] == want["info"]["converged"]
     np.testing.assert_allclose(m.lambda_used_, want["lambda_used"], rtol=1e-10)
+    assert rel_fro(m.beta_, want["beta"]) < tol
+    assert rel_fro(m.proportions_, want["proportions"]) < tol
+
+
+@pytest.mark.parametrize("family", ["gaussian", "counts_f32"])
+def test_config3_at_one_million_spots_against_the_oracle(family):
+    """BASELINE.json configs[2] ITSELF - 1M spots x 2000 genes x 30 types, d = 512, the inputs of bench.py - against the CPU
+    oracle (the pinned restatement of core/deconv.py:305-398, core/solver.py:385-413) on the same rows: same genes, the same
+    adjacency index for index, the same iteration count and stopping verdict, abundances and proportions within 1e-8 relative
+    Frobenius (contract 1e-4).  What the 10k / 100k cases above cannot see: a defect that only appears past 100k rows (32-bit
+    offsets, tile counts, Morton cells).  counts_f32: the count-like family of the bench (log-CPM, float32 rows: the reference
+    computes float32, the device a float32-class log1p - tolerance 1e-5 as above), 10 sweeps."""
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import fdx_oracle as orc
+    from conftest import rel_fro
+    from flashdeconv_amd import FlashDeconv, _lib
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2**30:
+        pytest.skip("BASELINE configs[2] needs 40 GB of free HBM")
+    n, dev = 1_000_000, torch.device("cuda", 0)
+    if family == "gaussian":
+        Y, X, coords = bench.gen_gaussian(torch, n, 2000, 30, dev, seed=3)
+        pre, max_iter, tol = "raw", 100, 1e-8
+    else:
+        Y, X, coords = bench.gen_counts(torch, n, 2000, 30, dev, seed=3)
+        pre, max_iter, tol = "log_cpm", 10, 1e-5
+    m = FlashDeconv(sketch_dim=512, preprocess=pre, n_hvg=2000, max_iter=max_iter).fit(Y, X, coords)
+    Yh = _lib.tensor_to_host(Y)                               # the float32 rows the device read
+    ch = _lib.tensor_to_host(coords)
+    del Y, coords
+    torch.cuda.empty_cache()
+    if family == "gaussian":
+        Yh = Yh.astype(np.float64)                            # raw: the reference's astype(float64) of the same values
+    want = orc.fit(Yh, X, ch, sketch_dim=512, preprocess_method=pre, n_hvg=2000, max_iter=max_iter, graph="kdtree")
+    del Yh
+    assert np.array_equal(m.gene_idx_, want["gene_idx"]) and len(m.gene_idx_) == 2000
+    A, B = m.adjacency_, want["adjacency"].tocsr()
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    assert m.info_["n_iterations"] == want["info"]["n_iterations"] and m.info_["converged"] == want["info"]["converged"]
+    np.testing.assert_allclose(m.lambda_used_, want["lambda_used"], rtol=1e-10 if family == "gaussian" else 1e-6)
+    np.testing.assert_allclose(m.info_["final_objective"], want["info"]["final_objective"], rtol=1e-9 if family == "gaussian" else 1e-5)
     assert rel_fro(m.beta_, want["beta"]) < tol
     assert rel_fro(m.proportions_, want["proportions"]) < tol
 
