@@ -512,11 +512,21 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
     double* cnt_h = (double*)pinned_scratch(5, 8 * sizeof(double));
     FDX_REQUIRE(cnt_h != nullptr, "fdx_shard_fit_dev: pinned host buffer");
     double tot[4] = {0, 0, 0, 0};
-    const bool queued_plan = g->shard_pending || g->counts_dev.p != nullptr;
-    if (queued_plan && g->counts_dev.p && W > 1 && !c->loopback) {
+    // A JOB-level decision (the caller's nnz_total < 0: the plan's counts are still to be summed), identical on every rank - NOT
+    // "does this rank's graph carry device counts": after an overflow remedy one rank's graph is a stepwise rebuild without them,
+    // and a rank that skipped the all-reduce its peers issued left the communicator mismatched (hang).  A rank without device
+    // counts contributes its host counts.
+    const bool job_reduces = prm->nnz_total < 0 && W > 1 && !c->loopback;
+    if (job_reduces) {
         FDX_TRY(dCnt.alloc(4 * sizeof(double)));
-        if (g->shard_pending) FDX_HIP(hipStreamWaitEvent(c->side, g->meta_event, 0));
-        FDX_HIP(hipMemcpyAsync(dCnt.p, g->counts_dev.p, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->side));
+        if (g->counts_dev.p) {
+            if (g->shard_pending) FDX_HIP(hipStreamWaitEvent(c->side, g->meta_event, 0));
+            FDX_HIP(hipMemcpyAsync(dCnt.p, g->counts_dev.p, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->side));
+        } else {
+            FDX_TRY(fdx::graph_meta_sync(g));
+            cnt_h[4] = (double)g->nnz; cnt_h[5] = (double)g->knn_ties; cnt_h[6] = (double)g->knn_far; cnt_h[7] = (double)g->shard_overflow;
+            FDX_HIP(hipMemcpyAsync(dCnt.p, cnt_h + 4, 4 * sizeof(double), hipMemcpyHostToDevice, c->side));
+        }
         FDX_TRY(allreduce(c, dCnt.p, 4, false, c->side));
         FDX_HIP(hipMemcpyAsync(cnt_h, dCnt.p, 4 * sizeof(double), hipMemcpyDeviceToHost, c->side));
         FDX_HIP(hipStreamSynchronize(c->side));

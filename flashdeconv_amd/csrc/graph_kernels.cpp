@@ -2731,7 +2731,11 @@ int shard_queue_rest(fdx_graph* loc, hipStream_t st) {
     hipLaunchKernelGGL(slice_width_kernel, dim3(wblocks), dim3(256), 0, st, loc->deg.as<int>(), n_own, loc->n_slices, width, part);
     FDX_CHECK_LAUNCH();
     FDX_TRY(exclusive_scan_int(width, loc->slice_off.as<int>(), loc->n_slices + 1, st, sb->scan_tmp));
-    const int w_cap = getenv("FDX_GRAPH_WCAP") ? std::max(1, atoi(getenv("FDX_GRAPH_WCAP"))) : std::min(96, std::max(24, 3 * kk + 3));
+    // (tests: FDX_GRAPH_WCAP forces the "bound too small" remedy, on every rank or - FDX_GRAPH_WCAP_RANK - on one)
+    int rank = 0;
+    while (rank + 1 < n_ranks && !(sb->bounds[rank] == lo && sb->bounds[rank + 1] == hi)) ++rank;
+    const bool cap_forced = getenv("FDX_GRAPH_WCAP") && (!getenv("FDX_GRAPH_WCAP_RANK") || atoi(getenv("FDX_GRAPH_WCAP_RANK")) == rank);
+    const int w_cap = cap_forced ? std::max(1, atoi(getenv("FDX_GRAPH_WCAP"))) : std::min(96, std::max(24, 3 * kk + 3));
     const long long cap = (long long)loc->n_slices * w_cap;
     loc->shard_ell_cap = cap;
     FDX_TRY(loc->ell.alloc((size_t)std::max<long long>(cap, 1) * 64 * 4));

@@ -326,6 +326,10 @@ class ShardedFlashDeconv:
         if self._native is not None or os.environ.get("FDX_PY_LOOP"):
             return self._native
         lib = _lib.load()
+        if getattr(self.comm, "native_handle", None) is not None:   # a comm that brings its own libfdx communicator (thread ranks
+            self._native = self.comm.native_handle                  # over fdx_comm_init_local in the tests)
+            self._native_borrowed = True
+            return self._native
         if getattr(self.comm, "loopback", False):              # measurement: one rank alone (LoopbackComm)
             h = ctypes.c_void_p()
             _lib.check(lib.fdx_comm_init_loopback(self.comm.rank, self.comm.world, ctypes.byref(h)))
@@ -368,7 +372,8 @@ class ShardedFlashDeconv:
 
     def close(self):
         if self._native is not None:
-            _lib.load().fdx_comm_destroy(self._native)
+            if not getattr(self, "_native_borrowed", False):
+                _lib.load().fdx_comm_destroy(self._native)
             self._native = None
         for g in (self._local, self._full):
             if g is not None:
@@ -563,6 +568,7 @@ class ShardedFlashDeconv:
         if self._local is not None:
             self._local.close()
         self._local = _lib.Graph(hl.value)
+        self.plan_rebuilt_stepwise_ = True          # (diagnostic: this rank's graph came from the remedy / the no-row path)
 
     def _ties_remedy_lists(self, coords, st):
         """The reference's neighbour lists (cKDTree's choice among equidistant candidates) for this rank's own rows and band, in
@@ -880,7 +886,10 @@ class ShardedFlashDeconv:
                                          ctypes.byref(info), st))
         self._mark("fit:native call")
         if info.status != 0:
-            self._finish_plan(totals=(float(info.nnz_total), float(info.knn_ties_total), 1.0 if info.status == _lib.SHARD_FAR else 0.0))
+            # (a bound too small on some rank: that rank rebuilds, and its exact edge count enters the job's total through a fresh
+            # all-reduce - every rank takes this branch, the status is the job's)
+            self._finish_plan(totals=None if info.status == _lib.SHARD_OVERFLOW else
+                              (float(info.nnz_total), float(info.knn_ties_total), 1.0 if info.status == _lib.SHARD_FAR else 0.0))
             return False
         if pending:
             self._pending_plan = None

@@ -660,6 +660,149 @@ def test_native_loop_8_ranks_at_1m_spots_config3():
     assert torch.equal(got, ref.beta_)
 
 
+class _ThreadWorld:
+    """W thread ranks of one process: libfdx's in-process transport (fdx_local_world_create) for the native calls, a barrier and
+    a slot list for the Python-side collectives of ShardedFlashDeconv."""
+
+    def __init__(self, W):
+        import threading
+        from flashdeconv_amd import _lib
+        self.W = W
+        self.barrier = threading.Barrier(W, timeout=60)
+        self.slots = [None] * W
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().fdx_local_world_create(W, ctypes.byref(self.handle)))
+
+    def close(self):
+        from flashdeconv_amd import _lib
+        _lib.load().fdx_local_world_destroy(self.handle)
+
+
+class _ThreadComm:
+    """The comm interface of flashdeconv_amd.distributed (TorchComm) for one thread rank; brings its own libfdx communicator, so
+    ShardedFlashDeconv takes the native path (fdx_shard_fit_dev, the C++ iteration loop) exactly as over RCCL."""
+
+    def __init__(self, world, rank):
+        from flashdeconv_amd import _lib
+        self.w, self.rank, self.world, self.group = world, rank, world.W, None
+        self.native_handle = ctypes.c_void_p()
+        _lib.check(_lib.load().fdx_comm_init_local(world.handle, rank, ctypes.byref(self.native_handle)))
+
+    def _gather(self, item):
+        import torch
+        torch.cuda.current_stream().synchronize()
+        self.w.slots[self.rank] = item
+        self.w.barrier.wait()
+        items = list(self.w.slots)
+        self.w.barrier.wait()
+        return items
+
+    def all_reduce_sum(self, t):
+        items = self._gather(t.clone())
+        acc = items[0].clone()
+        for x in items[1:]:
+            acc += x
+        t.copy_(acc)
+
+    def all_reduce_max(self, t):
+        import torch
+        items = self._gather(t.clone())
+        acc = items[0].clone()
+        for x in items[1:]:
+            acc = torch.maximum(acc, x)
+        t.copy_(acc)
+
+    def all_gather_rows(self, nbr, cnt, bounds):
+        lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        items = self._gather((nbr[lo:hi].clone(), cnt[lo:hi].clone()))
+        for q, (a, b) in enumerate(items):
+            if q != self.rank:
+                nbr[int(bounds[q]):int(bounds[q + 1])] = a
+                cnt[int(bounds[q]):int(bounds[q + 1])] = b
+
+    def exchange(self, send_bufs, recv_bufs):
+        items = self._gather({p: t.clone() for p, t in send_bufs.items()})
+        for peer, t in recv_bufs.items():
+            t.copy_(items[peer][self.rank])
+
+    def close(self):
+        from flashdeconv_amd import _lib
+        _lib.load().fdx_comm_destroy(self.native_handle)
+
+
+def _class_thread_ranks(torch, W, kw, Y, X, coords):
+    """ShardedFlashDeconv on W thread ranks of this process: plan + fit_transform per rank, results put together in the caller's
+    spot order.  Returns (proportions, [model of every rank])."""
+    import threading
+    from flashdeconv_amd.distributed import ShardedFlashDeconv
+    dev = torch.device("cuda", 0)
+    world = _ThreadWorld(W)
+    cd = torch.from_numpy(np.ascontiguousarray(coords)).to(dev)
+    Yt = torch.from_numpy(np.ascontiguousarray(Y)).to(dev)
+    n, K = Y.shape[0], X.shape[0]
+    got = np.zeros((n, K))
+    models, errors = [None] * W, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = _ThreadComm(world, r)
+            m = ShardedFlashDeconv(comm=comm, **kw)
+            own = m.plan(cd)
+            P = m.fit_transform(Yt[own], X)
+            got[own.cpu().numpy()] = P.cpu().numpy()
+            models[r] = m
+        except Exception as e:                                   # noqa: BLE001 - reported below; the peers' barrier times out
+            import traceback
+            errors.append((r, repr(e), traceback.format_exc()))
+            world.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank thread hangs"
+    assert not errors, errors
+    return got, models
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("W,force_overflow_on", [(3, None), (4, 1), (3, "all")])
+def test_sharded_class_on_thread_ranks_takes_the_native_fit(W, force_overflow_on, monkeypatch):
+    """ShardedFlashDeconv END TO END with W > 1 ranks through the native path - fdx_shard_fit_dev (csrc/comm.cpp): the plan's counts
+    all-reduced beside the sketch, lambda, the C++ iteration loop, objective sums - over libfdx's in-process transport: everything
+    the RCCL job runs except the wire.  Bits of the single-GPU fit.  force_overflow_on: the "bound too small" remedy of the queued
+    plan on ONE rank (the others keep their device-built graphs; the job-level all-reduce of the counts must still match on every
+    rank: it hung when it was decided per graph) or on all of them."""
+    import torch
+    from flashdeconv_amd import FlashDeconv
+    if force_overflow_on is not None:
+        monkeypatch.setenv("FDX_GRAPH_WCAP", "1")
+        if force_overflow_on != "all":
+            monkeypatch.setenv("FDX_GRAPH_WCAP_RANK", str(force_overflow_on))
+    n, G, K = 6000, 300, 9
+    Y, X, coords, _ = datagen.gaussian_raw(n, G, K, seed=4)
+    kw = dict(sketch_dim=64, preprocess="raw", n_hvg=G, max_iter=40)
+    monkeypatch.delenv("FDX_GRAPH_WCAP", raising=False) if force_overflow_on is None else None
+    env_cap = os.environ.pop("FDX_GRAPH_WCAP", None)             # the single-GPU reference is built without the forced bound
+    try:
+        ref = FlashDeconv(**kw).fit(Y, X, coords)
+    finally:
+        if env_cap is not None:
+            os.environ["FDX_GRAPH_WCAP"] = env_cap
+    got, models = _class_thread_ranks(torch, W, kw, Y, X, coords)
+    for m in models:
+        assert m.comm_report()["loop"] == "native"
+        assert m.info_["n_iterations"] == ref.info_["n_iterations"] and m.info_["converged"] == ref.info_["converged"]
+        np.testing.assert_allclose(m.lambda_used_, ref.lambda_used_, rtol=1e-14)
+        np.testing.assert_allclose(m.info_["final_objective"], ref.info_["final_objective"], rtol=1e-12)
+    assert np.array_equal(got, ref.proportions_)
+    rebuilt = [bool(getattr(m, "plan_rebuilt_stepwise_", False)) for m in models]
+    want = [force_overflow_on == "all" or r == force_overflow_on for r in range(W)] if force_overflow_on is not None else [False] * W
+    assert rebuilt == want, (rebuilt, want)                      # the remedy ran where it was forced, and only there
+
+
 @pytest.mark.parametrize("W", [2, 3])
 @pytest.mark.parametrize("method", ["radius", "grid"])
 def test_sharded_radius_build_equals_the_replicated_one(W, method):
