@@ -58,6 +58,8 @@ def parse():
                     help="--gpus N > 1 started from a bare shell: seconds after which a job whose ranks have produced no result "
                          "is ended (default 900)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-arrays", action="store_true",
+                    help="skip the host_arrays record (numpy / scipy in, numpy out: the literal drop-in, PCIe included)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="rows of the headline matrix the CPU baseline is timed on (default: all of configs[2]: ~30 s of CPU)")
     return ap.parse_args()
@@ -302,6 +304,69 @@ def cpu_baseline(Yh32, X, coords_h, d):
     return {"value": n_cpu / dt, "unit": "spots/s", "cores": cores, "kind": "port",
             "sample": f"{n_cpu} spots x {G} genes x {K} types (the headline's rows), gaussian/raw float64, {out['info']['n_iterations']} iterations, "
                       f"{dt:.1f} s wall (numpy/scipy stages single-threaded as in the reference, C/OpenMP BCD sweep on {cores} threads)"}
+
+
+def host_arrays_record(torch, n, G, K, d, sparse_genes, device):
+    """The literal drop-in (core/deconv.py:237-243, README.md:118-129: users hand numpy / scipy): host arrays in, numpy
+    proportions_ / beta_ out, the same 1M-spot jobs.  Never the headline `value` - PCIe dominates: the yardstick is the time ONE
+    pinned copy of the same bytes takes on this box's link (fdx_pinned_copy_rate); `ratio` = fit wall / that."""
+    import ctypes
+    from scipy import sparse as sp
+    from flashdeconv_amd import FlashDeconv, _lib
+    lib = _lib.load()
+    rate = {}
+    for name, to_dev in (("pinned_h2d_GBps", 1), ("pinned_d2h_GBps", 0)):
+        g = ctypes.c_double(0.0)
+        _lib.check(lib.fdx_pinned_copy_rate(1 << 30, to_dev, ctypes.byref(g)))
+        rate[name] = round(g.value, 2)
+    out = dict(rate)
+    out["note"] = ("wall of FlashDeconv.fit from host arrays to host arrays (numpy in, numpy out), 2 timed fits after 1; ideal_ms = bytes in / "
+                   "pinned H2D rate + bytes out / pinned D2H rate of this box; threaded staging through pinned buffers "
+                   "(csrc/host_transfer.cpp), integer counts narrowed to float32 on the way")
+    cases = {}
+
+    def run(label, Yh, X, ch, kw, in_bytes):
+        m = FlashDeconv(**kw)
+        m.fit(Yh, X, ch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            m.fit(Yh, X, ch)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        out_bytes = 2 * n * K * 8
+        ideal = (in_bytes / (rate["pinned_h2d_GBps"] * 1e9) + out_bytes / (rate["pinned_d2h_GBps"] * 1e9)) * 1e3
+        cases[label] = {"ms_per_fit": round(ms, 2), "in_GB": round(in_bytes / 1e9, 3), "out_GB": round(out_bytes / 1e9, 3),
+                        "ideal_ms": round(ideal, 2), "ratio": round(ms / ideal, 3), "effective_in_GBps": round(in_bytes / (ms * 1e-3) / 1e9, 2),
+                        "device_span_ms": round(m.timings_["span_ms"], 3), "n_iterations": m.info_["n_iterations"]}
+
+    Y, X, coords = gen_gaussian(torch, n, G, K, device, seed=0)
+    ch = _lib.tensor_to_host(coords)
+    Yh = _lib.tensor_to_host(Y)
+    del Y
+    torch.cuda.empty_cache()
+    run("dense_float32_raw", Yh, X, ch, dict(sketch_dim=d, preprocess="raw", n_hvg=G), Yh.nbytes)
+    Yh64 = Yh.astype(np.float64)
+    del Yh
+    run("dense_float64_raw", Yh64, X, ch, dict(sketch_dim=d, preprocess="raw", n_hvg=G), Yh64.nbytes)
+    del Yh64
+    Y, X, coords = gen_counts(torch, n, G, K, device, seed=0)
+    ch = _lib.tensor_to_host(coords)
+    Yi = _lib.tensor_to_host(Y.to(torch.int32))
+    del Y
+    torch.cuda.empty_cache()
+    run("dense_int32_log_cpm", Yi, X, ch, dict(sketch_dim=d, preprocess="log_cpm", n_hvg=G, max_iter=20), Yi.nbytes)
+    del Yi
+    Y, X, coords = gen_sparse(torch, n, sparse_genes, K, device, seed=0)
+    ch = _lib.tensor_to_host(coords)
+    Ys = sp.csr_matrix((_lib.tensor_to_host(Y.values()), _lib.tensor_to_host(Y.col_indices()), _lib.tensor_to_host(Y.crow_indices())),
+                       shape=(n, sparse_genes))
+    del Y
+    torch.cuda.empty_cache()
+    run("scipy_csr_float32_log_cpm", Ys, X, ch, dict(sketch_dim=d, preprocess="log_cpm", n_hvg=G, max_iter=20),
+        Ys.data.nbytes + Ys.indices.nbytes + Ys.indptr.nbytes)
+    out["cases"] = cases
+    return out
 
 
 def spawn_ranks(n_ranks, rendezvous_timeout_s=None):
@@ -627,6 +692,8 @@ def main():
         line["sparse_csr"] = results["sparse"]
     if "lattice" in results:
         line["lattice"] = results["lattice"]
+    if not a.no_host_arrays and a.config == 3 and a.family == "all":
+        line["host_arrays"] = host_arrays_record(torch, n, G, K, d, a.sparse_genes, device)
     if cpu_inputs is not None:
         line["cpu_baseline"] = cpu_baseline(*cpu_inputs, d)
     print(json.dumps(line))

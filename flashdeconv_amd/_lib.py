@@ -140,6 +140,9 @@ SIGNATURES = {
     "fdx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fdx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fdx_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "fdx_upload_convert_dev": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i64, p_double, c_void_p]),
+    "fdx_download_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fdx_pinned_copy_rate": (c_int, [c_size_t, c_i32, p_double]),
     "fdx_stream_sync": (c_int, [c_void_p]),
     "fdx_sketch": (c_int, [c_void_p, c_i32, c_i64, c_i32, p_i64, p_i32, p_double, c_i32, c_i32, p_double]),
     "fdx_prepare_csr_dev": (c_int, [ctypes.POINTER(CsrView), p_i32, c_i32, p_double, c_i32, p_i32, p_double, p_double, c_i32, c_i32,
@@ -279,7 +282,8 @@ def tensor_to_host(t):
     out = np.empty(tuple(t.shape), dtype=np.dtype(str(t.dtype).replace("torch.", "")))
     if out.nbytes:
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(load().fdx_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(t.data_ptr()), out.nbytes, st))
+        fn = load().fdx_download_dev if out.nbytes >= (32 << 20) else load().fdx_memcpy_d2h      # (large: threaded pinned ring)
+        check(fn(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(t.data_ptr()), out.nbytes, st))
     return out
 
 
@@ -302,6 +306,59 @@ def ptr_i32(a):
 FDX_F32, FDX_F64 = 0, 1
 PRE_RAW, PRE_LOG_CPM, PRE_LOG_CPM_SPARSE = 0, 1, 2
 PRE_F64_MATH = 0x100     # float32 storage of values the reference would transform in float64 (integer input)
+
+
+SRC_CODES = {"float32": 0, "float64": 1, "int8": 2, "uint8": 3, "bool": 3, "int16": 4, "uint16": 5, "int32": 6, "uint32": 7,
+             "int64": 8, "uint64": 9}
+_BIG = 32 << 20     # bytes from which a transfer goes through the threaded pinned ring (csrc/host_transfer.cpp)
+
+
+def upload_bytes(dev_ptr, arr):
+    """The bytes of a C-contiguous host array into HBM at dev_ptr; large arrays through the threaded pinned ring."""
+    if arr.nbytes >= _BIG and arr.nbytes % 4 == 0:
+        check(load().fdx_upload_convert_dev(dev_ptr, FDX_F32, arr.ctypes.data_as(c_void_p), SRC_CODES["float32"], arr.nbytes // 4, None, None))
+    elif arr.nbytes:
+        check(load().fdx_memcpy_h2d(dev_ptr, arr.ctypes.data_as(c_void_p), arr.nbytes, None))
+
+
+def download_bytes(arr, dev_ptr):
+    """HBM at dev_ptr into the C-contiguous host array `arr`; large arrays through the threaded pinned ring."""
+    if arr.nbytes >= _BIG:
+        check(load().fdx_download_dev(arr.ctypes.data_as(c_void_p), dev_ptr, arr.nbytes, None))
+    elif arr.nbytes:
+        check(load().fdx_memcpy_d2h(arr.ctypes.data_as(c_void_p), dev_ptr, arr.nbytes, None))
+
+
+def upload_matrix(Y):
+    """A dense host spot-by-gene matrix of any numeric dtype into HBM as the float32 / float64 matrix the kernels stream:
+    (device pointer - return it with fdx_free -, dtype code).  float32 / float64 pass through; integer counts (numpy promotes
+    them to float64 in the reference, core/deconv.py:190-191, 229) are narrowed to float32 WHILE they are staged when every
+    value is exactly representable (below 2**24: checked on the fly, no pass over the matrix on one host thread first), to
+    float64 otherwise.  Arithmetic on the device is float64 either way."""
+    lib = load()
+    Y = np.asarray(Y)
+    name = Y.dtype.name
+    if name not in SRC_CODES:                           # float16, longdouble, object ...: the reference's astype on the host
+        Y, name = Y.astype(np.float64), "float64"
+    if not Y.flags.c_contiguous:
+        Y = np.ascontiguousarray(Y)
+    count = int(Y.size)
+    integer = Y.dtype.kind in "iub"
+    order = [FDX_F64] if name == "float64" else [FDX_F32, FDX_F64] if integer and Y.dtype.itemsize > 2 else [FDX_F32]
+    for code in order:
+        ptr = c_void_p()
+        check(lib.fdx_malloc(ctypes.byref(ptr), max(count * (4 if code == FDX_F32 else 8), 8)))
+        try:
+            mx = c_double(0.0)
+            check(lib.fdx_upload_convert_dev(ptr, code, Y.ctypes.data_as(c_void_p), SRC_CODES[name], count, ctypes.byref(mx), None))
+        except Exception:
+            lib.fdx_free(ptr)
+            raise
+        if code == FDX_F32 and integer and mx.value >= float(1 << 24):
+            lib.fdx_free(ptr)                           # counts float32 cannot hold: once more, as float64
+            continue
+        return ptr, code
+    raise FdxError("upload_matrix: no destination type fits")
 
 
 def as_device_matrix(Y):
@@ -424,17 +481,23 @@ class CsrOnDevice:
             raise ValueError("CSR matrix has too many columns")
         indptr = np.ascontiguousarray(Y.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(Y.indices, dtype=np.int32)
-        data = np.ascontiguousarray(Y.data, dtype=cls._value_dtype(Y.data))
         self = cls()
         ptrs = []
-        for arr in (indptr, indices, data):
+        for arr in (indptr, indices):
             p = c_void_p()
             check(lib.fdx_malloc(ctypes.byref(p), max(arr.nbytes, 8)))
             self._owned.append(p)
-            if arr.nbytes:
-                check(lib.fdx_memcpy_h2d(p, arr.ctypes.data, arr.nbytes, None))
+            upload_bytes(p, arr)
             ptrs.append(p)
-        self._fill(ptrs[0].value, ptrs[1].value, ptrs[2].value, FDX_F32 if data.dtype == np.float32 else FDX_F64, n,
+        # the stored values like a dense matrix's: any numeric dtype, integer counts narrowed to float32 while they are staged
+        if Y.data.size:
+            pv, vcode = upload_matrix(Y.data)
+        else:
+            pv, vcode = c_void_p(), FDX_F32
+            check(lib.fdx_malloc(ctypes.byref(pv), 8))
+        self._owned.append(pv)
+        ptrs.append(pv)
+        self._fill(ptrs[0].value, ptrs[1].value, ptrs[2].value, vcode, n,
                    int(indptr[-1]) if len(indptr) else 0, G, sorted_rows=1 if Y.has_sorted_indices else 0)
         return self
 

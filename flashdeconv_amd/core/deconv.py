@@ -60,12 +60,20 @@ class _DeviceBuffer:
     def from_host(cls, arr):
         arr = np.ascontiguousarray(arr)
         buf = cls(arr.nbytes)
-        _lib.check(_lib.load().fdx_memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, None))
+        _lib.upload_bytes(buf.ptr, arr)
         return buf
 
-    def to_host(self, shape, dtype=np.float64):
-        out = np.empty(shape, dtype=dtype)
-        _lib.check(_lib.load().fdx_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None))
+    @classmethod
+    def adopt(cls, ptr, nbytes):
+        """Takes over a block handed out by the library (fdx_malloc inside _lib.upload_matrix)."""
+        buf = cls.__new__(cls)
+        buf.ptr, buf.nbytes = ptr, int(nbytes)
+        return buf
+
+    def to_host(self, shape, dtype=np.float64, out=None):
+        if out is None:
+            out = np.empty(shape, dtype=dtype)
+        _lib.download_bytes(out, self.ptr)
         return out
 
     def free(self):
@@ -272,10 +280,8 @@ class FlashDeconv:
                 y_sparse_rule = False
                 Yh = np.asarray(Y)
                 y_f64_math = Yh.dtype.kind in "iub"
-                Yh, y_code = _lib.as_device_matrix(Yh)
-                ybuf = _DeviceBuffer.from_host(Yh)
-                owned.append(ybuf)
-                y_ptr = ybuf.ptr
+                y_ptr, y_code = _lib.upload_matrix(Yh)         # threaded, staged, integer counts narrowed on the way
+                owned.append(_DeviceBuffer.adopt(y_ptr, Yh.size * (4 if y_code == _lib.FDX_F32 else 8)))
             csr_colsum = None
             # coordinates into HBM; with gene selection active (G > n_hvg) the spatial graph - which does not depend on the genes -
             # is queued FIRST: its ~0.7 ms of kernels then run under the gene statistics and the host's ranking of the G-vector
@@ -488,8 +494,11 @@ class FlashDeconv:
             if output == "torch":
                 self.beta_, self.proportions_ = beta_t, prop_t
             else:
-                self.beta_ = bbuf.to_host((n, K))
-                self.proportions_ = pbuf.to_host((n, K))
+                # A model that is fitted again and whose previous result arrays nobody else holds writes into them: releasing
+                # 240 MB arrays and faulting in fresh ones costs ~25 ms of munmap / page zeroing per fit at 1M x 30 - more than
+                # the device spends on the whole fit (unobservable: no other reference to the old arrays exists)
+                self.beta_ = bbuf.to_host((n, K), out=self._recyclable("beta_", (n, K)))
+                self.proportions_ = pbuf.to_host((n, K), out=self._recyclable("proportions_", (n, K)))
         finally:
             for b in owned:
                 b.free()
@@ -560,6 +569,14 @@ class FlashDeconv:
         log(f"  Iterations: {self.info_['n_iterations']}")
         log("FlashDeconv: Done!")
         return self
+
+    def _recyclable(self, name, shape):
+        """The model's previous result array `name` when it can take the new result in place: same shape, float64, owns its
+        memory, and referenced by nobody but the model (attribute + this frame's variable + getrefcount's argument)."""
+        old = getattr(self, name, None)
+        ok = (isinstance(old, np.ndarray) and old.shape == tuple(shape) and old.dtype == np.float64 and old.flags.c_contiguous
+              and old.flags.owndata and old.flags.writeable and sys.getrefcount(old) <= 3)
+        return old if ok else None
 
     def _graph_request(self, coords, coords_host):
         """(method, k, radius) of the graph build for this model's spatial_method (utils/graph.py:175-212)."""

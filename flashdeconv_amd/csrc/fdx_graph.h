@@ -74,6 +74,7 @@ struct fdx_graph {
     // per-peer offsets (n_ranks + 1 ints) the pack / unpack kernels of the native loop read.
     mutable bool shard_pending = false;
     mutable struct fdx_shard_build* keep_shard = nullptr;   // every buffer the queued kernels read
+    int shard_failed = 0;                                    // the queued second phase of a shard build failed (its return code): graph_meta_sync keeps failing
     mutable int shard_overflow = 0;                          // a bound of the deferred build was too small: rebuild by the stepwise path
     int shard_world = 0;
     long long shard_ell_cap = 0, shard_send_cap = 0, shard_halo_cap = 0;

@@ -2783,7 +2783,11 @@ int shard_queue_rest(fdx_graph* loc, hipStream_t st) {
 
 // takes over what the queued shard build left in the pinned block
 static int shard_meta_sync(fdx_graph* g) {
-    FDX_TRY(graph_shard_join(g));
+    // a failed second phase (helper-thread error, allocation failure in shard_queue_rest) stays failed: the join is a no-op the next
+    // time round, the meta event was never recorded and the pinned block is empty or absent - every later call must fail again
+    if (g->shard_failed) return fail(g->shard_failed, "graph: the queued shard build failed earlier; the graph is unusable");
+    if (const int jrc = graph_shard_join(g)) { g->shard_failed = jrc; return jrc; }
+    if (!g->meta_host || !g->meta_event) { g->shard_failed = FDX_ERR_INVALID; return fail(FDX_ERR_INVALID, "graph: the queued shard build left no counts"); }
     FDX_HIP(hipEventSynchronize(g->meta_event));
     g->shard_pending = false;
     if (g->keep_shard) { shard_build_drop(g->keep_shard); g->keep_shard = nullptr; }

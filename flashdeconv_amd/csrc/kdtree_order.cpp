@@ -63,11 +63,12 @@ struct KdTree {
 // afterwards (the index array is partitioned in place - disjoint ranges; the NUMBERING of the nodes differs from a serial build,
 // which nothing reads: queries follow the less / greater links).  The serial build was 130 of the 145 ms the tie remedy spent on
 // the host for a million lattice points: its top levels are cache-missing passes over all points.
+}  // namespace
 // Host threads this process may keep busy: the hardware's count, cut to the CPU bandwidth quota of the control group the process
 // runs in (containers: /sys/fs/cgroup/cpu.max or the v1 pair).  A burst on more threads than the quota covers gets the whole
 // process - its main thread included - throttled for the rest of the scheduler period: on a 256-thread host with a 16-CPU quota
 // the 128 query threads of one tie remedy cost the NEXT calls 10-30 ms stalls in unrelated places (measured; round 5).
-static unsigned host_cpu_budget() {
+unsigned host_cpu_budget() {
     static const unsigned budget = [] {
         unsigned hw = std::thread::hardware_concurrency();
         if (hw == 0) hw = 1;
@@ -88,6 +89,7 @@ static unsigned host_cpu_budget() {
     return budget;
 }
 
+namespace {
 static long long kd_fork_min() {
     static const long long v = getenv("FDX_KDTREE_FORK_MIN") ? std::max(1024, atoi(getenv("FDX_KDTREE_FORK_MIN"))) : 32768;
     return v;

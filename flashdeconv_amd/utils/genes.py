@@ -159,13 +159,11 @@ def _gene_moments(Y):
         finally:
             csr.free()
         return mean, var
-    Yh, code = _lib.as_device_matrix(Y)
     _lib.require_gpu()
     lib = _lib.load()
-    ptr = ctypes.c_void_p()
-    _lib.check(lib.fdx_malloc(ctypes.byref(ptr), Yh.nbytes))
+    Yh = np.asarray(Y)
+    ptr, code = _lib.upload_matrix(Yh)
     try:
-        _lib.check(lib.fdx_memcpy_h2d(ptr, Yh.ctypes.data, Yh.nbytes, None))
         return gene_moments_device(ptr, code, Yh.shape[0], Yh.shape[1], Yh.shape[1])
     finally:
         lib.fdx_free(ptr)

@@ -63,6 +63,30 @@ int fdx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes, void* stre
 int fdx_memset(void* dev_dst, int value, size_t bytes, void* stream);
 int fdx_stream_sync(void* stream);
 
+/* ---- caller (pageable) memory <-> HBM for the matrices a fit is handed (core/deconv.py:237-243: Y is an ndarray or a scipy
+ * matrix of any numeric dtype; core/deconv.py:190-191, 229: numpy promotes it to float64 on the host) --------------------------- */
+/* element type of a host source array */
+#define FDX_SRC_F32 0
+#define FDX_SRC_F64 1
+#define FDX_SRC_I8 2
+#define FDX_SRC_U8 3
+#define FDX_SRC_I16 4
+#define FDX_SRC_U16 5
+#define FDX_SRC_I32 6
+#define FDX_SRC_U32 7
+#define FDX_SRC_I64 8
+#define FDX_SRC_U64 9
+/* `count` elements of type src_code at src_host -> FDX_F32 / FDX_F64 elements at dst_dev: a team of host threads copies (integer
+ * counts: converts - the reference's astype on the host) chunk by chunk into recycled pinned buffers, every chunk's DMA queued as
+ * soon as it is filled.  max_abs_out (may be NULL): largest |value| of an integer source (is float32 exact?).  Returns with the
+ * data in HBM; work queued on `stream` before the call is waited for first. */
+int fdx_upload_convert_dev(void* dst_dev, int32_t dst_dtype, const void* src_host, int32_t src_code, int64_t count,
+                           double* max_abs_out, void* stream);
+/* bytes from HBM to caller memory through the same ring (beta_ / proportions_: core/deconv.py:395-398 are host arrays) */
+int fdx_download_dev(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+/* GB/s of ONE pinned copy of `bytes` over the box's link (to_device != 0: host to device) - the yardstick for the two above */
+int fdx_pinned_copy_rate(size_t bytes, int32_t to_device, double* gbps_out);
+
 /* ---- preprocess + sketch (replaces core/deconv.py:147-235 and core/sketching.py:160-206) ------------- */
 /* Y_sketch = f(Y) @ Omega for host arrays.  Y is (n, G) row-major of `dtype`; Omega (G x d) is given in CSC form
  * (col_ptr int64[d+1], gene_idx int32[nnz] ascending per column, weight f64[nnz]); `mode` is FDX_PRE_*.

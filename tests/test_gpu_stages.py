@@ -573,3 +573,39 @@ def test_device_ckdtree_queries_equal_the_host_restatement(case, monkeypatch):
         keep = np.setdiff1d(np.arange(n), rows)
         pk = rank[keep]
         assert np.array_equal(cn_d[pk], before[1].cpu().numpy()[pk]) and np.array_equal(nb_d[pk], before[0].cpu().numpy()[pk])
+
+
+def test_threaded_host_transfers_round_trip_every_source_dtype():
+    """csrc/host_transfer.cpp: caller (pageable) arrays of every numeric dtype into HBM as the float32 / float64 matrix the kernels
+    stream - bits of numpy's astype, several 16 MB chunks so that the ring, the thread team and the tails are all in play - and
+    back; integer counts above 2**24 take float64 (core/deconv.py:190-191, 229: the reference promotes on the host)."""
+    import ctypes
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(3)
+    n = 9_000_013                                            # odd length: the last chunk is partial
+    for dt in (np.float32, np.float64, np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64, np.bool_):
+        if np.dtype(dt).kind == "f":
+            a = rs.randn(n).astype(dt)
+        elif dt is np.bool_:
+            a = rs.rand(n) < 0.3
+        else:
+            a = rs.randint(0, 100, size=n).astype(dt)
+        ptr, code = _lib.upload_matrix(a)
+        want = a.astype(np.float64 if dt is np.float64 else np.float32)
+        assert code == (_lib.FDX_F64 if dt is np.float64 else _lib.FDX_F32)
+        got = np.empty_like(want)
+        _lib.download_bytes(got, ptr)
+        lib.fdx_free(ptr)
+        assert np.array_equal(got, want), dt
+    big = rs.randint(0, 100, size=n).astype(np.int64)
+    big[n // 2] = (1 << 24) + 1                              # float32 cannot hold it: the matrix goes up as float64
+    ptr, code = _lib.upload_matrix(big)
+    assert code == _lib.FDX_F64
+    got = np.empty(n, dtype=np.float64)
+    _lib.download_bytes(got, ptr)
+    lib.fdx_free(ptr)
+    assert np.array_equal(got, big.astype(np.float64))
+    g = ctypes.c_double(0.0)
+    _lib.check(lib.fdx_pinned_copy_rate(64 << 20, 1, ctypes.byref(g)))
+    assert g.value > 1.0
