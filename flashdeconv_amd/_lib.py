@@ -45,7 +45,7 @@ class FitParams(ctypes.Structure):
         ("sketch_dim", c_i32), ("mode_y", c_i32), ("mode_x", c_i32), ("graph_method", c_i32), ("k_neighbors", c_i32),
         ("lambda_auto", c_i32), ("max_iter", c_i32), ("verbose", c_i32),
         ("radius", c_double), ("lambda_spatial", c_double), ("rho_sparsity", c_double), ("tol", c_double),
-        ("stop_on_ties", c_i32), ("reserved", c_i32),
+        ("stop_on_ties", c_i32), ("reserved", c_i32), ("carry", c_void_p),
     ]
 
 
@@ -76,7 +76,7 @@ class FitInfo(ctypes.Structure):
         ("solve", SolveInfo), ("lambda_used", c_double), ("rho_effective", c_double), ("YtY", c_double), ("nnz", c_i64),
         ("graph_ms", c_double), ("sketch_ms", c_double), ("gram_ms", c_double), ("solve_ms", c_double),
         ("finish_ms", c_double), ("total_ms", c_double), ("prologue_ms", c_double), ("span_ms", c_double),
-        ("knn_ties", c_i64), ("status", c_i32), ("reserved", c_i32),
+        ("knn_ties", c_i64), ("status", c_i32), ("reserved", c_i32), ("carry", c_void_p),
     ]
 
 
@@ -109,6 +109,7 @@ SIGNATURES = {
     "fdx_fit_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, c_i32, p_i32, p_double, p_double, c_void_p,
                             c_i32, ctypes.POINTER(FitParams), ctypes.POINTER(c_void_p), c_void_p, c_void_p, p_double,
                             p_double, ctypes.POINTER(FitInfo), c_void_p]),
+    "fdx_fit_carry_free": (c_int, [c_void_p]),
     "fdx_graph_build_dev": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i32, c_double, c_void_p, ctypes.POINTER(c_void_p)]),
     "fdx_graph_perm_dev": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fdx_side_stream": (c_int, [ctypes.POINTER(c_void_p)]),

@@ -473,18 +473,26 @@ class FlashDeconv:
             run_fit()
             ties_remedy_ms = 0.0
             if info.status == _lib.FIT_TIES:
-                # ties under "auto": the reference's neighbour choice, then the fit proper (one solve; the sketch is queued again)
+                # ties under "auto": the reference's neighbour choice, then the fit proper.  The stopped call's sketch -> H stage is
+                # still running on the device while the host builds the tree; the second call takes it over (info.carry) - the
+                # rebuilt graph keeps the spot order.  The first graph stays alive until then: the running kernel reads its order.
                 n_ties = int(info.knn_ties)
                 log(f"k-NN ties on {n_ties} of {n} spots: rebuilding the graph on the reference's (cKDTree) neighbour choice")
-                self._graph.close()
+                stale, carry = self._graph, info.carry
                 self._graph = None
-                self._graph = reference_tie_graph(c_ptr, coords_host, n, dim, int(self.k_neighbors))
-                gh = ctypes.c_void_p(self._graph.handle.value)
-                prm.stop_on_ties = 0
-                ties_resolved_here = True
-                ties_remedy_ms = (time.perf_counter() - t_call) * 1e3
-                t_call = time.perf_counter()
-                run_fit()
+                try:
+                    self._graph = reference_tie_graph(c_ptr, coords_host, n, dim, int(self.k_neighbors))
+                    gh = ctypes.c_void_p(self._graph.handle.value)
+                    prm.stop_on_ties = 0
+                    prm.carry, carry = carry, None             # consumed by the call
+                    ties_resolved_here = True
+                    ties_remedy_ms = (time.perf_counter() - t_call) * 1e3
+                    t_call = time.perf_counter()
+                    run_fit()
+                finally:
+                    if carry:
+                        lib.fdx_fit_carry_free(carry)
+                    stale.close()
             else:
                 ties_resolved_here = False
             t_ret = time.perf_counter()

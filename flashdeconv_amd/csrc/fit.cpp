@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "fdx_graph.h"
@@ -261,6 +262,29 @@ extern "C" int fdx_column_sums_dev(const void* Y_dev, int32_t dtype, int64_t n, 
     return 0;
 }
 
+// What a fit that stopped on k-NN ties leaves behind for the fit that follows on the rebuilt graph: the sketch -> H stage (the
+// rebuilt graph keeps the Morton order, so H's columns are where the second fit wants them) with everything the still-running
+// kernel reads, and an event behind it.  The stopped call returns at once instead of draining ~3 ms of sketch that the tie remedy's
+// host work (a kd-tree build of ~20 ms) then runs beside.
+struct fdx_fit_carry {
+    fdx::DevBuf dH, dRowSq, dXs;
+    fdx::CsrSelection csr_sel;
+    std::shared_ptr<fdx::SketchPlan> plan_y;
+    hipEvent_t done = nullptr;
+    long long n = 0, ld = 0;
+    int K = 0, KP = 0, d = 0, G = 0, mode_y = 0;
+    const void* y_id = nullptr;
+    double sketch_ms = 0.0, gram_ms = 0.0;
+    ~fdx_fit_carry() {
+        if (done) { (void)hipEventSynchronize(done); (void)hipEventDestroy(done); }
+    }
+};
+
+extern "C" int fdx_fit_carry_free(void* carry) {
+    delete static_cast<fdx_fit_carry*>(carry);
+    return 0;
+}
+
 namespace {
 
 // Where the spot rows come from: a dense (n, G) device matrix, or a CSR matrix over G_all columns of which gene_idx
@@ -390,10 +414,19 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     SketchPlan plan_none;
     const SketchPlan& plan_y = plan_y_p ? *plan_y_p : plan_none;
 
+    // ---- a carry: the sketch -> H stage of a call that stopped on ties for these inputs (the rebuilt graph keeps the spot order)
+    std::unique_ptr<fdx_fit_carry> carry_in(static_cast<fdx_fit_carry*>(prm_in->carry));
+    if (carry_in) {
+        FDX_REQUIRE(carry_in->n == n && carry_in->ld == ld && carry_in->K == K && carry_in->KP == KP && carry_in->d == d &&
+                        carry_in->G == G && carry_in->mode_y == prm->mode_y && carry_in->y_id == (ysrc.csr ? (const void*)ysrc.csr->data : Y_dev),
+                    "fdx_fit_dev: the carry belongs to a different problem");
+    }
     // ---- Y_sketch in solver order, chunked, contracted into H (K, ld) as it is produced
-    FDX_TRY(dH.alloc((size_t)KP * ld * sizeof(double)));
-    if (KP != K) FDX_HIP(hipMemsetAsync(dH.as<double>() + (size_t)K * ld, 0, (size_t)(KP - K) * ld * sizeof(double), st));   // pad types
-    FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
+    if (!carry_in) {
+        FDX_TRY(dH.alloc((size_t)KP * ld * sizeof(double)));
+        if (KP != K) FDX_HIP(hipMemsetAsync(dH.as<double>() + (size_t)K * ld, 0, (size_t)(KP - K) * ld * sizeof(double), st));   // pad types
+        FDX_TRY(dRowSq.alloc((size_t)n * sizeof(double)));
+    }
     FDX_TRY(dSum.alloc(sizeof(double)));
     // Y_sketch is produced and consumed in chunks of 256k rows (1 GB at d = 512): measured on MI355X, smaller chunks
     // (down to Infinity-Cache size) under-fill the chip and are slower, larger ones gain nothing.
@@ -401,8 +434,8 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     if (const char* e = getenv("FDX_FIT_CHUNK")) chunk_rows = std::max<long long>(64, atoll(e));
     const long long chunk = std::min<long long>(n, chunk_rows);
     const bool fused = csr_fused || (!ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, prm->mode_y, plan_y.dev()));
-    if (!fused) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
-    FDX_TRY(solver_zero_pad(dH.as<double>(), ld, n, K, st));   // columns of real spots are all written by the sketch -> H stage
+    if (!fused && !carry_in) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
+    if (!carry_in) FDX_TRY(solver_zero_pad(dH.as<double>(), ld, n, K, st));   // columns of real spots are all written by the sketch -> H stage
     const int* row_map = g->identity_order ? nullptr : g->perm.as<int>();
     double sketch_ms = 0.0, gram_ms = 0.0;
     hipEvent_t eS0 = nullptr, eS1 = nullptr;     // around the sketch -> H stage; read at the end of the fit, no wait here
@@ -411,7 +444,14 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     FDX_HIP(hipEventCreate(&eS1));
     fit_trace_host("side-stream preamble queued, buffers allocated");
     FDX_HIP(hipEventRecord(eS0, st));            // the prologue (graph chain, X-side preamble) ends here
-    if (fused) {   // one kernel, no Y_sketch: rows -> LDS tile -> bucket sums -> MFMA contraction -> H  (tile_kernels.cpp)
+    if (carry_in) {                               // H and the rows' squared norms as the stopped call left them, behind its event
+        FDX_HIP(hipStreamWaitEvent(st, carry_in->done, 0));
+        dH.take(carry_in->dH);
+        dRowSq.take(carry_in->dRowSq);
+        sketch_ms = carry_in->sketch_ms;
+        gram_ms = carry_in->gram_ms;
+        FDX_HIP(hipEventRecord(eS1, st));
+    } else if (fused) {   // one kernel, no Y_sketch: rows -> LDS tile -> bucket sums -> MFMA contraction -> H  (tile_kernels.cpp)
         if (csr_fused)     // CSR rows -> LDS accumulators -> MFMA contraction -> H  (csr_kernels.cpp)
             FDX_TRY(launch_sketch_csr_contract((const long long*)ysrc.csr->indptr, ysrc.csr->indices, ysrc.csr->data, y_dtype,
                                                row_map, n, d, prm->mode_y, csr_sel, dXs.as<double>(), K, dH.as<double>(), ld,
@@ -459,6 +499,37 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         for (auto& e : ev) (void)hipEventDestroy(e);
         FDX_HIP(hipEventRecord(eS1, st));
     }
+    // ---- the graph's counts (a build that was only queued has long finished behind the sketch launch).  Ties under stop_on_ties: the
+    // caller wants the reference's choice among equidistant neighbours - nothing is solved on this graph, and the sketch -> H stage
+    // that is already running goes to the caller as a carry for the fit on the rebuilt graph (tie-free inputs never pay for the
+    // question; lattices no longer pay a second sketch and the wait for the first)
+    if (!prm->verbose) FDX_HIP(hipEventSynchronize(evG));
+    FDX_TRY(graph_meta_sync(g));
+    info->knn_ties = g->knn_ties;
+    info->nnz = g->nnz;
+    if (prm->stop_on_ties && g->knn_ties > 0) {
+        info->status = FDX_FIT_TIES;
+        if (carry_in) return 0;                   // (a carry on a graph that still has ties: dropped, drained by the guards)
+        auto carry = std::make_unique<fdx_fit_carry>();
+        FDX_HIP(hipEventCreateWithFlags(&carry->done, hipEventDisableTiming));
+        FDX_HIP(hipEventRecord(carry->done, st));
+        carry->dH.take(dH);
+        carry->dRowSq.take(dRowSq);
+        carry->dXs.take(dXs);                     // (read by the fused kernels; the X side is cheap to redo)
+        carry->csr_sel.slots.take(csr_sel.slots); carry->csr_sel.bits.take(csr_sel.bits); carry->csr_sel.words.take(csr_sel.words);
+        carry->csr_sel.w.take(csr_sel.w); carry->csr_sel.b.take(csr_sel.b);
+        carry->plan_y = plan_y_p;
+        carry->n = n; carry->ld = ld; carry->K = K; carry->KP = KP; carry->d = d; carry->G = G; carry->mode_y = prm->mode_y;
+        carry->y_id = ysrc.csr ? (const void*)ysrc.csr->data : Y_dev;
+        float t_sk = 0.f;
+        (void)t_sk;
+        carry->sketch_ms = 0.0;                   // (the stage's events belong to the stopped call: the second fit reports the stage as carried)
+        carry->gram_ms = gram_ms;
+        if (!fused) FDX_HIP(hipStreamSynchronize(st));   // the chunked path's Y_sketch buffer goes back to the pool with this call
+        info->carry = carry.release();
+        abort_drain.armed = false;                // everything the running kernel reads lives in the carry (Y and the graph: the caller's)
+        return 0;
+    }
     // YtY (core/solver.py:348) only enters the objective: its two small reductions and the read-back go to the side stream (behind the
     // sketch, beside the first sweep) instead of standing between the sketch and the sweeps; the verbose trace needs it at once
     double* YtY_h = (double*)pinned_scratch(1, sizeof(double));   // pinned: the host runs ahead and queues the solve behind the sketch
@@ -481,23 +552,11 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
         FDX_HIP(hipEventRecord(evY, ys));
     }
     if (prm->verbose) FDX_HIP(hipStreamSynchronize(st));
-    else FDX_HIP(hipEventSynchronize(evG));
     fit_trace_host("sketch queued, XtX on the host");
     tm.mark();  // 2
     double diag_mean = 0.0;
     for (int k = 0; k < K; ++k) diag_mean += Gh[(size_t)k * K + k];
     diag_mean /= (double)K;
-    // a graph whose build was only queued (graph_kernels.cpp, deferred completion) has long finished behind the sketch: take over
-    // its counts before lambda and the sweep launches need them
-    FDX_TRY(graph_meta_sync(g));
-    info->knn_ties = g->knn_ties;
-    info->nnz = g->nnz;
-    if (prm->stop_on_ties && g->knn_ties > 0) {
-        // the caller wants the reference's choice among equidistant neighbours: nothing is solved on this graph (the sketch that
-        // is already queued is waited for by the drains below and dropped - tie-free inputs never pay for the question)
-        info->status = FDX_FIT_TIES;
-        return 0;
-    }
     // auto_tune_lambda (core/spatial.py:181-190): alpha * mean(diag XtX) / max(mean degree, 1), alpha = 0.005
     double lambda = prm->lambda_spatial;
     if (prm->lambda_auto) {

@@ -237,6 +237,8 @@ typedef struct fdx_fit_params {
     int32_t stop_on_ties;    /* k-NN graphs: 1 = return with info->status = FDX_FIT_TIES before the solve when some spot's k-th neighbour is
                                 tied (the caller then rebuilds the graph on the reference's choice, utils/graph.py:60-63, and calls again) */
     int32_t reserved;
+    void* carry;             /* NULL, or the info->carry of a call that stopped on ties for the SAME inputs: its sketch -> H stage is taken
+                                over instead of being run again (the rebuilt graph keeps the spot order); consumed by the call */
 } fdx_fit_params;
 #define FDX_FIT_TIES 3
 
@@ -253,9 +255,13 @@ typedef struct fdx_fit_info {
      * prologue_ms + (sketch stage) + solve_ms + finish_ms = span_ms up to event granularity */
     double prologue_ms, span_ms;
     int64_t knn_ties;        /* spots whose k-th and (k+1)-th nearest neighbours are exactly equidistant (k-NN graphs built on the device) */
-    int32_t status;          /* 0: fitted; FDX_FIT_TIES: stopped before the solve (stop_on_ties) - nothing but knn_ties / nnz is valid */
+    int32_t status;          /* 0: fitted; FDX_FIT_TIES: stopped before the solve (stop_on_ties) - nothing but knn_ties / nnz / carry is valid */
     int32_t reserved;
+    void* carry;             /* FDX_FIT_TIES: the stopped call's sketch -> H stage, still running on the device when the call returns - hand
+                                it to the next fit of the same inputs (params->carry) or release it with fdx_fit_carry_free */
 } fdx_fit_info;
+/* Releases a carry that no fit consumed (waits for the work it holds). */
+int fdx_fit_carry_free(void* carry);
 
 /* Device-resident fit.  Y_dev: (n, G) matrix of `y_dtype` on the device, row stride ldy elements.  X: HOST (K, G)
  * f64 raw signatures (selected genes).  Omega as per-gene tables on the HOST: bucket int32[G] and the two weight

@@ -345,7 +345,7 @@ def test_bench_sweep_chunk_mirrors_the_kernel_table():
 
 
 @pytest.mark.parametrize("case", ["square", "square_scaled", "hex", "cube3d", "random2d", "random3d", "line", "duplicates",
-                                  "square_shuffled", "rect_large", "square_big", "random_big"])
+                                  "square_shuffled", "rect_large", "square_big", "random_big", "square_huge"])
 def test_ckdtree_order_restatement_matches_scipy(case):
     """fdx_ckdtree_knn (csrc/kdtree_order.cpp) is a host restatement of scipy.spatial.cKDTree's build and k-nearest query
     ORDER - what decides the reference's neighbour graph when distances tie exactly (flashdeconv/utils/graph.py:60-63).
@@ -370,6 +370,7 @@ def test_ckdtree_order_restatement_matches_scipy(case):
         # above 32768 points the subtrees are built on threads, above 4096 per node on contiguous (coordinate, index) pairs
         "square_big": (np.stack(np.meshgrid(np.arange(310.0), np.arange(300.0), indexing="ij"), -1).reshape(-1, 2), 7),
         "random_big": (np.round(rs.rand(70000, 2) * 40.0, 1), 7),          # many equal coordinates, a few coincident points
+        "square_huge": (np.stack(np.meshgrid(np.arange(640.0), np.arange(500.0), indexing="ij"), -1).reshape(-1, 2), 7),
     }[case]
     coords = np.ascontiguousarray(coords, dtype=np.float64)
     n, dim = coords.shape
