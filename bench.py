@@ -58,6 +58,9 @@ def parse():
                     help="--gpus N > 1 started from a bare shell: seconds after which a job whose ranks have produced no result "
                          "is ended (default 900)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not spawn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this run; "
+                         "the committed profile's figure is reported instead")
     ap.add_argument("--no-host-arrays", action="store_true",
                     help="skip the host_arrays record (numpy / scipy in, numpy out: the literal drop-in, PCIe included)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
@@ -173,6 +176,66 @@ def pmc_traffic(kernel, shape):
         return None
 
 
+def live_pmc_traffic(a, timeout_s=240):
+    """HBM bytes per launch of every libfdx kernel of THIS build on THIS box: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (counters in passes of their own, as the pool requires; the program itself
+    after `--`), one fit per family; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half of a wide
+    coalesced read - MI355X_MICROARCH.md, HBM section), mean over the launches that did work.  {} when rocprofv3 is not there
+    or a pass fails (the committed profile's figure is reported then)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {}
+    vals = {}
+    work = tempfile.mkdtemp(prefix="fdx_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--family", a.family, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-host-arrays", "--no-live-pmc",
+                   "--spots", str(a.spots), "--genes", str(a.genes), "--types", str(a.types), "--sketch-dim", str(a.sketch_dim),
+                   "--sparse-genes", str(a.sparse_genes)]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s, check=True)
+            except (subprocess.SubprocessError, OSError):
+                return {}
+            acc = defaultdict(list)
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") == ctr and "fdx::" in r.get("Kernel_Name", ""):
+                            acc[r["Kernel_Name"].replace("void ", "").split("(")[0]].append(float(r["Counter_Value"]))
+            vals[ctr] = acc
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    res = {}
+    for k, fv in vals.get("FETCH_SIZE", {}).items():
+        wv = vals.get("WRITE_SIZE", {}).get(k, [])
+        big = max(fv) if fv else 0.0
+        keep = [i for i, v in enumerate(fv) if v > 0.1 * big] if big else list(range(len(fv)))    # no-op launches (sweeps behind convergence) out
+        f_mean = sum(fv[i] for i in keep) / max(len(keep), 1)
+        w_keep = [wv[i] for i in keep if i < len(wv)]
+        res[k] = int((2.0 * f_mean + sum(w_keep) / max(len(w_keep), 1)) * 1024)
+    return res
+
+
+def apply_live_traffic(roof, live):
+    """roofline.traffic of a record from this run's counter passes when they hold its kernel."""
+    if not roof or not live:
+        return
+    k = roof.get("kernel", "")
+    hit = live.get(k) or next((v for name, v in live.items() if name.startswith(k) or k.startswith(name)), None)
+    if hit:
+        roof["traffic"] = int(hit)
+        roof["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by bench.py, (2 x FETCH + WRITE) x 1024 per launch"
+
+
 def sweep_chunk(K):
     """Cell types per chunk of the tiled sweep: mirror of sweep_chunk() in csrc/bcd_sweep_inst.cpp (second template argument
     of bcd_sweep_tiled_kernel; tests/test_host.py checks the two against each other)."""
@@ -188,7 +251,7 @@ def sweep_kernel_name(K):
     return "fdx::bcd_sweep_tiled_kernel<%d, %d, false, true, false>" % (K, sweep_chunk(K))    # <K, chunk, objective variant, quadratic term inside, constant start vector>
 
 
-def sketch_kernel_name(mode, K, d=512):
+def sketch_kernel_name(mode, K, d=512, dtype="float"):
     """Kernel that serves the sketch -> H stage of the bench shapes (csrc/tile_kernels.cpp: tile_cfg): template arguments
     <input type, preprocess, consumer waves, loader waves, groups per wave, type tiles, A operands from L2, log1p class
     (2 = float32-class for float32 rows), weights by gene in the stage buffers (wide raw), flat schedule>."""
@@ -203,8 +266,8 @@ def sketch_kernel_name(mode, K, d=512):
     if K > 32 or d > 4 * nwc * jw:                 # wide form (raw: weights by gene in a ring of three stage buffers)
         (nwc, nwl, jw), tt, avl2 = ((12, 4, 22) if mode == 0 else (8, 0, 32)), 4, True
         wg = mode == 0 and not os.environ.get("FDX_TILE_NO_WG")
-    return "fdx::tile_sketch_kernel<float, %d, %d, %d, %d, %d, %s, %d, %s, %s>" % (
-        mode, nwc, nwl, jw, tt, "true" if avl2 else "false", logv, "true" if wg else "false",
+    return "fdx::tile_sketch_kernel<%s, %d, %d, %d, %d, %d, %s, %d, %s, %s>" % (
+        dtype, mode, nwc, nwl, jw, tt, "true" if avl2 else "false", logv, "true" if wg else "false",
         "true" if (wg and os.environ.get("FDX_TILE_FLAT")) else "false")
 
 
@@ -562,6 +625,7 @@ def main():
     n, G, K, d = a.spots, a.genes, a.types, a.sketch_dim
     results = {}
     cpu_inputs = None
+    y_f64 = None
     fams = {"both": ["gaussian", "counts"], "all": ["gaussian", "counts", "sparse", "lattice"]}.get(a.family, [a.family])
     for fam in fams:
         if fam == "lattice":
@@ -612,7 +676,7 @@ def main():
                 "n_iterations": model.info_["n_iterations"], "converged": model.info_["converged"],
                 "stage_ms": stage_record(stage, ms_step),
                 "sketch_GBps": round(csr_gbs, 1),
-                "roofline": {"bound": "hbm", "kernel": "fdx::sketch_csr_contract_kernel<float, 2, 2, 2>" if stage["gram_ms"] == 0.0
+                "roofline": {"bound": "hbm", "kernel": "fdx::sketch_csr_contract_kernel<float, 2, 2, 2, 24, 12>" if stage["gram_ms"] == 0.0
                              else "fdx::sketch_csr_kernel<float, 2>", "achieved": round(csr_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(csr_gbs / HBM_PEAK_GBS, 4),
                              "traffic": pmc_traffic("fdx::sketch_csr_contract_kernel", (n, G, K, d)) if stage["gram_ms"] == 0.0 else None,
@@ -659,6 +723,21 @@ def main():
                          "alg_bytes_per_launch": int(bytes_launch), "ms_per_launch": round(ms_launch, 4)},
             "steps": steps,
         }
+        if fam == "gaussian" and a.config == 3 and a.family == "all":
+            # the same job with Y stored float64 in HBM - the reference's own dtype (core/deconv.py:229): twice the one-off read
+            Y64 = Y.double()
+            m64, dt64, st64 = run_family(torch, kw, Y64, X, coords, aux_steps(a), a.warmup, barrier)
+            ms64 = dt64 / aux_steps(a) * 1e3
+            g64 = n * G * 8 / (st64["sketch_ms"] * 1e-3) / 1e9
+            y_f64 = {"value": n / (ms64 * 1e-3), "unit": "spots/s", "ms_per_step": ms64, "steps": aux_steps(a),
+                     "step_ms_min_max": st64.pop("step_ms_min_max"), "cold_ms": round(st64["cold_ms"], 3),
+                     "n_iterations": m64.info_["n_iterations"], "converged": m64.info_["converged"], "workload": "same job, Y float64 in HBM (16 GB)",
+                     "roofline": {"bound": "hbm", "kernel": "fdx::tile_sketch_kernel<double, ...>", "achieved": round(g64, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(g64 / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "alg_bytes_per_launch": int(n * G * 8), "ms_per_launch": round(st64["sketch_ms"], 4)},
+                     "stage_ms": stage_record(st64, ms64)}
+            del Y64, m64
+            torch.cuda.empty_cache()
         if fam == "gaussian" and not a.no_cpu_baseline and a.config == 3:
             # the CPU baseline runs on these very rows, at the end (outside every timed region): a host copy through pinned staging
             from flashdeconv_amd import _lib as _fdx_lib
@@ -688,10 +767,18 @@ def main():
                               "step_ms_min_max": c["step_ms_min_max"], "cold_ms": c["cold_ms"],
                               "n_iterations": c["n_iterations"], "converged": c["converged"], "roofline": c["roofline"],
                               "stage_ms": c["stage_ms"], "workload": "same shape, count-like / log_cpm family (runs max_iter)"}
+    if y_f64 is not None:
+        line["y_f64"] = y_f64
     if "sparse" in results:
         line["sparse_csr"] = results["sparse"]
     if "lattice" in results:
         line["lattice"] = results["lattice"]
+    if not a.no_live_pmc and a.config == 3:
+        live = live_pmc_traffic(a)
+        apply_live_traffic(line.get("roofline"), live)
+        for key in ("count_like", "sparse_csr"):
+            if key in line:
+                apply_live_traffic(line[key].get("roofline"), live)
     if not a.no_host_arrays and a.config == 3 and a.family == "all":
         line["host_arrays"] = host_arrays_record(torch, n, G, K, d, a.sparse_genes, device)
     if cpu_inputs is not None:
