@@ -54,6 +54,9 @@ def parse():
                     help="the WHOLE configs[3] job (1M x 2000 x 30) or, with --config 5, configs[4] (10M x 5000 x 50; --spots overrides) "
                          "with this many virtual ranks on one GPU (tools/virtual_ranks.py): per-rank critical path, each rank timed "
                          "alone, the unsharded T1 and the projected speed-up (no RCCL wire time)")
+    ap.add_argument("--vr-family", choices=["gaussian", "counts"], default="gaussian",
+                    help="--virtual-ranks: gaussian = the metric's job (raw, converges in 7 sweeps); counts = the count-like family's cost "
+                         "profile (log_cpm sketch, all 100 sweeps)")
     ap.add_argument("--rendezvous-timeout", type=float, default=None,
                     help="--gpus N > 1 started from a bare shell: seconds after which a job whose ranks have produced no result "
                          "is ended (default 900)")
@@ -189,7 +192,10 @@ def live_pmc_traffic(a, timeout_s=240):
     import tempfile
     from collections import defaultdict
     exe = shutil.which("rocprofv3")
-    if exe is None:
+    # not from inside a profiled run: the outer profiler's preloaded library would initialise the GPU in the child launcher, whose
+    # exec of the program the box then refuses (tools/profile_round.sh passes --no-live-pmc as well)
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if exe is None or profiled:
         return {}
     vals = {}
     work = tempfile.mkdtemp(prefix="fdx_pmc_", dir="/tmp")
@@ -530,7 +536,8 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             keep = {}
-            _, _, info = vr.run_config5(torch, W, n=n, G=G, K=K, d=d, seed=11, alone=True, keep=keep)
+            vr_kw = dict(pre="log_cpm", tol=1e-300, max_iter=100) if a.vr_family == "counts" else {}
+            _, _, info = vr.run_config5(torch, W, n=n, G=G, K=K, d=d, seed=11, alone=True, keep=keep, **vr_kw)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
             coords, X = keep["coords"], keep["X"]
@@ -550,7 +557,11 @@ def main():
             step = 1 << 20
             for r0 in range(0, n, step):
                 Y[r0:min(n, r0 + step)] = vr.gaussian_rows(torch, X32, r0, min(n, r0 + step), 11)
-            model = FlashDeconv(sketch_dim=d, preprocess="raw", n_hvg=G)
+            if a.vr_family == "counts":
+                Y.abs_()
+                model = FlashDeconv(sketch_dim=d, preprocess="log_cpm", n_hvg=G, max_iter=100, tol=1e-300)
+            else:
+                model = FlashDeconv(sketch_dim=d, preprocess="raw", n_hvg=G)
             model.fit(Y, X, coords, output="torch")
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -561,7 +572,8 @@ def main():
             t1_ms = (time.perf_counter() - t0) / n_t1 * 1e3
             t1_iters = model.info_["n_iterations"]
             del Y, model
-        line = {"metric": f"projected strong scaling of {'configs[4] (10M x 5000 x 50, d 1024)' if big else 'configs[3] (1M x 2000 x 30, d 512)'}"
+        line = {"family": a.vr_family,
+                "metric": f"projected strong scaling of {'configs[4] (10M x 5000 x 50, d 1024)' if big else 'configs[3] (1M x 2000 x 30, d 512)'}"
                           f" over {W} ranks: per-rank critical path on one GPU, each rank timed alone",
                 "n_gpus": 1, "virtual_ranks": W, "spots": n, "n_iterations": info["n_iterations"][0], "t1_n_iterations": t1_iters,
                 "knn_ties": info["knn_ties"], "nnz": info["nnz"], "n_halo": info["n_halo"], "plan_route": t.get("plan_route"),

@@ -7,9 +7,9 @@ if [ $# -gt 0 ]; then pmc_args="$*"; else pmc_args="--family all"; fi   # all: t
 out=/root/repo/gpurun_out/${tag}_prof
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$out/bench_trace.json" 2> "$out/bench_trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline $pmc_args > "$out/bench_fetch.json" 2> "$out/bench_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline $pmc_args > "$out/bench_write.json" 2> "$out/bench_write.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-pmc --no-host-arrays "$@" > "$out/bench_trace.json" 2> "$out/bench_trace.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-live-pmc --no-host-arrays $pmc_args > "$out/bench_fetch.json" 2> "$out/bench_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-live-pmc --no-host-arrays $pmc_args > "$out/bench_write.json" 2> "$out/bench_write.err"
 # keep what the summaries need: stats + counter csvs (the full kernel traces are large)
 find "$out" -name "*kernel_trace.csv" -delete
 find "$out" -name "*agent_info.csv" -delete

@@ -432,7 +432,7 @@ def alone_pipelined(torch, coords, ranks, bounds, X, make_rows, d, mode, K, lam,
         torch.cuda.empty_cache()          # a 10M-spot job's shard is 25-100 GB: hand it back before the next rank's is made
 
 
-def driver_alone(torch, coords, ranks, X, make_rows, d, K, nnz_total, n_iter, times, reps=None, knn_ties="auto"):
+def driver_alone(torch, coords, ranks, X, make_rows, d, K, nnz_total, n_iter, times, reps=None, knn_ties="auto", pre="raw"):
     """Every rank's share through the REAL driver - ShardedFlashDeconv.plan + fit_transform, Python included - alone on the GPU:
     a LoopbackComm stands in for the process group (its all-reduce of the plan counts returns the job's totals, the native loop
     runs over the loopback transport for the job's iteration count).  One interval per rank, host clock, device idle before and
@@ -447,7 +447,7 @@ def driver_alone(torch, coords, ranks, X, make_rows, d, K, nnz_total, n_iter, ti
         dev = S["H"].device
         Y = make_rows(S["lo"], S["hi"])
         totals = {(3,): torch.tensor([float(nnz_total), 0.0, 0.0], dtype=torch.float64, device=dev)}
-        model = ShardedFlashDeconv(sketch_dim=d, preprocess="raw", n_hvg=G, max_iter=n_iter, tol=1e-300, knn_ties=knn_ties,
+        model = ShardedFlashDeconv(sketch_dim=d, preprocess=pre, n_hvg=G, max_iter=n_iter, tol=1e-300, knn_ties=knn_ties,
                                    comm=LoopbackComm(r, W, totals))
         best = None
         for rep in range(reps):
@@ -483,7 +483,8 @@ def assemble(torch, ranks, results, n, K, want_props=True):
     return beta, prop
 
 
-def run_config5(torch, W, n=10_000_000, G=5000, K=50, d=1024, seed=11, max_iter=100, tol=1e-4, coords=None, keep=None, alone=False):
+def run_config5(torch, W, n=10_000_000, G=5000, K=50, d=1024, seed=11, max_iter=100, tol=1e-4, coords=None, keep=None, alone=False,
+                pre="raw"):
     """The whole configs[4] job (or, with other n / G / K / d, configs[3]) with W virtual ranks; returns (beta, proportions, info
     dict with per-rank stage times).  alone=True: also every rank's iteration loop and finish timed alone (loopback transport) and
     `per_rank_critical_path_ms` = plan (lists + band + symmetrise) + localize + prepare + solve + finish of each rank."""
@@ -503,7 +504,13 @@ def run_config5(torch, W, n=10_000_000, G=5000, K=50, d=1024, seed=11, max_iter=
         torch.cuda.synchronize()
         times["coords_ms"] = (time.perf_counter() - t0) * 1e3
     ranks, nnz, ties, bounds = virtual_plan(torch, coords, W, 6, times)
-    yty = virtual_prepare(torch, ranks, X, lambda lo, hi: gaussian_rows(torch, X32, lo, hi, seed), d, _lib.PRE_RAW, 0, times)
+    # pre="log_cpm" (the count-like family's cost profile: the float32-class log1p sketch, every sweep of max_iter when tol is
+    # tiny): the same rows made non-negative - what the kernels cost does not depend on the values
+    mode = _lib.PRE_LOG_CPM if pre == "log_cpm" else _lib.PRE_RAW
+    rows = (lambda lo, hi: gaussian_rows(torch, X32, lo, hi, seed).abs_()) if pre == "log_cpm" else (lambda lo, hi: gaussian_rows(torch, X32, lo, hi, seed))
+    if pre == "log_cpm":
+        X = np.abs(X)
+    yty = virtual_prepare(torch, ranks, X, rows, d, mode, 0, times)
     gmean = diag_mean(ranks[0]["XtX_h"])
     lam = 0.005 * gmean / max(nnz / n, 1.0)                      # core/spatial.py:181-190 (lambda_spatial="auto")
     rho_eff = 0.01 * gmean                                       # core/solver.py:359-360
@@ -522,11 +529,11 @@ def run_config5(torch, W, n=10_000_000, G=5000, K=50, d=1024, seed=11, max_iter=
         times["per_rank_critical_path_ms"] = times["per_rank_stage_sum_ms"]
         if times.get("plan_route") == "pipeline":
             # ... and the rank's share timed as ONE interval, queued as the driver queues it
-            alone_pipelined(torch, coords, ranks, bounds, X, lambda lo, hi: gaussian_rows(torch, X32, lo, hi, seed), d, _lib.PRE_RAW, K,
+            alone_pipelined(torch, coords, ranks, bounds, X, rows, d, mode, K,
                             lam, rho_eff, results[0]["n_iterations"], times)
             # ... and through the real driver class (Python included): the figure the projection uses
-            driver_alone(torch, coords, ranks, X, lambda lo, hi: gaussian_rows(torch, X32, lo, hi, seed), d, K, nnz,
-                         results[0]["n_iterations"], times)
+            driver_alone(torch, coords, ranks, X, rows, d, K, nnz,
+                         results[0]["n_iterations"], times, pre=pre)
             times["per_rank_critical_path_ms"] = times["driver_ms"]
     info = dict(n=n, G=G, K=K, d=d, world=W, nnz=nnz, knn_ties=ties, lambda_used=lam, rho_eff=rho_eff, YtY=yty,
                 n_iterations=[r["n_iterations"] for r in results], converged=[r["converged"] for r in results],
