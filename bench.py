@@ -309,7 +309,9 @@ def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
     stage["step_ms_min_max"] = [round(min(walls), 3), round(max(walls), 3)]
     # cold fit: the same call with the library's content-keyed caches (sketch plans, tile schedules) bypassed - what a user who
     # calls fit_transform ONCE pays (the GPU context itself is warm); outside the timed region
+    from flashdeconv_amd import _lib as _fdx_lib
     os.environ["FDX_NO_PLAN_CACHE"] = "1"
+    _fdx_lib.env_reload()                          # (the library caches its switches: no fit is running here)
     try:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -318,6 +320,7 @@ def run_family(torch, model_kw, Y, X, coords, steps, warmup, barrier):
         stage["cold_ms"] = (time.perf_counter() - t1) * 1e3
     finally:
         del os.environ["FDX_NO_PLAN_CACHE"]
+        _fdx_lib.env_reload()
     return model, dt, stage
 
 

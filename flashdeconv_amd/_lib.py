@@ -131,6 +131,8 @@ SIGNATURES = {
     "fdx_gene_moments_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_double, p_double, c_void_p]),
     "fdx_gather_columns_dev": (c_int, [c_void_p, c_i32, c_i64, c_i32, c_i64, p_i32, c_i32, c_void_p, c_void_p]),
     "fdx_version": (c_int, []),
+    "fdx_env_reload": (c_int, []),
+    "fdx_env_switch": (ctypes.c_char_p, [c_i32, ctypes.POINTER(ctypes.c_char_p)]),
     "fdx_last_error": (ctypes.c_char_p, []),
     "fdx_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "fdx_set_device": (c_int, [c_int]),
@@ -180,6 +182,7 @@ SIGNATURES = {
     "fdx_graph_info": (c_int, [c_void_p, p_i64, p_i64, p_i32]),
     "fdx_graph_knn_ties": (c_int, [c_void_p, p_i64]),
     "fdx_graph_knn_far": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
+    "fdx_kdtree_set_threads": (c_int, [c_i32]),
     "fdx_ckdtree_knn": (c_int, [p_double, c_i64, c_i32, c_i32, c_void_p, c_void_p]),
     "fdx_ckdtree_knn_rows": (c_int, [p_double, c_i64, c_i32, c_i32, p_i64, c_i64, c_void_p]),
     "fdx_graph_plan_set_ckdtree_lists_dev": (c_int, [c_void_p, p_double, c_void_p, c_i64, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
@@ -232,6 +235,25 @@ def load():
                 fn.argtypes = args
             _lib = lib
     return _lib
+
+
+def env_reload():
+    """libfdx caches its FDX_* switches when it first reads them: after changing os.environ call this (no-op before the library
+    is loaded)."""
+    if _lib is not None:
+        _lib.fdx_env_reload()
+
+
+def runtime_switches():
+    """[(name, description)] of the library's runtime switches (csrc/fdx_env.cpp)."""
+    lib, out, i = load(), [], 0
+    while True:
+        what = ctypes.c_char_p()
+        name = lib.fdx_env_switch(i, ctypes.byref(what))
+        if not name:
+            return out
+        out.append((name.decode(), (what.value or b"").decode()))
+        i += 1
 
 
 def check(rc):

@@ -25,6 +25,7 @@
 // The NEXT sweep (or the finishing kernel) folds the 64 slots and evaluates
 //   rel_change = max_diff / (max_abs_old + 1e-10) < tol                       (solver.py:395-397,409)
 // on the device, so a converged solve turns the already-queued sweeps into no-ops without a host round trip.
+#include "fdx_env.h"
 #include <algorithm>
 
 #include "bcd_device.h"
@@ -211,7 +212,7 @@ static size_t sweep_lds_bytes(int K) {       // per workgroup of four waves
     return 4 * (KP * LDS_SW_STRIDE + KP) * sizeof(double);
 }
 bool sweep_uses_lds(int K) {
-    return !sweep_instantiated(K) && sweep_lds_bytes(K) <= 160 * 1024 && !getenv("FDX_SWEEP_GENERIC");
+    return !sweep_instantiated(K) && sweep_lds_bytes(K) <= 160 * 1024 && !fdx::exp_env("FDX_SWEEP_GENERIC");
 }
 size_t sweep_lds_pad_doubles(int K) { return (size_t)K * round_up(K, 16); }
 int sweep_lds_prepare(const double* XtX, int K, double* padded, hipStream_t st) {

@@ -25,6 +25,7 @@
 // The NEXT sweep (or the finishing kernel) folds the 64 slots and evaluates
 //   rel_change = max_diff / (max_abs_old + 1e-10) < tol                       (solver.py:395-397,409)
 // on the device, so a converged solve turns the already-queued sweeps into no-ops without a host round trip.
+#include "fdx_env.h"
 #include <algorithm>
 #include <cstdlib>
 #include "bcd_device.h"
@@ -394,7 +395,7 @@ static void launch_k(const BcdSweepArgs& a, hipStream_t st) {
             } else {
                 // FDX_SWEEP_LDS_PAD_KB (diagnostic): unused dynamic LDS on top, to time this kernel at the occupancy a fused
                 // two-sweep kernel would have (its intermediate iterate of tile + first ring lives in LDS: DESIGN section 7)
-                static const int pad_kb = getenv("FDX_SWEEP_LDS_PAD_KB") ? atoi(getenv("FDX_SWEEP_LDS_PAD_KB")) : 0;
+                static const int pad_kb = fdx::exp_env("FDX_SWEEP_LDS_PAD_KB") ? atoi(fdx::exp_env("FDX_SWEEP_LDS_PAD_KB")) : 0;
                 const size_t lds_launch = lds + (size_t)std::max(0, pad_kb) * 1024;
                 if (pad_kb > 0 && lds_launch > 64 * 1024)
                     (void)hipFuncSetAttribute((const void*)bcd_sweep_tiled_kernel<K, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1,4 +1,5 @@
 // Device-pointer C-ABI building blocks used by the spot-sharded multi-GPU driver (see include/fdx.h).
+#include "fdx_env.h"
 #include <algorithm>
 #include <cmath>
 #include <memory>
@@ -274,7 +275,7 @@ int prepare_queue(PrepareJob* job, const void* Y_dev, int y_dtype, long long n, 
     // on the library's side stream: queued on the caller's stream behind a shard plan that is still executing, the upload made
     // the host wait for the whole plan and the launches behind it arrived on an idle device (70 us of a 125k-spot rank's 1.6 ms).
     // The schedules of an Omega are built once per content and device (sketch_plan.cpp: the cache the single-GPU fit uses).
-    hipStream_t side = getenv("FDX_NO_SIDE_STREAM") ? nullptr : library_side_stream();
+    hipStream_t side = fdx::env("FDX_NO_SIDE_STREAM") ? nullptr : library_side_stream();
     if (side == st) side = nullptr;
     job->side = side;
     const hipStream_t xs = side ? side : st;

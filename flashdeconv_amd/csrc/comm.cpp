@@ -13,6 +13,7 @@
 //
 // Transports: RCCL (one process per GPU), and an in-process one (several host threads of one process act as ranks on ONE
 // GPU, device copies through a shared mailbox) that lets the tests run this very loop without N GPUs.
+#include "fdx_env.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -449,7 +450,7 @@ int fdx_sharded_solve_padded_dev(fdx_comm* c, const fdx_graph* g, const double* 
 // stages, core/solver.py:157-166 for the sharding.
 // FDX_TRACE_HOST=1: host clock at the steps of a shard's fit (stderr)
 static void shard_trace(const char* what) {
-    static const bool on = getenv("FDX_TRACE_HOST") != nullptr;
+    static const bool on = fdx::env("FDX_TRACE_HOST") != nullptr;
     if (!on) return;
     static auto t_prev = std::chrono::steady_clock::now();
     const auto t = std::chrono::steady_clock::now();
@@ -487,7 +488,7 @@ int fdx_shard_fit_dev(fdx_comm* c, const fdx_graph* g, const void* Y_dev, int32_
     // (FDX_SKETCH_RESERVE: compute units the sketch's persistent workgroups leave to that build; measured at 16 / 32 / 64 on a
     // 125k-spot shard it only slowed both down - the build is a chain of dependent launches, not a matter of free units.)
     int reserve = 0;
-    if (g->shard_pending) if (const char* e = getenv("FDX_SKETCH_RESERVE")) reserve = atoi(e);
+    if (g->shard_pending) if (const char* e = fdx::exp_env("FDX_SKETCH_RESERVE")) reserve = atoi(e);
     const int reserve_prev = tile_sketch_reserve_cus(reserve);
     const int prc = prepare_queue(&job, Y_dev, y_dtype, n_own, G, ldy, nullptr, X, K, bucket, weight_y, weight_x, prm->sketch_dim,
                                   prm->mode_y, prm->mode_x, dH.as<double>(), ldh, Gh, st, prm->X_dev);
@@ -659,7 +660,7 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     a.stats = stats.as<unsigned long long>(); a.rel_change = relchg_p;
     a.lambda = lambda; a.rho = rho_eff; a.tol = tol; a.ldh = (int)ldh; a.ld = (int)ld; a.n = (int)g->n;
     a.n_slices = g->n_slices; a.K = K;
-    const bool tiled = g->tiled && !getenv("FDX_NO_TILED");
+    const bool tiled = g->tiled && !fdx::env("FDX_NO_TILED");
     if (tiled) {
         a.tiled = 1; a.ell_local = g->ell_local.as<unsigned short>(); a.tile_halo = g->tile_halo.as<int>();
         a.tile_hcnt = g->tile_hcnt.as<int>(); a.n_tiles = g->n_tiles; a.halo_max = g->halo_max;
@@ -667,19 +668,19 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     a.beta_in = beta0_dev;
     a.beta_out = beta1_dev;
     // boundary-first ordering needs the tiled sweep (tile lists) and somebody to talk to
-    bool split = tiled && bcd_sweep_uses_tiles(a) && total_send > 0 && g->n > 0 && !getenv("FDX_NO_OVERLAP");
+    bool split = tiled && bcd_sweep_uses_tiles(a) && total_send > 0 && g->n > 0 && !fdx::env("FDX_NO_OVERLAP");
     // ... and a shard large enough for the split to pay: a sweep launch lasts at least one workgroup's life (~25-35 us) however few
     // tiles it has, so for shards of a few rounds of resident workgroups (256 CUs x 3) boundary + interior cost two such lives for the work of
     // one - 125k-spot shards: 36 + 34 us against 36 - and the interior sweep is too short to hide anything behind
     // (4096 tiles = 1M spots per rank: below that a rank's halo is a few hundred KB per peer - ~20 us of transfer and latency to
     // hide, against the ~36 us the extra launch costs; the 1.25M-spot ranks of configs[4], 1-2.6 MB per peer, are about even)
-    const int split_min_tiles = getenv("FDX_SPLIT_MIN_TILES") ? atoi(getenv("FDX_SPLIT_MIN_TILES")) : 4096;
+    const int split_min_tiles = fdx::env("FDX_SPLIT_MIN_TILES") ? atoi(fdx::env("FDX_SPLIT_MIN_TILES")) : 4096;
     if (split && g->n_tiles < split_min_tiles) split = false;
     // every rank must take the same route for the convergence slots: they ride with the halo only when NO rank of the job can
     // split (shards are equal to within one tile: the largest has at most ceil(tiles / W) + 1 of them)
     const long long tiles_max = g->world_n > 0 ? ((g->world_n + 255) / 256 + W - 1) / W + 1 : (1LL << 40);
-    const bool piggy_ok = W > 1 && !c->loopback && (c->nccl || c->local) && !getenv("FDX_STATS_ALLREDUCE") &&
-                          (tiles_max < split_min_tiles || getenv("FDX_NO_OVERLAP") != nullptr);
+    const bool piggy_ok = W > 1 && !c->loopback && (c->nccl || c->local) && !fdx::exp_env("FDX_STATS_ALLREDUCE") &&
+                          (tiles_max < split_min_tiles || fdx::env("FDX_NO_OVERLAP") != nullptr);
     if (split) {
         FDX_TRY(build_tile_lists(*g, st));          // no-op for a graph of the queued shard build: its lists were made on the device
         split = g->n_tiles_boundary > 0 && g->n_tiles_interior > 0;
@@ -688,7 +689,7 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     // beta0 = 1/K on own + halo (solver.py:372), pad types 0: a constant of the first sweep where the tiled kernel takes one
     // (bcd_sweep_inst.cpp, INIT: whole-shard launches, no pad types), written to the buffer otherwise
     double init_uniform = 0.0;
-    if (!split && tiled && K_real == K && K <= FDX_MAX_K_FAST && max_iter > 0 && g->n > 0 && bcd_sweep_uses_tiles(a) && !getenv("FDX_NO_INIT_SWEEP")) {
+    if (!split && tiled && K_real == K && K <= FDX_MAX_K_FAST && max_iter > 0 && g->n > 0 && bcd_sweep_uses_tiles(a) && !fdx::env("FDX_NO_INIT_SWEEP")) {
         init_uniform = 1.0 / (double)K;
         FDX_TRY(solver_zero_pad(beta0_dev, ld, g->n_total, K, st));
     } else {
@@ -697,7 +698,7 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
 
     // rows a peer needs are written into the send staging by the sweep itself (tiled kernel; bcd_sweep_inst.cpp) - the lists seen
     // from the rows are made once per graph
-    const bool fused_pack = tiled && total_send > 0 && g->n > 0 && bcd_sweep_uses_tiles(a) && !getenv("FDX_NO_FUSED_PACK");
+    const bool fused_pack = tiled && total_send > 0 && g->n > 0 && bcd_sweep_uses_tiles(a) && !fdx::env("FDX_NO_FUSED_PACK");
     if (fused_pack) {
         if (!g->send_head.p) {
             FDX_TRY(g->send_head.alloc((size_t)g->n * 4));
@@ -729,7 +730,7 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     double sweep_ms = 0.0;
     double* beta[2] = {beta0_dev, beta1_dev};
     // the in-process transport meets at host barriers: nothing is gained by queueing ahead there
-    const int n_ahead = (c->local || getenv("FDX_NO_SWEEP_AHEAD")) ? 0 : 2;
+    const int n_ahead = (c->local || fdx::exp_env("FDX_NO_SWEEP_AHEAD")) ? 0 : 2;
     auto iterate = [&](int it, bool last_of_chunk) -> int {
         a.it = it;
         a.beta_in = beta[it & 1];

@@ -25,6 +25,7 @@
 //                                stripe order.  csr_moments_tiled_kernel: rows whose columns are not sorted.
 // Several entries of one row can hit the same bucket, so the order of those additions is the hardware's; the reference's scipy
 // product carries the same freedom, and the 1e-4 parity budget is 12 orders of magnitude above it.
+#include "fdx_env.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -184,7 +185,7 @@ static int launch_sketch_csr_t(const long long* indptr, const int* indices, cons
         if (lds > 64 * 1024)
             FDX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, indptr, indices, data, row_map, row0, n, d,
-                           (const GeneSlot*)table, sel_bits, sel_words, Ys, ldys, row_sumsq, getenv("FDX_NO_LOG_TABLE") ? 1 : 0);
+                           (const GeneSlot*)table, sel_bits, sel_words, Ys, ldys, row_sumsq, fdx::env("FDX_NO_LOG_TABLE") ? 1 : 0);
         FDX_CHECK_LAUNCH();
         return 0;
     };
@@ -509,7 +510,7 @@ static size_t csr_contract_lds(int d, int TT, int sel_words) {
 // shapes the fused kernel takes: the A operands of a wave (NB x TT x 4 doubles) must fit beside the row's registers, and the keep
 // buffers need room for a wave's worth of entries at least
 bool csr_contract_ok(int d, int K, int sel_words) {
-    if (getenv("FDX_CSR_NO_FUSED")) return false;
+    if (fdx::exp_env("FDX_CSR_NO_FUSED")) return false;
     if (d <= 0 || K <= 0 || K > 64 || d % 4 != 0) return false;
     const int NB = (d + 255) / 256, TT = (K + 15) / 16;
     if (NB * TT > 4) return false;
@@ -529,10 +530,11 @@ static int launch_csr_contract_m(const long long* indptr, const int* indices, co
     const int sel_in_lds = (sel.n_sel < 65536 && base + tables + 256 * per_entry <= 160 * 1024) ? 1 : 0;
     FDX_REQUIRE(sel.n_sel < 65536, "sketch (CSR, fused): more than 65535 selected genes");
     const size_t used = base + (sel_in_lds ? tables : 16);
-    const int cap = (int)std::min<size_t>(((160 * 1024 - used) / per_entry) & ~(size_t)63, 4096);
+    int cap = (int)std::min<size_t>(((160 * 1024 - used) / per_entry) & ~(size_t)63, 4096);
+    if (const char* e = env("FDX_CSR_KEEP_CAP")) cap = std::min(cap, std::max(64, atoi(e) & ~63));   // tests: rows that overflow the buffer
     const size_t lds = used + (size_t)cap * per_entry;
     const int grid = (int)std::min<long long>((n + 15) / 16, 256);
-    const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
+    const int no_table = fdx::env("FDX_NO_LOG_TABLE") ? 1 : 0;
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024)
             FDX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -838,15 +840,15 @@ static int launch_csr_moments_t(const long long* indptr, const int* indices, con
                                 hipStream_t st) {
     // sorted rows: ONE 16-wave workgroup per CU at 128 registers with as much of the gene axis as 152 KB of LDS hold (fewer
     // visits per row, fewer windows that end beside a tile edge); FDX_CSR_MOM_CFG=2: two workgroups per CU, 64 KB tiles
-    const bool cursor_path = sorted_rows && nnz > 0 && !getenv("FDX_CSR_NO_CURSOR");
-    const bool one_wg = cursor_path && !(getenv("FDX_CSR_MOM_CFG") && atoi(getenv("FDX_CSR_MOM_CFG")) == 2);
+    const bool cursor_path = sorted_rows && nnz > 0 && !fdx::exp_env("FDX_CSR_NO_CURSOR");
+    const bool one_wg = cursor_path && !(fdx::exp_env("FDX_CSR_MOM_CFG") && atoi(fdx::exp_env("FDX_CSR_MOM_CFG")) == 2);
     // (+ 16 waves x 512 B of log1p tables, + 16 KB of row cursors on the sorted path)
     const int tile_max = (int)((one_wg ? 136 : (cursor_path ? 56 : 64)) * 1024 / (NS * sizeof(double)));
     const int tiles = ceil_div(G, tile_max);
     const int tile = one_wg ? std::min(G, (ceil_div(G, tiles) + 63) & ~63) : std::min(G, tile_max);
     const int stripes = one_wg ? (int)std::min<long long>(csr_moment_stripes(n), 256) : csr_moment_stripes(n);
     const int rows_per_stripe = (int)((n + stripes - 1) / stripes);
-    const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
+    const int no_table = fdx::env("FDX_NO_LOG_TABLE") ? 1 : 0;
     hipLaunchKernelGGL(csr_row_scale_kernel<T>, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, indptr, data, n, scale, no_table);
     FDX_CHECK_LAUNCH();
     const size_t lds_m = (size_t)NS * tile * sizeof(double) + 16 * 64 * sizeof(double);

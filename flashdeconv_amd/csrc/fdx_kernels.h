@@ -1,5 +1,6 @@
 // Internal launch interfaces between the kernel translation units and the C-ABI layer.
 #pragma once
+#include "fdx_env.h"
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 
@@ -19,7 +20,7 @@ constexpr int FDX_MAX_K_FAST = 64;  // register-resident sweep kernels are insta
 // at one wave per SIMD: 3.9; generic ~10), 120: 4.0, 200: 16.
 constexpr int FDX_MAX_K_PAD = 96;
 inline int solver_padded_K(int K) {
-    if (K <= FDX_MAX_K_FAST || K > FDX_MAX_K_PAD || getenv("FDX_NO_K_PAD")) return K;
+    if (K <= FDX_MAX_K_FAST || K > FDX_MAX_K_PAD || fdx::exp_env("FDX_NO_K_PAD")) return K;
     for (int kp : {72, 80, 88, 96})
         if (K <= kp) return kp;
     return K;

@@ -3,6 +3,7 @@
 //   -> BCD solve (core/solver.py:287-428) -> beta / proportions in the caller's spot order (core/solver.py:431-452).
 // Everything between "Y, coords resident in HBM" and "beta_, proportions_ resident in HBM" stays on the device; the
 // host only sees a handful of scalars (bounding box, XtX, rel_change trace).
+#include "fdx_env.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -24,7 +25,7 @@ namespace {
 
 // FDX_TRACE_HOST=1: host time between the marked points of a fit (stderr), to see whether the host keeps ahead of the device
 void fit_trace_host(const char* what) {
-    static const bool on = getenv("FDX_TRACE_HOST") != nullptr;
+    static const bool on = fdx::env("FDX_TRACE_HOST") != nullptr;
     if (!on) return;
     static auto t_prev = std::chrono::steady_clock::now();
     const auto t = std::chrono::steady_clock::now();
@@ -139,7 +140,7 @@ extern "C" int fdx_leverage_begin_opt(const double* X, int32_t K, int32_t G, dou
     std::memcpy(job->hX, X, (size_t)K * G * sizeof(double));
     // the upload (a pageable copy: the host waits for it) and the launches cost ~75 us of host time that the caller - on its way to
     // a graph build, with the scores not needed before the sketch tables - has better uses for: the helper thread queues them
-    const bool async = queue_async != 0 && !getenv("FDX_NO_HELPER_THREAD");
+    const bool async = queue_async != 0 && !fdx::exp_env("FDX_NO_HELPER_THREAD");
     auto run = [job, K, G, regularization]() -> int {
         PoolStream pool_stream(job->st);
         FDX_TRY(job->dX.alloc((size_t)K * G * sizeof(double)));
@@ -233,7 +234,7 @@ static int leverage_end_impl(fdx_leverage_job* job, double* lev_out, double** x_
         job->dX.p = nullptr;
         job->dX.bytes = job->dX.cap = 0;
     }
-    if (!rc && getenv("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
+    if (!rc && fdx::env("FDX_DEBUG"))   // phase stamps in 100 MHz ticks
         std::fprintf(stderr, "[fdx] leverage: K=%d G=%d route=%s passes/sweeps=%d converged=%d\n", job->K, job->G,
                      job->route == LEV_ROUTE_QR ? "cholesky-qr" : "jacobi-svd", dbg[0], dbg[6]);
     delete job;
@@ -361,7 +362,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     struct AbortDrain { hipStream_t s; bool armed = true; ~AbortDrain() { if (armed) (void)hipStreamSynchronize(s); } } abort_drain{st};
     hipEvent_t evInit = nullptr;
     struct EvGuard0 { hipEvent_t* e; ~EvGuard0() { if (*e) (void)hipEventDestroy(*e); } } evInit_guard{&evInit};
-    hipStream_t side = getenv("FDX_NO_SIDE_STREAM") ? nullptr : leverage_side_stream();
+    hipStream_t side = fdx::env("FDX_NO_SIDE_STREAM") ? nullptr : leverage_side_stream();
     if (side == st) side = nullptr;
     const hipStream_t xs = side ? side : st;
     if (side) side_drain.s = side;
@@ -372,7 +373,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     hipEvent_t evG = nullptr;
     FDX_HIP(hipEventCreateWithFlags(&evG, hipEventDisableTiming));
     struct EvGuard { hipEvent_t e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evG_guard{evG};
-    const bool beta0_virtual = side && KP == K && K <= FDX_MAX_K_FAST && prm->max_iter > 0 && !prm->verbose && !getenv("FDX_NO_INIT_SWEEP");
+    const bool beta0_virtual = side && KP == K && K <= FDX_MAX_K_FAST && prm->max_iter > 0 && !prm->verbose && !fdx::env("FDX_NO_INIT_SWEEP");
     {
         PoolStream pool_xs(xs);
         FDX_TRY(dB0.alloc((size_t)KP * ld * sizeof(double)));
@@ -431,7 +432,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     // Y_sketch is produced and consumed in chunks of 256k rows (1 GB at d = 512): measured on MI355X, smaller chunks
     // (down to Infinity-Cache size) under-fill the chip and are slower, larger ones gain nothing.
     long long chunk_rows = 1LL << 18;
-    if (const char* e = getenv("FDX_FIT_CHUNK")) chunk_rows = std::max<long long>(64, atoll(e));
+    if (const char* e = fdx::exp_env("FDX_FIT_CHUNK")) chunk_rows = std::max<long long>(64, atoll(e));
     const long long chunk = std::min<long long>(n, chunk_rows);
     const bool fused = csr_fused || (!ysrc.csr && fused_sketch_contract_ok(y_dtype, ldy, Y_dev, G, d, K, prm->mode_y, plan_y.dev()));
     if (!fused && !carry_in) FDX_TRY(dYs.alloc((size_t)chunk * d * sizeof(double)));
@@ -584,7 +585,7 @@ int fit_impl(const YSource& ysrc, int64_t n, int32_t G, const double* X, int32_t
     }
     FDX_TRY(solver_run(p, &r, st));          // its chunked read-backs synchronise the stream: YtY has arrived after it
     bool exported = false;
-    if ((beta_out_dev || prop_out_dev) && !prm->verbose && !getenv("FDX_NO_EXPORT_OVERLAP")) {
+    if ((beta_out_dev || prop_out_dev) && !prm->verbose && !fdx::exp_env("FDX_NO_EXPORT_OVERLAP")) {
         if (side) {
             FDX_HIP(hipEventCreateWithFlags(&evSolved, hipEventDisableTiming));
             FDX_HIP(hipEventCreateWithFlags(&evExported, hipEventDisableTiming));

@@ -11,6 +11,7 @@
 // plane (128-byte segments of the type-major H).  Within a 16-wide block of the contraction index, lane (r, q=l>>4)
 // loads the 4 CONSECUTIVE doubles 4q..4q+3 of row r (full 128-byte lines per row per wave) and MFMA step s
 // contracts {s, 4+s, 8+s, 12+s} - any order works as long as A and B agree.
+#include "fdx_env.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -231,7 +232,7 @@ int launch_xyt(const double* Xs, const double* Ys, long long ldy, long long n, i
     {   // large-n fast path: X_sketch register-resident, contraction split over 8 waves
         const bool ok = !sumsq_partials && (d % 16 == 0) && d <= 1024 && K <= 64 && (ldy % 4 == 0) &&
                         ((reinterpret_cast<uintptr_t>(Xs) & 31) == 0) && ((reinterpret_cast<uintptr_t>(Ys) & 31) == 0) &&
-                        !getenv("FDX_XYT_PLAIN");
+                        !fdx::exp_env("FDX_XYT_PLAIN");
         if (ok) {
             const int nb = (d + 127) / 128;             // 16-wide blocks per wave
             const int T = (K + 15) / 16;

@@ -16,6 +16,7 @@
 //   4. union symmetrisation: in-degree count (inside the k-NN kernel for whole-graph builds), reverse lists, per-row sort
 //      by original index + unique.
 //   5. sliced ELL (slice = 64 consecutive sorted points = one wavefront of the BCD sweep).
+#include "fdx_env.h"
 #include <chrono>
 #include <functional>
 #include <memory>
@@ -1206,7 +1207,7 @@ __global__ __launch_bounds__(256) void tile_ell_kernel(const int* __restrict__ w
 // ------------------------------------------------------------------------------------------------ host side
 // FDX_TRACE_HOST=1: host clock at the steps of a graph build (stderr), to see which calls the host spends its time in
 static void trace_host(const char* what) {
-    static const bool on = getenv("FDX_TRACE_HOST") != nullptr;
+    static const bool on = fdx::env("FDX_TRACE_HOST") != nullptr;
     if (!on) return;
     static auto t_prev = std::chrono::steady_clock::now();
     const auto t = std::chrono::steady_clock::now();
@@ -1253,7 +1254,7 @@ static int bbox_begin(const double* d_coords, long long n, int dim, hipStream_t 
     FDX_HIP(hipGetDevice(&job->dev));
     // (256 to 16384 blocks, one to sixteen points per thread, four loads in flight or one: 33-60 us for the 16 MB of a million 2-D
     // points whatever the shape - the kernel's time is not its loop; 512 blocks measured best)
-    const int nblk = (int)std::min<long long>(getenv("FDX_BBOX_BLOCKS") ? atoi(getenv("FDX_BBOX_BLOCKS")) : 512, (n + 255) / 256);
+    const int nblk = (int)std::min<long long>(fdx::exp_env("FDX_BBOX_BLOCKS") ? atoi(fdx::exp_env("FDX_BBOX_BLOCKS")) : 512, (n + 255) / 256);
     FDX_TRY(job->part.alloc((size_t)nblk * 6 * sizeof(double)));
     job->host = (double*)pinned_block_get();
     FDX_REQUIRE(job->host != nullptr, "graph: pinned host block");
@@ -1361,8 +1362,8 @@ static int bin_points(const double* d_coords, long long n, int dim, double targe
     int axis_bits = 1;
     while ((1LL << axis_bits) < (long long)max_axis) ++axis_bits;
     const int bits = std::min(64, axis_bits * dim);      // significant bits of the Morton key
-    const bool counting = bits <= 22 && (1LL << bits) <= 8 * n + 1024 && !getenv("FDX_GRAPH_SORT");
-    const bool shard_need = counting && shard_hi > shard_lo && (shard_lo > 0 || shard_hi < n) && shard_R > 0 && !getenv("FDX_BAND_FULL_BINNING");
+    const bool counting = bits <= 22 && (1LL << bits) <= 8 * n + 1024 && !fdx::env("FDX_GRAPH_SORT");
+    const bool shard_need = counting && shard_hi > shard_lo && (shard_lo > 0 || shard_hi < n) && shard_R > 0 && !fdx::exp_env("FDX_BAND_FULL_BINNING");
     {
         // the cell table, the key counters and (spot shards) the need flags start as zero: one block, one fill
         auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
@@ -1455,7 +1456,7 @@ static int build_tiles(fdx_graph* g, hipStream_t st) {
         for (int v : hc) { if (v < 0) ok = false; mx = std::max(mx, v); }
         g->tiled = ok;
         g->halo_max = mx;
-        if (getenv("FDX_TRACE_HOST")) std::fprintf(stderr, "[fdx-host] tiles: %d tiles, largest halo %d, tiled %d\n", g->n_tiles, mx, (int)ok);
+        if (fdx::env("FDX_TRACE_HOST")) std::fprintf(stderr, "[fdx-host] tiles: %d tiles, largest halo %d, tiled %d\n", g->n_tiles, mx, (int)ok);
     }
     return 0;
 }
@@ -1486,7 +1487,7 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
     if (defer) {
         // room per row: three times the list length, at least 24 (slice widths of a k = 6 graph are 9-12), at most 96; a graph
         // that needs more (hubs) is rebuilt with its exact size by graph_meta_sync
-        const int w_cap = getenv("FDX_GRAPH_WCAP") ? std::max(1, atoi(getenv("FDX_GRAPH_WCAP")))        // tests: force the rebuild
+        const int w_cap = fdx::env("FDX_GRAPH_WCAP") ? std::max(1, atoi(fdx::env("FDX_GRAPH_WCAP")))        // tests: force the rebuild
                                                 : std::min(96, std::max(24, 3 * std::max(seg_stride, 1) + 3));
         const long long cap = (long long)g->n_slices * w_cap;
         g->ell_cap_rows = cap;
@@ -1495,7 +1496,7 @@ static int finish_ell(fdx_graph* g, const int* ws, int seg_stride, const int* se
         FDX_TRY(g->tile_halo.alloc((size_t)std::max(g->n_tiles, 1) * FDX_TILE_HALO_CAP * 4));
         FDX_TRY(g->tile_hcnt.alloc((size_t)std::max(g->n_tiles, 1) * 4));
         FDX_TRY(g->ell_local.alloc(((size_t)cap + 16) * 64 * 2));
-        if (g->n_tiles > 0 && !getenv("FDX_GRAPH_TWO_ELL_KERNELS")) {
+        if (g->n_tiles > 0 && !fdx::env("FDX_GRAPH_TWO_ELL_KERNELS")) {
             hipLaunchKernelGGL(tile_ell_kernel, dim3(g->n_tiles), dim3(256), 0, st, ws, seg_stride, seg_extra, (int)g->n_total, g->ell.as<int>(),
                                g->deg.as<int>(), g->slice_off.as<int>(), n, g->tile_halo.as<int>(), g->tile_hcnt.as<int>(),
                                g->ell_local.as<unsigned short>(), cap, summary);
@@ -1577,7 +1578,7 @@ static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int
     const long long n_threads = n_direct >= 0 ? (long long)n_direct + list_cap : hi - lo;
     // candidates per round trip: 4 leaves the kernel 77 registers (6 waves per SIMD), 6: 87 (5 waves), 8: 97 (4 waves);
     // 1M spots, wall per fit: 4.69 / 4.84 / 4.88 ms
-    const int batch_env = getenv("FDX_KNN_BATCH") ? atoi(getenv("FDX_KNN_BATCH")) : 0;
+    const int batch_env = fdx::exp_env("FDX_KNN_BATCH") ? atoi(fdx::exp_env("FDX_KNN_BATCH")) : 0;
     // a launch of a few hundred thousand rows does not fill the chip anyway (a spot shard's own rows + band): what it takes is one
     // walk's chain of round trips, and 8 candidates per round trip halve that chain (97 registers, 4 waves per SIMD - no loss here)
     const int batch_auto = (KMAX <= 16 && n_threads <= 300000) ? 8 : 4;
@@ -1585,12 +1586,14 @@ static void launch_knn_range(const BinnedPoints& b, const int* perm, int kk, int
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(ceil_div(n_threads, 128)), dim3(128), 0, st, b.sc.as<double>(), b.sc2.as<double2>(), perm,
                            b.rank.as<int>(), b.cstart.as<int>(), b.cend_p, b.n, b.gp, kk, nbr, cnt, nn_dist, lo, hi, indeg, arrival,
-                           KMAX > kk ? ties : nullptr, getenv("FDX_KNN_NO_BATCH") ? 1 : 0, row_list, row_count, far_flag, far_R, far_drop,
+                           KMAX > kk ? ties : nullptr, fdx::exp_env("FDX_KNN_NO_BATCH") ? 1 : 0, row_list, row_count, far_flag, far_R, far_drop,
                            n_direct, list_cap);
     };
     if constexpr (KMAX <= 16) {
         if (batch == 4) go(knn_kernel<KMAX, 4>);
+#ifdef FDX_EXPERIMENT
         else if (batch == 6) go(knn_kernel<KMAX, 6>);
+#endif
         else go(knn_kernel<KMAX, 8>);
     } else {
         go(knn_kernel<KMAX, 8>);
@@ -1669,7 +1672,7 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     // ~4 points per grid cell: the 3 x 3 block of cells then always holds the k <= 8 nearest (no second shell, no divergence),
     // and the 256-spot Morton tiles come out more compact (1M jittered-lattice spots: graph 1.11 -> 0.95 ms, sweep 0.192 -> 0.186 ms;
     // uniform random spots: unchanged); FDX_GRAPH_TPC overrides (experiments)
-    const double tpc = getenv("FDX_GRAPH_TPC") ? atof(getenv("FDX_GRAPH_TPC")) : 4.0;
+    const double tpc = fdx::exp_env("FDX_GRAPH_TPC") ? atof(fdx::exp_env("FDX_GRAPH_TPC")) : 4.0;
     int rc = 0;
     if (dim > 3) {
         // solver order from the first three coordinates, exhaustive search in all of them
@@ -1734,10 +1737,10 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
     // Where the kernel's time goes at 1M spots (300 us): ~110 us are the 7M in-degree counters (returning atomics; measured
     // with the counters taken out), the rest the walk - waves parked on its gathers two thirds of their life.
     const long long rows = hi - lo;
-    const int pieces_env = getenv("FDX_KNN_PIECES") ? atoi(getenv("FDX_KNN_PIECES")) : 0;
+    const int pieces_env = fdx::exp_env("FDX_KNN_PIECES") ? atoi(fdx::exp_env("FDX_KNN_PIECES")) : 0;
     const int pieces = pieces_env > 0 ? pieces_env : 1;
     const long long step = ((rows + pieces - 1) / pieces + 127) / 128 * 128;
-    const bool merged = band && rows > 0 && pieces == 1 && rows < 0x3fffffffLL && !getenv("FDX_KNN_TWO_LAUNCHES");
+    const bool merged = band && rows > 0 && pieces == 1 && rows < 0x3fffffffLL && !fdx::exp_env("FDX_KNN_TWO_LAUNCHES");
     if (band && rows > 0) {
         // the band: cells next to a cell with an own row -> their rows outside [lo, hi) -> the lists of those rows.  Room for as
         // many band rows as own rows (a band is a surface: thousands of rows beside a million); an overflow is reported and the
@@ -1751,7 +1754,7 @@ int graph_knn_lists(const double* d_coords, long long n, int dim, int k, long lo
         if (!rc) rc = plan->band_rows.alloc((size_t)std::max(plan->band_cap, 1) * 4);
         if (!rc) rc = plan->band_counters.alloc(16);
         if (rc) { delete plan; return rc; }
-        const bool from_need = b.need_p && b.bins > 0 && !getenv("FDX_BAND_CELLS");
+        const bool from_need = b.need_p && b.bins > 0 && !fdx::exp_env("FDX_BAND_CELLS");
         if ((!from_need && hipMemsetAsync(cell_flag.p, 0, cell_flag.bytes, st) != hipSuccess) ||
             hipMemsetAsync(plan->band_counters.p, 0, 16, st) != hipSuccess) {
             delete plan;
@@ -1988,7 +1991,7 @@ int graph_meta_sync(const fdx_graph* gc) {
     g->ell_rows = rows;
     g->halo_max = (int)(g->meta_host[3] & 0xffffffffLL);
     g->tiled = g->n_tiles > 0 && rows > 0 && (g->meta_host[3] >> 32) == 0;
-    if (getenv("FDX_TRACE_HOST")) std::fprintf(stderr, "[fdx-host] meta: rows %lld of %lld, nnz %lld, largest halo %d, tiled %d\n", rows, g->ell_cap_rows, g->nnz, g->halo_max, (int)g->tiled);
+    if (fdx::env("FDX_TRACE_HOST")) std::fprintf(stderr, "[fdx-host] meta: rows %lld of %lld, nnz %lld, largest halo %d, tiled %d\n", rows, g->ell_cap_rows, g->nnz, g->halo_max, (int)g->tiled);
     return 0;
 }
 
@@ -2008,7 +2011,7 @@ int graph_build_knn(const double* d_coords, long long n, int dim, int k, fdx_gra
     FDX_TRY(graph_knn_lists(d_coords, n, dim, k, 0, n, nbr.as<int>(), cnt.as<int>(), &plan, st));
     // Whole graph in one piece: the rest is queued without a host round trip (FDX_GRAPH_SYNC=1: built to the end here); the
     // lists and the binned points stay with the graph until graph_meta_sync has seen the kernels finish.
-    const bool defer = !getenv("FDX_GRAPH_SYNC");
+    const bool defer = !fdx::env("FDX_GRAPH_SYNC");
     const int rc = graph_from_knn_lists_impl(plan, nbr.as<int>(), cnt.as<int>(), 0, n, g, st, defer);
     if (rc == 0 && defer && g->meta_pending) {
         g->keep_nbr.take(nbr);
@@ -2566,7 +2569,7 @@ namespace fdx {
 hipStream_t library_plan_stream() {
     static hipStream_t streams[64] = {};
     static std::mutex mu;
-    if (getenv("FDX_NO_PLAN_STREAM")) return nullptr;
+    if (fdx::exp_env("FDX_NO_PLAN_STREAM")) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
@@ -2628,8 +2631,8 @@ int graph_shard_knn(const double* d_coords, long long n, int dim, int k, int n_r
     // while this thread returns to the caller: a rank's critical path is the host's way to the sketch of its own rows, which does
     // not need the graph.  Consumers join (graph_shard_join).  FDX_SHARD_EAGER=1: here and now, on the caller's stream (=2: on the
     // plan stream); FDX_NO_HELPER_THREAD: by the first consumer.
-    if (const char* e = getenv("FDX_SHARD_EAGER")) return shard_queue_rest(loc, atoi(e) == 2 ? nullptr : st);   // 2: on the plan stream
-    if (!getenv("FDX_NO_HELPER_THREAD")) loc->keep_shard->ticket = helper_submit([loc] { return shard_queue_rest(loc, nullptr); });
+    if (const char* e = fdx::exp_env("FDX_SHARD_EAGER")) return shard_queue_rest(loc, atoi(e) == 2 ? nullptr : st);   // 2: on the plan stream
+    if (!fdx::exp_env("FDX_NO_HELPER_THREAD")) loc->keep_shard->ticket = helper_submit([loc] { return shard_queue_rest(loc, nullptr); });
     return 0;
 }
 
@@ -2734,8 +2737,8 @@ int shard_queue_rest(fdx_graph* loc, hipStream_t st) {
     // (tests: FDX_GRAPH_WCAP forces the "bound too small" remedy, on every rank or - FDX_GRAPH_WCAP_RANK - on one)
     int rank = 0;
     while (rank + 1 < n_ranks && !(sb->bounds[rank] == lo && sb->bounds[rank + 1] == hi)) ++rank;
-    const bool cap_forced = getenv("FDX_GRAPH_WCAP") && (!getenv("FDX_GRAPH_WCAP_RANK") || atoi(getenv("FDX_GRAPH_WCAP_RANK")) == rank);
-    const int w_cap = cap_forced ? std::max(1, atoi(getenv("FDX_GRAPH_WCAP"))) : std::min(96, std::max(24, 3 * kk + 3));
+    const bool cap_forced = fdx::env("FDX_GRAPH_WCAP") && (!fdx::env("FDX_GRAPH_WCAP_RANK") || atoi(fdx::env("FDX_GRAPH_WCAP_RANK")) == rank);
+    const int w_cap = cap_forced ? std::max(1, atoi(fdx::env("FDX_GRAPH_WCAP"))) : std::min(96, std::max(24, 3 * kk + 3));
     const long long cap = (long long)loc->n_slices * w_cap;
     loc->shard_ell_cap = cap;
     FDX_TRY(loc->ell.alloc((size_t)std::max<long long>(cap, 1) * 64 * 4));

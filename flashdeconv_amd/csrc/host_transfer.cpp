@@ -7,6 +7,7 @@
 // astype(float64) on the host becomes a narrowing to the float32 / float64 the kernels stream, done while the bytes are moved anyway -
 // chunk by chunk into a ring of recycled pinned buffers, each chunk's DMA queued as soon as it is filled: the CPU copies of later
 // chunks run under the DMA of earlier ones, and the caller's memory is only ever touched by plain loads.
+#include "fdx_env.h"
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -75,7 +76,7 @@ double convert_to(int code, const void* src, void* dst, size_t count) {
 // downloads into fresh pages 37.5 / 38.8 / 29.9 on 4 / 8 / 16 - a few threads saturate the link, more only contend
 int team_size(size_t bytes, int want) {
     int t = (int)std::min<unsigned>(host_cpu_budget(), (unsigned)want);
-    if (const char* e = getenv("FDX_TRANSFER_THREADS")) t = std::max(1, atoi(e));
+    if (const char* e = fdx::exp_env("FDX_TRANSFER_THREADS")) t = std::max(1, atoi(e));
     const size_t chunks = (bytes + kChunkBytes - 1) / kChunkBytes;
     return (int)std::max<size_t>(1, std::min<size_t>((size_t)t, chunks));
 }

@@ -26,6 +26,7 @@
 //             (min_distance += new - old) exactly as the library does, because equality decides here.
 // tests/test_host.py compares this entry with scipy itself (index arrays of the tree and query results) on lattices,
 // duplicated points, random clouds in 1-3 dimensions - no GPU involved.
+#include "fdx_env.h"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -34,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <system_error>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -89,9 +91,18 @@ unsigned host_cpu_budget() {
     return budget;
 }
 
+// Host threads the restated cKDTree may use (build forks, host queries): the process's budget, or the share the caller set with
+// fdx_kdtree_set_threads (the ranks of one host each build the tree of the replicated coordinates: they share its cores), or
+// FDX_KDTREE_THREADS.
+static std::atomic<int> g_kd_threads{0};
+static unsigned kd_thread_share() {
+    if (const char* e = fdx::env("FDX_KDTREE_THREADS")) return (unsigned)std::max(1, atoi(e));
+    const int v = g_kd_threads.load();
+    return v > 0 ? (unsigned)v : host_cpu_budget();
+}
 namespace {
 static long long kd_fork_min() {
-    static const long long v = getenv("FDX_KDTREE_FORK_MIN") ? std::max(1024, atoi(getenv("FDX_KDTREE_FORK_MIN"))) : 32768;
+    static const long long v = fdx::exp_env("FDX_KDTREE_FORK_MIN") ? std::max(1024, atoi(fdx::exp_env("FDX_KDTREE_FORK_MIN"))) : 32768;
     return v;
 }
 
@@ -321,7 +332,7 @@ int ckdtree_query_host(const KdTree& t, int32_t kk, const int64_t* rows, int64_t
 int ckdtree_knn_impl(const double* coords, int64_t n, int32_t dim, int32_t kk, const int64_t* rows, int64_t n_rows, int64_t* idx_out,
                      int64_t* tree_indices_out) {
     KdTree t;
-    const bool trace = getenv("FDX_TRACE_HOST") != nullptr;
+    const bool trace = fdx::env("FDX_TRACE_HOST") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     kd_build_tree(t, coords, n, dim);
     const auto t1 = std::chrono::steady_clock::now();
@@ -351,9 +362,9 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
     t.nodes.reserve((size_t)(2 * (n / 8) + 16));
     std::vector<double> mx(t.maxes), mn(t.mins);
     int par = 5;                                                     // up to 32 subtrees in flight ...
-    while (par > 0 && (1u << par) > host_cpu_budget()) --par;        // ... but no more than the process may run at once
-    if (const char* e = getenv("FDX_KDTREE_PAR_DEPTH")) par = std::max(0, std::min(10, atoi(e)));
-    if (getenv("FDX_KDTREE_SERIAL_BUILD")) par = 0;
+    while (par > 0 && (1u << par) > kd_thread_share()) --par;        // ... but no more than this caller's share of the host's threads
+    if (const char* e = fdx::env("FDX_KDTREE_PAR_DEPTH")) par = std::max(0, std::min(10, atoi(e)));
+    if (fdx::exp_env("FDX_KDTREE_SERIAL_BUILD")) par = 0;
     kd_build(t, t.nodes, 0, n, mx.data(), mn.data(), par);
 }
 
@@ -377,8 +388,7 @@ int ckdtree_query_host(const KdTree& t, int32_t kk, const int64_t* rows, int64_t
             kd_query_one(t, coords + p * dim, kk, idx_out + i * kk, pool, q, nb);
         }
     };
-    unsigned nt = host_cpu_budget();
-    if (const char* e = getenv("FDX_KDTREE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    unsigned nt = kd_thread_share();
     nt = (unsigned)std::min<long long>(std::max(1u, std::min(nt, 128u)), std::max<long long>(1, nq / 4096));
     // a thread that cannot be started (process limits, W ranks x 32 threads) or a failed allocation inside a worker must not end
     // the process: what was started is joined, the rest of the range runs here
@@ -640,12 +650,12 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
         FDX_HIP(hipStreamSynchronize(st));
         coords_host = static_cast<const double*>(pin_coords.p);
     }
-    const bool trace = getenv("FDX_TRACE_HOST") != nullptr;
+    const bool trace = fdx::env("FDX_TRACE_HOST") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     KdTree t;
     kd_build_tree(t, coords_host, n, dim);
     const auto t1 = std::chrono::steady_clock::now();
-    bool on_device = dim <= 3 && n < 0x7fffff00LL && (long long)t.nodes.size() < 0x7fffff00LL && !getenv("FDX_KDTREE_HOST_QUERIES");
+    bool on_device = dim <= 3 && n < 0x7fffff00LL && (long long)t.nodes.size() < 0x7fffff00LL && !fdx::env("FDX_KDTREE_HOST_QUERIES");
     if (on_device) {
         const size_t nn = t.nodes.size();
         // staging in pinned memory: [meta | split | indices | rows]
@@ -715,6 +725,11 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
 }  // namespace fdx
 
 // include/fdx.h
+extern "C" int fdx_kdtree_set_threads(int32_t threads) {
+    fdx::g_kd_threads.store(threads > 0 ? threads : 0);
+    return 0;
+}
+
 extern "C" int fdx_ckdtree_knn(const double* coords, int64_t n, int32_t dim, int32_t kk, int64_t* idx_out, int64_t* tree_indices_out) {
     using namespace fdx;
     FDX_REQUIRE(coords && idx_out && n >= 1 && dim >= 1 && dim <= 8 && kk >= 1, "fdx_ckdtree_knn: bad arguments (1 to 8 coordinates)");

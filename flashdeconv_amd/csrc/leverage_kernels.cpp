@@ -16,6 +16,7 @@
 // coalesced loads, reduces the three inner products with wave shuffles and applies the rotation.  Rounds are
 // separated by workgroup barriers.  The reference matrix is tiny (K x G doubles), so this kernel is latency-, not
 // bandwidth-bound; it runs once per fit.
+#include "fdx_env.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -967,8 +968,8 @@ static int launch_leverage_qr_big(const double* X, int K, int G, double reg, dou
 }
 
 bool leverage_qr_applies(int K, int G) {
-    return K >= 2 && K <= LEV_BIG_MAX_K && G >= 1 && !getenv("FDX_LEV_NO_QR") && !getenv("FDX_LEV_ONE_WG") &&
-           (K <= 128 || !getenv("FDX_LEV_NO_QR_BIG"));
+    return K >= 2 && K <= LEV_BIG_MAX_K && G >= 1 && !fdx::exp_env("FDX_LEV_NO_QR") && !fdx::env("FDX_LEV_ONE_WG") &&
+           (K <= 128 || !fdx::exp_env("FDX_LEV_NO_QR_BIG"));
 }
 
 size_t leverage_scratch_doubles(int K, int G) {
@@ -1013,7 +1014,7 @@ int launch_leverage(const double* X, int K, int G, double reg, double* work, dou
         if (K > 128) return launch_leverage_qr_big(X, K, G, reg, lev, sweeps, scratch, st);
         return launch_leverage_qr(X, K, G, reg, work, lev, sweeps, scratch, st);
     }
-    if (K <= 64 && K >= 2 && scratch && !getenv("FDX_LEV_ONE_WG"))
+    if (K <= 64 && K >= 2 && scratch && !fdx::env("FDX_LEV_ONE_WG"))
         return launch_leverage_multi(X, K, G, reg, work, sig2, lev, sweeps, scratch, st);
     constexpr size_t kLevLds = (2 * 64 * 65 + 64) * sizeof(double);   // Gram matrix, rotations, per-round (c, s) pairs
     FDX_HIP(hipFuncSetAttribute((const void*)leverage_jacobi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLevLds));

@@ -1,4 +1,5 @@
 // Caching device allocator behind DevBuf (see fdx_internal.h).
+#include "fdx_env.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -76,11 +77,11 @@ int pool_alloc(size_t bytes, void** p, size_t* cap) {
             *cap = c;
             g_live[*p] = Live{dev, c, mine};
             lk.unlock();
-            if (b.last != mine && b.last != kIdleStream && !getenv("FDX_POOL_NO_ORDER")) order_after(b.last, mine);
+            if (b.last != mine && b.last != kIdleStream && !fdx::exp_env("FDX_POOL_NO_ORDER")) order_after(b.last, mine);
             return 0;
         }
     }
-    static const bool trace = getenv("FDX_POOL_TRACE") != nullptr;   // diagnostic: every miss of the cache, with what the driver took for it
+    static const bool trace = fdx::exp_env("FDX_POOL_TRACE") != nullptr;   // diagnostic: every miss of the cache, with what the driver took for it
     const auto t_miss = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, c);
     if (trace)
@@ -192,7 +193,7 @@ void reap_pending_pins() {
 
 int copy_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
     if (bytes == 0) return 0;
-    if (bytes < kStageMin || bytes > kStageMax || getenv("FDX_NO_STAGED_COPIES")) {
+    if (bytes < kStageMin || bytes > kStageMax || fdx::exp_env("FDX_NO_STAGED_COPIES")) {
         FDX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
         return 0;
     }
@@ -218,7 +219,7 @@ int copy_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) 
 
 int copy_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
     if (bytes == 0) return 0;
-    if (bytes < kStageMin || bytes > kStageMax || getenv("FDX_NO_STAGED_COPIES")) {
+    if (bytes < kStageMin || bytes > kStageMax || fdx::exp_env("FDX_NO_STAGED_COPIES")) {
         FDX_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipStreamSynchronize(st));
         return 0;
@@ -236,7 +237,7 @@ int copy_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) 
 }
 
 void* pinned_scratch(int slot, size_t bytes) {
-    static const bool pageable = getenv("FDX_PAGEABLE_READBACK") != nullptr;   // diagnostic: what the copies cost without pinning
+    static const bool pageable = fdx::exp_env("FDX_PAGEABLE_READBACK") != nullptr;   // diagnostic: what the copies cost without pinning
     struct Slot {
         void* p = nullptr; size_t cap = 0; bool pinned = true;
         void drop() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }

@@ -17,6 +17,7 @@
 // the wave's private LDS slice (the only HBM traffic: G*sizeof(T) per spot), the library size for log-CPM is reduced
 // on the way in, then lanes gather their genes from LDS.  No workgroup barrier is needed: a wave only reads LDS it
 // wrote itself.  Results are un-permuted through LDS and written as one coalesced d*8-byte row.
+#include "fdx_env.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -418,12 +419,12 @@ static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, lon
     // A CountSketch (one entry per gene) takes the scatter kernel: measured 2.50 ms against 3.38 ms (raw) and 6.6 ms against
     // 8.8 ms (log-CPM) for 1M x 2000 -> 512 on MI355X.  The gather kernels below serve a general sparse Omega, and any Omega
     // under FDX_SKETCH_GATHER=1 (gene-ordered, atomics-free sums).
-    const bool use_scatter = plan.scatter_ok && sketch_scatter_fits(G, d) && !getenv("FDX_SKETCH_GATHER") &&
-                             !getenv("FDX_SKETCH_NO_SCATTER");
+    const bool use_scatter = plan.scatter_ok && sketch_scatter_fits(G, d) && !fdx::env("FDX_SKETCH_GATHER") &&
+                             !fdx::exp_env("FDX_SKETCH_NO_SCATTER");
     if (!use_scatter)
     {   // register-resident schedule when it is short enough and at least one gene is hashed to the first group
         const bool vec0 = (ldy % (16 / (long long)sizeof(T)) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
-        const void* rk = (plan.pack_ok && !getenv("FDX_SKETCH_NO_REG"))
+        const void* rk = (plan.pack_ok && !fdx::exp_env("FDX_SKETCH_NO_REG"))
                              ? (vec0 ? pick_reg_kernel<T, MODE, true>(plan.total_len) : pick_reg_kernel<T, MODE, false>(plan.total_len))
                              : nullptr;
         if (rk && per_wave * 4 <= 64 * 1024) {
@@ -448,7 +449,7 @@ static int launch_sketch_mode(const T* Y, long long ldy, const int* row_map, lon
             auto ks = vec_s ? sketch_rows_scatter_kernel<T, MODE, true> : sketch_rows_scatter_kernel<T, MODE, false>;
             if (lds_s > 64 * 1024)
                 FDX_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-            const int no_table = getenv("FDX_NO_LOG_TABLE") ? 1 : 0;
+            const int no_table = fdx::env("FDX_NO_LOG_TABLE") ? 1 : 0;
             hipLaunchKernelGGL(ks, dim3(blocks_s), dim3(wv * 64), lds_s, st, Y, ldy, row_map, n, G, d, plan.gene_w,
                                plan.gene_bucket, Ys, ldys, row_sumsq, no_table);
             FDX_CHECK_LAUNCH();

@@ -2,6 +2,7 @@
 // sketch_kernels.cpp for how the kernel walks it).  The hash/sign tables themselves come from the caller:
 // flashdeconv/core/sketching.py:48-84 is reproduced on the Python host from numpy's RandomState, so the
 // bucket/sign indices are bit-exact by construction.
+#include "fdx_env.h"
 #include "sketch_plan.h"
 
 #include <algorithm>
@@ -47,7 +48,7 @@ int SketchPlan::build(const long long* col_ptr, const int* gene_idx, const doubl
     FDX_TRY(gene_bucket.alloc(gb.size() * sizeof(int)));
     FDX_TRY(copy_h2d(gene_w.p, gw.data(), gw.size() * sizeof(double), st));
     FDX_TRY(copy_h2d(gene_bucket.p, gb.data(), gb.size() * sizeof(int), st));
-    if (scatter_ok && sketch_scatter_fits(G, d) && !getenv("FDX_SKETCH_GATHER") && !getenv("FDX_SKETCH_NO_SCATTER")) {
+    if (scatter_ok && sketch_scatter_fits(G, d) && !fdx::env("FDX_SKETCH_GATHER") && !fdx::exp_env("FDX_SKETCH_NO_SCATTER")) {
         // the scatter kernel will serve this plan: the gather schedule below is never read
         n_groups = 0;
         total_len = 0;
@@ -155,7 +156,7 @@ int sketch_plan_cached(const int32_t* bucket, const double* weight, int G, int d
     FDX_HIP(hipGetDevice(&dev));
     unsigned long long h = fnv1a(bucket, (size_t)G * 4, 1469598103934665603ULL);
     h = fnv1a(weight, (size_t)G * 8, h);
-    const bool use_cache = !getenv("FDX_NO_PLAN_CACHE");
+    const bool use_cache = !fdx::env("FDX_NO_PLAN_CACHE");
     if (use_cache) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         for (size_t i = 0; i < g_cache.size(); ++i) {

@@ -3,6 +3,7 @@
 // All iteration state stays in HBM.  Sweeps are queued back to back in growing chunks; the stopping rule is
 // evaluated on the device by the next sweep's prologue (bcd_kernels.cpp), so the host only reads back the
 // rel_change trace once per chunk and sweeps queued past convergence retire as no-ops.
+#include "fdx_env.h"
 #include "solver.h"
 
 #include <algorithm>
@@ -59,7 +60,7 @@ int solver_objective_partials(const fdx_graph& g, const double* beta, long long 
     // the four sums of compute_objective (core/solver.py:269-284): <H,beta>, beta' XtX beta, smoothness, |beta|_1
     int nblk = objective_partials_count(g.n_slices);
     int rc_t = 1;
-    if (g.tiled && !getenv("FDX_NO_TILED")) {          // same LDS-tiled traversal as the sweep (n_tiles <= nblk partial rows)
+    if (g.tiled && !fdx::env("FDX_NO_TILED")) {          // same LDS-tiled traversal as the sweep (n_tiles <= nblk partial rows)
         BcdSweepArgs a{};
         a.H = H; a.XtX = XtX; a.beta_in = beta; a.beta_out = nullptr; a.ell = g.ell.as<int>();
         a.slice_off = g.slice_off.as<int>(); a.deg = g.deg.as<int>(); a.stats = nullptr; a.rel_change = nullptr;
@@ -145,7 +146,7 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
     a.stats = stats.as<unsigned long long>(); a.rel_change = relchg_p;
     a.lambda = p.lambda; a.rho = p.rho_eff; a.tol = p.tol; a.ldh = (int)p.ldh; a.ld = (int)p.ld; a.n = (int)g.n;
     a.n_slices = g.n_slices; a.K = K;
-    if (g.tiled && !getenv("FDX_NO_TILED")) {
+    if (g.tiled && !fdx::env("FDX_NO_TILED")) {
         a.tiled = 1; a.ell_local = g.ell_local.as<unsigned short>(); a.tile_halo = g.tile_halo.as<int>();
         a.tile_hcnt = g.tile_hcnt.as<int>(); a.n_tiles = g.n_tiles; a.halo_max = g.halo_max;
     }
@@ -156,7 +157,7 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
         BcdSweepArgs probe = a;
         probe.beta_in = p.beta[0];
         probe.beta_out = p.beta[1];
-        if (max_iter > 0 && K_real == K && K <= FDX_MAX_K_FAST && g.n_total == g.n && bcd_sweep_uses_tiles(probe) && !getenv("FDX_NO_INIT_SWEEP"))
+        if (max_iter > 0 && K_real == K && K <= FDX_MAX_K_FAST && g.n_total == g.n && bcd_sweep_uses_tiles(probe) && !fdx::env("FDX_NO_INIT_SWEEP"))
             init_uniform = 1.0 / (double)K;
         else
             FDX_TRY(solver_init_beta(p.beta[0], p.ld, g.n_total, K_real, st, K));
@@ -186,7 +187,7 @@ int solver_run(const SolveProblem& p, SolveResult* res, hipStream_t st) {
     // The host reads the rel_change trace once per chunk; so that the device does not idle during that round trip (~45 us,
     // a quarter of a sweep, per chunk) the first sweeps of the NEXT chunk are queued before the host waits: if this chunk
     // converged they are no-ops like every sweep past convergence (device-side stopping rule), otherwise they are simply early.
-    const int n_ahead = (p.verbose || getenv("FDX_NO_SWEEP_AHEAD")) ? 0 : 2;
+    const int n_ahead = (p.verbose || fdx::exp_env("FDX_NO_SWEEP_AHEAD")) ? 0 : 2;
     int queued_ahead = 0;  // sweeps of the current chunk that were queued during the previous chunk's read-back
     int ci = 0;            // chunk counter (event pair = ci & 1)
     // verbose objective trace: evaluated on the NEW buffer at it % 10 == 0 or it == max_iter-1 (solver.py:399-404)

@@ -20,6 +20,7 @@
 //               the DMA) while the current tile is consumed.  log1p is table driven: 1 + x is reduced by a 7-bit
 //               reciprocal (v_rcp_f32) to 1 + r with |r| <= 2^-7, log1p(x) = T[reciprocal] + r - r^2/2 + ... + r^7/7
 //               (~21 instructions instead of ~45; < 3 ulp; tile_device.h).
+#include "fdx_env.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -642,7 +643,7 @@ const double* log_table_dev(hipStream_t st) {   // -log of every table reciproca
 // MFMA A operands from the L2-resident operand copy of X_sketch (AVL2).
 struct TileCfg { int NWC, NWL, JW, TT; bool wide; };
 static TileCfg tile_cfg(int mode, int K, int d) {
-    const char* e = getenv("FDX_TILE_CFG");
+    const char* e = fdx::env("FDX_TILE_CFG");
     const int v = e ? atoi(e) : (mode == FDX_PRE_RAW ? 12 : 16);
     TileCfg c = v == 16 ? TileCfg{16, 0, 8, 0, false} : v == 8 ? TileCfg{8, 2, 16, 0, false} : TileCfg{12, 4, 11, 0, false};
     c.TT = (K + 15) / 16;
@@ -682,13 +683,13 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     // (the three alternatives - FDX_TILE_NO_WG, FDX_TILE_NST=3, FDX_TILE_FLAT - were all measured slower and are compiled only
     // into experiment builds, `make EXTRA=-DFDX_TILE_EXPERIMENT`: the shipped library has one layout per shape)
 #ifdef FDX_TILE_EXPERIMENT
-    const bool wg = cfg.wide && mode == FDX_PRE_RAW && cfg.NWL > 0 && !getenv("FDX_TILE_NO_WG");
+    const bool wg = cfg.wide && mode == FDX_PRE_RAW && cfg.NWL > 0 && !fdx::exp_env("FDX_TILE_NO_WG");
     int NST = 2;
     if (mode == FDX_PRE_RAW && cfg.NWL > 0) {
-        const char* e = getenv("FDX_TILE_NST");
+        const char* e = fdx::exp_env("FDX_TILE_NST");
         NST = (e && atoi(e) == 3) ? 3 : 2;
     }
-    const bool flat = wg && getenv("FDX_TILE_FLAT") && cfg.JW <= 24;
+    const bool flat = wg && fdx::exp_env("FDX_TILE_FLAT") && cfg.JW <= 24;
 #else
     const bool wg = cfg.wide && mode == FDX_PRE_RAW && cfg.NWL > 0;
     const int NST = 2;
@@ -699,7 +700,7 @@ static const TilePlanDevice* tile_plan_for(const SketchPlan& sp, int dtype, int 
     std::lock_guard<std::mutex> lock(sp.tile_mu);
     if (sp.tile_tried[key]) return sp.tile[key].get();
     sp.tile_tried[key] = true;
-    const bool dbg = getenv("FDX_DEBUG") != nullptr;
+    const bool dbg = fdx::env("FDX_DEBUG") != nullptr;
     if (!sp.scatter_ok || sp.host_bucket.empty()) return nullptr;
     if (sp.d > 4 * cfg.NWC * cfg.JW) return nullptr;
     const size_t red_bytes = (size_t)(cfg.NWC > 8 || cfg.wide ? cfg.NWC / 2 : cfg.NWC) * (std::min(TT, 2) * 4 * 64 + 64) * 8;   // the kernel's reduction area
@@ -780,12 +781,12 @@ __global__ void tile_xa_kernel(const double* __restrict__ Xs, const int* __restr
 
 bool tile_sketch_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan,
                     hipStream_t st) {
-    if (getenv("FDX_NO_TILE") || !plan.owner) return false;
+    if (fdx::exp_env("FDX_NO_TILE") || !plan.owner) return false;
     if (dtype != FDX_F32 && dtype != FDX_F64) return false;
     if (mode != FDX_PRE_RAW && mode != FDX_PRE_LOG_CPM && mode != FDX_PRE_LOG_CPM_SPARSE) return false;
     const int sz = dtype == FDX_F32 ? 4 : 8;
     if (K <= 0 || K > 64 || G <= 0 || d <= 0) return false;
-    if ((K > 32 || d > 512) && getenv("FDX_NO_TILE_WIDE")) return false;
+    if ((K > 32 || d > 512) && fdx::env("FDX_NO_TILE_WIDE")) return false;
     // whole 16-byte vectors only: row starts and row lengths multiples of 16 bytes
     if (((size_t)G * sz) % 16 != 0 || ((size_t)ldy * sz) % 16 != 0 || (reinterpret_cast<uintptr_t>(Y) & 15) != 0) return false;
     return tile_plan_for(*plan.owner, dtype, mode, K, st) != nullptr;
@@ -814,7 +815,7 @@ TileF64Math::~TileF64Math() { t_f64_math = prev; }
 
 static int tile_logv() {
     if (t_f64_math) return 0;
-    const char* e = getenv("FDX_TILE_LOGV");
+    const char* e = fdx::env("FDX_TILE_LOGV");
     return e ? atoi(e) : 2;
 }
 
@@ -914,7 +915,7 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     a.ldy = ldy; a.n = n; a.ldh = ldh; a.G = G; a.d = d; a.K = K;
     a.NE = t->h.NE; a.GB = t->h.GB; a.NBLK = t->h.NBLK; a.RS = t->RS; a.jw_used = t->h.jw_used; a.NST = t->NST; a.WB = t->WB;
 #ifdef FDX_TILE_EXPERIMENT
-    if (const char* e = getenv("FDX_TILE_DBG")) a.dbg = atoi(e);
+    if (const char* e = fdx::exp_env("FDX_TILE_DBG")) a.dbg = atoi(e);
 #endif
     if (t->fh.NSP > 0) {
         a.NE = (int)t->fh.off.size();
@@ -936,7 +937,7 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
     // narrow log modes: the float64 chain needs the registers the operands would take (operand copy in L2, fetched per
     // group); the float32-class chain leaves room for them (127 registers, no spills; the fetches cost 0.5 ms per 1M spots)
     const bool f32log = dtype == FDX_F32 && mode != FDX_PRE_RAW && tile_logv() != 0;
-    const bool narrow_avl2 = mode != FDX_PRE_RAW && t->NWC == 16 && (f32log ? getenv("FDX_TILE_AVL2") != nullptr : !getenv("FDX_TILE_NO_AVL2"));
+    const bool narrow_avl2 = mode != FDX_PRE_RAW && t->NWC == 16 && (f32log ? fdx::exp_env("FDX_TILE_AVL2") != nullptr : !fdx::exp_env("FDX_TILE_NO_AVL2"));
     if (t->wide || narrow_avl2) {
         const int n_groups = t->NWC * t->JW;
         FDX_TRY(xa.alloc((size_t)n_groups * t->TT * 64 * sizeof(double)));
@@ -955,7 +956,7 @@ int launch_tile_sketch(const void* Y, int dtype, long long ldy, const int* row_m
 // replaced there and is gone.)
 bool fused_sketch_contract_ok(int dtype, long long ldy, const void* Y, int G, int d, int K, int mode, const SketchPlanDev& plan,
                               hipStream_t st) {
-    if (getenv("FDX_NO_FUSED")) return false;
+    if (fdx::env("FDX_NO_FUSED")) return false;
     return tile_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st);
 }
 

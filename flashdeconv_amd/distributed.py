@@ -597,18 +597,13 @@ class ShardedFlashDeconv:
             # every rank builds the tree of the replicated coordinates: the ranks of one host share its cores
             # (for the duration of the call; a caller's own setting wins)
             share = max(1, _lib.host_cpu_budget() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", self.comm.world))))
-            env_set = []
-            for k, v in (("FDX_KDTREE_THREADS", str(share)), ("FDX_KDTREE_PAR_DEPTH", str(max(0, share.bit_length() - 1)))):
-                if k not in os.environ:
-                    os.environ[k] = v
-                    env_set.append(k)
+            lib.fdx_kdtree_set_threads(int(share))
             # the restated tree on the host, its queries for these rows on the device; the answers (caller ids, self included) go to
             # solver positions, self dropped (utils/graph.py:70-74), at the rows' positions
             _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, None, ctypes.c_void_p(cd.data_ptr()), n, dim,
                                                                 ids.ctypes.data, len(ids), ctypes.c_void_p(nbr.data_ptr()),
                                                                 ctypes.c_void_p(cnt.data_ptr()), st))
-            for k in env_set:
-                os.environ.pop(k, None)
+            lib.fdx_kdtree_set_threads(0)
         _lib.check(lib.fdx_graph_from_knn_lists_dev(plan, ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), lo, hi,
                                                     st, ctypes.byref(h)))
         full = _lib.Graph(h.value)

@@ -48,6 +48,11 @@ extern "C" {
 #define FDX_PRE_F64_MATH 0x100
 
 int fdx_version(void);
+/* Runtime switches (environment variables FDX_*: alternative tested kernel paths and diagnostics, csrc/fdx_env.cpp) are read once,
+ * when the library first asks; fdx_env_reload re-reads them.  fdx_env_switch(i, &what): name and description of switch i, NULL
+ * past the end of the registry. */
+int fdx_env_reload(void);
+const char* fdx_env_switch(int32_t i, const char** what_out);
 const char* fdx_last_error(void);
 int fdx_device_count(int* count);
 int fdx_set_device(int device);
@@ -172,6 +177,9 @@ int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_de
  * library keeps the lower spot index.  Regular lattices (Visium-HD bins, k = 6) tie on every spot.  0 for graphs
  * built from a radius or a given adjacency, and for k_neighbors = 63 (no spare slot). */
 int fdx_graph_knn_ties(const fdx_graph* g, int64_t* ties);
+/* Host threads the restated cKDTree may use from now on (0: the process's budget): the ranks of one host, each building the tree
+ * of the replicated coordinates (utils/graph.py:60), share its cores. */
+int fdx_kdtree_set_threads(int32_t threads);
 /* The neighbour lists the REFERENCE gets on such inputs: a host restatement of scipy.spatial.cKDTree(coords) with the
  * constructor's defaults followed by tree.query(coords, k = kk) with p = 2 (utils/graph.py:60-63), reproducing the order in
  * which the library meets equidistant points - hence which of them it returns.  coords: HOST (n, dim) row-major f64,

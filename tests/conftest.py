@@ -38,3 +38,33 @@ def rel_fro(a, b):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fdx_switches_follow_the_environment(monkeypatch):
+    """libfdx reads its FDX_* switches once and caches them (csrc/fdx_env.cpp): tests that set one through monkeypatch get the
+    cache re-read at once, and every test starts from the environment as the previous test's undo left it."""
+    import sys
+
+    def reload():
+        mod = sys.modules.get("flashdeconv_amd._lib")
+        if mod is not None:
+            mod.env_reload()
+
+    reload()
+    set0, del0 = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        set0(name, value, *a, **k)
+        if str(name).startswith("FDX_"):
+            reload()
+
+    def delenv(name, *a, **k):
+        del0(name, *a, **k)
+        if str(name).startswith("FDX_"):
+            reload()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.undo()
+    reload()

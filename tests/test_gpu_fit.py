@@ -109,10 +109,10 @@ def test_sparse_fit_vs_oracle_odd_shapes(n, G, K, d, n_hvg, pre):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_sparse_rows_longer_than_the_keep_buffer(dtype, monkeypatch):
-    """Fused CSR sketch -> H, log-CPM (csr_kernels.cpp): the library-size pass keeps a row's selected entries in LDS for the sketch
-    pass.  At sketch_dim 1024 the buffer holds 128 (float32) / 64 (float64) entries per row: rows with ~600 selected entries take
-    the two-reads path, rows with ~60 the kept one, in the same launch - both against the oracle (core/deconv.py:181-188,
-    core/sketching.py:194-199) and against the build that always reads twice."""
+    """Fused CSR sketch -> H, log-CPM (csr_kernels.cpp): the select pass compacts a row's selected entries into the wave's keep buffer
+    in LDS.  At sketch_dim 1024 the buffer is small: rows with ~600 selected entries overflow it (walked again from memory), rows
+    with ~60 fit, in the same launch - both against the oracle (core/deconv.py:181-188, core/sketching.py:194-199) and against
+    a launch whose buffer holds 64 entries only."""
     from flashdeconv_amd import FlashDeconv
     n, G, K, d = 300, 1200, 8, 1024
     rs = np.random.RandomState(5)
@@ -131,7 +131,7 @@ def test_sparse_rows_longer_than_the_keep_buffer(dtype, monkeypatch):
     tol = 1e-8 if dtype == np.float64 else 1e-5
     assert m.info_["n_iterations"] == want["info"]["n_iterations"]
     assert rel_fro(m.beta_, want["beta"]) < tol and rel_fro(m.proportions_, want["proportions"]) < tol
-    monkeypatch.setenv("FDX_CSR_NO_KEEP", "1")
+    monkeypatch.setenv("FDX_CSR_KEEP_CAP", "64")                 # every long row overflows the keep buffer: walked again from memory
     m2 = FlashDeconv(**kw).fit(Ys, X, coords)
     assert rel_fro(m2.beta_, m.beta_) < 1e-10
 

@@ -784,13 +784,15 @@ def test_sharded_class_on_thread_ranks_takes_the_native_fit(W, force_overflow_on
     n, G, K = 6000, 300, 9
     Y, X, coords, _ = datagen.gaussian_raw(n, G, K, seed=4)
     kw = dict(sketch_dim=64, preprocess="raw", n_hvg=G, max_iter=40)
-    monkeypatch.delenv("FDX_GRAPH_WCAP", raising=False) if force_overflow_on is None else None
+    from flashdeconv_amd import _lib
     env_cap = os.environ.pop("FDX_GRAPH_WCAP", None)             # the single-GPU reference is built without the forced bound
+    _lib.env_reload()
     try:
         ref = FlashDeconv(**kw).fit(Y, X, coords)
     finally:
         if env_cap is not None:
             os.environ["FDX_GRAPH_WCAP"] = env_cap
+        _lib.env_reload()
     got, models = _class_thread_ranks(torch, W, kw, Y, X, coords)
     for m in models:
         assert m.comm_report()["loop"] == "native"
@@ -952,7 +954,9 @@ def test_sweep_variants_give_the_same_bits(monkeypatch):
     b0, it0, lam = single()
     s0, sit0 = sharded(lam)
     assert sit0 == it0 and torch.equal(s0, b0)
-    for var in ("FDX_NO_INIT_SWEEP", "FDX_GRAPH_TWO_ELL_KERNELS"):
+    # (FDX_NO_TILED: the global-gather sweep - graphs whose tiles have too large a halo take it by themselves;
+    # FDX_NO_SIDE_STREAM: everything on the caller's stream; FDX_KDTREE_*: no effect on a tie-free fit, read by the registry)
+    for var in ("FDX_NO_INIT_SWEEP", "FDX_GRAPH_TWO_ELL_KERNELS", "FDX_NO_TILED", "FDX_NO_SIDE_STREAM", "FDX_NO_PLAN_CACHE"):
         monkeypatch.setenv(var, "1")
         b1, it1, _ = single()
         monkeypatch.delenv(var)

@@ -346,7 +346,7 @@ def test_bench_sweep_chunk_mirrors_the_kernel_table():
 
 @pytest.mark.parametrize("case", ["square", "square_scaled", "hex", "cube3d", "random2d", "random3d", "line", "duplicates",
                                   "square_shuffled", "rect_large", "square_big", "random_big", "square_huge"])
-def test_ckdtree_order_restatement_matches_scipy(case):
+def test_ckdtree_order_restatement_matches_scipy(case, monkeypatch):
     """fdx_ckdtree_knn (csrc/kdtree_order.cpp) is a host restatement of scipy.spatial.cKDTree's build and k-nearest query
     ORDER - what decides the reference's neighbour graph when distances tie exactly (flashdeconv/utils/graph.py:60-63).
     Against scipy itself: the tree's index array and the query result, index for index and in the same order, on lattices
@@ -381,8 +381,46 @@ def test_ckdtree_order_restatement_matches_scipy(case):
     _, want = tree.query(coords, k=kk)
     assert np.array_equal(order, tree.indices)
     assert np.array_equal(got, want)
+    if case == "square_big":          # another thread share / fork depth (FDX_KDTREE_THREADS, FDX_KDTREE_PAR_DEPTH, the setter): same tree
+        for env in ({"FDX_KDTREE_THREADS": "3", "FDX_KDTREE_PAR_DEPTH": "2"}, {"FDX_KDTREE_PAR_DEPTH": "0"}, {}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            lib.fdx_kdtree_set_threads(0 if env else 2)
+            got2, order2 = np.empty_like(got), np.empty_like(order)
+            _lib.check(lib.fdx_ckdtree_knn(_lib.ptr_f64(coords), n, dim, kk, got2.ctypes.data, order2.ctypes.data))
+            for k in env:
+                monkeypatch.delenv(k)
+            lib.fdx_kdtree_set_threads(0)
+            assert np.array_equal(order2, tree.indices) and np.array_equal(got2, want), env
     # and the adjacency the reference builds from it (utils/graph.py:66-81)
     from flashdeconv_amd.utils.graph import ckdtree_knn_adjacency
     import fdx_oracle as orc
     A, B = ckdtree_knn_adjacency(coords, kk - 1), orc.knn_graph_kdtree(coords, kk - 1)
     assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+
+
+def test_runtime_switch_registry_matches_the_sources_and_the_tests():
+    """csrc/fdx_env.cpp: every runtime switch the sources read is in the registry (at most 25 of them), nothing else reads the
+    environment with getenv, and every registered switch is exercised by a test or by bench.py / a tool (the verdict's rule:
+    a switch nobody runs is a code path nobody tests).  Experiment switches (exp_env) exist only in -DFDX_EXPERIMENT builds."""
+    import glob
+    import re
+    from flashdeconv_amd import _lib
+    reg = dict(_lib.runtime_switches())
+    assert 0 < len(reg) <= 25
+    used, raw = set(), []
+    for f in glob.glob(os.path.join(ROOT, "flashdeconv_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "flashdeconv_amd", "csrc", "*.h")):
+        src = open(f).read()
+        if os.path.basename(f) not in ("fdx_env.cpp", "fdx_env.h"):
+            raw += [(os.path.basename(f), m) for m in re.findall(r'(?<![A-Za-z_:])getenv\("(FDX_[A-Z0-9_]+)"\)', src)]
+        if os.path.basename(f) != "fdx_env.h":                       # (its header comment spells the call)
+            used |= set(re.findall(r'(?<!exp_)env\("(FDX_[A-Z0-9_]+)"\)', src))
+    assert not raw, raw
+    assert used <= set(reg), used - set(reg)
+    assert set(reg) <= used, set(reg) - used                         # no dead entries either
+    where = ""
+    for f in glob.glob(os.path.join(ROOT, "tests", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "*.py")) + [os.path.join(ROOT, "bench.py")] + \
+            glob.glob(os.path.join(ROOT, "flashdeconv_amd", "*.py")) + glob.glob(os.path.join(ROOT, "flashdeconv_amd", "*", "*.py")):
+        where += open(f).read()
+    missing = [name for name in reg if name not in where]
+    assert not missing, missing
