@@ -166,8 +166,11 @@ __device__ __forceinline__ unsigned lane_off(unsigned off) {
 // INIT = true (first sweep of a solve that starts from the uniform 1/K, core/solver.py:372): the old abundances are the constant
 // init_v everywhere - own spots and halo alike - and are not read: the start vector is never written to HBM (240 MB at 1M x 30)
 // and the first sweep moves two thirds of a sweep's bytes.  Same arithmetic on the same values: same bits.
+#ifndef FDX_SWEEP_WPE
+#define FDX_SWEEP_WPE 1
+#endif
 template <int K, int KC, bool OBJ, bool QUAD = true, bool INIT = false>
-__global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <= 96)) ? 2 : 1) void bcd_sweep_tiled_kernel(
+__global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <= 96)) ? 2 : (OBJ ? 1 : FDX_SWEEP_WPE)) void bcd_sweep_tiled_kernel(
     const double* __restrict__ H, const double* __restrict__ XtX, const double* __restrict__ beta_in,
     double* __restrict__ beta_out, const unsigned short* __restrict__ ell_local, const int* __restrict__ slice_off,
     const int* __restrict__ deg, const int* __restrict__ tile_halo, const int* __restrict__ tile_hcnt,

@@ -681,6 +681,10 @@ static int sharded_solve_impl(fdx_comm* c, const fdx_graph* g, const double* H_d
     const long long tiles_max = g->world_n > 0 ? ((g->world_n + 255) / 256 + W - 1) / W + 1 : (1LL << 40);
     const bool piggy_ok = W > 1 && !c->loopback && (c->nccl || c->local) && !fdx::exp_env("FDX_STATS_ALLREDUCE") &&
                           (tiles_max < split_min_tiles || fdx::env("FDX_NO_OVERLAP") != nullptr);
+    // (piggy_ok is the JOB's decision - world size and spot count only.  A rank whose own shard is larger than the balanced bound, from
+    // bounds that fdx_graph_localize accepted but shard_bounds() would not have made, must not split on its own: it would all-reduce
+    // while its peers piggy-back - a mismatched communicator.  It sweeps unsplit like everybody else.)
+    if (piggy_ok) split = false;
     if (split) {
         FDX_TRY(build_tile_lists(*g, st));          // no-op for a graph of the queued shard build: its lists were made on the device
         split = g->n_tiles_boundary > 0 && g->n_tiles_interior > 0;
