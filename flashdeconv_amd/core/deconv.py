@@ -240,10 +240,10 @@ class FlashDeconv:
             raise ValueError(f"coords must be 2D with at least 1 coordinate dimension, got shape {tuple(coords.shape)}")
         from ..utils.graph import check_coord_dims
         check_coord_dims(int(coords.shape[0]), int(coords.shape[1]), self.spatial_method == "knn")
-        if self.spatial_method == "knn" and min(int(self.k_neighbors), int(coords.shape[0]) - 1) > 63:
-            # the reference takes any k (utils/graph.py:51); the device's k-NN lists hold at most 64 entries per spot (self included)
-            raise ValueError(f"k_neighbors = {self.k_neighbors}: at most 63 neighbours per spot on this backend "
-                             "(spatial_method='radius' builds denser graphs)")
+        # the reference takes any k (utils/graph.py:51); the device's k-NN lists hold at most 64 entries per spot (self included):
+        # above that the lists come from the restated cKDTree on the host (utils/graph.py: ckdtree_knn_adjacency - the reference's
+        # own neighbours, ties included) and the adjacency is uploaded as given (caller's spot order, untiled sweep)
+        big_k = self.spatial_method == "knn" and min(int(self.k_neighbors), int(coords.shape[0]) - 1) > 63
         _lib.require_gpu()
         lib = _lib.load()
         log = print if self.verbose else (lambda *a, **k: None)
@@ -298,7 +298,7 @@ class FlashDeconv:
                 c_ptr = cbuf.ptr
             dim = int(coords.shape[1])
             g_method, g_k, g_radius = self._graph_request(coords, coords_host)
-            graph_early = G_all > self.n_hvg
+            graph_early = G_all > self.n_hvg and not big_k
             t_graph = t_graph_done = None
             if self._graph is not None:
                 self._graph.close()
@@ -374,13 +374,19 @@ class FlashDeconv:
             ldy = G
 
             # Step 4 runs here, under the leverage SVD (no data dependence between core/deconv.py:318 and :358)
-            if not graph_early:
+            if big_k:
+                from ..utils.graph import ckdtree_knn_adjacency
+                t_graph = time.perf_counter()
+                A = ckdtree_knn_adjacency(coords_host if coords_host is not None else _lib.tensor_to_host(coords), int(self.k_neighbors))
+                self._graph = _lib.Graph.from_csr(A.indptr, A.indices, n)
+                self._adjacency = A                      # (adjacency_: the host matrix itself)
+            elif not graph_early:
                 t_graph = time.perf_counter()
                 gh = ctypes.c_void_p()
                 _lib.check(lib.fdx_graph_build_dev(c_ptr, n, dim, g_method, g_k, g_radius, None, ctypes.byref(gh)))
                 self._graph = _lib.Graph(gh.value)
             n_ties = 0
-            if self.spatial_method == "knn" and self.knn_ties == "ckdtree":
+            if self.spatial_method == "knn" and self.knn_ties == "ckdtree" and not big_k:
                 # the reference's tie order, on request: only when the device build met ties (this question waits for the
                 # build, which otherwise completes behind the sketch) the lists come from the host restatement of scipy's
                 # tree (csrc/kdtree_order.cpp) and the graph is rebuilt from the reference's own adjacency
@@ -435,7 +441,7 @@ class FlashDeconv:
             # "auto": the question "is any k-th neighbour tied?" is answered inside the fit, where the graph's counts are taken
             # over anyway - tie-free inputs pay nothing; on ties the call returns before the solve and the graph is rebuilt on the
             # reference's choice
-            prm.stop_on_ties = 1 if (self.spatial_method == "knn" and self.knn_ties == "auto") else 0
+            prm.stop_on_ties = 1 if (self.spatial_method == "knn" and self.knn_ties == "auto" and not big_k) else 0
             log("Step 4: Building spatial graph...")
 
             if output == "torch":

@@ -345,15 +345,24 @@ class ShardedFlashDeconv:
         dist.broadcast(t, src=dist.get_global_rank(self.comm.group, 0) if self.comm.group is not None else 0, group=self.comm.group)
         ident = t.cpu().numpy()
         h = ctypes.c_void_p()
+        err = None
         try:
             _lib.check(lib.fdx_comm_init(ident.ctypes.data, self.comm.rank, self.comm.world, ctypes.byref(h)))
         except _lib.FdxError as e:
+            err = str(e)
+        # every rank must take the same loop: one rank without its communicator and the others inside the native exchange would
+        # wait for each other for ever - the ranks agree on the outcome over torch's group first
+        ok = torch.tensor([0.0 if err else 1.0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.comm.group)
+        if float(ok.item()) < 1.0:
             # LOUD fallback: the Python exchange loop over torch.distributed (same kernels, same bits, slower per iteration)
             import warnings
-            self.native_error_ = str(e)
+            if h.value:
+                lib.fdx_comm_destroy(h)
+            self.native_error_ = err or "libfdx's RCCL communicator could not be created on another rank"
             os.environ["FDX_PY_LOOP"] = "1"          # do not try again in this process
-            warnings.warn(f"libfdx could not create its own RCCL communicator ({e}); the sharded fit falls back to the Python "
-                          "exchange loop over torch.distributed", RuntimeWarning, stacklevel=2)
+            warnings.warn(f"libfdx could not create its own RCCL communicator on every rank ({self.native_error_}); the sharded fit falls "
+                          "back to the Python exchange loop over torch.distributed", RuntimeWarning, stacklevel=2)
             return None
         self._native = h
         return self._native
@@ -425,6 +434,10 @@ class ShardedFlashDeconv:
         assert coords.is_cuda and coords.dtype == torch.float64
         coords = coords.contiguous()
         n, dim = coords.shape
+        if self.spatial_method == "knn" and min(int(self.k_neighbors), int(n) - 1) > 63:
+            # (FlashDeconv takes the host cKDTree route there; a shard plan has no such route: say so before any work)
+            raise ValueError(f"k_neighbors = {self.k_neighbors}: the sharded plan builds k-NN lists of at most 63 neighbours per spot "
+                             "(FlashDeconv on one GPU takes any k; spatial_method='radius' builds denser graphs on shards)")
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for g in (self._local, self._full):
             if g is not None:

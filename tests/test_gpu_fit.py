@@ -721,3 +721,18 @@ def test_anndata_surface_against_the_reference_goldens(kind, where):
     assert rel_fro(st.obsm["alt"].values, g["alt_obsm"]) < 1e-8
     assert [str(c) for c in st.obs["alt_dominant"]] == list(g["alt_dominant"])
     same_params(st.uns["alt_params"], g["alt_uns_json"])
+
+
+def test_more_than_63_neighbours_per_spot_against_the_oracle():
+    """The reference takes any k (utils/graph.py:51: k_actual = min(k, N - 1)); the device's k-NN lists stop at 63.  Above that the
+    lists come from the restated cKDTree on the host and the adjacency goes up as given: same graph, same fit as the oracle."""
+    from flashdeconv_amd import FlashDeconv
+    Y, X, coords, _ = datagen.gaussian_raw(700, 200, 6, seed=9)
+    for k in (64, 100, 5000):                                  # 5000 > n - 1: every spot is every spot's neighbour
+        m = FlashDeconv(sketch_dim=64, preprocess="raw", n_hvg=200, k_neighbors=k, max_iter=30).fit(Y, X, coords)
+        want = orc.fit(Y, X, coords, sketch_dim=64, preprocess_method="raw", n_hvg=200, k_neighbors=k, max_iter=30, graph="kdtree")
+        A, B = m.adjacency_, want["adjacency"].tocsr()
+        assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices), k
+        assert m.info_["n_iterations"] == want["info"]["n_iterations"]
+        np.testing.assert_allclose(m.lambda_used_, want["lambda_used"], rtol=1e-10)
+        assert rel_fro(m.beta_, want["beta"]) < 1e-8, k

@@ -85,9 +85,6 @@ def test_constructor_and_fit_validation_messages():
         m.fit(Y, X, c, cell_type_names=np.array(["a"]))
     with pytest.raises(ValueError, match="Unknown preprocess method"):
         FlashDeconv(preprocess="zscore").fit(Y, X, c)
-    # more than 63 neighbours per spot: refused before any work, naming the limit (k is capped by n - 1 first, utils/graph.py:51)
-    with pytest.raises(ValueError, match="at most 63 neighbours"):
-        FlashDeconv(k_neighbors=80).fit(np.ones((100, 9)), X, np.random.rand(100, 2))
 
 
 def test_countsketch_tables_bit_exact_on_host():
