@@ -179,7 +179,25 @@ def select_hvg(Y, n_top=2000, min_mean=0.0125, max_mean=3.0, min_disp=0.5):
 
 
 def _hvg_from_moments(mean, var, n_top, min_mean, max_mean, min_disp):
-    """Seurat-v3-style binned z-score of the variance, then top-n (utils/genes.py:104-145)."""
+    """Seurat-v3-style binned z-score of the variance, then top-n (utils/genes.py:104-145): libfdx's host restatement of the
+    numpy arithmetic (csrc/hvg_rank.cpp: 0.15 ms instead of 0.9 at 20000 genes, between two device phases of a fit); numpy
+    itself where exactly equal dispersions straddle the cut (the order its sort leaves them in decides) or one is NaN."""
+    mean = np.ascontiguousarray(mean, dtype=np.float64)
+    var = np.ascontiguousarray(var, dtype=np.float64)
+    G = len(mean)
+    idx = np.empty(max(min(int(n_top), G), 1), dtype=np.int64)
+    n_out, amb = ctypes.c_int32(0), ctypes.c_int32(0)
+    pos = np.sort(mean[mean > 0])                        # (numpy's vectorised sort: a tenth of std::sort's time)
+    _lib.check(_lib.load().fdx_hvg_from_moments(_lib.ptr_f64(mean), _lib.ptr_f64(var), G, _lib.ptr_f64(pos), len(pos), min(int(n_top), G),
+                                                float(min_mean), float(max_mean), float(min_disp), _lib.ptr_i64(idx), ctypes.byref(n_out),
+                                                ctypes.byref(amb)))
+    if not amb.value:
+        return idx[:n_out.value].astype(np.intp)
+    return _hvg_from_moments_numpy(mean, var, n_top, min_mean, max_mean, min_disp)
+
+
+def _hvg_from_moments_numpy(mean, var, n_top, min_mean, max_mean, min_disp):
+    """The same in numpy (the reference's own operations)."""
     G = len(mean)
     disp = np.zeros(G)
     pos = mean[mean > 0]

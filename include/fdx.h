@@ -177,6 +177,14 @@ int fdx_graph_info(const fdx_graph* g, int64_t* n, int64_t* nnz, int32_t* max_de
  * library keeps the lower spot index.  Regular lattices (Visium-HD bins, k = 6) tie on every spot.  0 for graphs
  * built from a radius or a given adjacency, and for k_neighbors = 63 (no spare slot). */
 int fdx_graph_knn_ties(const fdx_graph* g, int64_t* ties);
+/* The host tail of select_hvg (utils/genes.py:104-145) on a G-vector of per-gene moments, with numpy's arithmetic (percentile
+ * interpolation, pairwise sums): 20 percentile bins of the positive means, z-score of the variance per bin, the mean / dispersion
+ * filters, the n_top genes of largest dispersion - ascending indices in idx_out (room for n_top), their number in *n_out.
+ * sorted_pos: the n_pos positive means in ascending order (the caller's np.sort).
+ * *ambiguous = 1 (nothing written): exactly equal dispersions straddle the cut, or one is NaN - the order numpy's sort leaves them
+ * in decides, so the caller runs numpy itself.  Pure host code. */
+int fdx_hvg_from_moments(const double* mean, const double* var, int32_t G, const double* sorted_pos, int32_t n_pos, int32_t n_top,
+                         double min_mean, double max_mean, double min_disp, int64_t* idx_out, int32_t* n_out, int32_t* ambiguous);
 /* Host threads the restated cKDTree may use from now on (0: the process's budget): the ranks of one host, each building the tree
  * of the replicated coordinates (utils/graph.py:60), share its cores. */
 int fdx_kdtree_set_threads(int32_t threads);

@@ -421,3 +421,28 @@ def test_runtime_switch_registry_matches_the_sources_and_the_tests():
         where += open(f).read()
     missing = [name for name in reg if name not in where]
     assert not missing, missing
+
+
+def test_hvg_ranking_restatement_equals_numpy():
+    """csrc/hvg_rank.cpp (the host tail of select_hvg, utils/genes.py:104-145, with numpy's arithmetic) against the numpy form of
+    the same - the reference's own operations - on random moment vectors: sizes 1 ... 20000, zero means, NaN means, many exactly
+    equal values (ties across the cut fall back to numpy by design), every n_top regime.  Pure host code: no GPU."""
+    from flashdeconv_amd.utils import genes
+    rs = np.random.RandomState(0)
+    for trial in range(600):
+        G = int(rs.choice([1, 2, 3, 5, 8, 17, 40, 130, 260, 1000, 5000, 20000], p=[.03, .03, .03, .05, .05, .08, .1, .15, .15, .15, .13, .05]))
+        mean = np.abs(rs.randn(G)) * rs.choice([0.01, 0.3, 2.0])
+        var = np.abs(rs.randn(G)) * 0.2
+        mode = trial % 5
+        if mode == 1:
+            mean[rs.rand(G) < 0.3] = 0
+        if mode == 2:
+            mean, var = np.round(mean, 1), np.round(var, 1)
+        if mode == 3 and G > 3:
+            var[rs.randint(0, G, size=max(1, G // 10))] = var[0]
+        if mode == 4 and G > 4:
+            mean[rs.randint(0, G)] = np.nan
+        n_top = int(rs.choice([0, 1, 2, G // 3 + 1, max(G - 1, 1), G, G + 5, 2000]))
+        got = genes._hvg_from_moments(mean, var, n_top, 0.0125, 3.0, 0.5)
+        want = genes._hvg_from_moments_numpy(mean, var, n_top, 0.0125, 3.0, 0.5)
+        assert np.array_equal(got, want), (trial, G, n_top, mode)
