@@ -159,7 +159,7 @@ def alg_bytes(n, G, K, s_y, nnz, n_slices_width_rows, T):
     return sketch, sweep
 
 
-TRAFFIC_PROFILE = "profiles/r05_traffic.json"
+TRAFFIC_PROFILE = "profiles/r06_traffic.json"
 TRAFFIC_PROFILE_C5 = "profiles/r04_config5_traffic.json"     # the configs[4] shard (bench.py --config 5)
 
 
