@@ -222,11 +222,18 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
     // wider slices (rare) read the rest from memory
     unsigned slots[8];
     // all 16 loads go out together whatever the slice width (the table is padded by 16 rows, graph_kernels.cpp); entries
-    // past the width belong to the next slice and are never used
+    // past the width belong to the next slice: they are replaced by the tile's ZERO slot, so that the neighbour sums below can
+    // run over whole groups of four positions - a position past the width adds an exact +0.0 - instead of asking "m < w?" at
+    // each of the 16 positions of every chunk (the compiler kept those 16 wave-uniform answers as lane masks, 32 scalar
+    // registers it then spilled into vector lanes: two v_readlane, a select and a compare per position and chunk, ~400 of the
+    // 2830 vector instructions a spot costs at 30 types)
+    const unsigned zslot = (unsigned)(256 + Ht);
 #pragma unroll
     for (int m2 = 0; m2 < 8; ++m2) {
-        const unsigned lo = (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2) * 64]);
-        const unsigned hi = (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2 + 1) * 64]);
+        unsigned lo = (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2) * 64]);
+        unsigned hi = (unsigned)__builtin_nontemporal_load(&ell[(size_t)(2 * m2 + 1) * 64]);
+        lo = (2 * m2 < w) ? lo : zslot;
+        hi = (2 * m2 + 1 < w) ? hi : zslot;
         slots[m2] = lo | (hi << 16);
     }
     // Software pipeline over the chunks: what chunk c+1 needs from global memory - the old values of the first 256 halo
@@ -266,12 +273,15 @@ __global__ __launch_bounds__(256, ((OBJ && K > 40 && K <= 64) || (K > 64 && K <=
 #pragma unroll
         for (int q = 0; q < KC; ++q) c[q] = 0.0;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            if (m < w) {                                   // wave-uniform
-                const int slot = (int)((slots[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+        for (int m4 = 0; m4 < 16; m4 += 4) {
+            if (m4 < w) {                                  // wave-uniform; positions past the width hold the zero slot
 #pragma unroll
-                for (int q = 0; q < KC; ++q)
-                    if (kc + q < K) c[q] += lds[q * S + slot];
+                for (int m = m4; m < m4 + 4; ++m) {
+                    const int slot = (int)((slots[m >> 1] >> (16 * (m & 1))) & 0xffffu);
+#pragma unroll
+                    for (int q = 0; q < KC; ++q)
+                        if (kc + q < K) c[q] += lds[q * S + slot];
+                }
             }
         }
         for (int m = 16; m < w; ++m) {
