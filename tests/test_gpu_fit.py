@@ -736,3 +736,62 @@ def test_more_than_63_neighbours_per_spot_against_the_oracle():
         assert m.info_["n_iterations"] == want["info"]["n_iterations"]
         np.testing.assert_allclose(m.lambda_used_, want["lambda_used"], rtol=1e-10)
         assert rel_fro(m.beta_, want["beta"]) < 1e-8, k
+
+
+@pytest.mark.parametrize("dtype,K,d", [(np.float32, 8, 64), (np.float64, 8, 64), (np.float32, 40, 256), (np.float32, 60, 128)])
+def test_sparse_rows_longer_than_the_register_resident_part(dtype, K, d):
+    """Fused CSR sketch (csr_kernels.cpp): a wave holds 24 x 64 float32 (16 x 64 float64 / wide-type) entries of its row in
+    registers; what lies beyond is streamed from memory.  Rows of ~2400 stored entries beside short and empty ones, selected-gene
+    counts above the keep buffer, 8 / 40 / 60 cell types (one, three, four type tiles), against the oracle (core/deconv.py:181-188,
+    core/sketching.py:194-199)."""
+    from flashdeconv_amd import FlashDeconv
+    n, G = 230, 4000
+    rs = np.random.RandomState(8)
+    X = np.exp(rs.randn(K, G) * 0.7)
+    B = rs.dirichlet(np.ones(K), size=n)
+    dens = np.choose(np.arange(n) % 3, [0.6, 0.05, 0.3])[:, None]
+    Y = rs.poisson(B @ X * 2.0) * (rs.rand(n, G) < dens)
+    Y[7] = 0                                                  # an empty spot
+    Y[:, 1] += 1
+    Y[7, 1] = 0
+    coords = rs.rand(n, 2) * 20
+    Ys = sparse.csr_matrix(Y.astype(dtype))
+    assert (np.diff(Ys.indptr) > 1700).sum() > 40 and (np.diff(Ys.indptr) == 0).sum() == 1
+    kw = dict(sketch_dim=d, preprocess="log_cpm", n_hvg=5000, max_iter=8, tol=1e-9)
+    m = FlashDeconv(**kw).fit(Ys, X, coords)
+    want = orc.fit(sparse.csr_matrix(Y.astype(np.float64)), X, coords, sketch_dim=d, preprocess_method="log_cpm", n_hvg=5000, max_iter=8,
+                   tol=1e-9, graph="kdtree")
+    assert m.info_["n_iterations"] == want["info"]["n_iterations"]
+    tol = 1e-8 if dtype == np.float64 else 1e-5
+    assert rel_fro(m.beta_, want["beta"]) < tol and rel_fro(m.proportions_, want["proportions"]) < tol
+
+
+def test_csr_gene_moments_above_one_million_rows():
+    """csr_moments_cursor_kernel walks a stripe of more than 4096 rows (256 stripes: above 1,048,576 spots) in parts whose partial
+    sums add up in the stripe's slot - a path no smaller matrix takes.  1.2M very sparse rows against scipy's own sums
+    (utils/genes.py:52-83)."""
+    import torch
+    from flashdeconv_amd import _lib
+    n, G = 1_200_000, 700
+    g = torch.Generator(device="cuda").manual_seed(3)
+    nnz_row = 12
+    cols = torch.randint(0, G, (n, nnz_row), generator=g, device="cuda", dtype=torch.int64)
+    cols, _ = torch.sort(cols, dim=1)
+    keep = torch.ones_like(cols, dtype=torch.bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]                              # distinct columns per row
+    vals = torch.randint(1, 9, (n, nnz_row), generator=g, device="cuda").to(torch.float32)
+    crow = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    crow[1:] = torch.cumsum(keep.sum(dim=1), dim=0)
+    Yt = torch.sparse_csr_tensor(crow, cols[keep].to(torch.int32), vals[keep], size=(n, G))
+    csr = _lib.CsrOnDevice.from_torch(Yt)
+    assert csr.view.sorted_rows == 1
+    mean, var, _ = csr.gene_moments()
+    Ys = sparse.csr_matrix((vals[keep].cpu().numpy().astype(np.float64), cols[keep].cpu().numpy(), crow.cpu().numpy()), shape=(n, G))
+    lib = np.maximum(np.asarray(Ys.sum(axis=1)).ravel(), 1.0)
+    Z = (sparse.diags(10000.0 / lib) @ Ys).tocsr()
+    Z.data = np.log1p(Z.data)
+    m_ref = np.asarray(Z.sum(axis=0)).ravel() / n
+    sq = np.bincount(Z.indices, weights=Z.data ** 2, minlength=G) / n
+    v_ref = np.maximum(n / (n - 1) * (sq - m_ref ** 2), 0)
+    np.testing.assert_allclose(mean, m_ref, rtol=1e-11)
+    np.testing.assert_allclose(var, v_ref, rtol=1e-9)
