@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "fdx_internal.h"
@@ -41,16 +42,19 @@ size_t src_itemsize(int code) {
 
 template <typename S, typename D>
 double convert_span(const void* src, void* dst, size_t count) {
+    // the largest |value| in the source's own integer domain (unsigned magnitude): a loop the compiler vectorises - with the
+    // maximum taken in double the converting copy ran at 38-40 GB/s on 16 threads, below the link's 56
+    typedef typename std::make_unsigned<S>::type U;
     const S* s = static_cast<const S*>(src);
     D* d = static_cast<D*>(dst);
-    double mx = 0.0;
+    U mx = 0;
     for (size_t i = 0; i < count; ++i) {
         const S v = s[i];
         d[i] = (D)v;
-        const double a = std::fabs((double)v);
+        const U a = v < 0 ? (U)((U)0 - (U)v) : (U)v;
         mx = a > mx ? a : mx;
     }
-    return mx;
+    return (double)mx;
 }
 
 // count elements of the source type `code` at src -> count elements of float32 / float64 at dst; returns max |value| of integer
