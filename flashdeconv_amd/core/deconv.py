@@ -105,16 +105,21 @@ def reference_tie_graph(c_ptr, coords_host, n, dim, k):
     kk = min(int(k), n - 1) + 1
     nbr, cnt = _DeviceBuffer(n * kk * 4), _DeviceBuffer(n * 4)
     plan, h = ctypes.c_void_p(), ctypes.c_void_p()
+    # the host build of the restated tree (21-24 ms per million points) starts NOW, in a thread of the library's: the device's own
+    # lists below come first and wait ~3 ms behind the stopped fit's sketch
+    _ckdtree_restatement_matches_scipy()
+    ch_arr = None if coords_host is None else np.ascontiguousarray(coords_host, dtype=np.float64)
+    ch = None if ch_arr is None else _lib.ptr_f64(ch_arr)
+    if dim <= 8:
+        _lib.check(lib.fdx_ckdtree_prebuild(ch, c_ptr, n, dim))
     try:
         _lib.check(lib.fdx_graph_knn_lists_dev(c_ptr, n, dim, int(k), 0, n, nbr.ptr, cnt.ptr, None, ctypes.byref(plan)))
         try:
             mark("device lists + order")
             # the restated tree is built on the host, its queries run on the device (1-3 coordinates), and the answers go - as solver
             # positions, self dropped - to the rows' positions without leaving the device
-            _ckdtree_restatement_matches_scipy()
             # coordinates that only exist on the device are fetched by the library into pinned memory (a pageable copy here would be
             # pinned by the driver, and unmapping it afterwards stalls the process's GPU queues: DESIGN appendix)
-            ch = None if coords_host is None else _lib.ptr_f64(np.ascontiguousarray(coords_host, dtype=np.float64))
             _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, ch, c_ptr, n, dim, None, 0, nbr.ptr, cnt.ptr, None))
             mark("host tree + device queries + lists to positions")
         except Exception:

@@ -36,6 +36,8 @@
 #include <cstring>
 #include <system_error>
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -637,13 +639,76 @@ struct PinnedScope {
     ~PinnedScope() { if (p) pinned_buffer_put(p, cap); }
 };
 
+// A tree whose build was started ahead (fdx_ckdtree_prebuild): the tie remedy of a fit knows it will need the tree the moment the
+// device reports ties, ~4 ms before it gets round to asking for the lists (the device's own lists come first, behind the still
+// running sketch) - the 21-24 ms host build runs beside that.  One pending build per process, matched by its coordinates.
+struct KdPrebuilt {
+    const double* key_host = nullptr;
+    const double* key_dev = nullptr;
+    long long n = 0;
+    int dim = 0;
+    PinnedScope pin;                     // coordinates fetched from the device (key_host == NULL)
+    KdTree t;
+    std::thread th;
+    bool failed = false;
+};
+static std::mutex g_pre_mu;
+static std::unique_ptr<KdPrebuilt> g_pre;
+
+static void kd_prebuilt_drop(std::unique_ptr<KdPrebuilt>& p) {
+    if (p && p->th.joinable()) p->th.join();
+    p.reset();
+}
+
+int ckdtree_prebuild(const double* coords_host, const double* coords_dev, long long n, int dim) {
+    std::unique_ptr<KdPrebuilt> old;
+    {
+        std::lock_guard<std::mutex> lk(g_pre_mu);
+        old = std::move(g_pre);
+    }
+    kd_prebuilt_drop(old);
+    auto p = std::make_unique<KdPrebuilt>();
+    p->key_host = coords_host; p->key_dev = coords_dev; p->n = n; p->dim = dim;
+    const double* src = coords_host;
+    if (!src) {
+        // on the library's side stream: the caller's stream may still be busy (the sketch of the stopped fit), the coordinates
+        // are nobody's output
+        hipStream_t ss = library_side_stream();
+        FDX_TRY(p->pin.get((size_t)n * dim * sizeof(double)));
+        FDX_HIP(hipMemcpyAsync(p->pin.p, coords_dev, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToHost, ss));
+        FDX_HIP(hipStreamSynchronize(ss));
+        src = static_cast<const double*>(p->pin.p);
+    }
+    KdPrebuilt* raw = p.get();
+    try {
+        p->th = std::thread([raw, src, n, dim] {
+            try { kd_build_tree(raw->t, src, n, dim); } catch (...) { raw->failed = true; }
+        });
+    } catch (const std::system_error&) {
+        return 0;                        // no thread: the lists call builds the tree itself
+    }
+    std::lock_guard<std::mutex> lk(g_pre_mu);
+    g_pre = std::move(p);
+    return 0;
+}
+
 int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev, long long n, int dim, int kk, const long long* rows_host,
                          long long n_rows, long long* ids_dev, hipStream_t st) {
     const long long nq = rows_host ? n_rows : n;
     if (nq == 0) return 0;
+    std::unique_ptr<KdPrebuilt> pre;
+    {
+        std::lock_guard<std::mutex> lk(g_pre_mu);
+        if (g_pre && g_pre->key_host == coords_host_in && g_pre->key_dev == coords_dev && g_pre->n == n && g_pre->dim == dim) pre = std::move(g_pre);
+    }
+    if (pre) {
+        pre->th.join();
+        if (pre->failed) pre.reset();
+    }
     // coords_host NULL: the coordinates are fetched here, into pinned memory
     PinnedScope pin_coords;
     const double* coords_host = coords_host_in;
+    if (pre && !coords_host) coords_host = static_cast<const double*>(pre->pin.p);
     if (!coords_host) {
         FDX_TRY(pin_coords.get((size_t)n * dim * sizeof(double)));
         FDX_HIP(hipMemcpyAsync(pin_coords.p, coords_dev, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -652,8 +717,9 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
     }
     const bool trace = fdx::env("FDX_TRACE_HOST") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    KdTree t;
-    kd_build_tree(t, coords_host, n, dim);
+    KdTree t_own;
+    if (!pre) kd_build_tree(t_own, coords_host, n, dim);
+    KdTree& t = pre ? pre->t : t_own;
     const auto t1 = std::chrono::steady_clock::now();
     bool on_device = dim <= 3 && n < 0x7fffff00LL && (long long)t.nodes.size() < 0x7fffff00LL && !fdx::env("FDX_KDTREE_HOST_QUERIES");
     if (on_device) {
@@ -725,6 +791,16 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
 }  // namespace fdx
 
 // include/fdx.h
+extern "C" int fdx_ckdtree_prebuild(const double* coords_host, const double* coords_dev, int64_t n, int32_t dim) {
+    using namespace fdx;
+    FDX_REQUIRE((coords_host || coords_dev) && n >= 1 && dim >= 1 && dim <= 8, "fdx_ckdtree_prebuild: bad arguments (1 to 8 coordinates)");
+    try {
+        return fdx::ckdtree_prebuild(coords_host, coords_dev, n, dim);
+    } catch (...) {
+        return fail(FDX_ERR_INVALID, "fdx_ckdtree_prebuild: out of memory");
+    }
+}
+
 extern "C" int fdx_kdtree_set_threads(int32_t threads) {
     fdx::g_kd_threads.store(threads > 0 ? threads : 0);
     return 0;

@@ -185,6 +185,11 @@ int fdx_graph_knn_ties(const fdx_graph* g, int64_t* ties);
  * in decides, so the caller runs numpy itself.  Pure host code. */
 int fdx_hvg_from_moments(const double* mean, const double* var, int32_t G, const double* sorted_pos, int32_t n_pos, int32_t n_top,
                          double min_mean, double max_mean, double min_disp, int64_t* idx_out, int32_t* n_out, int32_t* ambiguous);
+/* Starts the host build of the restated cKDTree of these coordinates (utils/graph.py:60) in a thread of the library's own and
+ * returns: the next fdx_graph_plan_set_ckdtree_lists_dev on the SAME coordinates (same pointers, n, dim) takes the tree over
+ * instead of building it.  coords_host may be NULL (fetched from coords_dev on the library's side stream).  One pending build per
+ * process; the coordinates must stay valid until that call. */
+int fdx_ckdtree_prebuild(const double* coords_host, const double* coords_dev, int64_t n, int32_t dim);
 /* Host threads the restated cKDTree may use from now on (0: the process's budget): the ranks of one host, each building the tree
  * of the replicated coordinates (utils/graph.py:60), share its cores. */
 int fdx_kdtree_set_threads(int32_t threads);
