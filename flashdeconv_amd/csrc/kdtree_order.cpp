@@ -14,8 +14,9 @@
 //   build   - recursive; bounds of a node recomputed from its points; split dimension = largest spread (first wins);
 //             median by std::nth_element over the node's index range, compared by the coordinate alone, at
 //             position n/2; split value = coordinate of that element; then a Hoare-style pass moving "< split" left and
-//             ">= split" right (on a lattice many points equal the split: they all go right); empty-side repair by the
-//             minimum / maximum element; children [start, p) and [p, end).  The index array after all of this is the order
+//             ">= split" right (on a lattice many points equal the split: they all go right); when nothing is below the
+//             split (the median is the node's minimum) the split moves to nextafter(minimum, +inf) and the pass is repeated;
+//             children [start, p) and [p, end).  The index array after all of this is the order
 //             in which a leaf's points are tested.  (std::nth_element is libstdc++'s introselect here as in scipy's
 //             manylinux wheels.)
 //   query   - best-first over nodes with scipy's own binary heap (strict comparisons: ties keep insertion structure),
@@ -36,9 +37,12 @@
 #include <cstring>
 #include <system_error>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "fdx_internal.h"
@@ -53,12 +57,21 @@ struct KdNode {
     long long less = -1, greater = -1;
 };
 
+// std::vector that leaves new elements uninitialised (the index array is written in full right after its resize - by several
+// threads, each touching its own pages first)
+template <class T>
+struct KdRawAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = KdRawAlloc<U>; };
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+
 struct KdTree {
     const double* data = nullptr;
     long long n = 0;
     int m = 0;
     long long leafsize = 16;
-    std::vector<long long> indices;
+    std::vector<long long, KdRawAlloc<long long>> indices;
     std::vector<KdNode> nodes;
     std::vector<double> maxes, mins;   // of the whole data set
 };
@@ -97,19 +110,331 @@ unsigned host_cpu_budget() {
 // fdx_kdtree_set_threads (the ranks of one host each build the tree of the replicated coordinates: they share its cores), or
 // FDX_KDTREE_THREADS.
 static std::atomic<int> g_kd_threads{0};
+static std::atomic<long long> g_kd_team_min{0};
+static std::atomic<long long> g_kd_local_max{-1};
 static unsigned kd_thread_share() {
     if (const char* e = fdx::env("FDX_KDTREE_THREADS")) return (unsigned)std::max(1, atoi(e));
     const int v = g_kd_threads.load();
     return v > 0 ? (unsigned)v : host_cpu_budget();
 }
 namespace {
+// ---- a standing team of host threads for the passes of the tree's TOP nodes ------------------------------------------------
+// The build's critical path is the chain root -> child -> grandchild: bounds, selection and partition of a million, half a
+// million, a quarter of a million points, each a serial pass (12 + 6 + 3 ms of the 21 ms a million lattice points cost with the
+// subtrees already on threads of their own).  Starting threads per pass costs more than the pass (tried, round 5); a team that
+// is already waiting does not: its members spin a few microseconds for the next pass, then sleep on a condition variable.
+class KdTeam {
+public:
+    static KdTeam& get() { static KdTeam t; return t; }
+    // one user at a time (the nodes of a level queue here; what they queue for is short)
+    void acquire(int want) {
+        own_.lock();
+        want = std::max(1, std::min(want, 32));
+        if (pid_ != getpid()) {                                       // a fork()ed child has the objects but not the threads: leave them be
+            if (!th_.empty()) new std::vector<std::thread>(std::move(th_));
+            th_.clear();
+            pid_ = getpid();
+        }
+        while ((int)th_.size() + 1 < want) {
+            const int tid = (int)th_.size() + 1;
+            const uint64_t g0 = gen_.load();                          // (no pass is under way: the team is ours)
+            try { th_.emplace_back([this, tid, g0] { loop(tid, g0); }); } catch (const std::system_error&) { break; }
+        }
+        nt_ = (int)th_.size() + 1;
+    }
+    void release() { own_.unlock(); }
+    int size() const { return nt_; }
+    // f(tid, nt) on every member, the caller being member 0; returns when all are through
+    void run(const std::function<void(int, int)>& f) {
+        if (nt_ == 1) { f(0, 1); return; }
+        job_ = &f;
+        left_.store(nt_ - 1, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(m_); gen_.fetch_add(1, std::memory_order_release); }
+        cv_.notify_all();
+        f(0, nt_);
+        for (int s = 0; s < 20000 && left_.load(std::memory_order_acquire) != 0; ++s) __builtin_ia32_pause();
+        if (left_.load(std::memory_order_acquire) != 0) {
+            std::unique_lock<std::mutex> lk(m_);
+            done_.wait(lk, [this] { return left_.load(std::memory_order_acquire) == 0; });
+        }
+    }
+    std::vector<int32_t> lpos, rpos;                                  // scratch of the partition passes, kept between builds
+    ~KdTeam() {
+        if (pid_ != getpid()) { new std::vector<std::thread>(std::move(th_)); return; }
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) if (t.joinable()) t.join();
+    }
+private:
+    void loop(int tid, uint64_t seen) {
+        for (;;) {
+            for (int s = 0; s < 4000 && gen_.load(std::memory_order_acquire) == seen; ++s) __builtin_ia32_pause();
+            if (gen_.load(std::memory_order_acquire) == seen) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_acquire) != seen; });
+                if (stop_) return;
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            if (tid < nt_) (*job_)(tid, nt_);
+            if (left_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(m_);
+                done_.notify_one();
+            }
+        }
+    }
+    std::mutex own_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(int, int)>* job_ = nullptr;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> left_{0};
+    bool stop_ = false;
+    int nt_ = 1;
+    pid_t pid_ = getpid();
+};
+
+static long long kd_team_min() {                                     // fdx_kdtree_set_team_min: the tests send small nodes through the team
+    const long long v = g_kd_team_min.load();
+    return v > 0 ? v : 200000;
+}
+
+// libstdc++'s __unguarded_partition(lo, hi, pivot) over the index range [lo, hi), keys read through the index array - by the whole
+// team, with the result of the serial scan, swap for swap.  The serial scan stops its left pointer on every key >= pivot and its
+// right pointer on every key <= pivot and swaps the two; between the pointers the array is still as it was, so the k-th swap
+// is (k-th key >= pivot from the left, k-th key <= pivot from the right), for as long as the former lies left of the latter,
+// and the returned cut is where the left pointer stops next: the next such key from the left, or the right partner of the
+// last swap (which now holds a key >= pivot), whichever comes first.  (The pivot - moved to lo - 1 by the median step -
+// and the median's other two samples guarantee both lists are non-empty inside the range.)
+template <class Key>
+long long team_unguarded_partition(KdTeam& team, long long* idx, long long lo, long long hi, double pv, const Key& key) {
+    const long long len = hi - lo;
+    const int nt = team.size();
+    if ((long long)team.lpos.size() < len) { team.lpos.resize((size_t)len); team.rpos.resize((size_t)len); }
+    int32_t* lp = team.lpos.data();
+    int32_t* rp = team.rpos.data();
+    std::vector<long long> cb((size_t)nt + 1), cl((size_t)nt + 1, 0), cr((size_t)nt + 1, 0);
+    for (int t = 0; t <= nt; ++t) cb[(size_t)t] = len * t / nt;
+    team.run([&](int tid, int) {
+        const long long b = cb[(size_t)tid], e = cb[(size_t)tid + 1];
+        long long nl = 0, nr = 0;
+        for (long long i = b; i < e; ++i) {
+            const double v = key(idx[lo + i]);
+            lp[b + nl] = (int32_t)i;
+            nl += !(v < pv);
+            rp[b + nr] = (int32_t)i;
+            nr += !(pv < v);
+        }
+        cl[(size_t)tid + 1] = nl;
+        cr[(size_t)tid + 1] = nr;
+    });
+    // pl[t]: left-list entries before chunk t; sr[t]: right-list entries (counted from the right) after chunk t
+    std::vector<long long> pl((size_t)nt + 1, 0), sr((size_t)nt + 1, 0);
+    for (int t = 0; t < nt; ++t) pl[(size_t)t + 1] = pl[(size_t)t] + cl[(size_t)t + 1];
+    for (int t = nt - 1; t >= 0; --t) sr[(size_t)t] = sr[(size_t)t + 1] + cr[(size_t)t + 1];
+    const long long nL = pl[(size_t)nt], nR = sr[0];
+    auto L = [&](long long k) {
+        int t = (int)(std::upper_bound(pl.begin(), pl.end(), k) - pl.begin()) - 1;
+        return (long long)lp[cb[(size_t)t] + (k - pl[(size_t)t])];
+    };
+    auto R = [&](long long k) {                                       // chunk t holds the k with sr[t + 1] <= k < sr[t]
+        int t = nt - 1;
+        while (sr[(size_t)t] <= k) --t;
+        return (long long)rp[cb[(size_t)t] + (cr[(size_t)t + 1] - 1 - (k - sr[(size_t)t + 1]))];
+    };
+    long long a = 0, b = std::min(nL, nR);                            // K = number of k with L(k) < R(k): those come first
+    while (a < b) {
+        const long long mid = (a + b) / 2;
+        if (L(mid) < R(mid)) a = mid + 1; else b = mid;
+    }
+    const long long K = a;
+    if (K > 0)
+        team.run([&](int tid, int n_t) {
+            const long long k0 = K * tid / n_t, k1 = K * (tid + 1) / n_t;
+            if (k0 >= k1) return;
+            int tl = (int)(std::upper_bound(pl.begin(), pl.end(), k0) - pl.begin()) - 1;
+            long long il = k0 - pl[(size_t)tl];
+            int tr = nt - 1;
+            while (sr[(size_t)tr] <= k0) --tr;
+            long long ir = cr[(size_t)tr + 1] - 1 - (k0 - sr[(size_t)tr + 1]);
+            for (long long k = k0; k < k1; ++k) {
+                while (il >= cl[(size_t)tl + 1]) { ++tl; il = 0; }
+                while (ir < 0) { --tr; ir = cr[(size_t)tr + 1] - 1; }
+                std::swap(idx[lo + lp[cb[(size_t)tl] + il]], idx[lo + rp[cb[(size_t)tr] + ir]]);
+                ++il;
+                --ir;
+            }
+        });
+    long long cut = -1;
+    if (K < nL) cut = L(K);
+    if (K > 0) { const long long r = R(K - 1); cut = cut < 0 ? r : std::min(cut, r); }
+    return lo + cut;
+}
+
+// std::nth_element(idx + first, idx + nth, idx + last, key(a) < key(b)) - libstdc++'s introselect with the partition passes of the
+// long ranges done by the team; below `team_min` libstdc++'s own routine continues with the depth budget that is left.
+template <class Key>
+void team_nth_element(KdTeam& team, long long* idx, long long first, long long nth, long long last, const Key& key, long long team_min) {
+    auto cmp = [&key](long long a, long long b) { return key(a) < key(b); };
+    auto icmp = __gnu_cxx::__ops::__iter_comp_iter(cmp);
+    if (first == last || nth == last) return;
+    long long depth = 2 * (long long)std::__lg(last - first);
+    while (last - first > 3) {
+        if (last - first < team_min || depth == 0) {
+            std::__introselect(idx + first, idx + nth, idx + last, depth, icmp);
+            return;
+        }
+        --depth;
+        const long long mid = first + (last - first) / 2;
+        std::__move_median_to_first(idx + first, idx + first + 1, idx + mid, idx + last - 1, icmp);
+        const long long cut = team_unguarded_partition(team, idx, first + 1, last, key(idx[first]), key);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    std::__insertion_sort(idx + first, idx + last, icmp);
+}
+
 static long long kd_fork_min() {
     static const long long v = fdx::exp_env("FDX_KDTREE_FORK_MIN") ? std::max(1024, atoi(fdx::exp_env("FDX_KDTREE_FORK_MIN"))) : 32768;
     return v;
 }
 
+// A subtree small enough for a core's cache is built on a contiguous copy of its points - records {coordinates, index} in
+// index-array order - instead of through the index array: the same comparisons, hence the same swaps on the same positions and
+// the same index order when the records' indices are written back, but bounds, selection and partition stream through 24-byte
+// records that sit in L2 instead of chasing 8-byte indices into the coordinate array (the build is throughput-bound once its
+// subtrees have threads of their own: ~150 ms of core time per million points, 16 levels of three passes).
+template <int M>
+struct KdRec {
+    double c[M];
+    long long i;
+};
+
+static long long kd_local_max() {                                     // fdx_kdtree_tune(1, points); 0 switches the copy off
+    const long long v = g_kd_local_max.load();
+    return v >= 0 ? v : 65536;
+}
+
+// std::nth_element(r, r + nth, r + last, key d ascending) with the partition passes of libstdc++'s introselect done WITHOUT the
+// data-dependent branches of its two-pointer scan (half of them mispredicted on a median pivot - the larger part of a
+// subtree's build time): one pass lists the positions with key >= pivot and the positions with key <= pivot - the stops of the
+// scan's left and right pointer -, the k-th swap is (k-th of the first list, k-th from the end of the second) while the former
+// lies left of the latter, the cut is where the left pointer would stop next (team_unguarded_partition above has the argument).
+// Short ranges go to libstdc++'s own routine with the depth budget that is left.
+template <int M>
+void rec_nth_element(KdRec<M>* r, long long nth, long long last, int d, int32_t* scratch) {
+    auto cmp = [d](const KdRec<M>& a, const KdRec<M>& b) { return a.c[d] < b.c[d]; };
+    auto icmp = __gnu_cxx::__ops::__iter_comp_iter(cmp);
+    long long first = 0;
+    if (first == last || nth == last) return;
+    long long depth = 2 * (long long)std::__lg(last - first);
+    while (last - first > 3) {
+        if (last - first < 192 || depth == 0) {
+            std::__introselect(r + first, r + nth, r + last, depth, icmp);
+            return;
+        }
+        --depth;
+        const long long mid = first + (last - first) / 2;
+        std::__move_median_to_first(r + first, r + first + 1, r + mid, r + last - 1, icmp);
+        const double pv = r[first].c[d];
+        const long long lo = first + 1, len = last - lo;
+        int32_t* lp = scratch;
+        int32_t* rp = scratch + len;
+        long long nl = 0, nr = 0;
+        for (long long i = 0; i < len; ++i) {
+            const double v = r[lo + i].c[d];
+            lp[nl] = (int32_t)i;
+            nl += !(v < pv);
+            rp[nr] = (int32_t)i;
+            nr += !(pv < v);
+        }
+        long long a = 0, b = std::min(nl, nr);
+        while (a < b) {
+            const long long m2 = (a + b) / 2;
+            if (lp[m2] < rp[nr - 1 - m2]) a = m2 + 1; else b = m2;
+        }
+        const long long K = a;
+        for (long long k = 0; k < K; ++k) std::swap(r[lo + lp[k]], r[lo + rp[nr - 1 - k]]);
+        long long cut = K < nl ? lp[K] : len;
+        if (K > 0) cut = std::min<long long>(cut, rp[nr - K]);
+        cut += lo;
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    std::__insertion_sort(r + first, r + last, icmp);
+}
+
+template <int M>
+long long kd_build_local(const KdTree& t, std::vector<KdNode>& nodes, KdRec<M>* rec, long long base, long long start, long long end,
+                         int32_t* scratch) {
+    nodes.emplace_back();
+    const long long node_index = (long long)nodes.size() - 1;
+    nodes[(size_t)node_index].start = start;
+    nodes[(size_t)node_index].end = end;
+    const long long n = end - start;
+    if (n <= t.leafsize) return node_index;
+    KdRec<M>* r = rec + (start - base);
+    double mx[M], mn[M];
+    for (int i = 0; i < M; ++i) mx[i] = mn[i] = r[0].c[i];
+    for (long long j = 1; j < n; ++j)
+        for (int i = 0; i < M; ++i) {
+            const double v = r[j].c[i];
+            mx[i] = mx[i] > v ? mx[i] : v;
+            mn[i] = mn[i] < v ? mn[i] : v;
+        }
+    int d = 0;
+    double size = 0.0;
+    for (int i = 0; i < M; ++i)
+        if (mx[i] - mn[i] > size) { d = i; size = mx[i] - mn[i]; }
+    if (mx[d] == mn[d]) return node_index;
+    const long long half = n / 2;
+    rec_nth_element<M>(r, half, n, d, scratch);
+    double split = r[half].c[d];
+    long long p = 0, q = half - 1;                                    // (see kd_build for the pass and its shortcut)
+    while (p <= q) {
+        if (r[p].c[d] < split) ++p;
+        else if (r[q].c[d] >= split) --q;
+        else { std::swap(r[p], r[q]); ++p; --q; }
+    }
+    if (p == 0) {
+        split = std::nextafter(split, HUGE_VAL);
+        q = n - 1;
+        while (p <= q) {
+            if (r[p].c[d] < split) ++p;
+            else if (r[q].c[d] >= split) --q;
+            else { std::swap(r[p], r[q]); ++p; --q; }
+        }
+    }
+    const long long less = kd_build_local<M>(t, nodes, rec, base, start, start + p, scratch);
+    const long long greater = kd_build_local<M>(t, nodes, rec, base, start + p, end, scratch);
+    KdNode& nd = nodes[(size_t)node_index];
+    nd.split_dim = d;
+    nd.split = split;
+    nd.less = less;
+    nd.greater = greater;
+    return node_index;
+}
+
+template <int M>
+long long kd_build_on_copy(KdTree& t, std::vector<KdNode>& nodes, long long start, long long end) {
+    const long long n = end - start;
+    std::vector<KdRec<M>> rec((size_t)n);
+    long long* indices = t.indices.data();
+    for (long long j = 0; j < n; ++j) {
+        const long long i = indices[start + j];
+        for (int c = 0; c < M; ++c) rec[(size_t)j].c[c] = t.data[i * M + c];
+        rec[(size_t)j].i = i;
+    }
+    std::vector<int32_t> scratch((size_t)(2 * n));
+    const long long root = kd_build_local<M>(t, nodes, rec.data(), start, start, end, scratch.data());
+    for (long long j = 0; j < n; ++j) indices[start + j] = rec[(size_t)j].i;
+    return root;
+}
+
 long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long long end, double* maxes, double* mins, int par_depth) {
     const int m = t.m;
+    if (end - start > t.leafsize && end - start <= kd_local_max()) {
+        if (m == 1) return kd_build_on_copy<1>(t, nodes, start, end);
+        if (m == 2) return kd_build_on_copy<2>(t, nodes, start, end);
+        if (m == 3) return kd_build_on_copy<3>(t, nodes, start, end);
+    }
     const double* data = t.data;
     long long* indices = t.indices.data();
     nodes.emplace_back();
@@ -120,13 +445,48 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
     // compact nodes: bounds from the node's own points
     // (a thread team for the passes of the top nodes was tried: 24-27 ms per million points instead of 22-24 - starting the
     // threads costs more than the 2 ms pass they share)
-    for (int i = 0; i < m; ++i) maxes[i] = mins[i] = data[indices[start] * m + i];
-    for (long long j = start + 1; j < end; ++j)
+    // the top nodes' passes go to the standing team (KdTeam above): same bounds, same permutation
+    const bool teamed = end - start >= kd_team_min() && kd_thread_share() > 1 && m <= 8;
+    struct TeamHold {
+        KdTeam* t = nullptr;
+        ~TeamHold() { if (t) t->release(); }
+    } hold;
+    if (teamed) {
+        KdTeam& team = KdTeam::get();
+        team.acquire((int)std::min(kd_thread_share(), 16u));
+        hold.t = &team;
+        const int nt = team.size();
+        std::vector<double> bmx((size_t)nt * 8), bmn((size_t)nt * 8);
+        team.run([&](int tid, int n_t) {
+            const long long b = start + (end - start) * tid / n_t, e = start + (end - start) * (tid + 1) / n_t;
+            double mx[8], mn[8];
+            for (int i = 0; i < m; ++i) mx[i] = mn[i] = data[indices[b] * m + i];
+            for (long long j = b + 1; j < e; ++j)
+                for (int i = 0; i < m; ++i) {
+                    const double v = data[indices[j] * m + i];
+                    mx[i] = mx[i] > v ? mx[i] : v;
+                    mn[i] = mn[i] < v ? mn[i] : v;
+                }
+            for (int i = 0; i < m; ++i) { bmx[(size_t)tid * 8 + i] = mx[i]; bmn[(size_t)tid * 8 + i] = mn[i]; }
+        });
         for (int i = 0; i < m; ++i) {
-            const double v = data[indices[j] * m + i];
-            maxes[i] = maxes[i] > v ? maxes[i] : v;
-            mins[i] = mins[i] < v ? mins[i] : v;
+            maxes[i] = bmx[(size_t)i];
+            mins[i] = bmn[(size_t)i];
+            for (int t2 = 1; t2 < nt; ++t2) {
+                const double a = bmx[(size_t)t2 * 8 + i], b2 = bmn[(size_t)t2 * 8 + i];
+                maxes[i] = maxes[i] > a ? maxes[i] : a;
+                mins[i] = mins[i] < b2 ? mins[i] : b2;
+            }
         }
+    } else {
+        for (int i = 0; i < m; ++i) maxes[i] = mins[i] = data[indices[start] * m + i];
+        for (long long j = start + 1; j < end; ++j)
+            for (int i = 0; i < m; ++i) {
+                const double v = data[indices[j] * m + i];
+                maxes[i] = maxes[i] > v ? maxes[i] : v;
+                mins[i] = mins[i] < v ? mins[i] : v;
+            }
+    }
     int d = 0;
     double size = 0.0;
     for (int i = 0; i < m; ++i)
@@ -139,31 +499,64 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
     // the comparator of scipy 1.15.3 is the coordinate alone (no index tie-break: checked against the library's index array
     // on lattices - with one the leaves come out in another order), so equal coordinates fall where introselect leaves them
     auto cmp = [data, m, d](long long a, long long b) { return data[a * m + d] < data[b * m + d]; };
-    std::nth_element(indices + start, indices + start + half, indices + end, cmp);
+    auto key = [data, m, d](long long a) { return data[a * m + d]; };
+    if (teamed) team_nth_element(*hold.t, indices, start, start + half, end, key, std::max<long long>(kd_team_min() / 4, 16));
+    else std::nth_element(indices + start, indices + start + half, indices + end, cmp);
     double split = data[indices[start + half] * m + d];
     // scipy's two-pointer pass "< split | >= split" over the whole range.  After the selection everything from position `half` on
     // is >= split (std::nth_element's postcondition): the pass would walk q down through that half without a swap - it starts
     // where that walk ends.  Same swaps, same result, half the pass.
     long long p = start, q = start + half - 1;
+    if (teamed) {
+        // the same pass by the team: its k-th swap is (k-th key >= split from the left, k-th key < split from the right) while the
+        // former lies left of the latter, and it ends with p on the first key >= split - the number of keys below the split.
+        // After a selection only keys EQUAL to the split stand left of position `half`, so the left list is short: the
+        // team counts and lists, one thread pairs.
+        KdTeam& team = *hold.t;
+        const int nt = team.size();
+        std::vector<std::vector<long long>> lefts((size_t)nt);
+        std::vector<long long> below((size_t)nt, 0);
+        team.run([&](int tid, int n_t) {
+            const long long b = start + half * tid / n_t, e = start + half * (tid + 1) / n_t;
+            long long nb = 0;
+            for (long long i = b; i < e; ++i) {
+                if (data[indices[i] * m + d] < split) ++nb;
+                else lefts[(size_t)tid].push_back(i);
+            }
+            below[(size_t)tid] = nb;
+        });
+        long long n_below = 0;
+        for (int t2 = 0; t2 < nt; ++t2) n_below += below[(size_t)t2];
+        long long r = q;                                              // walks down over the keys < split
+        bool crossed = false;
+        for (int t2 = 0; t2 < nt && !crossed; ++t2)
+            for (long long l : lefts[(size_t)t2]) {
+                while (r > l && !(data[indices[r] * m + d] < split)) --r;
+                if (r <= l) { crossed = true; break; }
+                std::swap(indices[l], indices[r]);
+                --r;
+            }
+        p = start + n_below;
+    } else
     while (p <= q) {
         if (data[indices[p] * m + d] < split) ++p;
         else if (data[indices[q] * m + d] >= split) --q;
         else { std::swap(indices[p], indices[q]); ++p; --q; }
     }
-    if (p == start) {                                                 // nothing below the split: the minimum goes left alone
-        long long j = start;
-        split = data[indices[j] * m + d];
-        for (long long i = start + 1; i < end; ++i)
-            if (data[indices[i] * m + d] < split) { j = i; split = data[indices[j] * m + d]; }
-        std::swap(indices[start], indices[j]);
-        p = start + 1;
-    } else if (p == end) {                                            // nothing at or above it: the maximum goes right alone
-        long long j = end - 1;
-        split = data[indices[j] * m + d];
-        for (long long i = start; i < end - 1; ++i)
-            if (data[indices[i] * m + d] > split) { j = i; split = data[indices[j] * m + d]; }
-        std::swap(indices[end - 1], indices[j]);
-        p = end - 1;
+    if (hold.t) { hold.t->release(); hold.t = nullptr; }              // (the children take the team themselves)
+    if (p == start) {
+        // Nothing below the split: the median IS the node's minimum along d (more than half of its points share it - duplicated
+        // spots, or a ragged tissue edge).  scipy 1.15.3 then splits just ABOVE the minimum - the tree reports
+        // split == nextafter(minimum, +inf), with every point at the minimum in the lesser child - by the same two-pointer
+        // pass over the whole range.  (Rounds 1-5 restated the older "slide one point over" rule here; it never fired on a
+        // full lattice, and did on heavily duplicated coordinates - caught by the duplicates sweep of tests/test_host.py.)
+        split = std::nextafter(split, HUGE_VAL);
+        q = end - 1;
+        while (p <= q) {
+            if (data[indices[p] * m + d] < split) ++p;
+            else if (data[indices[q] * m + d] >= split) --q;
+            else { std::swap(indices[p], indices[q]); ++p; --q; }
+        }
     }
     long long less = -1, greater = -1;
     bool forked = false;
@@ -351,16 +744,38 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
     t.n = n;
     t.m = dim;
     t.indices.resize((size_t)n);
-    for (long long i = 0; i < n; ++i) t.indices[(size_t)i] = i;
     t.maxes.assign((size_t)dim, 0.0);
     t.mins.assign((size_t)dim, 0.0);
-    for (int a = 0; a < dim; ++a) t.maxes[(size_t)a] = t.mins[(size_t)a] = coords[a];
-    for (long long i = 1; i < n; ++i)
-        for (int a = 0; a < dim; ++a) {
-            const double v = coords[i * dim + a];
-            t.maxes[(size_t)a] = std::max(t.maxes[(size_t)a], v);
-            t.mins[(size_t)a] = std::min(t.mins[(size_t)a], v);
+    // identity index array and the bounds of the whole set: 3 ms of passes per million points when one thread makes them
+    auto span = [&](long long b, long long e, double* mx, double* mn) {
+        for (int a = 0; a < dim; ++a) mx[a] = mn[a] = coords[b * dim + a];
+        for (long long i = b; i < e; ++i) {
+            t.indices[(size_t)i] = i;
+            for (int a = 0; a < dim; ++a) {
+                const double v = coords[i * dim + a];
+                mx[a] = std::max(mx[a], v);
+                mn[a] = std::min(mn[a], v);
+            }
         }
+    };
+    if (n >= kd_team_min() && kd_thread_share() > 1 && dim <= 8) {
+        KdTeam& team = KdTeam::get();
+        team.acquire((int)std::min(kd_thread_share(), 16u));
+        const int nt = team.size();
+        std::vector<double> bmx((size_t)nt * 8), bmn((size_t)nt * 8);
+        team.run([&](int tid, int n_t) { span(n * tid / n_t, n * (tid + 1) / n_t, &bmx[(size_t)tid * 8], &bmn[(size_t)tid * 8]); });
+        team.release();
+        for (int a = 0; a < dim; ++a) {
+            t.maxes[(size_t)a] = bmx[(size_t)a];
+            t.mins[(size_t)a] = bmn[(size_t)a];
+            for (int t2 = 1; t2 < nt; ++t2) {
+                t.maxes[(size_t)a] = std::max(t.maxes[(size_t)a], bmx[(size_t)t2 * 8 + a]);
+                t.mins[(size_t)a] = std::min(t.mins[(size_t)a], bmn[(size_t)t2 * 8 + a]);
+            }
+        }
+    } else {
+        span(0, n, t.maxes.data(), t.mins.data());
+    }
     t.nodes.reserve((size_t)(2 * (n / 8) + 16));
     std::vector<double> mx(t.maxes), mn(t.mins);
     int par = 5;                                                     // up to 32 subtrees in flight ...
@@ -803,6 +1218,13 @@ extern "C" int fdx_ckdtree_prebuild(const double* coords_host, const double* coo
 
 extern "C" int fdx_kdtree_set_threads(int32_t threads) {
     fdx::g_kd_threads.store(threads > 0 ? threads : 0);
+    return 0;
+}
+
+extern "C" int fdx_kdtree_tune(int32_t what, int64_t points) {
+    FDX_REQUIRE(what == 0 || what == 1, "fdx_kdtree_tune: what is 0 (team_min) or 1 (local_max)");
+    if (what == 0) fdx::g_kd_team_min.store(points > 0 ? std::max<long long>(points, 64) : 0);
+    else fdx::g_kd_local_max.store(points);
     return 0;
 }
 

@@ -193,6 +193,12 @@ int fdx_ckdtree_prebuild(const double* coords_host, const double* coords_dev, in
 /* Host threads the restated cKDTree may use from now on (0: the process's budget): the ranks of one host, each building the tree
  * of the replicated coordinates (utils/graph.py:60), share its cores. */
 int fdx_kdtree_set_threads(int32_t threads);
+/* Two sizes of the restated tree's build, for the host tests and probes - the tree is the same whatever they are.
+ * what 0: nodes of at least `points` points have their passes (bounds, median selection, partition) done by the library's standing
+ *         team of host threads instead of the building thread alone (0: the default, 200000);
+ * what 1: subtrees of at most `points` points are built on a contiguous copy of their points (negative: the default, 65536;
+ *         0: never). */
+int fdx_kdtree_tune(int32_t what, int64_t points);
 /* The neighbour lists the REFERENCE gets on such inputs: a host restatement of scipy.spatial.cKDTree(coords) with the
  * constructor's defaults followed by tree.query(coords, k = kk) with p = 2 (utils/graph.py:60-63), reproducing the order in
  * which the library meets equidistant points - hence which of them it returns.  coords: HOST (n, dim) row-major f64,

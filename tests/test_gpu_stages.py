@@ -505,7 +505,8 @@ def test_fit_with_four_dimensional_coordinates():
 
 
 
-@pytest.mark.parametrize("case", ["square", "hex", "cube3d", "random2d_ties", "line", "duplicates", "square_big_rows"])
+@pytest.mark.parametrize("case", ["square", "hex", "cube3d", "random2d_ties", "line", "duplicates", "heavy_duplicates",
+                                  "square_big_rows"])
 def test_device_ckdtree_queries_equal_the_host_restatement(case, monkeypatch):
     """fdx_graph_plan_set_ckdtree_lists_dev (csrc/kdtree_order.cpp): the k-nearest queries of the restated cKDTree answered by a
     device kernel (one lane per query: the host's node visits, heap operations and comparisons, in its order) against the same
@@ -524,6 +525,8 @@ def test_device_ckdtree_queries_equal_the_host_restatement(case, monkeypatch):
         "random2d_ties": (np.round(rs.rand(30000, 2) * 25.0, 1), 6, None),
         "line": (np.round(rs.rand(900, 1) * 50.0), 3, None),
         "duplicates": (np.concatenate([rs.rand(300, 2), rs.rand(100, 2).repeat(3, axis=0)]), 5, None),
+        # a node's median is its minimum (scipy splits just above it): 25 distinct places, ~120 spots on each
+        "heavy_duplicates": (rs.randint(0, 5, size=(3000, 2)).astype(np.float64), 6, None),
         "square_big_rows": (np.stack(np.meshgrid(np.arange(260.0), np.arange(250.0), indexing="ij"), -1).reshape(-1, 2), 6,
                             np.sort(rs.choice(65000, 9000, replace=False)).astype(np.int64)),
     }[case]

@@ -341,6 +341,69 @@ def test_bench_sweep_chunk_mirrors_the_kernel_table():
         assert bench.sweep_chunk(K) == want, K
 
 
+def test_ckdtree_order_restatement_on_heavily_duplicated_coordinates():
+    """Many spots on few distinct places (integer coordinates out of 2 to 1000 values, 1 to 3 dimensions): the median of a node is
+    often its MINIMUM along the split dimension, where scipy 1.15.3 splits just above it (split == nextafter(minimum, +inf),
+    every point at the minimum in the lesser child).  Index array and query lists against scipy itself, with the passes of the
+    nodes on the building thread and on the standing thread team (fdx_kdtree_tune)."""
+    from scipy.spatial import cKDTree
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    try:
+        for it in range(90):
+            n, dim, rng = int(rs.randint(70, 6000)), int(rs.randint(1, 4)), int(rs.choice([2, 5, 30, 1000]))
+            coords = np.ascontiguousarray(rs.randint(0, rng, size=(n, dim)).astype(np.float64))
+            kk = 5
+            lib.fdx_kdtree_tune(0, 64 if it % 3 else 0)
+            lib.fdx_kdtree_tune(1, (0, -1, 300)[it % 5 % 3])          # subtrees on a contiguous copy: never, from 65536, from 300 points
+            lib.fdx_kdtree_set_threads(int(rs.randint(2, 12)))
+            got, order = np.empty((n, kk), dtype=np.int64), np.empty(n, dtype=np.int64)
+            _lib.check(lib.fdx_ckdtree_knn(_lib.ptr_f64(coords), n, dim, kk, got.ctypes.data, order.ctypes.data))
+            tree = cKDTree(coords)
+            assert np.array_equal(order, tree.indices), (it, n, dim, rng)
+            assert np.array_equal(got, tree.query(coords, k=kk)[1]), (it, n, dim, rng)
+    finally:
+        lib.fdx_kdtree_tune(0, 0)
+        lib.fdx_kdtree_tune(1, -1)
+        lib.fdx_kdtree_set_threads(0)
+    # the split the tree reports for the smallest such node
+    c = np.array([3.0] * 12 + [4.0] * 7).reshape(-1, 1)
+    t = cKDTree(c)
+    assert t.tree.split == np.nextafter(3.0, np.inf) and t.tree.lesser.children == 12
+
+
+def test_ckdtree_thread_team_survives_a_fork():
+    """The standing thread team of the tree build (csrc/kdtree_order.cpp: KdTeam) lives in the process that started it: a fork()ed
+    child (multiprocessing's default start method) has the team's object without its threads and must start its own - same tree."""
+    import os
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    coords = np.ascontiguousarray(np.random.RandomState(0).rand(30000, 2))
+
+    def lists():
+        lib.fdx_kdtree_tune(0, 64)
+        lib.fdx_kdtree_set_threads(4)
+        got = np.empty((len(coords), 3), dtype=np.int64)
+        try:
+            _lib.check(lib.fdx_ckdtree_knn(_lib.ptr_f64(coords), len(coords), 2, 3, _lib.ptr_i64(got), None))
+        finally:
+            lib.fdx_kdtree_tune(0, 0)
+            lib.fdx_kdtree_set_threads(0)
+        return got
+
+    want = lists()
+    pid = os.fork()
+    if pid == 0:
+        code = 3
+        try:
+            code = 0 if np.array_equal(lists(), want) else 4
+        finally:
+            os._exit(code)
+    _, status = os.waitpid(pid, 0)
+    assert status == 0, status
+
+
 @pytest.mark.parametrize("case", ["square", "square_scaled", "hex", "cube3d", "random2d", "random3d", "line", "duplicates",
                                   "square_shuffled", "rect_large", "square_big", "random_big", "square_huge"])
 def test_ckdtree_order_restatement_matches_scipy(case, monkeypatch):
@@ -389,6 +452,20 @@ def test_ckdtree_order_restatement_matches_scipy(case, monkeypatch):
                 monkeypatch.delenv(k)
             lib.fdx_kdtree_set_threads(0)
             assert np.array_equal(order2, tree.indices) and np.array_equal(got2, want), env
+    # the passes of the top nodes by the standing thread team (from 200000 points; here from 64 and from 5000): the same tree
+    # ... and with the subtrees built through the index array instead of on a contiguous copy of their points
+    for team_min, threads, local_max in ((64, 5, 0), (5000, 0, 2000), (0, 0, 0)) if n > 700 else ():
+        lib.fdx_kdtree_tune(0, team_min)
+        lib.fdx_kdtree_tune(1, local_max)
+        lib.fdx_kdtree_set_threads(threads)
+        try:
+            got2, order2 = np.empty_like(got), np.empty_like(order)
+            _lib.check(lib.fdx_ckdtree_knn(_lib.ptr_f64(coords), n, dim, kk, got2.ctypes.data, order2.ctypes.data))
+        finally:
+            lib.fdx_kdtree_tune(0, 0)
+            lib.fdx_kdtree_tune(1, -1)
+            lib.fdx_kdtree_set_threads(0)
+        assert np.array_equal(order2, tree.indices) and np.array_equal(got2, want), team_min
     # and the adjacency the reference builds from it (utils/graph.py:66-81)
     from flashdeconv_amd.utils.graph import ckdtree_knn_adjacency
     import fdx_oracle as orc
