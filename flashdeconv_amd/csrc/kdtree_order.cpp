@@ -125,10 +125,25 @@ namespace {
 // is already waiting does not: its members spin a few microseconds for the next pass, then sleep on a condition variable.
 class KdTeam {
 public:
-    static KdTeam& get() { static KdTeam t; return t; }
-    // one user at a time (the nodes of a level queue here; what they queue for is short)
+    static KdTeam& get() { return slot(0); }
+    // The whole-share team (slot 0: the root's passes, the passes over all points) and narrower ones for the levels below - two of
+    // half the share, four of a quarter -, so that the nodes of a level do not queue for one team.
+    static KdTeam& slot(int i) { static KdTeam t[7]; return t[i]; }
+    // the team for a node `level` forks below the root (0, 1, 2), acquired: a free one of that level's, else the first of them
+    static KdTeam& for_level(int level, unsigned share) {
+        const int first = (1 << level) - 1, count = 1 << level;
+        const int want = (int)std::max(2u, std::min(share, 16u) >> level);
+        for (int i = 0; i < count; ++i)
+            if (slot(first + i).own_.try_lock()) { slot(first + i).acquired(want); return slot(first + i); }
+        slot(first).acquire(want);
+        return slot(first);
+    }
+    // one user at a time
     void acquire(int want) {
         own_.lock();
+        acquired(want);
+    }
+    void acquired(int want) {
         want = std::max(1, std::min(want, 32));
         if (pid_ != getpid()) {                                       // a fork()ed child has the objects but not the threads: leave them be
             if (!th_.empty()) new std::vector<std::thread>(std::move(th_));
@@ -297,6 +312,47 @@ static long long kd_fork_min() {
     return v;
 }
 
+// The two children of a node, the `less` one on a thread of its own when the node is large and forks are left (see the note at
+// KdTree): build(nodes, lesser) appends the subtree of that child to `nodes` and returns its root's index there.
+template <class Build>
+void kd_children(std::vector<KdNode>& nodes, bool fork, const Build& build, long long& less, long long& greater) {
+    bool forked = false;
+    if (fork) {
+        std::vector<KdNode> sub;
+        long long sub_root = -1;
+        bool sub_ok = true;
+        try {
+            std::thread th([&] {
+                try {
+                    sub_root = build(sub, true);
+                } catch (...) { sub_ok = false; }
+            });
+            forked = true;
+            try {
+                greater = build(nodes, false);
+            } catch (...) { th.join(); throw; }
+            th.join();
+        } catch (const std::system_error&) {
+            if (forked) throw;                                        // came out of the join path
+        }
+        if (forked) {
+            if (!sub_ok) throw std::bad_alloc();
+            const long long off = (long long)nodes.size();
+            nodes.reserve(nodes.size() + sub.size());
+            for (KdNode nd2 : sub) {
+                if (nd2.less >= 0) nd2.less += off;
+                if (nd2.greater >= 0) nd2.greater += off;
+                nodes.push_back(nd2);
+            }
+            less = sub_root + off;
+        }
+    }
+    if (!forked) {
+        less = build(nodes, true);
+        greater = build(nodes, false);
+    }
+}
+
 // A subtree small enough for a core's cache is built on a contiguous copy of its points - records {coordinates, index} in
 // index-array order - instead of through the index array: the same comparisons, hence the same swaps on the same positions and
 // the same index order when the records' indices are written back, but bounds, selection and partition stream through 24-byte
@@ -363,7 +419,7 @@ void rec_nth_element(KdRec<M>* r, long long nth, long long last, int d, int32_t*
 
 template <int M>
 long long kd_build_local(const KdTree& t, std::vector<KdNode>& nodes, KdRec<M>* rec, long long base, long long start, long long end,
-                         int32_t* scratch) {
+                         int32_t* scratch, int par_depth) {
     nodes.emplace_back();
     const long long node_index = (long long)nodes.size() - 1;
     nodes[(size_t)node_index].start = start;
@@ -402,8 +458,14 @@ long long kd_build_local(const KdTree& t, std::vector<KdNode>& nodes, KdRec<M>* 
             else { std::swap(r[p], r[q]); ++p; --q; }
         }
     }
-    const long long less = kd_build_local<M>(t, nodes, rec, base, start, start + p, scratch);
-    const long long greater = kd_build_local<M>(t, nodes, rec, base, start + p, end, scratch);
+    long long less = -1, greater = -1;
+    const bool fork = par_depth > 0 && n > kd_fork_min();
+    kd_children(nodes, fork, [&](std::vector<KdNode>& into, bool lesser) {
+        if (!lesser) return kd_build_local<M>(t, into, rec, base, start + p, end, scratch, par_depth - 1);
+        if (!fork) return kd_build_local<M>(t, into, rec, base, start, start + p, scratch, par_depth - 1);
+        std::vector<int32_t, KdRawAlloc<int32_t>> own((size_t)(2 * p));   // on another thread: list scratch of its own
+        return kd_build_local<M>(t, into, rec, base, start, start + p, own.data(), par_depth - 1);
+    }, less, greater);
     KdNode& nd = nodes[(size_t)node_index];
     nd.split_dim = d;
     nd.split = split;
@@ -413,27 +475,28 @@ long long kd_build_local(const KdTree& t, std::vector<KdNode>& nodes, KdRec<M>* 
 }
 
 template <int M>
-long long kd_build_on_copy(KdTree& t, std::vector<KdNode>& nodes, long long start, long long end) {
+long long kd_build_on_copy(KdTree& t, std::vector<KdNode>& nodes, long long start, long long end, int par_depth) {
     const long long n = end - start;
-    std::vector<KdRec<M>> rec((size_t)n);
+    std::vector<KdRec<M>, KdRawAlloc<KdRec<M>>> rec((size_t)n);
     long long* indices = t.indices.data();
     for (long long j = 0; j < n; ++j) {
         const long long i = indices[start + j];
         for (int c = 0; c < M; ++c) rec[(size_t)j].c[c] = t.data[i * M + c];
         rec[(size_t)j].i = i;
     }
-    std::vector<int32_t> scratch((size_t)(2 * n));
-    const long long root = kd_build_local<M>(t, nodes, rec.data(), start, start, end, scratch.data());
+    std::vector<int32_t, KdRawAlloc<int32_t>> scratch((size_t)(2 * n));
+    const long long root = kd_build_local<M>(t, nodes, rec.data(), start, start, end, scratch.data(), par_depth);
     for (long long j = 0; j < n; ++j) indices[start + j] = rec[(size_t)j].i;
     return root;
 }
 
-long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long long end, double* maxes, double* mins, int par_depth) {
+long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long long end, double* maxes, double* mins, int par_depth,
+                   int level) {
     const int m = t.m;
     if (end - start > t.leafsize && end - start <= kd_local_max()) {
-        if (m == 1) return kd_build_on_copy<1>(t, nodes, start, end);
-        if (m == 2) return kd_build_on_copy<2>(t, nodes, start, end);
-        if (m == 3) return kd_build_on_copy<3>(t, nodes, start, end);
+        if (m == 1) return kd_build_on_copy<1>(t, nodes, start, end, par_depth);
+        if (m == 2) return kd_build_on_copy<2>(t, nodes, start, end, par_depth);
+        if (m == 3) return kd_build_on_copy<3>(t, nodes, start, end, par_depth);
     }
     const double* data = t.data;
     long long* indices = t.indices.data();
@@ -446,14 +509,13 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
     // (a thread team for the passes of the top nodes was tried: 24-27 ms per million points instead of 22-24 - starting the
     // threads costs more than the 2 ms pass they share)
     // the top nodes' passes go to the standing team (KdTeam above): same bounds, same permutation
-    const bool teamed = end - start >= kd_team_min() && kd_thread_share() > 1 && m <= 8;
+    const bool teamed = end - start >= kd_team_min() && kd_thread_share() > 1 && m <= 8 && level <= 2;
     struct TeamHold {
         KdTeam* t = nullptr;
         ~TeamHold() { if (t) t->release(); }
     } hold;
     if (teamed) {
-        KdTeam& team = KdTeam::get();
-        team.acquire((int)std::min(kd_thread_share(), 16u));
+        KdTeam& team = KdTeam::for_level(level, kd_thread_share());
         hold.t = &team;
         const int nt = team.size();
         std::vector<double> bmx((size_t)nt * 8), bmn((size_t)nt * 8);
@@ -559,42 +621,11 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
         }
     }
     long long less = -1, greater = -1;
-    bool forked = false;
-    if (par_depth > 0 && end - start > kd_fork_min()) {
-        std::vector<KdNode> sub;
-        long long sub_root = -1;
-        bool sub_ok = true;
-        try {
-            std::thread th([&] {
-                try {
-                    std::vector<double> mx((size_t)m), mn((size_t)m);
-                    sub_root = kd_build(t, sub, start, p, mx.data(), mn.data(), par_depth - 1);
-                } catch (...) { sub_ok = false; }
-            });
-            forked = true;
-            try {
-                greater = kd_build(t, nodes, p, end, maxes, mins, par_depth - 1);
-            } catch (...) { th.join(); throw; }
-            th.join();
-        } catch (const std::system_error&) {
-            if (forked) throw;                                        // came out of the join path
-        }
-        if (forked) {
-            if (!sub_ok) throw std::bad_alloc();
-            const long long off = (long long)nodes.size();
-            nodes.reserve(nodes.size() + sub.size());
-            for (KdNode nd2 : sub) {
-                if (nd2.less >= 0) nd2.less += off;
-                if (nd2.greater >= 0) nd2.greater += off;
-                nodes.push_back(nd2);
-            }
-            less = sub_root + off;
-        }
-    }
-    if (!forked) {
-        less = kd_build(t, nodes, start, p, maxes, mins, par_depth - 1);
-        greater = kd_build(t, nodes, p, end, maxes, mins, par_depth - 1);
-    }
+    kd_children(nodes, par_depth > 0 && end - start > kd_fork_min(), [&](std::vector<KdNode>& into, bool lesser) {
+        if (!lesser) return kd_build(t, into, p, end, maxes, mins, par_depth - 1, level + 1);
+        std::vector<double> mx((size_t)m), mn((size_t)m);            // (possibly on another thread: bounds scratch of its own)
+        return kd_build(t, into, start, p, mx.data(), mn.data(), par_depth - 1, level + 1);
+    }, less, greater);
     KdNode& nd = nodes[(size_t)node_index];                           // (the vector may have moved)
     nd.split_dim = d;
     nd.split = split;
@@ -778,11 +809,16 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
     }
     t.nodes.reserve((size_t)(2 * (n / 8) + 16));
     std::vector<double> mx(t.maxes), mn(t.mins);
-    int par = 5;                                                     // up to 32 subtrees in flight ...
-    while (par > 0 && (1u << par) > kd_thread_share()) --par;        // ... but no more than this caller's share of the host's threads
+    // Up to 32 subtrees in flight, on up to twice this caller's share of the host's threads where the hardware has them: the share
+    // is a CPU-time quota (host_cpu_budget), the subtrees are a burst of 2-4 ms - 32 threads for that long are a tenth of what
+    // 16 CPUs may spend per scheduler period, and a million lattice points build in 8.5 ms instead of 10.
+    int par = 5;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    while (par > 0 && (1u << par) > std::min(hw, 2u * kd_thread_share())) --par;
+    if (kd_thread_share() <= 1) par = 0;
     if (const char* e = fdx::env("FDX_KDTREE_PAR_DEPTH")) par = std::max(0, std::min(10, atoi(e)));
     if (fdx::exp_env("FDX_KDTREE_SERIAL_BUILD")) par = 0;
-    kd_build(t, t.nodes, 0, n, mx.data(), mn.data(), par);
+    kd_build(t, t.nodes, 0, n, mx.data(), mn.data(), par, 0);
 }
 
 int ckdtree_query_host(const KdTree& t, int32_t kk, const int64_t* rows, int64_t n_rows, int64_t* idx_out, int64_t* tree_indices_out) {
@@ -1147,13 +1183,23 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
         int4* meta = reinterpret_cast<int4*>(sp);
         double* split = reinterpret_cast<double*>(sp + o_split);
         int* idx32 = reinterpret_cast<int*>(sp + o_idx);
-        for (size_t i = 0; i < nn; ++i) {
-            const KdNode& nd = t.nodes[i];
-            const bool leaf = nd.split_dim == -1;
-            meta[i] = make_int4(leaf ? -1 : (int)nd.split_dim, (int)(leaf ? nd.start : nd.less), (int)(leaf ? nd.end : nd.greater), 0);
-            split[i] = nd.split;
+        auto stage_span = [&](int tid, int n_t) {                     // (1 ms per million points on one thread)
+            for (size_t i = nn * (size_t)tid / (size_t)n_t, e = nn * ((size_t)tid + 1) / (size_t)n_t; i < e; ++i) {
+                const KdNode& nd = t.nodes[i];
+                const bool leaf = nd.split_dim == -1;
+                meta[i] = make_int4(leaf ? -1 : (int)nd.split_dim, (int)(leaf ? nd.start : nd.less), (int)(leaf ? nd.end : nd.greater), 0);
+                split[i] = nd.split;
+            }
+            for (long long i = n * tid / n_t, e = n * (tid + 1) / n_t; i < e; ++i) idx32[(size_t)i] = (int)t.indices[(size_t)i];
+        };
+        if (n >= kd_team_min() && kd_thread_share() > 1) {
+            KdTeam& team = KdTeam::get();
+            team.acquire((int)std::min(kd_thread_share(), 16u));
+            try { team.run(stage_span); } catch (...) { team.release(); throw; }
+            team.release();
+        } else {
+            stage_span(0, 1);
         }
-        for (long long i = 0; i < n; ++i) idx32[(size_t)i] = (int)t.indices[(size_t)i];
         if (rows_host) std::memcpy(sp + o_rows, rows_host, (size_t)nq * 8);
         const long long L = std::min<long long>((nq + 255) / 256, 1024) * 256;
         DevBuf d_meta, d_split, d_idx, d_rows, d_over, qp, qnode, qs, np, ni;

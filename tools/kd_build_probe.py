@@ -15,8 +15,8 @@ n = len(coords)
 rows = np.zeros(1, dtype=np.int64)
 out = np.empty((1, 7), dtype=np.int64)
 for threads in (0, 8):
-    for local_max in (0, 8192, 32768, 65536, 131072, 400000):
-        for team_min in (1 << 40, 500000, 200000):
+    for local_max in (0, 65536, 131072, 262144, 524288, 1048576):
+        for team_min in (1 << 40, 400000, 200000):
             lib.fdx_kdtree_set_threads(threads)
             lib.fdx_kdtree_tune(0, team_min)
             lib.fdx_kdtree_tune(1, local_max)
