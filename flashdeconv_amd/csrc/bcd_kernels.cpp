@@ -236,6 +236,8 @@ bool bcd_sweep_dispatch_part4(const BcdSweepArgs&, hipStream_t);
 bool bcd_sweep_dispatch_part5(const BcdSweepArgs&, hipStream_t);
 bool bcd_sweep_dispatch_part6(const BcdSweepArgs&, hipStream_t);
 bool bcd_sweep_dispatch_part7(const BcdSweepArgs&, hipStream_t);
+bool bcd_sweep_dispatch_part8(const BcdSweepArgs&, hipStream_t);
+bool bcd_sweep_dispatch_part9(const BcdSweepArgs&, hipStream_t);
 
 int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scratch_ld, hipStream_t st) {
     if (a.n <= 0 || a.n_slices <= 0) return 0;
@@ -243,7 +245,8 @@ int launch_bcd_sweep(const BcdSweepArgs& a, double* generic_scratch, size_t scra
         const bool hit = bcd_sweep_dispatch_part0(a, st) || bcd_sweep_dispatch_part1(a, st) ||
                          bcd_sweep_dispatch_part2(a, st) || bcd_sweep_dispatch_part3(a, st) ||
                          bcd_sweep_dispatch_part4(a, st) || bcd_sweep_dispatch_part5(a, st) ||
-                         bcd_sweep_dispatch_part6(a, st) || bcd_sweep_dispatch_part7(a, st);
+                         bcd_sweep_dispatch_part6(a, st) || bcd_sweep_dispatch_part7(a, st) ||
+                         bcd_sweep_dispatch_part8(a, st) || bcd_sweep_dispatch_part9(a, st);
         if (!hit) return fail(FDX_ERR_INTERNAL, "bcd sweep dispatch failed");
     } else if (sweep_uses_lds(a.K)) {
         if (!generic_scratch || scratch_ld != 0) return fail(FDX_ERR_INVALID, "LDS-resident BCD sweep needs the padded copy of XtX (sweep_lds_prepare)");

@@ -609,6 +609,7 @@ struct TilePlanDevice {
     size_t lds = 0;
 };
 
+#if !FDX_TILE_PART
 const double* log_table_dev(hipStream_t st) {   // -log of every table reciprocal in [2^-15, 1], one copy per device
     static std::mutex mu;
     static double* tabs[64] = {};
@@ -634,6 +635,7 @@ const double* log_table_dev(hipStream_t st) {   // -log of every table reciproca
     }
     return tabs[dev];
 }
+#endif
 
 // Wave split of a workgroup: consumers x groups per consumer + loaders.  Raw: 12 + 4 (measured at 1M x 2000 x 30: 1.92 ms
 // against 2.05 ms self-staged and 2.25 ms with 14 + 2).  Log modes: 16 self-staging waves - the table-driven log1p makes
@@ -641,6 +643,7 @@ const double* log_table_dev(hipStream_t st) {   // -log of every table reciproca
 // FDX_TILE_CFG=12 / 16 / 8 forces 12 + 4 / 16 + 0 / 8 + 2 (tuning experiments).
 // Wide form (33..64 cell types, or more buckets than the narrow split owns): twice the groups per wave, four type tiles,
 // MFMA A operands from the L2-resident operand copy of X_sketch (AVL2).
+#if !FDX_TILE_PART
 struct TileCfg { int NWC, NWL, JW, TT; bool wide; };
 static TileCfg tile_cfg(int mode, int K, int d) {
     const char* e = fdx::env("FDX_TILE_CFG");
@@ -792,6 +795,8 @@ bool tile_sketch_ok(int dtype, long long ldy, const void* Y, int G, int d, int K
     return tile_plan_for(*plan.owner, dtype, mode, K, st) != nullptr;
 }
 
+#endif  // !FDX_TILE_PART
+
 struct TileLaunch {
     TileArgs a;
     const void* Y;
@@ -809,15 +814,21 @@ struct TileLaunch {
     bool flat = false;   // the flat schedule (FF)
 };
 
+// This file is compiled twice (Makefile): FDX_TILE_PART 0 holds the schedule, the entry points and the float32 kernels,
+// FDX_TILE_PART 1 the float64 kernels alone (launch_tile_mode<double>) - the kernel template's instantiations took 110 s in
+// one translation unit, the longest of the build.
+int tile_logv();
+#if !FDX_TILE_PART
 static thread_local bool t_f64_math = false;
 TileF64Math::TileF64Math(bool on) : prev(t_f64_math) { t_f64_math = on; }
 TileF64Math::~TileF64Math() { t_f64_math = prev; }
 
-static int tile_logv() {
+int tile_logv() {
     if (t_f64_math) return 0;
     const char* e = fdx::env("FDX_TILE_LOGV");
     return e ? atoi(e) : 2;
 }
+#endif
 
 template <typename T, int MODE, int NWC, int NWL, int JW>
 static int launch_tile_tt(const TileLaunch& L, int TT, size_t lds, int grid, hipStream_t st) {
@@ -883,7 +894,7 @@ static int launch_tile_cfg(const TileLaunch& L, int NWC, int TT, size_t lds, int
 }
 
 template <typename T>
-static int launch_tile_mode(const TileLaunch& L, int mode, int NWC, int TT, size_t lds, int grid, hipStream_t st) {
+int launch_tile_mode(const TileLaunch& L, int mode, int NWC, int TT, size_t lds, int grid, hipStream_t st) {
     switch (mode) {
         case FDX_PRE_RAW: return launch_tile_cfg<T, FDX_PRE_RAW>(L, NWC, TT, lds, grid, st);
         case FDX_PRE_LOG_CPM: return launch_tile_cfg<T, FDX_PRE_LOG_CPM>(L, NWC, TT, lds, grid, st);
@@ -891,6 +902,10 @@ static int launch_tile_mode(const TileLaunch& L, int mode, int NWC, int TT, size
         default: return fail(FDX_ERR_INVALID, "tile sketch: unknown preprocess mode");
     }
 }
+#if FDX_TILE_PART
+template int launch_tile_mode<double>(const TileLaunch&, int, int, int, size_t, int, hipStream_t);
+#else
+extern template int launch_tile_mode<double>(const TileLaunch&, int, int, int, size_t, int, hipStream_t);
 
 // H[:, 0..n) (type-major, row stride ldh) and row_sumsq[0..n) for the n spots listed by row_map (NULL = rows 0..n-1).
 // A persistent workgroup fills its compute unit (16 waves x 127 registers): a launch of 256 leaves nothing for kernels of another
@@ -967,9 +982,11 @@ int launch_sketch_contract(const void* Y, int dtype, long long ldy, const int* r
     if (!tile_sketch_ok(dtype, ldy, Y, G, d, K, mode, plan, st)) return fail(FDX_ERR_INVALID, "sketch -> H: no one-kernel form for this shape");
     return launch_tile_sketch(Y, dtype, ldy, row_map, n, G, d, mode, plan, Xs, K, H, ldh, row_sumsq, st);
 }
+#endif  // FDX_TILE_PART
 
 }  // namespace fdx
 
+#if !FDX_TILE_PART
 // include/fdx.h: the float32-class log1p of the tile kernel on a host array (accuracy tests)
 namespace fdx {
 __global__ void log1p_f32_probe_kernel(const float* __restrict__ y, float scale, long long n, float* __restrict__ out) {
@@ -1012,3 +1029,4 @@ extern "C" int fdx_tile_schedule(const int32_t* gene_bucket, const double* gene_
     std::copy(h.off.begin(), h.off.end(), off_out);
     return 0;
 }
+#endif  // !FDX_TILE_PART
