@@ -38,6 +38,7 @@
 #include <system_error>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -72,13 +73,30 @@ struct KdTree {
     int m = 0;
     long long leafsize = 16;
     std::vector<long long, KdRawAlloc<long long>> indices;
-    std::vector<KdNode> nodes;
+    // all nodes, root first: raw storage that the threads of the build's last pass fill (and touch first) in parallel
+    struct Nodes {
+        KdNode* p = nullptr;
+        size_t n = 0;
+        Nodes() = default;
+        Nodes(const Nodes&) = delete;
+        Nodes& operator=(const Nodes&) = delete;
+        ~Nodes() { ::operator delete(p); }
+        void raw(size_t count) { ::operator delete(p); p = static_cast<KdNode*>(::operator new(count * sizeof(KdNode))); n = count; }
+        size_t size() const { return n; }
+        const KdNode& operator[](size_t i) const { return p[i]; }
+    } nodes;
     std::vector<double> maxes, mins;   // of the whole data set
+    // build only: the node vectors of the subtrees that were built on threads of their own (kd_children), until kd_build_tree
+    // lays them out behind one another in `nodes`
+    std::mutex seg_mu;
+    std::deque<std::vector<KdNode>> segs;
 };
 
-// par_depth > 0: the `less` subtree of a large node is built by another thread into a node vector of its own and appended
-// afterwards (the index array is partitioned in place - disjoint ranges; the NUMBERING of the nodes differs from a serial build,
-// which nothing reads: queries follow the less / greater links).  The serial build was 130 of the 145 ms the tie remedy spent on
+// par_depth > 0: the `less` subtree of a large node is built by another thread into a node vector of its own, which joins the
+// tree's list of segments; the parent's link to it is the segment's tag until kd_build_tree lays all segments out in one
+// vector (appending every subtree to its parent's vector on the way up copied the nodes once per level: 2 of 12 ms per million
+// points).  The index array is partitioned in place - disjoint ranges; the NUMBERING of the nodes differs from a serial build,
+// which nothing reads: queries follow the less / greater links.  The serial build was 130 of the 145 ms the tie remedy spent on
 // the host for a million lattice points: its top levels are cache-missing passes over all points.
 }  // namespace
 // Host threads this process may keep busy: the hardware's count, cut to the CPU bandwidth quota of the control group the process
@@ -183,7 +201,7 @@ public:
 private:
     void loop(int tid, uint64_t seen) {
         for (;;) {
-            for (int s = 0; s < 4000 && gen_.load(std::memory_order_acquire) == seen; ++s) __builtin_ia32_pause();
+            for (int s = 0; s < 1500 && gen_.load(std::memory_order_acquire) == seen; ++s) __builtin_ia32_pause();
             if (gen_.load(std::memory_order_acquire) == seen) {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_acquire) != seen; });
@@ -314,17 +332,17 @@ static long long kd_fork_min() {
 
 // The two children of a node, the `less` one on a thread of its own when the node is large and forks are left (see the note at
 // KdTree): build(nodes, lesser) appends the subtree of that child to `nodes` and returns its root's index there.
+inline long long kd_seg_tag(long long seg) { return -(2 + seg); }     // a link to the root (node 0) of segment `seg`
 template <class Build>
-void kd_children(std::vector<KdNode>& nodes, bool fork, const Build& build, long long& less, long long& greater) {
+void kd_children(KdTree& t, std::vector<KdNode>& nodes, bool fork, const Build& build, long long& less, long long& greater) {
     bool forked = false;
     if (fork) {
         std::vector<KdNode> sub;
-        long long sub_root = -1;
         bool sub_ok = true;
         try {
             std::thread th([&] {
                 try {
-                    sub_root = build(sub, true);
+                    (void)build(sub, true);                               // (its root is node 0 of `sub`)
                 } catch (...) { sub_ok = false; }
             });
             forked = true;
@@ -337,14 +355,9 @@ void kd_children(std::vector<KdNode>& nodes, bool fork, const Build& build, long
         }
         if (forked) {
             if (!sub_ok) throw std::bad_alloc();
-            const long long off = (long long)nodes.size();
-            nodes.reserve(nodes.size() + sub.size());
-            for (KdNode nd2 : sub) {
-                if (nd2.less >= 0) nd2.less += off;
-                if (nd2.greater >= 0) nd2.greater += off;
-                nodes.push_back(nd2);
-            }
-            less = sub_root + off;
+            std::lock_guard<std::mutex> lk(t.seg_mu);
+            t.segs.push_back(std::move(sub));
+            less = kd_seg_tag((long long)t.segs.size() - 1);
         }
     }
     if (!forked) {
@@ -418,7 +431,7 @@ void rec_nth_element(KdRec<M>* r, long long nth, long long last, int d, int32_t*
 }
 
 template <int M>
-long long kd_build_local(const KdTree& t, std::vector<KdNode>& nodes, KdRec<M>* rec, long long base, long long start, long long end,
+long long kd_build_local(KdTree& t, std::vector<KdNode>& nodes, KdRec<M>* rec, long long base, long long start, long long end,
                          int32_t* scratch, int par_depth) {
     nodes.emplace_back();
     const long long node_index = (long long)nodes.size() - 1;
@@ -460,7 +473,7 @@ long long kd_build_local(const KdTree& t, std::vector<KdNode>& nodes, KdRec<M>* 
     }
     long long less = -1, greater = -1;
     const bool fork = par_depth > 0 && n > kd_fork_min();
-    kd_children(nodes, fork, [&](std::vector<KdNode>& into, bool lesser) {
+    kd_children(t, nodes, fork, [&](std::vector<KdNode>& into, bool lesser) {
         if (!lesser) return kd_build_local<M>(t, into, rec, base, start + p, end, scratch, par_depth - 1);
         if (!fork) return kd_build_local<M>(t, into, rec, base, start, start + p, scratch, par_depth - 1);
         std::vector<int32_t, KdRawAlloc<int32_t>> own((size_t)(2 * p));   // on another thread: list scratch of its own
@@ -621,7 +634,7 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
         }
     }
     long long less = -1, greater = -1;
-    kd_children(nodes, par_depth > 0 && end - start > kd_fork_min(), [&](std::vector<KdNode>& into, bool lesser) {
+    kd_children(t, nodes, par_depth > 0 && end - start > kd_fork_min(), [&](std::vector<KdNode>& into, bool lesser) {
         if (!lesser) return kd_build(t, into, p, end, maxes, mins, par_depth - 1, level + 1);
         std::vector<double> mx((size_t)m), mn((size_t)m);            // (possibly on another thread: bounds scratch of its own)
         return kd_build(t, into, start, p, mx.data(), mn.data(), par_depth - 1, level + 1);
@@ -807,7 +820,6 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
     } else {
         span(0, n, t.maxes.data(), t.mins.data());
     }
-    t.nodes.reserve((size_t)(2 * (n / 8) + 16));
     std::vector<double> mx(t.maxes), mn(t.mins);
     // Up to 32 subtrees in flight, on up to twice this caller's share of the host's threads where the hardware has them: the share
     // is a CPU-time quota (host_cpu_budget), the subtrees are a burst of 2-4 ms - 32 threads for that long are a tenth of what
@@ -818,7 +830,36 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
     if (kd_thread_share() <= 1) par = 0;
     if (const char* e = fdx::env("FDX_KDTREE_PAR_DEPTH")) par = std::max(0, std::min(10, atoi(e)));
     if (fdx::exp_env("FDX_KDTREE_SERIAL_BUILD")) par = 0;
-    kd_build(t, t.nodes, 0, n, mx.data(), mn.data(), par, 0);
+    std::vector<KdNode> top;
+    top.reserve(1024);
+    kd_build(t, top, 0, n, mx.data(), mn.data(), par, 0);
+    // one vector: the top nodes, then the segments in the order they were handed in; tags become indices
+    const size_t ns = t.segs.size();
+    std::vector<long long> off(ns + 2, 0);
+    off[1] = (long long)top.size();
+    for (size_t i = 0; i < ns; ++i) off[i + 2] = off[i + 1] + (long long)t.segs[i].size();
+    t.nodes.raw((size_t)off[ns + 1]);
+    KdNode* flat = t.nodes.p;
+    auto lay = [&](size_t si) {                                       // si = 0: the top nodes, else segment si - 1
+        const std::vector<KdNode>& src = si == 0 ? top : t.segs[si - 1];
+        const long long o = off[si];
+        auto link = [&](long long l) { return l >= 0 ? l + o : l == -1 ? -1 : off[(size_t)(-l - 2) + 1]; };
+        for (size_t i = 0; i < src.size(); ++i) {
+            KdNode nd = src[i];
+            nd.less = link(nd.less);
+            nd.greater = link(nd.greater);
+            ::new (flat + (size_t)o + i) KdNode(nd);
+        }
+    };
+    if (ns > 0 && kd_thread_share() > 1) {
+        KdTeam& team = KdTeam::get();
+        team.acquire((int)std::min(kd_thread_share(), 16u));
+        team.run([&](int tid, int n_t) { for (size_t si = (size_t)tid; si < ns + 1; si += (size_t)n_t) lay(si); });
+        team.release();
+    } else {
+        for (size_t si = 0; si < ns + 1; ++si) lay(si);
+    }
+    t.segs.clear();
 }
 
 int ckdtree_query_host(const KdTree& t, int32_t kk, const int64_t* rows, int64_t n_rows, int64_t* idx_out, int64_t* tree_indices_out) {
@@ -1125,15 +1166,23 @@ int ckdtree_prebuild(const double* coords_host, const double* coords_dev, long l
         // on the library's side stream: the caller's stream may still be busy (the sketch of the stopped fit), the coordinates
         // are nobody's output
         hipStream_t ss = library_side_stream();
+        const auto tf0 = std::chrono::steady_clock::now();
         FDX_TRY(p->pin.get((size_t)n * dim * sizeof(double)));
         FDX_HIP(hipMemcpyAsync(p->pin.p, coords_dev, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToHost, ss));
         FDX_HIP(hipStreamSynchronize(ss));
         src = static_cast<const double*>(p->pin.p);
+        if (fdx::env("FDX_TRACE_HOST"))
+            std::fprintf(stderr, "[fdx-host] ckdtree prebuild: coordinates fetched in %.2f ms\n",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count());
     }
     KdPrebuilt* raw = p.get();
     try {
         p->th = std::thread([raw, src, n, dim] {
+            const auto tb0 = std::chrono::steady_clock::now();
             try { kd_build_tree(raw->t, src, n, dim); } catch (...) { raw->failed = true; }
+            if (fdx::env("FDX_TRACE_HOST"))
+                std::fprintf(stderr, "[fdx-host] ckdtree prebuild: tree of %lld points built in %.2f ms\n", n,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
         });
     } catch (const std::system_error&) {
         return 0;                        // no thread: the lists call builds the tree itself
@@ -1152,10 +1201,12 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
         std::lock_guard<std::mutex> lk(g_pre_mu);
         if (g_pre && g_pre->key_host == coords_host_in && g_pre->key_dev == coords_dev && g_pre->n == n && g_pre->dim == dim) pre = std::move(g_pre);
     }
+    const auto tj0 = std::chrono::steady_clock::now();
     if (pre) {
         pre->th.join();
         if (pre->failed) pre.reset();
     }
+    const double join_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count();
     // coords_host NULL: the coordinates are fetched here, into pinned memory
     PinnedScope pin_coords;
     const double* coords_host = coords_host_in;
@@ -1220,6 +1271,7 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
             FDX_TRY(d_rows.alloc((size_t)nq * 8));
             FDX_HIP(hipMemcpyAsync(d_rows.p, sp + o_rows, (size_t)nq * 8, hipMemcpyHostToDevice, st));
         }
+        const auto ts1 = std::chrono::steady_clock::now();
         KdBounds bnd{};
         for (int a = 0; a < dim; ++a) { bnd.mins[a] = t.mins[(size_t)a]; bnd.maxes[a] = t.maxes[(size_t)a]; }
         const dim3 grid((unsigned)(L / 256)), blk(256);
@@ -1237,9 +1289,10 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
         FDX_HIP(hipMemcpyAsync(&over, d_over.p, 4, hipMemcpyDeviceToHost, st));
         FDX_HIP(hipStreamSynchronize(st));                 // the staging vectors are this function's; the flag decides the route
         if (trace)
-            std::fprintf(stderr, "[fdx-host] ckdtree: build %.1f ms (%lld nodes), %lld queries on the device %.1f ms%s\n",
-                         std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)nn, nq,
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(),
+            std::fprintf(stderr, "[fdx-host] ckdtree: waited %.1f ms for the tree, build here %.1f ms (%lld nodes), staging + uploads queued %.2f ms, %lld queries on the device %.2f ms%s\n",
+                         join_ms, std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)nn,
+                         std::chrono::duration<double, std::milli>(ts1 - t1).count(), nq,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count(),
                          over ? " (far-node heap too deep: repeated on the host)" : "");
         if (!over) return 0;
     }
