@@ -522,7 +522,7 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
     // (a thread team for the passes of the top nodes was tried: 24-27 ms per million points instead of 22-24 - starting the
     // threads costs more than the 2 ms pass they share)
     // the top nodes' passes go to the standing team (KdTeam above): same bounds, same permutation
-    const bool teamed = end - start >= kd_team_min() && kd_thread_share() > 1 && m <= 8 && level <= 2;
+    const bool teamed = end - start >= kd_team_min() && end - start < 0x7fffffffLL && kd_thread_share() > 1 && m <= 8 && level <= 2;   // (32-bit positions in the lists)
     struct TeamHold {
         KdTeam* t = nullptr;
         ~TeamHold() { if (t) t->release(); }
@@ -937,7 +937,9 @@ namespace {
 constexpr int KD_QCAP = 48;
 struct KdBounds { double mins[3], maxes[3]; };
 
-template <int M>
+// NBL: the k-nearest heap of a lane (kk <= 16 entries, by far the busiest of the two: a pop and a push per accepted candidate)
+// lives in LDS, lane-interleaved like its global form - 12 bytes x kk x 256 lanes
+template <int M, bool NBL>
 __global__ __launch_bounds__(256) void kd_query_kernel(const double* __restrict__ coords, const int4* __restrict__ meta,
                                                        const double* __restrict__ split, const int* __restrict__ indices,
                                                        const KdBounds bnd, int kk, const long long* __restrict__ rows, long long n_rows,
@@ -949,8 +951,11 @@ __global__ __launch_bounds__(256) void kd_query_kernel(const double* __restrict_
     auto QP = [&](int j) -> double& { return q_pri[(size_t)j * L + gid]; };
     auto QN = [&](int j) -> int& { return q_node[(size_t)j * L + gid]; };
     auto QS = [&](int j, int a) -> double& { return q_side[((size_t)j * M + a) * L + gid]; };
-    auto NP = [&](int j) -> double& { return nb_pri[(size_t)j * L + gid]; };
-    auto NI = [&](int j) -> int& { return nb_idx[(size_t)j * L + gid]; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char kd_smem[];
+    double* const l_pri = reinterpret_cast<double*>(kd_smem);
+    int* const l_idx = reinterpret_cast<int*>(kd_smem + (size_t)kk * 256 * sizeof(double));
+    auto NP = [&](int j) -> double& { return NBL ? l_pri[j * 256 + (int)threadIdx.x] : nb_pri[(size_t)j * L + gid]; };
+    auto NI = [&](int j) -> int& { return NBL ? l_idx[j * 256 + (int)threadIdx.x] : nb_idx[(size_t)j * L + gid]; };
     for (long long r = gid; r < n_rows; r += L) {
         const long long self = rows ? rows[r] : r;
         double x[M];
@@ -1252,7 +1257,7 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
             stage_span(0, 1);
         }
         if (rows_host) std::memcpy(sp + o_rows, rows_host, (size_t)nq * 8);
-        const long long L = std::min<long long>((nq + 255) / 256, 1024) * 256;
+        const long long L = std::min<long long>((nq + 255) / 256, 1024) * 256;   // (twice the lanes in flight - the kernel has the registers for it - measured no faster: 1.85 ms either way)
         DevBuf d_meta, d_split, d_idx, d_rows, d_over, qp, qnode, qs, np, ni;
         FDX_TRY(d_meta.alloc(nn * sizeof(int4)));
         FDX_TRY(d_split.alloc(nn * sizeof(double)));
@@ -1276,10 +1281,19 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
         for (int a = 0; a < dim; ++a) { bnd.mins[a] = t.mins[(size_t)a]; bnd.maxes[a] = t.maxes[(size_t)a]; }
         const dim3 grid((unsigned)(L / 256)), blk(256);
         const long long* rows_d = rows_host ? d_rows.as<long long>() : nullptr;
+        const bool nbl = kk <= 16;
+        const size_t nb_lds = nbl ? (size_t)kk * 256 * 12 : 0;
 #define FDX_KD_LAUNCH(MM)                                                                                                              \
-        hipLaunchKernelGGL(kd_query_kernel<MM>, grid, blk, 0, st, coords_dev, d_meta.as<int4>(), d_split.as<double>(), d_idx.as<int>(), bnd, \
-                           kk, rows_d, nq, ids_dev, qp.as<double>(), qnode.as<int>(), qs.as<double>(), np.as<double>(), ni.as<int>(), L,  \
-                           d_over.as<int>())
+        do {                                                                                                                           \
+            if (nbl)                                                                                                                   \
+                hipLaunchKernelGGL((kd_query_kernel<MM, true>), grid, blk, nb_lds, st, coords_dev, d_meta.as<int4>(), d_split.as<double>(), \
+                                   d_idx.as<int>(), bnd, kk, rows_d, nq, ids_dev, qp.as<double>(), qnode.as<int>(), qs.as<double>(),      \
+                                   np.as<double>(), ni.as<int>(), L, d_over.as<int>());                                                   \
+            else                                                                                                                       \
+                hipLaunchKernelGGL((kd_query_kernel<MM, false>), grid, blk, 0, st, coords_dev, d_meta.as<int4>(), d_split.as<double>(),    \
+                                   d_idx.as<int>(), bnd, kk, rows_d, nq, ids_dev, qp.as<double>(), qnode.as<int>(), qs.as<double>(),      \
+                                   np.as<double>(), ni.as<int>(), L, d_over.as<int>());                                                   \
+        } while (0)
         if (dim == 1) FDX_KD_LAUNCH(1);
         else if (dim == 2) FDX_KD_LAUNCH(2);
         else FDX_KD_LAUNCH(3);
