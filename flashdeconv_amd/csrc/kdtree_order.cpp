@@ -173,7 +173,7 @@ public:
             const uint64_t g0 = gen_.load();                          // (no pass is under way: the team is ours)
             try { th_.emplace_back([this, tid, g0] { loop(tid, g0); }); } catch (const std::system_error&) { break; }
         }
-        nt_ = (int)th_.size() + 1;
+        nt_ = std::min(want, (int)th_.size() + 1);                    // (a smaller share than an earlier caller's: the extra members sit passes out)
     }
     void release() { own_.unlock(); }
     int size() const { return nt_; }
@@ -181,7 +181,7 @@ public:
     void run(const std::function<void(int, int)>& f) {
         if (nt_ == 1) { f(0, 1); return; }
         job_ = &f;
-        left_.store(nt_ - 1, std::memory_order_relaxed);
+        left_.store((int)th_.size(), std::memory_order_relaxed);      // every member reports back, also those beyond nt_
         { std::lock_guard<std::mutex> lk(m_); gen_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
         f(0, nt_);
