@@ -90,9 +90,12 @@ struct KdTree {
     // lays them out behind one another in `nodes`
     std::mutex seg_mu;
     std::deque<std::vector<KdNode>> segs;
+    bool pooled = false;                 // the build may cut its work into tasks of the thread pool (more than one thread to its name)
+    std::atomic<bool> failed{false};     // a task ran out of memory
+    std::vector<int32_t, KdRawAlloc<int32_t>> lpos, rpos;   // the partition passes' position lists, by index-array position
 };
 
-// par_depth > 0: the `less` subtree of a large node is built by another thread into a node vector of its own, which joins the
+// par_depth > 0: the `less` subtree of a large node is built as a task of the thread pool into a node vector of its own, which joins the
 // tree's list of segments; the parent's link to it is the segment's tag until kd_build_tree lays all segments out in one
 // vector (appending every subtree to its parent's vector on the way up copied the nodes once per level: 2 of 12 ms per million
 // points).  The index array is partitioned in place - disjoint ranges; the NUMBERING of the nodes differs from a serial build,
@@ -136,99 +139,155 @@ static unsigned kd_thread_share() {
     return v > 0 ? (unsigned)v : host_cpu_budget();
 }
 namespace {
-// ---- a standing team of host threads for the passes of the tree's TOP nodes ------------------------------------------------
+// ---- one standing pool of host threads for everything the build does in parallel ------------------------------------------------
 // The build's critical path is the chain root -> child -> grandchild: bounds, selection and partition of a million, half a
-// million, a quarter of a million points, each a serial pass (12 + 6 + 3 ms of the 21 ms a million lattice points cost with the
-// subtrees already on threads of their own).  Starting threads per pass costs more than the pass (tried, round 5); a team that
-// is already waiting does not: its members spin a few microseconds for the next pass, then sleep on a condition variable.
-class KdTeam {
+// million, a quarter of a million points, each a serial pass in scipy (12 + 6 + 3 ms of the 21 ms a million lattice points cost
+// with the subtrees already on threads of their own).  Starting threads per pass costs more than the pass (tried, round 5);
+// threads that are already waiting do not.  Everything parallel is a TASK of this pool - the chunks of a top node's pass
+// (`parallel`), the `less` subtree of a large node (`spawn`) - and whoever waits for tasks of its own runs other tasks meanwhile
+// (`wait_help`), so several nodes have their passes under way at once on the same 16 threads, and the process never has more
+// than its share of the host's CPUs busy: a burst on 70 threads (teams per level + a thread per subtree, the first form of this
+// round) leaves a 5 ms scheduler slice stranded on every CPU it touched, and a 16-CPU quota then throttles a whole period
+// (3 of 28 periods in a 20-fit run: 10 ms steps among 32 ms ones).
+class KdPool {
 public:
-    static KdTeam& get() { return slot(0); }
-    // The whole-share team (slot 0: the root's passes, the passes over all points) and narrower ones for the levels below - two of
-    // half the share, four of a quarter -, so that the nodes of a level do not queue for one team.
-    static KdTeam& slot(int i) { static KdTeam t[7]; return t[i]; }
-    // the team for a node `level` forks below the root (0, 1, 2), acquired: a free one of that level's, else the first of them
-    static KdTeam& for_level(int level, unsigned share) {
-        const int first = (1 << level) - 1, count = 1 << level;
-        const int want = (int)std::max(2u, std::min(share, 16u) >> level);
-        for (int i = 0; i < count; ++i)
-            if (slot(first + i).own_.try_lock()) { slot(first + i).acquired(want); return slot(first + i); }
-        slot(first).acquire(want);
-        return slot(first);
-    }
-    // one user at a time
-    void acquire(int want) {
-        own_.lock();
-        acquired(want);
-    }
-    void acquired(int want) {
-        want = std::max(1, std::min(want, 32));
-        if (pid_ != getpid()) {                                       // a fork()ed child has the objects but not the threads: leave them be
-            if (!th_.empty()) new std::vector<std::thread>(std::move(th_));
-            th_.clear();
-            pid_ = getpid();
+    static KdPool& get() { static KdPool p; return p; }
+    // members (the caller included) this build may keep busy; creates what is missing
+    void want(int members) {
+        members = std::max(1, std::min(members, 32));
+        if (pid_.load() != getpid()) {
+            // A fork()ed child has the object but not the threads, and the mutex / condition variable in whatever state the
+            // parent's threads had them in at that instant (a worker about to sleep holds the condition variable's internal
+            // lock: the child's first notify would wait for it for ever).  Everything is made anew; the old thread objects are
+            // left alone (they cannot be joined).  The first caller in the child does this before anything else runs here.
+            new std::vector<std::thread>(std::move(th_));
+            new (&th_) std::vector<std::thread>();
+            new (&m_) std::mutex();
+            new (&cv_) std::condition_variable();
+            new (&q_) std::deque<Task>();
+            n_queued_.store(0);
+            active_.store(1);
+            pid_.store(getpid());
         }
-        while ((int)th_.size() + 1 < want) {
-            const int tid = (int)th_.size() + 1;
-            const uint64_t g0 = gen_.load();                          // (no pass is under way: the team is ours)
-            try { th_.emplace_back([this, tid, g0] { loop(tid, g0); }); } catch (const std::system_error&) { break; }
+        std::lock_guard<std::mutex> lk(m_);
+        while ((int)th_.size() + 1 < members) {
+            const int wid = (int)th_.size();
+            try { th_.emplace_back([this, wid] { loop(wid); }); } catch (const std::system_error&) { break; }
         }
-        nt_ = std::min(want, (int)th_.size() + 1);                    // (a smaller share than an earlier caller's: the extra members sit passes out)
+        active_.store(std::min(members, (int)th_.size() + 1));
     }
-    void release() { own_.unlock(); }
-    int size() const { return nt_; }
-    // f(tid, nt) on every member, the caller being member 0; returns when all are through
-    void run(const std::function<void(int, int)>& f) {
-        if (nt_ == 1) { f(0, 1); return; }
-        job_ = &f;
-        left_.store((int)th_.size(), std::memory_order_relaxed);      // every member reports back, also those beyond nt_
-        { std::lock_guard<std::mutex> lk(m_); gen_.fetch_add(1, std::memory_order_release); }
-        cv_.notify_all();
-        f(0, nt_);
-        for (int s = 0; s < 20000 && left_.load(std::memory_order_acquire) != 0; ++s) __builtin_ia32_pause();
-        if (left_.load(std::memory_order_acquire) != 0) {
+    int size() const { return active_.load(); }
+    // a task; *pending (may be NULL) is decremented when it has run
+    void spawn(std::function<void()> fn, std::atomic<int>* pending) {
+        if (pending) pending->fetch_add(1, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(Task{std::move(fn), pending});
+            n_queued_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_one();
+    }
+    // runs tasks until *pending is zero
+    // (a waiter with nothing to run spins briefly, then SLEEPS until a task is queued or a counter reaches zero: 32 members
+    // spinning through a 10 ms build were 0.3 CPU-seconds per fit, and a 16-CPU quota throttled one step in five)
+    void wait_help(std::atomic<int>& pending) {
+        int idle = 0;
+        while (pending.load(std::memory_order_acquire) != 0) {
+            if (run_one()) { idle = 0; continue; }
+            if (++idle < 400) { __builtin_ia32_pause(); continue; }
             std::unique_lock<std::mutex> lk(m_);
-            done_.wait(lk, [this] { return left_.load(std::memory_order_acquire) == 0; });
+            cv_.wait(lk, [&] { return pending.load(std::memory_order_acquire) == 0 || !q_.empty(); });
+            idle = 0;
         }
     }
-    std::vector<int32_t> lpos, rpos;                                  // scratch of the partition passes, kept between builds
-    ~KdTeam() {
-        if (pid_ != getpid()) { new std::vector<std::thread>(std::move(th_)); return; }
+    // f(tid, nt) for tid < nt, the caller taking tid 0 and whatever else nobody has started yet
+    // (a chunk that throws - out of memory - sets *failed; the caller looks at it when the build is over)
+    template <class F>
+    void parallel(int nt, const F& f, std::atomic<bool>* failed) {
+        if (nt <= 1) { f(0, 1); return; }
+        std::atomic<int> pending{nt - 1};
+        {                                                             // all chunks under one lock, one wake-up for everybody
+            std::lock_guard<std::mutex> lk(m_);
+            for (int tid = 1; tid < nt; ++tid)
+                q_.push_back(Task{[&f, tid, nt, failed] { try { f(tid, nt); } catch (...) { failed->store(true); } }, &pending});
+            n_queued_.fetch_add(nt - 1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        try { f(0, nt); } catch (...) { failed->store(true); }
+        wait_help(pending);
+    }
+    ~KdPool() {
+        if (pid_.load() != getpid()) { new std::vector<std::thread>(std::move(th_)); return; }
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
         cv_.notify_all();
         for (auto& t : th_) if (t.joinable()) t.join();
     }
 private:
-    void loop(int tid, uint64_t seen) {
+    struct Task { std::function<void()> fn; std::atomic<int>* pending; };
+    bool run_one() {
+        if (n_queued_.load(std::memory_order_acquire) == 0) return false;
+        Task t;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (q_.empty()) return false;
+            t = std::move(q_.back());                                 // newest first: the chunks of a pass that has just been cut run
+            q_.pop_back();                                            // before subtrees queued earlier - the passes are the critical path
+            n_queued_.fetch_sub(1, std::memory_order_release);
+        }
+        t.fn();                                                       // (tasks catch what they throw)
+        if (t.pending && t.pending->fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            { std::lock_guard<std::mutex> lk(m_); }                   // (a waiter between its test and its sleep holds this)
+            cv_.notify_all();
+        }
+        return true;
+    }
+    void loop(int wid) {
         for (;;) {
-            for (int s = 0; s < 1500 && gen_.load(std::memory_order_acquire) == seen; ++s) __builtin_ia32_pause();
-            if (gen_.load(std::memory_order_acquire) == seen) {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_acquire) != seen; });
-                if (stop_) return;
+            if (wid + 1 < active_.load(std::memory_order_relaxed) && run_one()) continue;
+            // nothing to do: a short spin (the next pass of a node usually follows within microseconds), then sleep
+            bool got = false;
+            for (int s = 0; s < 1500 && !got; ++s) {
+                __builtin_ia32_pause();
+                got = wid + 1 < active_.load(std::memory_order_relaxed) && n_queued_.load(std::memory_order_acquire) != 0;
             }
-            seen = gen_.load(std::memory_order_acquire);
-            if (tid < nt_) (*job_)(tid, nt_);
-            if (left_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-                std::lock_guard<std::mutex> lk(m_);
-                done_.notify_one();
-            }
+            if (got) continue;
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || (wid + 1 < active_.load(std::memory_order_relaxed) && !q_.empty()); });
+            if (stop_) return;
         }
     }
-    std::mutex own_, m_;
-    std::condition_variable cv_, done_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Task> q_;
+    std::atomic<int> n_queued_{0};
     std::vector<std::thread> th_;
-    const std::function<void(int, int)>* job_ = nullptr;
-    std::atomic<uint64_t> gen_{0};
-    std::atomic<int> left_{0};
+    std::atomic<int> active_{1};
     bool stop_ = false;
-    int nt_ = 1;
-    pid_t pid_ = getpid();
+    std::atomic<pid_t> pid_{getpid()};
 };
 
+// chunks a pass over `len` of the tree's n points is cut into: the node's share of the pool (the root all members, its children
+// half each: the nodes of a level have their passes under way together), at least two, never chunks under 256 points
+struct KdTree;
+static int kd_pass_chunks(const KdTree& t, long long len);
+// Members of the pool a build may keep busy: twice the caller's share of the host's CPUs where the hardware has the threads, 32
+// at most.  The share is a CPU-TIME quota (host_cpu_budget), a build is a burst of ~10 ms: 32 threads for that long are a fifth
+// of what 16 CPUs may spend per scheduler period, and the 32 subtrees of a million points run side by side instead of in two rounds.
+static int kd_pool_members() {
+    const unsigned share = kd_thread_share();
+    if (share <= 1) return 1;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (int)std::min(std::min(hw, 2u * share), 32u);
+}
 static long long kd_team_min() {                                     // fdx_kdtree_set_team_min: the tests send small nodes through the team
     const long long v = g_kd_team_min.load();
-    return v > 0 ? v : 200000;
+    return v > 0 ? v : 400000;                                        // (a million points: the root and its two children; 250000-point nodes do as well on one thread each)
+}
+
+static int kd_pass_chunks(const KdTree& t, long long len) {
+    const long long members = KdPool::get().size();
+    const long long share = (members * len + t.n - 1) / std::max<long long>(1, t.n);
+    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(members, std::max<long long>(2, share)), len / 256));
 }
 
 // libstdc++'s __unguarded_partition(lo, hi, pivot) over the index range [lo, hi), keys read through the index array - by the whole
@@ -239,15 +298,15 @@ static long long kd_team_min() {                                     // fdx_kdtr
 // last swap (which now holds a key >= pivot), whichever comes first.  (The pivot - moved to lo - 1 by the median step -
 // and the median's other two samples guarantee both lists are non-empty inside the range.)
 template <class Key>
-long long team_unguarded_partition(KdTeam& team, long long* idx, long long lo, long long hi, double pv, const Key& key) {
+long long team_unguarded_partition(KdTree& t, long long* idx, long long lo, long long hi, double pv, const Key& key) {
+    KdPool& team = KdPool::get();
     const long long len = hi - lo;
-    const int nt = team.size();
-    if ((long long)team.lpos.size() < len) { team.lpos.resize((size_t)len); team.rpos.resize((size_t)len); }
-    int32_t* lp = team.lpos.data();
-    int32_t* rp = team.rpos.data();
+    const int nt = kd_pass_chunks(t, len);
+    int32_t* lp = t.lpos.data() + lo;                                // (the ranges of two nodes are disjoint: so are their lists)
+    int32_t* rp = t.rpos.data() + lo;
     std::vector<long long> cb((size_t)nt + 1), cl((size_t)nt + 1, 0), cr((size_t)nt + 1, 0);
     for (int t = 0; t <= nt; ++t) cb[(size_t)t] = len * t / nt;
-    team.run([&](int tid, int) {
+    team.parallel(nt, [&](int tid, int) {
         const long long b = cb[(size_t)tid], e = cb[(size_t)tid + 1];
         long long nl = 0, nr = 0;
         for (long long i = b; i < e; ++i) {
@@ -259,7 +318,7 @@ long long team_unguarded_partition(KdTeam& team, long long* idx, long long lo, l
         }
         cl[(size_t)tid + 1] = nl;
         cr[(size_t)tid + 1] = nr;
-    });
+    }, &t.failed);
     // pl[t]: left-list entries before chunk t; sr[t]: right-list entries (counted from the right) after chunk t
     std::vector<long long> pl((size_t)nt + 1, 0), sr((size_t)nt + 1, 0);
     for (int t = 0; t < nt; ++t) pl[(size_t)t + 1] = pl[(size_t)t] + cl[(size_t)t + 1];
@@ -281,7 +340,7 @@ long long team_unguarded_partition(KdTeam& team, long long* idx, long long lo, l
     }
     const long long K = a;
     if (K > 0)
-        team.run([&](int tid, int n_t) {
+        team.parallel(nt, [&](int tid, int n_t) {
             const long long k0 = K * tid / n_t, k1 = K * (tid + 1) / n_t;
             if (k0 >= k1) return;
             int tl = (int)(std::upper_bound(pl.begin(), pl.end(), k0) - pl.begin()) - 1;
@@ -296,7 +355,7 @@ long long team_unguarded_partition(KdTeam& team, long long* idx, long long lo, l
                 ++il;
                 --ir;
             }
-        });
+        }, &t.failed);
     long long cut = -1;
     if (K < nL) cut = L(K);
     if (K > 0) { const long long r = R(K - 1); cut = cut < 0 ? r : std::min(cut, r); }
@@ -306,7 +365,7 @@ long long team_unguarded_partition(KdTeam& team, long long* idx, long long lo, l
 // std::nth_element(idx + first, idx + nth, idx + last, key(a) < key(b)) - libstdc++'s introselect with the partition passes of the
 // long ranges done by the team; below `team_min` libstdc++'s own routine continues with the depth budget that is left.
 template <class Key>
-void team_nth_element(KdTeam& team, long long* idx, long long first, long long nth, long long last, const Key& key, long long team_min) {
+void team_nth_element(KdTree& t, long long* idx, long long first, long long nth, long long last, const Key& key, long long team_min) {
     auto cmp = [&key](long long a, long long b) { return key(a) < key(b); };
     auto icmp = __gnu_cxx::__ops::__iter_comp_iter(cmp);
     if (first == last || nth == last) return;
@@ -319,7 +378,7 @@ void team_nth_element(KdTeam& team, long long* idx, long long first, long long n
         --depth;
         const long long mid = first + (last - first) / 2;
         std::__move_median_to_first(idx + first, idx + first + 1, idx + mid, idx + last - 1, icmp);
-        const long long cut = team_unguarded_partition(team, idx, first + 1, last, key(idx[first]), key);
+        const long long cut = team_unguarded_partition(t, idx, first + 1, last, key(idx[first]), key);
         if (cut <= nth) first = cut; else last = cut;
     }
     std::__insertion_sort(idx + first, idx + last, icmp);
@@ -330,40 +389,36 @@ static long long kd_fork_min() {
     return v;
 }
 
-// The two children of a node, the `less` one on a thread of its own when the node is large and forks are left (see the note at
-// KdTree): build(nodes, lesser) appends the subtree of that child to `nodes` and returns its root's index there.
+// The two children of a node, the `less` one as a task of the pool when the node is large and forks are left (see the note at
+// KdTree): build(nodes, lesser) appends the subtree of that child to `nodes` and returns its root's index there.  The parent
+// builds the other child, then runs pool tasks until its own has finished (its stack holds what the task works on).
 inline long long kd_seg_tag(long long seg) { return -(2 + seg); }     // a link to the root (node 0) of segment `seg`
 template <class Build>
 void kd_children(KdTree& t, std::vector<KdNode>& nodes, bool fork, const Build& build, long long& less, long long& greater) {
-    bool forked = false;
-    if (fork) {
-        std::vector<KdNode> sub;
-        bool sub_ok = true;
-        try {
-            std::thread th([&] {
-                try {
-                    (void)build(sub, true);                               // (its root is node 0 of `sub`)
-                } catch (...) { sub_ok = false; }
-            });
-            forked = true;
-            try {
-                greater = build(nodes, false);
-            } catch (...) { th.join(); throw; }
-            th.join();
-        } catch (const std::system_error&) {
-            if (forked) throw;                                        // came out of the join path
-        }
-        if (forked) {
-            if (!sub_ok) throw std::bad_alloc();
+    if (fork && t.pooled) {
+        std::vector<KdNode>* sub = nullptr;
+        long long seg = -1;
+        {
             std::lock_guard<std::mutex> lk(t.seg_mu);
-            t.segs.push_back(std::move(sub));
-            less = kd_seg_tag((long long)t.segs.size() - 1);
+            t.segs.emplace_back();                                    // (a deque: the element stays where it is)
+            sub = &t.segs.back();
+            seg = (long long)t.segs.size() - 1;
         }
+        std::atomic<int> pending{0};
+        KdPool& pool = KdPool::get();
+        pool.spawn([&build, &t, sub] { try { (void)build(*sub, true); } catch (...) { t.failed.store(true); } }, &pending);   // (its root is node 0 of `sub`)
+        less = kd_seg_tag(seg);
+        try {
+            greater = build(nodes, false);
+        } catch (...) {
+            pool.wait_help(pending);
+            throw;
+        }
+        pool.wait_help(pending);
+        return;
     }
-    if (!forked) {
-        less = build(nodes, true);
-        greater = build(nodes, false);
-    }
+    less = build(nodes, true);
+    greater = build(nodes, false);
 }
 
 // A subtree small enough for a core's cache is built on a contiguous copy of its points - records {coordinates, index} in
@@ -519,20 +574,13 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
     nodes[(size_t)node_index].end = end;
     if (end - start <= t.leafsize) return node_index;                 // leaf
     // compact nodes: bounds from the node's own points
-    // (a thread team for the passes of the top nodes was tried: 24-27 ms per million points instead of 22-24 - starting the
-    // threads costs more than the 2 ms pass they share)
-    // the top nodes' passes go to the standing team (KdTeam above): same bounds, same permutation
-    const bool teamed = end - start >= kd_team_min() && end - start < 0x7fffffffLL && kd_thread_share() > 1 && m <= 8 && level <= 2;   // (32-bit positions in the lists)
-    struct TeamHold {
-        KdTeam* t = nullptr;
-        ~TeamHold() { if (t) t->release(); }
-    } hold;
+    // the large nodes' passes are cut into tasks of the pool (KdPool above): same bounds, same permutation
+    const bool teamed = end - start >= kd_team_min() && end - start < 0x7fffffffLL && t.pooled && m <= 8;   // (32-bit positions in the lists)
+    KdPool& team = KdPool::get();
     if (teamed) {
-        KdTeam& team = KdTeam::for_level(level, kd_thread_share());
-        hold.t = &team;
-        const int nt = team.size();
+        const int nt = kd_pass_chunks(t, end - start);
         std::vector<double> bmx((size_t)nt * 8), bmn((size_t)nt * 8);
-        team.run([&](int tid, int n_t) {
+        team.parallel(nt, [&](int tid, int n_t) {
             const long long b = start + (end - start) * tid / n_t, e = start + (end - start) * (tid + 1) / n_t;
             double mx[8], mn[8];
             for (int i = 0; i < m; ++i) mx[i] = mn[i] = data[indices[b] * m + i];
@@ -543,7 +591,7 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
                     mn[i] = mn[i] < v ? mn[i] : v;
                 }
             for (int i = 0; i < m; ++i) { bmx[(size_t)tid * 8 + i] = mx[i]; bmn[(size_t)tid * 8 + i] = mn[i]; }
-        });
+        }, &t.failed);
         for (int i = 0; i < m; ++i) {
             maxes[i] = bmx[(size_t)i];
             mins[i] = bmn[(size_t)i];
@@ -575,7 +623,7 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
     // on lattices - with one the leaves come out in another order), so equal coordinates fall where introselect leaves them
     auto cmp = [data, m, d](long long a, long long b) { return data[a * m + d] < data[b * m + d]; };
     auto key = [data, m, d](long long a) { return data[a * m + d]; };
-    if (teamed) team_nth_element(*hold.t, indices, start, start + half, end, key, std::max<long long>(kd_team_min() / 4, 16));
+    if (teamed) team_nth_element(t, indices, start, start + half, end, key, std::max<long long>(kd_team_min() / 4, 16));
     else std::nth_element(indices + start, indices + start + half, indices + end, cmp);
     double split = data[indices[start + half] * m + d];
     // scipy's two-pointer pass "< split | >= split" over the whole range.  After the selection everything from position `half` on
@@ -583,15 +631,14 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
     // where that walk ends.  Same swaps, same result, half the pass.
     long long p = start, q = start + half - 1;
     if (teamed) {
-        // the same pass by the team: its k-th swap is (k-th key >= split from the left, k-th key < split from the right) while the
+        // the same pass in tasks: its k-th swap is (k-th key >= split from the left, k-th key < split from the right) while the
         // former lies left of the latter, and it ends with p on the first key >= split - the number of keys below the split.
         // After a selection only keys EQUAL to the split stand left of position `half`, so the left list is short: the
         // team counts and lists, one thread pairs.
-        KdTeam& team = *hold.t;
-        const int nt = team.size();
+        const int nt = kd_pass_chunks(t, half);
         std::vector<std::vector<long long>> lefts((size_t)nt);
         std::vector<long long> below((size_t)nt, 0);
-        team.run([&](int tid, int n_t) {
+        team.parallel(nt, [&](int tid, int n_t) {
             const long long b = start + half * tid / n_t, e = start + half * (tid + 1) / n_t;
             long long nb = 0;
             for (long long i = b; i < e; ++i) {
@@ -599,7 +646,7 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
                 else lefts[(size_t)tid].push_back(i);
             }
             below[(size_t)tid] = nb;
-        });
+        }, &t.failed);
         long long n_below = 0;
         for (int t2 = 0; t2 < nt; ++t2) n_below += below[(size_t)t2];
         long long r = q;                                              // walks down over the keys < split
@@ -618,7 +665,6 @@ long long kd_build(KdTree& t, std::vector<KdNode>& nodes, long long start, long 
         else if (data[indices[q] * m + d] >= split) --q;
         else { std::swap(indices[p], indices[q]); ++p; --q; }
     }
-    if (hold.t) { hold.t->release(); hold.t = nullptr; }              // (the children take the team themselves)
     if (p == start) {
         // Nothing below the split: the median IS the node's minimum along d (more than half of its points share it - duplicated
         // spots, or a ragged tissue edge).  scipy 1.15.3 then splits just ABOVE the minimum - the tree reports
@@ -802,13 +848,17 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
             }
         }
     };
-    if (n >= kd_team_min() && kd_thread_share() > 1 && dim <= 8) {
-        KdTeam& team = KdTeam::get();
-        team.acquire((int)std::min(kd_thread_share(), 16u));
-        const int nt = team.size();
+    // the pool's threads are asked for where they can pay: from a few thousand points (the forks start at 32768, the passes'
+    // tasks at 200000)
+    KdPool& pool = KdPool::get();
+    t.pooled = kd_thread_share() > 1 && n >= std::min<long long>(4096, kd_team_min()) && dim <= 8;
+    if (t.pooled) pool.want(kd_pool_members());
+    if (t.pooled && n >= kd_team_min()) {
+        t.lpos.resize((size_t)n);                                     // (uninitialised: first touched by the tasks that fill them)
+        t.rpos.resize((size_t)n);
+        const int nt = pool.size();
         std::vector<double> bmx((size_t)nt * 8), bmn((size_t)nt * 8);
-        team.run([&](int tid, int n_t) { span(n * tid / n_t, n * (tid + 1) / n_t, &bmx[(size_t)tid * 8], &bmn[(size_t)tid * 8]); });
-        team.release();
+        pool.parallel(nt, [&](int tid, int n_t) { span(n * tid / n_t, n * (tid + 1) / n_t, &bmx[(size_t)tid * 8], &bmn[(size_t)tid * 8]); }, &t.failed);
         for (int a = 0; a < dim; ++a) {
             t.maxes[(size_t)a] = bmx[(size_t)a];
             t.mins[(size_t)a] = bmn[(size_t)a];
@@ -821,14 +871,9 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
         span(0, n, t.maxes.data(), t.mins.data());
     }
     std::vector<double> mx(t.maxes), mn(t.mins);
-    // Up to 32 subtrees in flight, on up to twice this caller's share of the host's threads where the hardware has them: the share
-    // is a CPU-time quota (host_cpu_budget), the subtrees are a burst of 2-4 ms - 32 threads for that long are a tenth of what
-    // 16 CPUs may spend per scheduler period, and a million lattice points build in 8.5 ms instead of 10.
-    int par = 5;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    while (par > 0 && (1u << par) > std::min(hw, 2u * kd_thread_share())) --par;
-    if (kd_thread_share() <= 1) par = 0;
-    if (const char* e = fdx::env("FDX_KDTREE_PAR_DEPTH")) par = std::max(0, std::min(10, atoi(e)));
+    // the `less` child of every node above 32768 points becomes a task, five levels deep at most: 32 subtrees for a million points
+    int par = t.pooled ? 5 : 0;
+    if (const char* e = fdx::env("FDX_KDTREE_PAR_DEPTH")) par = t.pooled ? std::max(0, std::min(10, atoi(e))) : 0;
     if (fdx::exp_env("FDX_KDTREE_SERIAL_BUILD")) par = 0;
     std::vector<KdNode> top;
     top.reserve(1024);
@@ -851,14 +896,11 @@ void kd_build_tree(KdTree& t, const double* coords, int64_t n, int32_t dim) {
             ::new (flat + (size_t)o + i) KdNode(nd);
         }
     };
-    if (ns > 0 && kd_thread_share() > 1) {
-        KdTeam& team = KdTeam::get();
-        team.acquire((int)std::min(kd_thread_share(), 16u));
-        team.run([&](int tid, int n_t) { for (size_t si = (size_t)tid; si < ns + 1; si += (size_t)n_t) lay(si); });
-        team.release();
-    } else {
-        for (size_t si = 0; si < ns + 1; ++si) lay(si);
-    }
+    if (t.failed.load()) throw std::bad_alloc();
+    if (ns > 0 && t.pooled) pool.parallel(pool.size(), [&](int tid, int n_t) { for (size_t si = (size_t)tid; si < ns + 1; si += (size_t)n_t) lay(si); }, &t.failed);
+    else for (size_t si = 0; si < ns + 1; ++si) lay(si);
+    t.lpos = decltype(t.lpos)();
+    t.rpos = decltype(t.rpos)();
     t.segs.clear();
 }
 
@@ -1249,10 +1291,10 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
             for (long long i = n * tid / n_t, e = n * (tid + 1) / n_t; i < e; ++i) idx32[(size_t)i] = (int)t.indices[(size_t)i];
         };
         if (n >= kd_team_min() && kd_thread_share() > 1) {
-            KdTeam& team = KdTeam::get();
-            team.acquire((int)std::min(kd_thread_share(), 16u));
-            try { team.run(stage_span); } catch (...) { team.release(); throw; }
-            team.release();
+            KdPool& pool = KdPool::get();
+            pool.want(kd_pool_members());
+            std::atomic<bool> stage_failed{false};                   // (nothing in the span allocates)
+            pool.parallel(pool.size(), stage_span, &stage_failed);
         } else {
             stage_span(0, 1);
         }

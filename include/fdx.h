@@ -194,8 +194,8 @@ int fdx_ckdtree_prebuild(const double* coords_host, const double* coords_dev, in
  * of the replicated coordinates (utils/graph.py:60), share its cores. */
 int fdx_kdtree_set_threads(int32_t threads);
 /* Two sizes of the restated tree's build, for the host tests and probes - the tree is the same whatever they are.
- * what 0: nodes of at least `points` points have their passes (bounds, median selection, partition) done by the library's standing
- *         team of host threads instead of the building thread alone (0: the default, 200000);
+ * what 0: nodes of at least `points` points have their passes (bounds, median selection, partition) cut into tasks of the library's
+ *         pool of host threads instead of made by one thread (0: the default, 400000);
  * what 1: subtrees of at most `points` points are built on a contiguous copy of their points (negative: the default, 65536;
  *         0: never). */
 int fdx_kdtree_tune(int32_t what, int64_t points);

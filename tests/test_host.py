@@ -345,7 +345,7 @@ def test_ckdtree_order_restatement_on_heavily_duplicated_coordinates():
     """Many spots on few distinct places (integer coordinates out of 2 to 1000 values, 1 to 3 dimensions): the median of a node is
     often its MINIMUM along the split dimension, where scipy 1.15.3 splits just above it (split == nextafter(minimum, +inf),
     every point at the minimum in the lesser child).  Index array and query lists against scipy itself, with the passes of the
-    nodes on the building thread and on the standing thread team (fdx_kdtree_tune)."""
+    nodes on the building thread and on the thread pool's tasks (fdx_kdtree_tune)."""
     from scipy.spatial import cKDTree
     from flashdeconv_amd import _lib
     lib = _lib.load()
@@ -373,13 +373,15 @@ def test_ckdtree_order_restatement_on_heavily_duplicated_coordinates():
     assert t.tree.split == np.nextafter(3.0, np.inf) and t.tree.lesser.children == 12
 
 
-def test_ckdtree_thread_team_survives_a_fork():
-    """The standing thread team of the tree build (csrc/kdtree_order.cpp: KdTeam) lives in the process that started it: a fork()ed
-    child (multiprocessing's default start method) has the team's object without its threads and must start its own - same tree."""
+def test_ckdtree_thread_pool_survives_a_fork():
+    """The thread pool of the tree build (csrc/kdtree_order.cpp: KdPool) lives in the process that started it: a fork()ed child
+    (multiprocessing's default start method) has the pool's object without its threads - and its mutex / condition variable in
+    whatever state the parent's workers, just going to sleep, had them in - and must start anew: same tree.  50000 points: above
+    the size from which subtrees become pool tasks; the fork follows the parent's build at once."""
     import os
     from flashdeconv_amd import _lib
     lib = _lib.load()
-    coords = np.ascontiguousarray(np.random.RandomState(0).rand(30000, 2))
+    coords = np.ascontiguousarray(np.random.RandomState(0).rand(50000, 2))
 
     def lists():
         lib.fdx_kdtree_tune(0, 64)
@@ -392,16 +394,19 @@ def test_ckdtree_thread_team_survives_a_fork():
             lib.fdx_kdtree_set_threads(0)
         return got
 
-    want = lists()
-    pid = os.fork()
-    if pid == 0:
-        code = 3
-        try:
-            code = 0 if np.array_equal(lists(), want) else 4
-        finally:
-            os._exit(code)
-    _, status = os.waitpid(pid, 0)
-    assert status == 0, status
+    for _ in range(3):
+        want = lists()
+        pid = os.fork()
+        if pid == 0:
+            code = 3
+            try:
+                import faulthandler
+                faulthandler.dump_traceback_later(60, exit=True)         # a hang in the child fails the test instead of stalling it
+                code = 0 if np.array_equal(lists(), want) else 4
+            finally:
+                os._exit(code)
+        _, status = os.waitpid(pid, 0)
+        assert status == 0, status
 
 
 @pytest.mark.parametrize("case", ["square", "square_scaled", "hex", "cube3d", "random2d", "random3d", "line", "duplicates",
@@ -452,7 +457,7 @@ def test_ckdtree_order_restatement_matches_scipy(case, monkeypatch):
                 monkeypatch.delenv(k)
             lib.fdx_kdtree_set_threads(0)
             assert np.array_equal(order2, tree.indices) and np.array_equal(got2, want), env
-    # the passes of the top nodes by the standing thread team (from 200000 points; here from 64 and from 5000): the same tree
+    # the passes of the large nodes cut into tasks of the thread pool (from 400000 points; here from 64 and from 5000): the same tree
     # ... and with the subtrees built through the index array instead of on a contiguous copy of their points
     for team_min, threads, local_max in ((64, 5, 0), (5000, 0, 2000), (0, 0, 0)) if n > 700 else ():
         lib.fdx_kdtree_tune(0, team_min)
