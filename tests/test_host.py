@@ -373,6 +373,38 @@ def test_ckdtree_order_restatement_on_heavily_duplicated_coordinates():
     assert t.tree.split == np.nextafter(3.0, np.inf) and t.tree.lesser.children == 12
 
 
+def test_ckdtree_builds_from_several_threads_share_the_pool():
+    """Thread ranks of one process each build the restated tree of their coordinates at the same time: the builds cut their work
+    into tasks of ONE pool (csrc/kdtree_order.cpp: KdPool) and run each other's tasks while they wait.  Every tree against scipy."""
+    import threading
+    from scipy.spatial import cKDTree
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    lib.fdx_kdtree_tune(0, 64)
+    bad = []
+
+    def work(seed):
+        rs = np.random.RandomState(seed)
+        for it in range(6):
+            n, dim, rng = int(rs.randint(3000, 90000)), int(rs.randint(1, 4)), int(rs.choice([5, 1000, 100000]))
+            coords = np.ascontiguousarray(rs.randint(0, rng, size=(n, dim)).astype(np.float64))
+            got, order = np.empty((n, 4), dtype=np.int64), np.empty(n, dtype=np.int64)
+            _lib.check(lib.fdx_ckdtree_knn(_lib.ptr_f64(coords), n, dim, 4, _lib.ptr_i64(got), _lib.ptr_i64(order)))
+            tree = cKDTree(coords)
+            if not np.array_equal(order, tree.indices) or not np.array_equal(got, tree.query(coords, k=4)[1]):
+                bad.append((seed, it, n, dim, rng))
+
+    try:
+        threads = [threading.Thread(target=work, args=(s,)) for s in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        lib.fdx_kdtree_tune(0, 0)
+    assert not bad, bad
+
+
 def test_ckdtree_thread_pool_survives_a_fork():
     """The thread pool of the tree build (csrc/kdtree_order.cpp: KdPool) lives in the process that started it: a fork()ed child
     (multiprocessing's default start method) has the pool's object without its threads - and its mutex / condition variable in
