@@ -184,6 +184,7 @@ SIGNATURES = {
     "fdx_graph_knn_far": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "fdx_kdtree_set_threads": (c_int, [c_i32]),
     "fdx_kdtree_tune": (c_int, [c_i32, c_i64]),
+    "fdx_ckdtree_indices_dev": (c_int, [c_void_p, c_i64, c_i32, p_i64, p_i32, c_void_p]),
     "fdx_ckdtree_prebuild": (c_int, [p_double, c_void_p, c_i64, c_i32]),
     "fdx_hvg_from_moments": (c_int, [p_double, p_double, c_i32, p_double, c_i32, c_i32, c_double, c_double, c_double, p_i64,
                                      ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),

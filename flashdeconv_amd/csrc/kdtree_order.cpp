@@ -47,6 +47,7 @@
 #include <vector>
 
 #include "fdx_internal.h"
+#include "kdtree_dev.h"
 
 namespace fdx {
 namespace {
@@ -133,6 +134,7 @@ unsigned host_cpu_budget() {
 static std::atomic<int> g_kd_threads{0};
 static std::atomic<long long> g_kd_team_min{0};
 static std::atomic<long long> g_kd_local_max{-1};
+static std::atomic<int> g_kd_device_build{0};   // fdx_kdtree_tune(2, 1): the tree of 1-3 coordinates is built on the device (kdtree_build_dev.cpp)
 static unsigned kd_thread_share() {
     if (const char* e = fdx::env("FDX_KDTREE_THREADS")) return (unsigned)std::max(1, atoi(e));
     const int v = g_kd_threads.load();
@@ -1199,7 +1201,60 @@ static void kd_prebuilt_drop(std::unique_ptr<KdPrebuilt>& p) {
     p.reset();
 }
 
+// the k-nearest queries of `rows_host` (NULL: every point) on a tree that lies on the device: ids_dev gets kk ids per query;
+// *over = 1 when a lane's far-node heap was too deep (the caller repeats the queries on the host)
+int kd_queries_device(const double* coords_dev, long long n, int dim, int kk, const int4* meta_d, const double* split_d, const int* idx_d,
+                      const double* mins, const double* maxes, const long long* rows_host, long long nq, long long* ids_dev, int* over,
+                      hipStream_t st) {
+    (void)n;
+    const long long L = std::min<long long>((nq + 255) / 256, 1024) * 256;   // (twice the lanes in flight - the kernel has the registers for it - measured no faster: 1.85 ms either way)
+    DevBuf d_rows, d_over, qp, qnode, qs, np, ni;
+    PinnedScope stage;
+    FDX_TRY(d_over.alloc(4));
+    FDX_TRY(qp.alloc((size_t)KD_QCAP * L * 8));
+    FDX_TRY(qnode.alloc((size_t)KD_QCAP * L * 4));
+    FDX_TRY(qs.alloc((size_t)KD_QCAP * dim * L * 8));
+    FDX_TRY(np.alloc((size_t)kk * L * 8));
+    FDX_TRY(ni.alloc((size_t)kk * L * 4));
+    FDX_HIP(hipMemsetAsync(d_over.p, 0, 4, st));
+    if (rows_host) {
+        FDX_TRY(stage.get((size_t)nq * 8));
+        std::memcpy(stage.p, rows_host, (size_t)nq * 8);
+        FDX_TRY(d_rows.alloc((size_t)nq * 8));
+        FDX_HIP(hipMemcpyAsync(d_rows.p, stage.p, (size_t)nq * 8, hipMemcpyHostToDevice, st));
+    }
+    KdBounds bnd{};
+    for (int a = 0; a < dim; ++a) { bnd.mins[a] = mins[a]; bnd.maxes[a] = maxes[a]; }
+    const dim3 grid((unsigned)(L / 256)), blk(256);
+    const long long* rows_d = rows_host ? d_rows.as<long long>() : nullptr;
+    const bool nbl = kk <= 16;
+    const size_t nb_lds = nbl ? (size_t)kk * 256 * 12 : 0;
+#define FDX_KD_LAUNCH(MM)                                                                                                              \
+    do {                                                                                                                               \
+        if (nbl)                                                                                                                       \
+            hipLaunchKernelGGL((kd_query_kernel<MM, true>), grid, blk, nb_lds, st, coords_dev, meta_d, split_d, idx_d, bnd, kk, rows_d, nq,   \
+                               ids_dev, qp.as<double>(), qnode.as<int>(), qs.as<double>(), np.as<double>(), ni.as<int>(), L, d_over.as<int>()); \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((kd_query_kernel<MM, false>), grid, blk, 0, st, coords_dev, meta_d, split_d, idx_d, bnd, kk, rows_d, nq,       \
+                               ids_dev, qp.as<double>(), qnode.as<int>(), qs.as<double>(), np.as<double>(), ni.as<int>(), L, d_over.as<int>()); \
+    } while (0)
+    if (dim == 1) FDX_KD_LAUNCH(1);
+    else if (dim == 2) FDX_KD_LAUNCH(2);
+    else FDX_KD_LAUNCH(3);
+#undef FDX_KD_LAUNCH
+    FDX_CHECK_LAUNCH();
+    *over = 0;
+    FDX_HIP(hipMemcpyAsync(over, d_over.p, 4, hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));                     // the staging and the work areas are this function's; the flag decides the route
+    return 0;
+}
+
+static bool kd_device_build_serves(const double* coords_dev, long long n, int dim) {
+    return coords_dev && dim <= 3 && n < 0x3fffffffLL && g_kd_device_build.load() != 0 && !fdx::env("FDX_KDTREE_HOST_QUERIES");
+}
+
 int ckdtree_prebuild(const double* coords_host, const double* coords_dev, long long n, int dim) {
+    if (kd_device_build_serves(coords_dev, n, dim)) return 0;          // the tree is built on the device when the lists are asked for
     std::unique_ptr<KdPrebuilt> old;
     {
         std::lock_guard<std::mutex> lk(g_pre_mu);
@@ -1243,6 +1298,28 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
                          long long n_rows, long long* ids_dev, hipStream_t st) {
     const long long nq = rows_host ? n_rows : n;
     if (nq == 0) return 0;
+    if (kd_device_build_serves(coords_dev, n, dim)) {
+        // tree AND queries on the device (kdtree_build_dev.cpp); a selection that would leave introselect's partition loop, or a
+        // tree deeper than the level cap, sends the call down the host build below
+        const bool trace = fdx::env("FDX_TRACE_HOST") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        KdDeviceTree dt;
+        FDX_TRY(kd_build_device(coords_dev, n, dim, &dt, st));
+        const auto t1 = std::chrono::steady_clock::now();
+        if (!dt.overflow) {
+            int over = 0;
+            FDX_TRY(kd_queries_device(coords_dev, n, dim, kk, dt.meta.as<int4>(), dt.split.as<double>(), dt.idx.as<int>(), dt.mins, dt.maxes,
+                                      rows_host, nq, ids_dev, &over, st));
+            if (trace)
+                std::fprintf(stderr, "[fdx-host] ckdtree: tree built on the device in %.2f ms (%d nodes, %d levels), %lld queries %.2f ms%s\n",
+                             std::chrono::duration<double, std::milli>(t1 - t0).count(), dt.n_nodes, dt.levels, nq,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(),
+                             over ? " (far-node heap too deep: repeated on the host)" : "");
+            if (!over) return 0;
+        } else if (trace) {
+            std::fprintf(stderr, "[fdx-host] ckdtree: the device build gave up (selection depth / level cap): host build\n");
+        }
+    }
     std::unique_ptr<KdPrebuilt> pre;
     {
         std::lock_guard<std::mutex> lk(g_pre_mu);
@@ -1298,52 +1375,17 @@ int ckdtree_lists_device(const double* coords_host_in, const double* coords_dev,
         } else {
             stage_span(0, 1);
         }
-        if (rows_host) std::memcpy(sp + o_rows, rows_host, (size_t)nq * 8);
-        const long long L = std::min<long long>((nq + 255) / 256, 1024) * 256;   // (twice the lanes in flight - the kernel has the registers for it - measured no faster: 1.85 ms either way)
-        DevBuf d_meta, d_split, d_idx, d_rows, d_over, qp, qnode, qs, np, ni;
+        DevBuf d_meta, d_split, d_idx;
         FDX_TRY(d_meta.alloc(nn * sizeof(int4)));
         FDX_TRY(d_split.alloc(nn * sizeof(double)));
         FDX_TRY(d_idx.alloc((size_t)n * 4));
-        FDX_TRY(d_over.alloc(4));
-        FDX_TRY(qp.alloc((size_t)KD_QCAP * L * 8));
-        FDX_TRY(qnode.alloc((size_t)KD_QCAP * L * 4));
-        FDX_TRY(qs.alloc((size_t)KD_QCAP * dim * L * 8));
-        FDX_TRY(np.alloc((size_t)kk * L * 8));
-        FDX_TRY(ni.alloc((size_t)kk * L * 4));
         FDX_HIP(hipMemcpyAsync(d_meta.p, meta, nn * sizeof(int4), hipMemcpyHostToDevice, st));
         FDX_HIP(hipMemcpyAsync(d_split.p, split, nn * sizeof(double), hipMemcpyHostToDevice, st));
         FDX_HIP(hipMemcpyAsync(d_idx.p, idx32, (size_t)n * 4, hipMemcpyHostToDevice, st));
-        FDX_HIP(hipMemsetAsync(d_over.p, 0, 4, st));
-        if (rows_host) {
-            FDX_TRY(d_rows.alloc((size_t)nq * 8));
-            FDX_HIP(hipMemcpyAsync(d_rows.p, sp + o_rows, (size_t)nq * 8, hipMemcpyHostToDevice, st));
-        }
         const auto ts1 = std::chrono::steady_clock::now();
-        KdBounds bnd{};
-        for (int a = 0; a < dim; ++a) { bnd.mins[a] = t.mins[(size_t)a]; bnd.maxes[a] = t.maxes[(size_t)a]; }
-        const dim3 grid((unsigned)(L / 256)), blk(256);
-        const long long* rows_d = rows_host ? d_rows.as<long long>() : nullptr;
-        const bool nbl = kk <= 16;
-        const size_t nb_lds = nbl ? (size_t)kk * 256 * 12 : 0;
-#define FDX_KD_LAUNCH(MM)                                                                                                              \
-        do {                                                                                                                           \
-            if (nbl)                                                                                                                   \
-                hipLaunchKernelGGL((kd_query_kernel<MM, true>), grid, blk, nb_lds, st, coords_dev, d_meta.as<int4>(), d_split.as<double>(), \
-                                   d_idx.as<int>(), bnd, kk, rows_d, nq, ids_dev, qp.as<double>(), qnode.as<int>(), qs.as<double>(),      \
-                                   np.as<double>(), ni.as<int>(), L, d_over.as<int>());                                                   \
-            else                                                                                                                       \
-                hipLaunchKernelGGL((kd_query_kernel<MM, false>), grid, blk, 0, st, coords_dev, d_meta.as<int4>(), d_split.as<double>(),    \
-                                   d_idx.as<int>(), bnd, kk, rows_d, nq, ids_dev, qp.as<double>(), qnode.as<int>(), qs.as<double>(),      \
-                                   np.as<double>(), ni.as<int>(), L, d_over.as<int>());                                                   \
-        } while (0)
-        if (dim == 1) FDX_KD_LAUNCH(1);
-        else if (dim == 2) FDX_KD_LAUNCH(2);
-        else FDX_KD_LAUNCH(3);
-#undef FDX_KD_LAUNCH
-        FDX_CHECK_LAUNCH();
         int over = 0;
-        FDX_HIP(hipMemcpyAsync(&over, d_over.p, 4, hipMemcpyDeviceToHost, st));
-        FDX_HIP(hipStreamSynchronize(st));                 // the staging vectors are this function's; the flag decides the route
+        FDX_TRY(kd_queries_device(coords_dev, n, dim, kk, d_meta.as<int4>(), d_split.as<double>(), d_idx.as<int>(), t.mins.data(), t.maxes.data(),
+                                  rows_host, nq, ids_dev, &over, st));
         if (trace)
             std::fprintf(stderr, "[fdx-host] ckdtree: waited %.1f ms for the tree, build here %.1f ms (%lld nodes), staging + uploads queued %.2f ms, %lld queries on the device %.2f ms%s\n",
                          join_ms, std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)nn,
@@ -1377,9 +1419,25 @@ extern "C" int fdx_kdtree_set_threads(int32_t threads) {
 }
 
 extern "C" int fdx_kdtree_tune(int32_t what, int64_t points) {
-    FDX_REQUIRE(what == 0 || what == 1, "fdx_kdtree_tune: what is 0 (team_min) or 1 (local_max)");
+    FDX_REQUIRE(what >= 0 && what <= 2, "fdx_kdtree_tune: what is 0 (team_min), 1 (local_max) or 2 (device build)");
     if (what == 0) fdx::g_kd_team_min.store(points > 0 ? std::max<long long>(points, 64) : 0);
-    else fdx::g_kd_local_max.store(points);
+    else if (what == 1) fdx::g_kd_local_max.store(points);
+    else fdx::g_kd_device_build.store(points != 0 ? 1 : 0);
+    return 0;
+}
+
+extern "C" int fdx_ckdtree_indices_dev(const double* coords_dev, int64_t n, int32_t dim, int64_t* indices_out, int32_t* info_out, void* stream) {
+    using namespace fdx;
+    FDX_REQUIRE(coords_dev && indices_out && n >= 1 && dim >= 1 && dim <= 3, "fdx_ckdtree_indices_dev: bad arguments (1 to 3 coordinates)");
+    hipStream_t st = (hipStream_t)stream;
+    PoolStream pool_stream(st);
+    KdDeviceTree dt;
+    FDX_TRY(kd_build_device(coords_dev, n, dim, &dt, st));
+    std::vector<int> h((size_t)n);
+    FDX_HIP(hipMemcpyAsync(h.data(), dt.idx.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+    FDX_HIP(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < n; ++i) indices_out[i] = h[(size_t)i];
+    if (info_out) { info_out[0] = dt.n_nodes; info_out[1] = dt.levels; info_out[2] = dt.overflow ? 1 : 0; }
     return 0;
 }
 

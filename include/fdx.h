@@ -197,8 +197,17 @@ int fdx_kdtree_set_threads(int32_t threads);
  * what 0: nodes of at least `points` points have their passes (bounds, median selection, partition) cut into tasks of the library's
  *         pool of host threads instead of made by one thread (0: the default, 400000);
  * what 1: subtrees of at most `points` points are built on a contiguous copy of their points (negative: the default, 65536;
- *         0: never). */
+ *         0: never);
+ * what 2: 1 = fdx_graph_plan_set_ckdtree_lists_dev builds the tree of 1-3 coordinates ON THE DEVICE (csrc/kdtree_build_dev.cpp: the
+ *         same tree, level by level, a team of threads per node) instead of on the host's threads.  Default 0: at a million points
+ *         the device build takes 13-18 ms where the host's pool takes 9-11 beside the device's own work - its top five levels are one
+ *         workgroup per node. */
 int fdx_kdtree_tune(int32_t what, int64_t points);
+/* The index array of that tree as the DEVICE build makes it (1-3 coordinates; coords_dev: n x dim doubles on the device):
+ * indices_out (host, n) must equal scipy.spatial.cKDTree(coords).indices.  info_out[3] (may be NULL) = {nodes, levels of split
+ * nodes, 1 when the build gave up - a selection past introselect's depth budget or a tree deeper than the level cap; the product
+ * then builds on the host}.  Tests call this; the fit uses the same build through fdx_graph_plan_set_ckdtree_lists_dev. */
+int fdx_ckdtree_indices_dev(const double* coords_dev, int64_t n, int32_t dim, int64_t* indices_out, int32_t* info_out, void* stream);
 /* The neighbour lists the REFERENCE gets on such inputs: a host restatement of scipy.spatial.cKDTree(coords) with the
  * constructor's defaults followed by tree.query(coords, k = kk) with p = 2 (utils/graph.py:60-63), reproducing the order in
  * which the library meets equidistant points - hence which of them it returns.  coords: HOST (n, dim) row-major f64,

@@ -505,6 +505,50 @@ def test_fit_with_four_dimensional_coordinates():
 
 
 
+@pytest.mark.parametrize("case", ["square", "square_big", "hex", "cube3d", "random2d", "random2d_ties", "random3d", "line", "duplicates",
+                                  "heavy_duplicates", "binary", "shuffled", "tiny", "one_leaf", "million"])
+def test_device_built_ckdtree_has_scipys_index_array(case):
+    """csrc/kdtree_build_dev.cpp: the restated cKDTree built ON THE DEVICE - every node of a level at once, libstdc++'s introselect
+    replayed by a team of threads per node (partition passes in list form) - must leave scipy's index array, entry for entry: the
+    order in which a leaf's points are tested decides among equidistant neighbours (utils/graph.py:60-63).  Against scipy itself:
+    lattices, clouds with and without ties, 1-3 coordinates, few distinct values per axis (the split just above a node's minimum),
+    sizes of every team class (one wave / 256 / 1024 threads per node), trees of one leaf."""
+    import ctypes
+    import torch
+    from scipy.spatial import cKDTree
+    from flashdeconv_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(11)
+    sq = np.stack(np.meshgrid(np.arange(40.0), np.arange(33.0), indexing="ij"), -1).reshape(-1, 2)
+    coords = {
+        "square": sq,
+        "square_big": np.stack(np.meshgrid(np.arange(310.0), np.arange(300.0), indexing="ij"), -1).reshape(-1, 2),
+        "hex": np.array([(c + 0.5 * (r & 1), r * np.sqrt(3.0) / 2.0) for r in range(30) for c in range(29)]),
+        "cube3d": np.stack(np.meshgrid(*[np.arange(12.0)] * 3, indexing="ij"), -1).reshape(-1, 3),
+        "random2d": rs.rand(70000, 2) * 60.0,
+        "random2d_ties": np.round(rs.rand(30000, 2) * 25.0, 1),
+        "random3d": rs.rand(5000, 3) * 9.0,
+        "line": np.round(rs.rand(900, 1) * 50.0),
+        "duplicates": np.concatenate([rs.rand(300, 2), rs.rand(100, 2).repeat(3, axis=0)]),
+        "heavy_duplicates": rs.randint(0, 5, size=(3000, 2)).astype(np.float64),
+        "binary": rs.randint(0, 2, size=(40000, 2)).astype(np.float64),
+        "shuffled": sq[rs.permutation(len(sq))],
+        "tiny": rs.rand(17, 2),
+        "one_leaf": rs.rand(9, 3),
+        "million": np.stack(np.meshgrid(np.arange(1000.0), np.arange(1000.0), indexing="ij"), -1).reshape(-1, 2),
+    }[case]
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    n, dim = coords.shape
+    cd = torch.from_numpy(coords).cuda()
+    got = np.empty(n, dtype=np.int64)
+    info = np.zeros(3, dtype=np.int32)
+    _lib.check(lib.fdx_ckdtree_indices_dev(ctypes.c_void_p(cd.data_ptr()), n, dim, _lib.ptr_i64(got), _lib.ptr_i32(info), None))
+    torch.cuda.synchronize()
+    tree = cKDTree(coords)
+    assert info[2] == 0, info
+    assert np.array_equal(got, tree.indices), (case, int((got != tree.indices).sum()), info)
+
+
 @pytest.mark.parametrize("case", ["square", "hex", "cube3d", "random2d_ties", "line", "duplicates", "heavy_duplicates",
                                   "square_big_rows"])
 def test_device_ckdtree_queries_equal_the_host_restatement(case, monkeypatch):
@@ -560,6 +604,13 @@ def test_device_ckdtree_queries_equal_the_host_restatement(case, monkeypatch):
 
     nb_d, cn_d, perm_d, before = lists(False)
     nb_h, cn_h, perm_h, _ = lists(True)
+    # ... and with the tree itself built on the device (csrc/kdtree_build_dev.cpp, fdx_kdtree_tune(2, 1)): the same lists
+    lib.fdx_kdtree_tune(2, 1)
+    try:
+        nb_b, cn_b, perm_b, _ = lists(False)
+    finally:
+        lib.fdx_kdtree_tune(2, 0)
+    assert np.array_equal(nb_b, nb_d) and np.array_equal(cn_b, cn_d) and np.array_equal(perm_b, perm_d)
     assert np.array_equal(perm_d, perm_h)
     assert np.array_equal(cn_d, cn_h) and np.array_equal(nb_d, nb_h)
     # the lists are the restated tree's: position p holds the answer for caller id perm[p], as positions, self dropped
