@@ -20,15 +20,17 @@
 // are streaming passes.  The level loop is queued without reading anything back: level L has at most 2^L nodes, a launch covers
 // that many and the surplus workgroups leave at once; the queue lengths, the node count and the flags are read at the end.
 //
-// STATE (round 6): exact - scipy's index array on lattices, clouds, heavy duplicates, 1-3 coordinates, a million points
-// (tests/test_gpu_stages.py) - and NOT the default (fdx_kdtree_tune(2, 1) selects it): a million lattice points take 13.5 ms, of
-// which 10.6 are levels 0-4, where a node is one workgroup on one compute unit (2.5 / 4.5 / 2.1 / 0.9 / 0.6 ms; levels 5-9, 256
-// threads per node: 1.4 ms; levels 10-16, a wave per node: 1.4 ms), against 9-11 ms for the host's thread pool, which moreover
-// runs BESIDE the device's own lists.  What it needs next: several workgroups per node for the top levels (each pass then is
-// three or four launches - classify, rank, swap, advance - instead of a loop inside one workgroup).
+// STATE (round 6): exact - scipy's index array on lattices, clouds, heavy duplicates, sorted input, 1-3 coordinates, up to a
+// million points (tests/test_gpu_stages.py) - and the default for 1-3 coordinates (fdx_kdtree_tune(2, 0) selects the host's thread
+// pool): a million lattice points in 5.7-6.6 ms against the pool's 9-11.  Nodes above 100000 points are not one workgroup's work
+// (a million points through one compute unit: 2.5 ms for the root, 4.5 for its two children): each of their passes is four
+// launches over 64 workgroups per node - classify / count / swap / advance (kd_huge_*) - ~110 launches and two read-backs per
+// level, 4 ms for levels 0-3; level 4 (1024 threads per node) 0.6 ms, levels 5-9 (256 per node) 1.4 ms, levels 10-16 (a wave per
+// node) 1.4 ms.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <vector>
 
 #include "fdx_internal.h"
 #include "kdtree_dev.h"
@@ -38,8 +40,22 @@ namespace {
 
 struct KdWork { int node, start, end; };
 // team sizes by node size: up to 1024 points one wave, up to 32768 a workgroup of 256, above one of 1024
-constexpr int KD_SMALL = 1024, KD_MID = 32768;
-__host__ __device__ inline int kd_size_class(long long size) { return size <= KD_SMALL ? 0 : size <= KD_MID ? 1 : 2; }
+constexpr int KD_SMALL = 1024, KD_MID = 32768, KD_HUGE = 100000;
+__host__ __device__ inline int kd_size_class(long long size) { return size <= KD_SMALL ? 0 : size <= KD_MID ? 1 : size <= KD_HUGE ? 2 : 3; }
+struct KdQueues { KdWork* q[4]; };
+// Above KD_HUGE points a node is not one workgroup's work (a million points through one compute unit: 2.5 ms for the root, 4.5 ms
+// for its children): every pass of such a node is cut into KD_CH chunks, a wave each, over 64 workgroups, and the phases of a pass
+// that need everybody's results of the one before are separate launches - classify / count / swap / advance (kd_huge_*).
+constexpr int KD_CH = 256;
+struct KdHuge {
+    int node, start, end;
+    int first, last, nth, depth, d;
+    int phase;                 // 1 selection, 2 the "< split | >= split" pass, 3 that pass with the split just above the minimum, 4 finished
+    int lo, hi;                // the range of the pass under way
+    int K, nL, nR, cutL, cutR;
+    int pad;
+    double pv;                 // the pivot of a selection pass, the split of a split pass
+};
 
 struct KdBuildState {
     int n_nodes;        // nodes allocated so far
@@ -51,6 +67,55 @@ struct KdBuildState {
 template <int M>
 __device__ __forceinline__ double kd_key(const double* __restrict__ coords, int point, int d) {
     return coords[(size_t)point * M + d];
+}
+
+// libstdc++'s way out of introselect when the depth budget (2 log2 n partitions) is spent - a few nodes in every ten thousand of a
+// random cloud: std::__heap_select(first, nth + 1, last) and std::iter_swap(first, nth), transcribed (make_heap by __adjust_heap
+// from the last parent down, then every later element smaller than the heap's top replaces it: __pop_heap).  One thread: the
+// ranges that get here are what a selection has left over.
+template <int M>
+__device__ void kd_adjust_heap(const double* __restrict__ coords, int* __restrict__ a, int hole, int len, int value, int d) {
+    const double kv = kd_key<M>(coords, value, d);
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (kd_key<M>(coords, a[child], d) < kd_key<M>(coords, a[child - 1], d)) --child;
+        a[hole] = a[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[hole] = a[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;                                          // __push_heap
+    while (hole > top && kd_key<M>(coords, a[parent], d) < kv) {
+        a[hole] = a[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[hole] = value;
+}
+
+template <int M>
+__device__ void kd_heap_select_and_swap(const double* __restrict__ coords, int* __restrict__ idx, int first, int nth, int last, int d) {
+    int* a = idx + first;
+    const int len = nth + 1 - first;                                      // the heap: [first, nth + 1)
+    if (len >= 2)
+        for (int parent = (len - 2) / 2;; --parent) {
+            kd_adjust_heap<M>(coords, a, parent, len, a[parent], d);
+            if (parent == 0) break;
+        }
+    for (int i = nth + 1; i < last; ++i)
+        if (kd_key<M>(coords, idx[i], d) < kd_key<M>(coords, a[0], d)) {  // __pop_heap(first, middle, i)
+            const int value = idx[i];
+            idx[i] = a[0];
+            kd_adjust_heap<M>(coords, a, 0, len, value, d);
+        }
+    const int t = idx[first];                                             // std::iter_swap(first, nth)
+    idx[first] = idx[nth];
+    idx[nth] = t;
 }
 
 // The list form of a two-pointer pass over positions [lo, hi) of idx: left stops = positions whose key satisfies SL, right stops =
@@ -150,8 +215,7 @@ __device__ KdPassOut kd_pass(const double* __restrict__ coords, int* __restrict_
 template <int M, int T>
 __global__ __launch_bounds__(T) void kd_level_kernel(const double* __restrict__ coords, int* __restrict__ idx, int4* __restrict__ meta,
                                                      double* __restrict__ split_out, const KdWork* __restrict__ cur,
-                                                     const int* __restrict__ n_cur, KdWork* __restrict__ next0, KdWork* __restrict__ next1,
-                                                     KdWork* __restrict__ next2, int* __restrict__ n_next,
+                                                     const int* __restrict__ n_cur, const KdQueues next, int* __restrict__ n_next,
                                                      KdBuildState* __restrict__ st, int* __restrict__ lp, int* __restrict__ rp, int leafsize) {
 #pragma clang fp contract(off)
     __shared__ int s_nl[T / 64], s_nr[T / 64], s_cnt[T / 64], s_out[8];
@@ -224,9 +288,10 @@ __global__ __launch_bounds__(T) void kd_level_kernel(const double* __restrict__ 
         int first = w.start, last = w.end;
         int depth = 2 * (31 - __clz(size));
         while (last - first > 3) {
-            if (depth == 0) {
-                if (tid == 0) atomicExch(&st->overflow, 1);
-                return;                                                   // (uniform: every thread sees the same depth)
+            if (depth == 0) {                                             // (uniform: every thread sees the same depth)
+                if (tid == 0) kd_heap_select_and_swap<M>(coords, idx, first, nth, last, d);
+                first = last;                                             // introselect returns here: no insertion sort
+                break;
             }
             --depth;
             if (tid == 0) {                                               // __move_median_to_first(first, first + 1, mid, last - 1)
@@ -283,14 +348,321 @@ __global__ __launch_bounds__(T) void kd_level_kernel(const double* __restrict__ 
             } else {                                                       // the next level's queue of its team size
                 const int cls = kd_size_class(ce[c] - cs[c]);
                 const int slot = atomicAdd(n_next + cls, 1);
-                (cls == 0 ? next0 : cls == 1 ? next1 : next2)[slot] = KdWork{c0 + c, cs[c], ce[c]};
+                next.q[cls][slot] = KdWork{c0 + c, cs[c], ce[c]};
             }
         }
     }
 }
 
-__global__ void kd_init_kernel(int* __restrict__ idx, long long n, KdWork* __restrict__ q0, KdWork* __restrict__ q1, KdWork* __restrict__ q2,
-                               int* __restrict__ counts, KdBuildState* st, int4* __restrict__ meta, int leafsize) {
+// ---- nodes above KD_HUGE points: a pass in four launches --------------------------------------------------------------------
+template <int M>
+__device__ void kd_huge_begin_select(const double* __restrict__ coords, int* __restrict__ idx, KdHuge& h, KdBuildState* st) {
+    if (h.depth == 0) {                                                   // the budget is spent: heap select, and the selection is over
+        kd_heap_select_and_swap<M>(coords, idx, h.first, h.nth, h.last, h.d);
+        h.pv = kd_key<M>(coords, idx[h.nth], h.d);                        // the split
+        h.lo = h.start;
+        h.hi = h.nth;
+        h.phase = 2;
+        return;
+    }
+    --h.depth;
+    const int ia = h.first + 1, ib = h.first + (h.last - h.first) / 2, ic = h.last - 1;   // __move_median_to_first(first, first + 1, mid, last - 1)
+    const double ka = kd_key<M>(coords, idx[ia], h.d), kb = kd_key<M>(coords, idx[ib], h.d), kc = kd_key<M>(coords, idx[ic], h.d);
+    int pick;
+    if (ka < kb) pick = kb < kc ? ib : (ka < kc ? ic : ia);
+    else pick = ka < kc ? ia : (kb < kc ? ic : ib);
+    const int t0 = idx[h.first];
+    idx[h.first] = idx[pick];
+    idx[pick] = t0;
+    h.pv = kd_key<M>(coords, idx[h.first], h.d);
+    h.lo = h.first + 1;
+    h.hi = h.last;
+    h.phase = 1;
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void kd_huge_bounds_kernel(const double* __restrict__ coords, const int* __restrict__ idx,
+                                                             const KdWork* __restrict__ cur, const int* __restrict__ n_cur,
+                                                             double* __restrict__ hb) {
+    const int slot = blockIdx.y;
+    if (slot >= *n_cur) return;
+    const KdWork w = cur[slot];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    const long long len = (long long)w.end - w.start;
+    const int cb = w.start + (int)(len * c / KD_CH), ce = w.start + (int)(len * (c + 1) / KD_CH);
+    double mx[M], mn[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) { mx[a] = -HUGE_VAL; mn[a] = HUGE_VAL; }
+    for (int i = cb + lane; i < ce; i += 64) {
+        const int pt = idx[i];
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            const double v = coords[(size_t)pt * M + a];
+            mx[a] = mx[a] > v ? mx[a] : v;
+            mn[a] = mn[a] < v ? mn[a] : v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ox = __shfl_xor(mx[a], off), on = __shfl_xor(mn[a], off);
+            mx[a] = mx[a] > ox ? mx[a] : ox;
+            mn[a] = mn[a] < on ? mn[a] : on;
+        }
+        if (lane == 0) { hb[((size_t)slot * KD_CH + c) * 6 + a] = mx[a]; hb[((size_t)slot * KD_CH + c) * 6 + 3 + a] = mn[a]; }
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void kd_huge_setup_kernel(const double* __restrict__ coords, int* __restrict__ idx,
+                                                            const KdWork* __restrict__ cur, const int* __restrict__ n_cur,
+                                                            const double* __restrict__ hb, KdHuge* __restrict__ hs, int4* __restrict__ meta,
+                                                            KdBuildState* __restrict__ st) {
+#pragma clang fp contract(off)
+    __shared__ double s_red[4 * 6];
+    const int slot = blockIdx.x;
+    if (slot >= *n_cur) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double mx[M], mn[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        mx[a] = hb[((size_t)slot * KD_CH + tid) * 6 + a];                 // (KD_CH == 256 == the workgroup: a chunk per thread)
+        mn[a] = hb[((size_t)slot * KD_CH + tid) * 6 + 3 + a];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ox = __shfl_xor(mx[a], off), on = __shfl_xor(mn[a], off);
+            mx[a] = mx[a] > ox ? mx[a] : ox;
+            mn[a] = mn[a] < on ? mn[a] : on;
+        }
+        if (lane == 0) { s_red[wave * 6 + a] = mx[a]; s_red[wave * 6 + 3 + a] = mn[a]; }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const KdWork w = cur[slot];
+    double bx[M], bn[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        bx[a] = s_red[a];
+        bn[a] = s_red[3 + a];
+        for (int wv = 1; wv < 4; ++wv) {
+            bx[a] = bx[a] > s_red[wv * 6 + a] ? bx[a] : s_red[wv * 6 + a];
+            bn[a] = bn[a] < s_red[wv * 6 + 3 + a] ? bn[a] : s_red[wv * 6 + 3 + a];
+        }
+    }
+    if (w.node == 0) {
+#pragma unroll
+        for (int a = 0; a < M; ++a) { st->maxes[a] = bx[a]; st->mins[a] = bn[a]; }
+    }
+    int d = 0;
+    double sz = 0.0;
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+        if (bx[a] - bn[a] > sz) { d = a; sz = bx[a] - bn[a]; }
+    KdHuge h{};
+    h.node = w.node; h.start = w.start; h.end = w.end;
+    h.d = d;
+    if (bx[d] == bn[d]) {                                                 // all points identical: a leaf
+        meta[w.node] = make_int4(-1, w.start, w.end, 0);
+        h.phase = 4;
+        hs[slot] = h;
+        return;
+    }
+    const int size = w.end - w.start;
+    h.first = w.start; h.last = w.end; h.nth = w.start + size / 2;
+    h.depth = 2 * (31 - __clz(size));
+    kd_huge_begin_select<M>(coords, idx, h, st);                          // (size > 3)
+    hs[slot] = h;
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void kd_huge_classify_kernel(const double* __restrict__ coords, const int* __restrict__ idx,
+                                                               const KdHuge* __restrict__ hs, const int* __restrict__ n_cur,
+                                                               int* __restrict__ lp, int* __restrict__ rp, int* __restrict__ hc) {
+    const int slot = blockIdx.y;
+    if (slot >= *n_cur) return;
+    const int phase = hs[slot].phase;
+    if (phase == 4) return;
+    const int lo = hs[slot].lo, hi = hs[slot].hi, d = hs[slot].d;
+    const double pv = hs[slot].pv;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    const long long len = (long long)hi - lo;
+    const int cb = lo + (int)(len * c / KD_CH), ce = lo + (int)(len * (c + 1) / KD_CH);
+    const unsigned long long lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+    int nl = 0, nr = 0;
+    for (int base = cb; base < ce; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < ce;
+        const double v = valid ? kd_key<M>(coords, idx[i], d) : 0.0;
+        const bool sl = valid && !(v < pv);
+        const bool sr_ = valid && (phase == 1 ? !(pv < v) : v < pv);
+        const unsigned long long ml = __ballot(sl), mr = __ballot(sr_);
+        if (sl) lp[cb + nl + __popcll(ml & lt)] = i;
+        if (sr_) rp[cb + nr + __popcll(mr & lt)] = i;
+        nl += __popcll(ml);
+        nr += __popcll(mr);
+    }
+    if (lane == 0) { hc[(slot * 5 + 0) * KD_CH + c] = nl; hc[(slot * 5 + 1) * KD_CH + c] = nr; }
+}
+
+__global__ __launch_bounds__(256) void kd_huge_count_kernel(KdHuge* __restrict__ hs, const int* __restrict__ n_cur, const int* __restrict__ lp,
+                                                            const int* __restrict__ rp, int* __restrict__ hc) {
+    const int slot = blockIdx.y;
+    if (slot >= *n_cur) return;
+    if (hs[slot].phase == 4) return;
+    const int lo = hs[slot].lo, hi = hs[slot].hi;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    const long long len = (long long)hi - lo;
+    const int cb = lo + (int)(len * c / KD_CH);
+    const int* cl = hc + (slot * 5 + 0) * KD_CH;
+    const int* cr = hc + (slot * 5 + 1) * KD_CH;
+    int pl = 0, sr = 0, nL = 0, nR = 0;
+    for (int u = lane; u < KD_CH; u += 64) {
+        const int a = cl[u], b = cr[u];
+        pl += u < c ? a : 0;
+        sr += u > c ? b : 0;
+        nL += a;
+        nR += b;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        pl += __shfl_xor(pl, off);
+        sr += __shfl_xor(sr, off);
+        nL += __shfl_xor(nL, off);
+        nR += __shfl_xor(nR, off);
+    }
+    const int nl = cl[c], nr = cr[c];
+    int cnt = 0;
+    for (int j0 = 0; j0 < nl; j0 += 64) {
+        const int j = j0 + lane;
+        bool ok = false;
+        if (j < nl) {
+            const int x = lp[cb + j];
+            int a = 0, e = nr;                                            // first local right stop with position > x
+            while (a < e) {
+                const int mid = (a + e) >> 1;
+                if (rp[cb + mid] <= x) a = mid + 1; else e = mid;
+            }
+            ok = sr + (nr - a) > pl + j;
+        }
+        const int got = __popcll(__ballot(ok));
+        cnt += got;
+        if (got < 64) break;
+    }
+    if (lane == 0) {
+        hc[(slot * 5 + 2) * KD_CH + c] = pl;
+        hc[(slot * 5 + 3) * KD_CH + c] = sr;
+        hc[(slot * 5 + 4) * KD_CH + c] = cnt;
+        if (c == 0) { hs[slot].nL = nL; hs[slot].nR = nR; hs[slot].cutL = hi; hs[slot].cutR = hi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void kd_huge_swap_kernel(int* __restrict__ idx, KdHuge* __restrict__ hs, const int* __restrict__ n_cur,
+                                                           const int* __restrict__ lp, const int* __restrict__ rp, const int* __restrict__ hc) {
+    __shared__ int s_sr[KD_CH], s_nr[KD_CH], s_red[4];
+    const int slot = blockIdx.y;
+    if (slot >= *n_cur) return;
+    if (hs[slot].phase == 4) return;
+    const int lo = hs[slot].lo, hi = hs[slot].hi, nL = hs[slot].nL;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    s_sr[tid] = hc[(slot * 5 + 3) * KD_CH + tid];                         // (KD_CH == 256 == the workgroup)
+    s_nr[tid] = hc[(slot * 5 + 1) * KD_CH + tid];
+    int k_part = hc[(slot * 5 + 4) * KD_CH + tid];
+    for (int off = 32; off > 0; off >>= 1) k_part += __shfl_xor(k_part, off);
+    if (lane == 0) s_red[wave] = k_part;
+    __syncthreads();
+    const int K = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const long long len = (long long)hi - lo;
+    auto right_by_rank = [&](int k) -> int {                              // chunk u with s_sr[u] <= k < s_sr[u] + s_nr[u]: the smallest u with s_sr[u] <= k
+        int a = 0, e = KD_CH - 1;
+        while (a < e) {
+            const int mid = (a + e) >> 1;
+            if (s_sr[mid] <= k) e = mid; else a = mid + 1;
+        }
+        const int ub = lo + (int)(len * a / KD_CH);
+        return rp[ub + (s_nr[a] - 1 - (k - s_sr[a]))];
+    };
+    const int c = blockIdx.x * 4 + wave;
+    const int cb = lo + (int)(len * c / KD_CH);
+    const int pl = hc[(slot * 5 + 2) * KD_CH + c], nl = hc[(slot * 5 + 0) * KD_CH + c];
+    const int mine = min(nl, max(0, K - pl));
+    for (int j = lane; j < mine; j += 64) {
+        const int x = lp[cb + j];
+        const int y = right_by_rank(pl + j);
+        const int t = idx[x];
+        idx[x] = idx[y];
+        idx[y] = t;
+    }
+    if (lane == 0) {
+        if (K < nL && pl <= K && K < pl + nl) hs[slot].cutL = lp[cb + (K - pl)];   // L(K): the next stop of the left pointer
+        if (c == 0) {
+            hs[slot].K = K;
+            if (K > 0) hs[slot].cutR = right_by_rank(K - 1);              // R(K - 1): where the last swap put a left-stopping key
+        }
+    }
+}
+
+template <int M>
+__global__ void kd_huge_advance_kernel(const double* __restrict__ coords, int* __restrict__ idx, KdHuge* __restrict__ hs,
+                                       const int* __restrict__ n_cur, int4* __restrict__ meta, double* __restrict__ split_out,
+                                       const KdQueues next, int* __restrict__ n_next, KdBuildState* __restrict__ st, int leafsize) {
+#pragma clang fp contract(off)
+    const int slot = blockIdx.x;
+    if (slot >= *n_cur || threadIdx.x != 0) return;
+    KdHuge h = hs[slot];
+    if (h.phase == 4) return;
+    int p = -1;
+    if (h.phase == 1) {
+        const int cut = h.cutL < h.cutR ? h.cutL : h.cutR;                // (hi stands for "none")
+        if (cut <= h.nth) h.first = cut; else h.last = cut;
+        if (h.last - h.first > 3) {
+            kd_huge_begin_select<M>(coords, idx, h, st);
+        } else {
+            for (int i = h.first + 1; i < h.last; ++i) {                  // __insertion_sort of the last (at most three) elements
+                const int val = idx[i];
+                const double kv = kd_key<M>(coords, val, h.d);
+                int j = i;
+                while (j > h.first && kv < kd_key<M>(coords, idx[j - 1], h.d)) { idx[j] = idx[j - 1]; --j; }
+                idx[j] = val;
+            }
+            h.pv = kd_key<M>(coords, idx[h.nth], h.d);                    // the split; everything from nth on is >= it
+            h.lo = h.start;
+            h.hi = h.nth;
+            h.phase = 2;
+        }
+    } else if (h.phase == 2) {
+        p = h.start + h.nR;                                               // the keys below the split
+        if (p == h.start) {                                               // the median is the minimum: split just above it
+            h.pv = nextafter(h.pv, HUGE_VAL);
+            h.lo = h.start;
+            h.hi = h.end;
+            h.phase = 3;
+            p = -1;
+        }
+    } else {
+        p = h.start + h.nR;
+    }
+    if (p >= 0) {
+        const int c0 = atomicAdd(&st->n_nodes, 2);
+        meta[h.node] = make_int4(h.d, c0, c0 + 1, 0);
+        split_out[h.node] = h.pv;
+        const int cs[2] = {h.start, p}, ce[2] = {p, h.end};
+        for (int c = 0; c < 2; ++c) {
+            if (ce[c] - cs[c] <= leafsize) {
+                meta[c0 + c] = make_int4(-1, cs[c], ce[c], 0);
+            } else {
+                const int cls = kd_size_class(ce[c] - cs[c]);
+                const int q = atomicAdd(n_next + cls, 1);
+                next.q[cls][q] = KdWork{c0 + c, cs[c], ce[c]};
+            }
+        }
+        h.phase = 4;
+    }
+    hs[slot] = h;
+}
+
+__global__ void kd_init_kernel(int* __restrict__ idx, long long n, const KdQueues q, int* __restrict__ counts, KdBuildState* st,
+                               int4* __restrict__ meta, int leafsize) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) idx[i] = (int)i;
     if (i == 0) {
@@ -301,8 +673,8 @@ __global__ void kd_init_kernel(int* __restrict__ idx, long long n, KdWork* __res
             meta[0] = make_int4(-1, 0, (int)n, 0);
         } else {
             const int cls = kd_size_class(n);
-            (cls == 0 ? q0 : cls == 1 ? q1 : q2)[0] = KdWork{0, 0, (int)n};
-            counts[cls] = 1;                                              // (level 0's three counters; the rest were cleared)
+            q.q[cls][0] = KdWork{0, 0, (int)n};
+            counts[cls] = 1;                                              // (level 0's four counters; the rest were cleared)
         }
     }
 }
@@ -339,18 +711,55 @@ __global__ void kd_root_bounds_kernel(const double* __restrict__ coords, long lo
 }
 
 template <int M>
-int kd_launch_level(const double* coords, int* idx, int4* meta, double* split, KdWork* const (&cur)[3], const int* n_cur, KdWork* const (&next)[3],
+int kd_launch_level(const double* coords, int* idx, int4* meta, double* split, KdWork* const (&cur)[4], const int* n_cur, const KdQueues& next,
                     int* n_next, KdBuildState* st, int* lp, int* rp, const long long (&grid)[3], int leafsize, hipStream_t s) {
     if (grid[2] > 0)
-        hipLaunchKernelGGL((kd_level_kernel<M, 1024>), dim3((unsigned)grid[2]), dim3(1024), 0, s, coords, idx, meta, split, cur[2], n_cur + 2, next[0],
-                           next[1], next[2], n_next, st, lp, rp, leafsize);
+        hipLaunchKernelGGL((kd_level_kernel<M, 1024>), dim3((unsigned)grid[2]), dim3(1024), 0, s, coords, idx, meta, split, cur[2], n_cur + 2, next,
+                           n_next, st, lp, rp, leafsize);
     if (grid[1] > 0)
-        hipLaunchKernelGGL((kd_level_kernel<M, 256>), dim3((unsigned)grid[1]), dim3(256), 0, s, coords, idx, meta, split, cur[1], n_cur + 1, next[0],
-                           next[1], next[2], n_next, st, lp, rp, leafsize);
+        hipLaunchKernelGGL((kd_level_kernel<M, 256>), dim3((unsigned)grid[1]), dim3(256), 0, s, coords, idx, meta, split, cur[1], n_cur + 1, next,
+                           n_next, st, lp, rp, leafsize);
     if (grid[0] > 0)
-        hipLaunchKernelGGL((kd_level_kernel<M, 64>), dim3((unsigned)grid[0]), dim3(64), 0, s, coords, idx, meta, split, cur[0], n_cur, next[0], next[1],
-                           next[2], n_next, st, lp, rp, leafsize);
+        hipLaunchKernelGGL((kd_level_kernel<M, 64>), dim3((unsigned)grid[0]), dim3(64), 0, s, coords, idx, meta, split, cur[0], n_cur, next, n_next, st,
+                           lp, rp, leafsize);
     FDX_CHECK_LAUNCH();
+    return 0;
+}
+
+// the huge nodes of one level (count known: it was read back): bounds, then passes of four launches until every node has its children
+template <int M>
+int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const KdWork* cur3, const int* n_cur3, int count, long long max_size,
+                const KdQueues& next, int* n_next, KdBuildState* st, int* lp, int* rp, KdHuge* hs, int* hc, double* hb, int leafsize,
+                bool* gave_up, hipStream_t s) {
+    const dim3 wide(KD_CH / 4, (unsigned)count), one((unsigned)count);
+    hipLaunchKernelGGL((kd_huge_bounds_kernel<M>), wide, dim3(256), 0, s, coords, idx, cur3, n_cur3, hb);
+    hipLaunchKernelGGL((kd_huge_setup_kernel<M>), one, dim3(256), 0, s, coords, idx, cur3, n_cur3, hb, hs, meta, st);
+    FDX_CHECK_LAUNCH();
+    auto round = [&]() -> int {
+        hipLaunchKernelGGL((kd_huge_classify_kernel<M>), wide, dim3(256), 0, s, coords, idx, hs, n_cur3, lp, rp, hc);
+        hipLaunchKernelGGL(kd_huge_count_kernel, wide, dim3(256), 0, s, hs, n_cur3, lp, rp, hc);
+        hipLaunchKernelGGL(kd_huge_swap_kernel, wide, dim3(256), 0, s, idx, hs, n_cur3, lp, rp, hc);
+        hipLaunchKernelGGL((kd_huge_advance_kernel<M>), one, dim3(64), 0, s, coords, idx, hs, n_cur3, meta, split, next, n_next, st, leafsize);
+        FDX_CHECK_LAUNCH();
+        return 0;
+    };
+    // a selection over `size` elements takes about log2(size) + a few partition passes (the budget is twice that), then one or two
+    // split passes: that many rounds blind, then the phases are looked at
+    int lg = 0;
+    while ((1LL << (lg + 1)) <= max_size) ++lg;
+    const int budget = 2 * lg + 4;                                        // libstdc++'s depth budget + the last pass + the split passes
+    int done_rounds = 0;
+    for (int r = 0; r < std::min(budget, lg + 8); ++r, ++done_rounds) FDX_TRY(round());
+    std::vector<KdHuge> h((size_t)count);
+    for (;;) {
+        FDX_HIP(hipMemcpyAsync(h.data(), hs, (size_t)count * sizeof(KdHuge), hipMemcpyDeviceToHost, s));
+        FDX_HIP(hipStreamSynchronize(s));
+        bool all = true;
+        for (const KdHuge& x : h) all = all && x.phase == 4;
+        if (all) break;
+        if (done_rounds >= budget) { *gave_up = true; return 0; }
+        for (int r = 0; r < 4 && done_rounds < budget; ++r, ++done_rounds) FDX_TRY(round());
+    }
     return 0;
 }
 
@@ -365,18 +774,22 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
     FDX_TRY(out->split.alloc((size_t)cap_nodes * sizeof(double)));
     FDX_TRY(out->idx.alloc((size_t)n * sizeof(int)));
     // queues of the nodes still to split, by level parity and team size: a level holds at most n / (size class's lower bound) of a class
-    const long long qcap[3] = {n / (leafsize + 1) + 2, n / (KD_SMALL + 1) + 2, n / (KD_MID + 1) + 2};
-    DevBuf q[2][3], counts, state, lp, rp;
+    const long long qcap[4] = {n / (leafsize + 1) + 2, n / (KD_SMALL + 1) + 2, n / (KD_MID + 1) + 2, n / (KD_HUGE + 1) + 2};
+    DevBuf q[2][4], counts, state, lp, rp, hs, hc, hb;
     for (int par = 0; par < 2; ++par)
-        for (int c = 0; c < 3; ++c) FDX_TRY(q[par][c].alloc((size_t)qcap[c] * sizeof(KdWork)));
+        for (int c = 0; c < 4; ++c) FDX_TRY(q[par][c].alloc((size_t)qcap[c] * sizeof(KdWork)));
     const int max_levels = 128;
-    FDX_TRY(counts.alloc((size_t)(max_levels + 2) * 3 * sizeof(int)));
+    FDX_TRY(counts.alloc((size_t)(max_levels + 2) * 4 * sizeof(int)));
     FDX_TRY(state.alloc(sizeof(KdBuildState)));
     FDX_TRY(lp.alloc((size_t)n * sizeof(int)));
     FDX_TRY(rp.alloc((size_t)n * sizeof(int)));
-    FDX_HIP(hipMemsetAsync(counts.p, 0, (size_t)(max_levels + 2) * 3 * sizeof(int), st));
-    hipLaunchKernelGGL(kd_init_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out->idx.as<int>(), n, q[0][0].as<KdWork>(),
-                       q[0][1].as<KdWork>(), q[0][2].as<KdWork>(), counts.as<int>(), state.as<KdBuildState>(), out->meta.as<int4>(), leafsize);
+    FDX_TRY(hs.alloc((size_t)qcap[3] * sizeof(KdHuge)));
+    FDX_TRY(hc.alloc((size_t)qcap[3] * 5 * KD_CH * sizeof(int)));
+    FDX_TRY(hb.alloc((size_t)qcap[3] * KD_CH * 6 * sizeof(double)));
+    FDX_HIP(hipMemsetAsync(counts.p, 0, (size_t)(max_levels + 2) * 4 * sizeof(int), st));
+    KdQueues q0{{q[0][0].as<KdWork>(), q[0][1].as<KdWork>(), q[0][2].as<KdWork>(), q[0][3].as<KdWork>()}};
+    hipLaunchKernelGGL(kd_init_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out->idx.as<int>(), n, q0, counts.as<int>(),
+                       state.as<KdBuildState>(), out->meta.as<int4>(), leafsize);
     FDX_CHECK_LAUNCH();
     if (n <= leafsize) {
         hipLaunchKernelGGL(kd_root_bounds_kernel, dim3(1), dim3(256), 0, st, coords_dev, n, dim, state.as<KdBuildState>());
@@ -385,22 +798,37 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
     // A balanced tree of n points has ceil(log2(n / leafsize)) + 1 levels of split nodes; the split above the minimum (heavily
     // duplicated coordinates) can make it deeper: the expected levels are queued blind - level L has at most 2^L nodes, a launch
     // covers that many (and no more than the class can hold) and the surplus workgroups leave at once -, then the queue lengths
-    // are looked at.
+    // are looked at.  While a level can still hold huge nodes (a child is smaller than its parent: once a level has none, none
+    // follows) their number is read first - their passes are launches of their own (kd_run_huge).
     int expected = 1;
     while (((long long)leafsize << (expected - 1)) < n) ++expected;
+    bool huge_alive = n > KD_HUGE, gave_up = false;
     auto run_level = [&](int level) -> int {
+        KdWork* cur[4];
+        KdQueues nxt;
+        for (int c = 0; c < 4; ++c) { cur[c] = q[level & 1][c].as<KdWork>(); nxt.q[c] = q[(level + 1) & 1][c].as<KdWork>(); }
+        const int* n_cur = counts.as<int>() + 4 * level;
+        int* n_next = counts.as<int>() + 4 * (level + 1);
+        int n_huge = 0;
+        if (huge_alive) {
+            FDX_HIP(hipMemcpyAsync(&n_huge, n_cur + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+            FDX_HIP(hipStreamSynchronize(st));
+            if (n_huge == 0) huge_alive = false;
+        }
         long long grid[3];
         for (int c = 0; c < 3; ++c) grid[c] = std::min<long long>(qcap[c] - 1, level < 40 ? (1LL << level) : qcap[c]);
         // a node of `level` forks below the root has shed at least `level` points (each split gives both sides one or more)
         if (n - level <= KD_MID) grid[2] = 0;
         if (n - level <= KD_SMALL) grid[1] = 0;
-        KdWork* cur[3] = {q[level & 1][0].as<KdWork>(), q[level & 1][1].as<KdWork>(), q[level & 1][2].as<KdWork>()};
-        KdWork* nxt[3] = {q[(level + 1) & 1][0].as<KdWork>(), q[(level + 1) & 1][1].as<KdWork>(), q[(level + 1) & 1][2].as<KdWork>()};
-        const int* n_cur = counts.as<int>() + 3 * level;
-        int* n_next = counts.as<int>() + 3 * (level + 1);
 #define FDX_KDL(MM)                                                                                                              \
-        return kd_launch_level<MM>(coords_dev, out->idx.as<int>(), out->meta.as<int4>(), out->split.as<double>(), cur, n_cur, nxt, n_next, \
-                                   state.as<KdBuildState>(), lp.as<int>(), rp.as<int>(), grid, leafsize, st)
+        do {                                                                                                                     \
+            if (n_huge > 0)                                                                                                      \
+                FDX_TRY(kd_run_huge<MM>(coords_dev, out->idx.as<int>(), out->meta.as<int4>(), out->split.as<double>(), cur[3], n_cur + 3, n_huge, \
+                                        std::max<long long>(4, n - level), nxt, n_next, state.as<KdBuildState>(), lp.as<int>(), rp.as<int>(),     \
+                                        hs.as<KdHuge>(), hc.as<int>(), hb.as<double>(), leafsize, &gave_up, st));                                  \
+            return kd_launch_level<MM>(coords_dev, out->idx.as<int>(), out->meta.as<int4>(), out->split.as<double>(), cur, n_cur, nxt, n_next,     \
+                                       state.as<KdBuildState>(), lp.as<int>(), rp.as<int>(), grid, leafsize, st);                                 \
+        } while (0)
         if (dim == 1) FDX_KDL(1);
         if (dim == 2) FDX_KDL(2);
         FDX_KDL(3);
@@ -408,24 +836,24 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
     };
     int level = 0;
     if (n > leafsize) {
-        for (; level < expected && level < max_levels; ++level) FDX_TRY(run_level(level));
-        for (;;) {
-            int left[3] = {0, 0, 0};
-            FDX_HIP(hipMemcpyAsync(left, counts.as<int>() + 3 * level, sizeof(left), hipMemcpyDeviceToHost, st));
+        for (; level < expected && level < max_levels && !gave_up; ++level) FDX_TRY(run_level(level));
+        while (!gave_up) {
+            int left[4] = {0, 0, 0, 0};
+            FDX_HIP(hipMemcpyAsync(left, counts.as<int>() + 4 * level, sizeof(left), hipMemcpyDeviceToHost, st));
             FDX_HIP(hipStreamSynchronize(st));
-            if (left[0] + left[1] + left[2] == 0) break;
-            if (level >= max_levels) { out->overflow = true; return 0; }
+            if (left[0] + left[1] + left[2] + left[3] == 0) break;
+            if (level >= max_levels) { gave_up = true; break; }
             FDX_TRY(run_level(level));
             ++level;
         }
     }
-    KdBuildState hs{};
-    FDX_HIP(hipMemcpyAsync(&hs, state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    KdBuildState hstate{};
+    FDX_HIP(hipMemcpyAsync(&hstate, state.p, sizeof(hstate), hipMemcpyDeviceToHost, st));
     FDX_HIP(hipStreamSynchronize(st));
-    out->n_nodes = hs.n_nodes;
-    out->overflow = hs.overflow != 0;
+    out->n_nodes = hstate.n_nodes;
+    out->overflow = gave_up || hstate.overflow != 0;
     out->levels = level;
-    for (int a = 0; a < 3; ++a) { out->mins[a] = hs.mins[a]; out->maxes[a] = hs.maxes[a]; }
+    for (int a = 0; a < 3; ++a) { out->mins[a] = hstate.mins[a]; out->maxes[a] = hstate.maxes[a]; }
     return 0;
 }
 

@@ -134,7 +134,7 @@ unsigned host_cpu_budget() {
 static std::atomic<int> g_kd_threads{0};
 static std::atomic<long long> g_kd_team_min{0};
 static std::atomic<long long> g_kd_local_max{-1};
-static std::atomic<int> g_kd_device_build{0};   // fdx_kdtree_tune(2, 1): the tree of 1-3 coordinates is built on the device (kdtree_build_dev.cpp)
+static std::atomic<int> g_kd_device_build{1};   // fdx_kdtree_tune(2, 0): the tree of 1-3 coordinates is built on the host even where the device could (kdtree_build_dev.cpp)
 static unsigned kd_thread_share() {
     if (const char* e = fdx::env("FDX_KDTREE_THREADS")) return (unsigned)std::max(1, atoi(e));
     const int v = g_kd_threads.load();

@@ -198,10 +198,9 @@ int fdx_kdtree_set_threads(int32_t threads);
  *         pool of host threads instead of made by one thread (0: the default, 400000);
  * what 1: subtrees of at most `points` points are built on a contiguous copy of their points (negative: the default, 65536;
  *         0: never);
- * what 2: 1 = fdx_graph_plan_set_ckdtree_lists_dev builds the tree of 1-3 coordinates ON THE DEVICE (csrc/kdtree_build_dev.cpp: the
- *         same tree, level by level, a team of threads per node) instead of on the host's threads.  Default 0: at a million points
- *         the device build takes 13-18 ms where the host's pool takes 9-11 beside the device's own work - its top five levels are one
- *         workgroup per node. */
+ * what 2: 0 = fdx_graph_plan_set_ckdtree_lists_dev builds the tree on the host's threads even for 1-3 coordinates (default 1: ON
+ *         THE DEVICE, csrc/kdtree_build_dev.cpp - the same tree, level by level, a team of threads per node; a tree deeper than
+ *         128 levels falls back to the host build by itself). */
 int fdx_kdtree_tune(int32_t what, int64_t points);
 /* The index array of that tree as the DEVICE build makes it (1-3 coordinates; coords_dev: n x dim doubles on the device):
  * indices_out (host, n) must equal scipy.spatial.cKDTree(coords).indices.  info_out[3] (may be NULL) = {nodes, levels of split

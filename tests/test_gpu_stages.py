@@ -506,7 +506,8 @@ def test_fit_with_four_dimensional_coordinates():
 
 
 @pytest.mark.parametrize("case", ["square", "square_big", "hex", "cube3d", "random2d", "random2d_ties", "random3d", "line", "duplicates",
-                                  "heavy_duplicates", "binary", "shuffled", "tiny", "one_leaf", "million"])
+                                  "heavy_duplicates", "binary", "shuffled", "tiny", "one_leaf", "million", "random_huge", "binary_huge",
+                                  "ties_huge_3d", "line_huge"])
 def test_device_built_ckdtree_has_scipys_index_array(case):
     """csrc/kdtree_build_dev.cpp: the restated cKDTree built ON THE DEVICE - every node of a level at once, libstdc++'s introselect
     replayed by a team of threads per node (partition passes in list form) - must leave scipy's index array, entry for entry: the
@@ -536,6 +537,11 @@ def test_device_built_ckdtree_has_scipys_index_array(case):
         "tiny": rs.rand(17, 2),
         "one_leaf": rs.rand(9, 3),
         "million": np.stack(np.meshgrid(np.arange(1000.0), np.arange(1000.0), indexing="ij"), -1).reshape(-1, 2),
+        # above 100000 points a node's passes are launches of their own over 64 workgroups (kd_huge_*)
+        "random_huge": rs.rand(300000, 2),
+        "binary_huge": rs.randint(0, 2, size=(300000, 2)).astype(np.float64),
+        "ties_huge_3d": np.round(rs.rand(250000, 3) * 20.0, 1),
+        "line_huge": np.round(rs.rand(400000, 1) * 1000.0),
     }[case]
     coords = np.ascontiguousarray(coords, dtype=np.float64)
     n, dim = coords.shape
@@ -604,12 +610,13 @@ def test_device_ckdtree_queries_equal_the_host_restatement(case, monkeypatch):
 
     nb_d, cn_d, perm_d, before = lists(False)
     nb_h, cn_h, perm_h, _ = lists(True)
-    # ... and with the tree itself built on the device (csrc/kdtree_build_dev.cpp, fdx_kdtree_tune(2, 1)): the same lists
-    lib.fdx_kdtree_tune(2, 1)
+    # (the tree itself was built on the device there - csrc/kdtree_build_dev.cpp, the default for 1-3 coordinates) ... and with
+    # the tree built by the host's thread pool, queries on the device (fdx_kdtree_tune(2, 0)): the same lists
+    lib.fdx_kdtree_tune(2, 0)
     try:
         nb_b, cn_b, perm_b, _ = lists(False)
     finally:
-        lib.fdx_kdtree_tune(2, 0)
+        lib.fdx_kdtree_tune(2, 1)
     assert np.array_equal(nb_b, nb_d) and np.array_equal(cn_b, cn_d) and np.array_equal(perm_b, perm_d)
     assert np.array_equal(perm_d, perm_h)
     assert np.array_equal(cn_d, cn_h) and np.array_equal(nb_d, nb_h)
