@@ -22,16 +22,20 @@
 //
 // STATE (round 6): exact - scipy's index array on lattices, clouds, heavy duplicates, sorted input, 1-3 coordinates, up to a
 // million points (tests/test_gpu_stages.py) - and the default for 1-3 coordinates (fdx_kdtree_tune(2, 0) selects the host's thread
-// pool): a million lattice points in 5.7-6.6 ms against the pool's 9-11.  Nodes above 100000 points are not one workgroup's work
-// (a million points through one compute unit: 2.5 ms for the root, 4.5 for its two children): each of their passes is four
-// launches over 64 workgroups per node - classify / count / swap / advance (kd_huge_*) - ~110 launches and two read-backs per
-// level, 4 ms for levels 0-3; level 4 (1024 threads per node) 0.6 ms, levels 5-9 (256 per node) 1.4 ms, levels 10-16 (a wave per
-// node) 1.4 ms.
+// pool): a million lattice points in 5.9-6.2 ms against the pool's 9-11.  Nodes above 100000 points are not one workgroup's work
+// (a million points through one compute unit: 2.5 ms for the root, 4.5 for its two children): each of their passes is three
+// launches over 64 workgroups per node - classify / count / swap, the node's last workgroup through the swap doing what follows
+// the pass (kd_huge_*) - ~85 launches and two read-backs per level, bound by the HOST's launch rate: 0.6-0.75 ms per level, 2.7 ms
+// for levels 0-3; levels 4-7 (1024 threads per node) 1.2 ms, levels 8-9 (256 per node) 0.3 ms, levels 10-16 (a wave per node)
+// 1.4 ms.  Next: the launches of a level as one hipGraph (cached per shape), the wave-per-node levels out of LDS.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <vector>
 
+#include "fdx_env.h"
 #include "fdx_internal.h"
 #include "kdtree_dev.h"
 
@@ -39,10 +43,14 @@ namespace fdx {
 namespace {
 
 struct KdWork { int node, start, end; };
-// team sizes by node size: up to 1024 points one wave, up to 32768 a workgroup of 256, above one of 1024
-constexpr int KD_SMALL = 1024, KD_MID = 32768, KD_HUGE = 100000;
+// team sizes by node size: up to 1024 points one wave, up to 4096 a workgroup of 256, above one of 1024
+constexpr int KD_SMALL = 1024, KD_MID = 4096, KD_HUGE = 100000;
+// classes: 0 = a wave per node, 1 = 256 threads, 2 = 1024 threads, 3 = huge (launches of their own).  (A lane per node for the
+// nodes of at most 64 points - the serial algorithm itself, half of a tree's nodes - measured no faster than a wave per node: 64
+// lanes chasing 64 nodes through L2 are as latency-bound as 20 passes of ballots.)
 __host__ __device__ inline int kd_size_class(long long size) { return size <= KD_SMALL ? 0 : size <= KD_MID ? 1 : size <= KD_HUGE ? 2 : 3; }
-struct KdQueues { KdWork* q[4]; };
+constexpr int KD_NCLS = 4;
+struct KdQueues { KdWork* q[KD_NCLS]; };
 // Above KD_HUGE points a node is not one workgroup's work (a million points through one compute unit: 2.5 ms for the root, 4.5 ms
 // for its children): every pass of such a node is cut into KD_CH chunks, a wave each, over 64 workgroups, and the phases of a pass
 // that need everybody's results of the one before are separate launches - classify / count / swap / advance (kd_huge_*).
@@ -557,59 +565,20 @@ __global__ __launch_bounds__(256) void kd_huge_count_kernel(KdHuge* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void kd_huge_swap_kernel(int* __restrict__ idx, KdHuge* __restrict__ hs, const int* __restrict__ n_cur,
-                                                           const int* __restrict__ lp, const int* __restrict__ rp, const int* __restrict__ hc) {
-    __shared__ int s_sr[KD_CH], s_nr[KD_CH], s_red[4];
-    const int slot = blockIdx.y;
-    if (slot >= *n_cur) return;
-    if (hs[slot].phase == 4) return;
-    const int lo = hs[slot].lo, hi = hs[slot].hi, nL = hs[slot].nL;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    s_sr[tid] = hc[(slot * 5 + 3) * KD_CH + tid];                         // (KD_CH == 256 == the workgroup)
-    s_nr[tid] = hc[(slot * 5 + 1) * KD_CH + tid];
-    int k_part = hc[(slot * 5 + 4) * KD_CH + tid];
-    for (int off = 32; off > 0; off >>= 1) k_part += __shfl_xor(k_part, off);
-    if (lane == 0) s_red[wave] = k_part;
-    __syncthreads();
-    const int K = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    const long long len = (long long)hi - lo;
-    auto right_by_rank = [&](int k) -> int {                              // chunk u with s_sr[u] <= k < s_sr[u] + s_nr[u]: the smallest u with s_sr[u] <= k
-        int a = 0, e = KD_CH - 1;
-        while (a < e) {
-            const int mid = (a + e) >> 1;
-            if (s_sr[mid] <= k) e = mid; else a = mid + 1;
-        }
-        const int ub = lo + (int)(len * a / KD_CH);
-        return rp[ub + (s_nr[a] - 1 - (k - s_sr[a]))];
-    };
-    const int c = blockIdx.x * 4 + wave;
-    const int cb = lo + (int)(len * c / KD_CH);
-    const int pl = hc[(slot * 5 + 2) * KD_CH + c], nl = hc[(slot * 5 + 0) * KD_CH + c];
-    const int mine = min(nl, max(0, K - pl));
-    for (int j = lane; j < mine; j += 64) {
-        const int x = lp[cb + j];
-        const int y = right_by_rank(pl + j);
-        const int t = idx[x];
-        idx[x] = idx[y];
-        idx[y] = t;
-    }
-    if (lane == 0) {
-        if (K < nL && pl <= K && K < pl + nl) hs[slot].cutL = lp[cb + (K - pl)];   // L(K): the next stop of the left pointer
-        if (c == 0) {
-            hs[slot].K = K;
-            if (K > 0) hs[slot].cutR = right_by_rank(K - 1);              // R(K - 1): where the last swap put a left-stopping key
-        }
-    }
-}
-
+// What follows a pass, by ONE thread, once every swap of the pass is done and visible: narrow the selection and set up its next pass
+// (median of three, pivot), or end it (insertion sort, the split pass), or make the node's children.
 template <int M>
-__global__ void kd_huge_advance_kernel(const double* __restrict__ coords, int* __restrict__ idx, KdHuge* __restrict__ hs,
-                                       const int* __restrict__ n_cur, int4* __restrict__ meta, double* __restrict__ split_out,
-                                       const KdQueues next, int* __restrict__ n_next, KdBuildState* __restrict__ st, int leafsize) {
+__device__ void kd_huge_advance(const double* __restrict__ coords, int* idx, KdHuge* hs, int slot, int4* __restrict__ meta,
+                                double* __restrict__ split_out, const KdQueues& next, int* __restrict__ n_next, KdBuildState* st,
+                                int leafsize) {
 #pragma clang fp contract(off)
-    const int slot = blockIdx.x;
-    if (slot >= *n_cur || threadIdx.x != 0) return;
     KdHuge h = hs[slot];
+    // (written by other workgroups of the launch that calls this: real loads, not what this thread may hold in registers)
+    h.K = __atomic_load_n(&hs[slot].K, __ATOMIC_RELAXED);
+    h.nL = __atomic_load_n(&hs[slot].nL, __ATOMIC_RELAXED);
+    h.nR = __atomic_load_n(&hs[slot].nR, __ATOMIC_RELAXED);
+    h.cutL = __atomic_load_n(&hs[slot].cutL, __ATOMIC_RELAXED);
+    h.cutR = __atomic_load_n(&hs[slot].cutR, __ATOMIC_RELAXED);
     if (h.phase == 4) return;
     int p = -1;
     if (h.phase == 1) {
@@ -659,6 +628,66 @@ __global__ void kd_huge_advance_kernel(const double* __restrict__ coords, int* _
         h.phase = 4;
     }
     hs[slot] = h;
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void kd_huge_swap_kernel(const double* __restrict__ coords, int* idx, KdHuge* hs, const int* __restrict__ n_cur,
+                                                           const int* __restrict__ lp, const int* __restrict__ rp, const int* __restrict__ hc,
+                                                           int* __restrict__ tickets, int4* __restrict__ meta, double* __restrict__ split_out,
+                                                           const KdQueues next, int* __restrict__ n_next, KdBuildState* st, int leafsize) {
+    __shared__ int s_sr[KD_CH], s_nr[KD_CH], s_red[4];
+    const int slot = blockIdx.y;
+    if (slot >= *n_cur) return;
+    if (hs[slot].phase == 4) return;
+    const int lo = hs[slot].lo, hi = hs[slot].hi, nL = hs[slot].nL;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    s_sr[tid] = hc[(slot * 5 + 3) * KD_CH + tid];                         // (KD_CH == 256 == the workgroup)
+    s_nr[tid] = hc[(slot * 5 + 1) * KD_CH + tid];
+    int k_part = hc[(slot * 5 + 4) * KD_CH + tid];
+    for (int off = 32; off > 0; off >>= 1) k_part += __shfl_xor(k_part, off);
+    if (lane == 0) s_red[wave] = k_part;
+    __syncthreads();
+    const int K = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const long long len = (long long)hi - lo;
+    auto right_by_rank = [&](int k) -> int {                              // chunk u with s_sr[u] <= k < s_sr[u] + s_nr[u]: the smallest u with s_sr[u] <= k
+        int a = 0, e = KD_CH - 1;
+        while (a < e) {
+            const int mid = (a + e) >> 1;
+            if (s_sr[mid] <= k) e = mid; else a = mid + 1;
+        }
+        const int ub = lo + (int)(len * a / KD_CH);
+        return rp[ub + (s_nr[a] - 1 - (k - s_sr[a]))];
+    };
+    const int c = blockIdx.x * 4 + wave;
+    const int cb = lo + (int)(len * c / KD_CH);
+    const int pl = hc[(slot * 5 + 2) * KD_CH + c], nl = hc[(slot * 5 + 0) * KD_CH + c];
+    const int mine = min(nl, max(0, K - pl));
+    for (int j = lane; j < mine; j += 64) {
+        const int x = lp[cb + j];
+        const int y = right_by_rank(pl + j);
+        const int t = idx[x];
+        idx[x] = idx[y];
+        idx[y] = t;
+    }
+    if (lane == 0) {
+        if (K < nL && pl <= K && K < pl + nl) hs[slot].cutL = lp[cb + (K - pl)];   // L(K): the next stop of the left pointer
+        if (c == 0) {
+            hs[slot].K = K;
+            if (K > 0) hs[slot].cutR = right_by_rank(K - 1);              // R(K - 1): where the last swap put a left-stopping key
+        }
+    }
+    // the node's last workgroup through here does what follows the pass (a launch of its own otherwise): its swaps and everybody
+    // else's are visible to it - each workgroup fences its writes before it draws its ticket, the last one fences again behind it
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(&tickets[slot], 1);
+        if (ticket == (int)gridDim.x - 1) {
+            tickets[slot] = 0;
+            __threadfence();
+            kd_huge_advance<M>(coords, idx, hs, slot, meta, split_out, next, n_next, st, leafsize);
+        }
+    }
 }
 
 __global__ void kd_init_kernel(int* __restrict__ idx, long long n, const KdQueues q, int* __restrict__ counts, KdBuildState* st,
@@ -711,7 +740,7 @@ __global__ void kd_root_bounds_kernel(const double* __restrict__ coords, long lo
 }
 
 template <int M>
-int kd_launch_level(const double* coords, int* idx, int4* meta, double* split, KdWork* const (&cur)[4], const int* n_cur, const KdQueues& next,
+int kd_launch_level(const double* coords, int* idx, int4* meta, double* split, KdWork* const (&cur)[KD_NCLS], const int* n_cur, const KdQueues& next,
                     int* n_next, KdBuildState* st, int* lp, int* rp, const long long (&grid)[3], int leafsize, hipStream_t s) {
     if (grid[2] > 0)
         hipLaunchKernelGGL((kd_level_kernel<M, 1024>), dim3((unsigned)grid[2]), dim3(1024), 0, s, coords, idx, meta, split, cur[2], n_cur + 2, next,
@@ -729,8 +758,8 @@ int kd_launch_level(const double* coords, int* idx, int4* meta, double* split, K
 // the huge nodes of one level (count known: it was read back): bounds, then passes of four launches until every node has its children
 template <int M>
 int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const KdWork* cur3, const int* n_cur3, int count, long long max_size,
-                const KdQueues& next, int* n_next, KdBuildState* st, int* lp, int* rp, KdHuge* hs, int* hc, double* hb, int leafsize,
-                bool* gave_up, hipStream_t s) {
+                const KdQueues& next, int* n_next, KdBuildState* st, int* lp, int* rp, KdHuge* hs, int* hc, double* hb, int* tickets,
+                int leafsize, bool* gave_up, hipStream_t s) {
     const dim3 wide(KD_CH / 4, (unsigned)count), one((unsigned)count);
     hipLaunchKernelGGL((kd_huge_bounds_kernel<M>), wide, dim3(256), 0, s, coords, idx, cur3, n_cur3, hb);
     hipLaunchKernelGGL((kd_huge_setup_kernel<M>), one, dim3(256), 0, s, coords, idx, cur3, n_cur3, hb, hs, meta, st);
@@ -738,8 +767,8 @@ int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const
     auto round = [&]() -> int {
         hipLaunchKernelGGL((kd_huge_classify_kernel<M>), wide, dim3(256), 0, s, coords, idx, hs, n_cur3, lp, rp, hc);
         hipLaunchKernelGGL(kd_huge_count_kernel, wide, dim3(256), 0, s, hs, n_cur3, lp, rp, hc);
-        hipLaunchKernelGGL(kd_huge_swap_kernel, wide, dim3(256), 0, s, idx, hs, n_cur3, lp, rp, hc);
-        hipLaunchKernelGGL((kd_huge_advance_kernel<M>), one, dim3(64), 0, s, coords, idx, hs, n_cur3, meta, split, next, n_next, st, leafsize);
+        hipLaunchKernelGGL((kd_huge_swap_kernel<M>), wide, dim3(256), 0, s, coords, idx, hs, n_cur3, lp, rp, hc, tickets, meta, split, next, n_next,
+                           st, leafsize);
         FDX_CHECK_LAUNCH();
         return 0;
     };
@@ -774,19 +803,21 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
     FDX_TRY(out->split.alloc((size_t)cap_nodes * sizeof(double)));
     FDX_TRY(out->idx.alloc((size_t)n * sizeof(int)));
     // queues of the nodes still to split, by level parity and team size: a level holds at most n / (size class's lower bound) of a class
-    const long long qcap[4] = {n / (leafsize + 1) + 2, n / (KD_SMALL + 1) + 2, n / (KD_MID + 1) + 2, n / (KD_HUGE + 1) + 2};
-    DevBuf q[2][4], counts, state, lp, rp, hs, hc, hb;
+    const long long qcap[KD_NCLS] = {n / (leafsize + 1) + 2, n / (KD_SMALL + 1) + 2, n / (KD_MID + 1) + 2, n / (KD_HUGE + 1) + 2};
+    DevBuf q[2][KD_NCLS], counts, state, lp, rp, hs, hc, hb, tickets;
     for (int par = 0; par < 2; ++par)
-        for (int c = 0; c < 4; ++c) FDX_TRY(q[par][c].alloc((size_t)qcap[c] * sizeof(KdWork)));
+        for (int c = 0; c < KD_NCLS; ++c) FDX_TRY(q[par][c].alloc((size_t)qcap[c] * sizeof(KdWork)));
     const int max_levels = 128;
-    FDX_TRY(counts.alloc((size_t)(max_levels + 2) * 4 * sizeof(int)));
+    FDX_TRY(counts.alloc((size_t)(max_levels + 2) * KD_NCLS * sizeof(int)));
     FDX_TRY(state.alloc(sizeof(KdBuildState)));
     FDX_TRY(lp.alloc((size_t)n * sizeof(int)));
     FDX_TRY(rp.alloc((size_t)n * sizeof(int)));
     FDX_TRY(hs.alloc((size_t)qcap[3] * sizeof(KdHuge)));
     FDX_TRY(hc.alloc((size_t)qcap[3] * 5 * KD_CH * sizeof(int)));
     FDX_TRY(hb.alloc((size_t)qcap[3] * KD_CH * 6 * sizeof(double)));
-    FDX_HIP(hipMemsetAsync(counts.p, 0, (size_t)(max_levels + 2) * 4 * sizeof(int), st));
+    FDX_TRY(tickets.alloc((size_t)qcap[3] * sizeof(int)));
+    FDX_HIP(hipMemsetAsync(tickets.p, 0, (size_t)qcap[3] * sizeof(int), st));
+    FDX_HIP(hipMemsetAsync(counts.p, 0, (size_t)(max_levels + 2) * KD_NCLS * sizeof(int), st));
     KdQueues q0{{q[0][0].as<KdWork>(), q[0][1].as<KdWork>(), q[0][2].as<KdWork>(), q[0][3].as<KdWork>()}};
     hipLaunchKernelGGL(kd_init_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out->idx.as<int>(), n, q0, counts.as<int>(),
                        state.as<KdBuildState>(), out->meta.as<int4>(), leafsize);
@@ -804,11 +835,11 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
     while (((long long)leafsize << (expected - 1)) < n) ++expected;
     bool huge_alive = n > KD_HUGE, gave_up = false;
     auto run_level = [&](int level) -> int {
-        KdWork* cur[4];
+        KdWork* cur[KD_NCLS];
         KdQueues nxt;
-        for (int c = 0; c < 4; ++c) { cur[c] = q[level & 1][c].as<KdWork>(); nxt.q[c] = q[(level + 1) & 1][c].as<KdWork>(); }
-        const int* n_cur = counts.as<int>() + 4 * level;
-        int* n_next = counts.as<int>() + 4 * (level + 1);
+        for (int c = 0; c < KD_NCLS; ++c) { cur[c] = q[level & 1][c].as<KdWork>(); nxt.q[c] = q[(level + 1) & 1][c].as<KdWork>(); }
+        const int* n_cur = counts.as<int>() + KD_NCLS * level;
+        int* n_next = counts.as<int>() + KD_NCLS * (level + 1);
         int n_huge = 0;
         if (huge_alive) {
             FDX_HIP(hipMemcpyAsync(&n_huge, n_cur + 3, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -825,7 +856,7 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
             if (n_huge > 0)                                                                                                      \
                 FDX_TRY(kd_run_huge<MM>(coords_dev, out->idx.as<int>(), out->meta.as<int4>(), out->split.as<double>(), cur[3], n_cur + 3, n_huge, \
                                         std::max<long long>(4, n - level), nxt, n_next, state.as<KdBuildState>(), lp.as<int>(), rp.as<int>(),     \
-                                        hs.as<KdHuge>(), hc.as<int>(), hb.as<double>(), leafsize, &gave_up, st));                                  \
+                                        hs.as<KdHuge>(), hc.as<int>(), hb.as<double>(), tickets.as<int>(), leafsize, &gave_up, st));                                  \
             return kd_launch_level<MM>(coords_dev, out->idx.as<int>(), out->meta.as<int4>(), out->split.as<double>(), cur, n_cur, nxt, n_next,     \
                                        state.as<KdBuildState>(), lp.as<int>(), rp.as<int>(), grid, leafsize, st);                                 \
         } while (0)
@@ -835,11 +866,19 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
 #undef FDX_KDL
     };
     int level = 0;
+    const bool trace = fdx::env("FDX_TRACE_HOST") != nullptr;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now_ms();
     if (n > leafsize) {
-        for (; level < expected && level < max_levels && !gave_up; ++level) FDX_TRY(run_level(level));
+        for (; level < expected && level < max_levels && !gave_up; ++level) {
+            const bool was_huge = huge_alive;
+            const double t0 = now_ms();
+            FDX_TRY(run_level(level));
+            if (trace && was_huge) std::fprintf(stderr, "[fdx-host] kd device build: level %d queued at +%.2f ms, host time %.2f ms\n", level, t0 - t_start, now_ms() - t0);
+        }
         while (!gave_up) {
-            int left[4] = {0, 0, 0, 0};
-            FDX_HIP(hipMemcpyAsync(left, counts.as<int>() + 4 * level, sizeof(left), hipMemcpyDeviceToHost, st));
+            int left[KD_NCLS] = {0, 0, 0, 0};
+            FDX_HIP(hipMemcpyAsync(left, counts.as<int>() + KD_NCLS * level, sizeof(left), hipMemcpyDeviceToHost, st));
             FDX_HIP(hipStreamSynchronize(st));
             if (left[0] + left[1] + left[2] + left[3] == 0) break;
             if (level >= max_levels) { gave_up = true; break; }
