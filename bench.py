@@ -645,8 +645,8 @@ def main():
     for fam in fams:
         if fam == "lattice":
             # Visium-HD bins sit on a regular lattice: with k = 6 every spot's k-th neighbour is tied (four at distance 1, four at
-            # sqrt 2) and the default knn_ties="auto" has to reproduce the reference's (cKDTree) choice - a host tree build plus
-            # its queries.  Count-like rows, log_cpm (runs max_iter); few steps: a fit takes of the order of a second.
+            # sqrt 2) and the default knn_ties="auto" has to reproduce the reference's (cKDTree) choice - the restated tree (built on
+            # the device since the end of round 6) plus its queries.  Count-like rows, log_cpm (runs max_iter).
             Y, X, coords = gen_counts(torch, n, G, K, device, seed=0)
             side = int(np.ceil(np.sqrt(n)))
             ii = torch.arange(n, device=device)

@@ -105,8 +105,9 @@ def reference_tie_graph(c_ptr, coords_host, n, dim, k):
     kk = min(int(k), n - 1) + 1
     nbr, cnt = _DeviceBuffer(n * kk * 4), _DeviceBuffer(n * 4)
     plan, h = ctypes.c_void_p(), ctypes.c_void_p()
-    # the host build of the restated tree (21-24 ms per million points) starts NOW, in a thread of the library's: the device's own
-    # lists below come first and wait ~3 ms behind the stopped fit's sketch
+    # where the tree is built on the host (4-8 coordinates, fdx_kdtree_tune(2, 0)) that build starts NOW, in the library's thread
+    # pool, beside the device's own lists below, which wait ~3 ms behind the stopped fit's sketch; for 1-3 coordinates the tree is
+    # built on the device when the lists are asked for and this call returns at once
     _ckdtree_restatement_matches_scipy()
     ch_arr = None if coords_host is None else np.ascontiguousarray(coords_host, dtype=np.float64)
     ch = None if ch_arr is None else _lib.ptr_f64(ch_arr)
@@ -121,7 +122,7 @@ def reference_tie_graph(c_ptr, coords_host, n, dim, k):
             # coordinates that only exist on the device are fetched by the library into pinned memory (a pageable copy here would be
             # pinned by the driver, and unmapping it afterwards stalls the process's GPU queues: DESIGN appendix)
             _lib.check(lib.fdx_graph_plan_set_ckdtree_lists_dev(plan, ch, c_ptr, n, dim, None, 0, nbr.ptr, cnt.ptr, None))
-            mark("host tree + device queries + lists to positions")
+            mark("tree (device, 1-3 coordinates; else the host's pool) + device queries + lists to positions")
         except Exception:
             dead = ctypes.c_void_p()                                           # the plan owns device buffers: consume it
             lib.fdx_graph_from_knn_lists_dev(plan, nbr.ptr, cnt.ptr, 0, 0, None, ctypes.byref(dead))
