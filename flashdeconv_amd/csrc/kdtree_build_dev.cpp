@@ -778,7 +778,7 @@ int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const
     while ((1LL << (lg + 1)) <= max_size) ++lg;
     const int budget = 2 * lg + 4;                                        // libstdc++'s depth budget + the last pass + the split passes
     int done_rounds = 0;
-    for (int r = 0; r < std::min(budget, lg + 8); ++r, ++done_rounds) FDX_TRY(round());
+    for (int r = 0; r < std::min(budget, lg + 4); ++r, ++done_rounds) FDX_TRY(round());   // (sorted input: lg + 1 selection passes and a split pass)
     std::vector<KdHuge> h((size_t)count);
     for (;;) {
         FDX_HIP(hipMemcpyAsync(h.data(), hs, (size_t)count * sizeof(KdHuge), hipMemcpyDeviceToHost, s));
@@ -787,7 +787,7 @@ int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const
         for (const KdHuge& x : h) all = all && x.phase == 4;
         if (all) break;
         if (done_rounds >= budget) { *gave_up = true; return 0; }
-        for (int r = 0; r < 4 && done_rounds < budget; ++r, ++done_rounds) FDX_TRY(round());
+        for (int r = 0; r < 3 && done_rounds < budget; ++r, ++done_rounds) FDX_TRY(round());
     }
     return 0;
 }
