@@ -22,12 +22,14 @@
 //
 // STATE (round 6): exact - scipy's index array on lattices, clouds, heavy duplicates, sorted input, 1-3 coordinates, up to a
 // million points (tests/test_gpu_stages.py) - and the default for 1-3 coordinates (fdx_kdtree_tune(2, 0) selects the host's thread
-// pool): a million lattice points in 5.9-6.2 ms against the pool's 9-11.  Nodes above 100000 points are not one workgroup's work
+// pool): a million lattice points in 5.3 ms against the pool's 9-11.  Nodes above 100000 points are not one workgroup's work
 // (a million points through one compute unit: 2.5 ms for the root, 4.5 for its two children): each of their passes is three
 // launches over 64 workgroups per node - classify / count / swap, the node's last workgroup through the swap doing what follows
-// the pass (kd_huge_*) - ~85 launches and two read-backs per level, bound by the HOST's launch rate: 0.6-0.75 ms per level, 2.7 ms
-// for levels 0-3; levels 4-7 (1024 threads per node) 1.2 ms, levels 8-9 (256 per node) 0.3 ms, levels 10-16 (a wave per node)
-// 1.4 ms.  Next: the launches of a level as one hipGraph (cached per shape), the wave-per-node levels out of LDS.
+// the pass (kd_huge_*) - ~70 launches and two read-backs per level, bound by the HOST's launch rate: 0.6-0.75 ms per level, 2.7 ms
+// for levels 0-3; levels 4-7 (1024 threads per node) 1.2 ms, levels 8-9 (256 per node) 0.2 ms, levels 10-16 (a wave per node, the
+// node staged in LDS) 0.7 ms - of which 0.4 are still the ONE queue counter 16384 nodes of the last-but-one level add to (the
+// children's ids come without a counter, both children are pushed with one addition: 5.9 -> 5.3 ms).
+// Next: the launches of a level as one hipGraph (cached per shape); per-wave aggregation of the queue pushes.
 #include <algorithm>
 #include <cmath>
 #include <chrono>
@@ -51,6 +53,32 @@ constexpr int KD_SMALL = 1024, KD_MID = 4096, KD_HUGE = 100000;
 __host__ __device__ inline int kd_size_class(long long size) { return size <= KD_SMALL ? 0 : size <= KD_MID ? 1 : size <= KD_HUGE ? 2 : 3; }
 constexpr int KD_NCLS = 4;
 struct KdQueues { KdWork* q[KD_NCLS]; };
+// both children of a node into the next level's queues: one atomic when they are of one class (the counters of a tree's last levels
+// are what tens of thousands of nodes add to at once)
+__device__ __forceinline__ void kd_push_children(const KdQueues& next, int* __restrict__ n_next, int4* __restrict__ meta, int c0, const int (&cs)[2],
+                                                 const int (&ce)[2], int leafsize) {
+    const bool leaf0 = ce[0] - cs[0] <= leafsize, leaf1 = ce[1] - cs[1] <= leafsize;
+    if (leaf0) meta[c0] = make_int4(-1, cs[0], ce[0], 0);
+    if (leaf1) meta[c0 + 1] = make_int4(-1, cs[1], ce[1], 0);
+    const int cls0 = leaf0 ? -1 : kd_size_class(ce[0] - cs[0]), cls1 = leaf1 ? -2 : kd_size_class(ce[1] - cs[1]);
+    if (cls0 == cls1) {
+        const int slot = atomicAdd(n_next + cls0, 2);
+        next.q[cls0][slot] = KdWork{c0, cs[0], ce[0]};
+        next.q[cls0][slot + 1] = KdWork{c0 + 1, cs[1], ce[1]};
+        return;
+    }
+    if (!leaf0) next.q[cls0][atomicAdd(n_next + cls0, 1)] = KdWork{c0, cs[0], ce[0]};
+    if (!leaf1) next.q[cls1][atomicAdd(n_next + cls1, 1)] = KdWork{c0 + 1, cs[1], ce[1]};
+}
+
+// The ids of a node's two children without a shared counter (32768 nodes of a tree's last level adding to ONE address cost more than
+// their selections): entry e of class c at a level owns the slots base + 2 (entries of the classes below c + e), base = 1 + twice
+// the entries of all earlier levels (kd_level_base_kernel).  A node that turns out a leaf leaves its two slots unused.
+__device__ __forceinline__ int kd_child_ids(const int* __restrict__ level_counts, int cls, int entry, const int* __restrict__ base) {
+    int off = 0;
+    for (int c = 0; c < cls; ++c) off += level_counts[c];
+    return *base + 2 * (off + entry);
+}
 // Above KD_HUGE points a node is not one workgroup's work (a million points through one compute unit: 2.5 ms for the root, 4.5 ms
 // for its children): every pass of such a node is cut into KD_CH chunks, a wave each, over 64 workgroups, and the phases of a pass
 // that need everybody's results of the one before are separate launches - classify / count / swap / advance (kd_huge_*).
@@ -224,7 +252,8 @@ template <int M, int T>
 __global__ __launch_bounds__(T) void kd_level_kernel(const double* __restrict__ coords, int* __restrict__ idx, int4* __restrict__ meta,
                                                      double* __restrict__ split_out, const KdWork* __restrict__ cur,
                                                      const int* __restrict__ n_cur, const KdQueues next, int* __restrict__ n_next,
-                                                     KdBuildState* __restrict__ st, int* __restrict__ lp, int* __restrict__ rp, int leafsize) {
+                                                     KdBuildState* __restrict__ st, int* __restrict__ lp, int* __restrict__ rp, int leafsize,
+                                                     int size_above, const int* __restrict__ level_counts, int cls, const int* __restrict__ base) {
 #pragma clang fp contract(off)
     __shared__ int s_nl[T / 64], s_nr[T / 64], s_cnt[T / 64], s_out[8];
     __shared__ double s_red[2 * 3 * (T / 64)];
@@ -234,6 +263,7 @@ __global__ __launch_bounds__(T) void kd_level_kernel(const double* __restrict__ 
     if ((int)blockIdx.x >= *n_cur) return;
     const KdWork w = cur[blockIdx.x];
     const int size = w.end - w.start;
+    if (size <= size_above) return;                                     // (the wave class: such a node is kd_small_kernel's, out of LDS)
     // ---- bounds of the node's own points
     {
         double mx[M], mn[M];
@@ -346,19 +376,181 @@ __global__ __launch_bounds__(T) void kd_level_kernel(const double* __restrict__ 
     }
     // ---- the children
     if (tid == 0) {
-        const int c0 = atomicAdd(&st->n_nodes, 2);
+        const int c0 = kd_child_ids(level_counts, cls, (int)blockIdx.x, base);
         meta[w.node] = make_int4(d, c0, c0 + 1, 0);
         split_out[w.node] = split;
         const int cs[2] = {w.start, p}, ce[2] = {p, w.end};
-        for (int c = 0; c < 2; ++c) {
-            if (ce[c] - cs[c] <= leafsize) {
-                meta[c0 + c] = make_int4(-1, cs[c], ce[c], 0);
-            } else {                                                       // the next level's queue of its team size
-                const int cls = kd_size_class(ce[c] - cs[c]);
-                const int slot = atomicAdd(n_next + cls, 1);
-                next.q[cls][slot] = KdWork{c0 + c, cs[c], ce[c]};
-            }
+        kd_push_children(next, n_next, meta, c0, cs, ce, leafsize);
+    }
+}
+
+// ---- the wave class out of LDS: a node of at most `cap` points (cap x 16 bytes of LDS: the keys along the split dimension, the
+// indices, the two position lists) is staged once, every pass of its selection and its split runs on the staged copy - the same
+// passes as kd_pass, one chunk -, and the indices are written back.  The last six levels of a tree: 1.4 ms per million points
+// through L2, where every one of a node's ~20 passes is a chain of global round trips.
+template <int M>
+__global__ __launch_bounds__(64) void kd_small_kernel(const double* __restrict__ coords, int* __restrict__ idx, int4* __restrict__ meta,
+                                                      double* __restrict__ split_out, const KdWork* __restrict__ cur, const int* __restrict__ n_cur,
+                                                      const KdQueues next, int* __restrict__ n_next, KdBuildState* __restrict__ st, int leafsize,
+                                                      int cap, const int* __restrict__ level_counts, const int* __restrict__ base) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char kd_lds[];
+    double* s_key = reinterpret_cast<double*>(kd_lds);
+    int* s_idx = reinterpret_cast<int*>(s_key + cap);
+    unsigned short* s_lp = reinterpret_cast<unsigned short*>(s_idx + cap);
+    unsigned short* s_rp = s_lp + cap;
+    if ((int)blockIdx.x >= *n_cur) return;
+    const KdWork w = cur[blockIdx.x];
+    const int n = w.end - w.start;
+    if (n > cap) return;                                                  // (kd_level_kernel<M, 64>'s, through global memory)
+    const int lane = threadIdx.x;
+    const unsigned long long lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+    double mx[M], mn[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) { mx[a] = -HUGE_VAL; mn[a] = HUGE_VAL; }
+    for (int i = lane; i < n; i += 64) {
+        const int pt = idx[w.start + i];
+        s_idx[i] = pt;
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            const double v = coords[(size_t)pt * M + a];
+            mx[a] = mx[a] > v ? mx[a] : v;
+            mn[a] = mn[a] < v ? mn[a] : v;
         }
+    }
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ox = __shfl_xor(mx[a], off), on = __shfl_xor(mn[a], off);
+            mx[a] = mx[a] > ox ? mx[a] : ox;
+            mn[a] = mn[a] < on ? mn[a] : on;
+        }
+    int d = 0;
+    double sz = 0.0;
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+        if (mx[a] - mn[a] > sz) { d = a; sz = mx[a] - mn[a]; }
+    if (w.node == 0 && lane == 0) {
+#pragma unroll
+        for (int a = 0; a < M; ++a) { st->maxes[a] = mx[a]; st->mins[a] = mn[a]; }
+    }
+    if (!(sz > 0.0)) {                                                    // maxes[d] == mins[d]: all points identical, a leaf
+        if (lane == 0) meta[w.node] = make_int4(-1, w.start, w.end, 0);
+        return;
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) s_key[i] = coords[(size_t)s_idx[i] * M + d];
+    __syncthreads();
+    auto swap_at = [&](int a, int b) {
+        const int ti = s_idx[a]; s_idx[a] = s_idx[b]; s_idx[b] = ti;
+        const double tk = s_key[a]; s_key[a] = s_key[b]; s_key[b] = tk;
+    };
+    // one pass in list form over positions [lo, hi): K swaps; nR; L(K) and R(K - 1) (hi when there is none)
+    auto pass = [&](int lo, int hi, auto stop_left, auto stop_right, int& nR_out, int& LK, int& RK1) {
+        int nl = 0, nr = 0;
+        for (int base = lo; base < hi; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < hi;
+            const double v = valid ? s_key[i] : 0.0;
+            const bool sl = valid && stop_left(v), sr_ = valid && stop_right(v);
+            const unsigned long long ml = __ballot(sl), mr = __ballot(sr_);
+            if (sl) s_lp[nl + __popcll(ml & lt)] = (unsigned short)i;
+            if (sr_) s_rp[nr + __popcll(mr & lt)] = (unsigned short)i;
+            nl += __popcll(ml);
+            nr += __popcll(mr);
+        }
+        __syncthreads();
+        int K = 0;
+        for (int j0 = 0; j0 < nl; j0 += 64) {
+            const int j = j0 + lane;
+            bool ok = false;
+            if (j < nl) {
+                const int x = s_lp[j];
+                int a = 0, e = nr;                                        // first right stop with position > x
+                while (a < e) {
+                    const int mid = (a + e) >> 1;
+                    if ((int)s_rp[mid] <= x) a = mid + 1; else e = mid;
+                }
+                ok = nr - a > j;
+            }
+            const int got = __popcll(__ballot(ok));
+            K += got;
+            if (got < 64) break;
+        }
+        for (int j = lane; j < K; j += 64) swap_at(s_lp[j], s_rp[nr - 1 - j]);
+        LK = K < nl ? (int)s_lp[K] : hi;
+        RK1 = K > 0 ? (int)s_rp[nr - K] : hi;
+        nR_out = nr;
+        __syncthreads();
+    };
+    // ---- std::nth_element(0, n / 2, n) by the staged keys
+    const int nth = n / 2;
+    {
+        int first = 0, last = n;
+        int depth = 2 * (31 - __clz(n));
+        while (last - first > 3) {
+            if (depth == 0) {                                             // heap select: rare - through the global copy
+                __syncthreads();
+                for (int i = lane; i < n; i += 64) idx[w.start + i] = s_idx[i];
+                __syncthreads();
+                if (lane == 0) {
+                    __threadfence_block();
+                    kd_heap_select_and_swap<M>(coords, idx, w.start + first, w.start + nth, w.start + last, d);
+                    __threadfence_block();
+                }
+                __syncthreads();
+                for (int i = lane; i < n; i += 64) { const int pt = idx[w.start + i]; s_idx[i] = pt; s_key[i] = coords[(size_t)pt * M + d]; }
+                __syncthreads();
+                first = last;
+                break;
+            }
+            --depth;
+            if (lane == 0) {                                              // __move_median_to_first(first, first + 1, mid, last - 1)
+                const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+                const double ka = s_key[ia], kb = s_key[ib], kc = s_key[ic];
+                int pick;
+                if (ka < kb) pick = kb < kc ? ib : (ka < kc ? ic : ia);
+                else pick = ka < kc ? ia : (kb < kc ? ic : ib);
+                swap_at(first, pick);
+            }
+            __syncthreads();
+            const double pv = s_key[first];
+            int nR, LK, RK1;
+            pass(first + 1, last, [pv](double v) { return !(v < pv); }, [pv](double v) { return !(pv < v); }, nR, LK, RK1);
+            const int cut = LK < RK1 ? LK : RK1;
+            if (cut <= nth) first = cut; else last = cut;
+        }
+        if (lane == 0)
+            for (int i = first + 1; i < last; ++i) {                      // __insertion_sort of the last (at most three) elements
+                const int vi = s_idx[i];
+                const double kv = s_key[i];
+                int j = i;
+                while (j > first && kv < s_key[j - 1]) { s_idx[j] = s_idx[j - 1]; s_key[j] = s_key[j - 1]; --j; }
+                s_idx[j] = vi;
+                s_key[j] = kv;
+            }
+        __syncthreads();
+    }
+    // ---- scipy's "< split | >= split" pass; the split just above the minimum when nothing is below it
+    double split = s_key[nth];
+    int p;
+    {
+        int nR, LK, RK1;
+        pass(0, nth, [split](double v) { return !(v < split); }, [split](double v) { return v < split; }, nR, LK, RK1);
+        p = nR;
+        if (p == 0) {
+            split = nextafter(split, HUGE_VAL);
+            pass(0, n, [split](double v) { return !(v < split); }, [split](double v) { return v < split; }, nR, LK, RK1);
+            p = nR;
+        }
+    }
+    for (int i = lane; i < n; i += 64) idx[w.start + i] = s_idx[i];
+    if (lane == 0) {
+        const int c0 = kd_child_ids(level_counts, 0, (int)blockIdx.x, base);
+        meta[w.node] = make_int4(d, c0, c0 + 1, 0);
+        split_out[w.node] = split;
+        const int cs[2] = {w.start, w.start + p}, ce[2] = {w.start + p, w.end};
+        kd_push_children(next, n_next, meta, c0, cs, ce, leafsize);
     }
 }
 
@@ -570,7 +762,7 @@ __global__ __launch_bounds__(256) void kd_huge_count_kernel(KdHuge* __restrict__
 template <int M>
 __device__ void kd_huge_advance(const double* __restrict__ coords, int* idx, KdHuge* hs, int slot, int4* __restrict__ meta,
                                 double* __restrict__ split_out, const KdQueues& next, int* __restrict__ n_next, KdBuildState* st,
-                                int leafsize) {
+                                int leafsize, const int* __restrict__ level_counts, const int* __restrict__ base) {
 #pragma clang fp contract(off)
     KdHuge h = hs[slot];
     // (written by other workgroups of the launch that calls this: real loads, not what this thread may hold in registers)
@@ -612,19 +804,11 @@ __device__ void kd_huge_advance(const double* __restrict__ coords, int* idx, KdH
         p = h.start + h.nR;
     }
     if (p >= 0) {
-        const int c0 = atomicAdd(&st->n_nodes, 2);
+        const int c0 = kd_child_ids(level_counts, 3, slot, base);
         meta[h.node] = make_int4(h.d, c0, c0 + 1, 0);
         split_out[h.node] = h.pv;
         const int cs[2] = {h.start, p}, ce[2] = {p, h.end};
-        for (int c = 0; c < 2; ++c) {
-            if (ce[c] - cs[c] <= leafsize) {
-                meta[c0 + c] = make_int4(-1, cs[c], ce[c], 0);
-            } else {
-                const int cls = kd_size_class(ce[c] - cs[c]);
-                const int q = atomicAdd(n_next + cls, 1);
-                next.q[cls][q] = KdWork{c0 + c, cs[c], ce[c]};
-            }
-        }
+        kd_push_children(next, n_next, meta, c0, cs, ce, leafsize);
         h.phase = 4;
     }
     hs[slot] = h;
@@ -634,7 +818,8 @@ template <int M>
 __global__ __launch_bounds__(256) void kd_huge_swap_kernel(const double* __restrict__ coords, int* idx, KdHuge* hs, const int* __restrict__ n_cur,
                                                            const int* __restrict__ lp, const int* __restrict__ rp, const int* __restrict__ hc,
                                                            int* __restrict__ tickets, int4* __restrict__ meta, double* __restrict__ split_out,
-                                                           const KdQueues next, int* __restrict__ n_next, KdBuildState* st, int leafsize) {
+                                                           const KdQueues next, int* __restrict__ n_next, KdBuildState* st, int leafsize,
+                                                           const int* __restrict__ level_counts, const int* __restrict__ base) {
     __shared__ int s_sr[KD_CH], s_nr[KD_CH], s_red[4];
     const int slot = blockIdx.y;
     if (slot >= *n_cur) return;
@@ -685,17 +870,25 @@ __global__ __launch_bounds__(256) void kd_huge_swap_kernel(const double* __restr
         if (ticket == (int)gridDim.x - 1) {
             tickets[slot] = 0;
             __threadfence();
-            kd_huge_advance<M>(coords, idx, hs, slot, meta, split_out, next, n_next, st, leafsize);
+            kd_huge_advance<M>(coords, idx, hs, slot, meta, split_out, next, n_next, st, leafsize, level_counts, base);
         }
     }
 }
 
-__global__ void kd_init_kernel(int* __restrict__ idx, long long n, const KdQueues q, int* __restrict__ counts, KdBuildState* st,
-                               int4* __restrict__ meta, int leafsize) {
+__global__ void kd_level_base_kernel(const int* __restrict__ level_counts, int* __restrict__ base, KdBuildState* st) {
+    int e = 0;
+    for (int c = 0; c < KD_NCLS; ++c) e += level_counts[c];
+    base[1] = base[0] + 2 * e;                                            // the first child slot of the next level's entries
+    st->n_nodes = base[1];                                                // (slots handed out so far: the high-water mark)
+}
+
+__global__ void kd_init_kernel(int* __restrict__ idx, long long n, const KdQueues q, int* __restrict__ counts, int* __restrict__ bases,
+                               KdBuildState* st, int4* __restrict__ meta, int leafsize) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) idx[i] = (int)i;
     if (i == 0) {
         st->n_nodes = 1;
+        bases[0] = 1;                                                     // node 0 is the root
         st->overflow = 0;
         for (int a = 0; a < 3; ++a) { st->mins[a] = 0.0; st->maxes[a] = 0.0; }
         if (n <= leafsize) {
@@ -741,23 +934,30 @@ __global__ void kd_root_bounds_kernel(const double* __restrict__ coords, long lo
 
 template <int M>
 int kd_launch_level(const double* coords, int* idx, int4* meta, double* split, KdWork* const (&cur)[KD_NCLS], const int* n_cur, const KdQueues& next,
-                    int* n_next, KdBuildState* st, int* lp, int* rp, const long long (&grid)[3], int leafsize, hipStream_t s) {
+                    int* n_next, KdBuildState* st, int* lp, int* rp, const long long (&grid)[3], int small_cap, int leafsize, const int* base,
+                    hipStream_t s) {
     if (grid[2] > 0)
         hipLaunchKernelGGL((kd_level_kernel<M, 1024>), dim3((unsigned)grid[2]), dim3(1024), 0, s, coords, idx, meta, split, cur[2], n_cur + 2, next,
-                           n_next, st, lp, rp, leafsize);
+                           n_next, st, lp, rp, leafsize, 0, n_cur, 2, base);
     if (grid[1] > 0)
         hipLaunchKernelGGL((kd_level_kernel<M, 256>), dim3((unsigned)grid[1]), dim3(256), 0, s, coords, idx, meta, split, cur[1], n_cur + 1, next,
-                           n_next, st, lp, rp, leafsize);
-    if (grid[0] > 0)
-        hipLaunchKernelGGL((kd_level_kernel<M, 64>), dim3((unsigned)grid[0]), dim3(64), 0, s, coords, idx, meta, split, cur[0], n_cur, next, n_next, st,
-                           lp, rp, leafsize);
+                           n_next, st, lp, rp, leafsize, 0, n_cur, 1, base);
+    if (grid[0] > 0) {
+        // the wave class: nodes of at most `small_cap` points (what a balanced tree holds at this level, with a factor two to spare)
+        // out of LDS, the others through global memory
+        hipLaunchKernelGGL((kd_small_kernel<M>), dim3((unsigned)grid[0]), dim3(64), (size_t)small_cap * 16, s, coords, idx, meta, split, cur[0], n_cur,
+                           next, n_next, st, leafsize, small_cap, n_cur, base);
+        if (small_cap < KD_SMALL)
+            hipLaunchKernelGGL((kd_level_kernel<M, 64>), dim3((unsigned)grid[0]), dim3(64), 0, s, coords, idx, meta, split, cur[0], n_cur, next, n_next,
+                               st, lp, rp, leafsize, small_cap, n_cur, 0, base);
+    }
     FDX_CHECK_LAUNCH();
     return 0;
 }
 
 // the huge nodes of one level (count known: it was read back): bounds, then passes of four launches until every node has its children
 template <int M>
-int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const KdWork* cur3, const int* n_cur3, int count, long long max_size,
+int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const KdWork* cur3, const int* n_cur3, const int* base, int count, long long max_size,
                 const KdQueues& next, int* n_next, KdBuildState* st, int* lp, int* rp, KdHuge* hs, int* hc, double* hb, int* tickets,
                 int leafsize, bool* gave_up, hipStream_t s) {
     const dim3 wide(KD_CH / 4, (unsigned)count), one((unsigned)count);
@@ -768,7 +968,7 @@ int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const
         hipLaunchKernelGGL((kd_huge_classify_kernel<M>), wide, dim3(256), 0, s, coords, idx, hs, n_cur3, lp, rp, hc);
         hipLaunchKernelGGL(kd_huge_count_kernel, wide, dim3(256), 0, s, hs, n_cur3, lp, rp, hc);
         hipLaunchKernelGGL((kd_huge_swap_kernel<M>), wide, dim3(256), 0, s, coords, idx, hs, n_cur3, lp, rp, hc, tickets, meta, split, next, n_next,
-                           st, leafsize);
+                           st, leafsize, n_cur3 - 3, base);
         FDX_CHECK_LAUNCH();
         return 0;
     };
@@ -804,11 +1004,12 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
     FDX_TRY(out->idx.alloc((size_t)n * sizeof(int)));
     // queues of the nodes still to split, by level parity and team size: a level holds at most n / (size class's lower bound) of a class
     const long long qcap[KD_NCLS] = {n / (leafsize + 1) + 2, n / (KD_SMALL + 1) + 2, n / (KD_MID + 1) + 2, n / (KD_HUGE + 1) + 2};
-    DevBuf q[2][KD_NCLS], counts, state, lp, rp, hs, hc, hb, tickets;
+    DevBuf q[2][KD_NCLS], counts, bases, state, lp, rp, hs, hc, hb, tickets;
     for (int par = 0; par < 2; ++par)
         for (int c = 0; c < KD_NCLS; ++c) FDX_TRY(q[par][c].alloc((size_t)qcap[c] * sizeof(KdWork)));
     const int max_levels = 128;
     FDX_TRY(counts.alloc((size_t)(max_levels + 2) * KD_NCLS * sizeof(int)));
+    FDX_TRY(bases.alloc((size_t)(max_levels + 3) * sizeof(int)));
     FDX_TRY(state.alloc(sizeof(KdBuildState)));
     FDX_TRY(lp.alloc((size_t)n * sizeof(int)));
     FDX_TRY(rp.alloc((size_t)n * sizeof(int)));
@@ -820,7 +1021,7 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
     FDX_HIP(hipMemsetAsync(counts.p, 0, (size_t)(max_levels + 2) * KD_NCLS * sizeof(int), st));
     KdQueues q0{{q[0][0].as<KdWork>(), q[0][1].as<KdWork>(), q[0][2].as<KdWork>(), q[0][3].as<KdWork>()}};
     hipLaunchKernelGGL(kd_init_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out->idx.as<int>(), n, q0, counts.as<int>(),
-                       state.as<KdBuildState>(), out->meta.as<int4>(), leafsize);
+                       bases.as<int>(), state.as<KdBuildState>(), out->meta.as<int4>(), leafsize);
     FDX_CHECK_LAUNCH();
     if (n <= leafsize) {
         hipLaunchKernelGGL(kd_root_bounds_kernel, dim3(1), dim3(256), 0, st, coords_dev, n, dim, state.as<KdBuildState>());
@@ -840,6 +1041,8 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
         for (int c = 0; c < KD_NCLS; ++c) { cur[c] = q[level & 1][c].as<KdWork>(); nxt.q[c] = q[(level + 1) & 1][c].as<KdWork>(); }
         const int* n_cur = counts.as<int>() + KD_NCLS * level;
         int* n_next = counts.as<int>() + KD_NCLS * (level + 1);
+        int* base_l = bases.as<int>() + level;                            // bases[level]: first child slot of this level's entries
+        hipLaunchKernelGGL(kd_level_base_kernel, dim3(1), dim3(1), 0, st, n_cur, base_l, state.as<KdBuildState>());
         int n_huge = 0;
         if (huge_alive) {
             FDX_HIP(hipMemcpyAsync(&n_huge, n_cur + 3, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -851,14 +1054,17 @@ int kd_build_device(const double* coords_dev, long long n, int dim, KdDeviceTree
         // a node of `level` forks below the root has shed at least `level` points (each split gives both sides one or more)
         if (n - level <= KD_MID) grid[2] = 0;
         if (n - level <= KD_SMALL) grid[1] = 0;
+        long long bal = level < 40 ? (n >> level) + 1 : 1;                // a balanced tree's node at this level
+        int small_cap = 64;
+        while (small_cap < KD_SMALL && small_cap < 2 * bal) small_cap *= 2;
 #define FDX_KDL(MM)                                                                                                              \
         do {                                                                                                                     \
             if (n_huge > 0)                                                                                                      \
-                FDX_TRY(kd_run_huge<MM>(coords_dev, out->idx.as<int>(), out->meta.as<int4>(), out->split.as<double>(), cur[3], n_cur + 3, n_huge, \
+                FDX_TRY(kd_run_huge<MM>(coords_dev, out->idx.as<int>(), out->meta.as<int4>(), out->split.as<double>(), cur[3], n_cur + 3, base_l, n_huge, \
                                         std::max<long long>(4, n - level), nxt, n_next, state.as<KdBuildState>(), lp.as<int>(), rp.as<int>(),     \
                                         hs.as<KdHuge>(), hc.as<int>(), hb.as<double>(), tickets.as<int>(), leafsize, &gave_up, st));                                  \
             return kd_launch_level<MM>(coords_dev, out->idx.as<int>(), out->meta.as<int4>(), out->split.as<double>(), cur, n_cur, nxt, n_next,     \
-                                       state.as<KdBuildState>(), lp.as<int>(), rp.as<int>(), grid, leafsize, st);                                 \
+                                       state.as<KdBuildState>(), lp.as<int>(), rp.as<int>(), grid, small_cap, leafsize, base_l, st);              \
         } while (0)
         if (dim == 1) FDX_KDL(1);
         if (dim == 2) FDX_KDL(2);
