@@ -581,14 +581,10 @@ __device__ void kd_huge_begin_select(const double* __restrict__ coords, int* __r
 }
 
 template <int M>
-__global__ __launch_bounds__(256) void kd_huge_bounds_kernel(const double* __restrict__ coords, const int* __restrict__ idx,
-                                                             const KdWork* __restrict__ cur, const int* __restrict__ n_cur,
-                                                             double* __restrict__ hb) {
-    const int slot = blockIdx.y;
-    if (slot >= *n_cur) return;
+__device__ void kd_huge_bounds(const double* __restrict__ coords, const int* idx, const KdWork* __restrict__ cur, double* hb, int slot, int wg) {
     const KdWork w = cur[slot];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + wave;
+    const int c = wg * 4 + wave;
     const long long len = (long long)w.end - w.start;
     const int cb = w.start + (int)(len * c / KD_CH), ce = w.start + (int)(len * (c + 1) / KD_CH);
     double mx[M], mn[M];
@@ -615,14 +611,10 @@ __global__ __launch_bounds__(256) void kd_huge_bounds_kernel(const double* __res
 }
 
 template <int M>
-__global__ __launch_bounds__(256) void kd_huge_setup_kernel(const double* __restrict__ coords, int* __restrict__ idx,
-                                                            const KdWork* __restrict__ cur, const int* __restrict__ n_cur,
-                                                            const double* __restrict__ hb, KdHuge* __restrict__ hs, int4* __restrict__ meta,
-                                                            KdBuildState* __restrict__ st) {
+__device__ void kd_huge_setup(const double* __restrict__ coords, int* idx, const KdWork* __restrict__ cur, const double* hb, KdHuge* hs,
+                              int4* __restrict__ meta, KdBuildState* st, int slot) {
 #pragma clang fp contract(off)
     __shared__ double s_red[4 * 6];
-    const int slot = blockIdx.x;
-    if (slot >= *n_cur) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double mx[M], mn[M];
 #pragma unroll
@@ -675,17 +667,13 @@ __global__ __launch_bounds__(256) void kd_huge_setup_kernel(const double* __rest
 }
 
 template <int M>
-__global__ __launch_bounds__(256) void kd_huge_classify_kernel(const double* __restrict__ coords, const int* __restrict__ idx,
-                                                               const KdHuge* __restrict__ hs, const int* __restrict__ n_cur,
-                                                               int* __restrict__ lp, int* __restrict__ rp, int* __restrict__ hc) {
-    const int slot = blockIdx.y;
-    if (slot >= *n_cur) return;
+__device__ void kd_huge_classify(const double* __restrict__ coords, const int* idx, const KdHuge* hs, int* lp, int* rp, int* hc, int slot, int wg) {
     const int phase = hs[slot].phase;
     if (phase == 4) return;
     const int lo = hs[slot].lo, hi = hs[slot].hi, d = hs[slot].d;
     const double pv = hs[slot].pv;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + wave;
+    const int c = wg * 4 + wave;
     const long long len = (long long)hi - lo;
     const int cb = lo + (int)(len * c / KD_CH), ce = lo + (int)(len * (c + 1) / KD_CH);
     const unsigned long long lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
@@ -705,14 +693,11 @@ __global__ __launch_bounds__(256) void kd_huge_classify_kernel(const double* __r
     if (lane == 0) { hc[(slot * 5 + 0) * KD_CH + c] = nl; hc[(slot * 5 + 1) * KD_CH + c] = nr; }
 }
 
-__global__ __launch_bounds__(256) void kd_huge_count_kernel(KdHuge* __restrict__ hs, const int* __restrict__ n_cur, const int* __restrict__ lp,
-                                                            const int* __restrict__ rp, int* __restrict__ hc) {
-    const int slot = blockIdx.y;
-    if (slot >= *n_cur) return;
+__device__ void kd_huge_count(KdHuge* hs, const int* lp, const int* rp, int* hc, int slot, int wg) {
     if (hs[slot].phase == 4) return;
     const int lo = hs[slot].lo, hi = hs[slot].hi;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + wave;
+    const int c = wg * 4 + wave;
     const long long len = (long long)hi - lo;
     const int cb = lo + (int)(len * c / KD_CH);
     const int* cl = hc + (slot * 5 + 0) * KD_CH;
@@ -814,16 +799,10 @@ __device__ void kd_huge_advance(const double* __restrict__ coords, int* idx, KdH
     hs[slot] = h;
 }
 
-template <int M>
-__global__ __launch_bounds__(256) void kd_huge_swap_kernel(const double* __restrict__ coords, int* idx, KdHuge* hs, const int* __restrict__ n_cur,
-                                                           const int* __restrict__ lp, const int* __restrict__ rp, const int* __restrict__ hc,
-                                                           int* __restrict__ tickets, int4* __restrict__ meta, double* __restrict__ split_out,
-                                                           const KdQueues next, int* __restrict__ n_next, KdBuildState* st, int leafsize,
-                                                           const int* __restrict__ level_counts, const int* __restrict__ base) {
+// (returns false when the node is finished: nothing was done)
+__device__ bool kd_huge_swap(int* idx, KdHuge* hs, const int* lp, const int* rp, const int* hc, int slot, int wg) {
     __shared__ int s_sr[KD_CH], s_nr[KD_CH], s_red[4];
-    const int slot = blockIdx.y;
-    if (slot >= *n_cur) return;
-    if (hs[slot].phase == 4) return;
+    if (hs[slot].phase == 4) return false;
     const int lo = hs[slot].lo, hi = hs[slot].hi, nL = hs[slot].nL;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     s_sr[tid] = hc[(slot * 5 + 3) * KD_CH + tid];                         // (KD_CH == 256 == the workgroup)
@@ -843,7 +822,7 @@ __global__ __launch_bounds__(256) void kd_huge_swap_kernel(const double* __restr
         const int ub = lo + (int)(len * a / KD_CH);
         return rp[ub + (s_nr[a] - 1 - (k - s_sr[a]))];
     };
-    const int c = blockIdx.x * 4 + wave;
+    const int c = wg * 4 + wave;
     const int cb = lo + (int)(len * c / KD_CH);
     const int pl = hc[(slot * 5 + 2) * KD_CH + c], nl = hc[(slot * 5 + 0) * KD_CH + c];
     const int mine = min(nl, max(0, K - pl));
@@ -861,10 +840,58 @@ __global__ __launch_bounds__(256) void kd_huge_swap_kernel(const double* __restr
             if (K > 0) hs[slot].cutR = right_by_rank(K - 1);              // R(K - 1): where the last swap put a left-stopping key
         }
     }
+    return true;
+}
+
+// (A one-launch form - all of a level's passes inside one launch, the 64 workgroups of a node meeting at a barrier of their own
+// between the steps, every wait bounded - was built and measured: correct, and 12.1 ms per million points against 5.3.  The
+// node's workgroups sit on all eight XCDs, whose L2s are not coherent with one another: every barrier is an agent-scope release
+// and acquire, i.e. an L2 write-back and invalidate, ~30 us each - what a kernel boundary does once, for everybody.)
+// ---- the general form: a launch per step
+template <int M>
+__global__ __launch_bounds__(256) void kd_huge_bounds_kernel(const double* __restrict__ coords, const int* __restrict__ idx,
+                                                             const KdWork* __restrict__ cur, const int* __restrict__ n_cur,
+                                                             double* __restrict__ hb) {
+    if ((int)blockIdx.y >= *n_cur) return;
+    kd_huge_bounds<M>(coords, idx, cur, hb, blockIdx.y, blockIdx.x);
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void kd_huge_setup_kernel(const double* __restrict__ coords, int* __restrict__ idx,
+                                                            const KdWork* __restrict__ cur, const int* __restrict__ n_cur,
+                                                            const double* __restrict__ hb, KdHuge* __restrict__ hs, int4* __restrict__ meta,
+                                                            KdBuildState* __restrict__ st) {
+    if ((int)blockIdx.x >= *n_cur) return;
+    kd_huge_setup<M>(coords, idx, cur, hb, hs, meta, st, blockIdx.x);
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void kd_huge_classify_kernel(const double* __restrict__ coords, const int* __restrict__ idx,
+                                                               const KdHuge* __restrict__ hs, const int* __restrict__ n_cur,
+                                                               int* __restrict__ lp, int* __restrict__ rp, int* __restrict__ hc) {
+    if ((int)blockIdx.y >= *n_cur) return;
+    kd_huge_classify<M>(coords, idx, hs, lp, rp, hc, blockIdx.y, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void kd_huge_count_kernel(KdHuge* __restrict__ hs, const int* __restrict__ n_cur, const int* __restrict__ lp,
+                                                            const int* __restrict__ rp, int* __restrict__ hc) {
+    if ((int)blockIdx.y >= *n_cur) return;
+    kd_huge_count(hs, lp, rp, hc, blockIdx.y, blockIdx.x);
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void kd_huge_swap_kernel(const double* __restrict__ coords, int* idx, KdHuge* hs, const int* __restrict__ n_cur,
+                                                           const int* __restrict__ lp, const int* __restrict__ rp, const int* __restrict__ hc,
+                                                           int* __restrict__ tickets, int4* __restrict__ meta, double* __restrict__ split_out,
+                                                           const KdQueues next, int* __restrict__ n_next, KdBuildState* st, int leafsize,
+                                                           const int* __restrict__ level_counts, const int* __restrict__ base) {
+    const int slot = blockIdx.y;
+    if (slot >= *n_cur) return;
+    if (!kd_huge_swap(idx, hs, lp, rp, hc, slot, blockIdx.x)) return;
     // the node's last workgroup through here does what follows the pass (a launch of its own otherwise): its swaps and everybody
     // else's are visible to it - each workgroup fences its writes before it draws its ticket, the last one fences again behind it
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         __threadfence();
         const int ticket = atomicAdd(&tickets[slot], 1);
         if (ticket == (int)gridDim.x - 1) {
@@ -961,6 +988,9 @@ int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const
                 const KdQueues& next, int* n_next, KdBuildState* st, int* lp, int* rp, KdHuge* hs, int* hc, double* hb, int* tickets,
                 int leafsize, bool* gave_up, hipStream_t s) {
     const dim3 wide(KD_CH / 4, (unsigned)count), one((unsigned)count);
+    int lg = 0;
+    while ((1LL << (lg + 1)) <= max_size) ++lg;
+    const int budget = 2 * lg + 4;                                        // libstdc++'s depth budget + the last pass + the split passes
     hipLaunchKernelGGL((kd_huge_bounds_kernel<M>), wide, dim3(256), 0, s, coords, idx, cur3, n_cur3, hb);
     hipLaunchKernelGGL((kd_huge_setup_kernel<M>), one, dim3(256), 0, s, coords, idx, cur3, n_cur3, hb, hs, meta, st);
     FDX_CHECK_LAUNCH();
@@ -974,9 +1004,6 @@ int kd_run_huge(const double* coords, int* idx, int4* meta, double* split, const
     };
     // a selection over `size` elements takes about log2(size) + a few partition passes (the budget is twice that), then one or two
     // split passes: that many rounds blind, then the phases are looked at
-    int lg = 0;
-    while ((1LL << (lg + 1)) <= max_size) ++lg;
-    const int budget = 2 * lg + 4;                                        // libstdc++'s depth budget + the last pass + the split passes
     int done_rounds = 0;
     for (int r = 0; r < std::min(budget, lg + 4); ++r, ++done_rounds) FDX_TRY(round());   // (sorted input: lg + 1 selection passes and a split pass)
     std::vector<KdHuge> h((size_t)count);
