@@ -172,16 +172,24 @@ __device__ KdPassOut kd_pass(const double* __restrict__ coords, int* __restrict_
     const int cb = lo + (int)(len * wave / NW), ce = lo + (int)(len * (wave + 1) / NW);
     const unsigned long long lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
     int nl = 0, nr = 0;
-    for (int base = cb; base < ce; base += 64) {
-        const int i = base + lane;
-        const bool valid = i < ce;
-        const double v = valid ? kd_key<M>(coords, idx[i], d) : 0.0;
-        const bool sl = valid && stop_left(v), sr_ = valid && stop_right(v);
-        const unsigned long long ml = __ballot(sl), mr = __ballot(sr_);
-        if (sl) lp[cb + nl + __popcll(ml & lt)] = i;
-        if (sr_) rp[cb + nr + __popcll(mr & lt)] = i;
-        nl += __popcll(ml);
-        nr += __popcll(mr);
+    for (int base = cb; base < ce; base += 256) {                          // four 64-position blocks at a time: their loads in flight together
+        int pt[4];
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = base + 64 * u + lane; pt[u] = i < ce ? idx[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = pt[u] >= 0 ? kd_key<M>(coords, pt[u], d) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + 64 * u + lane;
+            const bool valid = pt[u] >= 0;
+            const bool sl = valid && stop_left(v[u]), sr_ = valid && stop_right(v[u]);
+            const unsigned long long ml = __ballot(sl), mr = __ballot(sr_);
+            if (sl) lp[cb + nl + __popcll(ml & lt)] = i;
+            if (sr_) rp[cb + nr + __popcll(mr & lt)] = i;
+            nl += __popcll(ml);
+            nr += __popcll(mr);
+        }
     }
     if (lane == 0) { s_nl[wave] = nl; s_nr[wave] = nr; }
     __syncthreads();                                                      // (also: the lists are written)
@@ -678,17 +686,25 @@ __device__ void kd_huge_classify(const double* __restrict__ coords, const int* i
     const int cb = lo + (int)(len * c / KD_CH), ce = lo + (int)(len * (c + 1) / KD_CH);
     const unsigned long long lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
     int nl = 0, nr = 0;
-    for (int base = cb; base < ce; base += 64) {
-        const int i = base + lane;
-        const bool valid = i < ce;
-        const double v = valid ? kd_key<M>(coords, idx[i], d) : 0.0;
-        const bool sl = valid && !(v < pv);
-        const bool sr_ = valid && (phase == 1 ? !(pv < v) : v < pv);
-        const unsigned long long ml = __ballot(sl), mr = __ballot(sr_);
-        if (sl) lp[cb + nl + __popcll(ml & lt)] = i;
-        if (sr_) rp[cb + nr + __popcll(mr & lt)] = i;
-        nl += __popcll(ml);
-        nr += __popcll(mr);
+    for (int base = cb; base < ce; base += 256) {                          // four 64-position blocks at a time: their loads in flight together
+        int pt[4];
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = base + 64 * u + lane; pt[u] = i < ce ? idx[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = pt[u] >= 0 ? kd_key<M>(coords, pt[u], d) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + 64 * u + lane;
+            const bool valid = pt[u] >= 0;
+            const bool sl = valid && !(v[u] < pv);
+            const bool sr_ = valid && (phase == 1 ? !(pv < v[u]) : v[u] < pv);
+            const unsigned long long ml = __ballot(sl), mr = __ballot(sr_);
+            if (sl) lp[cb + nl + __popcll(ml & lt)] = i;
+            if (sr_) rp[cb + nr + __popcll(mr & lt)] = i;
+            nl += __popcll(ml);
+            nr += __popcll(mr);
+        }
     }
     if (lane == 0) { hc[(slot * 5 + 0) * KD_CH + c] = nl; hc[(slot * 5 + 1) * KD_CH + c] = nr; }
 }
